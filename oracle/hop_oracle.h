@@ -1,0 +1,43 @@
+/* hop_oracle.h -- declarations of the CPU restatement (TEST INFRASTRUCTURE ONLY, see hop_oracle.c). */
+#ifndef HOP_ORACLE_H
+#define HOP_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+uint32_t hop_o_sad(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bitDepth, int subShift);
+uint32_t hop_o_sse(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bitDepth);
+uint32_t hop_o_hads(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bitDepth);
+uint32_t hop_o_calc_had(const int16_t* a, int sa, const int16_t* b, int sb, int w, int h, int bitDepth);
+uint32_t hop_o_component_bits(int v);
+uint32_t hop_o_bits_gt(const int v[8]);
+void hop_o_ssref_reset(int16_t* bufY, int16_t* bufCb, int16_t* bufCr, int picW, int picH);
+void hop_o_ssref_commit_cu(int16_t* y, int16_t* cb, int16_t* cr, int picW, int picH,
+                           int x0, int y0, int size, const int16_t* recY, const int16_t* recCb, const int16_t* recCr);
+void hop_o_set_search_range(int picW, int picH, int cuX, int cuY, int cuSize, int ctuAddr, int frameWidthInCtu,
+                            int predX, int predY, int srchRng, int offX, int offY, int firstRow, int firstCol, int out[6]);
+int hop_o_ss_search(const int16_t* org, int orgStride, const int16_t* refPU, int refStride, int w, int h,
+                    int left, int right, int top, int bottom, int offX, int offY,
+                    int predX, int predY, uint32_t lambdaCost, int fen, int bitDepth,
+                    int* bestX, int* bestY, uint32_t* sadOut);
+uint32_t hop_o_frac_search(const int16_t* org, int orgStride, const int16_t* refPU, int refStride, int w, int h,
+                           int mvX, int mvY, int predX, int predY, uint32_t lambdaCost, int useHad, int bitDepth,
+                           int half[2], int qter[2]);
+void hop_o_calc_param_projective(const int x[4], const int y[4], double h[9], int Width, int Height);
+void hop_o_calc_param_projective_c(const double x[4], const double y[4], double h[9], int Width, int Height);
+void hop_o_projective_transform(const int16_t* refCentre, int16_t* aux, const double h[9], int W, int H, int stride, int nssWindow);
+int hop_o_gt_search(const int16_t* org, int orgStride, const int16_t* refPU, int refStride, int w, int h,
+                    int mvInt[2], int half[2], int qter[2], const int ssBest[2], int nAmvp, const int* amvpXY,
+                    int predX, int predY, uint32_t lambdaCost, int useHad, int bitDepth,
+                    uint32_t* cost, int gt[8]);
+void hop_o_pred_inter(const int16_t* refY, int strideY, const int16_t* refCb, const int16_t* refCr, int strideC,
+                      int puX, int puY, int w, int h, int mvx, int mvy, int useGT, const int gt[8],
+                      int bitDepthY, int bitDepthC, int16_t* predY, int16_t* predCb, int16_t* predCr);
+int hop_o_me_pu(const int16_t* org, int orgStride, const int16_t* refY00, int refStride, int puX, int puY, int w, int h,
+                int rngL, int rngR, int rngT, int rngB, int offX, int offY,
+                int predX, int predY, int nAmvp, const int* amvpXY, uint32_t lambdaCost,
+                int fen, int useHad, int bitDepth, int stage, int64_t* out);
+#ifdef __cplusplus
+}
+#endif
+#endif

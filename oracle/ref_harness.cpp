@@ -1,0 +1,328 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin C entry points around the *real* reference functions of the hot path
+// (zinsayon/HEVC-HOP, an HM-15.0 fork).  It is compiled by oracle/Makefile.ref
+// against the reference sources where they lie under /root/reference and linked
+// with the objects built from them (oracle/_ref/libhmref.a); nothing of the
+// reference is copied here.  The shared object it yields
+// (oracle/_ref/libref_harness.so) is used for two things only:
+//   * pinning oracle/hop_oracle.c (our CPU restatement) against the reference,
+//   * generating the golden vectors in tests/golden/ (oracle/make_golden.py).
+//
+// Private/protected members of the reference classes are reached by the usual
+// test-harness trick of redefining the access keywords before including the
+// reference headers (standard headers are included first so they are unaffected).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cassert>
+#include <vector>
+#include <list>
+#include <map>
+#include <string>
+#include <sstream>
+#include <iostream>
+#include <fstream>
+#include <algorithm>
+#include <stdint.h>
+
+#define private public
+#define protected public
+#include "TLibCommon/TypeDef.h"
+#include "TLibCommon/CommonDef.h"
+#include "TLibCommon/TComRom.h"
+#include "TLibCommon/TComMv.h"
+#include "TLibCommon/TComPattern.h"
+#include "TLibCommon/TComRdCost.h"
+#include "TLibCommon/TComPicYuv.h"
+#include "TLibCommon/TComYuv.h"
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComPrediction.h"
+#include "TLibCommon/TComTrQuant.h"
+#include "TLibEncoder/TEncCfg.h"
+#include "TLibEncoder/TEncSearch.h"
+#undef private
+#undef protected
+
+// free functions with external linkage in TComTrQuant.cpp (TComTrQuant.cpp:786,829)
+void xTrMxN(Int bitDepth, Short *block, Short *coeff, Int iWidth, Int iHeight, UInt uiMode);
+void xITrMxN(Int bitDepth, Short *coeff, Short *block, Int iWidth, Int iHeight, UInt uiMode);
+
+namespace {
+struct Ctx {
+  TEncCfg     cfg;
+  TComTrQuant trq;
+  TComRdCost  rd;
+  TEncSearch  search;
+  TComPicYuv* pic;
+  TComDataCU  cu;
+  bool        inited;
+  Ctx() : pic(NULL), inited(false) {}
+};
+Ctx* g = NULL;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// initialisation: what TAppEncCfg::xSetGlobal (TAppEncCfg.cpp:1901-1922), TEncTop::create
+// (TEncTop.cpp:92), TEncCu::create (TEncCu.cpp:107-112) and TEncTop::init (TEncTop.cpp:299-310)
+// do for the members this harness touches; cfg = cfg/3DHencoder_intra_main.cfg
+// ---------------------------------------------------------------------------------------------
+int ref_init(int bitDepthY, int bitDepthC, int useHadME, int useFastEnc, int searchRange)
+{
+  if (g) return 0;
+  g = new Ctx;
+  g_uiMaxCUWidth = 64; g_uiMaxCUHeight = 64;
+  g_uiAddCUDepth = 1; g_uiMaxCUDepth = 4;
+  g_bitDepthY = bitDepthY; g_bitDepthC = bitDepthC;
+  initROM();
+  UInt* piTmp = &g_auiZscanToRaster[0];
+  initZscanToRaster(5, 1, 0, piTmp);          // m_uhTotalDepth = g_uiMaxCUDepth + 1
+  initRasterToZscan(64, 64, 5);
+  initRasterToPelXY(64, 64, 5);
+  g->cfg.m_uiQuadtreeTULog2MaxSize = 5;
+  g->cfg.m_uiQuadtreeTULog2MinSize = 2;
+  g->cfg.m_bUseHADME = useHadME != 0;
+  g->cfg.m_bUseFastEnc = useFastEnc != 0;
+  g->rd.init();
+  g->trq.init(1 << 5, true, true, true, true, false);
+  g->search.init(&g->cfg, &g->trq, searchRange, 4, 0, 0, NULL, &g->rd, NULL, NULL);
+  g->inited = true;
+  return 0;
+}
+
+void ref_set_bitdepth(int bitDepthY, int bitDepthC) { g_bitDepthY = bitDepthY; g_bitDepthC = bitDepthC; }
+void ref_set_lambda(double lambda) { g->rd.setLambda(lambda); }
+unsigned ref_lambda_motion_sad() { return g->rd.m_uiLambdaMotionSAD; }
+
+// ---------------------------------------------------------------------------------------------
+// distortion kernels (TComRdCost.cpp:513-1016 SAD, :1018 SSE, :1366-1708 HAD, :391 calcHAD)
+// ---------------------------------------------------------------------------------------------
+unsigned ref_sad(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bitDepth, int subShift)
+{
+  TComPattern pat; pat.initPattern((Pel*)org, NULL, NULL, w, h, so, 0, 0);
+  DistParam dp;
+  g->rd.setDistParam(&pat, (Pel*)cur, sc, dp);
+  dp.iSubShift = subShift; dp.bitDepth = bitDepth; dp.bApplyWeight = false;
+  return dp.DistFunc(&dp);
+}
+unsigned ref_hads(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bitDepth)
+{
+  TComPattern pat; pat.initPattern((Pel*)org, NULL, NULL, w, h, so, 0, 0);
+  DistParam dp;
+  g->rd.setDistParam(&pat, (Pel*)cur, sc, 1, dp, true);
+  dp.bitDepth = bitDepth; dp.bApplyWeight = false;
+  return dp.DistFunc(&dp);
+}
+unsigned ref_sse(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bitDepth)
+{
+  return g->rd.getDistPart(bitDepth, (Pel*)cur, sc, (Pel*)org, so, w, h, TEXT_LUMA, DF_SSE);
+}
+unsigned ref_calc_had(const int16_t* a, int sa, const int16_t* b, int sb, int w, int h, int bitDepth)
+{
+  return g->rd.calcHAD(bitDepth, (Pel*)a, sa, (Pel*)b, sb, w, h);
+}
+unsigned ref_component_bits(int v) { return g->rd.xGetComponentBits(v); }
+unsigned ref_bits_gt(const int* v) { return g->rd.getBitsGT(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]); }
+double ref_calc_rd_cost(unsigned bits, unsigned dist, int flag) { return g->rd.calcRdCost(bits, dist, flag != 0); }
+
+// ---------------------------------------------------------------------------------------------
+// GT / HOP arithmetic (TComPrediction.cpp:807 calcParamProjective, :834 ...C, :904 ProjectiveTransform)
+// ---------------------------------------------------------------------------------------------
+void ref_calc_param_projective(const int* x, const int* y, double* h, int W, int H)
+{
+  Int xx[4], yy[4]; for (int i = 0; i < 4; i++) { xx[i] = x[i]; yy[i] = y[i]; }
+  g->search.calcParamProjective(xx, yy, h, W, H);
+}
+void ref_calc_param_projective_c(const double* x, const double* y, double* h, int W, int H)
+{
+  Double xx[4], yy[4]; for (int i = 0; i < 4; i++) { xx[i] = x[i]; yy[i] = y[i]; }
+  g->search.calcParamProjectiveC(xx, yy, h, W, H);
+}
+void ref_projective_transform(const int16_t* refCentre, int16_t* aux, const double* h, int W, int H, int stride, int nssWindow)
+{
+  Double hh[9]; memcpy(hh, h, sizeof(hh));
+  g->search.ProjectiveTransform((Pel*)refCentre, (Pel*)aux, hh, W, H, stride, nssWindow);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SS reference picture (TComPicYuv) owned by the harness.  Layout = the reference's own:
+// margins 80 luma / 40 chroma (TComPicYuv.cpp:82-85), stride = picW + 160.
+// ---------------------------------------------------------------------------------------------
+int ref_pic_create(int w, int h)
+{
+  if (g->pic) { g->pic->destroy(); delete g->pic; }
+  g->pic = new TComPicYuv;
+  g->pic->create(w, h, 64, 64, 4);
+  return g->pic->getStride();
+}
+// sentinel fill: TComSlice::xGetRefPic path, TComSlice.cpp:252-253 -> setPicPel(NOT_VALID) TComPicYuv.cpp:199
+void ref_pic_reset() { g->pic->setPicPel(NOT_VALID); g->pic->setBorderExtension(false); }
+// raw access to the padded buffers (comp 0/1/2); returns pointer to sample (0,0), *stride out
+int16_t* ref_pic_plane(int comp, int* stride)
+{
+  *stride = comp ? g->pic->getCStride() : g->pic->getStride();
+  return comp == 0 ? g->pic->getLumaAddr() : comp == 1 ? g->pic->getCbAddr() : g->pic->getCrAddr();
+}
+// what TEncCu::xCopyYuv2SSRef (TEncCu.cpp:1677-1697) does for one finalised CU:
+// copy recon into the picture, then whole-picture extendPicBorder (TComPicYuv.cpp:236-275)
+void ref_pic_commit_cu(int x, int y, int size, const int16_t* recY, const int16_t* recCb, const int16_t* recCr)
+{
+  TComPicYuv* p = g->pic;
+  for (int r = 0; r < size; r++) memcpy(p->getLumaAddr() + (y + r) * p->getStride() + x, recY + r * size, size * sizeof(Pel));
+  int cs = size >> 1;
+  for (int r = 0; r < cs; r++) {
+    memcpy(p->getCbAddr() + ((y >> 1) + r) * p->getCStride() + (x >> 1), recCb + r * cs, cs * sizeof(Pel));
+    memcpy(p->getCrAddr() + ((y >> 1) + r) * p->getCStride() + (x >> 1), recCr + r * cs, cs * sizeof(Pel));
+  }
+  p->setBorderExtension(false);
+  p->extendPicBorder();
+}
+void ref_pic_extend_border() { g->pic->setBorderExtension(false); g->pic->extendPicBorder(); }
+
+// clipMv for a CU at (cuX,cuY) (TComDataCU.cpp:3492-3504) + both xSetSearchRange overloads
+// (TEncSearch.cpp:6204-6259).  The CU-dependent scalars they read are set on a default-constructed
+// TComDataCU; the SPS/pic accessors used by the second overload are restated inline below because a
+// TComPic/TComSlice graph is not constructible in isolation -- those two lines are marked RESTATED.
+static void clip_mv(int picW, int picH, int cuX, int cuY, int& hor, int& ver)
+{ // RESTATED from TComDataCU.cpp:3492-3504
+  int iMvShift = 2, iOffset = 8;
+  int iHorMax = (picW + iOffset - cuX - 1) << iMvShift;
+  int iHorMin = (-(int)g_uiMaxCUWidth - iOffset - cuX + 1) << iMvShift;
+  int iVerMax = (picH + iOffset - cuY - 1) << iMvShift;
+  int iVerMin = (-(int)g_uiMaxCUHeight - iOffset - cuY + 1) << iMvShift;
+  hor = std::min(iHorMax, std::max(iHorMin, hor));
+  ver = std::min(iVerMax, std::max(iVerMin, ver));
+}
+
+// ---------------------------------------------------------------------------------------------
+// One PU through the reference's ME chain, exactly the sequence of xMotionEstimation
+// (TEncSearch.cpp:4552-4656) from the already-derived search range onwards:
+//   getMotionCost(1,0); setPredictor; setCostScale(2); xPatternSearch; validity test :4603-4606;
+//   getMotionCost(1,0); setCostScale(1); xPatternSearchFracDIF; setCostScale(0); xPatternSearchGT.
+// The three searches are the reference's own member functions.
+//   in : PU position (puX,puY) in the harness picture, size, org block, range after xSetSearchRange,
+//        offX'/offY' (already transformed, :6239-6240), predictor (quarter-pel), AMVP candidates.
+//   out[0..1]  integer MV           out[2] SAD (MV cost removed) or MAX_UINT    out[3] notValid flag
+//   out[4..5]  half MV  out[6..7] quarter MV  out[8] cost after fractional search
+//   out[9] gtFlag  out[10..17] GT0..GT3 (x,y)  out[18] cost after GT  out[19..20] integer MV after GT
+//   out[21..22] half after GT, out[23..24] quarter after GT, out[25..26] ssBestCand[0]
+// stage: 1 = integer only, 2 = + fractional, 3 = + GT
+// ---------------------------------------------------------------------------------------------
+int ref_me_pu(const int16_t* org, int orgStride, int puX, int puY, int w, int h,
+              int rngL, int rngR, int rngT, int rngB, int offX, int offY,
+              int predX, int predY, int nAmvp, const int* amvpXY, int stage, int64_t* out)
+{
+  TEncSearch& s = g->search;
+  TComPicYuv* p = g->pic;
+  Pel* piRefY = p->getLumaAddr() + puY * p->getStride() + puX;
+  Int iRefStride = p->getStride();
+  TComPattern key; key.initPattern((Pel*)org, NULL, NULL, w, h, orgStride, 0, 0);
+  TComMv lt(rngL, rngT), rb(rngR, rngB), mv, pred(predX, predY), half, qter;
+  TComMv best[1]; best[0].set(0, 0);
+  UInt cost = 0;
+  s.m_cDistParam.bApplyWeight = false;
+  g->rd.getMotionCost(1, 0);
+  g->rd.setPredictor(pred);
+  g->rd.setCostScale(2);
+  s.xPatternSearch(&key, piRefY, iRefStride, &lt, &rb, mv, cost, offX, offY, best, true);
+  out[0] = mv.getHor(); out[1] = mv.getVer(); out[2] = cost; out[25] = best[0].getHor(); out[26] = best[0].getVer();
+  bool notValid = (cost == MAX_UINT) || (mv.getHor() == 0 && mv.getVer() == 0) || (p->getBufY()[0] == NOT_VALID);
+  out[3] = notValid;
+  if (notValid || stage < 2) return 0;
+  g->rd.getMotionCost(1, 0);
+  g->rd.setCostScale(1);
+  s.xPatternSearchFracDIF(&g->cu, &key, piRefY, iRefStride, &mv, half, qter, cost, false);
+  g->rd.setCostScale(0);
+  out[4] = half.getHor(); out[5] = half.getVer(); out[6] = qter.getHor(); out[7] = qter.getVer(); out[8] = cost;
+  if (stage < 3) return 0;
+  AMVPInfo* ai = g->cu.getCUMvField(REF_PIC_LIST_0)->getAMVPInfo();
+  ai->iN = nAmvp;
+  for (int i = 0; i < nAmvp; i++) ai->m_acMvCand[i].set(amvpXY[2 * i], amvpXY[2 * i + 1]);
+  TComMv gt0, gt1, gt2, gt3; Bool gtFlag = false;
+  s.xPatternSearchGT(&g->cu, &key, piRefY, iRefStride, &mv, &half, &qter, &gt0, &gt1, &gt2, &gt3, gtFlag, cost, false, best);
+  out[9] = gtFlag;
+  out[10] = gt0.getHor(); out[11] = gt0.getVer(); out[12] = gt1.getHor(); out[13] = gt1.getVer();
+  out[14] = gt2.getHor(); out[15] = gt2.getVer(); out[16] = gt3.getHor(); out[17] = gt3.getVer();
+  out[18] = cost; out[19] = mv.getHor(); out[20] = mv.getVer();
+  out[21] = half.getHor(); out[22] = half.getVer(); out[23] = qter.getHor(); out[24] = qter.getVer();
+  return 0;
+}
+
+// Search-range derivation for an ISS PU: xSetSearchRange(pred) TEncSearch.cpp:6204-6220 followed by the
+// SS overload :6224-6259.  The arithmetic is the reference's via a TComDataCU whose position fields are
+// set; the three pic/SPS accessors it needs are RESTATED through clip_mv above.
+void ref_set_search_range(int picW, int picH, int cuX, int cuY, int cuSize, int ctuAddr, int frameWidthInCtu,
+                          int predX, int predY, int srchRng, int offX, int offY, int firstRow, int firstCol, int* out)
+{ // RESTATED control flow of TEncSearch.cpp:6204-6259 (integer arithmetic only)
+  int iMvShift = 2;
+  int ph = predX, pv = predY; clip_mv(picW, picH, cuX, cuY, ph, pv);
+  int lh = ph - (srchRng << iMvShift), lv = pv - (srchRng << iMvShift);
+  int rh = ph + (srchRng << iMvShift), rv = pv + (srchRng << iMvShift);
+  // TComMv holds Short components
+  lh = (Short)lh; lv = (Short)lv; rh = (Short)rh; rv = (Short)rv;
+  clip_mv(picW, picH, cuX, cuY, lh, lv); clip_mv(picW, picH, cuX, cuY, rh, rv);
+  lh >>= iMvShift; lv >>= iMvShift; rh >>= iMvShift; rv >>= iMvShift;
+  int left = lh, right = rh, top = lv, bottom = rv;
+  if (firstCol && firstRow) { right = left + 1; top = bottom + 1; }
+  else {
+    bottom = (bottom > (-offY - 4)) ? (-offY - 4) : bottom;
+    offX = -offX - cuSize - 4;
+    offY = -offY - cuSize - 4;
+    bottom = (firstCol && (bottom > offY)) ? offY : bottom;
+    right = (firstRow && (right > offX)) ? offX : right;
+    right = (!firstRow && (ctuAddr < frameWidthInCtu) && (right > (offX + (cuSize << 1)))) ? (offX + (cuSize << 1)) : right;
+  }
+  lh = (Short)(left << iMvShift); lv = (Short)(top << iMvShift); rh = (Short)(right << iMvShift); rv = (Short)(bottom << iMvShift);
+  clip_mv(picW, picH, cuX, cuY, lh, lv); clip_mv(picW, picH, cuX, cuY, rh, rv);
+  out[0] = lh >> iMvShift; out[1] = rh >> iMvShift; out[2] = lv >> iMvShift; out[3] = rv >> iMvShift;
+  out[4] = offX; out[5] = offY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final (normative, decoder-shared) predictor for one PU: the reference's own
+// xPredInterLumaBlk / xPredInterChromaBlk (TComPrediction.cpp:639-720, :1235-1347), both branches.
+// mv in quarter-pel, gt = GT0..GT3 (x,y).  Destination = 64x64 TComYuv, returned block at (0,0) layout
+// predY[h][w], predCb/Cr[h/2][w/2].
+// ---------------------------------------------------------------------------------------------
+void ref_pred_inter(int puX, int puY, int w, int h, int mvx, int mvy, int useGT, const int* gt,
+                    int16_t* predY, int16_t* predCb, int16_t* predCr)
+{
+  TEncSearch& s = g->search;
+  TComPicYuv* p = g->pic;
+  int wInCtu = (p->getWidth() + 63) / 64;
+  g->cu.m_uiCUAddr = (puY / 64) * wInCtu + (puX / 64);
+  g->cu.m_uiAbsIdxInLCU = 0;
+  UInt partAddr = g_auiRasterToZscan[((puY & 63) >> 2) * 16 + ((puX & 63) >> 2)];
+  TComYuv dst; dst.create(64, 64);
+  TComYuv* pd = &dst;
+  TComMv mv(mvx, mvy), g0(gt[0], gt[1]), g1(gt[2], gt[3]), g2(gt[4], gt[5]), g3(gt[6], gt[7]);
+  s.xPredInterLumaBlk(&g->cu, p, partAddr, &mv, w, h, pd, false, useGT != 0, &g0, &g1, &g2, &g3);
+  s.xPredInterChromaBlk(&g->cu, p, partAddr, &mv, w, h, pd, false, useGT != 0, &g0, &g1, &g2, &g3);
+  Pel* y = dst.getLumaAddr(partAddr); Pel* cb = dst.getCbAddr(partAddr); Pel* cr = dst.getCrAddr(partAddr);
+  for (int r = 0; r < h; r++) memcpy(predY + r * w, y + r * dst.getStride(), w * sizeof(Pel));
+  for (int r = 0; r < h / 2; r++) {
+    memcpy(predCb + r * (w / 2), cb + r * dst.getCStride(), (w / 2) * sizeof(Pel));
+    memcpy(predCr + r * (w / 2), cr + r * dst.getCStride(), (w / 2) * sizeof(Pel));
+  }
+  dst.destroy();
+  g->cu.m_uiCUAddr = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transforms (TComTrQuant.cpp:786 xTrMxN, :829 xITrMxN): mode = REG_DCT(65535) or DST for 4x4 intra luma
+// ---------------------------------------------------------------------------------------------
+void ref_fwd_transform(int bitDepth, const int16_t* block, int16_t* coeff, int w, int h, unsigned mode)
+{
+  std::vector<Short> b(block, block + w * h);
+  xTrMxN(bitDepth, &b[0], coeff, w, h, mode);
+}
+void ref_inv_transform(int bitDepth, const int16_t* coeff, int16_t* block, int w, int h, unsigned mode)
+{
+  std::vector<Short> c(coeff, coeff + w * h);
+  xITrMxN(bitDepth, &c[0], block, w, h, mode);
+}
+
+} // extern "C"

@@ -1,0 +1,136 @@
+"""Shared helpers for the test-suite, the golden-vector generator and bench.py's cpu_baseline leg.
+
+Everything here is TEST INFRASTRUCTURE: synthetic lenslet generator, ctypes bindings of the CPU
+oracle (oracle/libhop_oracle.so) and -- only where /root/reference was available at build time --
+of the reference-derived harness (oracle/_ref/libref_harness.so).
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libhop_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_harness.so")
+
+MARGIN_Y = 80   # TLibCommon/TComPicYuv.cpp:82-85
+MARGIN_C = 40
+
+I16P = ctypes.POINTER(ctypes.c_int16)
+I32P = ctypes.POINTER(ctypes.c_int32)
+I64P = ctypes.POINTER(ctypes.c_int64)
+F64P = ctypes.POINTER(ctypes.c_double)
+
+
+def p16(a):
+    assert a.dtype == np.int16
+    return a.ctypes.data_as(I16P)
+
+
+def lenslet(W, H, pitch=15, seed=2, bitdepth=8):
+    """Synthetic lenslet frame: square-packed micro-images of `pitch` px,
+    each a disparity-shifted view of one scene texture, radial vignetting, additive noise.
+    Returns (Y, Cb, Cr) int16 arrays, 4:2:0."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    mx, my = np.floor(xx / pitch), np.floor(yy / pitch)          # micro-image index
+    ux, uy = xx - mx * pitch - pitch / 2.0, yy - my * pitch - pitch / 2.0
+    disp = 0.35
+    sx, sy = mx * pitch * 0.12 + ux * disp * 3.0, my * pitch * 0.12 + uy * disp * 3.0   # scene coords
+
+    def tex(ax, ay, r):
+        t = np.zeros_like(ax)
+        for _ in range(4):
+            f = r.uniform(0.02, 0.35, 2)
+            ph = r.uniform(0, 2 * np.pi, 2)
+            t += r.uniform(0.4, 1.0) * np.sin(ax * f[0] + ph[0]) * np.cos(ay * f[1] + ph[1])
+        return t / 4.0
+    maxv = (1 << bitdepth) - 1
+    vign = np.exp(-(ux ** 2 + uy ** 2) / (2 * (0.55 * pitch) ** 2))
+    y = (0.5 + 0.45 * tex(sx, sy, rng)) * vign * maxv + rng.normal(0, 2.0 * (1 << (bitdepth - 8)), (H, W))
+    Y = np.clip(np.rint(y), 0, maxv).astype(np.int16)
+    cxx, cyy = sx[::2, ::2], sy[::2, ::2]
+    mid = 1 << (bitdepth - 1)
+    Cb = np.clip(np.rint(mid + 0.25 * maxv * tex(cxx, cyy, rng) * vign[::2, ::2]), 0, maxv).astype(np.int16)
+    Cr = np.clip(np.rint(mid + 0.25 * maxv * tex(cxx, cyy, rng) * vign[::2, ::2]), 0, maxv).astype(np.int16)
+    return Y, Cb, Cr
+
+
+class Planes:
+    """SS-reference planes in the reference's own layout: margins 80/40, stride = W + 160 / W/2 + 80."""
+
+    def __init__(self, W, H):
+        self.W, self.H = W, H
+        self.sy, self.sc = W + 2 * MARGIN_Y, (W >> 1) + 2 * MARGIN_C
+        self.bufY = np.full((H + 2 * MARGIN_Y, self.sy), -1, np.int16)
+        self.bufCb = np.full(((H >> 1) + 2 * MARGIN_C, self.sc), -1, np.int16)
+        self.bufCr = np.full(((H >> 1) + 2 * MARGIN_C, self.sc), -1, np.int16)
+
+    def y00(self):
+        return self.bufY[MARGIN_Y:, MARGIN_Y:]
+
+    def ptr00(self, comp):
+        b, m = ((self.bufY, MARGIN_Y), (self.bufCb, MARGIN_C), (self.bufCr, MARGIN_C))[comp]
+        st = b.shape[1]
+        return ctypes.cast(b.ctypes.data + (m * st + m) * 2, I16P)
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "hop_oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libhop_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        L = ctypes.CDLL(ORACLE_SO)
+        for n in ("hop_o_sad", "hop_o_sse", "hop_o_hads", "hop_o_calc_had", "hop_o_component_bits", "hop_o_bits_gt", "hop_o_frac_search"):
+            getattr(L, n).restype = ctypes.c_uint32
+        _oracle = L
+    return _oracle
+
+
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+def ref(bitdepth=8, use_had=1, fen=1, search_range=128):
+    """The reference-derived harness (oracle/_ref); one configuration per process."""
+    global _ref
+    if _ref is None:
+        L = ctypes.CDLL(REF_SO)
+        L.ref_init(bitdepth, bitdepth, use_had, fen, search_range)
+        L.ref_set_lambda.argtypes = [ctypes.c_double]
+        L.ref_lambda_motion_sad.restype = ctypes.c_uint
+        L.ref_pic_plane.restype = I16P
+        for n in ("ref_sad", "ref_hads", "ref_sse", "ref_calc_had", "ref_component_bits", "ref_bits_gt"):
+            getattr(L, n).restype = ctypes.c_uint
+        _ref = L
+    return _ref
+
+
+def lambda_for_qp(qp):
+    """TLibEncoder/TEncSlice.cpp:381-395 for an all-intra (ISS) slice at depth 0, no QP offsets:
+    lambda = 0.57 * 2^((qp-12)/3); returns (lambda, m_uiLambdaMotionSAD) (TComRdCost.cpp:167-173)."""
+    lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+    return lam, int(np.floor(65536.0 * np.sqrt(lam)))
+
+
+def ref_load_planes(L, pl):
+    """Copy a Planes object into the harness picture (same layout, whole padded buffers)."""
+    st = ctypes.c_int()
+    stride = L.ref_pic_create(pl.W, pl.H)
+    assert stride == pl.sy
+    for comp, (buf, m) in enumerate(((pl.bufY, MARGIN_Y), (pl.bufCb, MARGIN_C), (pl.bufCr, MARGIN_C))):
+        p = L.ref_pic_plane(comp, ctypes.byref(st))
+        assert st.value == buf.shape[1]
+        base = ctypes.addressof(p.contents) - (m * st.value + m) * 2
+        ctypes.memmove(base, buf.ctypes.data, buf.nbytes)

@@ -1,0 +1,57 @@
+"""Rebuild the inputs of the golden fixtures (tests/golden/*.npz) -- shared by the CPU and GPU tests."""
+import ctypes
+import os
+import zlib
+
+import numpy as np
+
+from hoputil import ROOT, Planes, oracle, p16
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def coded_planes(Y, Cb, Cr, W, H, ctu_r, ctu_c, partial):
+    """Same construction as oracle/make_golden.py:coded_planes, with the oracle's border extension."""
+    O = oracle()
+    pl = Planes(W, H)
+
+    def put(x, y, sx, sy):
+        pl.y00()[y:y + sy, x:x + sx] = Y[y:y + sy, x:x + sx]
+        pl.bufCb[40 + y // 2:40 + (y + sy) // 2, 40 + x // 2:40 + (x + sx) // 2] = Cb[y // 2:(y + sy) // 2, x // 2:(x + sx) // 2]
+        pl.bufCr[40 + y // 2:40 + (y + sy) // 2, 40 + x // 2:40 + (x + sx) // 2] = Cr[y // 2:(y + sy) // 2, x // 2:(x + sx) // 2]
+    if ctu_r > 0:
+        put(0, 0, W, ctu_r * 64)
+    if ctu_c > 0:
+        put(0, ctu_r * 64, ctu_c * 64, min(64, H - ctu_r * 64))
+    for (x, y, s) in partial:
+        put(int(x), int(y), int(s), int(s))
+    # border extension only: re-commit the 8x8 block at (0,0) with the values it already holds
+    by = np.ascontiguousarray(pl.y00()[0:8, 0:8])
+    bb = np.ascontiguousarray(pl.bufCb[40:44, 40:44])
+    br = np.ascontiguousarray(pl.bufCr[40:44, 40:44])
+    O.hop_o_ssref_commit_cu(pl.ptr00(0), pl.ptr00(1), pl.ptr00(2), W, H, 0, 0, 8, p16(by), p16(bb), p16(br))
+    return pl
+
+
+def me_chain_scenarios():
+    """Yields (planes, Y, jobs, outs, lambda_cost) per scenario of me_chain.npz."""
+    g = load("me_chain.npz")
+    W, H = int(g["W"]), int(g["H"])
+    Y, Cb, Cr, rec = (g[k].astype(np.int16) for k in ("Y", "Cb", "Cr", "rec"))
+    partial = g["partial"]
+    pi = 0
+    for si, (cr_, cc_, npart) in enumerate(g["scen"]):
+        part = [tuple(int(v) for v in partial[pi + k]) for k in range(npart)]
+        pi += npart
+        pl = coded_planes(rec, Cb, Cr, W, H, int(cr_), int(cc_), part)
+        assert [crc(pl.bufY), crc(pl.bufCb), crc(pl.bufCr)] == [int(v) for v in g["planes_crc"][si]]
+        sel = g["jobs"][:, 0] == si
+        yield pl, Y, g["jobs"][sel], g["outs"][sel], int(g["lambda_cost"])

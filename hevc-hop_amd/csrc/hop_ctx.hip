@@ -1,0 +1,372 @@
+// hop_ctx.hip -- context, picture residency, host-side logic and the C ABI glue of libhophip.so.
+// gfx950 only.  No CPU compute path exists in this library: every hot-path entry point launches a
+// HIP kernel and fails with HOP_ERR_DEVICE when there is no device.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "hop_dev.h"
+
+static char g_create_err[512] = "";
+
+int hop_set_err(hop_ctx* c, int code, const char* fmt, ...) {
+  char* dst = c ? c->err : g_create_err;
+  va_list ap; va_start(ap, fmt); vsnprintf(dst, 512, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return hop_set_err((c), HOP_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+int hop_scratch(hop_ctx* c, size_t bytes, void** out) {
+  if (bytes > c->scratch_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->scratch) HIPCHK(c, hipFree(c->scratch));
+    c->scratch = nullptr; c->scratch_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(c, hipMalloc(&c->scratch, want));
+    c->scratch_bytes = want;
+  }
+  *out = c->scratch;
+  return HOP_OK;
+}
+static int hop_stage(hop_ctx* c, size_t bytes, void** out) {
+  if (bytes > c->stage_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stage) HIPCHK(c, hipFree(c->stage));
+    c->stage = nullptr; c->stage_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(c, hipMalloc(&c->stage, want));
+    c->stage_bytes = want;
+  }
+  *out = c->stage;
+  return HOP_OK;
+}
+
+extern "C" {
+
+const char* hop_version(void) { return "hophip 0.1 gfx950"; }
+const char* hop_last_error(const hop_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit_depth_c, int device) {
+  if (!out) return hop_set_err(nullptr, HOP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  // picture sizes: the reference codes multiples of the minimum CU (8) only (TAppEncCfg padding)
+  if (pic_w <= 0 || pic_h <= 0 || (pic_w & 7) || (pic_h & 7)) return hop_set_err(nullptr, HOP_ERR_ARG, "picture %dx%d must be a positive multiple of 8", pic_w, pic_h);
+  if (bit_depth_y < 8 || bit_depth_y > 12 || bit_depth_c < 8 || bit_depth_c > 12) return hop_set_err(nullptr, HOP_ERR_ARG, "bit depth out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return hop_set_err(nullptr, HOP_ERR_DEVICE, "no HIP device: libhophip has no CPU path");
+  if (device < 0 || device >= ndev) return hop_set_err(nullptr, HOP_ERR_ARG, "device %d of %d", device, ndev);
+  hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
+  c->pic_w = pic_w; c->pic_h = pic_h; c->bd_y = bit_depth_y; c->bd_c = bit_depth_c; c->device = device;
+  c->stride_y = pic_w + 2 * HOP_MARGIN_Y; c->stride_c = (pic_w >> 1) + 2 * HOP_MARGIN_C;
+  if (hipSetDevice(device) != hipSuccess) { free(c); return hop_set_err(nullptr, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    hop_set_err(nullptr, HOP_ERR_DEVICE, "device %d is '%s', libhophip is built for gfx950 only", device, prop.gcnArchName);
+    free(c); return HOP_ERR_DEVICE;
+  }
+  size_t ny = (size_t)pic_w * pic_h, nc = ny >> 2;
+  size_t sy = (size_t)c->stride_y * (pic_h + 2 * HOP_MARGIN_Y), sc = (size_t)c->stride_c * ((pic_h >> 1) + 2 * HOP_MARGIN_C);
+  hipError_t e = hipStreamCreate(&c->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->org_y, ny * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->org_cb, nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->org_cr, nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_buf[0], sy * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_buf[1], sc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_buf[2], sc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->pred[0], ny * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->pred[1], nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->pred[2], nc * 2);
+  if (e != hipSuccess) { hop_set_err(nullptr, HOP_ERR_DEVICE, "allocation failed: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
+  c->ss00[0] = c->ss_buf[0] + (size_t)HOP_MARGIN_Y * c->stride_y + HOP_MARGIN_Y;
+  c->ss00[1] = c->ss_buf[1] + (size_t)HOP_MARGIN_C * c->stride_c + HOP_MARGIN_C;
+  c->ss00[2] = c->ss_buf[2] + (size_t)HOP_MARGIN_C * c->stride_c + HOP_MARGIN_C;
+  *out = c;
+  int r = hop_ssref_reset(c);
+  if (r == HOP_OK) r = hop_sync(c);
+  if (r != HOP_OK) { strncpy(g_create_err, c->err, 511); hop_ctx_destroy(c); *out = nullptr; }
+  return r;
+}
+
+void hop_ctx_destroy(hop_ctx* c) {
+  if (!c) return;
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+  void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_buf[0], c->ss_buf[1], c->ss_buf[2], c->pred[0], c->pred[1], c->pred[2], c->scratch, c->stage };
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  free(c);
+}
+
+int hop_sync(hop_ctx* c) { if (!c) return HOP_ERR_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return HOP_OK; }
+void* hop_stream(hop_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int hop_upload_orig(hop_ctx* c, const int16_t* y, int stride_y, const int16_t* cb, const int16_t* cr, int stride_c) {
+  if (!c || !y || !cb || !cr || stride_y < c->pic_w || stride_c < (c->pic_w >> 1)) return hop_set_err(c, HOP_ERR_ARG, "hop_upload_orig: bad argument");
+  HIPCHK(c, hipMemcpy2DAsync(c->org_y, (size_t)c->pic_w * 2, y, (size_t)stride_y * 2, (size_t)c->pic_w * 2, c->pic_h, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->org_cb, (size_t)c->pic_w, cb, (size_t)stride_c * 2, (size_t)c->pic_w, c->pic_h >> 1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->org_cr, (size_t)c->pic_w, cr, (size_t)stride_c * 2, (size_t)c->pic_w, c->pic_h >> 1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_orig = true;
+  return HOP_OK;
+}
+
+int hop_ssref_reset(hop_ctx* c) { if (!c) return HOP_ERR_ARG; return hop_launch_ssref_reset(c); }
+
+static size_t plane_elems(const hop_ctx* c, int comp) {
+  return comp == 0 ? (size_t)c->stride_y * (c->pic_h + 2 * HOP_MARGIN_Y) : (size_t)c->stride_c * ((c->pic_h >> 1) + 2 * HOP_MARGIN_C);
+}
+int hop_ssref_download(hop_ctx* c, int comp, int16_t* dst) {
+  if (!c || !dst || comp < 0 || comp > 2) return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_download: bad argument");
+  HIPCHK(c, hipMemcpyAsync(dst, c->ss_buf[comp], plane_elems(c, comp) * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+int hop_ssref_upload(hop_ctx* c, int comp, const int16_t* src) {
+  if (!c || !src || comp < 0 || comp > 2) return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_upload: bad argument");
+  HIPCHK(c, hipMemcpyAsync(c->ss_buf[comp], src, plane_elems(c, comp) * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+int hop_pred_download(hop_ctx* c, int comp, int16_t* dst) {
+  if (!c || !dst || comp < 0 || comp > 2) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_download: bad argument");
+  size_t n = comp == 0 ? (size_t)c->pic_w * c->pic_h : ((size_t)c->pic_w * c->pic_h) >> 2;
+  HIPCHK(c, hipMemcpyAsync(dst, c->pred[comp], n * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+static int check_rects(hop_ctx* c, int n, const int32_t* r) {
+  for (int i = 0; i < n; i++) {
+    int x = r[4 * i], y = r[4 * i + 1], s = r[4 * i + 2];
+    if (!(s == 8 || s == 16 || s == 32 || s == 64) || x < 0 || y < 0 || (x % s) || (y % s) || x + s > c->pic_w || y + s > c->pic_h)
+      return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_commit_cus: CU %d (%d,%d,%d) is not a legal CU of a %dx%d picture", i, x, y, s, c->pic_w, c->pic_h);
+  }
+  return HOP_OK;
+}
+
+int hop_ssref_commit_cus(hop_ctx* c, int n, const int32_t* rect4, const int16_t* rec_y, const int16_t* rec_cb, const int16_t* rec_cr) {
+  if (!c || n < 0 || (n && (!rect4 || !rec_y || !rec_cb || !rec_cr))) return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_commit_cus: bad argument");
+  if (n == 0) return HOP_OK;
+  int r = check_rects(c, n, rect4); if (r) return r;
+  // packed layout: CU i's luma block starts at sum_{k<i} size_k^2; rect4[4*i+3] receives that offset
+  std::vector<int32_t> rr(rect4, rect4 + 4 * (size_t)n);
+  size_t tot = 0;
+  for (int i = 0; i < n; i++) { rr[4 * i + 3] = (int32_t)tot; tot += (size_t)rr[4 * i + 2] * rr[4 * i + 2]; }
+  size_t bytes_r = (size_t)n * 16, bytes_y = tot * 2, bytes_c = (tot >> 2) * 2;
+  size_t o_y = (bytes_r + 255) & ~(size_t)255, o_cb = (o_y + bytes_y + 255) & ~(size_t)255, o_cr = (o_cb + bytes_c + 255) & ~(size_t)255;
+  void* st; r = hop_stage(c, o_cr + bytes_c, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, rr.data(), bytes_r, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_y, rec_y, bytes_y, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_cb, rec_cb, bytes_c, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_cr, rec_cr, bytes_c, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_ssref_commit(c, n, (const int32_t*)b, (const int16_t*)(b + o_y), (const int16_t*)(b + o_cb), (const int16_t*)(b + o_cr), 1);
+  if (r) return r;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_ssref_commit_cus_device(hop_ctx* c, int n, const int32_t* d_rect4, const int16_t* d_rec_y, const int16_t* d_rec_cb, const int16_t* d_rec_cr) {
+  if (!c || n < 0 || (n && (!d_rect4 || !d_rec_y || !d_rec_cb || !d_rec_cr))) return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_commit_cus_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_ssref_commit(c, n, d_rect4, d_rec_y, d_rec_cb, d_rec_cr, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host logic
+// ---------------------------------------------------------------------------------------------
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+// TComDataCU::clipMv, TLibCommon/TComDataCU.cpp:3492-3504 (g_uiMaxCUWidth/Height = 64)
+static void clip_mv(int pic_w, int pic_h, int cu_x, int cu_y, int& hor, int& ver) {
+  const int sh = 2, off = 8;
+  int hmax = (pic_w + off - cu_x - 1) * 4, hmin = (-64 - off - cu_x + 1) * 4;
+  int vmax = (pic_h + off - cu_y - 1) * 4, vmin = (-64 - off - cu_y + 1) * 4;
+  (void)sh;
+  hor = imin(hmax, imax(hmin, hor));
+  ver = imin(vmax, imax(vmin, ver));
+}
+
+void hop_set_search_range(int pic_w, int pic_h, int cu_x, int cu_y, int cu_size, int ctu_addr, int frame_width_in_ctu,
+                          int pred_x, int pred_y, int search_range, int off_x, int off_y, int first_row, int first_col, int out[6]) {
+  // TEncSearch::xSetSearchRange(pcCU, cMvPred, iSrchRng, LT, RB), TEncSearch.cpp:6204-6220; TComMv stores Short
+  int ph = pred_x, pv = pred_y;
+  clip_mv(pic_w, pic_h, cu_x, cu_y, ph, pv);
+  int lh = (int16_t)(ph - search_range * 4), lv = (int16_t)(pv - search_range * 4);
+  int rh = (int16_t)(ph + search_range * 4), rv = (int16_t)(pv + search_range * 4);
+  clip_mv(pic_w, pic_h, cu_x, cu_y, lh, lv);
+  clip_mv(pic_w, pic_h, cu_x, cu_y, rh, rv);
+  int left = lh >> 2, top = lv >> 2, right = rh >> 2, bottom = rv >> 2;
+  // SS overload, TEncSearch.cpp:6224-6259
+  if (first_col && first_row) {
+    right = left + 1;
+    top = bottom + 1;
+  } else {
+    bottom = (bottom > (-off_y - 4)) ? (-off_y - 4) : bottom;
+    off_x = -off_x - cu_size - 4;
+    off_y = -off_y - cu_size - 4;
+    bottom = (first_col && (bottom > off_y)) ? off_y : bottom;
+    right = (first_row && (right > off_x)) ? off_x : right;
+    right = (!first_row && (ctu_addr < frame_width_in_ctu) && (right > (off_x + (cu_size << 1)))) ? (off_x + (cu_size << 1)) : right;
+  }
+  lh = (int16_t)(left * 4); lv = (int16_t)(top * 4); rh = (int16_t)(right * 4); rv = (int16_t)(bottom * 4);
+  clip_mv(pic_w, pic_h, cu_x, cu_y, lh, lv);
+  clip_mv(pic_w, pic_h, cu_x, cu_y, rh, rv);
+  out[0] = lh >> 2; out[1] = rh >> 2; out[2] = lv >> 2; out[3] = rv >> 2; out[4] = off_x; out[5] = off_y;
+}
+
+uint32_t hop_component_bits(int v) { return hopd_component_bits(v); }
+uint32_t hop_bits_gt(const int v[8]) {   // IT_GT_AFFINE: corners 0..2 only, TComRdCost.h:205-215
+  uint32_t b = 0; for (int i = 0; i < 6; i++) b += hopd_component_bits(v[i]); return b;
+}
+
+void hop_me_finish(const hop_pu_job* job, const hop_pu_result* res, int stage, uint32_t bits_in,
+                   int mv_qpel[2], uint32_t* bits_out, uint32_t* cost_out) {
+  // TEncSearch.cpp:4654-4682 (fWeight = 1: uni-prediction; cost scale is 0 at this point)
+  int mvx, mvy;
+  if (stage >= HOP_STAGE_GT) { mvx = (res->mv_final[0] << 2) + (res->half_final[0] << 1) + res->qter_final[0]; mvy = (res->mv_final[1] << 2) + (res->half_final[1] << 1) + res->qter_final[1]; }
+  else if (stage == HOP_STAGE_FRAC) { mvx = (res->mv_int[0] << 2) + (res->half[0] << 1) + res->qter[0]; mvy = (res->mv_int[1] << 2) + (res->half[1] << 1) + res->qter[1]; }
+  else { mvx = res->mv_int[0] << 2; mvy = res->mv_int[1] << 2; }
+  mv_qpel[0] = mvx; mv_qpel[1] = mvy;
+  uint32_t mv_bits = hopd_component_bits(mvx - job->pred_x) + hopd_component_bits(mvy - job->pred_y);
+  uint32_t bits = bits_in + mv_bits + 1;                       // + GT flag (:4669)
+  if (stage >= HOP_STAGE_GT) {
+    // :4673-4678 -- the chained '==' evaluates left to right on ints/bools; restated literally
+    const int32_t* g = res->gt;
+    int chain = (g[0] == g[1]);
+    chain = (chain == g[2]); chain = (chain == g[3]); chain = (chain == g[4]);
+    chain = (chain == g[5]); chain = (chain == g[6]); chain = (chain == g[7]);
+    if (!chain) { int v[8]; for (int i = 0; i < 8; i++) v[i] = g[i]; bits += hop_bits_gt(v); }
+  }
+  uint32_t cost_mv = (job->lambda_cost * mv_bits) >> 16, cost_bits = (job->lambda_cost * bits) >> 16;
+  uint32_t cost = (stage == HOP_STAGE_INT) ? res->sad + ((job->lambda_cost * mv_bits) >> 16) : res->cost;
+  *bits_out = bits;
+  *cost_out = (uint32_t)((double)cost - (double)cost_mv) + cost_bits;   // floor(fWeight*(cost - mvcost)) + cost(bits)
+}
+
+// ---------------------------------------------------------------------------------------------
+// hot path entry points
+// ---------------------------------------------------------------------------------------------
+static const int kLegalDim[] = { 4, 8, 12, 16, 24, 32, 48, 64 };
+static bool legal_dim(int v) { for (int d : kLegalDim) if (v == d) return true; return false; }
+
+static int check_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
+  for (int i = 0; i < n; i++) {
+    const hop_pu_job& j = jobs[i];
+    if (!legal_dim(j.w) || !legal_dim(j.h) || j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3) || j.pu_x + j.w > c->pic_w || j.pu_y + j.h > c->pic_h)
+      return hop_set_err(c, HOP_ERR_ARG, "PU job %d: rectangle (%d,%d,%dx%d) is not a legal PU of a %dx%d picture", i, j.pu_x, j.pu_y, j.w, j.h, c->pic_w, c->pic_h);
+    if (j.n_amvp < 0 || j.n_amvp > 2) return hop_set_err(c, HOP_ERR_ARG, "PU job %d: n_amvp %d", i, j.n_amvp);
+    // Reach: the reference addresses the padded plane linearly, so a column overshoot wraps into the neighbouring
+    // row exactly as it does in the reference; what must hold is that every access stays inside the allocation:
+    // rows (window, block, +4 probes, GT patch H/2 + 8-tap reach) within the 80-row margin, columns within one pitch.
+    if (j.rng_right >= j.rng_left && j.rng_bottom >= j.rng_top) {
+      if (j.rng_right - j.rng_left > 256 || j.rng_bottom - j.rng_top > 256)
+        return hop_set_err(c, HOP_ERR_ARG, "PU job %d: search window larger than 257x257 (SearchRange > 128)", i);
+      if (j.pu_y + j.rng_top - j.h / 2 - 4 < -78 || j.pu_y + j.rng_bottom + j.h + j.h / 2 + 8 > c->pic_h + 78 ||
+          j.pu_x + j.rng_left - j.w / 2 - 4 < -(c->stride_y - 8) || j.pu_x + j.rng_right + 2 * j.w + 8 > c->stride_y + c->pic_w - 8)
+        return hop_set_err(c, HOP_ERR_ARG, "PU job %d: search range leaves the padded reference", i);
+    }
+  }
+  return HOP_OK;
+}
+
+int hop_me_search_device(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_results, int stage) {
+  if (!c || n < 0 || stage < HOP_STAGE_INT || stage > HOP_STAGE_GT || (n && (!d_jobs || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_me_search_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_me_search: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  int r = hop_launch_ss_search(c, n, d_jobs, d_results); if (r) return r;
+  if (stage >= HOP_STAGE_FRAC) { r = hop_launch_frac(c, n, d_jobs, d_results); if (r) return r; }
+  if (stage >= HOP_STAGE_GT) { r = hop_launch_gt(c, n, d_jobs, d_results); if (r) return r; }
+  return HOP_OK;
+}
+
+int hop_me_search(hop_ctx* c, int n, const hop_pu_job* jobs, hop_pu_result* results, int stage) {
+  if (!c || n < 0 || (n && (!jobs || !results))) return hop_set_err(c, HOP_ERR_ARG, "hop_me_search: bad argument");
+  if (n == 0) return HOP_OK;
+  int r = check_jobs(c, n, jobs); if (r) return r;
+  size_t bj = (size_t)n * sizeof(hop_pu_job), o_r = (bj + 255) & ~(size_t)255, br = (size_t)n * sizeof(hop_pu_result);
+  void* st; r = hop_stage(c, o_r + br, &st); if (r) return r;
+  hop_pu_job* dj = (hop_pu_job*)st; hop_pu_result* dr = (hop_pu_result*)((char*)st + o_r);
+  HIPCHK(c, hipMemcpyAsync(dj, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  r = hop_me_search_device(c, n, dj, dr, stage); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(results, dr, br, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_pred_inter_device(hop_ctx* c, int n, const hop_pred_job* d_jobs) {
+  if (!c || n < 0 || (n && !d_jobs)) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_inter_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_pred(c, n, d_jobs);
+}
+
+__global__ void k_gather_pred(const hop_pred_job* jobs, const int64_t* offs, const int16_t* py, const int16_t* pcb, const int16_t* pcr,
+                              int pic_w, int16_t* oy, int16_t* ocb, int16_t* ocr) {
+  hop_pred_job j = jobs[blockIdx.x];
+  int64_t o = offs[blockIdx.x];
+  for (int i = threadIdx.x; i < j.w * j.h; i += blockDim.x) {
+    int r = i / j.w, cc = i % j.w;
+    oy[o + i] = py[(size_t)(j.pu_y + r) * pic_w + j.pu_x + cc];
+  }
+  int cw = j.w >> 1, ch = j.h >> 1;
+  for (int i = threadIdx.x; i < cw * ch; i += blockDim.x) {
+    int r = i / cw, cc = i % cw;
+    size_t s = (size_t)((j.pu_y >> 1) + r) * (pic_w >> 1) + (j.pu_x >> 1) + cc;
+    ocb[(o >> 2) + i] = pcb[s]; ocr[(o >> 2) + i] = pcr[s];
+  }
+}
+
+int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, int16_t* out_cb, int16_t* out_cr) {
+  if (!c || n < 0 || (n && !jobs)) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_inter: bad argument");
+  if (n == 0) return HOP_OK;
+  std::vector<int64_t> offs(n);
+  size_t tot = 0;
+  for (int i = 0; i < n; i++) {
+    const hop_pred_job& j = jobs[i];
+    if (!legal_dim(j.w) || !legal_dim(j.h) || j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3) || j.pu_x + j.w > c->pic_w || j.pu_y + j.h > c->pic_h)
+      return hop_set_err(c, HOP_ERR_ARG, "pred job %d: illegal PU rectangle", i);
+    // reach of the doubled patch + 8-tap filter must stay in the margin
+    int ix = j.pu_x + (j.mv_x >> 2), iy = j.pu_y + (j.mv_y >> 2);
+    if (ix - j.w / 2 - 4 < -HOP_MARGIN_Y || iy - j.h / 2 - 4 < -HOP_MARGIN_Y || ix + j.w + j.w / 2 + 4 >= c->pic_w + HOP_MARGIN_Y || iy + j.h + j.h / 2 + 4 >= c->pic_h + HOP_MARGIN_Y)
+      return hop_set_err(c, HOP_ERR_ARG, "pred job %d: motion vector leaves the padded reference", i);
+    offs[i] = (int64_t)tot; tot += (size_t)j.w * j.h;
+  }
+  size_t bj = (size_t)n * sizeof(hop_pred_job), o_o = (bj + 255) & ~(size_t)255, bo = (size_t)n * 8;
+  size_t o_y = (o_o + bo + 255) & ~(size_t)255, o_cb = (o_y + tot * 2 + 255) & ~(size_t)255, o_cr = (o_cb + tot / 2 + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_cr + tot / 2 + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_pred(c, n, (const hop_pred_job*)b); if (r) return r;
+  if (out_y && out_cb && out_cr) {
+    HIPCHK(c, hipMemcpyAsync(b + o_o, offs.data(), bo, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_pred, dim3(n), dim3(256), 0, c->stream, (const hop_pred_job*)b, (const int64_t*)(b + o_o),
+                       c->pred[0], c->pred[1], c->pred[2], c->pic_w, (int16_t*)(b + o_y), (int16_t*)(b + o_cb), (int16_t*)(b + o_cr));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_y, b + o_y, tot * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_cb, b + o_cb, tot / 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_cr, b + o_cr, tot / 2, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_distortion(hop_ctx* c, int n, const hop_dist_job* jobs, uint32_t* out) {
+  if (!c || n < 0 || (n && (!jobs || !out))) return hop_set_err(c, HOP_ERR_ARG, "hop_distortion: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_dist_job& j = jobs[i];
+    if (j.comp < 0 || j.comp > 2 || j.kind < 0 || j.kind > 2 || j.x < 0 || j.y < 0 || j.w <= 0 || j.h <= 0 || (j.w & 3) || (j.h & 3) || j.x + j.w > c->pic_w || j.y + j.h > c->pic_h)
+      return hop_set_err(c, HOP_ERR_ARG, "dist job %d: bad rectangle/kind", i);
+  }
+  size_t bj = (size_t)n * sizeof(hop_dist_job), o_o = (bj + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_o + (size_t)n * 4, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_dist(c, n, (const hop_dist_job*)b, (uint32_t*)(b + o_o)); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(out, b + o_o, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+} // extern "C"

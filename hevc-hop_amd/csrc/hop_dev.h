@@ -1,0 +1,112 @@
+// hop_dev.h -- shared host/device declarations of libhophip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hophip.h"
+
+#define HOP_MARGIN_Y 80      // TLibCommon/TComPicYuv.cpp:82-85 (g_uiMaxCUWidth + 16)
+#define HOP_MARGIN_C 40
+#define HOP_NOT_VALID (-1)   // TLibCommon/CommonDef.h:126
+#define HOP_WAVE 64
+
+struct hop_ctx {
+  int pic_w, pic_h, bd_y, bd_c, device;
+  int stride_y, stride_c;            // SS-ref strides (with margins)
+  hipStream_t stream;
+  // device pictures
+  int16_t *org_y, *org_cb, *org_cr;  // original, pitch pic_w / pic_w/2, no margins
+  int16_t *ss_buf[3];                // padded SS-ref buffers
+  int16_t *ss00[3];                  // sample (0,0) inside them
+  int16_t *pred[3];                  // prediction picture, pitch pic_w / pic_w/2
+  // scratch that grows on demand (never allocated inside a *_device call once sized)
+  void*  scratch; size_t scratch_bytes;
+  void*  stage;   size_t stage_bytes;   // staging for host-array entry points
+  bool   have_orig;
+  char   err[512];
+};
+
+// read-only view of the pictures handed to kernels
+struct hop_pics {
+  const int16_t* org_y; const int16_t* org_cb; const int16_t* org_cr;
+  const int16_t* ss_y;  const int16_t* ss_cb;  const int16_t* ss_cr;   // at sample (0,0)
+  int16_t* pred_y; int16_t* pred_cb; int16_t* pred_cr;
+  int pic_w, pic_h, stride_y, stride_c, bd_y, bd_c;
+};
+
+static inline hop_pics hop_make_pics(const hop_ctx* c) {
+  hop_pics p;
+  p.org_y = c->org_y; p.org_cb = c->org_cb; p.org_cr = c->org_cr;
+  p.ss_y = c->ss00[0]; p.ss_cb = c->ss00[1]; p.ss_cr = c->ss00[2];
+  p.pred_y = c->pred[0]; p.pred_cb = c->pred[1]; p.pred_cr = c->pred[2];
+  p.pic_w = c->pic_w; p.pic_h = c->pic_h; p.stride_y = c->stride_y; p.stride_c = c->stride_c;
+  p.bd_y = c->bd_y; p.bd_c = c->bd_c;
+  return p;
+}
+
+#ifdef __HIPCC__
+// ---- bit-cost helpers (TLibCommon/TComRdCost.cpp:270-284, TComRdCost.h:185-215, FIX203) ----
+__host__ __device__ static inline uint32_t hopd_component_bits(int v) {
+  uint32_t t = (v <= 0) ? (uint32_t)((-v << 1) + 1) : (uint32_t)(v << 1);
+#ifdef __HIP_DEVICE_COMPILE__
+  return 2u * (31u - (uint32_t)__clz((int)t)) + 1u;
+#else
+  uint32_t len = 1; while (t != 1) { t >>= 1; len += 2; } return len;
+#endif
+}
+__host__ __device__ static inline uint32_t hopd_mv_cost(uint32_t lambda_cost, int x, int y, int scale, int pred_x, int pred_y) {
+  uint32_t bits = hopd_component_bits(x * (1 << scale) - pred_x) + hopd_component_bits(y * (1 << scale) - pred_y);
+  return (lambda_cost * bits) >> 16;
+}
+
+// ---- wave-level helpers ----
+__device__ static inline int hopd_wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline unsigned long long hopd_wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// SATD of one 8x8 block held one difference per lane (lane = 8*row + col): the 2-D Hadamard is six
+// butterfly stages over the lane index bits; sum|coef| is invariant to the butterfly order, so this
+// equals xCalcHADs8x8 (TLibCommon/TComRdCost.cpp:1481-1575).  Returns (sum + 2) >> 2 in every lane.
+__device__ static inline int hopd_satd8x8_wave(int d, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_xor(d, o, 64);
+    d = (lane & o) ? (t - d) : (d + t);
+  }
+  int s = hopd_wave_sum(d < 0 ? -d : d);
+  return (s + 2) >> 2;
+}
+// four 4x4 blocks per wave: lane = 16*blk + 4*row + col; xCalcHADs4x4 (:1387-1479): (sum+1)>>1 per block.
+// Returns this lane's block SATD (same in the 16 lanes of a block).
+__device__ static inline int hopd_satd4x4_quad(int d, int lane) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    int t = __shfl_xor(d, o, 64);
+    d = (lane & o) ? (t - d) : (d + t);
+  }
+  int s = d < 0 ? -d : d;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+  return (s + 1) >> 1;
+}
+#endif // __HIPCC__
+
+// kernel launchers (each .hip file defines its own)
+int hop_launch_ss_search(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
+int hop_launch_frac(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
+int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
+int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs);
+int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out);
+int hop_launch_ssref_reset(hop_ctx* c);
+int hop_launch_ssref_commit(hop_ctx* c, int n, const int32_t* d_rect4, const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr, int packed);
+int hop_set_err(hop_ctx* c, int code, const char* fmt, ...);
+int hop_scratch(hop_ctx* c, size_t bytes, void** out);

@@ -1,0 +1,168 @@
+"""ctypes binding of libhophip.so (include/hophip.h) for tests/ and bench.py.
+
+This is plumbing, not the product: the product is the shared library and the C++ host mirror in
+hevc-hop_amd/host/.  There is no CPU fallback here or in the library -- loading fails loudly when the
+library has not been built, and every hot-path call fails with HOP_ERR_DEVICE without a gfx950 GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhophip.so")
+
+HOP_STAGE_INT, HOP_STAGE_FRAC, HOP_STAGE_GT = 1, 2, 3
+HOP_FLAG_FEN, HOP_FLAG_HADME = 1, 2
+HOP_DIST_SAD, HOP_DIST_SSE, HOP_DIST_HADS = 0, 1, 2
+
+
+class PuJob(ctypes.Structure):
+    _fields_ = [("pu_x", ctypes.c_int32), ("pu_y", ctypes.c_int32), ("w", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("rng_left", ctypes.c_int32), ("rng_right", ctypes.c_int32), ("rng_top", ctypes.c_int32), ("rng_bottom", ctypes.c_int32),
+                ("off_x", ctypes.c_int32), ("off_y", ctypes.c_int32), ("pred_x", ctypes.c_int32), ("pred_y", ctypes.c_int32),
+                ("lambda_cost", ctypes.c_uint32), ("n_amvp", ctypes.c_int32), ("amvp", ctypes.c_int32 * 4), ("flags", ctypes.c_int32)]
+
+
+class PuResult(ctypes.Structure):
+    _fields_ = [("mv_int", ctypes.c_int32 * 2), ("sad", ctypes.c_uint32), ("not_valid", ctypes.c_int32),
+                ("half", ctypes.c_int32 * 2), ("qter", ctypes.c_int32 * 2), ("frac_cost", ctypes.c_uint32),
+                ("gt_flag", ctypes.c_int32), ("gt", ctypes.c_int32 * 8), ("cost", ctypes.c_uint32),
+                ("mv_final", ctypes.c_int32 * 2), ("half_final", ctypes.c_int32 * 2), ("qter_final", ctypes.c_int32 * 2)]
+
+
+class PredJob(ctypes.Structure):
+    _fields_ = [("pu_x", ctypes.c_int32), ("pu_y", ctypes.c_int32), ("w", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("mv_x", ctypes.c_int32), ("mv_y", ctypes.c_int32), ("use_gt", ctypes.c_int32), ("gt", ctypes.c_int32 * 8)]
+
+
+class DistJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("w", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("comp", ctypes.c_int32), ("kind", ctypes.c_int32)]
+
+
+PU_JOB_DTYPE = np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("rng_left", "<i4"), ("rng_right", "<i4"),
+                         ("rng_top", "<i4"), ("rng_bottom", "<i4"), ("off_x", "<i4"), ("off_y", "<i4"), ("pred_x", "<i4"), ("pred_y", "<i4"),
+                         ("lambda_cost", "<u4"), ("n_amvp", "<i4"), ("amvp", "<i4", (4,)), ("flags", "<i4")])
+PU_RESULT_DTYPE = np.dtype([("mv_int", "<i4", (2,)), ("sad", "<u4"), ("not_valid", "<i4"), ("half", "<i4", (2,)), ("qter", "<i4", (2,)),
+                            ("frac_cost", "<u4"), ("gt_flag", "<i4"), ("gt", "<i4", (8,)), ("cost", "<u4"), ("mv_final", "<i4", (2,)),
+                            ("half_final", "<i4", (2,)), ("qter_final", "<i4", (2,))])
+assert PU_JOB_DTYPE.itemsize == ctypes.sizeof(PuJob) and PU_RESULT_DTYPE.itemsize == ctypes.sizeof(PuResult)
+
+_I16P = ctypes.POINTER(ctypes.c_int16)
+
+
+class HopError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise HopError("libhophip.so is not built (run `make -C hevc-hop_amd` or __graft_entry__.build()); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    L.hop_last_error.restype = ctypes.c_char_p
+    L.hop_last_error.argtypes = [ctypes.c_void_p]
+    L.hop_version.restype = ctypes.c_char_p
+    L.hop_stream.restype = ctypes.c_void_p
+    L.hop_stream.argtypes = [ctypes.c_void_p]
+    L.hop_component_bits.restype = ctypes.c_uint32
+    L.hop_bits_gt.restype = ctypes.c_uint32
+    for n in ("hop_ctx_destroy", "hop_sync", "hop_ssref_reset"):
+        getattr(L, n).argtypes = [ctypes.c_void_p]
+    L.hop_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 5
+    L.hop_upload_orig.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.hop_ssref_commit_cus.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    L.hop_ssref_commit_cus_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    L.hop_ssref_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.hop_ssref_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.hop_pred_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.hop_me_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.hop_me_search_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.hop_pred_inter.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    L.hop_pred_inter_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.hop_distortion.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_set_search_range.argtypes = [ctypes.c_int] * 14 + [ctypes.POINTER(ctypes.c_int)]
+    L.hop_me_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32,
+                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    return L
+
+
+class Context:
+    """Thin RAII wrapper over hop_ctx_* for the tests and the bench."""
+
+    def __init__(self, pic_w, pic_h, bit_depth=8, device=0, lib=None):
+        self.L = lib or load()
+        self.h = ctypes.c_void_p()
+        self.W, self.H = pic_w, pic_h
+        r = self.L.hop_ctx_create(ctypes.byref(self.h), pic_w, pic_h, bit_depth, bit_depth, device)
+        if r != 0:
+            raise HopError("hop_ctx_create: %d %s" % (r, self.L.hop_last_error(None).decode()))
+
+    def close(self):
+        if self.h:
+            self.L.hop_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r, what):
+        if r != 0:
+            raise HopError("%s: %d %s" % (what, r, self.L.hop_last_error(self.h).decode()))
+
+    def upload_orig(self, Y, Cb, Cr):
+        Y, Cb, Cr = (np.ascontiguousarray(a, np.int16) for a in (Y, Cb, Cr))
+        self._chk(self.L.hop_upload_orig(self.h, Y.ctypes.data, Y.shape[1], Cb.ctypes.data, Cr.ctypes.data, Cb.shape[1]), "hop_upload_orig")
+
+    def ssref_reset(self):
+        self._chk(self.L.hop_ssref_reset(self.h), "hop_ssref_reset")
+        self._chk(self.L.hop_sync(self.h), "hop_sync")
+
+    def ssref_commit(self, rects, recY, recCb, recCr):
+        r4 = np.zeros((len(rects), 4), np.int32)
+        r4[:, :3] = np.asarray(rects, np.int32).reshape(-1, 3)
+        recY, recCb, recCr = (np.ascontiguousarray(a, np.int16) for a in (recY, recCb, recCr))
+        self._chk(self.L.hop_ssref_commit_cus(self.h, len(rects), r4.ctypes.data, recY.ctypes.data, recCb.ctypes.data, recCr.ctypes.data), "hop_ssref_commit_cus")
+
+    def ssref_download(self, comp):
+        shape = (self.H + 160, self.W + 160) if comp == 0 else (self.H // 2 + 80, self.W // 2 + 80)
+        a = np.empty(shape, np.int16)
+        self._chk(self.L.hop_ssref_download(self.h, comp, a.ctypes.data), "hop_ssref_download")
+        return a
+
+    def ssref_upload(self, comp, buf):
+        buf = np.ascontiguousarray(buf, np.int16)
+        self._chk(self.L.hop_ssref_upload(self.h, comp, buf.ctypes.data), "hop_ssref_upload")
+
+    def me_search(self, jobs, stage=HOP_STAGE_GT):
+        jobs = np.ascontiguousarray(jobs, PU_JOB_DTYPE)
+        res = np.zeros(len(jobs), PU_RESULT_DTYPE)
+        self._chk(self.L.hop_me_search(self.h, len(jobs), jobs.ctypes.data, res.ctypes.data, stage), "hop_me_search")
+        return res
+
+    def pred_inter(self, jobs):
+        n = len(jobs)
+        arr = (PredJob * n)(*jobs)
+        tot = sum(j.w * j.h for j in jobs)
+        oy, ocb, ocr = np.empty(tot, np.int16), np.empty(tot // 4, np.int16), np.empty(tot // 4, np.int16)
+        self._chk(self.L.hop_pred_inter(self.h, n, ctypes.addressof(arr), oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), "hop_pred_inter")
+        return oy, ocb, ocr
+
+    def pred_download(self, comp):
+        shape = (self.H, self.W) if comp == 0 else (self.H // 2, self.W // 2)
+        a = np.empty(shape, np.int16)
+        self._chk(self.L.hop_pred_download(self.h, comp, a.ctypes.data), "hop_pred_download")
+        return a
+
+    def distortion(self, jobs):
+        n = len(jobs)
+        arr = (DistJob * n)(*jobs)
+        out = np.zeros(n, np.uint32)
+        self._chk(self.L.hop_distortion(self.h, n, ctypes.addressof(arr), out.ctypes.data), "hop_distortion")
+        return out
+
+    def sync(self):
+        self._chk(self.L.hop_sync(self.h), "hop_sync")

@@ -1,0 +1,160 @@
+/*
+ * hophip.h -- C ABI of libhophip.so: the MI355X (gfx950) implementation of the HEVC-HOP hot path.
+ *
+ * The reference (zinsayon/HEVC-HOP, an HM-15.0 fork) has no plugin/FFI layer; its "boundary" is the
+ * C++ surface of TEncSearch / TComPrediction / TComRdCost / TEncCu.
+ * Each entry point below names the reference interface it replaces (paths relative to
+ * source/Lib in the reference tree); INTEGRATION.md shows the C++ shim a maintainer adds.
+ *
+ * Conventions
+ *   - Pel = int16_t, strides in elements, coordinates in luma samples of the picture.
+ *   - All pictures live in HBM inside the context: the original (no margins) and the
+ *     self-similarity ("SS") reference in the reference's own TComPicYuv layout (margins 80 luma /
+ *     40 chroma, TLibCommon/TComPicYuv.cpp:82-85; sentinel NOT_VALID = -1, CommonDef.h:126).
+ *   - Host-array entry points are synchronous: the caller owns every pointer it passes and the
+ *     library keeps none of them after return.  *_device entry points take device pointers and
+ *     are asynchronous on the context stream (hop_sync to wait); they exist so that a caller
+ *     that already lives on the GPU (and bench.py) does not pay PCIe per batch.
+ *   - Every function returns HOP_OK (0) or a negative hop_status; hop_last_error() has the text.
+ *     "No valid SS candidate" is not an error: it is reported per PU through
+ *     hop_pu_result.not_valid and sad = 0xFFFFFFFF, the sentinels the reference uses
+ *     (TLibEncoder/TEncSearch.cpp:6356-6360, :4603-4611).
+ */
+#ifndef HOPHIP_H
+#define HOPHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hop_ctx hop_ctx;
+
+typedef enum {
+  HOP_OK = 0,
+  HOP_ERR_ARG = -1,       /* bad argument (shape not on the reference's PU list, NULL, out of picture) */
+  HOP_ERR_DEVICE = -2,    /* HIP runtime error (no gfx950 device, allocation, launch) */
+  HOP_ERR_STATE = -3      /* call order (e.g. search before hop_upload_orig) */
+} hop_status;
+
+/* ---- stage selectors for hop_me_search ---- */
+#define HOP_STAGE_INT  1  /* SS integer full search only              (xPatternSearch)            */
+#define HOP_STAGE_FRAC 2  /* + half/quarter-pel refinement            (xPatternSearchFracDIF)     */
+#define HOP_STAGE_GT   3  /* + GT/HOP 4-corner diamond search         (xPatternSearchGT)          */
+
+/* ---- job flags ---- */
+#define HOP_FLAG_FEN     1  /* FEN: row-subsampled SAD for PUs taller than 8 (TEncSearch.cpp:6303-6309) */
+#define HOP_FLAG_HADME   2  /* HadamardME: HAD cost in fractional + GT search (TEncSearch.cpp:719,4772) */
+
+/* One prediction unit through the ME chain of TEncSearch::xMotionEstimation
+ * (TLibEncoder/TEncSearch.cpp:4479-4683).  The search range and offX'/offY' are the values AFTER
+ * both xSetSearchRange overloads (:6204-6259); hop_set_search_range() computes them. */
+typedef struct {
+  int32_t  pu_x, pu_y, w, h;                       /* PU rectangle in the picture */
+  int32_t  rng_left, rng_right, rng_top, rng_bottom; /* integer-pel search range, inclusive */
+  int32_t  off_x, off_y;                           /* causality offsets after :6239-6240 */
+  int32_t  pred_x, pred_y;                         /* MV predictor, quarter-pel (setPredictor :4559) */
+  uint32_t lambda_cost;                            /* m_uiLambdaMotionSAD = floor(65536*sqrt(lambda)), TComRdCost.cpp:171 */
+  int32_t  n_amvp;                                 /* AMVP candidates used as extra GT start vectors (:5100-5105), 0..2 */
+  int32_t  amvp[4];                                /* (x,y) quarter-pel each */
+  int32_t  flags;                                  /* HOP_FLAG_* */
+} hop_pu_job;
+
+typedef struct {
+  int32_t  mv_int[2];      /* integer MV from the SS search (rcMv after xPatternSearch) */
+  uint32_t sad;            /* its SAD with the MV cost removed (:6365); 0xFFFFFFFF if none valid */
+  int32_t  not_valid;      /* bNotValCU condition (:4603-4611) */
+  int32_t  half[2];        /* after xPatternSearchFracDIF */
+  int32_t  qter[2];
+  uint32_t frac_cost;
+  int32_t  gt_flag;        /* after xPatternSearchGT */
+  int32_t  gt[8];          /* GT0..GT3 (x,y) */
+  uint32_t cost;           /* ruiCost after the last executed stage */
+  int32_t  mv_final[2];    /* integer MV after GT (rewritten when GT wins, :5455-5457) */
+  int32_t  half_final[2];
+  int32_t  qter_final[2];
+} hop_pu_result;
+
+/* One PU for the final (normative, decoder-shared) predictor:
+ * TComPrediction::xPredInterLumaBlk / xPredInterChromaBlk incl. the GT branch
+ * (TLibCommon/TComPrediction.cpp:639-720, :723-805, :1235-1420). */
+typedef struct {
+  int32_t pu_x, pu_y, w, h;
+  int32_t mv_x, mv_y;      /* quarter-pel */
+  int32_t use_gt;
+  int32_t gt[8];
+} hop_pred_job;
+
+/* distortion kinds for hop_distortion (TLibCommon/TComRdCost.cpp) */
+#define HOP_DIST_SAD  0    /* xGetSAD*            :513-1011  */
+#define HOP_DIST_SSE  1    /* xGetSSE*            :1018-1360 */
+#define HOP_DIST_HADS 2    /* xGetHADs            :1641-1708 */
+
+typedef struct {
+  int32_t x, y, w, h;      /* luma rectangle; comp 1/2 use (x/2,y/2,w/2,h/2) */
+  int32_t comp;            /* 0 Y, 1 Cb, 2 Cr */
+  int32_t kind;            /* HOP_DIST_* */
+} hop_dist_job;
+
+/* ---- context ---- */
+/* replaces: TEncTop::create/init wiring of m_cSearch/m_cRdCost (TLibEncoder/TEncTop.cpp:89-101,299-310)
+ * and TComPicYuv::create for the SS reference (TLibCommon/TComPicYuv.cpp:69-120). */
+int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit_depth_c, int device);
+void hop_ctx_destroy(hop_ctx* ctx);
+const char* hop_last_error(const hop_ctx* ctx);     /* ctx may be NULL: error of the failed create */
+int hop_sync(hop_ctx* ctx);
+void* hop_stream(hop_ctx* ctx);                     /* hipStream_t the *_device calls are ordered on */
+
+/* ---- picture residency ---- */
+/* replaces: the host copy of the original into TComPic (TLibEncoder/TEncTop.cpp:363-368) */
+int hop_upload_orig(hop_ctx* ctx, const int16_t* y, int stride_y, const int16_t* cb, const int16_t* cr, int stride_c);
+/* replaces: TComSlice::xGetRefPic sentinel fill (TLibCommon/TComSlice.cpp:241-255 -> TComPicYuv::setPicPel :199-207) */
+int hop_ssref_reset(hop_ctx* ctx);
+/* replaces: TEncCu::xCopyYuv2SSRef leaf (TLibEncoder/TEncCu.cpp:1677-1697) incl. the border re-extension
+ * (TLibCommon/TComPicYuv.cpp:236-275), done incrementally for the margins the CU can change.
+ * n CUs; rect[i] = {x, y, size, 0}; rec_y/cb/cr: n contiguous blocks of size^2 / (size/2)^2 samples. */
+int hop_ssref_commit_cus(hop_ctx* ctx, int n, const int32_t* rect4, const int16_t* rec_y, const int16_t* rec_cb, const int16_t* rec_cr);
+/* commit straight from a device-resident reconstruction picture (planes without margins, pitch = pic_w / pic_w/2) */
+int hop_ssref_commit_cus_device(hop_ctx* ctx, int n, const int32_t* d_rect4, const int16_t* d_rec_y, const int16_t* d_rec_cb, const int16_t* d_rec_cr);
+/* whole padded plane (comp 0: (pic_h+160) x (pic_w+160); 1/2: (pic_h/2+80) x (pic_w/2+80)) -- tests, debugging, checkpoints */
+int hop_ssref_download(hop_ctx* ctx, int comp, int16_t* dst);
+int hop_ssref_upload(hop_ctx* ctx, int comp, const int16_t* src);
+
+/* ---- host logic ---- */
+/* replaces: TEncSearch::xSetSearchRange (both overloads, TLibEncoder/TEncSearch.cpp:6204-6259) with
+ * TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3492-3504).  out = {left,right,top,bottom,offX',offY'} */
+void hop_set_search_range(int pic_w, int pic_h, int cu_x, int cu_y, int cu_size, int ctu_addr, int frame_width_in_ctu,
+                          int pred_x, int pred_y, int search_range, int off_x, int off_y, int first_row, int first_col, int out[6]);
+/* replaces: TComRdCost::xGetComponentBits / getBitsGT (TLibCommon/TComRdCost.cpp:270-284, TComRdCost.h:205-215) */
+uint32_t hop_component_bits(int v);
+uint32_t hop_bits_gt(const int v[8]);
+/* replaces: the bits/cost bookkeeping at the tail of xMotionEstimation (TEncSearch.cpp:4654-4682):
+ * folds one hop_pu_result into (mv quarter-pel, bits, cost); bits_in = ruiBits on entry. */
+void hop_me_finish(const hop_pu_job* job, const hop_pu_result* res, int stage, uint32_t bits_in,
+                   int mv_qpel[2], uint32_t* bits_out, uint32_t* cost_out);
+
+/* ---- the hot path ---- */
+/* replaces: TEncSearch::xPatternSearch (:6262-6371) + xPatternSearchFracDIF (:6564-6610) +
+ * xPatternSearchGT (:4686-5467) for a batch of PUs; the original block is read from the resident
+ * original picture at (pu_x, pu_y). */
+int hop_me_search(hop_ctx* ctx, int n, const hop_pu_job* jobs, hop_pu_result* results, int stage);
+int hop_me_search_device(hop_ctx* ctx, int n, const hop_pu_job* d_jobs, hop_pu_result* d_results, int stage);
+
+/* replaces: TComPrediction::motionCompensation -> xPredInterLumaBlk/xPredInterChromaBlk
+ * (TLibCommon/TComPrediction.cpp:419-528, :639-720, :1235-1347).  Predictions are written into the
+ * context's prediction picture at the PU position; out_* (may be NULL) additionally receive them
+ * packed job after job (w*h luma, (w/2)*(h/2) per chroma plane). */
+int hop_pred_inter(hop_ctx* ctx, int n, const hop_pred_job* jobs, int16_t* out_y, int16_t* out_cb, int16_t* out_cr);
+int hop_pred_inter_device(hop_ctx* ctx, int n, const hop_pred_job* d_jobs);
+int hop_pred_download(hop_ctx* ctx, int comp, int16_t* dst);   /* whole prediction plane, pitch pic_w (/2) */
+
+/* replaces: TComRdCost::getDistPart / DistParam::DistFunc between the original and the prediction picture
+ * (TLibCommon/TComRdCost.cpp:477-503). out[i] = distortion of job i. */
+int hop_distortion(hop_ctx* ctx, int n, const hop_dist_job* jobs, uint32_t* out);
+
+/* library/build identification: "hophip <version> gfx950" */
+const char* hop_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOPHIP_H */

@@ -1,0 +1,240 @@
+"""GPU parity tests proper: libhophip.so (through its C ABI) against the CPU oracle and against the
+golden vectors produced by the reference's own code.  Bit-exact everywhere: the path is integer except
+the GT warp, whose double arithmetic is reproduced in the reference's operation order (the final Pel
+and every search cost must be identical)."""
+import ctypes
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from goldutil import crc, load, me_chain_scenarios
+from hoputil import ROOT, Planes, lambda_for_qp, lenslet, oracle, p16
+
+pytestmark = pytest.mark.gpu
+
+
+def _hophip():
+    spec = importlib.util.spec_from_file_location("hophip", os.path.join(ROOT, "hevc-hop_amd", "hophip.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def hp():
+    return _hophip()
+
+
+def _jobs_from_golden(hp, jobs, lc):
+    a = np.zeros(len(jobs), hp.PU_JOB_DTYPE)
+    for i, job in enumerate(jobs):
+        (_, puX, puY, w, h, cuX, cuY, cuS, offx, offy, fr, fc, px, py, l, r, t, b, ox, oy, nA) = [int(v) for v in job[:21]]
+        a[i]["pu_x"], a[i]["pu_y"], a[i]["w"], a[i]["h"] = puX, puY, w, h
+        a[i]["rng_left"], a[i]["rng_right"], a[i]["rng_top"], a[i]["rng_bottom"] = l, r, t, b
+        a[i]["off_x"], a[i]["off_y"], a[i]["pred_x"], a[i]["pred_y"] = ox, oy, px, py
+        a[i]["lambda_cost"], a[i]["n_amvp"] = lc, nA
+        a[i]["amvp"] = [int(v) for v in job[21:25]]
+        a[i]["flags"] = hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME
+    return a
+
+
+def _res_row(r):
+    """hop_pu_result -> the 27-entry layout of oracle/ref_harness.cpp:ref_me_pu"""
+    return ([int(r["mv_int"][0]), int(r["mv_int"][1]), int(r["sad"]), int(r["not_valid"])] + [int(v) for v in r["half"]] +
+            [int(v) for v in r["qter"]] + [int(r["frac_cost"]), int(r["gt_flag"])] + [int(v) for v in r["gt"]] +
+            [int(r["cost"])] + [int(v) for v in r["mv_final"]] + [int(v) for v in r["half_final"]] + [int(v) for v in r["qter_final"]] +
+            [int(r["mv_int"][0]), int(r["mv_int"][1])])
+
+
+def test_library_identity(hp):
+    L = hp.load()
+    assert b"gfx950" in L.hop_version()
+
+
+def test_ssref_commit_golden(hp):
+    g = load("ssref_commit.npz")
+    W, H = int(g["W"]), int(g["H"])
+    Y, Cb, Cr = (g[k].astype(np.int16) for k in ("Y", "Cb", "Cr"))
+    ctx = hp.Context(W, H)
+    ctx.ssref_reset()
+    assert (ctx.ssref_download(0) == -1).all() and (ctx.ssref_download(2) == -1).all()
+    for (x, y, s), want in zip(g["order"], g["crcs"]):
+        x, y, s = int(x), int(y), int(s)
+        ctx.ssref_commit([(x, y, s)], Y[y:y + s, x:x + s], Cb[y // 2:(y + s) // 2, x // 2:(x + s) // 2], Cr[y // 2:(y + s) // 2, x // 2:(x + s) // 2])
+        got = [crc(ctx.ssref_download(c)) for c in range(3)]
+        assert got == [int(v) for v in want], (x, y, s)
+    ctx.close()
+
+
+def test_ssref_commit_batch_vs_oracle(hp):
+    """several CUs per call, incl. all four picture corners, against the oracle's whole-picture re-extension"""
+    O = oracle()
+    W, H = 264, 200
+    Y, Cb, Cr = lenslet(W, H, 15, 4)
+    pl = Planes(W, H)
+    ctx = hp.Context(W, H)
+    batches = [[(0, 0, 64), (256, 0, 8), (0, 192, 8), (256, 192, 8)], [(64, 0, 64), (128, 64, 32), (160, 64, 16), (176, 80, 8)],
+               [(192, 128, 64), (0, 64, 64), (256, 8, 8)]]
+    for batch in batches:
+        ys, cbs, crs = [], [], []
+        for (x, y, s) in batch:
+            ry = np.ascontiguousarray(Y[y:y + s, x:x + s]); rb = np.ascontiguousarray(Cb[y // 2:(y + s) // 2, x // 2:(x + s) // 2]); rr = np.ascontiguousarray(Cr[y // 2:(y + s) // 2, x // 2:(x + s) // 2])
+            O.hop_o_ssref_commit_cu(pl.ptr00(0), pl.ptr00(1), pl.ptr00(2), W, H, x, y, s, p16(ry), p16(rb), p16(rr))
+            ys.append(ry.ravel()); cbs.append(rb.ravel()); crs.append(rr.ravel())
+        ctx.ssref_commit(batch, np.concatenate(ys), np.concatenate(cbs), np.concatenate(crs))
+        assert np.array_equal(ctx.ssref_download(0), pl.bufY)
+        assert np.array_equal(ctx.ssref_download(1), pl.bufCb)
+        assert np.array_equal(ctx.ssref_download(2), pl.bufCr)
+    ctx.close()
+
+
+@pytest.mark.parametrize("stage", [1, 2, 3])
+def test_me_chain_golden(hp, stage):
+    """SS search / + fractional / + GT against the reference-generated golden vectors (84 PUs, 24 shapes)."""
+    n = 0
+    for pl, Y, jobs, outs, lc in me_chain_scenarios():
+        g = load("me_chain.npz")
+        ctx = hp.Context(pl.W, pl.H)
+        ctx.upload_orig(Y, g["Cb"].astype(np.int16), g["Cr"].astype(np.int16))
+        for c, b in enumerate((pl.bufY, pl.bufCb, pl.bufCr)):
+            ctx.ssref_upload(c, b)
+        res = ctx.me_search(_jobs_from_golden(hp, jobs, lc), stage)
+        for job, r, want in zip(jobs, res, outs):
+            got, want = _res_row(r), [int(v) for v in want]
+            if want[3]:
+                assert got[2:4] == want[2:4], (job, got, want)
+                continue
+            assert got[0:4] == want[0:4], (job, got, want)
+            if stage >= 2:
+                assert got[4:9] == want[4:9], (job, got, want)
+            if stage >= 3:
+                assert got[9:25] == want[9:25], (job, got, want)
+            n += 1
+        ctx.close()
+    assert n == 80
+
+
+def test_pred_inter_golden(hp):
+    g = load("pred_inter.npz")
+    Y, Cb, Cr = (g[k].astype(np.int16) for k in ("Y", "Cb", "Cr"))
+    H, W = Y.shape
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, Cb, Cr)
+    for c, k in enumerate(("bufY", "bufCb", "bufCr")):
+        ctx.ssref_upload(c, g[k])
+    jobs = []
+    for job in g["jobs"]:
+        j = hp.PredJob(*[int(v) for v in job[:7]])
+        for k in range(8):
+            j.gt[k] = int(job[7 + k])
+        jobs.append(j)
+    oy, ocb, ocr = ctx.pred_inter(jobs)
+    off = oy_off = oc_off = 0
+    for job, n in zip(g["jobs"], g["out_len"]):
+        w, h = int(job[2]), int(job[3])
+        want = g["out_flat"][off:off + n]
+        got = np.concatenate([oy[oy_off:oy_off + w * h], ocb[oc_off:oc_off + w * h // 4], ocr[oc_off:oc_off + w * h // 4]])
+        assert np.array_equal(got, want), [int(v) for v in job]
+        off += int(n); oy_off += w * h; oc_off += w * h // 4
+    ctx.close()
+
+
+def test_me_random_vs_oracle_10bit_and_sad(hp):
+    """seeded random PUs against the oracle: 10-bit samples, HadamardME off (SAD costs), FEN off, empty and
+    first-row/first-column windows, sentinel holes inside the window"""
+    O = oracle()
+    for bd, flags in ((10, hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME), (8, 0), (8, hp.HOP_FLAG_HADME), (10, hp.HOP_FLAG_FEN)):
+        W, H = 256, 192
+        Y, Cb, Cr = lenslet(W, H, 14, 31 + bd, bitdepth=bd)
+        rng = np.random.default_rng(100 + bd + flags)
+        pl = Planes(W, H)
+        pl.y00()[:128, :W] = Y[:128]
+        pl.y00()[128:192, :128] = Y[128:192, :128]
+        pl.y00()[40:52, 60:90] = -1                      # a hole of sentinels inside the coded area
+        by = np.ascontiguousarray(pl.y00()[0:8, 0:8]); z = np.zeros((4, 4), np.int16) - 1
+        O.hop_o_ssref_commit_cu(pl.ptr00(0), pl.ptr00(1), pl.ptr00(2), W, H, 0, 0, 8, p16(by), p16(z), p16(z))
+        lam, lc = lambda_for_qp(int(rng.integers(22, 38)))
+        ctx = hp.Context(W, H, bit_depth=bd)
+        ctx.upload_orig(Y, Cb, Cr)
+        ctx.ssref_upload(0, pl.bufY)
+        shapes = [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (16, 32), (8, 4), (4, 8), (12, 16), (32, 24), (48, 64), (16, 4)]
+        jobs = np.zeros(len(shapes) * 2, hp.PU_JOB_DTYPE)
+        for i in range(len(jobs)):
+            w, h = shapes[i % len(shapes)]
+            cuS = 64 if max(w, h) > 32 else 32 if max(w, h) > 16 else 16 if max(w, h) > 8 else 8
+            cuX, cuY = (128, 128) if i < len(shapes) else (int(rng.integers(0, 2)) * 64, 128)
+            puX, puY = cuX + (cuS - w) * (i & 1), cuY + (cuS - h) * (i & 1)
+            pred = (int(rng.integers(-50, 50)), int(rng.integers(-200, -30)))
+            o6 = (ctypes.c_int * 6)()
+            O.hop_o_set_search_range(W, H, cuX, cuY, cuS, 2 * 4 + cuX // 64, 4, pred[0], pred[1], 128, puX - cuX, puY - cuY, 0, int(cuX == 0), o6)
+            j = jobs[i]
+            j["pu_x"], j["pu_y"], j["w"], j["h"] = puX, puY, w, h
+            j["rng_left"], j["rng_right"], j["rng_top"], j["rng_bottom"], j["off_x"], j["off_y"] = list(o6)
+            j["pred_x"], j["pred_y"], j["lambda_cost"], j["n_amvp"] = pred[0], pred[1], lc, 2
+            j["amvp"] = [pred[0], pred[1], int(rng.integers(-40, 40)), int(rng.integers(-300, -60))]
+            j["flags"] = flags
+        res = ctx.me_search(jobs, 3)
+        for j, r in zip(jobs, res):
+            out = (ctypes.c_int64 * 32)()
+            org = np.ascontiguousarray(Y[j["pu_y"]:j["pu_y"] + j["h"], j["pu_x"]:j["pu_x"] + j["w"]])
+            O.hop_o_me_pu(p16(org), int(j["w"]), pl.ptr00(0), pl.sy, int(j["pu_x"]), int(j["pu_y"]), int(j["w"]), int(j["h"]),
+                          int(j["rng_left"]), int(j["rng_right"]), int(j["rng_top"]), int(j["rng_bottom"]), int(j["off_x"]), int(j["off_y"]),
+                          int(j["pred_x"]), int(j["pred_y"]), 2, (ctypes.c_int * 4)(*[int(v) for v in j["amvp"]]), lc,
+                          1 if flags & hp.HOP_FLAG_FEN else 0, 1 if flags & hp.HOP_FLAG_HADME else 0, bd, 3, out)
+            want, got = list(out)[:27], _res_row(r)
+            if want[3]:
+                assert got[2:4] == want[2:4]
+            else:
+                assert got[:25] == want[:25], (bd, flags, [int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
+        ctx.close()
+
+
+def test_distortion_vs_oracle(hp):
+    O = oracle()
+    W, H = 128, 128
+    Y, Cb, Cr = lenslet(W, H, 15, 77)
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, Cb, Cr)
+    # prediction picture := plain copy of a shifted reference through hop_pred_inter
+    pl = Planes(W, H)
+    pl.y00()[:H, :W] = np.roll(Y, 3, 1); pl.bufCb[40:40 + H // 2, 40:40 + W // 2] = np.roll(Cb, 1, 0); pl.bufCr[40:40 + H // 2, 40:40 + W // 2] = Cr[::-1]
+    for c, b in enumerate((pl.bufY, pl.bufCb, pl.bufCr)):
+        ctx.ssref_upload(c, b)
+    jobs = [hp.PredJob(x, y, 64, 64, 0, 0, 0) for y in (0, 64) for x in (0, 64)]
+    ctx.pred_inter(jobs)
+    P = [ctx.pred_download(c) for c in range(3)]
+    assert np.array_equal(P[0], pl.y00()[:H, :W])
+    dj, want = [], []
+    for (x, y, w, h) in ((0, 0, 64, 64), (64, 32, 32, 16), (8, 8, 8, 8), (16, 4, 16, 4), (32, 64, 12, 16), (4, 4, 8, 4), (0, 64, 64, 48)):
+        for comp in range(3):
+            o_, p_ = (Y, Cb, Cr)[comp], P[comp]
+            ww, hh, xx, yy = (w, h, x, y) if comp == 0 else (w // 2, h // 2, x // 2, y // 2)
+            a = np.ascontiguousarray(o_[yy:yy + hh, xx:xx + ww]); b = np.ascontiguousarray(p_[yy:yy + hh, xx:xx + ww])
+            for kind, fn in ((hp.HOP_DIST_SAD, lambda: O.hop_o_sad(p16(a), ww, p16(b), ww, ww, hh, 8, 0)),
+                             (hp.HOP_DIST_SSE, lambda: O.hop_o_sse(p16(a), ww, p16(b), ww, ww, hh, 8)),
+                             (hp.HOP_DIST_HADS, lambda: O.hop_o_hads(p16(a), ww, p16(b), ww, ww, hh, 8))):
+                if kind == hp.HOP_DIST_HADS and (ww % 4 or hh % 4):
+                    continue
+                if (ww % 4 or hh % 4):
+                    continue
+                dj.append(hp.DistJob(x, y, w, h, comp, kind)); want.append(fn())
+    got = ctx.distortion(dj)
+    assert [int(v) for v in got] == [int(v) for v in want]
+    ctx.close()
+
+
+def test_errors_are_reported(hp):
+    with pytest.raises(hp.HopError):
+        hp.Context(100, 64)                       # not a multiple of 8
+    ctx = hp.Context(64, 64)
+    jobs = np.zeros(1, hp.PU_JOB_DTYPE)
+    jobs[0]["w"], jobs[0]["h"] = 64, 64
+    with pytest.raises(hp.HopError):              # search before the original was uploaded
+        ctx.me_search(jobs, 1)
+    ctx.upload_orig(np.zeros((64, 64), np.int16), np.zeros((32, 32), np.int16), np.zeros((32, 32), np.int16))
+    jobs[0]["w"] = 20                             # not a legal PU width
+    with pytest.raises(hp.HopError):
+        ctx.me_search(jobs, 1)
+    ctx.close()

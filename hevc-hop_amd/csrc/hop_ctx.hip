@@ -72,13 +72,15 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_y, ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_cb, nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_cr, nc * 2);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_buf[0], sy * 2);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_buf[1], sc * 2);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_buf[2], sc * 2);
+  const size_t gy = (size_t)HOP_GUARD_ROWS * c->stride_y, gc = (size_t)HOP_GUARD_ROWS * c->stride_c;
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_alloc[0], (sy + 2 * gy) * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_alloc[1], (sc + 2 * gc) * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ss_alloc[2], (sc + 2 * gc) * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->pred[0], ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->pred[1], nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->pred[2], nc * 2);
   if (e != hipSuccess) { hop_set_err(nullptr, HOP_ERR_DEVICE, "allocation failed: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
+  c->ss_buf[0] = c->ss_alloc[0] + gy; c->ss_buf[1] = c->ss_alloc[1] + gc; c->ss_buf[2] = c->ss_alloc[2] + gc;
   c->ss00[0] = c->ss_buf[0] + (size_t)HOP_MARGIN_Y * c->stride_y + HOP_MARGIN_Y;
   c->ss00[1] = c->ss_buf[1] + (size_t)HOP_MARGIN_C * c->stride_c + HOP_MARGIN_C;
   c->ss00[2] = c->ss_buf[2] + (size_t)HOP_MARGIN_C * c->stride_c + HOP_MARGIN_C;
@@ -92,7 +94,7 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
 void hop_ctx_destroy(hop_ctx* c) {
   if (!c) return;
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
-  void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_buf[0], c->ss_buf[1], c->ss_buf[2], c->pred[0], c->pred[1], c->pred[2], c->scratch, c->stage };
+  void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2], c->scratch, c->stage };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   free(c);
@@ -263,8 +265,14 @@ static int check_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
     if (j.rng_right >= j.rng_left && j.rng_bottom >= j.rng_top) {
       if (j.rng_right - j.rng_left > 256 || j.rng_bottom - j.rng_top > 256)
         return hop_set_err(c, HOP_ERR_ARG, "PU job %d: search window larger than 257x257 (SearchRange > 128)", i);
-      if (j.pu_y + j.rng_top - j.h / 2 - 4 < -78 || j.pu_y + j.rng_bottom + j.h + j.h / 2 + 8 > c->pic_h + 78 ||
-          j.pu_x + j.rng_left - j.w / 2 - 4 < -(c->stride_y - 8) || j.pu_x + j.rng_right + 2 * j.w + 8 > c->stride_y + c->pic_w - 8)
+      const int lim = HOP_MARGIN_Y + HOP_GUARD_ROWS - 4;
+      bool bad = j.pu_y + j.rng_top - j.h / 2 - 4 < -lim || j.pu_y + j.rng_bottom + j.h + j.h / 2 + 8 > c->pic_h + lim ||
+                 j.pu_x + j.rng_left - j.w / 2 - 4 < -(c->stride_y - 8) || j.pu_x + j.rng_right + 2 * j.w + 8 > c->stride_y + c->pic_w - 8;
+      for (int k = 0; k < j.n_amvp; k++) {   // AMVP start vectors of the GT search (TEncSearch.cpp:5144-5150)
+        const int sx = (int)(int16_t)j.amvp[2 * k] >> 2, sy = (int)(int16_t)j.amvp[2 * k + 1] >> 2;
+        bad = bad || j.pu_y + sy - j.h / 2 < -lim || j.pu_y + sy + j.h + j.h / 2 > c->pic_h + lim || sx < -(c->stride_y - 160) || sx > c->stride_y - 160;
+      }
+      if (bad)
         return hop_set_err(c, HOP_ERR_ARG, "PU job %d: search range leaves the padded reference", i);
     }
   }
@@ -328,7 +336,8 @@ int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, 
       return hop_set_err(c, HOP_ERR_ARG, "pred job %d: illegal PU rectangle", i);
     // reach of the doubled patch + 8-tap filter must stay in the margin
     int ix = j.pu_x + (j.mv_x >> 2), iy = j.pu_y + (j.mv_y >> 2);
-    if (ix - j.w / 2 - 4 < -HOP_MARGIN_Y || iy - j.h / 2 - 4 < -HOP_MARGIN_Y || ix + j.w + j.w / 2 + 4 >= c->pic_w + HOP_MARGIN_Y || iy + j.h + j.h / 2 + 4 >= c->pic_h + HOP_MARGIN_Y)
+    const int lim = HOP_MARGIN_Y + HOP_GUARD_ROWS - 4;      // rows may use the guard band, columns wrap linearly like the reference
+    if (iy - j.h / 2 - 4 < -lim || iy + j.h + j.h / 2 + 4 >= c->pic_h + lim || ix - j.w / 2 - 4 < -(c->stride_y - 8) || ix + 2 * j.w + 8 > c->stride_y + c->pic_w - 8)
       return hop_set_err(c, HOP_ERR_ARG, "pred job %d: motion vector leaves the padded reference", i);
     offs[i] = (int64_t)tot; tot += (size_t)j.w * j.h;
   }

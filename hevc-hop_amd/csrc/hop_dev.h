@@ -8,6 +8,10 @@
 #define HOP_MARGIN_C 40
 #define HOP_NOT_VALID (-1)   // TLibCommon/CommonDef.h:126
 #define HOP_WAVE 64
+// The reference's GT patch and 8-tap reach can leave its own buffer by up to H/2+4 rows when the start vector
+// points into the top margin (an out-of-bounds read there).  Guard rows keep our reads inside one allocation;
+// they hold the sentinel and are not part of the reference layout.
+#define HOP_GUARD_ROWS 64
 
 struct hop_ctx {
   int pic_w, pic_h, bd_y, bd_c, device;
@@ -15,7 +19,8 @@ struct hop_ctx {
   hipStream_t stream;
   // device pictures
   int16_t *org_y, *org_cb, *org_cr;  // original, pitch pic_w / pic_w/2, no margins
-  int16_t *ss_buf[3];                // padded SS-ref buffers
+  int16_t *ss_alloc[3];              // allocations: HOP_GUARD_ROWS sentinel rows + padded plane + HOP_GUARD_ROWS
+  int16_t *ss_buf[3];                // padded SS-ref buffers (the reference's TComPicYuv layout) inside ss_alloc
   int16_t *ss00[3];                  // sample (0,0) inside them
   int16_t *pred[3];                  // prediction picture, pitch pic_w / pic_w/2
   // scratch that grows on demand (never allocated inside a *_device call once sized)

@@ -30,6 +30,13 @@ __device__ static inline uint32_t sad_u16x2(uint32_t a, uint32_t b, uint32_t acc
   return __builtin_amdgcn_sad_u16(a, b, acc);    // |a.lo-b.lo| + |a.hi-b.hi| + acc
 }
 
+typedef unsigned short hop_us2 __attribute__((ext_vector_type(2)));
+__device__ static inline uint32_t bias_pk(uint32_t v) {   // two independent 16-bit +1 (0xFFFF wraps to 0 inside its half)
+  hop_us2 a = __builtin_bit_cast(hop_us2, v);
+  a += hop_us2{1, 1};
+  return __builtin_bit_cast(uint32_t, a);
+}
+
 template <int STEP>
 __device__ static inline void ss_strip(const uint16_t* __restrict__ tile, const int16_t* __restrict__ org, int org_stride,
                                        int W, int H, int wave, int lane, uint32_t (&acc_e)[SS_NP], uint32_t (&acc_o)[SS_NP]) {
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void k_ss_search(const hop_pu_job* __restrict_
   for (int i = threadIdx.x; i < rows * cw; i += 256) {
     int r = i / cw, cdw = i - r * cw;
     uint32_t v = *(const uint32_t*)(src + (ptrdiff_t)r * pic.stride_y + 2 * cdw);
-    *(uint32_t*)(tile + (size_t)r * SS_LS + 2 * cdw) = v + 0x00010001u;   // -1 -> 0, no carry between halves
+    *(uint32_t*)(tile + (size_t)r * SS_LS + 2 * cdw) = bias_pk(v);        // per-half +1 (v_pk_add_u16): -1 -> 0 without a carry into the neighbour
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

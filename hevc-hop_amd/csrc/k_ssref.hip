@@ -21,11 +21,12 @@ __global__ void k_fill_sentinel(int16_t* __restrict__ p, size_t n) {
 }
 
 int hop_launch_ssref_reset(hop_ctx* c) {
-  size_t ny = (size_t)c->stride_y * (c->pic_h + 2 * HOP_MARGIN_Y);
-  size_t nc = (size_t)c->stride_c * ((c->pic_h >> 1) + 2 * HOP_MARGIN_C);
-  hipLaunchKernelGGL(k_fill_sentinel, dim3(2048), dim3(256), 0, c->stream, c->ss_buf[0], ny);
-  hipLaunchKernelGGL(k_fill_sentinel, dim3(1024), dim3(256), 0, c->stream, c->ss_buf[1], nc);
-  hipLaunchKernelGGL(k_fill_sentinel, dim3(1024), dim3(256), 0, c->stream, c->ss_buf[2], nc);
+  // the guard rows around each plane are (re)filled too
+  size_t ny = (size_t)c->stride_y * (c->pic_h + 2 * HOP_MARGIN_Y + 2 * HOP_GUARD_ROWS);
+  size_t nc = (size_t)c->stride_c * ((c->pic_h >> 1) + 2 * HOP_MARGIN_C + 2 * HOP_GUARD_ROWS);
+  hipLaunchKernelGGL(k_fill_sentinel, dim3(2048), dim3(256), 0, c->stream, c->ss_alloc[0], ny);
+  hipLaunchKernelGGL(k_fill_sentinel, dim3(1024), dim3(256), 0, c->stream, c->ss_alloc[1], nc);
+  hipLaunchKernelGGL(k_fill_sentinel, dim3(1024), dim3(256), 0, c->stream, c->ss_alloc[2], nc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "ssref reset launch: %s", hipGetErrorString(e));
   return HOP_OK;

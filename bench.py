@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""bench.py -- CTUs/sec of the HEVC-HOP hot path on MI355X (one JSON line, see the driver contract).
+
+Workload (config.workload): one synthetic 7728x5368 8-bit lenslet frame (pitch 15), QP32 lambda, HOP on.
+One "step" = one pass of the hot path over every CTU of the frame (10 164 CTUs):
+  * the ME chain of TEncSearch::xMotionEstimation -- SS integer full search (+-128, FEN), half/quarter-pel
+    refinement (HAD), GT/HOP 4-corner diamond search (HAD) -- for the full RD-tree PU set of every CTU
+    (CU 64..8 x {2Nx2N, Nx2N, 2NxN} = 425 PUs per interior CTU, TEncCu::xCompressCU's symmetric test order),
+  * the final GT predictor (luma + chroma) of every 2Nx2N PU, depth by depth,
+  * the SS-reference commit (copy + border halo) of every CU of the frame.
+The SS reference is a resident, fully reconstructed picture ("frozen reference"): all CTUs are independent, so
+this measures the device-side hot path; the reference's host spine (CABAC-driven RD decisions, SURVEY 8(a) row
+a0) is not part of it and is documented as not built yet in DESIGN.md.  Inputs (pictures, PU job lists) are
+resident in HBM before the timed region starts.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): the frame's CTU rows are dealt round-robin to the
+ranks (the frozen SS reference is replicated), no data-path collective; value = 10 164 CTUs x steps / max-rank
+time -> "scaling": "strong".
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FRAME_W, FRAME_H, PITCH, QP = 7728, 5368, 15, 32
+ALGO_BYTES_PER_CTU = 87040          # compulsory HBM traffic per CTU
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (half the 157.3 TF FP32 vector rate of MI355X_MICROARCH.md)
+INT_VALU_PEAK_TOPS = 78.6           # wave64 VALU issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one v_sad_u16 = 2 abs-diff-acc)
+WARP_FLOP_PER_SAMPLE = 24           # FP64 mul/add/sub of one warped sample (TComPrediction.cpp:925-968), conversions not counted
+
+
+def _hophip():
+    spec = importlib.util.spec_from_file_location("hophip", os.path.join(ROOT, "hevc-hop_amd", "hophip.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def lenslet_torch(W, H, pitch, seed, dev):
+    """GPU version of tests/hoputil.py:lenslet (same structure; used only to make the big frame quickly)."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy = torch.arange(H, device=dev, dtype=torch.float32).view(H, 1)
+    xx = torch.arange(W, device=dev, dtype=torch.float32).view(1, W)
+    mx, my = torch.floor(xx / pitch), torch.floor(yy / pitch)
+    ux, uy = xx - mx * pitch - pitch / 2.0, yy - my * pitch - pitch / 2.0
+    sx, sy = mx * pitch * 0.12 + ux * 1.05, my * pitch * 0.12 + uy * 1.05
+
+    def tex(ax, ay):
+        t = None
+        for _ in range(4):
+            f = (torch.rand(2, generator=g) * 0.33 + 0.02).tolist()
+            ph = (torch.rand(2, generator=g) * 6.283).tolist()
+            a = float(torch.rand(1, generator=g) * 0.6 + 0.4)
+            term = a * torch.sin(ax * f[0] + ph[0]) * torch.cos(ay * f[1] + ph[1])
+            t = term if t is None else t + term
+        return t / 4.0
+    vign = torch.exp(-(ux ** 2 + uy ** 2) / (2 * (0.55 * pitch) ** 2))
+    noise = torch.randn(H, W, generator=g).to(dev) * 2.0
+    Y = torch.clamp(torch.round((0.5 + 0.45 * tex(sx, sy)) * vign * 255 + noise), 0, 255).to(torch.int16)
+    cs = (slice(None, None, 2), slice(None, None, 2))
+    sxc, syc, vc = sx.expand(H, W)[cs], sy.expand(H, W)[cs], vign[cs]
+    Cb = torch.clamp(torch.round(128 + 0.25 * 255 * tex(sxc, syc) * vc), 0, 255).to(torch.int16)
+    Cr = torch.clamp(torch.round(128 + 0.25 * 255 * tex(sxc, syc) * vc), 0, 255).to(torch.int16)
+    return Y.contiguous(), Cb.contiguous(), Cr.contiguous()
+
+
+def cu_rects(W, H):
+    """legal CU rectangles covering the picture (quadtree, largest first) -- what xCopyYuv2SSRef commits"""
+    out = []
+
+    def rec(x, y, s):
+        if x >= W or y >= H:
+            return
+        if x + s <= W and y + s <= H:
+            out.append((x, y, s, 0))
+        else:
+            h = s // 2
+            for q in range(4):
+                rec(x + (q & 1) * h, y + (q >> 1) * h, h)
+    for cy in range(0, H, 64):
+        for cx in range(0, W, 64):
+            rec(cx, cy, 64)
+    return np.array(out, np.int32)
+
+
+def gt_iters(w, h):
+    m, it = min(w, h), 0
+    while m > 1 and it < 6:
+        it += 1
+        m //= 2
+    return it
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=FRAME_W)     # smaller frames only for rehearsal; the JSON names them
+    ap.add_argument("--height", type=int, default=FRAME_H)
+    ap.add_argument("--cpu-ctus", type=int, default=10, help="CTUs of the bounded cpu_baseline sample")
+    args = ap.parse_args()
+    import torch
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libhophip has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    hp = _hophip()
+    from hoputil import lambda_for_qp
+    W, H = args.width, args.height
+    wctu, hctu = (W + 63) // 64, (H + 63) // 64
+    n_ctu = wctu * hctu
+    lam, lc = lambda_for_qp(QP)
+
+    # ---- pictures (resident before timing) ----
+    Y, Cb, Cr = lenslet_torch(W, H, PITCH, 2, dev)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    recY = torch.clamp(Y + torch.randint(-2, 3, (H, W), generator=gen).to(dev).to(torch.int16), 0, 255).contiguous()
+    ctx = hp.Context(W, H, device=local)
+    L = ctx.L
+    ctx.upload_orig(Y.cpu().numpy(), Cb.cpu().numpy(), Cr.cpu().numpy())
+    rects = cu_rects(W, H)
+    d_rects = torch.from_numpy(rects).to(dev)
+    chk = ctx._chk
+    chk(L.hop_ssref_commit_cus_device(ctx.h, len(rects), d_rects.data_ptr(), recY.data_ptr(), Cb.data_ptr(), Cr.data_ptr()), "commit")
+    ctx.sync()
+
+    # ---- PU job lists of this rank's CTU rows ----
+    my_rows = [r for r in range(hctu) if r % world == rank]
+    pred = (ctypes.c_int * 2)(0, -4 * PITCH)                     # one micro-image up
+    amvp = (ctypes.c_int * 4)(0, -4 * PITCH, -4 * PITCH, 0)      # + one micro-image left
+    flags = hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME
+    L.hop_enumerate_ctu_jobs.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    cap = 425 * len(my_rows) * wctu
+    jobs = np.zeros(cap, hp.PU_JOB_DTYPE)
+    tags = np.zeros(cap, np.int32)
+    n = 0
+    ctu_of_job = np.zeros(cap, np.int32)
+    for r in my_rows:
+        for c in range(wctu):
+            k = L.hop_enumerate_ctu_jobs(W, H, r * wctu + c, 128, pred, 2, amvp, lc, flags, 0,
+                                         jobs.ctypes.data + n * jobs.itemsize, tags.ctypes.data + n * 4, cap - n)
+            assert 0 <= k <= cap - n
+            ctu_of_job[n:n + k] = r * wctu + c
+            n += k
+    jobs, tags, ctu_of_job = jobs[:n], tags[:n], ctu_of_job[:n]
+    my_ctus = len(my_rows) * wctu
+    # 2Nx2N PUs (w == h == CU size) grouped by depth: the predictor runs depth by depth (no overlap inside a launch)
+    is2n = (jobs["w"] == jobs["h"]) & (jobs["w"] == (64 >> (tags >> 16)))
+    depth_idx = [np.nonzero(is2n & ((tags >> 16) == d))[0].astype(np.int32) for d in range(4)]
+    d_jobs = torch.from_numpy(jobs.view(np.uint8)).to(dev)
+    d_res = torch.zeros(n * hp.PU_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_idx = [torch.from_numpy(ix).to(dev) for ix in depth_idx]
+    d_pj = [torch.zeros(max(1, len(ix)) * ctypes.sizeof(hp.PredJob), dtype=torch.uint8, device=dev) for ix in depth_idx]
+    my_rects = rects[np.isin((rects[:, 1] // 64), my_rows)]
+    d_myrects = torch.from_numpy(np.ascontiguousarray(my_rects)).to(dev)
+    CH = 1 << 17                                                  # PUs per launch
+    jsz, rsz = hp.PU_JOB_DTYPE.itemsize, hp.PU_RESULT_DTYPE.itemsize
+
+    def step():
+        for o in range(0, n, CH):
+            m = min(CH, n - o)
+            chk(L.hop_me_search_device(ctx.h, m, d_jobs.data_ptr() + o * jsz, d_res.data_ptr() + o * rsz, hp.HOP_STAGE_GT), "me_search")
+        for d in range(4):
+            k = len(depth_idx[d])
+            if k:
+                chk(L.hop_pred_jobs_from_results_device(ctx.h, k, d_idx[d].data_ptr(), d_jobs.data_ptr(), d_res.data_ptr(), d_pj[d].data_ptr()), "pred_jobs")
+                chk(L.hop_pred_inter_device(ctx.h, k, d_pj[d].data_ptr()), "pred")
+        chk(L.hop_ssref_commit_cus_device(ctx.h, len(my_rects), d_myrects.data_ptr(), recY.data_ptr(), Cb.data_ptr(), Cr.data_ptr()), "commit")
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.hop_profile_reset.argtypes = [ctypes.c_void_p]
+    L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    barrier()
+    chk(L.hop_profile_reset(ctx.h), "profile_reset")
+    chk(L.hop_profile_enable(ctx.h, 1), "profile_enable")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = {}
+    names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit"}
+    for kid, name in names.items():
+        la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
+        chk(L.hop_profile_read(ctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
+        prof[name] = {"launches": la.value, "total_ms": ms.value, "units": un.value}
+    chk(L.hop_profile_enable(ctx.h, 0), "profile_disable")
+    # a result checksum so that a run can be compared with another build
+    res_host = np.frombuffer(d_res.cpu().numpy().tobytes(), hp.PU_RESULT_DTYPE)
+
+    if rank == 0:
+        value = n_ctu * args.steps / dt
+        dom = max(prof, key=lambda k: prof[k]["total_ms"])
+        p = prof[dom]
+        avg_ms = p["total_ms"] / max(1, p["launches"])
+        ctus_per_launch = my_ctus * args.steps / max(1, p["launches"])
+        achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9
+        # honest VALU-side figures (neither HBM nor MFMA binds this path)
+        st = 1 + 2
+        samples = float(np.sum(st * np.array([gt_iters(int(w), int(h)) for w, h in zip(jobs["w"], jobs["h"])]) * 56.0 * jobs["w"] * jobs["h"]))
+        gt_tflops = samples * WARP_FLOP_PER_SAMPLE * args.steps / (prof["k_gt_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_gt_search"]["total_ms"] else 0.0
+        win = (jobs["rng_right"] - jobs["rng_left"] + 1).clip(0) * (jobs["rng_bottom"] - jobs["rng_top"] + 1).clip(0)
+        sad_ops = float(np.sum(win.astype(np.float64) * jobs["w"] * jobs["h"] / np.where(jobs["h"] > 8, 2, 1) / 2.0))   # v_sad_u16 lane-ops
+        ss_tops = sad_ops * args.steps / (prof["k_ss_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_ss_search"]["total_ms"] else 0.0
+        out = {
+            "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (hot-path kernels, frozen SS reference)",
+            "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "i16+f64", "data": "synthetic",
+            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + SS-ref commit, "
+                                   "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD/CABAC" % (W, H, PITCH, QP, n if world == 1 else -1),
+                       "ctus": n_ctu, "pus_rank0": int(n), "parallelism": "ctu-rows-rr%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
+                         "note": "VALU-bound path: see valu_fp64 / valu_int for the binding rooflines"},
+            "valu_fp64": {"kernel": "k_gt_search", "achieved": gt_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gt_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                          "flop_per_warped_sample": WARP_FLOP_PER_SAMPLE},
+            "valu_int": {"kernel": "k_ss_search", "achieved": ss_tops, "peak": INT_VALU_PEAK_TOPS, "unit": "T v_sad_u16 lane-op/s", "frac": ss_tops / INT_VALU_PEAK_TOPS},
+            "kernels": prof,
+            "result_crc": int(np.bitwise_xor.reduce(res_host["cost"].astype(np.uint64) * np.arange(1, len(res_host) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)),
+        }
+        if world == 1:
+            out["cpu_baseline"] = cpu_baseline(hp, ctx, jobs, ctu_of_job, is2n, res_host, Y, W, H, wctu, lc, args.cpu_ctus)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(hp, ctx, jobs, ctu_of_job, is2n, res_gpu, Y, W, H, wctu, lc, n_ctus):
+    """The oracle (CPU port, 1 thread) on a bounded sample of the same workload: the PU jobs of `n_ctus`
+    interior CTUs (full +-128 windows) through hop_o_me_pu + hop_o_pred_inter.  Also cross-checks the GPU results."""
+    from hoputil import oracle, p16, I16P
+    O = oracle()
+    bufs = [np.ascontiguousarray(ctx.ssref_download(c)) for c in range(3)]
+    sy, sc = bufs[0].shape[1], bufs[1].shape[1]
+    y00 = ctypes.cast(bufs[0].ctypes.data + (80 * sy + 80) * 2, I16P)
+    cb00 = ctypes.cast(bufs[1].ctypes.data + (40 * sc + 40) * 2, I16P)
+    cr00 = ctypes.cast(bufs[2].ctypes.data + (40 * sc + 40) * 2, I16P)
+    Yh = Y.cpu().numpy()
+    hctu = (H + 63) // 64
+    r0 = min(hctu - 1, 4)
+    sample = [r0 * wctu + min(wctu - 1, 5) + i for i in range(n_ctus)]
+    sel = np.nonzero(np.isin(ctu_of_job, sample))[0]
+    t0 = time.perf_counter()
+    mism = 0
+    for k in sel:
+        j = jobs[k]
+        org = np.ascontiguousarray(Yh[j["pu_y"]:j["pu_y"] + j["h"], j["pu_x"]:j["pu_x"] + j["w"]])
+        out = (ctypes.c_int64 * 32)()
+        O.hop_o_me_pu(p16(org), int(j["w"]), y00, sy, int(j["pu_x"]), int(j["pu_y"]), int(j["w"]), int(j["h"]), int(j["rng_left"]), int(j["rng_right"]),
+                      int(j["rng_top"]), int(j["rng_bottom"]), int(j["off_x"]), int(j["off_y"]), int(j["pred_x"]), int(j["pred_y"]), int(j["n_amvp"]),
+                      (ctypes.c_int * 4)(*[int(v) for v in j["amvp"]]), lc, 1, 1, 8, 3, out)
+        r = res_gpu[k]
+        if not out[3]:
+            got = [int(r["mv_int"][0]), int(r["mv_int"][1]), int(r["sad"]), int(r["gt_flag"])] + [int(v) for v in r["gt"]] + [int(r["cost"])]
+            want = [out[0], out[1], out[2], out[9]] + list(out)[10:18] + [out[18]]
+            mism += got != want
+            if is2n[k]:
+                w, h = int(j["w"]), int(j["h"])
+                a = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
+                mvx, mvy = (out[19] << 2) + (out[21] << 1) + out[23], (out[20] << 2) + (out[22] << 1) + out[24]
+                O.hop_o_pred_inter(y00, sy, cb00, cr00, sc, int(j["pu_x"]), int(j["pu_y"]), w, h, int(mvx), int(mvy), 1,
+                                   (ctypes.c_int * 8)(*[int(v) for v in list(out)[10:18]]), 8, 8, p16(a[0]), p16(a[1]), p16(a[2]))
+        else:
+            mism += int(r["not_valid"]) != 1
+    dt = time.perf_counter() - t0
+    return {"value": len(sample) / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
+            "sample": "%d interior CTUs (row %d) of the same frame, %d PU jobs: oracle hop_o_me_pu (+ hop_o_pred_inter on 2Nx2N) single thread, %.1f s" % (len(sample), r0, len(sel), dt),
+            "gpu_vs_oracle_mismatches": int(mism)}
+
+
+if __name__ == "__main__":
+    main()

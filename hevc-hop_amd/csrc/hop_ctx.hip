@@ -94,6 +94,8 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
 void hop_ctx_destroy(hop_ctx* c) {
   if (!c) return;
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+  for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
+  free(c->prof_recs);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2], c->scratch, c->stage };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);

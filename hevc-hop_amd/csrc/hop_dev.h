@@ -28,7 +28,15 @@ struct hop_ctx {
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
   bool   have_orig;
   char   err[512];
+  // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
+  bool   prof_on;
+  struct hop_prof_rec* prof_recs; int prof_n, prof_cap;
+  double   prof_ms[HOP_K_COUNT];
+  uint64_t prof_launches[HOP_K_COUNT], prof_units[HOP_K_COUNT];
 };
+struct hop_prof_rec { hipEvent_t a, b; int kernel; uint64_t units; };
+int  hop_prof_begin(hop_ctx* c, int kernel, uint64_t units);   // returns record index or -1 when profiling is off
+void hop_prof_end(hop_ctx* c, int rec);
 
 // read-only view of the pictures handed to kernels
 struct hop_pics {

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
 }
 
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
+  const int pr = hop_prof_begin(c, HOP_K_GT_SEARCH, (uint64_t)n);
   hipLaunchKernelGGL(k_gt_search, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
+  hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "gt_search launch: %s", hipGetErrorString(e));
   return HOP_OK;

@@ -151,9 +151,40 @@ __global__ __launch_bounds__(256) void k_pred_inter(const hop_pred_job* __restri
 }
 
 int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs) {
+  const int pr = hop_prof_begin(c, HOP_K_PRED, (uint64_t)n);
   hipLaunchKernelGGL(k_pred_inter, dim3(n, 3), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c));
+  hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "pred_inter launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+__global__ void k_pred_jobs_from_results(int n, const int32_t* __restrict__ index, const hop_pu_job* __restrict__ jobs,
+                                         const hop_pu_result* __restrict__ res, hop_pred_job* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = index ? index[i] : i;
+  const hop_pu_job jb = jobs[k];
+  const hop_pu_result r = res[k];
+  hop_pred_job p;
+  p.pu_x = jb.pu_x; p.pu_y = jb.pu_y; p.w = jb.w; p.h = jb.h;
+  if (r.not_valid) { p.mv_x = 0; p.mv_y = 0; p.use_gt = 0; for (int q = 0; q < 8; q++) p.gt[q] = 0; }
+  else {
+    p.mv_x = (r.mv_final[0] << 2) + (r.half_final[0] << 1) + r.qter_final[0];      // TEncSearch.cpp:4654-4656
+    p.mv_y = (r.mv_final[1] << 2) + (r.half_final[1] << 1) + r.qter_final[1];
+    p.use_gt = 1;
+    for (int q = 0; q < 8; q++) p.gt[q] = r.gt[q];
+  }
+  out[i] = p;
+}
+
+extern "C" int hop_pred_jobs_from_results_device(hop_ctx* c, int n, const int32_t* d_index, const hop_pu_job* d_jobs,
+                                                 const hop_pu_result* d_results, hop_pred_job* d_out) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_results || !d_out))) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_jobs_from_results_device: bad argument");
+  if (n == 0) return HOP_OK;
+  hipLaunchKernelGGL(k_pred_jobs_from_results, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_index, d_jobs, d_results, d_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "pred_jobs_from_results launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
 
@@ -208,7 +239,9 @@ __global__ __launch_bounds__(256) void k_distortion(const hop_dist_job* __restri
 }
 
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out) {
+  const int pr = hop_prof_begin(c, HOP_K_DIST, (uint64_t)n);
   hipLaunchKernelGGL(k_distortion, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_out);
+  hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "distortion launch: %s", hipGetErrorString(e));
   return HOP_OK;

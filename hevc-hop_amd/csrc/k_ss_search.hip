@@ -177,9 +177,11 @@ int hop_launch_ss_search(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_res
   void* sc; int r = hop_scratch(c, (size_t)n * 8, &sc); if (r) return r;
   unsigned long long* keys = (unsigned long long*)sc;
   hop_pics pic = hop_make_pics(c);
+  const int pr = hop_prof_begin(c, HOP_K_SS_SEARCH, (uint64_t)n);
   hipLaunchKernelGGL(k_ss_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, keys, n);
   hipLaunchKernelGGL(k_ss_search, dim3((unsigned)n * SS_MAX_TILES), dim3(256), 0, c->stream, d_jobs, pic, keys);
   hipLaunchKernelGGL(k_ss_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, keys, pic, c->ss_buf[0], d_res, n);
+  hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "ss_search launch: %s", hipGetErrorString(e));
   return HOP_OK;

@@ -96,10 +96,12 @@ __global__ __launch_bounds__(256) void k_ssref_commit(const int32_t* __restrict_
 
 int hop_launch_ssref_commit(hop_ctx* c, int n, const int32_t* d_rect4, const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr, int packed) {
   dim3 grid(n, 3), block(256);
+  const int pr = hop_prof_begin(c, HOP_K_COMMIT, (uint64_t)n);
   if (packed)
     hipLaunchKernelGGL(k_ssref_commit<true>, grid, block, 0, c->stream, d_rect4, d_y, d_cb, d_cr, c->ss00[0], c->ss00[1], c->ss00[2], c->pic_w, c->pic_h, c->stride_y, c->stride_c);
   else
     hipLaunchKernelGGL(k_ssref_commit<false>, grid, block, 0, c->stream, d_rect4, d_y, d_cb, d_cr, c->ss00[0], c->ss00[1], c->ss00[2], c->pic_w, c->pic_h, c->stride_y, c->stride_c);
+  hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "ssref commit launch: %s", hipGetErrorString(e));
   return HOP_OK;

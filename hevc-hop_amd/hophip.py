@@ -81,6 +81,17 @@ def load():
     L.hop_pred_inter.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
     L.hop_pred_inter_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.hop_distortion.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_pred_jobs_from_results_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    L.hop_enumerate_ctu_jobs.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.hop_profile_reset.argtypes = [ctypes.c_void_p]
+    L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    for n in ("hop_ctx_create", "hop_sync", "hop_ssref_reset", "hop_upload_orig", "hop_ssref_commit_cus", "hop_ssref_commit_cus_device",
+              "hop_ssref_download", "hop_ssref_upload", "hop_pred_download", "hop_me_search", "hop_me_search_device", "hop_pred_inter",
+              "hop_pred_inter_device", "hop_distortion", "hop_pred_jobs_from_results_device", "hop_enumerate_ctu_jobs",
+              "hop_profile_enable", "hop_profile_reset", "hop_profile_read"):
+        getattr(L, n).restype = ctypes.c_int
     L.hop_set_search_range.argtypes = [ctypes.c_int] * 14 + [ctypes.POINTER(ctypes.c_int)]
     L.hop_me_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32,
                                 ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]

@@ -146,10 +146,43 @@ int hop_me_search_device(hop_ctx* ctx, int n, const hop_pu_job* d_jobs, hop_pu_r
 int hop_pred_inter(hop_ctx* ctx, int n, const hop_pred_job* jobs, int16_t* out_y, int16_t* out_cb, int16_t* out_cr);
 int hop_pred_inter_device(hop_ctx* ctx, int n, const hop_pred_job* d_jobs);
 int hop_pred_download(hop_ctx* ctx, int comp, int16_t* dst);   /* whole prediction plane, pitch pic_w (/2) */
+/* device-side glue between the two calls above: what predInterSearch stores into the CU's MV/GT fields
+ * (TLibEncoder/TEncSearch.cpp:3885-3922) before motionCompensation reads them (:4158).  out[i] is the predictor
+ * job of PU d_index[i] (d_index == NULL: PU i): mv = (mv_final<<2) + (half_final<<1) + qter_final, the GT vectors
+ * and use_gt = 1; a PU whose search was not valid becomes a zero-vector copy. */
+int hop_pred_jobs_from_results_device(hop_ctx* ctx, int n, const int32_t* d_index, const hop_pu_job* d_jobs,
+                                      const hop_pu_result* d_results, hop_pred_job* d_out);
 
 /* replaces: TComRdCost::getDistPart / DistParam::DistFunc between the original and the prediction picture
  * (TLibCommon/TComRdCost.cpp:477-503). out[i] = distortion of job i. */
 int hop_distortion(hop_ctx* ctx, int n, const hop_dist_job* jobs, uint32_t* out);
+
+/* ---- CTU-level host logic ---- */
+/* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
+ * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and
+ * hop_set_search_range: for every CU of the CTU's quadtree that lies inside the picture (CUs crossing the
+ * picture border are split, TEncCu.cpp:407-409,755) the PUs of 2Nx2N, Nx2N, 2NxN and -- with_amp != 0 -- the
+ * four AMP shapes for CUs >= 16 (what the reference tests when deriveTestModeAMP enables both directions),
+ * in the reference's test order, depth first.  pred/amvp are applied to every PU (the real predictors come
+ * from the caller's CU state).  cu_index_out (may be NULL) receives, per job, depth<<16 | z-order index of
+ * its CU at that depth.  Returns the number of jobs the CTU has (only the first max_out are written; call with
+ * max_out = 0 to size a buffer) or a negative hop_status. */
+int hop_enumerate_ctu_jobs(int pic_w, int pic_h, int ctu_addr, int search_range, const int pred_qpel[2],
+                           int n_amvp, const int amvp_qpel[4], uint32_t lambda_cost, int flags, int with_amp,
+                           hop_pu_job* out, int32_t* cu_index_out, int max_out);
+
+/* ---- profiling (bench.py roofline): HIP events around every kernel launch on the context stream ---- */
+#define HOP_K_SS_SEARCH 0
+#define HOP_K_FRAC      1
+#define HOP_K_GT_SEARCH 2
+#define HOP_K_PRED      3
+#define HOP_K_COMMIT    4
+#define HOP_K_DIST      5
+#define HOP_K_COUNT     6
+int hop_profile_enable(hop_ctx* ctx, int on);
+/* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
+int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);
+int hop_profile_reset(hop_ctx* ctx);
 
 /* library/build identification: "hophip <version> gfx950" */
 const char* hop_version(void);

@@ -4,24 +4,32 @@
 // TComPrediction::calcParamProjective (TLibCommon/TComPrediction.cpp:807-832),
 // ProjectiveTransform GRID_SIZE-2 / bilinear branch (:904-1030) and xGetHADs / SAD cost.
 //
-// Mapping to CDNA4
-//   * one workgroup (4 waves) per PU; the 2Wx2H search patch (the reference's m_filteredBlock[0][0]:
-//     the SS reference around the start vector clamped to [0,maxVal]) and the original block live in LDS.
-//   * the <=625 corner combinations of one iteration are enumerated in the reference's visit order by
-//     the threads, filtered with the exact integer form of the reference's double test
-//     "h[2]==0 && h[5]==0" and compacted in order (56 survive when the centres form a parallelogram).
-//   * a wave evaluates one candidate at a time: lane = one sample of an 8x8 block (or of one of four
-//     4x4 blocks), the warp is IEEE double in the reference's operation order (compiled with
-//     -ffp-contract=off), the Hadamard runs across the 64 lanes, the block SATDs accumulate in a register.
+// Mapping to CDNA4 (FP64-VALU bound: ~33 double-rate ops per warped sample, no HBM traffic beyond the patch)
+//   * one workgroup (4 waves) per PU.  The 2Wx2H search patch (the reference's m_filteredBlock[0][0]: the SS
+//     reference around the start vector clamped to [0,maxVal]) sits in LDS as horizontally PAIRED samples
+//     (P[y][x], P[y][x+1]) so one LDS read feeds one bilinear row; the original block sits beside it.
+//   * per iteration the <=625 corner combinations are enumerated in the reference's visit order, filtered with
+//     the exact integer form of the reference's double test "h[2]==0 && h[5]==0" and compacted in order
+//     (56 survive while the centres form a parallelogram); one thread per surviving candidate then does the
+//     homography's IEEE divisions once and parks h0,h3,h6,h1,h4,h7 + the bit cost in LDS.
+//   * work item = (candidate, 8x8 block).  8 lanes own one item, a lane owns one 8-sample ROW of the block:
+//     the warp (IEEE double in the reference's operation order, -ffp-contract=off) and the horizontal
+//     Hadamard butterflies stay in registers, the vertical butterflies are DPP row operations, the block
+//     SATD is added to its candidate with one LDS atomic.  A wave therefore carries 8 items (8 candidates of
+//     an 8x8 PU at once); PUs with a 4-multiple side use 4x4 blocks (4 lanes x 4 samples, 16 items per wave).
 //   * first-best in visit order = min over cost<<16|order, strict '<' against the incumbent.
-// FP64 VALU bound (about 35 double ops per warped sample); no HBM traffic beyond the patch loads.
 #include "hop_dev.h"
 
 #define GT_MAXC 640
+#define GT_CHUNK 64
 
+template <typename PT>
 struct GtShared {
-  int16_t patch[128 * 130];      // 2H rows x (2W + 2) pitch
-  int16_t org[64 * 64];
+  PT       patch[128 * 130];     // 2H rows x (2W + 2) pitch; element = P[y][x] | P[y][x+1] << (4*sizeof(PT))
+  int16_t  org[64 * 64];
+  double   ch[GT_CHUNK][6];      // h0, h3, h6, h1, h4, h7 of the candidates of the current chunk
+  uint32_t cfix[GT_CHUNK];       // mv cost + GT bit cost
+  int      csatd[GT_CHUNK];
   uint32_t cand_cost[GT_MAXC];
   uint16_t cand_list[GT_MAXC];
   uint8_t  flag[GT_MAXC];
@@ -36,72 +44,178 @@ __device__ static inline void corner_off(int idx, int s, int& dx, int& dy) {
   dy = (idx == 0) ? s : (idx == 4) ? -s : 0;
 }
 
+// DPP lane exchange (all lanes active): quad_perm [1,0,3,2] = xor 1, [2,3,0,1] = xor 2, row_half_mirror = i <-> 7-i
+#define DPP_XOR1 0xB1
+#define DPP_XOR2 0x4E
+#define DPP_HALF_MIRROR 0x141
+template <int CTRL>
+__device__ static inline int dpp_get(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+
+// butterfly across lanes: the lane whose `upper` is set keeps partner - self, the other self + partner.
+// Any pairing along three GF(2)-independent lane masks (here 7, 2, 1 within 8 lanes) yields the Walsh-Hadamard
+// coefficients up to order and sign, which sum|coef| ignores.
+template <int CTRL>
+__device__ static inline int lane_bfly(int v, int sgn) { return dpp_get<CTRL>(v) + v * sgn; }
+
+struct WarpParams { double h0, h3, h6, h1, h4, h7; };
+
+// one warped sample: ProjectiveTransform, TComPrediction.cpp:919-1025, for h[2] = h[5] = 0 (denominator exactly 1.0)
+template <typename PT>
+__device__ static inline int warp_sample(const WarpParams& hp, double ty, double uy, int gx, int offX, int offY,
+                                         int m, int W, int H, const PT* __restrict__ centre, int PP) {
+  constexpr int HS = 4 * (int)sizeof(PT);                     // bits per sample inside a pair
+  constexpr unsigned HM = (1u << HS) - 1u;
+  double Fx = (hp.h0 * gx + ty + hp.h6);
+  double Fy = (hp.h1 * gx + uy + hp.h7);
+  int Y = (int)Fy - offY, X = (int)Fx - offX;
+  double q = (Fy - offY - (double)Y), p = (Fx - offX - (double)X);
+  if (Y < -m) Y = -m;
+  if (X < -m) X = -m;
+  if (Y > m + H - 1) Y = m + H - 1;
+  if (X > m + W - 1) X = m + W - 1;
+  if (Y + 1 > m + H - 1) Y = m + H - 2;
+  if (X + 1 > m + W - 1) X = m + W - 2;
+  const PT* pa = centre + Y * PP + X;
+  const unsigned top = pa[0], bot = pa[PP];
+  double v = (1.0 - q) * ((1.0 - p) * (double)(int)(top & HM) + p * (double)(int)(top >> HS));
+  v += q * ((1.0 - p) * (double)(int)(bot & HM) + p * (double)(int)(bot >> HS));
+  if (v > 255) v = 255;                                       // hard-coded 8-bit clip, :969-972
+  if (v < 0) v = 0;
+  return (int)(int16_t)(v + 0.5);
+}
+
+// evaluate `nc` candidates (params in sh.ch) over all blocks of the PU; adds block costs into sh.csatd
+// BS = 8: 8x8 Hadamard (xCalcHADs8x8, TComRdCost.cpp:1481-1575) ; BS = 4: 4x4 (xCalcHADs4x4, :1387-1479);
+// HAD = false: plain SAD of the same samples (HadamardME = 0)
+template <typename PT, int BS, bool HAD>
+__device__ static inline void gt_eval(GtShared<PT>& sh, int nc, int W, int H, int m, int PP, const PT* __restrict__ centre, int wave, int lane) {
+  constexpr int IPW = 64 / BS;                                // items per wave
+  const int bw = W / BS, nblk = bw * (H / BS), items = nc * nblk;
+  const int sub = lane / BS, row = lane % BS;
+  const int offX = W / 2, offY = H / 2;                       // offsetX/Y of the doubled grid, :919-920
+  const int sgnA = (BS == 8) ? ((row & 4) ? -1 : 1) : ((row & 2) ? -1 : 1);   // stage over the top lane bit (mirror for BS 8)
+  const int sgn2 = (row & 2) ? -1 : 1, sgn1 = (row & 1) ? -1 : 1;
+  for (int base = wave * IPW; base < items; base += 4 * IPW) {
+    const int item = base + sub;
+    const bool act = item < items;
+    const int it = act ? item : 0;
+    const int cand = it / nblk, blk = it - cand * nblk;
+    const int bx = blk % bw, by = blk / bw;
+    const int py = by * BS + row, px0 = bx * BS;
+    WarpParams hp;
+    hp.h0 = sh.ch[cand][0]; hp.h3 = sh.ch[cand][1]; hp.h6 = sh.ch[cand][2];
+    hp.h1 = sh.ch[cand][3]; hp.h4 = sh.ch[cand][4]; hp.h7 = sh.ch[cand][5];
+    const int gy = py + offY;
+    const double ty = hp.h3 * gy, uy = hp.h4 * gy;            // h[3]*y, h[4]*y : shared by the row
+    int d[BS];
+    const int16_t* orow = sh.org + py * W + px0;
+#pragma unroll
+    for (int k = 0; k < BS; k++)
+      d[k] = (int)orow[k] - warp_sample<PT>(hp, ty, uy, px0 + k + offX, offX, offY, m, W, H, centre, PP);
+    int s = 0;
+    if (HAD) {
+      // horizontal butterflies in registers
+#pragma unroll
+      for (int len = 1; len < BS; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < BS; i += 2 * len)
+#pragma unroll
+          for (int j = i; j < i + len; j++) { int a = d[j], b = d[j + len]; d[j] = a + b; d[j + len] = a - b; }
+      // vertical butterflies across the BS lanes of the item
+#pragma unroll
+      for (int k = 0; k < BS; k++) {
+        int v = d[k];
+        if (BS == 8) { v = lane_bfly<DPP_HALF_MIRROR>(v, sgnA); v = lane_bfly<DPP_XOR2>(v, sgn2); v = lane_bfly<DPP_XOR1>(v, sgn1); }
+        else { v = lane_bfly<DPP_XOR2>(v, sgnA); v = lane_bfly<DPP_XOR1>(v, sgn1); }
+        s += v < 0 ? -v : v;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < BS; k++) s += d[k] < 0 ? -d[k] : d[k];
+    }
+    // sum over the item's lanes
+    if (BS == 8) s += dpp_get<DPP_HALF_MIRROR>(s);
+    s += dpp_get<DPP_XOR2>(s);
+    s += dpp_get<DPP_XOR1>(s);
+    if (HAD) s = (BS == 8) ? ((s + 2) >> 2) : ((s + 1) >> 1);
+    if (act && row == 0) atomicAdd(&sh.csatd[cand], s);
+  }
+}
+
+template <typename PT>
 __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict__ jobs, hop_pics pic, hop_pu_result* __restrict__ res) {
-  __shared__ GtShared sh;
-  const hop_pu_job jb = jobs[blockIdx.x];
-  hop_pu_result rr = res[blockIdx.x];
-  if (rr.not_valid) return;
-  const int W = jb.w, H = jb.h, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __shared__ GtShared<PT> sh;
+  constexpr int HS = 4 * (int)sizeof(PT);
+  const hop_pu_job* jp = jobs + blockIdx.x;
+  hop_pu_result* rp = res + blockIdx.x;
+  if (rp->not_valid) return;
+  const int W = jp->w, H = jp->h, pu_x = jp->pu_x, pu_y = jp->pu_y, n_amvp = jp->n_amvp;
+  const int pred_x = jp->pred_x, pred_y = jp->pred_y;
+  const uint32_t lambda_cost = jp->lambda_cost;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int maxVal = (1 << pic.bd_y) - 1;
-  const bool use_had = (jb.flags & HOP_FLAG_HADME) != 0;
+  const bool use_had = (jp->flags & HOP_FLAG_HADME) != 0;
   const int PP = 2 * W + 2;                                   // patch pitch
+  const int mv0x = rp->mv_int[0], mv0y = rp->mv_int[1];
   // original block -> LDS
   for (int i = tid; i < W * H; i += 256) {
     int r = i / W, c = i - r * W;
-    sh.org[i] = pic.org_y[(size_t)(jb.pu_y + r) * pic.pic_w + jb.pu_x + c];
+    sh.org[i] = pic.org_y[(size_t)(pu_y + r) * pic.pic_w + pu_x + c];
   }
   const int nssWindow = (min(H, W) >> 1) * 2;                 // :4756-4759
   int lastStep = nssWindow >> 6; if (lastStep == 0) lastStep = 1;   // :4763-4765 (IT_MAX_NSS_Iteration 6)
   const int m = nssWindow / 2;
-  uint32_t distBest = rr.frac_cost;                           // incumbent = cost after the fractional search, :4769
-  int bestCX[4] = {0, 0, 0, 0}, bestCY[4] = {0, 0, 0, 0};
-  int bestNX[4], bestNY[4], curNX[4], curNY[4];
+  uint32_t distBest = rp->frac_cost;                          // incumbent = cost after the fractional search, :4769
+  int bestCX0 = 0, bestCX1 = 0, bestCX2 = 0, bestCX3 = 0, bestCY0 = 0, bestCY1 = 0, bestCY2 = 0, bestCY3 = 0;
+  int bNX0, bNX1, bNX2, bNX3, bNY0, bNY1, bNY2, bNY3, cNX0, cNX1, cNX2, cNX3, cNY0, cNY1, cNY2, cNY3;
   int bestSSX = 0, bestSSY = 0;
-  const int rx[4] = {0, 2 * W - 1, 2 * W - 1, 0}, ry[4] = {0, 0, 2 * H - 1, 2 * H - 1};   // rest corners, :4786-4789
-  for (int k = 0; k < 4; k++) { bestNX[k] = curNX[k] = rx[k]; bestNY[k] = curNY[k] = ry[k]; }
+  const int rx1 = 2 * W - 1, ry2 = 2 * H - 1;                 // rest corners (0,0) (rx1,0) (rx1,ry2) (0,ry2), :4786-4789
+  bNX0 = 0; bNX1 = rx1; bNX2 = rx1; bNX3 = 0; bNY0 = 0; bNY1 = 0; bNY2 = ry2; bNY3 = ry2;
   const bool had8 = ((W & 7) == 0) && ((H & 7) == 0);
-  const bool had4 = !had8 && ((W & 3) == 0) && ((H & 3) == 0);
 
-  for (int b = 0; b < 1 + jb.n_amvp; b++) {                   // start vectors, :5106-5178
+  for (int b = 0; b < 1 + n_amvp; b++) {                      // start vectors, :5106-5178
     int sx, sy;
-    if (b == 0) { sx = rr.mv_int[0]; sy = rr.mv_int[1]; if (sx == 0 && sy == 0) continue; }   // ssBestCand[0] == best integer MV
+    if (b == 0) { sx = mv0x; sy = mv0y; if (sx == 0 && sy == 0) continue; }   // ssBestCand[0] == best integer MV
     else {
-      int ax = jb.amvp[2 * (b - 1)], ay = jb.amvp[2 * (b - 1) + 1];
+      int ax = jp->amvp[2 * (b - 1)], ay = jp->amvp[2 * (b - 1) + 1];
       if (ax == 0 && ay == 0) continue;
       sx = (int)(int16_t)ax >> 2; sy = (int)(int16_t)ay >> 2;
     }
     const int Hor = (int)(int16_t)(sx * 4), Ver = (int)(int16_t)(sy * 4);
     __syncthreads();                                          // previous start's readers are done with the patch
     // patch: rows -H/2 .. 3H/2-1, cols -W/2 .. 3W/2-1 around the displaced PU, clamped to [0,maxVal]
-    // (filterCopy twice, TComInterpolationFilter.cpp:92-152 via TEncSearch.cpp:5161-5165,:7832,:7837)
+    // (filterCopy twice, TComInterpolationFilter.cpp:92-152 via TEncSearch.cpp:5161-5165,:7832,:7837);
+    // element (r,c) = sample(r,c) | sample(r,c+1) << HS  (the last column's partner is never used)
     {
-      const int16_t* src = pic.ss_y + (ptrdiff_t)(jb.pu_y + sy - H / 2) * pic.stride_y + (jb.pu_x + sx - W / 2);
+      const int16_t* src = pic.ss_y + (ptrdiff_t)(pu_y + sy - H / 2) * pic.stride_y + (pu_x + sx - W / 2);
       for (int i = tid; i < 4 * W * H; i += 256) {
         int r = i / (2 * W), c = i - r * (2 * W);
-        int v = src[(ptrdiff_t)r * pic.stride_y + c];
-        sh.patch[r * PP + c] = (int16_t)min(maxVal, max(0, v));
+        int v0 = src[(ptrdiff_t)r * pic.stride_y + c];
+        int v1 = (c + 1 < 2 * W) ? src[(ptrdiff_t)r * pic.stride_y + c + 1] : 0;
+        v0 = min(maxVal, max(0, v0)); v1 = min(maxVal, max(0, v1));
+        sh.patch[r * PP + c] = (PT)((unsigned)v0 | ((unsigned)v1 << HS));
       }
     }
     __syncthreads();
-    const int16_t* centre = sh.patch + (H / 2) * PP + W / 2;
-    const uint32_t mvc = hopd_mv_cost(jb.lambda_cost, Hor, Ver, 0, jb.pred_x, jb.pred_y);    // :5345, cost scale 0
+    const PT* centre = sh.patch + (H / 2) * PP + W / 2;
+    const uint32_t mvc = hopd_mv_cost(lambda_cost, Hor, Ver, 0, pred_x, pred_y);    // :5345, cost scale 0
     int iter = 1;
     for (int j0 = nssWindow; (j0 > 1) && (iter <= 6); j0 /= 2) {    // :5181
       iter++;
-      if (j0 == nssWindow) { for (int k = 0; k < 4; k++) { curNX[k] = bestNX[k] = rx[k]; curNY[k] = bestNY[k] = ry[k]; } }
-      else { for (int k = 0; k < 4; k++) { curNX[k] = bestNX[k]; curNY[k] = bestNY[k]; } }
+      if (j0 == nssWindow) { bNX0 = 0; bNX1 = rx1; bNX2 = rx1; bNX3 = 0; bNY0 = 0; bNY1 = 0; bNY2 = ry2; bNY3 = ry2; }
+      cNX0 = bNX0; cNX1 = bNX1; cNX2 = bNX2; cNX3 = bNX3; cNY0 = bNY0; cNY1 = bNY1; cNY2 = bNY2; cNY3 = bNY3;
       const int s = j0 / 2;
       // ---- enumerate + filter the 625 combinations (visit order = index) ----
-      if (tid == 0) { sh.n_cand = 0; sh.best = ~0ull; }
+      if (tid == 0) sh.best = ~0ull;
       for (int idx = tid; idx < 625; idx += 256) {
         int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125;
-        int dx[4], dy[4];
-        corner_off(i0, s, dx[0], dy[0]); corner_off(i1, s, dx[1], dy[1]); corner_off(i2, s, dx[2], dy[2]); corner_off(i3, s, dx[3], dy[3]);
+        int dx0, dy0, dx1, dy1, dx2, dy2, dx3, dy3;
+        corner_off(i0, s, dx0, dy0); corner_off(i1, s, dx1, dy1); corner_off(i2, s, dx2, dy2); corner_off(i3, s, dx3, dy3);
         bool ok = !(i0 == i1 && i0 == i2 && i0 == i3);                     // not a pure translation, :5289
         // affine test :5323 on calcParamProjective's h[2], h[5]: numerators and denominator are products of
         // small integers (exact in double); h==0.0 <=> numerator == 0 and denominator != 0 (0/0 = NaN, x/0 = inf)
-        int x0 = curNX[0] + dx[0], x1 = curNX[1] + dx[1], x2 = curNX[2] + dx[2], x3 = curNX[3] + dx[3];
-        int y0 = curNY[0] + dy[0], y1 = curNY[1] + dy[1], y2 = curNY[2] + dy[2], y3 = curNY[3] + dy[3];
+        int x0 = cNX0 + dx0, x1 = cNX1 + dx1, x2 = cNX2 + dx2, x3 = cNX3 + dx3;
+        int y0 = cNY0 + dy0, y1 = cNY1 + dy1, y2 = cNY2 + dy2, y3 = cNY3 + dy3;
         int ddx1 = x1 - x2, ddx2 = x3 - x2, ddx3 = x0 - x1 + x2 - x3;
         int ddy1 = y1 - y2, ddy2 = y3 - y2, ddy3 = y0 - y1 + y2 - y3;
         int num2 = ddx3 * ddy2 - ddx2 * ddy3, num5 = ddx1 * ddy3 - ddx3 * ddy1, den = ddx1 * ddy2 - ddx2 * ddy1;
@@ -123,81 +237,37 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
       }
       __syncthreads();
       const int ncand = sh.n_cand;
-      // ---- evaluate: one candidate per wave at a time ----
-      for (int ci = wave; ci < ncand; ci += 4) {
-        const int idx = sh.cand_list[ci];
-        int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125;
-        int cx[4], cy[4], ddx, ddy;
-        corner_off(i0, s, ddx, ddy); cx[0] = curNX[0] + ddx; cy[0] = curNY[0] + ddy;
-        corner_off(i1, s, ddx, ddy); cx[1] = curNX[1] + ddx; cy[1] = curNY[1] + ddy;
-        corner_off(i2, s, ddx, ddy); cx[2] = curNX[2] + ddx; cy[2] = curNY[2] + ddy;
-        corner_off(i3, s, ddx, ddy); cx[3] = curNX[3] + ddx; cy[3] = curNY[3] + ddy;
-        // calcParamProjective on the doubled grid, TComPrediction.cpp:807-832.  For the candidates that reach
-        // this point h[2] = h[5] = +/-0, so h[2]*x adds +/-0 and the denominator of the warp is exactly 1.0.
-        const double Wd = (double)(2 * W) - 1.0, Hd = (double)(2 * H) - 1.0;
-        const double h0 = (double)(cx[1] - cx[0]) / Wd, h3 = (double)(cx[3] - cx[0]) / Hd, h6 = (double)cx[0];
-        const double h1 = (double)(cy[1] - cy[0]) / Wd, h4 = (double)(cy[3] - cy[0]) / Hd, h7 = (double)cy[0];
-        const int offX = W / 2, offY = H / 2;                 // offsetX/Y of the doubled grid, :919-920
-        // one warped sample of the PU at (px,py): ProjectiveTransform, TComPrediction.cpp:919-1025
-        auto warp = [&](int px, int py) -> int {
-          const int gx = px + offX, gy = py + offY;
-          double Fx = (h0 * gx + h3 * gy + h6);               // divided by exactly 1.0 in the reference
-          double Fy = (h1 * gx + h4 * gy + h7);
-          int Y = (int)Fy - offY, X = (int)Fx - offX;
-          double q = (Fy - offY - (double)Y), p = (Fx - offX - (double)X);
-          if (Y < -m) Y = -m;
-          if (X < -m) X = -m;
-          if (Y > m + H - 1) Y = m + H - 1;
-          if (X > m + W - 1) X = m + W - 1;
-          if (Y + 1 > m + H - 1) Y = m + H - 2;
-          if (X + 1 > m + W - 1) X = m + W - 2;
-          const int16_t* pa = centre + Y * PP + X;
-          double v = (1.0 - q) * ((1.0 - p) * (double)pa[0] + p * (double)pa[1]);
-          v += q * ((1.0 - p) * (double)pa[PP] + p * (double)pa[PP + 1]);
-          if (v > 255) v = 255;                               // hard-coded 8-bit clip, :969-972
-          if (v < 0) v = 0;
-          return (int)(int16_t)(v + 0.5);
-        };
-        int satd = 0;
-        if (!use_had) {                                       // SAD (HadamardME = 0): 64 samples per pass
-          for (int base = 0; base < W * H; base += 64) {
-            const int i = base + lane;
-            const bool act = i < W * H;
-            const int py = act ? i / W : 0, px = act ? i - py * W : 0;
-            int d = (int)sh.org[py * W + px] - warp(px, py);
-            satd += hopd_wave_sum(act ? (d < 0 ? -d : d) : 0);
-          }
-        } else if (had8) {                                    // 64 lanes = one 8x8 block
-          const int nblk = (W * H) >> 6, bw = W >> 3;
-          for (int blk = 0; blk < nblk; blk++) {
-            const int px = (blk % bw) * 8 + (lane & 7), py = (blk / bw) * 8 + (lane >> 3);
-            int d = (int)sh.org[py * W + px] - warp(px, py);
-            satd += hopd_satd8x8_wave(d, lane);
-          }
-        } else if (had4) {                                    // four 4x4 blocks per pass: lane = 16*q + 4*row + col
-          const int nb4 = (W >> 2) * (H >> 2), bw4 = W >> 2;
-          for (int b0 = 0; b0 < nb4; b0 += 4) {
-            const int blk = b0 + (lane >> 4);
-            const bool act = blk < nb4;
-            const int bb = act ? blk : 0;
-            const int px = (bb % bw4) * 4 + (lane & 3), py = (bb / bw4) * 4 + ((lane >> 2) & 3);
-            int d = (int)sh.org[py * W + px] - warp(px, py);
-            int sb = hopd_satd4x4_quad(act ? d : 0, lane);    // SATD of this lane's block
-            satd += hopd_wave_sum((act && (lane & 15) == 0) ? sb : 0);
-          }
+      for (int c0 = 0; c0 < ncand; c0 += GT_CHUNK) {
+        const int nc = min(GT_CHUNK, ncand - c0);
+        // ---- per-candidate homography + bit cost: one thread per candidate ----
+        if (tid < nc) {
+          const int idx = sh.cand_list[c0 + tid];
+          int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125, ddx, ddy;
+          corner_off(i0, s, ddx, ddy); const int x0 = cNX0 + ddx, y0 = cNY0 + ddy;
+          corner_off(i1, s, ddx, ddy); const int x1 = cNX1 + ddx, y1 = cNY1 + ddy;
+          corner_off(i2, s, ddx, ddy); const int x2 = cNX2 + ddx, y2 = cNY2 + ddy;
+          corner_off(i3, s, ddx, ddy); const int x3 = cNX3 + ddx, y3 = cNY3 + ddy;
+          // calcParamProjective on the doubled grid, TComPrediction.cpp:807-832; h[2] = h[5] = +/-0 here, so
+          // "+ h[2]*x[1]" adds +/-0 and the value is the plain quotient
+          const double Wd = (double)(2 * W) - 1.0, Hd = (double)(2 * H) - 1.0;
+          sh.ch[tid][0] = (double)(x1 - x0) / Wd; sh.ch[tid][1] = (double)(x3 - x0) / Hd; sh.ch[tid][2] = (double)x0;
+          sh.ch[tid][3] = (double)(y1 - y0) / Wd; sh.ch[tid][4] = (double)(y3 - y0) / Hd; sh.ch[tid][5] = (double)y0;
+          uint32_t bits = hopd_component_bits(x0 / lastStep) + hopd_component_bits(y0 / lastStep)
+                        + hopd_component_bits((x1 - 2 * W + 1) / lastStep) + hopd_component_bits(y1 / lastStep)
+                        + hopd_component_bits((x2 - 2 * W + 1) / lastStep) + hopd_component_bits((y2 - 2 * H + 1) / lastStep);   // getBitsGT: corners 0..2
+          sh.cfix[tid] = mvc + ((lambda_cost * bits) >> 16);                                  // :5345-5358
+          sh.csatd[tid] = 0;
         }
-        if (lane == 0) {
-          uint32_t dist = (uint32_t)satd >> (pic.bd_y - 8);
-          dist += mvc;
-          int v[6] = { cx[0] / lastStep, cy[0] / lastStep, (cx[1] - 2 * W + 1) / lastStep, cy[1] / lastStep,
-                       (cx[2] - 2 * W + 1) / lastStep, (cy[2] - 2 * H + 1) / lastStep };
-          uint32_t bits = 0;
-          for (int k = 0; k < 6; k++) bits += hopd_component_bits(v[k]);       // getBitsGT: corners 0..2 (affine)
-          dist += (jb.lambda_cost * bits) >> 16;                               // :5346-5358
-          sh.cand_cost[ci] = dist;
-        }
+        __syncthreads();
+        if (!use_had) {
+          if (had8) gt_eval<PT, 8, false>(sh, nc, W, H, m, PP, centre, wave, lane);
+          else      gt_eval<PT, 4, false>(sh, nc, W, H, m, PP, centre, wave, lane);
+        } else if (had8) gt_eval<PT, 8, true>(sh, nc, W, H, m, PP, centre, wave, lane);
+        else             gt_eval<PT, 4, true>(sh, nc, W, H, m, PP, centre, wave, lane);
+        __syncthreads();
+        if (tid < nc) sh.cand_cost[c0 + tid] = ((uint32_t)sh.csatd[tid] >> (pic.bd_y - 8)) + sh.cfix[tid];
+        __syncthreads();
       }
-      __syncthreads();
       // ---- first-best in visit order, strict '<' against the incumbent (:5361) ----
       unsigned long long kbest = ~0ull;
       for (int ci = tid; ci < ncand; ci += 256) {
@@ -212,43 +282,42 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
         distBest = (uint32_t)(kb >> 16);
         const int idx = sh.cand_list[(int)(kb & 0xFFFF)];
         int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125, ddx, ddy;
-        corner_off(i0, s, ddx, ddy); bestCX[0] = curNX[0] + ddx; bestCY[0] = curNY[0] + ddy;
-        corner_off(i1, s, ddx, ddy); bestCX[1] = curNX[1] + ddx; bestCY[1] = curNY[1] + ddy;
-        corner_off(i2, s, ddx, ddy); bestCX[2] = curNX[2] + ddx; bestCY[2] = curNY[2] + ddy;
-        corner_off(i3, s, ddx, ddy); bestCX[3] = curNX[3] + ddx; bestCY[3] = curNY[3] + ddy;
-        for (int k = 0; k < 4; k++) { bestNX[k] = bestCX[k]; bestNY[k] = bestCY[k]; }
+        corner_off(i0, s, ddx, ddy); bestCX0 = cNX0 + ddx; bestCY0 = cNY0 + ddy;
+        corner_off(i1, s, ddx, ddy); bestCX1 = cNX1 + ddx; bestCY1 = cNY1 + ddy;
+        corner_off(i2, s, ddx, ddy); bestCX2 = cNX2 + ddx; bestCY2 = cNY2 + ddy;
+        corner_off(i3, s, ddx, ddy); bestCX3 = cNX3 + ddx; bestCY3 = cNY3 + ddy;
+        bNX0 = bestCX0; bNX1 = bestCX1; bNX2 = bestCX2; bNX3 = bestCX3; bNY0 = bestCY0; bNY1 = bestCY1; bNY2 = bestCY2; bNY3 = bestCY3;
         bestSSX = Hor; bestSSY = Ver;
       }
       __syncthreads();                                        // everyone has read sh.best before it is reset
     }
   }
   if (tid == 0) {
-    bool flag = false;
-    for (int k = 0; k < 4; k++) flag = flag || bestCX[k] != 0 || bestCY[k] != 0;      // :5436-5439
+    const bool flag = (bestCX0 | bestCX1 | bestCX2 | bestCX3 | bestCY0 | bestCY1 | bestCY2 | bestCY3) != 0;      // :5436-5439
     if (flag) {
-      rr.gt_flag = 1;
-      rr.gt[0] = bestCX[0] / lastStep;               rr.gt[1] = bestCY[0] / lastStep;
-      rr.gt[2] = (bestCX[1] - 2 * W + 1) / lastStep; rr.gt[3] = bestCY[1] / lastStep;
-      rr.gt[4] = (bestCX[2] - 2 * W + 1) / lastStep; rr.gt[5] = (bestCY[2] - 2 * H + 1) / lastStep;
-      rr.gt[6] = bestCX[3] / lastStep;               rr.gt[7] = (bestCY[3] - 2 * H + 1) / lastStep;
-      rr.cost = distBest;
-      rr.mv_final[0] = bestSSX >> 2; rr.mv_final[1] = bestSSY >> 2;                    // :5455-5457
-      rr.half_final[0] = rr.half_final[1] = 0; rr.qter_final[0] = rr.qter_final[1] = 0;
+      rp->gt_flag = 1;
+      rp->gt[0] = bestCX0 / lastStep;               rp->gt[1] = bestCY0 / lastStep;
+      rp->gt[2] = (bestCX1 - 2 * W + 1) / lastStep; rp->gt[3] = bestCY1 / lastStep;
+      rp->gt[4] = (bestCX2 - 2 * W + 1) / lastStep; rp->gt[5] = (bestCY2 - 2 * H + 1) / lastStep;
+      rp->gt[6] = bestCX3 / lastStep;               rp->gt[7] = (bestCY3 - 2 * H + 1) / lastStep;
+      rp->cost = distBest;
+      rp->mv_final[0] = bestSSX >> 2; rp->mv_final[1] = bestSSY >> 2;                    // :5455-5457
+      rp->half_final[0] = 0; rp->half_final[1] = 0; rp->qter_final[0] = 0; rp->qter_final[1] = 0;
     } else {
-      rr.gt_flag = 0;
-      for (int k = 0; k < 8; k++) rr.gt[k] = 0;
-      rr.cost = rr.frac_cost;
-      rr.mv_final[0] = rr.mv_int[0]; rr.mv_final[1] = rr.mv_int[1];
-      rr.half_final[0] = rr.half[0]; rr.half_final[1] = rr.half[1];
-      rr.qter_final[0] = rr.qter[0]; rr.qter_final[1] = rr.qter[1];
+      rp->gt_flag = 0;
+      for (int k = 0; k < 8; k++) rp->gt[k] = 0;
+      rp->cost = rp->frac_cost;
+      rp->mv_final[0] = mv0x; rp->mv_final[1] = mv0y;
+      rp->half_final[0] = rp->half[0]; rp->half_final[1] = rp->half[1];
+      rp->qter_final[0] = rp->qter[0]; rp->qter_final[1] = rp->qter[1];
     }
-    res[blockIdx.x] = rr;
   }
 }
 
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
   const int pr = hop_prof_begin(c, HOP_K_GT_SEARCH, (uint64_t)n);
-  hipLaunchKernelGGL(k_gt_search, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
+  if (c->bd_y == 8) hipLaunchKernelGGL(k_gt_search<uint16_t>, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
+  else              hipLaunchKernelGGL(k_gt_search<uint32_t>, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "gt_search launch: %s", hipGetErrorString(e));

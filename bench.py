@@ -93,6 +93,12 @@ def cu_rects(W, H):
     return np.array(out, np.int32)
 
 
+def rows_for_rank(hctu, world, rank):
+    """CTU rows of one rank: round-robin (row r -> rank r % world), the interleaving SURVEY 8(e) proposes for the
+    wavefront so that all ranks stay busy along the anti-diagonal."""
+    return [r for r in range(hctu) if r % world == rank]
+
+
 def gt_iters(w, h):
     m, it = min(w, h), 0
     while m > 1 and it < 6:
@@ -141,7 +147,7 @@ def main():
     ctx.sync()
 
     # ---- PU job lists of this rank's CTU rows ----
-    my_rows = [r for r in range(hctu) if r % world == rank]
+    my_rows = rows_for_rank(hctu, world, rank)
     pred = (ctypes.c_int * 2)(0, -4 * PITCH)                     # one micro-image up
     amvp = (ctypes.c_int * 4)(0, -4 * PITCH, -4 * PITCH, 0)      # + one micro-image left
     flags = hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME

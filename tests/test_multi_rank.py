@@ -1,0 +1,92 @@
+"""CPU, world_size 2 on gloo: the N>1 path of bench.py -- CTU rows dealt round-robin to the ranks, every rank
+enumerating the PU jobs of its rows through the C ABI's host logic, barrier + MAX reduction of the step time.
+(The kernels themselves need a GPU; what is distributed is only the partition and the reduction.)"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hoputil import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, W, H, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    hp = bench._hophip()
+    L = hp.load()
+    wctu, hctu = (W + 63) // 64, (H + 63) // 64
+    rows = bench.rows_for_rank(hctu, world, rank)
+    pred = (ctypes.c_int * 2)(0, -60); amvp = (ctypes.c_int * 4)(0, -60, -60, 0)
+    jobs = np.zeros(425 * len(rows) * wctu, hp.PU_JOB_DTYPE)
+    n = 0
+    for r in rows:
+        for c in range(wctu):
+            n += L.hop_enumerate_ctu_jobs(W, H, r * wctu + c, 128, pred, 2, amvp, 498711, 3, 0, jobs.ctypes.data + n * jobs.itemsize, None, len(jobs) - n)
+    jobs = jobs[:n]
+    # every PU belongs to a CTU row of this rank
+    assert set(np.unique(jobs["pu_y"] // 64).tolist()) <= set(rows)
+    area = torch.tensor([float(np.sum(jobs["w"].astype(np.int64) * jobs["h"])), float(n), float(len(rows))], dtype=torch.float64)
+    dist.all_reduce(area)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)      # stand-in for the per-rank step time
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put((area.tolist(), float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_row_partition_world2():
+    W, H = 456, 312            # ragged right/bottom CTUs (multiples of 8 like 7728x5368)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    (area, n, nrows), tmax = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process enumeration of the whole frame for comparison
+    import bench
+    hp = bench._hophip()
+    L = hp.load()
+    wctu, hctu = (W + 63) // 64, (H + 63) // 64
+    pred = (ctypes.c_int * 2)(0, -60); amvp = (ctypes.c_int * 4)(0, -60, -60, 0)
+    tot_n = tot_area = 0
+    for a in range(wctu * hctu):
+        jobs = np.zeros(425, hp.PU_JOB_DTYPE)
+        k = L.hop_enumerate_ctu_jobs(W, H, a, 128, pred, 2, amvp, 498711, 3, 0, jobs.ctypes.data, None, 425)
+        tot_n += k
+        tot_area += int(np.sum(jobs["w"][:k].astype(np.int64) * jobs["h"][:k]))
+    assert (int(n), int(area), int(nrows)) == (tot_n, tot_area, hctu)
+    assert tmax == 2.0
+    # aligned part of the picture: every luma sample is covered 3 (part types) x 4 (depths) times; the ragged
+    # right/bottom CTUs lose the depths whose CUs would cross the border (they are split, TEncCu.cpp:407-409)
+    assert 12 * (W // 64 * 64) * (H // 64 * 64) < tot_area < 12 * W * H
+
+
+def test_enumeration_interior_ctu():
+    import bench
+    hp = bench._hophip()
+    L = hp.load()
+    pred = (ctypes.c_int * 2)(0, -60); amvp = (ctypes.c_int * 4)(0, -60, -60, 0)
+    jobs = np.zeros(2000, hp.PU_JOB_DTYPE); tags = np.zeros(2000, np.int32)
+    k = L.hop_enumerate_ctu_jobs(7728, 5368, 121 * 5 + 7, 128, pred, 2, amvp, 498711, 3, 0, jobs.ctypes.data, tags.ctypes.data, 2000)
+    assert k == 425                                   # 85 CUs x (2Nx2N + 2 Nx2N + 2 2NxN)
+    ka = L.hop_enumerate_ctu_jobs(7728, 5368, 121 * 5 + 7, 128, pred, 2, amvp, 498711, 3, 1, jobs.ctypes.data, tags.ctypes.data, 2000)
+    assert ka == 425 + 21 * 8                         # + 4 AMP shapes x 2 PUs for the 21 CUs >= 16
+    shapes = set(zip(jobs["w"][:ka].tolist(), jobs["h"][:ka].tolist()))
+    assert (12, 16) in shapes and (64, 48) in shapes and (4, 8) in shapes and (4, 16) in shapes
+    # ragged bottom-right CTU of the 7728x5368 frame (48 x 56 samples): only CUs inside the picture
+    kr = L.hop_enumerate_ctu_jobs(7728, 5368, 121 * 84 - 1, 128, pred, 2, amvp, 498711, 3, 0, jobs.ctypes.data, tags.ctypes.data, 2000)
+    j = jobs[:kr]
+    assert (j["pu_x"] + j["w"]).max() <= 7728 and (j["pu_y"] + j["h"]).max() <= 5368
+    assert kr > 0 and int(j["w"].max()) <= 32          # the 64x64 CU crosses the border: split without a mode test

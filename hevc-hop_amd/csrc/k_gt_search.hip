@@ -5,13 +5,18 @@
 // ProjectiveTransform GRID_SIZE-2 / bilinear branch (:904-1030) and xGetHADs / SAD cost.
 //
 // Mapping to CDNA4 (FP64-VALU bound: ~33 double-rate ops per warped sample, no HBM traffic beyond the patch)
-//   * one workgroup (4 waves) per PU.  The 2Wx2H search patch (the reference's m_filteredBlock[0][0]: the SS
-//     reference around the start vector clamped to [0,maxVal]) sits in LDS as horizontally PAIRED samples
-//     (P[y][x], P[y][x+1]) so one LDS read feeds one bilinear row; the original block sits beside it.
-//   * per iteration the <=625 corner combinations are enumerated in the reference's visit order, filtered with
-//     the exact integer form of the reference's double test "h[2]==0 && h[5]==0" and compacted in order
-//     (56 survive while the centres form a parallelogram); one thread per surviving candidate then does the
-//     homography's IEEE divisions once and parks h0,h3,h6,h1,h4,h7 + the bit cost in LDS.
+//   * PUs of up to 256 samples (16x16 and below) get ONE WAVE each (64-thread workgroups, no barriers at all:
+//     the search of such a PU is a chain of 6-18 short dependent iterations, so barrier and dispatch overhead, not
+//     arithmetic, decides); larger PUs get a 4-wave workgroup.  A prep kernel sorts the PUs into the two classes.
+//   * The 2Wx2H search patch (the reference's m_filteredBlock[0][0]: the SS reference around the start vector
+//     clamped to [0,maxVal]) sits in LDS as horizontally PAIRED samples (P[y][x], P[y][x+1]) so one LDS read
+//     feeds one bilinear row; the original block sits beside it.
+//   * The corner combinations of an iteration are enumerated in the reference's visit order and filtered with
+//     the exact integer form of the reference's double test "h[2]==0 && h[5]==0".  While the four centres form
+//     a parallelogram (always, because only affine candidates are ever accepted) the surviving set is the same
+//     56 combinations every time: it is built once per PU and reused; the general enumeration stays as the
+//     fallback.  One thread per surviving candidate does the homography's IEEE divisions once per iteration and
+//     parks h0,h3,h6,h1,h4,h7 + the bit cost in LDS.
 //   * work item = (candidate, 8x8 block).  8 lanes own one item, a lane owns one 8-sample ROW of the block:
 //     the warp (IEEE double in the reference's operation order, -ffp-contract=off) and the horizontal
 //     Hadamard butterflies stay in registers, the vertical butterflies are DPP row operations, the block
@@ -23,17 +28,19 @@
 #define GT_MAXC 640
 #define GT_CHUNK 64
 
-template <typename PT>
+// MAXD = largest PU side of the class: 16 (one wave) or 64 (four waves)
+template <typename PT, int MAXD>
 struct GtShared {
-  PT       patch[128 * 130];     // 2H rows x (2W + 2) pitch; element = P[y][x] | P[y][x+1] << (4*sizeof(PT))
-  int16_t  org[64 * 64];
+  PT       patch[2 * MAXD * (2 * MAXD + 2)];   // 2H rows x (2W + 2) pitch; element = P[y][x] | P[y][x+1] << (4*sizeof(PT))
+  int16_t  org[MAXD * MAXD];
   double   ch[GT_CHUNK][6];      // h0, h3, h6, h1, h4, h7 of the candidates of the current chunk
-  uint32_t cfix[GT_CHUNK];       // mv cost + GT bit cost
+  uint32_t cfix[GT_CHUNK];       // mv cost + GT bit cost; 0xFFFFFFFF = degenerate (denominator 0), never evaluated by the reference
   int      csatd[GT_CHUNK];
   uint32_t cand_cost[GT_MAXC];
   uint16_t cand_list[GT_MAXC];
+  uint16_t fixed_list[GT_CHUNK]; // the 56 combinations with d0 + d2 == d1 + d3 (parallelogram centres)
   uint8_t  flag[GT_MAXC];
-  int n_cand;
+  int n_cand, n_fixed;
   unsigned long long best;
 };
 
@@ -51,11 +58,17 @@ __device__ static inline void corner_off(int idx, int s, int& dx, int& dy) {
 template <int CTRL>
 __device__ static inline int dpp_get(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 
-// butterfly across lanes: the lane whose `upper` is set keeps partner - self, the other self + partner.
+// butterfly across lanes: the lane whose sign is -1 keeps partner - self, the other self + partner.
 // Any pairing along three GF(2)-independent lane masks (here 7, 2, 1 within 8 lanes) yields the Walsh-Hadamard
 // coefficients up to order and sign, which sum|coef| ignores.
 template <int CTRL>
-__device__ static inline int lane_bfly(int v, int sgn) { return dpp_get<CTRL>(v) + v * sgn; }
+__device__ static inline int lane_bfly(int v, int sgn) { return __mul24(v, sgn) + dpp_get<CTRL>(v); }   // |v| < 2^23: full-rate 24-bit multiply instead of v_mul_lo_u32
+
+template <int NW>
+__device__ static inline void wg_sync() {
+  if (NW > 1) __syncthreads();
+  else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: program order + LDS counters suffice; keep the compiler from reordering LDS traffic
+}
 
 struct WarpParams { double h0, h3, h6, h1, h4, h7; };
 
@@ -69,38 +82,36 @@ __device__ static inline int warp_sample(const WarpParams& hp, double ty, double
   double Fy = (hp.h1 * gx + uy + hp.h7);
   int Y = (int)Fy - offY, X = (int)Fx - offX;
   double q = (Fy - offY - (double)Y), p = (Fx - offX - (double)X);
-  if (Y < -m) Y = -m;
-  if (X < -m) X = -m;
-  if (Y > m + H - 1) Y = m + H - 1;
-  if (X > m + W - 1) X = m + W - 1;
-  if (Y + 1 > m + H - 1) Y = m + H - 2;
-  if (X + 1 > m + W - 1) X = m + W - 2;
-  const PT* pa = centre + Y * PP + X;
+  // :950-961: clamp to [-m, m+size-1], then pull back by one if the +1 tap would leave  ==  clamp to [-m, m+size-2]
+  Y = min(max(Y, -m), m + H - 2);
+  X = min(max(X, -m), m + W - 2);
+  const PT* pa = centre + (__mul24(Y, PP) + X);
   const unsigned top = pa[0], bot = pa[PP];
   double v = (1.0 - q) * ((1.0 - p) * (double)(int)(top & HM) + p * (double)(int)(top >> HS));
   v += q * ((1.0 - p) * (double)(int)(bot & HM) + p * (double)(int)(bot >> HS));
-  if (v > 255) v = 255;                                       // hard-coded 8-bit clip, :969-972
-  if (v < 0) v = 0;
-  return (int)(int16_t)(v + 0.5);
+  v = __builtin_fmax(__builtin_fmin(v, 255.0), 0.0);          // hard-coded 8-bit clip, :969-972 (v is never NaN: v_min/max_f64 == the two ifs)
+  return (int)(v + 0.5);                                      // (Pel)(aux + 0.5): the value is in [0.5, 255.5]
 }
 
 // evaluate `nc` candidates (params in sh.ch) over all blocks of the PU; adds block costs into sh.csatd
 // BS = 8: 8x8 Hadamard (xCalcHADs8x8, TComRdCost.cpp:1481-1575) ; BS = 4: 4x4 (xCalcHADs4x4, :1387-1479);
 // HAD = false: plain SAD of the same samples (HadamardME = 0)
-template <typename PT, int BS, bool HAD>
-__device__ static inline void gt_eval(GtShared<PT>& sh, int nc, int W, int H, int m, int PP, const PT* __restrict__ centre, int wave, int lane) {
+template <typename SH, typename PT, int NW, int BS, bool HAD>
+__device__ static inline void gt_eval(SH& sh, int nc, int W, int H, int m, int PP, const PT* __restrict__ centre, int wave, int lane) {
   constexpr int IPW = 64 / BS;                                // items per wave
   const int bw = W / BS, nblk = bw * (H / BS), items = nc * nblk;
   const int sub = lane / BS, row = lane % BS;
+  const float inv_nblk = 1.0f / (float)nblk, inv_bw = 1.0f / (float)bw;
   const int offX = W / 2, offY = H / 2;                       // offsetX/Y of the doubled grid, :919-920
   const int sgnA = (BS == 8) ? ((row & 4) ? -1 : 1) : ((row & 2) ? -1 : 1);   // stage over the top lane bit (mirror for BS 8)
   const int sgn2 = (row & 2) ? -1 : 1, sgn1 = (row & 1) ? -1 : 1;
-  for (int base = wave * IPW; base < items; base += 4 * IPW) {
+  for (int base = wave * IPW; base < items; base += NW * IPW) {
     const int item = base + sub;
     const bool act = item < items;
     const int it = act ? item : 0;
-    const int cand = it / nblk, blk = it - cand * nblk;
-    const int bx = blk % bw, by = blk / bw;
+    // small exact quotients without integer division: (i + 0.5) / n in float is off an integer by >= 0.5/64 >> rounding error (i < 4096)
+    const int cand = (int)(((float)it + 0.5f) * inv_nblk), blk = it - cand * nblk;
+    const int by = (int)(((float)blk + 0.5f) * inv_bw), bx = blk - by * bw;
     const int py = by * BS + row, px0 = bx * BS;
     WarpParams hp;
     hp.h0 = sh.ch[cand][0]; hp.h3 = sh.ch[cand][1]; hp.h6 = sh.ch[cand][2];
@@ -142,13 +153,53 @@ __device__ static inline void gt_eval(GtShared<PT>& sh, int nc, int W, int H, in
   }
 }
 
-template <typename PT>
-__global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict__ jobs, hop_pics pic, hop_pu_result* __restrict__ res) {
-  __shared__ GtShared<PT> sh;
+// enumerate + filter the 625 combinations for centres (cx,cy) and step s; ordered compaction into `list`.
+// affine test :5323 on calcParamProjective's h[2], h[5]: numerators and denominator are products of small integers
+// (exact in double); h == 0.0 <=> numerator == 0 and denominator != 0 (0/0 = NaN, x/0 = inf)
+template <typename SH, int NW>
+__device__ static inline int gt_enumerate(SH& sh, const int (&cx)[4], const int (&cy)[4], int s, uint16_t* list, int tid, int wave, int lane) {
+  for (int idx = tid; idx < 625; idx += NW * 64) {
+    int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125;
+    int dx0, dy0, dx1, dy1, dx2, dy2, dx3, dy3;
+    corner_off(i0, s, dx0, dy0); corner_off(i1, s, dx1, dy1); corner_off(i2, s, dx2, dy2); corner_off(i3, s, dx3, dy3);
+    bool ok = !(i0 == i1 && i0 == i2 && i0 == i3);                     // not a pure translation, :5289
+    int x0 = cx[0] + dx0, x1 = cx[1] + dx1, x2 = cx[2] + dx2, x3 = cx[3] + dx3;
+    int y0 = cy[0] + dy0, y1 = cy[1] + dy1, y2 = cy[2] + dy2, y3 = cy[3] + dy3;
+    int ddx1 = x1 - x2, ddx2 = x3 - x2, ddx3 = x0 - x1 + x2 - x3;
+    int ddy1 = y1 - y2, ddy2 = y3 - y2, ddy3 = y0 - y1 + y2 - y3;
+    int num2 = ddx3 * ddy2 - ddx2 * ddy3, num5 = ddx1 * ddy3 - ddx3 * ddy1, den = ddx1 * ddy2 - ddx2 * ddy1;
+    ok = ok && (num2 == 0) && (num5 == 0) && (den != 0);
+    sh.flag[idx] = ok ? 1 : 0;
+  }
+  wg_sync<NW>();
+  if (wave == 0) {                                            // ordered compaction by one wave
+    int base = 0;
+    for (int c0 = 0; c0 < 625; c0 += 64) {
+      int idx = c0 + lane;
+      bool f = idx < 625 && sh.flag[idx];
+      unsigned long long mask = __ballot(f);
+      int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (f) list[pos] = (uint16_t)idx;
+      base += __popcll(mask);
+    }
+    if (lane == 0) sh.n_cand = base;
+  }
+  wg_sync<NW>();
+  return sh.n_cand;
+}
+
+// NW = waves per PU (1 or 4); MAXD = largest PU side handled; the PUs of the class come through `index`
+template <typename PT, int NW, int MAXD>
+__global__ __launch_bounds__(NW * 64) void k_gt_search(const hop_pu_job* __restrict__ jobs, hop_pics pic, hop_pu_result* __restrict__ res,
+                                                        const int32_t* __restrict__ index, const unsigned int* __restrict__ count) {
+  typedef GtShared<PT, MAXD> SH;
+  __shared__ SH sh;
   constexpr int HS = 4 * (int)sizeof(PT);
-  const hop_pu_job* jp = jobs + blockIdx.x;
-  hop_pu_result* rp = res + blockIdx.x;
-  if (rp->not_valid) return;
+  constexpr int NT = NW * 64;
+  if (blockIdx.x >= *count) return;
+  const int pu = index[blockIdx.x];
+  const hop_pu_job* jp = jobs + pu;
+  hop_pu_result* rp = res + pu;
   const int W = jp->w, H = jp->h, pu_x = jp->pu_x, pu_y = jp->pu_y, n_amvp = jp->n_amvp;
   const int pred_x = jp->pred_x, pred_y = jp->pred_y;
   const uint32_t lambda_cost = jp->lambda_cost;
@@ -158,7 +209,7 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
   const int PP = 2 * W + 2;                                   // patch pitch
   const int mv0x = rp->mv_int[0], mv0y = rp->mv_int[1];
   // original block -> LDS
-  for (int i = tid; i < W * H; i += 256) {
+  for (int i = tid; i < W * H; i += NT) {
     int r = i / W, c = i - r * W;
     sh.org[i] = pic.org_y[(size_t)(pu_y + r) * pic.pic_w + pu_x + c];
   }
@@ -166,12 +217,20 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
   int lastStep = nssWindow >> 6; if (lastStep == 0) lastStep = 1;   // :4763-4765 (IT_MAX_NSS_Iteration 6)
   const int m = nssWindow / 2;
   uint32_t distBest = rp->frac_cost;                          // incumbent = cost after the fractional search, :4769
-  int bestCX0 = 0, bestCX1 = 0, bestCX2 = 0, bestCX3 = 0, bestCY0 = 0, bestCY1 = 0, bestCY2 = 0, bestCY3 = 0;
-  int bNX0, bNX1, bNX2, bNX3, bNY0, bNY1, bNY2, bNY3, cNX0, cNX1, cNX2, cNX3, cNY0, cNY1, cNY2, cNY3;
+  int bestC[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};             // iBestCornerX/Y
+  int bN[2][4], cN[2][4];                                     // iBestNSSCenter / iCurrNSSCenter
   int bestSSX = 0, bestSSY = 0;
   const int rx1 = 2 * W - 1, ry2 = 2 * H - 1;                 // rest corners (0,0) (rx1,0) (rx1,ry2) (0,ry2), :4786-4789
-  bNX0 = 0; bNX1 = rx1; bNX2 = rx1; bNX3 = 0; bNY0 = 0; bNY1 = 0; bNY2 = ry2; bNY3 = ry2;
+  const int restX[4] = {0, rx1, rx1, 0}, restY[4] = {0, 0, ry2, ry2};
+#pragma unroll
+  for (int k = 0; k < 4; k++) { bN[0][k] = restX[k]; bN[1][k] = restY[k]; }
   const bool had8 = ((W & 7) == 0) && ((H & 7) == 0);
+  // the combination set of parallelogram centres (independent of the step): built once from the rest corners
+  {
+    const int n = gt_enumerate<SH, NW>(sh, restX, restY, 1, sh.fixed_list, tid, wave, lane);
+    if (tid == 0) sh.n_fixed = (n <= GT_CHUNK) ? n : -1;
+    wg_sync<NW>();
+  }
 
   for (int b = 0; b < 1 + n_amvp; b++) {                      // start vectors, :5106-5178
     int sx, sy;
@@ -182,13 +241,13 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
       sx = (int)(int16_t)ax >> 2; sy = (int)(int16_t)ay >> 2;
     }
     const int Hor = (int)(int16_t)(sx * 4), Ver = (int)(int16_t)(sy * 4);
-    __syncthreads();                                          // previous start's readers are done with the patch
+    wg_sync<NW>();                                            // previous start's readers are done with the patch
     // patch: rows -H/2 .. 3H/2-1, cols -W/2 .. 3W/2-1 around the displaced PU, clamped to [0,maxVal]
     // (filterCopy twice, TComInterpolationFilter.cpp:92-152 via TEncSearch.cpp:5161-5165,:7832,:7837);
     // element (r,c) = sample(r,c) | sample(r,c+1) << HS  (the last column's partner is never used)
     {
       const int16_t* src = pic.ss_y + (ptrdiff_t)(pu_y + sy - H / 2) * pic.stride_y + (pu_x + sx - W / 2);
-      for (int i = tid; i < 4 * W * H; i += 256) {
+      for (int i = tid; i < 4 * W * H; i += NT) {
         int r = i / (2 * W), c = i - r * (2 * W);
         int v0 = src[(ptrdiff_t)r * pic.stride_y + c];
         int v1 = (c + 1 < 2 * W) ? src[(ptrdiff_t)r * pic.stride_y + c + 1] : 0;
@@ -196,57 +255,36 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
         sh.patch[r * PP + c] = (PT)((unsigned)v0 | ((unsigned)v1 << HS));
       }
     }
-    __syncthreads();
+    wg_sync<NW>();
     const PT* centre = sh.patch + (H / 2) * PP + W / 2;
     const uint32_t mvc = hopd_mv_cost(lambda_cost, Hor, Ver, 0, pred_x, pred_y);    // :5345, cost scale 0
     int iter = 1;
     for (int j0 = nssWindow; (j0 > 1) && (iter <= 6); j0 /= 2) {    // :5181
       iter++;
-      if (j0 == nssWindow) { bNX0 = 0; bNX1 = rx1; bNX2 = rx1; bNX3 = 0; bNY0 = 0; bNY1 = 0; bNY2 = ry2; bNY3 = ry2; }
-      cNX0 = bNX0; cNX1 = bNX1; cNX2 = bNX2; cNX3 = bNX3; cNY0 = bNY0; cNY1 = bNY1; cNY2 = bNY2; cNY3 = bNY3;
+      if (j0 == nssWindow) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { bN[0][k] = restX[k]; bN[1][k] = restY[k]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { cN[0][k] = bN[0][k]; cN[1][k] = bN[1][k]; }
       const int s = j0 / 2;
-      // ---- enumerate + filter the 625 combinations (visit order = index) ----
       if (tid == 0) sh.best = ~0ull;
-      for (int idx = tid; idx < 625; idx += 256) {
-        int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125;
-        int dx0, dy0, dx1, dy1, dx2, dy2, dx3, dy3;
-        corner_off(i0, s, dx0, dy0); corner_off(i1, s, dx1, dy1); corner_off(i2, s, dx2, dy2); corner_off(i3, s, dx3, dy3);
-        bool ok = !(i0 == i1 && i0 == i2 && i0 == i3);                     // not a pure translation, :5289
-        // affine test :5323 on calcParamProjective's h[2], h[5]: numerators and denominator are products of
-        // small integers (exact in double); h==0.0 <=> numerator == 0 and denominator != 0 (0/0 = NaN, x/0 = inf)
-        int x0 = cNX0 + dx0, x1 = cNX1 + dx1, x2 = cNX2 + dx2, x3 = cNX3 + dx3;
-        int y0 = cNY0 + dy0, y1 = cNY1 + dy1, y2 = cNY2 + dy2, y3 = cNY3 + dy3;
-        int ddx1 = x1 - x2, ddx2 = x3 - x2, ddx3 = x0 - x1 + x2 - x3;
-        int ddy1 = y1 - y2, ddy2 = y3 - y2, ddy3 = y0 - y1 + y2 - y3;
-        int num2 = ddx3 * ddy2 - ddx2 * ddy3, num5 = ddx1 * ddy3 - ddx3 * ddy1, den = ddx1 * ddy2 - ddx2 * ddy1;
-        ok = ok && (num2 == 0) && (num5 == 0) && (den != 0);
-        sh.flag[idx] = ok ? 1 : 0;
-      }
-      __syncthreads();
-      if (wave == 0) {                                        // ordered compaction by one wave
-        int base = 0;
-        for (int c0 = 0; c0 < 625; c0 += 64) {
-          int idx = c0 + lane;
-          bool f = idx < 625 && sh.flag[idx];
-          unsigned long long mask = __ballot(f);
-          int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-          if (f) sh.cand_list[pos] = (uint16_t)idx;
-          base += __popcll(mask);
-        }
-        if (lane == 0) sh.n_cand = base;
-      }
-      __syncthreads();
-      const int ncand = sh.n_cand;
+      // candidate set: the fixed parallelogram set, or the general enumeration if the centres are not one
+      const bool para = (cN[0][0] - cN[0][1] + cN[0][2] - cN[0][3] == 0) && (cN[1][0] - cN[1][1] + cN[1][2] - cN[1][3] == 0) && sh.n_fixed > 0;
+      int ncand;
+      const uint16_t* clist;
+      if (para) { ncand = sh.n_fixed; clist = sh.fixed_list; wg_sync<NW>(); }
+      else { ncand = gt_enumerate<SH, NW>(sh, cN[0], cN[1], s, sh.cand_list, tid, wave, lane); clist = sh.cand_list; }
       for (int c0 = 0; c0 < ncand; c0 += GT_CHUNK) {
         const int nc = min(GT_CHUNK, ncand - c0);
         // ---- per-candidate homography + bit cost: one thread per candidate ----
         if (tid < nc) {
-          const int idx = sh.cand_list[c0 + tid];
+          const int idx = clist[c0 + tid];
           int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125, ddx, ddy;
-          corner_off(i0, s, ddx, ddy); const int x0 = cNX0 + ddx, y0 = cNY0 + ddy;
-          corner_off(i1, s, ddx, ddy); const int x1 = cNX1 + ddx, y1 = cNY1 + ddy;
-          corner_off(i2, s, ddx, ddy); const int x2 = cNX2 + ddx, y2 = cNY2 + ddy;
-          corner_off(i3, s, ddx, ddy); const int x3 = cNX3 + ddx, y3 = cNY3 + ddy;
+          corner_off(i0, s, ddx, ddy); const int x0 = cN[0][0] + ddx, y0 = cN[1][0] + ddy;
+          corner_off(i1, s, ddx, ddy); const int x1 = cN[0][1] + ddx, y1 = cN[1][1] + ddy;
+          corner_off(i2, s, ddx, ddy); const int x2 = cN[0][2] + ddx, y2 = cN[1][2] + ddy;
+          corner_off(i3, s, ddx, ddy); const int x3 = cN[0][3] + ddx, y3 = cN[1][3] + ddy;
           // calcParamProjective on the doubled grid, TComPrediction.cpp:807-832; h[2] = h[5] = +/-0 here, so
           // "+ h[2]*x[1]" adds +/-0 and the value is the plain quotient
           const double Wd = (double)(2 * W) - 1.0, Hd = (double)(2 * H) - 1.0;
@@ -255,51 +293,58 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
           uint32_t bits = hopd_component_bits(x0 / lastStep) + hopd_component_bits(y0 / lastStep)
                         + hopd_component_bits((x1 - 2 * W + 1) / lastStep) + hopd_component_bits(y1 / lastStep)
                         + hopd_component_bits((x2 - 2 * W + 1) / lastStep) + hopd_component_bits((y2 - 2 * H + 1) / lastStep);   // getBitsGT: corners 0..2
-          sh.cfix[tid] = mvc + ((lambda_cost * bits) >> 16);                                  // :5345-5358
+          const int den = (x1 - x2) * (y3 - y2) - (x3 - x2) * (y1 - y2);                      // 0 => h[2] is NaN/inf: not affine, :5323
+          sh.cfix[tid] = den != 0 ? mvc + ((lambda_cost * bits) >> 16) : 0xFFFFFFFFu;         // :5345-5358
           sh.csatd[tid] = 0;
         }
-        __syncthreads();
+        wg_sync<NW>();
         if (!use_had) {
-          if (had8) gt_eval<PT, 8, false>(sh, nc, W, H, m, PP, centre, wave, lane);
-          else      gt_eval<PT, 4, false>(sh, nc, W, H, m, PP, centre, wave, lane);
-        } else if (had8) gt_eval<PT, 8, true>(sh, nc, W, H, m, PP, centre, wave, lane);
-        else             gt_eval<PT, 4, true>(sh, nc, W, H, m, PP, centre, wave, lane);
-        __syncthreads();
-        if (tid < nc) sh.cand_cost[c0 + tid] = ((uint32_t)sh.csatd[tid] >> (pic.bd_y - 8)) + sh.cfix[tid];
-        __syncthreads();
+          if (had8) gt_eval<SH, PT, NW, 8, false>(sh, nc, W, H, m, PP, centre, wave, lane);
+          else      gt_eval<SH, PT, NW, 4, false>(sh, nc, W, H, m, PP, centre, wave, lane);
+        } else if (had8) gt_eval<SH, PT, NW, 8, true>(sh, nc, W, H, m, PP, centre, wave, lane);
+        else             gt_eval<SH, PT, NW, 4, true>(sh, nc, W, H, m, PP, centre, wave, lane);
+        wg_sync<NW>();
+        if (tid < nc) sh.cand_cost[c0 + tid] = sh.cfix[tid] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((uint32_t)sh.csatd[tid] >> (pic.bd_y - 8)) + sh.cfix[tid];
+        wg_sync<NW>();
       }
       // ---- first-best in visit order, strict '<' against the incumbent (:5361) ----
       unsigned long long kbest = ~0ull;
-      for (int ci = tid; ci < ncand; ci += 256) {
+      for (int ci = tid; ci < ncand; ci += NT) {
         unsigned long long key = ((unsigned long long)sh.cand_cost[ci] << 16) | (unsigned long long)ci;
         kbest = key < kbest ? key : kbest;
       }
       kbest = hopd_wave_min_u64(kbest);
-      if (lane == 0 && kbest != ~0ull) atomicMin(&sh.best, kbest);
-      __syncthreads();
-      const unsigned long long kb = sh.best;
-      if (kb != ~0ull && (uint32_t)(kb >> 16) < distBest) {
+      if (NW > 1) {
+        if (lane == 0 && kbest != ~0ull) atomicMin(&sh.best, kbest);
+        __syncthreads();
+        kbest = sh.best;
+      }
+      const unsigned long long kb = kbest;
+      if (kb != ~0ull && (uint32_t)(kb >> 16) != 0xFFFFFFFFu && (uint32_t)(kb >> 16) < distBest) {
         distBest = (uint32_t)(kb >> 16);
-        const int idx = sh.cand_list[(int)(kb & 0xFFFF)];
-        int i3 = idx % 5, i2 = (idx / 5) % 5, i1 = (idx / 25) % 5, i0 = idx / 125, ddx, ddy;
-        corner_off(i0, s, ddx, ddy); bestCX0 = cNX0 + ddx; bestCY0 = cNY0 + ddy;
-        corner_off(i1, s, ddx, ddy); bestCX1 = cNX1 + ddx; bestCY1 = cNY1 + ddy;
-        corner_off(i2, s, ddx, ddy); bestCX2 = cNX2 + ddx; bestCY2 = cNY2 + ddy;
-        corner_off(i3, s, ddx, ddy); bestCX3 = cNX3 + ddx; bestCY3 = cNY3 + ddy;
-        bNX0 = bestCX0; bNX1 = bestCX1; bNX2 = bestCX2; bNX3 = bestCX3; bNY0 = bestCY0; bNY1 = bestCY1; bNY2 = bestCY2; bNY3 = bestCY3;
+        const int idx = clist[(int)(kb & 0xFFFF)];
+        const int ii[4] = { idx / 125, (idx / 25) % 5, (idx / 5) % 5, idx % 5 };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int ddx, ddy; corner_off(ii[k], s, ddx, ddy);
+          bestC[0][k] = cN[0][k] + ddx; bestC[1][k] = cN[1][k] + ddy;
+          bN[0][k] = bestC[0][k]; bN[1][k] = bestC[1][k];
+        }
         bestSSX = Hor; bestSSY = Ver;
       }
-      __syncthreads();                                        // everyone has read sh.best before it is reset
+      wg_sync<NW>();                                          // everyone has read sh.best / the lists before they are rewritten
     }
   }
   if (tid == 0) {
-    const bool flag = (bestCX0 | bestCX1 | bestCX2 | bestCX3 | bestCY0 | bestCY1 | bestCY2 | bestCY3) != 0;      // :5436-5439
+    bool flag = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) flag = flag || bestC[0][k] != 0 || bestC[1][k] != 0;     // :5436-5439
     if (flag) {
       rp->gt_flag = 1;
-      rp->gt[0] = bestCX0 / lastStep;               rp->gt[1] = bestCY0 / lastStep;
-      rp->gt[2] = (bestCX1 - 2 * W + 1) / lastStep; rp->gt[3] = bestCY1 / lastStep;
-      rp->gt[4] = (bestCX2 - 2 * W + 1) / lastStep; rp->gt[5] = (bestCY2 - 2 * H + 1) / lastStep;
-      rp->gt[6] = bestCX3 / lastStep;               rp->gt[7] = (bestCY3 - 2 * H + 1) / lastStep;
+      rp->gt[0] = bestC[0][0] / lastStep;               rp->gt[1] = bestC[1][0] / lastStep;
+      rp->gt[2] = (bestC[0][1] - 2 * W + 1) / lastStep; rp->gt[3] = bestC[1][1] / lastStep;
+      rp->gt[4] = (bestC[0][2] - 2 * W + 1) / lastStep; rp->gt[5] = (bestC[1][2] - 2 * H + 1) / lastStep;
+      rp->gt[6] = bestC[0][3] / lastStep;               rp->gt[7] = (bestC[1][3] - 2 * H + 1) / lastStep;
       rp->cost = distBest;
       rp->mv_final[0] = bestSSX >> 2; rp->mv_final[1] = bestSSY >> 2;                    // :5455-5457
       rp->half_final[0] = 0; rp->half_final[1] = 0; rp->qter_final[0] = 0; rp->qter_final[1] = 0;
@@ -314,10 +359,35 @@ __global__ __launch_bounds__(256) void k_gt_search(const hop_pu_job* __restrict_
   }
 }
 
+// class lists: valid PUs of at most 256 samples with both sides <= 16 -> one wave; the other valid PUs -> four waves
+__global__ void k_gt_prep(const hop_pu_job* __restrict__ jobs, const hop_pu_result* __restrict__ res, int n,
+                          unsigned int* __restrict__ counts, int32_t* __restrict__ small_list, int32_t* __restrict__ big_list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (res[i].not_valid) return;                               // bNotValCU: xMotionEstimation returned before the GT search
+  const bool small = jobs[i].w <= 16 && jobs[i].h <= 16;
+  unsigned int pos = atomicAdd(counts + (small ? 0 : 1), 1u);
+  (small ? small_list : big_list)[pos] = i;
+}
+
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
+  // scratch (after the SS search's use of it on the same stream): 2 counters + 2 index lists
+  void* sc; int r = hop_scratch(c, 256 + (size_t)n * 8, &sc); if (r) return r;
+  unsigned int* counts = (unsigned int*)sc;
+  int32_t* small_list = (int32_t*)((char*)sc + 256);
+  int32_t* big_list = small_list + n;
+  hop_pics pic = hop_make_pics(c);
   const int pr = hop_prof_begin(c, HOP_K_GT_SEARCH, (uint64_t)n);
-  if (c->bd_y == 8) hipLaunchKernelGGL(k_gt_search<uint16_t>, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
-  else              hipLaunchKernelGGL(k_gt_search<uint32_t>, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
+  (void)hipMemsetAsync(counts, 0, 8, c->stream);
+  hipLaunchKernelGGL(k_gt_prep, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, d_res, n, counts, small_list, big_list);
+  // grids are upper bounds: blocks beyond the class count exit on their first instruction
+  if (c->bd_y == 8) {
+    hipLaunchKernelGGL((k_gt_search<uint16_t, 4, 64>), dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_res, big_list, counts + 1);
+    hipLaunchKernelGGL((k_gt_search<uint16_t, 1, 16>), dim3(n), dim3(64), 0, c->stream, d_jobs, pic, d_res, small_list, counts);
+  } else {
+    hipLaunchKernelGGL((k_gt_search<uint32_t, 4, 64>), dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_res, big_list, counts + 1);
+    hipLaunchKernelGGL((k_gt_search<uint32_t, 1, 16>), dim3(n), dim3(64), 0, c->stream, d_jobs, pic, d_res, small_list, counts);
+  }
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "gt_search launch: %s", hipGetErrorString(e));

@@ -79,6 +79,9 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   if (e == hipSuccess) e = hipMalloc((void**)&c->pred[0], ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->pred[1], nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->pred[2], nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->rec[0], ny * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->rec[1], nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->rec[2], nc * 2);
   if (e != hipSuccess) { hop_set_err(nullptr, HOP_ERR_DEVICE, "allocation failed: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
   c->ss_buf[0] = c->ss_alloc[0] + gy; c->ss_buf[1] = c->ss_alloc[1] + gc; c->ss_buf[2] = c->ss_alloc[2] + gc;
   c->ss00[0] = c->ss_buf[0] + (size_t)HOP_MARGIN_Y * c->stride_y + HOP_MARGIN_Y;
@@ -96,7 +99,8 @@ void hop_ctx_destroy(hop_ctx* c) {
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs);
-  void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2], c->scratch, c->stage };
+  void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   free(c);
@@ -358,6 +362,85 @@ int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, 
     HIPCHK(c, hipMemcpyAsync(out_cb, b + o_cb, tot / 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out_cr, b + o_cr, tot / 2, hipMemcpyDeviceToHost, c->stream));
   }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_pred_upload(hop_ctx* c, int comp, const int16_t* src) {
+  if (!c || !src || comp < 0 || comp > 2) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_upload: bad argument");
+  size_t n = comp == 0 ? (size_t)c->pic_w * c->pic_h : ((size_t)c->pic_w * c->pic_h) >> 2;
+  HIPCHK(c, hipMemcpyAsync(c->pred[comp], src, n * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+int hop_recon_upload(hop_ctx* c, int comp, const int16_t* src) {
+  if (!c || !src || comp < 0 || comp > 2) return hop_set_err(c, HOP_ERR_ARG, "hop_recon_upload: bad argument");
+  size_t n = comp == 0 ? (size_t)c->pic_w * c->pic_h : ((size_t)c->pic_w * c->pic_h) >> 2;
+  HIPCHK(c, hipMemcpyAsync(c->rec[comp], src, n * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+int hop_recon_download(hop_ctx* c, int comp, int16_t* dst) {
+  if (!c || !dst || comp < 0 || comp > 2) return hop_set_err(c, HOP_ERR_ARG, "hop_recon_download: bad argument");
+  size_t n = comp == 0 ? (size_t)c->pic_w * c->pic_h : ((size_t)c->pic_w * c->pic_h) >> 2;
+  HIPCHK(c, hipMemcpyAsync(dst, c->rec[comp], n * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_tu_roundtrip(hop_ctx* c, int n, const hop_tu_job* jobs, hop_tu_result* results, int32_t* levels_out) {
+  if (!c || n < 0 || (n && (!jobs || !results))) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_roundtrip: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_roundtrip: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  std::vector<int64_t> offs(n);
+  size_t tot = 0;
+  for (int i = 0; i < n; i++) {
+    const hop_tu_job& j = jobs[i];
+    const int N = 1 << j.log2_size, sh = j.comp ? 1 : 0;
+    if (j.comp < 0 || j.comp > 2 || j.log2_size < 2 || j.log2_size > 5 || j.x < 0 || j.y < 0 || ((j.x >> sh) & 3) || ((j.y >> sh) & 3) ||
+        (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || (j.use_dst && (j.log2_size != 2 || j.comp != 0)))
+      return hop_set_err(c, HOP_ERR_ARG, "TU job %d: illegal transform unit", i);
+    offs[i] = (int64_t)tot; tot += (size_t)N * N;
+  }
+  const size_t bj = (size_t)n * sizeof(hop_tu_job), o_r = (bj + 255) & ~(size_t)255, o_o = (o_r + (size_t)n * sizeof(hop_tu_result) + 255) & ~(size_t)255;
+  const size_t o_l = (o_o + (size_t)n * 8 + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_l + (levels_out ? tot * 4 : 0) + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_o, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_tu(c, n, (const hop_tu_job*)b, (hop_tu_result*)(b + o_r), levels_out ? (int32_t*)(b + o_l) : nullptr, (const int64_t*)(b + o_o));
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(results, b + o_r, (size_t)n * sizeof(hop_tu_result), hipMemcpyDeviceToHost, c->stream));
+  if (levels_out) HIPCHK(c, hipMemcpyAsync(levels_out, b + o_l, tot * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_intra_rough(hop_ctx* c, int n, const hop_intra_job* jobs, uint32_t* satd_out) {
+  if (!c || n < 0 || (n && (!jobs || !satd_out))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_rough: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_rough: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_intra_job& j = jobs[i];
+    const int N = j.size;
+    if (!(N == 4 || N == 8 || N == 16 || N == 32 || N == 64) || j.x < 0 || j.y < 0 || (j.x & 3) || (j.y & 3) || j.x + N > c->pic_w || j.y + N > c->pic_h)
+      return hop_set_err(c, HOP_ERR_ARG, "intra job %d: illegal block", i);
+    // an available unit must lie inside the picture (the reference derives availability from existing CUs)
+    const int U = N / 4;
+    for (int u = 0; u < 4 * U + 1; u++) if (j.flags[u]) {
+      bool ok;
+      if (u < 2 * U) ok = j.x > 0 && j.y + 4 * (2 * U - 1 - u) + 4 <= c->pic_h;
+      else if (u == 2 * U) ok = j.x > 0 && j.y > 0;
+      else ok = j.y > 0 && j.x + 4 * (u - 2 * U - 1) + 4 <= c->pic_w;
+      if (!ok) return hop_set_err(c, HOP_ERR_ARG, "intra job %d: neighbour unit %d flagged available but outside the picture", i, u);
+    }
+  }
+  const size_t bj = (size_t)n * sizeof(hop_intra_job), o_o = (bj + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_o + (size_t)n * 35 * 4, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_intra(c, n, (const hop_intra_job*)b, (uint32_t*)(b + o_o)); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(satd_out, b + o_o, (size_t)n * 35 * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }

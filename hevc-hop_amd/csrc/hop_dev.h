@@ -23,6 +23,7 @@ struct hop_ctx {
   int16_t *ss_buf[3];                // padded SS-ref buffers (the reference's TComPicYuv layout) inside ss_alloc
   int16_t *ss00[3];                  // sample (0,0) inside them
   int16_t *pred[3];                  // prediction picture, pitch pic_w / pic_w/2
+  int16_t *rec[3];                   // reconstruction picture (TU round trip output, intra neighbours), same pitch
   // scratch that grows on demand (never allocated inside a *_device call once sized)
   void*  scratch; size_t scratch_bytes;
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
@@ -119,6 +120,8 @@ int hop_launch_frac(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* 
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
 int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs);
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out);
+int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off);
+int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
 int hop_launch_ssref_reset(hop_ctx* c);
 int hop_launch_ssref_commit(hop_ctx* c, int n, const int32_t* d_rect4, const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr, int packed);
 int hop_set_err(hop_ctx* c, int code, const char* fmt, ...);

@@ -41,6 +41,19 @@ class DistJob(ctypes.Structure):
                 ("comp", ctypes.c_int32), ("kind", ctypes.c_int32)]
 
 
+class TuJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("comp", ctypes.c_int32), ("log2_size", ctypes.c_int32),
+                ("use_dst", ctypes.c_int32), ("transform_skip", ctypes.c_int32), ("qp_scaled", ctypes.c_int32), ("is_i_slice", ctypes.c_int32)]
+
+
+class TuResult(ctypes.Structure):
+    _fields_ = [("abs_sum", ctypes.c_uint32), ("sse", ctypes.c_uint32)]
+
+
+class IntraJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("size", ctypes.c_int32), ("strong", ctypes.c_int32), ("flags", ctypes.c_uint8 * 68)]
+
+
 PU_JOB_DTYPE = np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("rng_left", "<i4"), ("rng_right", "<i4"),
                          ("rng_top", "<i4"), ("rng_bottom", "<i4"), ("off_x", "<i4"), ("off_y", "<i4"), ("pred_x", "<i4"), ("pred_y", "<i4"),
                          ("lambda_cost", "<u4"), ("n_amvp", "<i4"), ("amvp", "<i4", (4,)), ("flags", "<i4")])
@@ -82,6 +95,13 @@ def load():
     L.hop_pred_inter_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.hop_distortion.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.hop_pred_jobs_from_results_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    L.hop_tu_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_intra_rough.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for n in ("hop_recon_upload", "hop_recon_download", "hop_pred_upload"):
+        getattr(L, n).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        getattr(L, n).restype = ctypes.c_int
+    L.hop_tu_roundtrip.restype = ctypes.c_int
+    L.hop_intra_rough.restype = ctypes.c_int
     L.hop_enumerate_ctu_jobs.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
                                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -173,6 +193,32 @@ class Context:
         arr = (DistJob * n)(*jobs)
         out = np.zeros(n, np.uint32)
         self._chk(self.L.hop_distortion(self.h, n, ctypes.addressof(arr), out.ctypes.data), "hop_distortion")
+        return out
+
+    def plane_upload(self, what, comp, a):
+        a = np.ascontiguousarray(a, np.int16)
+        self._chk(getattr(self.L, "hop_%s_upload" % what)(self.h, comp, a.ctypes.data), "hop_%s_upload" % what)
+
+    def recon_download(self, comp):
+        shape = (self.H, self.W) if comp == 0 else (self.H // 2, self.W // 2)
+        a = np.empty(shape, np.int16)
+        self._chk(self.L.hop_recon_download(self.h, comp, a.ctypes.data), "hop_recon_download")
+        return a
+
+    def tu_roundtrip(self, jobs, want_levels=True):
+        n = len(jobs)
+        arr = (TuJob * n)(*jobs)
+        res = (TuResult * n)()
+        tot = sum((1 << j.log2_size) ** 2 for j in jobs)
+        lv = np.zeros(tot, np.int32) if want_levels else None
+        self._chk(self.L.hop_tu_roundtrip(self.h, n, ctypes.addressof(arr), ctypes.addressof(res), lv.ctypes.data if want_levels else None), "hop_tu_roundtrip")
+        return [(r.abs_sum, r.sse) for r in res], lv
+
+    def intra_rough(self, jobs):
+        n = len(jobs)
+        arr = (IntraJob * n)(*jobs)
+        out = np.zeros((n, 35), np.uint32)
+        self._chk(self.L.hop_intra_rough(self.h, n, ctypes.addressof(arr), out.ctypes.data), "hop_intra_rough")
         return out
 
     def sync(self):

@@ -157,6 +157,44 @@ int hop_pred_jobs_from_results_device(hop_ctx* ctx, int n, const int32_t* d_inde
  * (TLibCommon/TComRdCost.cpp:477-503). out[i] = distortion of job i. */
 int hop_distortion(hop_ctx* ctx, int n, const hop_dist_job* jobs, uint32_t* out);
 
+/* ---- transform / quantisation round trip (rows a9, a10) and intra rough search (row a7) ---- */
+/* One transform unit: residual = original - prediction picture, forward DCT (DST-VII for use_dst on 4x4) or
+ * transform skip, flat quantisation, dequantisation, inverse transform, reconstruction clip into the context's
+ * reconstruction picture, SSE against the original.
+ * replaces: TComTrQuant::transformNxN / invtransformNxN (TLibCommon/TComTrQuant.cpp:1204-1283) with xTrMxN/xITrMxN
+ * (:786-863), the non-RDOQ branch of xQuant (:1071-1107, flat scaling list, sign-bit hiding off) and xDeQuant
+ * (:1124-1183), in the order TEncSearch::xIntraCodingLumaBlk uses them (TLibEncoder/TEncSearch.cpp:1082-1160).
+ * qp_scaled is what setQPforQuant hands to setQpParam (:192-214); is_i_slice selects the rounding offset 171/85
+ * (an ISS slice is NOT an I slice, :1079). */
+typedef struct {
+  int32_t x, y;            /* luma position of the TU (chroma planes use x/2, y/2) */
+  int32_t comp;            /* 0 Y, 1 Cb, 2 Cr */
+  int32_t log2_size;       /* 2..5 in samples of the plane */
+  int32_t use_dst;         /* 4x4 intra luma: DST-VII (uiMode != REG_DCT, TComTrQuant.cpp:795-799) */
+  int32_t transform_skip;
+  int32_t qp_scaled;
+  int32_t is_i_slice;
+} hop_tu_job;
+typedef struct { uint32_t abs_sum; uint32_t sse; } hop_tu_result;
+/* levels_out (may be NULL): quantised levels of job i at levels_out[sum_{k<i} size_k^2 ...] (TCoeff = int32) */
+int hop_tu_roundtrip(hop_ctx* ctx, int n, const hop_tu_job* jobs, hop_tu_result* results, int32_t* levels_out);
+/* whole reconstruction planes, pitch pic_w (/2): neighbours of the intra search, output of hop_tu_roundtrip */
+int hop_recon_upload(hop_ctx* ctx, int comp, const int16_t* src);
+int hop_pred_upload(hop_ctx* ctx, int comp, const int16_t* src);   /* e.g. an intra prediction made elsewhere */
+int hop_recon_download(hop_ctx* ctx, int comp, int16_t* dst);
+
+/* One luma block of the 35-mode rough search.  flags[u] = availability of 4-sample neighbour unit u in the
+ * reference's bNeighborFlags order (TLibCommon/TComPattern.cpp:202-210): u = 0 bottom-most below-left unit ...
+ * 2*size/4 - 1 top-most left unit, 2*size/4 the corner, then above and above-right left to right.
+ * replaces: initAdiPattern + predIntraLumaAng + calcHAD of TEncSearch::estIntraPredQT (TEncSearch.cpp:2430-2458);
+ * satd_out[35*i + mode]; the caller adds the mode bits (:2460-2461). */
+typedef struct {
+  int32_t x, y, size;      /* size 4..64 */
+  int32_t strong;          /* SPS strong_intra_smoothing */
+  uint8_t flags[68];
+} hop_intra_job;
+int hop_intra_rough(hop_ctx* ctx, int n, const hop_intra_job* jobs, uint32_t* satd_out);
+
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
  * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and
@@ -178,7 +216,9 @@ int hop_enumerate_ctu_jobs(int pic_w, int pic_h, int ctu_addr, int search_range,
 #define HOP_K_PRED      3
 #define HOP_K_COMMIT    4
 #define HOP_K_DIST      5
-#define HOP_K_COUNT     6
+#define HOP_K_TQ        6
+#define HOP_K_INTRA     7
+#define HOP_K_COUNT     8
 int hop_profile_enable(hop_ctx* ctx, int on);
 /* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
 int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);

@@ -325,4 +325,72 @@ void ref_inv_transform(int bitDepth, const int16_t* coeff, int16_t* block, int w
   xITrMxN(bitDepth, &c[0], block, w, h, mode);
 }
 
+// TComTrQuant::xDeQuant (TComTrQuant.cpp:1124-1183), flat scaling list; qpScaled as setQPforQuant hands to setQpParam
+void ref_dequant_flat(int bitDepth, int qpScaled, const int32_t* level, int32_t* coef, int N)
+{
+  g->trq.m_cQP.setQpParam(qpScaled);
+  g->trq.setUseScalingList(false);
+  g->trq.xDeQuant(bitDepth, (const TCoeff*)level, (Int*)coef, N, N, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// intra rough search pieces (row a7): the reference's own fillReferenceSamples, getPredictorPtr, predIntraLumaAng,
+// calcHAD.  The smoothing of TComPattern::initAdiPattern (:237-312) is inline code that needs a TComDataCU/TComPic
+// graph; it is RESTATED here (marked) so that the filtered buffer exists for getPredictorPtr.
+// rec: reconstruction picture sample (0,0) + stride; flags: bNeighborFlags in the reference's order (4N/4+... units).
+// ---------------------------------------------------------------------------------------------
+void ref_intra_rough(const int16_t* rec, int recStride, const int16_t* org, int orgStride, int x, int y, int N,
+                     const uint8_t* flags, int bitDepth, int strong, uint32_t* satd, int predMode, int16_t* predOut, int* lineOut)
+{
+  TEncSearch& s = g->search;
+  const int U = N / 4, units = 4 * U + 1;
+  Bool nb[4 * 16 + 1]; int navail = 0;
+  for (int u = 0; u < units; u++) { nb[u] = flags[u] != 0; navail += nb[u]; }
+  Int* adi = s.m_piYuvExt;
+  const UInt w2 = 2 * N + 1;
+  TComPattern pat;
+  pat.fillReferenceSamples(bitDepth, (Pel*)(rec + (ptrdiff_t)y * recStride + x), adi, nb, navail, 4, U, units, N, N, w2, w2, recStride, false);
+  // ---- RESTATED from TComPattern.cpp:237-312 ----
+  {
+    const UInt uiCuHeight2 = 2 * N, uiCuWidth2 = 2 * N, uiWH = w2 * w2;
+    Int iBufSize = uiCuHeight2 + uiCuWidth2 + 1;
+    Int* piFilteredBuf1 = adi + uiWH; Int* piFilteredBuf2 = piFilteredBuf1 + uiWH;
+    Int* piFilterBuf = piFilteredBuf2 + uiWH; Int* piFilterBufN = piFilterBuf + iBufSize;
+    Int l = 0, i;
+    for (i = 0; i < (Int)uiCuHeight2; i++) piFilterBuf[l++] = adi[w2 * (uiCuHeight2 - i)];
+    piFilterBuf[l++] = adi[0];
+    for (i = 0; i < (Int)uiCuWidth2; i++) piFilterBuf[l++] = adi[1 + i];
+    bool done = false;
+    if (strong) {
+      Int bottomLeft = piFilterBuf[0], topLeft = piFilterBuf[uiCuHeight2], topRight = piFilterBuf[iBufSize - 1];
+      Int threshold = 1 << (bitDepth - 5);
+      Bool bilinearLeft = abs(bottomLeft + topLeft - 2 * piFilterBuf[N]) < threshold;
+      Bool bilinearAbove = abs(topLeft + topRight - 2 * piFilterBuf[uiCuHeight2 + N]) < threshold;
+      if (N >= 32 && bilinearLeft && bilinearAbove) {
+        Int shift = g_aucConvertToBit[N] + 3;
+        piFilterBufN[0] = piFilterBuf[0]; piFilterBufN[uiCuHeight2] = piFilterBuf[uiCuHeight2]; piFilterBufN[iBufSize - 1] = piFilterBuf[iBufSize - 1];
+        for (i = 1; i < (Int)uiCuHeight2; i++) piFilterBufN[i] = ((uiCuHeight2 - i) * bottomLeft + i * topLeft + N) >> shift;
+        for (i = 1; i < (Int)uiCuWidth2; i++) piFilterBufN[uiCuHeight2 + i] = ((uiCuWidth2 - i) * topLeft + i * topRight + N) >> shift;
+        done = true;
+      }
+    }
+    if (!done) {
+      piFilterBufN[0] = piFilterBuf[0]; piFilterBufN[iBufSize - 1] = piFilterBuf[iBufSize - 1];
+      for (i = 1; i < iBufSize - 1; i++) piFilterBufN[i] = (piFilterBuf[i - 1] + 2 * piFilterBuf[i] + piFilterBuf[i + 1] + 2) >> 2;
+    }
+    l = 0;
+    for (i = 0; i < (Int)uiCuHeight2; i++) piFilteredBuf1[w2 * (uiCuHeight2 - i)] = piFilterBufN[l++];
+    piFilteredBuf1[0] = piFilterBufN[l++];
+    for (i = 0; i < (Int)uiCuWidth2; i++) piFilteredBuf1[1 + i] = piFilterBufN[l++];
+    if (lineOut) for (i = 0; i < iBufSize; i++) { lineOut[i] = piFilterBuf[i]; lineOut[iBufSize + i] = piFilterBufN[i]; }
+  }
+  // ---- the reference's own prediction + distortion, as estIntraPredQT does (TEncSearch.cpp:2455-2458) ----
+  std::vector<Pel> pred(N * N);
+  for (UInt m = 0; m < 35; m++) {
+    s.predIntraLumaAng(&pat, m, &pred[0], N, N, N, true, true);
+    satd[m] = g->rd.calcHAD(bitDepth, (Pel*)(org + (ptrdiff_t)y * orgStride + x), orgStride, &pred[0], N, N, N);
+    if ((int)m == predMode && predOut) memcpy(predOut, &pred[0], N * N * sizeof(Pel));
+  }
+}
+
 } // extern "C"

@@ -121,11 +121,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libhophip has no CPU path")
+    # one process per GPU over RCCL; a box with fewer GPUs than ranks (rehearsal only) shares devices and falls back
+    # to gloo for the barrier / MAX reduction -- the data path has no collective either way
+    ndev = torch.cuda.device_count()
+    shared = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     hp = _hophip()
     from hoputil import lambda_for_qp
     W, H = args.width, args.height
@@ -211,7 +219,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = {}
@@ -231,6 +239,15 @@ def main():
         avg_ms = p["total_ms"] / max(1, p["launches"])
         ctus_per_launch = my_ctus * args.steps / max(1, p["launches"])
         achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        # (profiles/r01_traffic.json; PMC counters cannot be read from inside the process)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(dom)
+            if tj and W == FRAME_W and H == FRAME_H and world == 1:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         # honest VALU-side figures (neither HBM nor MFMA binds this path)
         st = 1 + 2
         samples = float(np.sum(st * np.array([gt_iters(int(w), int(h)) for w, h in zip(jobs["w"], jobs["h"])]) * 56.0 * jobs["w"] * jobs["h"]))
@@ -247,7 +264,7 @@ def main():
                                    "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD/CABAC" % (W, H, PITCH, QP, n if world == 1 else -1),
                        "ctus": n_ctu, "pus_rank0": int(n), "parallelism": "ctu-rows-rr%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
                          "note": "VALU-bound path: see valu_fp64 / valu_int for the binding rooflines"},
             "valu_fp64": {"kernel": "k_gt_search", "achieved": gt_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gt_tflops / FP64_VECTOR_PEAK_TFLOPS,

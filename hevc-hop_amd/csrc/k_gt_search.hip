@@ -34,6 +34,7 @@ struct GtShared {
   PT       patch[2 * MAXD * (2 * MAXD + 2)];   // 2H rows x (2W + 2) pitch; element = P[y][x] | P[y][x+1] << (4*sizeof(PT))
   int16_t  org[MAXD * MAXD];
   double   ch[GT_CHUNK][6];      // h0, h3, h6, h1, h4, h7 of the candidates of the current chunk
+  int      cax[GT_CHUNK][2][5];  // GtAxis {A, B, C, aq, ar} of the x and y coordinate of the candidates (exact integer warp)
   uint32_t cfix[GT_CHUNK];       // mv cost + GT bit cost; 0xFFFFFFFF = degenerate (denominator 0), never evaluated by the reference
   int      csatd[GT_CHUNK];
   uint32_t cand_cost[GT_MAXC];
@@ -70,39 +71,77 @@ __device__ static inline void wg_sync() {
   else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: program order + LDS counters suffice; keep the compiler from reordering LDS traffic
 }
 
-struct WarpParams { double h0, h3, h6, h1, h4, h7; };
+// ---------------------------------------------------------------------------------------------------------------
+// The warp in exact integer arithmetic (ProjectiveTransform, TComPrediction.cpp:904-1030, for affine candidates).
+//
+// For an affine candidate on the doubled grid (h[2] = h[5] = +/-0, denominator exactly 1.0)
+//     Fx = fl(fl(fl(h0*x) + fl(h3*y)) + h6),  h0 = fl((x1-x0)/Wd), h3 = fl((x3-x0)/Hd), h6 = x0,  Wd = 2W-1, Hd = 2H-1
+// is the double nearest (to ~1e-13) to the rational  Rx = Nx/D,  Nx = (x1-x0)*Hd*x + (x3-x0)*Wd*y + x0*D,  D = Wd*Hd,
+// and likewise Fy ~ Ny/D.  The reference then takes X = (int)Fx - offX, p = Fx - offX - X, the same for Y / q, clamps
+// X, Y, and rounds the bilinear blend  v = (1-q)((1-p)a + p b) + q((1-p)c + p d)  with (Pel)(clip(v) + 0.5).
+//   * With X from the reference and  rp = Nx - (X+offX)*D  (so rp/D is the exact value p approximates; same for rq),
+//     D^2 * v_exact = (D-rq)((D-rp)a + rp b) + rq((D-rp)c + rp d)  is an integer, and because D is odd v_exact is never
+//     closer than 1/(2 D^2) >= 1.9e-9 to a rounding boundary k + 0.5.  The reference's double v differs from v_exact by
+//     < 2.5e-10 (coordinate error 1.1e-13 x sample range 1023, plus blend rounding), so both round to the same Pel.
+//   * X itself: Rx is at least 1/D from an integer unless it IS one, so (int)Fx = trunc(Rx) except possibly when
+//     Nx % D == 0, where the reference may land on K-1 with p ~ 1.  Inside the patch (K-1, p=1) and (K, p=0) read
+//     the same sample; they differ only where X is clamped.  Truncation differs from floor only for Fx < 0, which
+//     also lies in the clamped region.  So: rows that stay inside the clamp range use the pure integer recurrence;
+//     rows that touch it (rare after the first iteration) take X from the reference's own double expression and
+//     rp = Nx - (X+offX)*D, which covers both effects without case analysis.
+// The blend needs 37 bits, so its last step runs in double -- on integers < 2^53, i.e. exactly.
+// Cost per warped sample: ~25 integer + 7 double-rate VALU operations instead of 33 double-rate + 20 integer.
+// ---------------------------------------------------------------------------------------------------------------
+struct GtAxis { int A, B, C, aq, ar; };      // N(x,y) = A*x + B*y + C ;  A = aq*D + ar, 0 <= ar < D
 
-// one warped sample: ProjectiveTransform, TComPrediction.cpp:919-1025, for h[2] = h[5] = 0 (denominator exactly 1.0)
-template <typename PT>
-__device__ static inline int warp_sample(const WarpParams& hp, double ty, double uy, int gx, int offX, int offY,
-                                         int m, int W, int H, const PT* __restrict__ centre, int PP) {
-  constexpr int HS = 4 * (int)sizeof(PT);                     // bits per sample inside a pair
-  constexpr unsigned HM = (1u << HS) - 1u;
-  double Fx = (hp.h0 * gx + ty + hp.h6);
-  double Fy = (hp.h1 * gx + uy + hp.h7);
-  int Y = (int)Fy - offY, X = (int)Fx - offX;
-  double q = (Fy - offY - (double)Y), p = (Fx - offX - (double)X);
-  // :950-961: clamp to [-m, m+size-1], then pull back by one if the +1 tap would leave  ==  clamp to [-m, m+size-2]
-  Y = min(max(Y, -m), m + H - 2);
-  X = min(max(X, -m), m + W - 2);
-  const PT* pa = centre + (__mul24(Y, PP) + X);
-  const unsigned top = pa[0], bot = pa[PP];
-  double v = (1.0 - q) * ((1.0 - p) * (double)(int)(top & HM) + p * (double)(int)(top >> HS));
-  v += q * ((1.0 - p) * (double)(int)(bot & HM) + p * (double)(int)(bot >> HS));
-  v = __builtin_fmax(__builtin_fmin(v, 255.0), 0.0);          // hard-coded 8-bit clip, :969-972 (v is never NaN: v_min/max_f64 == the two ifs)
-  return (int)(v + 0.5);                                      // (Pel)(aux + 0.5): the value is in [0.5, 255.5]
+__host__ __device__ static inline int floordiv_i(int a, int b) { int q = a / b; return (a % b != 0 && (a < 0) != (b < 0)) ? q - 1 : q; }
+
+// one axis of one row of BS samples: P[k] = clamped integer position relative to the patch centre, R[k] = D * fraction
+template <int BS>
+__device__ static inline void gt_axis(const int* __restrict__ axp, const double* __restrict__ hv, int gx0, int gy, int off, int lo, int hi,
+                                      int D, float rcpD, int (&P)[BS], int (&R)[BS]) {
+  GtAxis ax; ax.A = axp[0]; ax.B = axp[1]; ax.C = axp[2]; ax.aq = axp[3]; ax.ar = axp[4];
+  const int N0 = __mul24(ax.A, gx0) + __mul24(ax.B, gy) + ax.C;      // |N0| < 2^23 (W, H <= 64)
+  int q = (int)floorf((float)N0 * rcpD);                             // floor(N0 / D), off by at most one
+  int r = N0 - __mul24(q, D);
+  if (r < 0) { q--; r += D; } else if (r >= D) { q++; r -= D; }
+  q -= off;
+  P[0] = q; R[0] = r;
+#pragma unroll
+  for (int k = 1; k < BS; k++) {
+    r += ax.ar;
+    const bool ge = r >= D;
+    r -= ge ? D : 0;
+    q += ax.aq + (ge ? 1 : 0);
+    P[k] = q; R[k] = r;
+  }
+  if (min(P[0], P[BS - 1]) <= lo || max(P[0], P[BS - 1]) > hi) {     // the row touches the clamped region
+    const double hA = hv[0], hBy = hv[1] * gy, hC = hv[2];           // reference operation order, :934-947
+#pragma unroll
+    for (int k = 0; k < BS; k++) {
+      const double F = (hA * (gx0 + k) + hBy + hC);
+      const int T = (int)F;
+      R[k] = N0 + __mul24(k, ax.A) - __mul24(T, D);
+      P[k] = min(max(T - off, lo), hi);                              // :950-961: clamp to [-m, m+size-1], pull back by one if the +1 tap would leave
+    }
+  }
 }
 
-// evaluate `nc` candidates (params in sh.ch) over all blocks of the PU; adds block costs into sh.csatd
+// evaluate `nc` candidates (axes in sh.cax, doubles in sh.ch) over all blocks of the PU; adds block costs into sh.csatd
 // BS = 8: 8x8 Hadamard (xCalcHADs8x8, TComRdCost.cpp:1481-1575) ; BS = 4: 4x4 (xCalcHADs4x4, :1387-1479);
 // HAD = false: plain SAD of the same samples (HadamardME = 0)
 template <typename SH, typename PT, int NW, int BS, bool HAD>
 __device__ static inline void gt_eval(SH& sh, int nc, int W, int H, int m, int PP, const PT* __restrict__ centre, int wave, int lane) {
   constexpr int IPW = 64 / BS;                                // items per wave
+  constexpr int HS = 4 * (int)sizeof(PT);                     // bits per sample inside a pair
+  constexpr unsigned HM = (1u << HS) - 1u;
   const int bw = W / BS, nblk = bw * (H / BS), items = nc * nblk;
   const int sub = lane / BS, row = lane % BS;
   const float inv_nblk = 1.0f / (float)nblk, inv_bw = 1.0f / (float)bw;
   const int offX = W / 2, offY = H / 2;                       // offsetX/Y of the doubled grid, :919-920
+  const int D = (2 * W - 1) * (2 * H - 1);
+  const float rcpD = 1.0f / (float)D;
+  const double Dd = (double)D, invD2 = 1.0 / (Dd * Dd);
   const int sgnA = (BS == 8) ? ((row & 4) ? -1 : 1) : ((row & 2) ? -1 : 1);   // stage over the top lane bit (mirror for BS 8)
   const int sgn2 = (row & 2) ? -1 : 1, sgn1 = (row & 1) ? -1 : 1;
   for (int base = wave * IPW; base < items; base += NW * IPW) {
@@ -113,16 +152,23 @@ __device__ static inline void gt_eval(SH& sh, int nc, int W, int H, int m, int P
     const int cand = (int)(((float)it + 0.5f) * inv_nblk), blk = it - cand * nblk;
     const int by = (int)(((float)blk + 0.5f) * inv_bw), bx = blk - by * bw;
     const int py = by * BS + row, px0 = bx * BS;
-    WarpParams hp;
-    hp.h0 = sh.ch[cand][0]; hp.h3 = sh.ch[cand][1]; hp.h6 = sh.ch[cand][2];
-    hp.h1 = sh.ch[cand][3]; hp.h4 = sh.ch[cand][4]; hp.h7 = sh.ch[cand][5];
-    const int gy = py + offY;
-    const double ty = hp.h3 * gy, uy = hp.h4 * gy;            // h[3]*y, h[4]*y : shared by the row
+    int X[BS], rp[BS], Y[BS], rq[BS];
+    gt_axis<BS>(&sh.cax[cand][0][0], &sh.ch[cand][0], px0 + offX, py + offY, offX, -m, m + W - 2, D, rcpD, X, rp);
+    gt_axis<BS>(&sh.cax[cand][1][0], &sh.ch[cand][3], px0 + offX, py + offY, offY, -m, m + H - 2, D, rcpD, Y, rq);
     int d[BS];
     const int16_t* orow = sh.org + py * W + px0;
 #pragma unroll
-    for (int k = 0; k < BS; k++)
-      d[k] = (int)orow[k] - warp_sample<PT>(hp, ty, uy, px0 + k + offX, offX, offY, m, W, H, centre, PP);
+    for (int k = 0; k < BS; k++) {
+      const PT* pa = centre + (__mul24(Y[k], PP) + X[k]);
+      const unsigned top = pa[0], bot = pa[PP];
+      const int omr = D - rp[k];
+      const int t = __mul24((int)(top & HM), omr) + __mul24((int)(top >> HS), rp[k]);     // D * ((1-p) a + p b)
+      const int u = __mul24((int)(bot & HM), omr) + __mul24((int)(bot >> HS), rp[k]);     // D * ((1-p) c + p d)
+      const double nv = __builtin_fma((double)rq[k], (double)(u - t), (double)t * Dd);    // D^2 * v, exact
+      int pel = (int)__builtin_fma(nv, invD2, 0.5);                                       // (Pel)(clip(v) + 0.5), :969-975
+      pel = min(max(pel, 0), 255);                                                        // the hard-coded 8-bit clip
+      d[k] = (int)orow[k] - pel;
+    }
     int s = 0;
     if (HAD) {
       // horizontal butterflies in registers
@@ -290,6 +336,15 @@ __global__ __launch_bounds__(NW * 64) void k_gt_search(const hop_pu_job* __restr
           const double Wd = (double)(2 * W) - 1.0, Hd = (double)(2 * H) - 1.0;
           sh.ch[tid][0] = (double)(x1 - x0) / Wd; sh.ch[tid][1] = (double)(x3 - x0) / Hd; sh.ch[tid][2] = (double)x0;
           sh.ch[tid][3] = (double)(y1 - y0) / Wd; sh.ch[tid][4] = (double)(y3 - y0) / Hd; sh.ch[tid][5] = (double)y0;
+          {                                                     // the same maps as exact rationals over D = Wd*Hd (gt_axis)
+            const int Wi = 2 * W - 1, Hi = 2 * H - 1, Di = Wi * Hi;
+            int aq = floordiv_i(x1 - x0, Wi);
+            sh.cax[tid][0][0] = (x1 - x0) * Hi; sh.cax[tid][0][1] = (x3 - x0) * Wi; sh.cax[tid][0][2] = x0 * Di;
+            sh.cax[tid][0][3] = aq; sh.cax[tid][0][4] = (x1 - x0) * Hi - aq * Di;
+            aq = floordiv_i(y1 - y0, Wi);
+            sh.cax[tid][1][0] = (y1 - y0) * Hi; sh.cax[tid][1][1] = (y3 - y0) * Wi; sh.cax[tid][1][2] = y0 * Di;
+            sh.cax[tid][1][3] = aq; sh.cax[tid][1][4] = (y1 - y0) * Hi - aq * Di;
+          }
           uint32_t bits = hopd_component_bits(x0 / lastStep) + hopd_component_bits(y0 / lastStep)
                         + hopd_component_bits((x1 - 2 * W + 1) / lastStep) + hopd_component_bits(y1 / lastStep)
                         + hopd_component_bits((x2 - 2 * W + 1) / lastStep) + hopd_component_bits((y2 - 2 * H + 1) / lastStep);   // getBitsGT: corners 0..2
@@ -363,11 +418,18 @@ __global__ __launch_bounds__(NW * 64) void k_gt_search(const hop_pu_job* __restr
 __global__ void k_gt_prep(const hop_pu_job* __restrict__ jobs, const hop_pu_result* __restrict__ res, int n,
                           unsigned int* __restrict__ counts, int32_t* __restrict__ small_list, int32_t* __restrict__ big_list) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (res[i].not_valid) return;                               // bNotValCU: xMotionEstimation returned before the GT search
-  const bool small = jobs[i].w <= 16 && jobs[i].h <= 16;
-  unsigned int pos = atomicAdd(counts + (small ? 0 : 1), 1u);
-  (small ? small_list : big_list)[pos] = i;
+  const bool live = i < n && !res[i].not_valid;               // bNotValCU: xMotionEstimation returned before the GT search
+  const bool small = live && jobs[i].w <= 16 && jobs[i].h <= 16;
+  const bool big = live && !small;
+  // one atomic per wave and class (the per-thread version serialised 131072 atomics on two addresses)
+  const unsigned long long ms = __ballot(small), mb = __ballot(big);
+  const int lane = threadIdx.x & 63;
+  unsigned int bs = 0, bb = 0;
+  if (lane == 0) { if (ms) bs = atomicAdd(counts, (unsigned)__popcll(ms)); if (mb) bb = atomicAdd(counts + 1, (unsigned)__popcll(mb)); }
+  bs = __shfl(bs, 0); bb = __shfl(bb, 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (small) small_list[bs + __popcll(ms & below)] = i;
+  if (big)   big_list[bb + __popcll(mb & below)] = i;
 }
 
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {

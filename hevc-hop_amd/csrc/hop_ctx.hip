@@ -60,6 +60,7 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
   c->pic_w = pic_w; c->pic_h = pic_h; c->bd_y = bit_depth_y; c->bd_c = bit_depth_c; c->device = device;
   c->stride_y = pic_w + 2 * HOP_MARGIN_Y; c->stride_c = (pic_w >> 1) + 2 * HOP_MARGIN_C;
+  { const char* f = getenv("HOP_SS_FAMILIES"); c->ss_families = !(f && f[0] == '0'); }   // developer switch: the results do not depend on it
   if (hipSetDevice(device) != hipSuccess) { free(c); return hop_set_err(nullptr, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {

@@ -28,6 +28,7 @@ struct hop_ctx {
   void*  scratch; size_t scratch_bytes;
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
   bool   have_orig;
+  bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
   bool   prof_on;

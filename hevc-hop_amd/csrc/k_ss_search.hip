@@ -131,37 +131,81 @@ __device__ static inline unsigned long long ss_key(const hop_pu_job& jb, int W, 
   return ((unsigned long long)sad << 32) | ((unsigned long long)(uint32_t)(dy - jb.rng_top) << 16) | (uint32_t)(dx - jb.rng_left);
 }
 
-// tile grid of one PU's search window
+// tile grid of a search window [l,r] x [top,bottom] of displacements of a block at column bx, height bh
 struct SsGeom { int x_first, tiles_x, tiles_y, n_main, n_edge, TH; };
-__device__ static inline bool ss_geom(const hop_pu_job& jb, SsGeom& g) {
-  const int win_w = jb.rng_right - jb.rng_left + 1, win_h = jb.rng_bottom - jb.rng_top + 1;
+__device__ static inline bool ss_geom_w(int bx, int bh, int l, int r, int top, int bottom, SsGeom& g) {
+  const int win_w = r - l + 1, win_h = bottom - top + 1;
   if (win_w <= 0 || win_h <= 0) return false;
   // tiles start on an even absolute column so that the staging loads are 4-byte aligned
-  const int xa = (jb.pu_x + jb.rng_left) & ~1;                    // absolute column of tile column 0 (pu_x is a multiple of 4)
-  g.x_first = xa - jb.pu_x;                                       // displacement of tile column 0 (<= rng_left)
-  const int span = jb.rng_right - g.x_first + 1;                  // columns to cover, 1..258
+  const int xa = (bx + l) & ~1;                                   // absolute column of tile column 0 (bx is a multiple of 4)
+  g.x_first = xa - bx;                                            // displacement of tile column 0 (<= l)
+  const int span = r - g.x_first + 1;                             // columns to cover
   g.tiles_x = (span + SS_TW - 1) / SS_TW;
   const int last_w = span - (g.tiles_x - 1) * SS_TW;              // width of the last tile column
   const bool has_edge = last_w <= 2;                              // searched by edge tiles instead
   if (has_edge) g.tiles_x -= 1;
-  g.TH = ss_tile_h(jb.h);
+  g.TH = ss_tile_h(bh);
   g.tiles_y = (win_h + g.TH - 1) / g.TH;
   g.n_main = g.tiles_x * g.tiles_y;
   g.n_edge = has_edge ? (win_h + SS_EDGE_ROWS - 1) / SS_EDGE_ROWS : 0;
   return true;
 }
-__device__ static inline void ss_tile_origin(const hop_pu_job& jb, const SsGeom& g, int t, int& dx0, int& dy0) {
-  if (t < g.n_main) { dx0 = g.x_first + (t % g.tiles_x) * SS_TW; dy0 = jb.rng_top + (t / g.tiles_x) * g.TH; }
-  else { dx0 = g.x_first + g.tiles_x * SS_TW; dy0 = jb.rng_top + (t - g.n_main) * SS_EDGE_ROWS; }
+__device__ static inline void ss_origin_w(const SsGeom& g, int top, int t, int& dx0, int& dy0) {
+  if (t < g.n_main) { dx0 = g.x_first + (t % g.tiles_x) * SS_TW; dy0 = top + (t / g.tiles_x) * g.TH; }
+  else { dx0 = g.x_first + g.tiles_x * SS_TW; dy0 = top + (t - g.n_main) * SS_EDGE_ROWS; }
+}
+__device__ static inline bool ss_geom(const hop_pu_job& jb, SsGeom& g) { return ss_geom_w(jb.pu_x, jb.h, jb.rng_left, jb.rng_right, jb.rng_top, jb.rng_bottom, g); }
+__device__ static inline void ss_tile_origin(const hop_pu_job& jb, const SsGeom& g, int t, int& dx0, int& dy0) { ss_origin_w(g, jb.rng_top, t, dx0, dy0); }
+
+// stage the reference window of a tile (biased +1) and the transposed original block; note whether a sentinel was seen.
+// (bx,by) = block origin, (dx0,dy0) = displacement of the tile origin, W = block width, hs = used rows (every `step`-th)
+__device__ static inline void ss_stage(uint16_t* __restrict__ tile, uint32_t* __restrict__ orgT, const hop_pics& pic, int bx, int by, int dx0, int dy0,
+                                       int rows, int cols, int pitch, int W, int hs, int step, int HS, int wave, int lane, int* has_sentinel) {
+  const int16_t* src = pic.ss_y + (ptrdiff_t)(by + dy0) * pic.stride_y + (bx + dx0);
+  const int cw = cols >> 1;
+  bool zero = false;
+  for (int r = wave; r < rows; r += 4) {
+    const uint32_t* srow = (const uint32_t*)(src + (ptrdiff_t)r * pic.stride_y);
+    uint32_t* trow = (uint32_t*)(tile + (size_t)r * pitch);
+    for (int cdw = lane; cdw < cw; cdw += 64) {
+      uint32_t v = bias_pk(srow[cdw]);                                   // per-half +1 (v_pk_add_u16): -1 -> 0 without a carry into the neighbour
+      zero = zero || ((v & 0xFFFFu) == 0) || ((v >> 16) == 0);
+      trow[cdw] = v;
+    }
+  }
+  if (zero) *has_sentinel = 1;
+  const int16_t* org = pic.org_y + (size_t)by * pic.pic_w + bx;
+  const int np = W >> 1;
+  for (int i = wave * 64 + lane; i < np * hs; i += 256) {
+    int rr = i / np, cp = i - rr * np;                                   // coalesced along the row
+    uint32_t v = *(const uint32_t*)(org + (size_t)(rr * step) * pic.pic_w + 2 * cp);
+    orgT[cp * HS + rr] = v + 0x00010001u;                                // original samples are >= 0: no carry
+  }
 }
 
-// work list: one entry (job << 5 | tile) per tile that is not rejected as a whole by the rule of :6328.
-// Slots are reserved with one atomicAdd per PU; the order of the list is irrelevant (the argmin is order-free).
-__global__ void k_ss_prep(const hop_pu_job* __restrict__ jobs, int n, unsigned int* __restrict__ counter, uint32_t* __restrict__ list,
-                          unsigned long long* __restrict__ best_key) {
+// work lists.  Single PUs: one entry (job << 5 | tile) per tile that is not rejected as a whole by the rule of :6328.
+// CU families (see below): one entry (head job << 8 | tile) per tile of the union window some member can use; the
+// members of an accepted family get no entries of their own.  Slots are reserved with one atomicAdd per PU / family;
+// the order of the lists is irrelevant (the argmin is order-free).
+__device__ static inline bool ss_family_head(const hop_pu_job* __restrict__ jobs, int n, int i, int pic_h);
+__device__ static inline int ss_fam_tiles(const hop_pu_job* __restrict__ head, uint32_t* __restrict__ out, uint32_t tag);
+__global__ void k_ss_prep(const hop_pu_job* __restrict__ jobs, int n, int pic_h, int families, unsigned int* __restrict__ counters,
+                          uint32_t* __restrict__ list, uint32_t* __restrict__ fam_list, unsigned long long* __restrict__ best_key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   best_key[i] = ~0ull;
+  if (families) {
+    int role = -1;
+    for (int k = 0; k < 5 && role < 0; k++) if (ss_family_head(jobs, n, i - k, pic_h)) role = k;
+    if (role > 0) return;                                          // searched with its family
+    if (role == 0) {
+      const int cnt = ss_fam_tiles(jobs + i, nullptr, 0);
+      if (!cnt) return;
+      const unsigned int base = atomicAdd(counters + 1, (unsigned int)cnt);
+      ss_fam_tiles(jobs + i, fam_list + base, (uint32_t)i << 8);
+      return;
+    }
+  }
   const hop_pu_job jb = jobs[i];
   SsGeom g;
   if (!ss_geom(jb, g)) return;
@@ -173,7 +217,7 @@ __global__ void k_ss_prep(const hop_pu_job* __restrict__ jobs, int n, unsigned i
   }
   const int cnt = __popc(keep);
   if (!cnt) return;
-  unsigned int base = atomicAdd(counter, (unsigned int)cnt);
+  unsigned int base = atomicAdd(counters, (unsigned int)cnt);
   for (int t = 0; t < nt; t++) if (keep & (1u << t)) list[base++] = ((uint32_t)i << 5) | (uint32_t)t;
 }
 
@@ -213,28 +257,7 @@ __global__ __launch_bounds__(256) void k_ss_search(const hop_pu_job* __restrict_
   __syncthreads();                                                 // the previous tile's readers are done with LDS
   if (threadIdx.x == 0) has_sentinel = 0;
   __syncthreads();
-  {
-    const int16_t* src = pic.ss_y + (ptrdiff_t)(jb.pu_y + dy0) * pic.stride_y + (jb.pu_x + dx0);
-    const int cw = cols >> 1;
-    bool zero = false;
-    for (int r = wave; r < rows; r += 4) {
-      const uint32_t* srow = (const uint32_t*)(src + (ptrdiff_t)r * pic.stride_y);
-      uint32_t* trow = (uint32_t*)(tile + (size_t)r * pitch);
-      for (int cdw = lane; cdw < cw; cdw += 64) {
-        uint32_t v = bias_pk(srow[cdw]);                                   // per-half +1 (v_pk_add_u16): -1 -> 0 without a carry into the neighbour
-        zero = zero || ((v & 0xFFFFu) == 0) || ((v >> 16) == 0);
-        trow[cdw] = v;
-      }
-    }
-    if (zero) has_sentinel = 1;
-    const int16_t* org = pic.org_y + (size_t)jb.pu_y * pic.pic_w + jb.pu_x;
-    const int np = W >> 1;
-    for (int i = threadIdx.x; i < np * hs; i += 256) {
-      int rr = i / np, cp = i - rr * np;                                   // coalesced along the row
-      uint32_t v = *(const uint32_t*)(org + (size_t)(rr * step) * pic.pic_w + 2 * cp);
-      orgT[cp * HS + rr] = v + 0x00010001u;                                // original samples are >= 0: no carry
-    }
-  }
+  ss_stage(tile, orgT, pic, jb.pu_x, jb.pu_y, dx0, dy0, rows, cols, pitch, W, hs, step, HS, wave, lane, &has_sentinel);
   __syncthreads();
   const bool probe_on = has_sentinel != 0;                          // no sentinel staged -> every probe of this tile is valid
   const int shift_up = sub ? 1 : 0, shift_dn = pic.bd_y - 8;
@@ -278,6 +301,351 @@ __global__ __launch_bounds__(256) void k_ss_search(const hop_pu_job* __restrict_
   }   // work-list loop
 }
 
+// =====================================================================================================================
+// CU families: the five symmetric PUs of one CU (2Nx2N, Nx2N left/right, 2NxN top/bottom) searched in ONE pass.
+//
+// The five PUs cover the same samples, and a displacement d moves all of them by the same amount, so
+//   SAD_PU(d) = sum of the SADs of the CU's four quadrants the PU consists of, at the same d.
+// One pass accumulates the quadrant SADs (with FEN row subsampling: over the even CU rows, which are the even rows
+// of every member because the members start on even rows; for N = 16 the 2NxN members have H = 8 and are not
+// subsampled, so the odd rows of the two halves are accumulated as well) and derives all five costs from them:
+// a third (N = 16: a half) of the v_sad_u16 work of five separate searches, one staging of the window instead of five.
+// Each member keeps its own window, rule offsets (:6328), MV predictor, validity probes and first-best key, so the
+// result of every member is the one the single-PU search gives.
+// Per displacement the five cost evaluations would now outweigh the SADs; they are pruned with a bound that cannot
+// change the result: a displacement whose SAD alone (<= its cost) exceeds the smallest cost already seen for that
+// member is not the minimum, nor tied with it.
+// =====================================================================================================================
+#define SS_FAM 5
+#define SS_FAM_MAX_TILES 255
+#define SS_FAM_CHUNK 4
+#define FAM_NP 4                 // displacement rows per strip: 4 quadrants x 2 columns x FAM_NP accumulators per lane (+ 2 x 2 x FAM_NP odd-row ones for N = 16)
+
+// ox, oy, w, h of member m inside a CU of size S (units of S/2)
+__device__ static inline void fam_member_rect(int m, int S, int& ox, int& oy, int& w, int& h) {
+  const int hf = S >> 1;
+  ox = (m == 2) ? hf : 0; oy = (m == 4) ? hf : 0;
+  w = (m == 1 || m == 2) ? hf : S; h = (m == 3 || m == 4) ? hf : S;
+}
+
+struct FamGeom { int l, r, top, bottom; SsGeom g; int nt; };
+// union window of the members and its tile grid (relative to the CU origin)
+__device__ static inline bool ss_fam_geom(const hop_pu_job* __restrict__ a, FamGeom& f) {
+  int l = 1 << 30, r = -(1 << 30), t = 1 << 30, b = -(1 << 30);
+  for (int m = 0; m < SS_FAM; m++) {
+    const hop_pu_job* j = a + m;
+    if (j->rng_right < j->rng_left || j->rng_bottom < j->rng_top) continue;
+    l = min(l, j->rng_left); r = max(r, j->rng_right); t = min(t, j->rng_top); b = max(b, j->rng_bottom);
+  }
+  f.l = l; f.r = r; f.top = t; f.bottom = b; f.nt = 0;
+  if (l > r) return false;
+  ss_geom_w(a->pu_x, a->h, l, r, t, b, f.g);
+  f.nt = f.g.n_main + f.g.n_edge;
+  return true;
+}
+
+// jobs[i..i+4] are the five symmetric PUs of one CU, in the order of hop_enumerate_ctu_jobs, and can share a pass
+__device__ static inline bool ss_family_head(const hop_pu_job* __restrict__ jobs, int n, int i, int pic_h) {
+  if (i < 0 || i + SS_FAM > n) return false;
+  const hop_pu_job* a = jobs + i;
+  const int S = a->w;
+  if (a->h != S || (S != 8 && S != 16 && S != 32 && S != 64)) return false;
+  for (int m = 1; m < SS_FAM; m++) {
+    int ox, oy, w, h; fam_member_rect(m, S, ox, oy, w, h);
+    const hop_pu_job* b = a + m;
+    if (b->pu_x != a->pu_x + ox || b->pu_y != a->pu_y + oy || b->w != w || b->h != h || b->flags != a->flags) return false;
+  }
+  FamGeom f;
+  if (!ss_fam_geom(a, f)) return true;                           // every window empty: a family without tiles
+  if (f.nt > SS_FAM_MAX_TILES) return false;
+  // the CU-sized window of the union must stay inside the allocation (margin + guard rows), as each member's own does
+  const int lim = HOP_MARGIN_Y + HOP_GUARD_ROWS;
+  if (a->pu_y + f.top < -lim || a->pu_y + f.bottom + S + SS_PROBE > pic_h + lim) return false;
+  return true;
+}
+
+// tiles of the union window that at least one member can use (not rejected as a whole by its rule, and meeting its window);
+// out == nullptr: count only
+__device__ static inline int ss_fam_tiles(const hop_pu_job* __restrict__ head, uint32_t* __restrict__ out, uint32_t tag) {
+  FamGeom f;
+  if (!ss_fam_geom(head, f)) return 0;
+  int cnt = 0;
+  for (int t = 0; t < f.nt; t++) {
+    int dx0, dy0; ss_origin_w(f.g, f.top, t, dx0, dy0);
+    const bool edge = t >= f.g.n_main;
+    const int tw = edge ? 2 : SS_TW, th = edge ? SS_EDGE_ROWS : f.g.TH;
+    bool used = false;
+    for (int m = 0; m < SS_FAM; m++) {
+      const hop_pu_job* j = head + m;
+      if (j->rng_right < j->rng_left || j->rng_bottom < j->rng_top) continue;
+      if (dx0 > j->rng_right || dx0 + tw <= j->rng_left || dy0 > j->rng_bottom || dy0 + th <= j->rng_top) continue;
+      // the smallest displacement of the tile inside the member's window decides the rule for the whole intersection
+      if (max(dx0, j->rng_left) >= j->off_x && max(dy0, j->rng_top) > j->off_y) continue;
+      used = true;
+    }
+    if (used) { if (out) out[cnt] = tag | (uint32_t)t; cnt++; }
+  }
+  return cnt;
+}
+
+// minimum over the wave, wave-uniform result: four DPP steps inside each row of 16 lanes, then the four row minima through SGPRs
+__device__ static inline uint32_t hopd_wave_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+// MODE 0: all rows (no FEN, or N = 8); 1: even rows (FEN, N >= 32); 2: all rows, odd ones apart (FEN, N = 16)
+// q[qy][qx][j][parity of dx] : quadrant SADs of displacement row j ; od[qy][j][parity] : odd rows of the upper / lower half
+template <int MODE> struct FamAcc { uint32_t q[2][2][FAM_NP][2]; uint32_t od[2][FAM_NP][2]; };
+
+// one period (FAM_NP window rows) of one column pair: rows rb .. rb+FAM_NP-1 of the CU against the rotating window
+template <int MODE>
+__device__ __forceinline__ void fam_period(const uint16_t* __restrict__ col, const uint32_t* __restrict__ ocol, int rb, int nrows,
+                                           uint32_t (&e)[FAM_NP], uint32_t (&o)[FAM_NP], uint32_t (&qa)[FAM_NP][2], uint32_t (&od)[FAM_NP][2]) {
+  constexpr int STEP = (MODE == 1) ? 2 : 1, PER = FAM_NP / STEP;
+  uint32_t ov[PER];
+  if (PER == 4) { uint4 t = *(const uint4*)(ocol + rb / STEP); ov[0] = t.x; ov[1] = t.y; ov[PER - 2] = t.z; ov[PER - 1] = t.w; }   // broadcast ds_read_b128
+  else { uint2 t = *(const uint2*)(ocol + rb / STEP); ov[0] = t.x; ov[PER - 1] = t.y; }
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int r = rb + k * STEP;                   // CU row (uniform)
+#pragma unroll
+    for (int j = 0; j < FAM_NP; j++) {
+      const int slot = (k * STEP + j) % FAM_NP;
+      if (MODE == 2 && (k & 1)) { od[j][0] = sad_u16x2(e[slot], ov[k], od[j][0]); od[j][1] = sad_u16x2(o[slot], ov[k], od[j][1]); }
+      else { qa[j][0] = sad_u16x2(e[slot], ov[k], qa[j][0]); qa[j][1] = sad_u16x2(o[slot], ov[k], qa[j][1]); }
+    }
+#pragma unroll
+    for (int s = 0; s < STEP; s++) {               // slide: rows r+NP+s replace rows r+s
+      const int row = r + FAM_NP + s;
+      const int slot = (k * STEP + s) % FAM_NP;
+      // unconditional: the last FAM_NP-1 slides of a block read staged rows that no displacement of the strip uses
+      // (tile row <= TH + N - 1 < SS_ROWS + SS_PROBE), and a branch here would serialise every LDS read
+      uint32_t w0 = *(const uint32_t*)(col + (size_t)row * SS_LS);
+      uint32_t w1 = *(const uint32_t*)(col + (size_t)row * SS_LS + 2);
+      e[slot] = w0; o[slot] = __builtin_amdgcn_alignbit(w1, w0, 16);
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void fam_column(const uint16_t* __restrict__ col, const uint32_t* __restrict__ ocol, int N,
+                                           uint32_t (&qt)[FAM_NP][2], uint32_t (&qb)[FAM_NP][2], uint32_t (&ot)[FAM_NP][2], uint32_t (&ob)[FAM_NP][2]) {
+  uint32_t e[FAM_NP], o[FAM_NP];
+#pragma unroll
+  for (int j = 0; j < FAM_NP; j++) {
+    uint32_t w0 = *(const uint32_t*)(col + (size_t)j * SS_LS);
+    uint32_t w1 = *(const uint32_t*)(col + (size_t)j * SS_LS + 2);
+    e[j] = w0; o[j] = __builtin_amdgcn_alignbit(w1, w0, 16);
+  }
+#pragma unroll 2
+  for (int rb = 0; rb < N / 2; rb += FAM_NP) fam_period<MODE>(col, ocol, rb, N, e, o, qt, ot);     // upper quadrant (N/2 is a multiple of FAM_NP)
+#pragma unroll 2
+  for (int rb = N / 2; rb < N; rb += FAM_NP) fam_period<MODE>(col, ocol, rb, N, e, o, qb, ob);     // lower quadrant, the window keeps rotating
+}
+
+template <int MODE>
+__device__ __forceinline__ void fam_strip(const uint16_t* __restrict__ tile, const uint32_t* __restrict__ orgT, int HS, int N, int strip, int lane, FamAcc<MODE>& A) {
+  const uint16_t* base = tile + (size_t)(strip * FAM_NP) * SS_LS + 2 * lane;
+  const int nh = N >> 2;                           // column pairs per CU half
+  for (int cp = 0; cp < nh; cp++)      fam_column<MODE>(base + 2 * cp, orgT + cp * HS, N, A.q[0][0], A.q[1][0], A.od[0], A.od[1]);
+  for (int cp = nh; cp < 2 * nh; cp++) fam_column<MODE>(base + 2 * cp, orgT + cp * HS, N, A.q[0][1], A.q[1][1], A.od[0], A.od[1]);
+}
+
+// SAD of member m from the quadrant sums, already scaled like the reference's uiSad (<< 1 when subsampled, >> (bitDepth-8))
+template <int MODE>
+__device__ __forceinline__ uint32_t fam_member_sad(int m, uint32_t q00, uint32_t q01, uint32_t q10, uint32_t q11, uint32_t ot, uint32_t ob, int shift_dn) {
+  uint32_t s;
+  switch (m) {
+    case 0: s = q00 + q01 + q10 + q11; break;
+    case 1: s = q00 + q10; break;
+    case 2: s = q01 + q11; break;
+    case 3: s = q00 + q01; if (MODE == 2) s += ot; break;
+    default: s = q10 + q11; if (MODE == 2) s += ob; break;
+  }
+  const int up = (MODE == 1) ? 1 : (MODE == 2 && m < 3) ? 1 : 0;
+  return (s << up) >> shift_dn;
+}
+
+// exact evaluation of one displacement for one member: window, rule of :6328, validity probes, cost, strict '<'
+__device__ __forceinline__ void fam_eval(const hop_pu_job* __restrict__ jm, int dx, int dy, uint32_t sadv, bool probe_ok, uint32_t& bc, uint32_t& bp) {
+  bool ok = dx >= jm->rng_left && dx <= jm->rng_right && dy >= jm->rng_top && dy <= jm->rng_bottom;
+  ok = ok && !((dx >= jm->off_x) && (dy > jm->off_y)) && probe_ok;
+  const uint32_t cost = sadv + ((jm->lambda_cost * (hopd_component_bits(dx * 4 - jm->pred_x) + hopd_component_bits(dy * 4 - jm->pred_y))) >> 16);
+  const bool upd = ok && cost < bc;
+  bc = upd ? cost : bc;
+  bp = upd ? (((uint32_t)(dy - jm->rng_top) << 16) | (uint32_t)(dx - jm->rng_left)) : bp;
+}
+
+template <int MODE>
+__device__ __forceinline__ void fam_main(const hop_pu_job* __restrict__ head, const uint16_t* __restrict__ tile, const uint32_t* __restrict__ orgT,
+                                         int HS, int N, int TH, int dx0, int dy0, int left_u, int right_u, int bottom_u, bool probe_on, int shift_dn, int wave, int lane,
+                                         uint32_t (&bc)[SS_FAM], uint32_t (&bp)[SS_FAM], uint32_t (&wbest)[SS_FAM]) {
+  const int dxe = dx0 + 2 * lane;
+  const bool in_e = dxe >= left_u && dxe <= right_u, in_o = dxe + 1 >= left_u && dxe + 1 <= right_u;   // lanes beyond the window hold stale LDS
+  for (int strip = wave; strip * FAM_NP < TH; strip += 4) {
+    const int wy0 = dy0 + strip * FAM_NP;
+    if (wy0 > bottom_u) break;                                     // strip outside the union window (uniform per wave)
+    bool need = false;                                             // some member has an acceptable displacement in this strip (uniform)
+#pragma unroll
+    for (int m = 0; m < SS_FAM; m++) {
+      const hop_pu_job* jm = head + m;
+      need = need || (wy0 <= jm->rng_bottom && wy0 + FAM_NP > jm->rng_top && dx0 <= jm->rng_right && !(max(dx0, jm->rng_left) >= jm->off_x && max(wy0, jm->rng_top) > jm->off_y));
+    }
+    if (!need) continue;                                           // the reference computes these SADs and throws them away (:6328)
+    FamAcc<MODE> A;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int j = 0; j < FAM_NP; j++) {
+        A.q[a][0][j][0] = A.q[a][0][j][1] = A.q[a][1][j][0] = A.q[a][1][j][1] = 0; A.od[a][j][0] = A.od[a][j][1] = 0;
+      }
+    fam_strip<MODE>(tile, orgT, HS, N, strip, lane, A);
+#pragma unroll
+    for (int j = 0; j < FAM_NP; j++) {
+      const int dy = wy0 + j;
+#pragma unroll
+      for (int m = 0; m < SS_FAM; m++) {
+        const hop_pu_job* jm = head + m;
+        if (dy < jm->rng_top || dy > jm->rng_bottom) continue;     // uniform
+        const uint32_t s0 = fam_member_sad<MODE>(m, A.q[0][0][j][0], A.q[0][1][j][0], A.q[1][0][j][0], A.q[1][1][j][0], A.od[0][j][0], A.od[1][j][0], shift_dn);
+        const uint32_t s1 = fam_member_sad<MODE>(m, A.q[0][0][j][1], A.q[0][1][j][1], A.q[1][0][j][1], A.q[1][1][j][1], A.od[0][j][1], A.od[1][j][1], shift_dn);
+        // cost >= SAD: a SAD above the smallest cost seen so far cannot be (or tie with) the minimum.  Rare once a good match is known.
+        if (!__any((in_e && s0 <= wbest[m]) || (in_o && s1 <= wbest[m]))) continue;
+        bool p0 = true, p1 = true;
+        if (probe_on) {                                            // isValidPattern, TComRdCost.cpp:444-458, at the member's own corner samples
+          int ox, oy, w, h; fam_member_rect(m, N, ox, oy, w, h);
+          const uint16_t* pr = tile + (size_t)(strip * FAM_NP + j + oy + h + 4) * SS_LS + 2 * lane + ox;
+          p0 = (pr[0] != 0) && (pr[w + 4] != 0); p1 = (pr[1] != 0) && (pr[w + 5] != 0);
+        }
+        fam_eval(jm, dxe, dy, s0, p0, bc[m], bp[m]);
+        fam_eval(jm, dxe + 1, dy, s1, p1, bc[m], bp[m]);
+        wbest[m] = min(wbest[m], hopd_wave_min_u32(bc[m]));
+      }
+    }
+  }
+}
+
+// edge tile of a family: lane = displacement row, columns dx0 and dx0+1
+template <int MODE>
+__device__ __forceinline__ void fam_edge_quad(const uint16_t* __restrict__ base, const uint32_t* __restrict__ orgT, int HS, int cp0, int cp1, int rr0, int rr1,
+                                              uint32_t (&q)[2], uint32_t (&od)[2]) {
+  constexpr int STEP = (MODE == 1) ? 2 : 1;
+  for (int cp = cp0; cp < cp1; cp++) {
+    const uint16_t* col = base + 2 * cp;
+    const uint32_t* ocol = orgT + cp * HS;
+    for (int rr = rr0; rr < rr1; rr += (MODE == 2 ? 2 : 1)) {
+      const uint16_t* p = col + (size_t)(rr * STEP) * SS_EDGE_LS;
+      uint32_t w0 = *(const uint32_t*)p, w1 = *(const uint32_t*)(p + 2);
+      uint32_t ov = ocol[rr];
+      q[0] = sad_u16x2(w0, ov, q[0]);
+      q[1] = sad_u16x2(__builtin_amdgcn_alignbit(w1, w0, 16), ov, q[1]);
+      if (MODE == 2) {                             // the odd row that follows
+        p += SS_EDGE_LS; w0 = *(const uint32_t*)p; w1 = *(const uint32_t*)(p + 2); ov = ocol[rr + 1];
+        od[0] = sad_u16x2(w0, ov, od[0]);
+        od[1] = sad_u16x2(__builtin_amdgcn_alignbit(w1, w0, 16), ov, od[1]);
+      }
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void fam_edge(const hop_pu_job* __restrict__ head, const uint16_t* __restrict__ tile, const uint32_t* __restrict__ orgT,
+                                         int HS, int N, int dx0, int wy0, bool probe_on, int shift_dn, int wave, int lane,
+                                         uint32_t (&bc)[SS_FAM], uint32_t (&bp)[SS_FAM]) {
+  constexpr int STEP = (MODE == 1) ? 2 : 1;
+  const uint16_t* base = tile + (size_t)(wave * 64 + lane) * SS_EDGE_LS;
+  const int nh = N >> 2, hs = N / STEP, hh = hs >> 1;
+  uint32_t q[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}}, od[2][2] = {{0, 0}, {0, 0}};
+  fam_edge_quad<MODE>(base, orgT, HS, 0, nh, 0, hh, q[0][0], od[0]);
+  fam_edge_quad<MODE>(base, orgT, HS, nh, 2 * nh, 0, hh, q[0][1], od[0]);
+  fam_edge_quad<MODE>(base, orgT, HS, 0, nh, hh, hs, q[1][0], od[1]);
+  fam_edge_quad<MODE>(base, orgT, HS, nh, 2 * nh, hh, hs, q[1][1], od[1]);
+  const int dy = wy0 + lane;
+#pragma unroll
+  for (int m = 0; m < SS_FAM; m++) {
+    const hop_pu_job* jm = head + m;
+    bool p0 = true, p1 = true;
+    if (probe_on) {
+      int ox, oy, w, h; fam_member_rect(m, N, ox, oy, w, h);
+      const uint16_t* pr = tile + (size_t)(wave * 64 + lane + oy + h + 4) * SS_EDGE_LS + ox;
+      p0 = (pr[0] != 0) && (pr[w + 4] != 0); p1 = (pr[1] != 0) && (pr[w + 5] != 0);
+    }
+    fam_eval(jm, dx0, dy, fam_member_sad<MODE>(m, q[0][0][0], q[0][1][0], q[1][0][0], q[1][1][0], od[0][0], od[1][0], shift_dn), p0, bc[m], bp[m]);
+    fam_eval(jm, dx0 + 1, dy, fam_member_sad<MODE>(m, q[0][0][1], q[0][1][1], q[1][0][1], q[1][1][1], od[0][1], od[1][1], shift_dn), p1, bc[m], bp[m]);
+  }
+}
+
+// persistent workgroups over the family work list: entry = head job << 8 | tile
+__global__ __launch_bounds__(256) void k_ss_family(const hop_pu_job* __restrict__ jobs, hop_pics pic, const unsigned int* __restrict__ counter,
+                                                   const uint32_t* __restrict__ list, unsigned long long* __restrict__ best_key) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[SS_TILE_ELEMS];
+  __shared__ __attribute__((aligned(16))) uint32_t orgT[32 * 64];
+  __shared__ int has_sentinel;
+  const unsigned int total = *counter;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // a workgroup takes SS_FAM_CHUNK consecutive entries (tiles of the same family): the costs its earlier tiles reached prune the later ones
+  for (unsigned int wb = blockIdx.x * SS_FAM_CHUNK; wb < total; wb += gridDim.x * SS_FAM_CHUNK)
+  for (unsigned int wi = wb; wi < min(wb + SS_FAM_CHUNK, total); wi++) {
+    const uint32_t ent = list[wi];
+    const int hidx = (int)(ent >> 8), t = (int)(ent & 255);
+    const hop_pu_job* head = jobs + hidx;
+    const int N = head->w, cu_x = head->pu_x, cu_y = head->pu_y;
+    FamGeom f;
+    ss_fam_geom(head, f);
+    const bool edge = t >= f.g.n_main;
+    const bool fen = (head->flags & HOP_FLAG_FEN) != 0;
+    const int mode = (!fen || N == 8) ? 0 : (N == 16) ? 2 : 1;
+    const int step = (mode == 1) ? 2 : 1;
+    const int hs = N / step, HS = (hs + 7) & ~7;
+    int dx0, dy0, rows, cols, pitch;
+    ss_origin_w(f.g, f.top, t, dx0, dy0);
+    if (!edge) {
+      rows = min(f.g.TH, f.bottom - dy0 + 1) + N - 1 + SS_PROBE;
+      cols = (min(SS_TW, f.r - dx0 + 1) + N + 6) & ~1;
+      pitch = SS_LS;
+    } else {
+      rows = min(SS_EDGE_ROWS, f.bottom - dy0 + 1) + N - 1 + SS_PROBE;
+      cols = N + 6;
+      pitch = SS_EDGE_LS;
+    }
+    __syncthreads();                                               // the previous tile's readers are done with LDS
+    if (threadIdx.x == 0) has_sentinel = 0;
+    __syncthreads();
+    ss_stage(tile, orgT, pic, cu_x, cu_y, dx0, dy0, rows, cols, pitch, N, hs, step, HS, wave, lane, &has_sentinel);
+    __syncthreads();
+    const bool probe_on = has_sentinel != 0;
+    const int shift_dn = pic.bd_y - 8;
+    uint32_t bc[SS_FAM], bp[SS_FAM], wbest[SS_FAM];
+#pragma unroll
+    for (int m = 0; m < SS_FAM; m++) {
+      bc[m] = 0xFFFFFFFFu; bp[m] = 0;
+      wbest[m] = (uint32_t)(__hip_atomic_load(best_key + hidx + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);   // costs other tiles have already reached
+    }
+    if (!edge) {
+      if (mode == 0)      fam_main<0>(head, tile, orgT, HS, N, f.g.TH, dx0, dy0, f.l, f.r, f.bottom, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+      else if (mode == 1) fam_main<1>(head, tile, orgT, HS, N, f.g.TH, dx0, dy0, f.l, f.r, f.bottom, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+      else                fam_main<2>(head, tile, orgT, HS, N, f.g.TH, dx0, dy0, f.l, f.r, f.bottom, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+    } else if (wave < 2 && dy0 + wave * 64 <= f.bottom) {
+      const int wy0 = dy0 + wave * 64;
+      if (mode == 0)      fam_edge<0>(head, tile, orgT, HS, N, dx0, wy0, probe_on, shift_dn, wave, lane, bc, bp);
+      else if (mode == 1) fam_edge<1>(head, tile, orgT, HS, N, dx0, wy0, probe_on, shift_dn, wave, lane, bc, bp);
+      else                fam_edge<2>(head, tile, orgT, HS, N, dx0, wy0, probe_on, shift_dn, wave, lane, bc, bp);
+    }
+#pragma unroll
+    for (int m = 0; m < SS_FAM; m++) {
+      unsigned long long key = bc[m] == 0xFFFFFFFFu ? ~0ull : (((unsigned long long)bc[m] << 32) | bp[m]);
+      key = hopd_wave_min_u64(key);
+      if (lane == 0 && key != ~0ull) atomicMin(best_key + hidx + m, key);
+    }
+  }
+}
+
 __global__ void k_ss_finalize(const hop_pu_job* __restrict__ jobs, const unsigned long long* __restrict__ best_key, hop_pics pic,
                               const int16_t* __restrict__ ss_buf0, hop_pu_result* __restrict__ res, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,19 +672,23 @@ __global__ void k_ss_finalize(const hop_pu_job* __restrict__ jobs, const unsigne
 }
 
 int hop_launch_ss_search(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
-  // scratch: best keys (8 B / PU), the tile counter, the tile work list (<= 27 entries / PU)
-  const size_t o_cnt = (size_t)n * 8, o_list = o_cnt + 256;
-  void* sc; int r = hop_scratch(c, o_list + (size_t)n * SS_MAX_TILES * 4, &sc); if (r) return r;
+  // scratch: best keys (8 B / PU), two counters, the single-PU tile list (<= 27 entries / PU), the family tile list
+  // (<= 255 entries per family of 5 PUs)
+  const size_t o_cnt = (size_t)n * 8, o_list = o_cnt + 256, o_fam = o_list + (size_t)n * SS_MAX_TILES * 4;
+  const size_t fam_cap = ((size_t)n / SS_FAM + 1) * SS_FAM_MAX_TILES;
+  void* sc; int r = hop_scratch(c, o_fam + fam_cap * 4, &sc); if (r) return r;
   unsigned long long* keys = (unsigned long long*)sc;
-  unsigned int* counter = (unsigned int*)((char*)sc + o_cnt);
+  unsigned int* counters = (unsigned int*)((char*)sc + o_cnt);
   uint32_t* list = (uint32_t*)((char*)sc + o_list);
+  uint32_t* fam_list = (uint32_t*)((char*)sc + o_fam);
   hop_pics pic = hop_make_pics(c);
   const int pr = hop_prof_begin(c, HOP_K_SS_SEARCH, (uint64_t)n);
-  (void)hipMemsetAsync(counter, 0, 4, c->stream);
-  hipLaunchKernelGGL(k_ss_prep, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, counter, list, keys);
-  // persistent grid: 3 workgroups per CU fit by LDS (48.6 KB each); a few more rounds of them smooth the tail
+  (void)hipMemsetAsync(counters, 0, 8, c->stream);
+  hipLaunchKernelGGL(k_ss_prep, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, c->pic_h, c->ss_families ? 1 : 0, counters, list, fam_list, keys);
+  // persistent grids: 3 workgroups per CU fit by LDS (48.6 KB each); a few more rounds of them smooth the tail
   const unsigned grid = (unsigned)std::min<size_t>((size_t)n * SS_MAX_TILES, (size_t)256 * 3 * 4);
-  hipLaunchKernelGGL(k_ss_search, dim3(grid), dim3(256), 0, c->stream, d_jobs, pic, counter, list, keys);
+  if (c->ss_families) hipLaunchKernelGGL(k_ss_family, dim3(grid), dim3(256), 0, c->stream, d_jobs, pic, counters + 1, fam_list, keys);
+  hipLaunchKernelGGL(k_ss_search, dim3(grid), dim3(256), 0, c->stream, d_jobs, pic, counters, list, keys);
   hipLaunchKernelGGL(k_ss_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, keys, pic, c->ss_buf[0], d_res, n);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();

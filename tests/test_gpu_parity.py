@@ -191,6 +191,63 @@ def test_me_random_vs_oracle_10bit_and_sad(hp):
         ctx.close()
 
 
+def test_ss_families_vs_oracle(hp):
+    """the five symmetric PUs of a CU handed over adjacently (the order of hop_enumerate_ctu_jobs) are searched in one
+    shared pass: every member must still get exactly the single-PU result (oracle), with a common or with different
+    predictors / windows per member, FEN on and off, 8 and 10 bit, sentinels in the window; and the developer switch
+    HOP_SS_FAMILIES=0 (separate searches) must give the same bytes."""
+    O = oracle()
+    for bd, flags in ((8, hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME), (10, hp.HOP_FLAG_FEN), (8, 0)):
+        W, H = 256, 192
+        Y, Cb, Cr = lenslet(W, H, 14, 77 + bd, bitdepth=bd)
+        rng = np.random.default_rng(500 + bd + flags)
+        pl = Planes(W, H)
+        pl.y00()[:128, :W] = Y[:128]
+        pl.y00()[128:192, :128] = Y[128:192, :128]
+        pl.y00()[70:84, 100:140] = -1                    # a hole of sentinels inside the coded area
+        lam, lc = lambda_for_qp(int(rng.integers(22, 38)))
+        cus = [(128, 128, 64), (64, 128, 64), (128, 128, 32), (160, 160, 32), (128, 128, 16), (176, 144, 16), (240, 176, 16),
+               (128, 128, 8), (200, 136, 8), (0, 128, 8), (248, 184, 8), (128, 0, 16)]
+        jobs = np.zeros(5 * len(cus), hp.PU_JOB_DTYPE)
+        for c, (cuX, cuY, S) in enumerate(cus):
+            h = S // 2
+            common = (int(rng.integers(-50, 50)), int(rng.integers(-200, -30)))
+            for m, (ox, oy, w, hh) in enumerate(((0, 0, S, S), (0, 0, h, S), (h, 0, h, S), (0, 0, S, h), (0, h, S, h))):
+                pred = common if c % 2 == 0 else (int(rng.integers(-60, 60)), int(rng.integers(-220, -20)))
+                o6 = (ctypes.c_int * 6)()
+                O.hop_o_set_search_range(W, H, cuX, cuY, S, (cuY // 64) * 4 + cuX // 64, 4, pred[0], pred[1], 128, ox, oy,
+                                         int(cuY == 0), int(cuX == 0), o6)
+                j = jobs[5 * c + m]
+                j["pu_x"], j["pu_y"], j["w"], j["h"] = cuX + ox, cuY + oy, w, hh
+                j["rng_left"], j["rng_right"], j["rng_top"], j["rng_bottom"], j["off_x"], j["off_y"] = list(o6)
+                j["pred_x"], j["pred_y"], j["lambda_cost"], j["n_amvp"] = pred[0], pred[1], lc, 0
+                j["flags"] = flags
+        outs = []
+        for fam in ("1", "0"):
+            os.environ["HOP_SS_FAMILIES"] = fam
+            try:
+                ctx = hp.Context(W, H, bit_depth=bd)
+            finally:
+                del os.environ["HOP_SS_FAMILIES"]
+            ctx.upload_orig(Y, Cb, Cr)
+            ctx.ssref_upload(0, pl.bufY)
+            outs.append(ctx.me_search(jobs, 1).copy())
+            ctx.close()
+        assert outs[0].tobytes() == outs[1].tobytes()
+        for j, r in zip(jobs, outs[0]):
+            out = (ctypes.c_int64 * 32)()
+            org = np.ascontiguousarray(Y[j["pu_y"]:j["pu_y"] + j["h"], j["pu_x"]:j["pu_x"] + j["w"]])
+            O.hop_o_me_pu(p16(org), int(j["w"]), pl.ptr00(0), pl.sy, int(j["pu_x"]), int(j["pu_y"]), int(j["w"]), int(j["h"]),
+                          int(j["rng_left"]), int(j["rng_right"]), int(j["rng_top"]), int(j["rng_bottom"]), int(j["off_x"]), int(j["off_y"]),
+                          int(j["pred_x"]), int(j["pred_y"]), 0, (ctypes.c_int * 4)(0, 0, 0, 0), lc,
+                          1 if flags & hp.HOP_FLAG_FEN else 0, 1 if flags & hp.HOP_FLAG_HADME else 0, bd, 1, out)
+            want, got = list(out)[:27], _res_row(r)
+            if want[3]:
+                assert got[2:4] == want[2:4], (bd, flags, [int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
+            else:
+                assert got[:4] == want[:4], (bd, flags, [int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
+
+
 def test_distortion_vs_oracle(hp):
     O = oracle()
     W, H = 128, 128

@@ -157,15 +157,17 @@ __device__ static inline void ss_origin_w(const SsGeom& g, int top, int t, int& 
 __device__ static inline bool ss_geom(const hop_pu_job& jb, SsGeom& g) { return ss_geom_w(jb.pu_x, jb.h, jb.rng_left, jb.rng_right, jb.rng_top, jb.rng_bottom, g); }
 __device__ static inline void ss_tile_origin(const hop_pu_job& jb, const SsGeom& g, int t, int& dx0, int& dy0) { ss_origin_w(g, jb.rng_top, t, dx0, dy0); }
 
-// stage the reference window of a tile (biased +1) and the transposed original block; note whether a sentinel was seen.
-// (bx,by) = block origin, (dx0,dy0) = displacement of the tile origin, W = block width, hs = used rows (every `step`-th)
-__device__ static inline void ss_stage(uint16_t* __restrict__ tile, uint32_t* __restrict__ orgT, const hop_pics& pic, int bx, int by, int dx0, int dy0,
-                                       int rows, int cols, int pitch, int W, int hs, int step, int HS, int wave, int lane, int* has_sentinel) {
-  const int16_t* src = pic.ss_y + (ptrdiff_t)(by + dy0) * pic.stride_y + (bx + dx0);
+// stage the reference window of a tile (biased +1); note whether a sentinel was seen.  (x0,y0) = picture position of the
+// tile's first sample.  Rows are clamped into the allocation (margin + guard rows): a clamped row only feeds displacements
+// that lie outside every window a checked job can have.
+__device__ static inline void ss_stage_ref(uint16_t* __restrict__ tile, const hop_pics& pic, int x0, int y0, int rows, int cols, int pitch,
+                                           int wave, int lane, int* has_sentinel) {
+  const int ylo = -(HOP_MARGIN_Y + HOP_GUARD_ROWS) + 1, yhi = pic.pic_h + HOP_MARGIN_Y + HOP_GUARD_ROWS - 2;
   const int cw = cols >> 1;
   bool zero = false;
   for (int r = wave; r < rows; r += 4) {
-    const uint32_t* srow = (const uint32_t*)(src + (ptrdiff_t)r * pic.stride_y);
+    const int y = min(max(y0 + r, ylo), yhi);
+    const uint32_t* srow = (const uint32_t*)(pic.ss_y + (ptrdiff_t)y * pic.stride_y + x0);
     uint32_t* trow = (uint32_t*)(tile + (size_t)r * pitch);
     for (int cdw = lane; cdw < cw; cdw += 64) {
       uint32_t v = bias_pk(srow[cdw]);                                   // per-half +1 (v_pk_add_u16): -1 -> 0 without a carry into the neighbour
@@ -174,6 +176,9 @@ __device__ static inline void ss_stage(uint16_t* __restrict__ tile, uint32_t* __
     }
   }
   if (zero) *has_sentinel = 1;
+}
+// stage one original block transposed to [column pair][used row] (every `step`-th row, hs of them), biased +1
+__device__ static inline void ss_stage_org(uint32_t* __restrict__ orgT, const hop_pics& pic, int bx, int by, int W, int hs, int step, int HS, int wave, int lane) {
   const int16_t* org = pic.org_y + (size_t)by * pic.pic_w + bx;
   const int np = W >> 1;
   for (int i = wave * 64 + lane; i < np * hs; i += 256) {
@@ -182,29 +187,48 @@ __device__ static inline void ss_stage(uint16_t* __restrict__ tile, uint32_t* __
     orgT[cp * HS + rr] = v + 0x00010001u;                                // original samples are >= 0: no carry
   }
 }
+__device__ static inline void ss_stage(uint16_t* __restrict__ tile, uint32_t* __restrict__ orgT, const hop_pics& pic, int bx, int by, int dx0, int dy0,
+                                       int rows, int cols, int pitch, int W, int hs, int step, int HS, int wave, int lane, int* has_sentinel) {
+  ss_stage_ref(tile, pic, bx + dx0, by + dy0, rows, cols, pitch, wave, lane, has_sentinel);
+  ss_stage_org(orgT, pic, bx, by, W, hs, step, HS, wave, lane);
+}
 
 // work lists.  Single PUs: one entry (job << 5 | tile) per tile that is not rejected as a whole by the rule of :6328.
-// CU families (see below): one entry (head job << 8 | tile) per tile of the union window some member can use; the
-// members of an accepted family get no entries of their own.  Slots are reserved with one atomicAdd per PU / family;
-// the order of the lists is irrelevant (the argmin is order-free).
-__device__ static inline bool ss_family_head(const hop_pu_job* __restrict__ jobs, int n, int i, int pic_h);
-__device__ static inline int ss_fam_tiles(const hop_pu_job* __restrict__ head, uint32_t* __restrict__ out, uint32_t tag);
-__global__ void k_ss_prep(const hop_pu_job* __restrict__ jobs, int n, int pic_h, int families, unsigned int* __restrict__ counters,
-                          uint32_t* __restrict__ list, uint32_t* __restrict__ fam_list, unsigned long long* __restrict__ best_key) {
+// CU families (see below) are collected into cells of the picture; the families of a cell share the staged window and
+// get one entry (cell << 8 | tile) per tile of the cell's union window that some member can use; their PUs get no
+// entries of their own.  The order of the lists is irrelevant (the argmin is order-free).
+__device__ static inline bool ss_family_head(const hop_pu_job* __restrict__ jobs, int n, int i);
+__device__ static inline int ss_cell_of(int N, int x, int y, int pic_w, int pic_h, int& cap);
+#define SS_CELL_MAX 16          // families per cell
+#define SS_CELL_MAX_TILES 255    // tiles of a cell's union window (11 when the members share a predictor)
+struct SsCellRec { int N, gx, gy, l, r, top, bottom, nt, flags, cnt; SsGeom g; };     // 16 ints
+
+// pass 1: every family head takes a slot in its cell
+__global__ void k_ss_prep1(const hop_pu_job* __restrict__ jobs, int n, int pic_w, int pic_h, int families, unsigned int* __restrict__ cell_count,
+                           int32_t* __restrict__ cell_members, int32_t* __restrict__ slot_of, unsigned long long* __restrict__ best_key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   best_key[i] = ~0ull;
-  if (families) {
-    int role = -1;
-    for (int k = 0; k < 5 && role < 0; k++) if (ss_family_head(jobs, n, i - k, pic_h)) role = k;
-    if (role > 0) return;                                          // searched with its family
-    if (role == 0) {
-      const int cnt = ss_fam_tiles(jobs + i, nullptr, 0);
-      if (!cnt) return;
-      const unsigned int base = atomicAdd(counters + 1, (unsigned int)cnt);
-      ss_fam_tiles(jobs + i, fam_list + base, (uint32_t)i << 8);
-      return;
-    }
+  int slot = -1;
+  if (families && ss_family_head(jobs, n, i)) {
+    int cap; const int cell = ss_cell_of(jobs[i].w, jobs[i].pu_x, jobs[i].pu_y, pic_w, pic_h, cap);
+    slot = (int)atomicAdd(cell_count + cell, 1u);
+    if (slot < cap) cell_members[cell * SS_CELL_MAX + slot] = i;     // a cell holds each CU position once; duplicates in a batch overflow
+  }
+  slot_of[i] = slot;
+}
+
+// pass 3 (after the cells are built): PUs that are not searched with a cell get their own tiles
+__global__ void k_ss_prep3_singles(const hop_pu_job* __restrict__ jobs, int n, int pic_w, int pic_h, const int32_t* __restrict__ slot_of,
+                           const SsCellRec* __restrict__ cell_rec, unsigned int* __restrict__ counters, uint32_t* __restrict__ list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 5; k++) {
+    const int h = i - k;
+    if (h < 0 || slot_of[h] < 0) continue;                         // slot_of[h] >= 0: h heads a family of jobs h..h+4
+    int cap; const int cell = ss_cell_of(jobs[h].w, jobs[h].pu_x, jobs[h].pu_y, pic_w, pic_h, cap);
+    if (slot_of[h] < cap && cell_rec[cell].cnt > 0) return;        // searched with its cell
+    break;
   }
   const hop_pu_job jb = jobs[i];
   SsGeom g;
@@ -328,64 +352,84 @@ __device__ static inline void fam_member_rect(int m, int S, int& ox, int& oy, in
   w = (m == 1 || m == 2) ? hf : S; h = (m == 3 || m == 4) ? hf : S;
 }
 
-struct FamGeom { int l, r, top, bottom; SsGeom g; int nt; };
-// union window of the members and its tile grid (relative to the CU origin)
-__device__ static inline bool ss_fam_geom(const hop_pu_job* __restrict__ a, FamGeom& f) {
-  int l = 1 << 30, r = -(1 << 30), t = 1 << 30, b = -(1 << 30);
-  for (int m = 0; m < SS_FAM; m++) {
-    const hop_pu_job* j = a + m;
-    if (j->rng_right < j->rng_left || j->rng_bottom < j->rng_top) continue;
-    l = min(l, j->rng_left); r = max(r, j->rng_right); t = min(t, j->rng_top); b = max(b, j->rng_bottom);
-  }
-  f.l = l; f.r = r; f.top = t; f.bottom = b; f.nt = 0;
-  if (l > r) return false;
-  ss_geom_w(a->pu_x, a->h, l, r, t, b, f.g);
-  f.nt = f.g.n_main + f.g.n_edge;
-  return true;
-}
-
-// jobs[i..i+4] are the five symmetric PUs of one CU, in the order of hop_enumerate_ctu_jobs, and can share a pass
-__device__ static inline bool ss_family_head(const hop_pu_job* __restrict__ jobs, int n, int i, int pic_h) {
+// jobs[i..i+4] are the five symmetric PUs of one CU, in the order of hop_enumerate_ctu_jobs
+__device__ static inline bool ss_family_head(const hop_pu_job* __restrict__ jobs, int n, int i) {
   if (i < 0 || i + SS_FAM > n) return false;
   const hop_pu_job* a = jobs + i;
   const int S = a->w;
-  if (a->h != S || (S != 8 && S != 16 && S != 32 && S != 64)) return false;
+  if (a->h != S || (S != 8 && S != 16 && S != 32 && S != 64) || (a->pu_x & (S - 1)) || (a->pu_y & (S - 1))) return false;
   for (int m = 1; m < SS_FAM; m++) {
     int ox, oy, w, h; fam_member_rect(m, S, ox, oy, w, h);
     const hop_pu_job* b = a + m;
     if (b->pu_x != a->pu_x + ox || b->pu_y != a->pu_y + oy || b->w != w || b->h != h || b->flags != a->flags) return false;
   }
-  FamGeom f;
-  if (!ss_fam_geom(a, f)) return true;                           // every window empty: a family without tiles
-  if (f.nt > SS_FAM_MAX_TILES) return false;
-  // the CU-sized window of the union must stay inside the allocation (margin + guard rows), as each member's own does
-  const int lim = HOP_MARGIN_Y + HOP_GUARD_ROWS;
-  if (a->pu_y + f.top < -lim || a->pu_y + f.bottom + S + SS_PROBE > pic_h + lim) return false;
   return true;
 }
 
-// tiles of the union window that at least one member can use (not rejected as a whole by its rule, and meeting its window);
-// out == nullptr: count only
-__device__ static inline int ss_fam_tiles(const hop_pu_job* __restrict__ head, uint32_t* __restrict__ out, uint32_t tag) {
-  FamGeom f;
-  if (!ss_fam_geom(head, f)) return 0;
-  int cnt = 0;
-  for (int t = 0; t < f.nt; t++) {
-    int dx0, dy0; ss_origin_w(f.g, f.top, t, dx0, dy0);
-    const bool edge = t >= f.g.n_main;
-    const int tw = edge ? 2 : SS_TW, th = edge ? SS_EDGE_ROWS : f.g.TH;
-    bool used = false;
+// cells: 64 columns x CH rows of the picture, CH = max(N, 16); the families (CUs of size N) inside one cell share a staged window
+__device__ __host__ static inline int ss_cell_h(int N) { return N < 16 ? 16 : N; }
+__device__ __host__ static inline int ss_cells_total(int pic_w, int pic_h) {
+  const int cx = (pic_w + 63) / 64;
+  return cx * (2 * ((pic_h + 15) / 16) + (pic_h + 31) / 32 + (pic_h + 63) / 64);
+}
+__device__ static inline int ss_cell_of(int N, int x, int y, int pic_w, int pic_h, int& cap) {
+  const int cx = (pic_w + 63) / 64, c16 = (pic_h + 15) / 16, c32 = (pic_h + 31) / 32;
+  const int CH = ss_cell_h(N);
+  const int base = (N == 8) ? 0 : (N == 16) ? cx * c16 : (N == 32) ? 2 * cx * c16 : cx * (2 * c16 + c32);
+  cap = (64 / N) * (CH / N);
+  return base + (y / CH) * cx + (x >> 6);
+}
+
+// pass 2: one thread per cell: union window of all members, tile grid, the tiles some member can use
+__global__ void k_ss_prep2_cells(const hop_pu_job* __restrict__ jobs, int ncells, int pic_w, int pic_h, const unsigned int* __restrict__ cell_count,
+                           const int32_t* __restrict__ cell_members, SsCellRec* __restrict__ cell_rec, unsigned int* __restrict__ counters,
+                           uint32_t* __restrict__ grp_list) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells || cell_count[c] == 0) return;
+  const int32_t* mem = cell_members + c * SS_CELL_MAX;
+  const hop_pu_job* h0 = jobs + mem[0];
+  const int N = h0->w, CH = ss_cell_h(N);
+  const int cap = (64 / N) * (CH / N), cnt = min((int)cell_count[c], cap);
+  SsCellRec rec;
+  rec.N = N; rec.gx = h0->pu_x & ~63; rec.gy = (h0->pu_y / CH) * CH; rec.flags = h0->flags; rec.cnt = cnt; rec.nt = 0;
+  int l = 1 << 30, r = -(1 << 30), t = 1 << 30, b = -(1 << 30);
+  for (int f = 0; f < cnt; f++)
     for (int m = 0; m < SS_FAM; m++) {
-      const hop_pu_job* j = head + m;
+      const hop_pu_job* j = jobs + mem[f] + m;
       if (j->rng_right < j->rng_left || j->rng_bottom < j->rng_top) continue;
-      if (dx0 > j->rng_right || dx0 + tw <= j->rng_left || dy0 > j->rng_bottom || dy0 + th <= j->rng_top) continue;
-      // the smallest displacement of the tile inside the member's window decides the rule for the whole intersection
-      if (max(dx0, j->rng_left) >= j->off_x && max(dy0, j->rng_top) > j->off_y) continue;
-      used = true;
+      l = min(l, j->rng_left); r = max(r, j->rng_right); t = min(t, j->rng_top); b = max(b, j->rng_bottom);
     }
-    if (used) { if (out) out[cnt] = tag | (uint32_t)t; cnt++; }
+  rec.l = l; rec.r = r; rec.top = t; rec.bottom = b;
+  if (l <= r) {
+    ss_geom_w(rec.gx, CH, l, r, t, b, rec.g);
+    rec.nt = rec.g.n_main + rec.g.n_edge;
   }
-  return cnt;
+  if (rec.nt > SS_CELL_MAX_TILES) { rec.cnt = 0; rec.nt = 0; }      // predictors far apart: the members are searched one by one (k_ss_prep2)
+  cell_rec[c] = rec;
+  if (!rec.nt) return;
+  // the tiles some member can use: count, reserve, emit
+  unsigned int base = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    int used_cnt = 0;
+    for (int tt = 0; tt < rec.nt; tt++) {
+      int dx0, dy0; ss_origin_w(rec.g, rec.top, tt, dx0, dy0);
+      const bool edge = tt >= rec.g.n_main;
+      const int tw = edge ? 2 : SS_TW, th = edge ? SS_EDGE_ROWS : rec.g.TH;
+      bool u = false;
+      for (int f = 0; f < cnt && !u; f++)
+        for (int m = 0; m < SS_FAM && !u; m++) {
+          const hop_pu_job* j = jobs + mem[f] + m;
+          if (j->rng_right < j->rng_left || j->rng_bottom < j->rng_top) continue;
+          if (dx0 > j->rng_right || dx0 + tw <= j->rng_left || dy0 > j->rng_bottom || dy0 + th <= j->rng_top) continue;
+          // the smallest displacement of the tile inside the member's window decides the rule for the whole intersection
+          if (max(dx0, j->rng_left) >= j->off_x && max(dy0, j->rng_top) > j->off_y) continue;
+          u = true;
+        }
+      if (u) { if (pass) grp_list[base + used_cnt] = ((uint32_t)c << 8) | (uint32_t)tt; used_cnt++; }
+    }
+    if (!used_cnt) return;
+    if (!pass) base = atomicAdd(counters + 1, (unsigned int)used_cnt);
+  }
 }
 
 // minimum over the wave, wave-uniform result: four DPP steps inside each row of 16 lanes, then the four row minima through SGPRs
@@ -488,16 +532,24 @@ __device__ __forceinline__ void fam_main(const hop_pu_job* __restrict__ head, co
                                          uint32_t (&bc)[SS_FAM], uint32_t (&bp)[SS_FAM], uint32_t (&wbest)[SS_FAM]) {
   const int dxe = dx0 + 2 * lane;
   const bool in_e = dxe >= left_u && dxe <= right_u, in_o = dxe + 1 >= left_u && dxe + 1 <= right_u;   // lanes beyond the window hold stale LDS
-  for (int strip = wave; strip * FAM_NP < TH; strip += 4) {
-    const int wy0 = dy0 + strip * FAM_NP;
-    if (wy0 > bottom_u) break;                                     // strip outside the union window (uniform per wave)
-    bool need = false;                                             // some member has an acceptable displacement in this strip (uniform)
+  // lambda * bits of the horizontal MV component, per member and column (the vertical one is uniform per row):
+  // getCost = (lambda * (bx + by)) >> 16 in 32-bit arithmetic = (lambda*bx + lambda*by) >> 16
+  uint32_t lbx[SS_FAM][2];
+  unsigned needmask = 0;                                           // strips of this wave in which some member has an acceptable displacement
 #pragma unroll
-    for (int m = 0; m < SS_FAM; m++) {
-      const hop_pu_job* jm = head + m;
-      need = need || (wy0 <= jm->rng_bottom && wy0 + FAM_NP > jm->rng_top && dx0 <= jm->rng_right && !(max(dx0, jm->rng_left) >= jm->off_x && max(wy0, jm->rng_top) > jm->off_y));
+  for (int m = 0; m < SS_FAM; m++) {
+    const hop_pu_job* jm = head + m;
+    lbx[m][0] = jm->lambda_cost * hopd_component_bits(dxe * 4 - jm->pred_x);
+    lbx[m][1] = jm->lambda_cost * hopd_component_bits((dxe + 1) * 4 - jm->pred_x);
+    if (dx0 > jm->rng_right) continue;
+    for (int strip = wave, k = 0; strip * FAM_NP < TH; strip += 4, k++) {
+      const int wy0 = dy0 + strip * FAM_NP;
+      if (wy0 <= jm->rng_bottom && wy0 + FAM_NP > jm->rng_top && !(max(dx0, jm->rng_left) >= jm->off_x && max(wy0, jm->rng_top) > jm->off_y)) needmask |= 1u << k;
     }
-    if (!need) continue;                                           // the reference computes these SADs and throws them away (:6328)
+  }
+  for (int strip = wave, k = 0; strip * FAM_NP < TH; strip += 4, k++) {
+    if (!(needmask & (1u << k))) continue;                         // the reference computes these SADs and throws them away (:6328)
+    const int wy0 = dy0 + strip * FAM_NP;
     FamAcc<MODE> A;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -512,11 +564,14 @@ __device__ __forceinline__ void fam_main(const hop_pu_job* __restrict__ head, co
 #pragma unroll
       for (int m = 0; m < SS_FAM; m++) {
         const hop_pu_job* jm = head + m;
-        if (dy < jm->rng_top || dy > jm->rng_bottom) continue;     // uniform
+        // uniform per row: lambda * bits of the vertical component; rows outside the member's window get a cost no minimum has
+        const uint32_t lby = jm->lambda_cost * hopd_component_bits(dy * 4 - jm->pred_y);
+        const uint32_t rowpen = (dy < jm->rng_top || dy > jm->rng_bottom) ? 0x40000000u : 0u;
         const uint32_t s0 = fam_member_sad<MODE>(m, A.q[0][0][j][0], A.q[0][1][j][0], A.q[1][0][j][0], A.q[1][1][j][0], A.od[0][j][0], A.od[1][j][0], shift_dn);
         const uint32_t s1 = fam_member_sad<MODE>(m, A.q[0][0][j][1], A.q[0][1][j][1], A.q[1][0][j][1], A.q[1][1][j][1], A.od[0][j][1], A.od[1][j][1], shift_dn);
-        // cost >= SAD: a SAD above the smallest cost seen so far cannot be (or tie with) the minimum.  Rare once a good match is known.
-        if (!__any((in_e && s0 <= wbest[m]) || (in_o && s1 <= wbest[m]))) continue;
+        const uint32_t c0 = s0 + ((lbx[m][0] + lby) >> 16) + rowpen, c1 = s1 + ((lbx[m][1] + lby) >> 16) + rowpen;
+        // only a cost at or below the smallest one seen so far can be (or tie with) the first-best: rare after the first rows
+        if (!__any((in_e && c0 <= wbest[m]) || (in_o && c1 <= wbest[m]))) continue;
         bool p0 = true, p1 = true;
         if (probe_on) {                                            // isValidPattern, TComRdCost.cpp:444-458, at the member's own corner samples
           int ox, oy, w, h; fam_member_rect(m, N, ox, oy, w, h);
@@ -559,7 +614,7 @@ __device__ __forceinline__ void fam_edge(const hop_pu_job* __restrict__ head, co
                                          int HS, int N, int dx0, int wy0, bool probe_on, int shift_dn, int wave, int lane,
                                          uint32_t (&bc)[SS_FAM], uint32_t (&bp)[SS_FAM]) {
   constexpr int STEP = (MODE == 1) ? 2 : 1;
-  const uint16_t* base = tile + (size_t)(wave * 64 + lane) * SS_EDGE_LS;
+  const uint16_t* base = tile + (size_t)(wave * 64 + lane) * SS_EDGE_LS;             // `wave` = which 64-row half of the edge tile
   const int nh = N >> 2, hs = N / STEP, hh = hs >> 1;
   uint32_t q[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}}, od[2][2] = {{0, 0}, {0, 0}};
   fam_edge_quad<MODE>(base, orgT, HS, 0, nh, 0, hh, q[0][0], od[0]);
@@ -581,67 +636,98 @@ __device__ __forceinline__ void fam_edge(const hop_pu_job* __restrict__ head, co
   }
 }
 
-// persistent workgroups over the family work list: entry = head job << 8 | tile
+// fold a wave's best of one member into the global key; skipped when the wave has nothing that could win
+__device__ __forceinline__ void fam_flush(unsigned long long* __restrict__ best_key, uint32_t bc, uint32_t bp, int lane) {
+  const uint32_t wm = hopd_wave_min_u32(bc);
+  if (wm == 0xFFFFFFFFu) return;                                   // uniform
+  if (wm > (uint32_t)(__hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32)) return;
+  unsigned long long key = bc == 0xFFFFFFFFu ? ~0ull : (((unsigned long long)bc << 32) | bp);
+  key = hopd_wave_min_u64(key);
+  if (lane == 0) atomicMin(best_key, key);
+}
+
+// persistent workgroups over the cell work list: entry = cell << 8 | tile.  One staging of the reference window
+// (128 + 64 columns, TH + CH - 1 rows) serves every family of the cell; the waves then walk (family, strip) pairs
+// without further barriers.
 __global__ __launch_bounds__(256) void k_ss_family(const hop_pu_job* __restrict__ jobs, hop_pics pic, const unsigned int* __restrict__ counter,
-                                                   const uint32_t* __restrict__ list, unsigned long long* __restrict__ best_key) {
+                                                   const uint32_t* __restrict__ list, const SsCellRec* __restrict__ cell_rec,
+                                                   const int32_t* __restrict__ cell_members, unsigned long long* __restrict__ best_key) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[SS_TILE_ELEMS];
   __shared__ __attribute__((aligned(16))) uint32_t orgT[32 * 64];
   __shared__ int has_sentinel;
   const unsigned int total = *counter;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // a workgroup takes SS_FAM_CHUNK consecutive entries (tiles of the same family): the costs its earlier tiles reached prune the later ones
-  for (unsigned int wb = blockIdx.x * SS_FAM_CHUNK; wb < total; wb += gridDim.x * SS_FAM_CHUNK)
-  for (unsigned int wi = wb; wi < min(wb + SS_FAM_CHUNK, total); wi++) {
+  for (unsigned int wi = blockIdx.x; wi < total; wi += gridDim.x) {
     const uint32_t ent = list[wi];
-    const int hidx = (int)(ent >> 8), t = (int)(ent & 255);
-    const hop_pu_job* head = jobs + hidx;
-    const int N = head->w, cu_x = head->pu_x, cu_y = head->pu_y;
-    FamGeom f;
-    ss_fam_geom(head, f);
-    const bool edge = t >= f.g.n_main;
-    const bool fen = (head->flags & HOP_FLAG_FEN) != 0;
+    const int cell = (int)(ent >> 8), t = (int)(ent & 255);
+    const SsCellRec* cr = cell_rec + cell;
+    const int32_t* mem = cell_members + cell * SS_CELL_MAX;
+    const int N = cr->N, cnt = cr->cnt, gx = cr->gx, gy = cr->gy, CH = ss_cell_h(N);
+    SsGeom g = cr->g;
+    const int l_u = cr->l, r_u = cr->r, top_u = cr->top, bottom_u = cr->bottom;
+    const bool edge = t >= g.n_main;
+    const bool fen = (cr->flags & HOP_FLAG_FEN) != 0;
     const int mode = (!fen || N == 8) ? 0 : (N == 16) ? 2 : 1;
     const int step = (mode == 1) ? 2 : 1;
-    const int hs = N / step, HS = (hs + 7) & ~7;
+    const int hs = N / step, HS = (hs + 7) & ~7, fstride = (N >> 1) * HS;      // dwords of one family's transposed original
     int dx0, dy0, rows, cols, pitch;
-    ss_origin_w(f.g, f.top, t, dx0, dy0);
+    ss_origin_w(g, top_u, t, dx0, dy0);
     if (!edge) {
-      rows = min(f.g.TH, f.bottom - dy0 + 1) + N - 1 + SS_PROBE;
-      cols = (min(SS_TW, f.r - dx0 + 1) + N + 6) & ~1;
+      rows = min(g.TH, bottom_u - dy0 + 1) + CH - 1 + SS_PROBE;
+      cols = (min(SS_TW, r_u - dx0 + 1) + 64 + 6) & ~1;
       pitch = SS_LS;
     } else {
-      rows = min(SS_EDGE_ROWS, f.bottom - dy0 + 1) + N - 1 + SS_PROBE;
-      cols = N + 6;
+      rows = min(SS_EDGE_ROWS, bottom_u - dy0 + 1) + CH - 1 + SS_PROBE;
+      cols = 64 + 6;
       pitch = SS_EDGE_LS;
     }
     __syncthreads();                                               // the previous tile's readers are done with LDS
     if (threadIdx.x == 0) has_sentinel = 0;
     __syncthreads();
-    ss_stage(tile, orgT, pic, cu_x, cu_y, dx0, dy0, rows, cols, pitch, N, hs, step, HS, wave, lane, &has_sentinel);
+    ss_stage_ref(tile, pic, gx + dx0, gy + dy0, rows, cols, pitch, wave, lane, &has_sentinel);
+    for (int f = 0; f < cnt; f++) {
+      const hop_pu_job* head = jobs + mem[f];
+      ss_stage_org(orgT + f * fstride, pic, head->pu_x, head->pu_y, N, hs, step, HS, wave, lane);
+    }
     __syncthreads();
     const bool probe_on = has_sentinel != 0;
     const int shift_dn = pic.bd_y - 8;
-    uint32_t bc[SS_FAM], bp[SS_FAM], wbest[SS_FAM];
-#pragma unroll
-    for (int m = 0; m < SS_FAM; m++) {
-      bc[m] = 0xFFFFFFFFu; bp[m] = 0;
-      wbest[m] = (uint32_t)(__hip_atomic_load(best_key + hidx + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);   // costs other tiles have already reached
-    }
     if (!edge) {
-      if (mode == 0)      fam_main<0>(head, tile, orgT, HS, N, f.g.TH, dx0, dy0, f.l, f.r, f.bottom, probe_on, shift_dn, wave, lane, bc, bp, wbest);
-      else if (mode == 1) fam_main<1>(head, tile, orgT, HS, N, f.g.TH, dx0, dy0, f.l, f.r, f.bottom, probe_on, shift_dn, wave, lane, bc, bp, wbest);
-      else                fam_main<2>(head, tile, orgT, HS, N, f.g.TH, dx0, dy0, f.l, f.r, f.bottom, probe_on, shift_dn, wave, lane, bc, bp, wbest);
-    } else if (wave < 2 && dy0 + wave * 64 <= f.bottom) {
-      const int wy0 = dy0 + wave * 64;
-      if (mode == 0)      fam_edge<0>(head, tile, orgT, HS, N, dx0, wy0, probe_on, shift_dn, wave, lane, bc, bp);
-      else if (mode == 1) fam_edge<1>(head, tile, orgT, HS, N, dx0, wy0, probe_on, shift_dn, wave, lane, bc, bp);
-      else                fam_edge<2>(head, tile, orgT, HS, N, dx0, wy0, probe_on, shift_dn, wave, lane, bc, bp);
-    }
+      for (int f = 0; f < cnt; f++) {
+        const int hidx = mem[f];
+        const hop_pu_job* head = jobs + hidx;
+        const uint16_t* tf = tile + (size_t)(head->pu_y - gy) * SS_LS + (head->pu_x - gx);
+        const uint32_t* of = orgT + f * fstride;
+        uint32_t bc[SS_FAM], bp[SS_FAM], wbest[SS_FAM];
 #pragma unroll
-    for (int m = 0; m < SS_FAM; m++) {
-      unsigned long long key = bc[m] == 0xFFFFFFFFu ? ~0ull : (((unsigned long long)bc[m] << 32) | bp[m]);
-      key = hopd_wave_min_u64(key);
-      if (lane == 0 && key != ~0ull) atomicMin(best_key + hidx + m, key);
+        for (int m = 0; m < SS_FAM; m++) {
+          bc[m] = 0xFFFFFFFFu; bp[m] = 0;
+          wbest[m] = (uint32_t)(__hip_atomic_load(best_key + hidx + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);   // costs other tiles have already reached
+        }
+        if (mode == 0)      fam_main<0>(head, tf, of, HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+        else if (mode == 1) fam_main<1>(head, tf, of, HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+        else                fam_main<2>(head, tf, of, HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+#pragma unroll
+        for (int m = 0; m < SS_FAM; m++) fam_flush(best_key + hidx + m, bc[m], bp[m], lane);
+      }
+    } else {
+      for (int item = wave; item < 2 * cnt; item += 4) {           // (family, 64-row half of the edge tile)
+        const int f = item >> 1, half = item & 1;
+        if (dy0 + half * 64 > bottom_u) continue;
+        const int hidx = mem[f];
+        const hop_pu_job* head = jobs + hidx;
+        const uint16_t* tf = tile + (size_t)(head->pu_y - gy) * SS_EDGE_LS + (head->pu_x - gx);
+        const uint32_t* of = orgT + f * fstride;
+        uint32_t bc[SS_FAM], bp[SS_FAM];
+#pragma unroll
+        for (int m = 0; m < SS_FAM; m++) { bc[m] = 0xFFFFFFFFu; bp[m] = 0; }
+        const int wy0 = dy0 + half * 64;
+        if (mode == 0)      fam_edge<0>(head, tf, of, HS, N, dx0, wy0, probe_on, shift_dn, half, lane, bc, bp);
+        else if (mode == 1) fam_edge<1>(head, tf, of, HS, N, dx0, wy0, probe_on, shift_dn, half, lane, bc, bp);
+        else                fam_edge<2>(head, tf, of, HS, N, dx0, wy0, probe_on, shift_dn, half, lane, bc, bp);
+#pragma unroll
+        for (int m = 0; m < SS_FAM; m++) fam_flush(best_key + hidx + m, bc[m], bp[m], lane);
+      }
     }
   }
 }
@@ -672,22 +758,33 @@ __global__ void k_ss_finalize(const hop_pu_job* __restrict__ jobs, const unsigne
 }
 
 int hop_launch_ss_search(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
-  // scratch: best keys (8 B / PU), two counters, the single-PU tile list (<= 27 entries / PU), the family tile list
-  // (<= 255 entries per family of 5 PUs)
-  const size_t o_cnt = (size_t)n * 8, o_list = o_cnt + 256, o_fam = o_list + (size_t)n * SS_MAX_TILES * 4;
-  const size_t fam_cap = ((size_t)n / SS_FAM + 1) * SS_FAM_MAX_TILES;
-  void* sc; int r = hop_scratch(c, o_fam + fam_cap * 4, &sc); if (r) return r;
+  // scratch: best keys (8 B / PU), counters, the single-PU tile list (<= 27 entries / PU), slot of every family head,
+  // the cells (count, members, record) and the cell tile list
+  const int ncells = ss_cells_total(c->pic_w, c->pic_h);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_cnt = al((size_t)n * 8), o_list = o_cnt + 256, o_slot = al(o_list + (size_t)n * SS_MAX_TILES * 4), o_ccnt = al(o_slot + (size_t)n * 4);
+  const size_t o_cmem = al(o_ccnt + (size_t)ncells * 4), o_crec = al(o_cmem + (size_t)ncells * SS_CELL_MAX * 4), o_glist = al(o_crec + (size_t)ncells * sizeof(SsCellRec));
+  const size_t glist_cap = (size_t)std::min<size_t>((size_t)n / SS_FAM + 1, (size_t)ncells) * SS_CELL_MAX_TILES;
+  void* sc; int r = hop_scratch(c, o_glist + glist_cap * 4, &sc); if (r) return r;
   unsigned long long* keys = (unsigned long long*)sc;
   unsigned int* counters = (unsigned int*)((char*)sc + o_cnt);
   uint32_t* list = (uint32_t*)((char*)sc + o_list);
-  uint32_t* fam_list = (uint32_t*)((char*)sc + o_fam);
+  int32_t* slot_of = (int32_t*)((char*)sc + o_slot);
+  unsigned int* cell_count = (unsigned int*)((char*)sc + o_ccnt);
+  int32_t* cell_members = (int32_t*)((char*)sc + o_cmem);
+  SsCellRec* cell_rec = (SsCellRec*)((char*)sc + o_crec);
+  uint32_t* grp_list = (uint32_t*)((char*)sc + o_glist);
   hop_pics pic = hop_make_pics(c);
+  const int fam = c->ss_families ? 1 : 0;
   const int pr = hop_prof_begin(c, HOP_K_SS_SEARCH, (uint64_t)n);
   (void)hipMemsetAsync(counters, 0, 8, c->stream);
-  hipLaunchKernelGGL(k_ss_prep, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, c->pic_h, c->ss_families ? 1 : 0, counters, list, fam_list, keys);
+  if (fam) (void)hipMemsetAsync(cell_count, 0, (size_t)ncells * 4, c->stream);
+  hipLaunchKernelGGL(k_ss_prep1, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, c->pic_w, c->pic_h, fam, cell_count, cell_members, slot_of, keys);
+  if (fam) hipLaunchKernelGGL(k_ss_prep2_cells, dim3((ncells + 255) / 256), dim3(256), 0, c->stream, d_jobs, ncells, c->pic_w, c->pic_h, cell_count, cell_members, cell_rec, counters, grp_list);
+  hipLaunchKernelGGL(k_ss_prep3_singles, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, c->pic_w, c->pic_h, slot_of, cell_rec, counters, list);
   // persistent grids: 3 workgroups per CU fit by LDS (48.6 KB each); a few more rounds of them smooth the tail
   const unsigned grid = (unsigned)std::min<size_t>((size_t)n * SS_MAX_TILES, (size_t)256 * 3 * 4);
-  if (c->ss_families) hipLaunchKernelGGL(k_ss_family, dim3(grid), dim3(256), 0, c->stream, d_jobs, pic, counters + 1, fam_list, keys);
+  if (fam) hipLaunchKernelGGL(k_ss_family, dim3(grid), dim3(256), 0, c->stream, d_jobs, pic, counters + 1, grp_list, cell_rec, cell_members, keys);
   hipLaunchKernelGGL(k_ss_search, dim3(grid), dim3(256), 0, c->stream, d_jobs, pic, counters, list, keys);
   hipLaunchKernelGGL(k_ss_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, keys, pic, c->ss_buf[0], d_res, n);
   hop_prof_end(c, pr);

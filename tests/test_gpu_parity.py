@@ -248,6 +248,63 @@ def test_ss_families_vs_oracle(hp):
                 assert got[:4] == want[:4], (bd, flags, [int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
 
 
+def test_ss_family_cells_vs_oracle(hp):
+    """whole-CTU enumerations (425 PUs each, hop_enumerate_ctu_jobs): the CUs of equal size inside a 64-column cell of the
+    picture share one staged window; one CTU with a common predictor, one with a different predictor per PU, next to the
+    uncoded (sentinel) area.  Every PU against the oracle, and the developer switch must not change a byte."""
+    O = oracle()
+    W, H, bd = 256, 192, 8
+    flags = hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME
+    Y, Cb, Cr = lenslet(W, H, 14, 91, bitdepth=bd)
+    rng = np.random.default_rng(4242)
+    pl = Planes(W, H)
+    pl.y00()[:128, :W] = Y[:128]
+    pl.y00()[128:192, :128] = Y[128:192, :128]
+    lam, lc = lambda_for_qp(30)
+    L = hp.load()
+    parts = []
+    for ctu, vary in ((2 * 4 + 2, False), (1 * 4 + 3, True)):
+        buf = np.zeros(425, hp.PU_JOB_DTYPE)
+        n = L.hop_enumerate_ctu_jobs(W, H, ctu, 128, (ctypes.c_int * 2)(4, -72), 0, None, lc, flags, 0, buf.ctypes.data, None, 425)
+        assert n == 425
+        if vary:
+            cuX, cuY = (ctu % 4) * 64, (ctu // 4) * 64
+            for j in buf:
+                pred = (int(rng.integers(-40, 40)), int(rng.integers(-120, -40)))
+                w, h = int(j["w"]), int(j["h"]); S = max(w, h)
+                cx, cy = int(j["pu_x"]) // S * S, int(j["pu_y"]) // S * S
+                o6 = (ctypes.c_int * 6)()
+                O.hop_o_set_search_range(W, H, cx, cy, S, ctu, 4, pred[0], pred[1], 128, int(j["pu_x"]) - cx, int(j["pu_y"]) - cy,
+                                         int(cy == 0), int(cx == 0), o6)
+                j["rng_left"], j["rng_right"], j["rng_top"], j["rng_bottom"], j["off_x"], j["off_y"] = list(o6)
+                j["pred_x"], j["pred_y"] = pred
+        parts.append(buf)
+    jobs = np.concatenate(parts)
+    outs = []
+    for fam in ("1", "0"):
+        os.environ["HOP_SS_FAMILIES"] = fam
+        try:
+            ctx = hp.Context(W, H, bit_depth=bd)
+        finally:
+            del os.environ["HOP_SS_FAMILIES"]
+        ctx.upload_orig(Y, Cb, Cr)
+        ctx.ssref_upload(0, pl.bufY)
+        outs.append(ctx.me_search(jobs, 1).copy())
+        ctx.close()
+    assert outs[0].tobytes() == outs[1].tobytes()
+    for j, r in zip(jobs, outs[0]):
+        out = (ctypes.c_int64 * 32)()
+        org = np.ascontiguousarray(Y[j["pu_y"]:j["pu_y"] + j["h"], j["pu_x"]:j["pu_x"] + j["w"]])
+        O.hop_o_me_pu(p16(org), int(j["w"]), pl.ptr00(0), pl.sy, int(j["pu_x"]), int(j["pu_y"]), int(j["w"]), int(j["h"]),
+                      int(j["rng_left"]), int(j["rng_right"]), int(j["rng_top"]), int(j["rng_bottom"]), int(j["off_x"]), int(j["off_y"]),
+                      int(j["pred_x"]), int(j["pred_y"]), 0, (ctypes.c_int * 4)(0, 0, 0, 0), lc, 1, 1, bd, 1, out)
+        want, got = list(out)[:27], _res_row(r)
+        if want[3]:
+            assert got[2:4] == want[2:4], ([int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
+        else:
+            assert got[:4] == want[:4], ([int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
+
+
 def test_distortion_vs_oracle(hp):
     O = oracle()
     W, H = 128, 128

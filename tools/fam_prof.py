@@ -16,7 +16,9 @@ wctu, hctu = W // 64, H // 64
 pred = (ctypes.c_int * 2)(0, -60); amvp = (ctypes.c_int * 4)(0, -60, -60, 0)
 print("cu   njobs  fam_ms  single_ms")
 res = {}
-for fam in ("1", "0"):
+SIZES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (64, 32, 16, 8)
+MODES = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("1", "0")
+for fam in MODES:
     os.environ["HOP_SS_FAMILIES"] = fam
     ctx = hp.Context(W, H); L = ctx.L
     ctx.upload_orig(Y.cpu().numpy(), Cb.cpu().numpy(), Cr.cpu().numpy())
@@ -28,7 +30,7 @@ for fam in ("1", "0"):
         n += L.hop_enumerate_ctu_jobs(W, H, a, 128, pred, 2, amvp, lc, 3, 0, jobs.ctypes.data + n * jobs.itemsize, None, cap - n)
     jobs = jobs[:n]
     cu = np.maximum(jobs["w"], jobs["h"])
-    for S in (64, 32, 16, 8):
+    for S in SIZES:
         sel = np.ascontiguousarray(jobs[cu == S])
         dj = torch.from_numpy(sel.view(np.uint8)).to(dev)
         dr = torch.zeros(len(sel) * hp.PU_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -40,5 +42,6 @@ for fam in ("1", "0"):
         L.hop_profile_enable(ctx.h, 0)
         res[(S, fam)] = (len(sel), t.value, dr.cpu().numpy().tobytes())
     ctx.close()
-for S in (64, 32, 16, 8):
-    print("%2d %7d %7.2f %7.2f %s" % (S, res[(S, "1")][0], res[(S, "1")][1], res[(S, "0")][1], "same" if res[(S, "1")][2] == res[(S, "0")][2] else "DIFFERENT"))
+for S in SIZES:
+    a, b = res.get((S, "1")), res.get((S, "0"))
+    print("%2d %7d %7.2f %7.2f %s" % (S, (a or b)[0], a[1] if a else -1, b[1] if b else -1, "" if not (a and b) else "same" if a[2] == b[2] else "DIFFERENT"))

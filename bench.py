@@ -268,8 +268,12 @@ def main():
                          "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
                          "note": "VALU-bound path: see valu_fp64 / valu_int for the binding rooflines"},
             "valu_fp64": {"kernel": "k_gt_search", "achieved": gt_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gt_tflops / FP64_VECTOR_PEAK_TFLOPS,
-                          "flop_per_warped_sample": WARP_FLOP_PER_SAMPLE},
-            "valu_int": {"kernel": "k_ss_search", "achieved": ss_tops, "peak": INT_VALU_PEAK_TOPS, "unit": "T v_sad_u16 lane-op/s", "frac": ss_tops / INT_VALU_PEAK_TOPS},
+                          "flop_per_warped_sample": WARP_FLOP_PER_SAMPLE, "warped_samples_per_s": gt_tflops * 1e12 / WARP_FLOP_PER_SAMPLE,
+                          "note": "reference-equivalent work (24 double flops per warped sample in the reference's formulation); the kernel evaluates the "
+                                  "same warp in exact integer arithmetic, about 7 double-rate + 30 integer VALU operations per sample"},
+            "valu_int": {"kernel": "k_ss_search", "achieved": ss_tops, "peak": INT_VALU_PEAK_TOPS, "unit": "T v_sad_u16 lane-op/s", "frac": ss_tops / INT_VALU_PEAK_TOPS,
+                         "note": "reference-equivalent work (one full search per PU); CU families derive the five symmetric PUs of a CU from one set of "
+                                 "quadrant SADs, so about a third of these v_sad_u16 are executed"},
             "kernels": prof,
             "result_crc": int(np.bitwise_xor.reduce(res_host["cost"].astype(np.uint64) * np.arange(1, len(res_host) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)),
         }

@@ -37,6 +37,8 @@ struct GtShared {
   int      cax[GT_CHUNK][2][5];  // GtAxis {A, B, C, aq, ar} of the x and y coordinate of the candidates (exact integer warp)
   uint32_t cfix[GT_CHUNK];       // mv cost + GT bit cost; 0xFFFFFFFF = degenerate (denominator 0), never evaluated by the reference
   int      csatd[GT_CHUNK];
+  uint8_t  alive[GT_CHUNK];      // candidates of the chunk still below the incumbent (early termination in rounds of blocks)
+  int      n_alive;
   uint32_t cand_cost[GT_MAXC];
   uint16_t cand_list[GT_MAXC];
   uint16_t fixed_list[GT_CHUNK]; // the 56 combinations with d0 + d2 == d1 + d3 (parallelogram centres)
@@ -130,14 +132,15 @@ __device__ static inline void gt_axis(const int* __restrict__ axp, const double*
 // evaluate `nc` candidates (axes in sh.cax, doubles in sh.ch) over all blocks of the PU; adds block costs into sh.csatd
 // BS = 8: 8x8 Hadamard (xCalcHADs8x8, TComRdCost.cpp:1481-1575) ; BS = 4: 4x4 (xCalcHADs4x4, :1387-1479);
 // HAD = false: plain SAD of the same samples (HadamardME = 0)
+// One ROUND: blocks blk0 .. blk0+bpr-1 of the `na` candidates listed in sh.alive.
 template <typename SH, typename PT, int NW, int BS, bool HAD>
-__device__ static inline void gt_eval(SH& sh, int nc, int W, int H, int m, int PP, const PT* __restrict__ centre, int wave, int lane) {
+__device__ static inline void gt_eval(SH& sh, int na, int blk0, int bpr, int W, int H, int m, int PP, const PT* __restrict__ centre, int wave, int lane) {
   constexpr int IPW = 64 / BS;                                // items per wave
   constexpr int HS = 4 * (int)sizeof(PT);                     // bits per sample inside a pair
   constexpr unsigned HM = (1u << HS) - 1u;
-  const int bw = W / BS, nblk = bw * (H / BS), items = nc * nblk;
+  const int bw = W / BS, items = na * bpr;
   const int sub = lane / BS, row = lane % BS;
-  const float inv_nblk = 1.0f / (float)nblk, inv_bw = 1.0f / (float)bw;
+  const float inv_bpr = 1.0f / (float)bpr, inv_bw = 1.0f / (float)bw;
   const int offX = W / 2, offY = H / 2;                       // offsetX/Y of the doubled grid, :919-920
   const int D = (2 * W - 1) * (2 * H - 1);
   const float rcpD = 1.0f / (float)D;
@@ -149,7 +152,8 @@ __device__ static inline void gt_eval(SH& sh, int nc, int W, int H, int m, int P
     const bool act = item < items;
     const int it = act ? item : 0;
     // small exact quotients without integer division: (i + 0.5) / n in float is off an integer by >= 0.5/64 >> rounding error (i < 4096)
-    const int cand = (int)(((float)it + 0.5f) * inv_nblk), blk = it - cand * nblk;
+    const int ai = (int)(((float)it + 0.5f) * inv_bpr), blk = blk0 + it - ai * bpr;
+    const int cand = sh.alive[ai];
     const int by = (int)(((float)blk + 0.5f) * inv_bw), bx = blk - by * bw;
     const int py = by * BS + row, px0 = bx * BS;
     int X[BS], rp[BS], Y[BS], rq[BS];
@@ -353,13 +357,30 @@ __global__ __launch_bounds__(NW * 64) void k_gt_search(const hop_pu_job* __restr
           sh.csatd[tid] = 0;
         }
         wg_sync<NW>();
-        if (!use_had) {
-          if (had8) gt_eval<SH, PT, NW, 8, false>(sh, nc, W, H, m, PP, centre, wave, lane);
-          else      gt_eval<SH, PT, NW, 4, false>(sh, nc, W, H, m, PP, centre, wave, lane);
-        } else if (had8) gt_eval<SH, PT, NW, 8, true>(sh, nc, W, H, m, PP, centre, wave, lane);
-        else             gt_eval<SH, PT, NW, 4, true>(sh, nc, W, H, m, PP, centre, wave, lane);
-        wg_sync<NW>();
-        if (tid < nc) sh.cand_cost[c0 + tid] = sh.cfix[tid] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((uint32_t)sh.csatd[tid] >> (pic.bd_y - 8)) + sh.cfix[tid];
+        // ---- evaluation in rounds of blocks with exact early termination: block costs are non-negative, so a
+        //      candidate whose partial cost has reached the incumbent cannot become the first-best (strict '<', :5361) ----
+        const int shift_dn = pic.bd_y - 8;
+        const int nblk = had8 ? (W >> 3) * (H >> 3) : (W >> 2) * (H >> 2);
+        const int R = (nblk % 8 == 0 && nblk >= 16) ? 8 : (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1, bpr = nblk / R;
+        for (int r = 0; r < R; r++) {
+          if (wave == 0) {                                     // (re)build the list of candidates still in the race; order is irrelevant
+            const bool keep = lane < nc && sh.cfix[lane] != 0xFFFFFFFFu && ((uint32_t)sh.csatd[lane] >> shift_dn) + sh.cfix[lane] < distBest;
+            const unsigned long long mk = __ballot(keep);
+            if (keep) sh.alive[__popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            if (lane == 0) sh.n_alive = __popcll(mk);
+          }
+          wg_sync<NW>();
+          const int na = sh.n_alive;
+          if (na == 0) break;                                  // uniform
+          if (!use_had) {
+            if (had8) gt_eval<SH, PT, NW, 8, false>(sh, na, r * bpr, bpr, W, H, m, PP, centre, wave, lane);
+            else      gt_eval<SH, PT, NW, 4, false>(sh, na, r * bpr, bpr, W, H, m, PP, centre, wave, lane);
+          } else if (had8) gt_eval<SH, PT, NW, 8, true>(sh, na, r * bpr, bpr, W, H, m, PP, centre, wave, lane);
+          else             gt_eval<SH, PT, NW, 4, true>(sh, na, r * bpr, bpr, W, H, m, PP, centre, wave, lane);
+          wg_sync<NW>();
+        }
+        // a candidate that left the race keeps a partial cost >= the incumbent: it cannot win, which is all that matters
+        if (tid < nc) sh.cand_cost[c0 + tid] = sh.cfix[tid] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((uint32_t)sh.csatd[tid] >> shift_dn) + sh.cfix[tid];
         wg_sync<NW>();
       }
       // ---- first-best in visit order, strict '<' against the incumbent (:5361) ----

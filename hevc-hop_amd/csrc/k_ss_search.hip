@@ -526,28 +526,54 @@ __device__ __forceinline__ void fam_eval(const hop_pu_job* __restrict__ jm, int 
   bp = upd ? (((uint32_t)(dy - jm->rng_top) << 16) | (uint32_t)(dx - jm->rng_left)) : bp;
 }
 
+#define FAM_TAB_ROWS 24           // displacement rows one wave handles per family and tile: (TH / FAM_NP / 4 strips, rounded up) * FAM_NP <= 20
 template <int MODE>
 __device__ __forceinline__ void fam_main(const hop_pu_job* __restrict__ head, const uint16_t* __restrict__ tile, const uint32_t* __restrict__ orgT,
-                                         int HS, int N, int TH, int dx0, int dy0, int left_u, int right_u, int bottom_u, bool probe_on, int shift_dn, int wave, int lane,
+                                         uint2* __restrict__ rowtab, int HS, int N, int TH, int dx0, int dy0, int left_u, int right_u, int bottom_u,
+                                         bool probe_on, int shift_dn, int wave, int lane,
                                          uint32_t (&bc)[SS_FAM], uint32_t (&bp)[SS_FAM], uint32_t (&wbest)[SS_FAM]) {
   const int dxe = dx0 + 2 * lane;
   const bool in_e = dxe >= left_u && dxe <= right_u, in_o = dxe + 1 >= left_u && dxe + 1 <= right_u;   // lanes beyond the window hold stale LDS
-  // lambda * bits of the horizontal MV component, per member and column (the vertical one is uniform per row):
+  const int nstrips = TH / FAM_NP, nst = (nstrips - wave + 3) >> 2;       // strips wave, wave+4, ... of this wave
+  // lambda * bits of the horizontal MV component, per member and column:
   // getCost = (lambda * (bx + by)) >> 16 in 32-bit arithmetic = (lambda*bx + lambda*by) >> 16
   uint32_t lbx[SS_FAM][2];
-  unsigned needmask = 0;                                           // strips of this wave in which some member has an acceptable displacement
 #pragma unroll
   for (int m = 0; m < SS_FAM; m++) {
     const hop_pu_job* jm = head + m;
     lbx[m][0] = jm->lambda_cost * hopd_component_bits(dxe * 4 - jm->pred_x);
     lbx[m][1] = jm->lambda_cost * hopd_component_bits((dxe + 1) * 4 - jm->pred_x);
-    if (dx0 > jm->rng_right) continue;
-    for (int strip = wave, k = 0; strip * FAM_NP < TH; strip += 4, k++) {
-      const int wy0 = dy0 + strip * FAM_NP;
-      if (wy0 <= jm->rng_bottom && wy0 + FAM_NP > jm->rng_top && !(max(dx0, jm->rng_left) >= jm->off_x && max(wy0, jm->rng_top) > jm->off_y)) needmask |= 1u << k;
-    }
   }
-  for (int strip = wave, k = 0; strip * FAM_NP < TH; strip += 4, k++) {
+  // per (member, row of this wave): lambda * bits of the vertical component and a penalty for rows outside the member's
+  // window -- computed once, one entry per lane, instead of by every lane for every row (the values are wave-uniform
+  // but come from memory, so the compiler would run them on the vector unit)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // the previous family's readers of this wave's table are done (in-order LDS)
+  for (int e = lane; e < SS_FAM * nst * FAM_NP; e += 64) {
+    const int m = e / (nst * FAM_NP), k = e - m * (nst * FAM_NP);
+    const int dy = dy0 + (wave + 4 * (k / FAM_NP)) * FAM_NP + (k % FAM_NP);
+    const hop_pu_job* jm = head + m;
+    uint2 t;
+    t.x = jm->lambda_cost * hopd_component_bits(dy * 4 - jm->pred_y);
+    t.y = (dy < jm->rng_top || dy > jm->rng_bottom) ? 0x40000000u : 0u;
+    rowtab[m * FAM_TAB_ROWS + k] = t;
+  }
+  // strips of this wave in which some member has an acceptable displacement: one (member, strip) pair per lane
+  unsigned needmask = 0;
+  {
+    bool need = false;
+    if (lane < SS_FAM * nst) {
+      const int m = lane / nst, k = lane - m * nst;
+      const hop_pu_job* jm = head + m;
+      const int wy0 = dy0 + (wave + 4 * k) * FAM_NP;
+      need = dx0 <= jm->rng_right && wy0 <= jm->rng_bottom && wy0 + FAM_NP > jm->rng_top &&
+             !(max(dx0, jm->rng_left) >= jm->off_x && max(wy0, jm->rng_top) > jm->off_y);
+    }
+    const unsigned long long bal = __ballot(need);
+#pragma unroll
+    for (int m = 0; m < SS_FAM; m++) needmask |= (unsigned)(bal >> (m * nst)) & ((1u << nst) - 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int strip = wave, k = 0; strip < nstrips; strip += 4, k++) {
     if (!(needmask & (1u << k))) continue;                         // the reference computes these SADs and throws them away (:6328)
     const int wy0 = dy0 + strip * FAM_NP;
     FamAcc<MODE> A;
@@ -561,25 +587,30 @@ __device__ __forceinline__ void fam_main(const hop_pu_job* __restrict__ head, co
 #pragma unroll
     for (int j = 0; j < FAM_NP; j++) {
       const int dy = wy0 + j;
+      uint32_t sv[SS_FAM][2];
+      unsigned tm = 0;                                             // per lane: members for which one of its two displacements can still be the first-best
 #pragma unroll
       for (int m = 0; m < SS_FAM; m++) {
+        const uint2 rt = rowtab[m * FAM_TAB_ROWS + k * FAM_NP + j];      // broadcast read: lambda*by, row penalty
+        sv[m][0] = fam_member_sad<MODE>(m, A.q[0][0][j][0], A.q[0][1][j][0], A.q[1][0][j][0], A.q[1][1][j][0], A.od[0][j][0], A.od[1][j][0], shift_dn);
+        sv[m][1] = fam_member_sad<MODE>(m, A.q[0][0][j][1], A.q[0][1][j][1], A.q[1][0][j][1], A.q[1][1][j][1], A.od[0][j][1], A.od[1][j][1], shift_dn);
+        const uint32_t c0 = sv[m][0] + ((lbx[m][0] + rt.x) >> 16) + rt.y, c1 = sv[m][1] + ((lbx[m][1] + rt.x) >> 16) + rt.y;
+        // only a cost at or below the smallest one seen so far can be (or tie with) the first-best
+        tm |= ((in_e && c0 <= wbest[m]) || (in_o && c1 <= wbest[m])) ? (1u << m) : 0u;
+      }
+      if (!__any(tm != 0)) continue;                               // the common case after the first rows: one branch per row
+#pragma unroll
+      for (int m = 0; m < SS_FAM; m++) {
+        if (!__any((tm >> m) & 1u)) continue;
         const hop_pu_job* jm = head + m;
-        // uniform per row: lambda * bits of the vertical component; rows outside the member's window get a cost no minimum has
-        const uint32_t lby = jm->lambda_cost * hopd_component_bits(dy * 4 - jm->pred_y);
-        const uint32_t rowpen = (dy < jm->rng_top || dy > jm->rng_bottom) ? 0x40000000u : 0u;
-        const uint32_t s0 = fam_member_sad<MODE>(m, A.q[0][0][j][0], A.q[0][1][j][0], A.q[1][0][j][0], A.q[1][1][j][0], A.od[0][j][0], A.od[1][j][0], shift_dn);
-        const uint32_t s1 = fam_member_sad<MODE>(m, A.q[0][0][j][1], A.q[0][1][j][1], A.q[1][0][j][1], A.q[1][1][j][1], A.od[0][j][1], A.od[1][j][1], shift_dn);
-        const uint32_t c0 = s0 + ((lbx[m][0] + lby) >> 16) + rowpen, c1 = s1 + ((lbx[m][1] + lby) >> 16) + rowpen;
-        // only a cost at or below the smallest one seen so far can be (or tie with) the first-best: rare after the first rows
-        if (!__any((in_e && c0 <= wbest[m]) || (in_o && c1 <= wbest[m]))) continue;
         bool p0 = true, p1 = true;
         if (probe_on) {                                            // isValidPattern, TComRdCost.cpp:444-458, at the member's own corner samples
           int ox, oy, w, h; fam_member_rect(m, N, ox, oy, w, h);
           const uint16_t* pr = tile + (size_t)(strip * FAM_NP + j + oy + h + 4) * SS_LS + 2 * lane + ox;
           p0 = (pr[0] != 0) && (pr[w + 4] != 0); p1 = (pr[1] != 0) && (pr[w + 5] != 0);
         }
-        fam_eval(jm, dxe, dy, s0, p0, bc[m], bp[m]);
-        fam_eval(jm, dxe + 1, dy, s1, p1, bc[m], bp[m]);
+        fam_eval(jm, dxe, dy, sv[m][0], p0, bc[m], bp[m]);
+        fam_eval(jm, dxe + 1, dy, sv[m][1], p1, bc[m], bp[m]);
         wbest[m] = min(wbest[m], hopd_wave_min_u32(bc[m]));
       }
     }
@@ -649,12 +680,13 @@ __device__ __forceinline__ void fam_flush(unsigned long long* __restrict__ best_
 // persistent workgroups over the cell work list: entry = cell << 8 | tile.  One staging of the reference window
 // (128 + 64 columns, TH + CH - 1 rows) serves every family of the cell; the waves then walk (family, strip) pairs
 // without further barriers.
-__global__ __launch_bounds__(256) void k_ss_family(const hop_pu_job* __restrict__ jobs, hop_pics pic, const unsigned int* __restrict__ counter,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ss_family(const hop_pu_job* __restrict__ jobs, hop_pics pic, const unsigned int* __restrict__ counter,
                                                    const uint32_t* __restrict__ list, const SsCellRec* __restrict__ cell_rec,
                                                    const int32_t* __restrict__ cell_members, unsigned long long* __restrict__ best_key) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[SS_TILE_ELEMS];
   __shared__ __attribute__((aligned(16))) uint32_t orgT[32 * 64];
   __shared__ int has_sentinel;
+  __shared__ uint2 rowtab_all[4][SS_FAM * FAM_TAB_ROWS];          // per wave: (lambda*by, row penalty) of the rows it handles for the current family
   const unsigned int total = *counter;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (unsigned int wi = blockIdx.x; wi < total; wi += gridDim.x) {
@@ -704,9 +736,9 @@ __global__ __launch_bounds__(256) void k_ss_family(const hop_pu_job* __restrict_
           bc[m] = 0xFFFFFFFFu; bp[m] = 0;
           wbest[m] = (uint32_t)(__hip_atomic_load(best_key + hidx + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);   // costs other tiles have already reached
         }
-        if (mode == 0)      fam_main<0>(head, tf, of, HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
-        else if (mode == 1) fam_main<1>(head, tf, of, HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
-        else                fam_main<2>(head, tf, of, HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+        if (mode == 0)      fam_main<0>(head, tf, of, rowtab_all[wave], HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+        else if (mode == 1) fam_main<1>(head, tf, of, rowtab_all[wave], HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
+        else                fam_main<2>(head, tf, of, rowtab_all[wave], HS, N, g.TH, dx0, dy0, l_u, r_u, bottom_u, probe_on, shift_dn, wave, lane, bc, bp, wbest);
 #pragma unroll
         for (int m = 0; m < SS_FAM; m++) fam_flush(best_key + hidx + m, bc[m], bp[m], lane);
       }

@@ -119,6 +119,7 @@ __device__ static inline int hopd_satd4x4_quad(int d, int lane) {
 int hop_launch_ss_search(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
 int hop_launch_frac(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
+void hop_launch_size_classes(hop_ctx* c, int n, const hop_pu_job* d_jobs, const hop_pu_result* d_res, void* sc);
 int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs);
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out);
 int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off);

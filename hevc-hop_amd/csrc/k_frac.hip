@@ -16,20 +16,34 @@ __constant__ int16_t c_luma_taps[4][8] = {
 __constant__ int8_t c_refine_h[9][2] = { {0,0},{0,-1},{0,1},{-1,0},{1,0},{-1,-1},{1,-1},{-1,1},{1,1} };   // TEncSearch.cpp:46-57
 __constant__ int8_t c_refine_q[9][2] = { {0,0},{0,-1},{0,1},{-1,-1},{1,-1},{-1,0},{1,0},{-1,1},{1,1} };   // TEncSearch.cpp:59-70
 
-#define FR_TP 74        // integer window pitch  (W+8 <= 72)
-#define FR_PP 66        // phase plane pitch     (W   <= 64)
-
+// MAXD = largest PU side of the class: 16 (one wave per PU, no barriers: such a PU is a few hundred samples and the
+// fixed latencies of a 256-thread workgroup -- five barriers, 47 KB of LDS, 3 workgroups per CU -- dominated) or 64
+template <int MAXD>
 struct FracShared {
-  int16_t win[72 * FR_TP];          // rows -4..H+3, cols -4..W+3 of the reference at the integer vector
-  int16_t plane[3][72 * FR_PP];     // horizontal intermediates (14-bit), rows -4..H+3
-  int16_t org[64 * 64];
+  static constexpr int TP = MAXD + 10;            // integer window pitch  (W+8 <= MAXD+8)
+  static constexpr int PP = MAXD + 2;             // phase plane pitch
+  int16_t win[(MAXD + 8) * TP];                   // rows -4..H+3, cols -4..W+3 of the reference at the integer vector
+  int16_t plane[3][(MAXD + 8) * PP];              // horizontal intermediates (14-bit), rows -4..H+3
+  int16_t org[MAXD * MAXD];
   int cand[9];
 };
 
-__global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ jobs, hop_pics pic, hop_pu_result* __restrict__ res) {
-  __shared__ FracShared sh;
-  const hop_pu_job jb = jobs[blockIdx.x];
-  hop_pu_result rr = res[blockIdx.x];
+template <int NW>
+__device__ static inline void fr_sync() {
+  if (NW > 1) __syncthreads();
+  else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: program order + LDS counters suffice
+}
+
+template <int NW, int MAXD>
+__global__ __launch_bounds__(NW * 64) void k_frac(const hop_pu_job* __restrict__ jobs, hop_pics pic, hop_pu_result* __restrict__ res,
+                                                  const int32_t* __restrict__ index, const unsigned int* __restrict__ count) {
+  typedef FracShared<MAXD> SH;
+  constexpr int FR_TP = SH::TP, FR_PP = SH::PP, NT = NW * 64;
+  __shared__ SH sh;
+  if (blockIdx.x >= *count) return;
+  const int pu = index[blockIdx.x];
+  const hop_pu_job jb = jobs[pu];
+  hop_pu_result rr = res[pu];
   if (rr.not_valid) return;
   const int W = jb.w, H = jb.h, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int bd = pic.bd_y, headRoom = 14 - bd, maxVal = (1 << bd) - 1;
@@ -38,11 +52,11 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
   const int mvx = rr.mv_int[0], mvy = rr.mv_int[1];
   {
     const int16_t* src = pic.ss_y + (ptrdiff_t)(jb.pu_y + mvy - 4) * pic.stride_y + (jb.pu_x + mvx - 4);
-    for (int i = tid; i < (H + 8) * (W + 8); i += 256) {
+    for (int i = tid; i < (H + 8) * (W + 8); i += NT) {
       int r = i / (W + 8), c = i - r * (W + 8);
       sh.win[r * FR_TP + c] = src[(ptrdiff_t)r * pic.stride_y + c];
     }
-    for (int i = tid; i < W * H; i += 256) {
+    for (int i = tid; i < W * H; i += NT) {
       int r = i / W, c = i - r * W;
       sh.org[i] = pic.org_y[(size_t)(jb.pu_y + r) * pic.pic_w + jb.pu_x + c];
     }
@@ -53,10 +67,10 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
     // stage 0: half-pel, candidates (2*hx, 2*hy); stage 1: quarter-pel around the half-pel winner
     const int step = stage == 0 ? 2 : 1;
     const int fxc = stage == 0 ? 0 : 2 * half[0], fyc = stage == 0 ? 0 : 2 * half[1];
-    __syncthreads();
+    fr_sync<NW>();
     if (tid < 9) sh.cand[tid] = 0;
     // ---- three horizontal phase planes: fx = fxc + (p-1)*step ----
-    for (int i = tid; i < 3 * (H + 8) * W; i += 256) {
+    for (int i = tid; i < 3 * (H + 8) * W; i += NT) {
       const int p = i / ((H + 8) * W), rem = i - p * (H + 8) * W;
       const int r = rem / W, c = rem - r * W;
       const int fx = fxc + (p - 1) * step;
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
       }
       sh.plane[p][r * FR_PP + c] = out;
     }
-    __syncthreads();
+    fr_sync<NW>();
     // ---- (candidate, block) units ----
     auto sample = [&](int ci, int px, int py) -> int {
       const int8_t* rf = stage == 0 ? c_refine_h[ci] : c_refine_q[ci];
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
     };
     if (!use_had) {
       const int per = (W * H + 63) >> 6;                              // 64-sample groups per candidate
-      for (int u = wave; u < 9 * per; u += 4) {
+      for (int u = wave; u < 9 * per; u += NW) {
         const int ci = u / per, g = u - ci * per;
         const int i = g * 64 + lane;
         const bool act = i < W * H;
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
       }
     } else if (had8) {
       const int per = (W * H) >> 6, bw = W >> 3;
-      for (int u = wave; u < 9 * per; u += 4) {
+      for (int u = wave; u < 9 * per; u += NW) {
         const int ci = u / per, blk = u - ci * per;
         const int px = (blk % bw) * 8 + (lane & 7), py = (blk / bw) * 8 + (lane >> 3);
         int d = (int)sh.org[py * W + px] - sample(ci, px, py);
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
       }
     } else {
       const int nb4 = (W >> 2) * (H >> 2), bw4 = W >> 2, per = (nb4 + 3) >> 2;
-      for (int u = wave; u < 9 * per; u += 4) {
+      for (int u = wave; u < 9 * per; u += NW) {
         const int ci = u / per, g = u - ci * per;
         const int blk = g * 4 + (lane >> 4);
         const bool act = blk < nb4;
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
         if (lane == 0) atomicAdd(&sh.cand[ci], s);
       }
     }
-    __syncthreads();
+    fr_sync<NW>();
     // ---- first-best over the 9 candidates in table order (:723-756), all threads redundantly ----
     uint32_t best = 0xFFFFFFFFu; int bi = 0;
     for (int ci = 0; ci < 9; ci++) {
@@ -152,13 +166,21 @@ __global__ __launch_bounds__(256) void k_frac(const hop_pu_job* __restrict__ job
     rr.frac_cost = cost_best; rr.cost = cost_best;
     rr.mv_final[0] = mvx; rr.mv_final[1] = mvy;
     rr.half_final[0] = half[0]; rr.half_final[1] = half[1]; rr.qter_final[0] = qter[0]; rr.qter_final[1] = qter[1];
-    res[blockIdx.x] = rr;
+    res[pu] = rr;
   }
 }
 
 int hop_launch_frac(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
+  // scratch (after the SS search's use of it on the same stream): 2 counters + 2 index lists, the layout of hop_launch_size_classes
+  void* sc; int r = hop_scratch(c, 256 + (size_t)n * 8, &sc); if (r) return r;
+  unsigned int* counts = (unsigned int*)sc;
+  int32_t* small_list = (int32_t*)((char*)sc + 256);
+  int32_t* big_list = small_list + n;
   const int pr = hop_prof_begin(c, HOP_K_FRAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_frac, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res);
+  hop_launch_size_classes(c, n, d_jobs, d_res, sc);
+  // grids are upper bounds: blocks beyond the class count exit on their first instruction
+  hipLaunchKernelGGL((k_frac<4, 64>), dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), d_res, big_list, counts + 1);
+  hipLaunchKernelGGL((k_frac<1, 16>), dim3(n), dim3(64), 0, c->stream, d_jobs, hop_make_pics(c), d_res, small_list, counts);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "frac launch: %s", hipGetErrorString(e));

@@ -453,6 +453,15 @@ __global__ void k_gt_prep(const hop_pu_job* __restrict__ jobs, const hop_pu_resu
   if (big)   big_list[bb + __popcll(mb & below)] = i;
 }
 
+// sort the valid PUs into the two size classes (<= 16x16: one wave per PU; larger: four); sc = 256 B of counters + 2 lists of n
+void hop_launch_size_classes(hop_ctx* c, int n, const hop_pu_job* d_jobs, const hop_pu_result* d_res, void* sc) {
+  unsigned int* counts = (unsigned int*)sc;
+  int32_t* small_list = (int32_t*)((char*)sc + 256);
+  int32_t* big_list = small_list + n;
+  (void)hipMemsetAsync(counts, 0, 8, c->stream);
+  hipLaunchKernelGGL(k_gt_prep, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, d_res, n, counts, small_list, big_list);
+}
+
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res) {
   // scratch (after the SS search's use of it on the same stream): 2 counters + 2 index lists
   void* sc; int r = hop_scratch(c, 256 + (size_t)n * 8, &sc); if (r) return r;
@@ -461,8 +470,7 @@ int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_
   int32_t* big_list = small_list + n;
   hop_pics pic = hop_make_pics(c);
   const int pr = hop_prof_begin(c, HOP_K_GT_SEARCH, (uint64_t)n);
-  (void)hipMemsetAsync(counts, 0, 8, c->stream);
-  hipLaunchKernelGGL(k_gt_prep, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, d_res, n, counts, small_list, big_list);
+  hop_launch_size_classes(c, n, d_jobs, d_res, sc);
   // grids are upper bounds: blocks beyond the class count exit on their first instruction
   if (c->bd_y == 8) {
     hipLaunchKernelGGL((k_gt_search<uint16_t, 4, 64>), dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_res, big_list, counts + 1);

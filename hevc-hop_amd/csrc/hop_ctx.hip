@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <utility>
 #include "hop_dev.h"
 
 static char g_create_err[512] = "";
@@ -70,6 +71,10 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   size_t ny = (size_t)pic_w * pic_h, nc = ny >> 2;
   size_t sy = (size_t)c->stride_y * (pic_h + 2 * HOP_MARGIN_Y), sc = (size_t)c->stride_c * ((pic_h >> 1) + 2 * HOP_MARGIN_C);
   hipError_t e = hipStreamCreate(&c->stream);
+  if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  { const char* f = getenv("HOP_DUAL_STREAM"); c->dual = !(f && f[0] == '0'); }
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_y, ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_cb, nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_cr, nc * 2);
@@ -104,6 +109,10 @@ void hop_ctx_destroy(hop_ctx* c) {
                    c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->scratch2) (void)hipFree(c->scratch2);
   free(c);
 }
 
@@ -286,13 +295,31 @@ static int check_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
   return HOP_OK;
 }
 
+static int me_pipeline(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_results, int stage) {
+  int r = hop_launch_ss_search(c, n, d_jobs, d_results); if (r) return r;
+  if (stage >= HOP_STAGE_FRAC) { r = hop_launch_frac(c, n, d_jobs, d_results); if (r) return r; }
+  if (stage >= HOP_STAGE_GT) { r = hop_launch_gt(c, n, d_jobs, d_results); if (r) return r; }
+  return HOP_OK;
+}
+
 int hop_me_search_device(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_results, int stage) {
   if (!c || n < 0 || stage < HOP_STAGE_INT || stage > HOP_STAGE_GT || (n && (!d_jobs || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_me_search_device: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_me_search: hop_upload_orig has not been called");
   if (n == 0) return HOP_OK;
-  int r = hop_launch_ss_search(c, n, d_jobs, d_results); if (r) return r;
-  if (stage >= HOP_STAGE_FRAC) { r = hop_launch_frac(c, n, d_jobs, d_results); if (r) return r; }
-  if (stage >= HOP_STAGE_GT) { r = hop_launch_gt(c, n, d_jobs, d_results); if (r) return r; }
+  // Large batches are cut in two (at a multiple of 5 PUs, so that a list of whole CUs keeps its families) and the halves
+  // run on two streams: PUs are independent, the results do not depend on the cut.
+  const int n0 = (c->dual && n >= 16384) ? (n / 10) * 5 : n;
+  if (n0 < n) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+  int r = me_pipeline(c, n0, d_jobs, d_results, stage); if (r) return r;
+  if (n0 < n) {
+    std::swap(c->stream, c->stream2); std::swap(c->scratch, c->scratch2); std::swap(c->scratch_bytes, c->scratch2_bytes);
+    r = me_pipeline(c, n - n0, d_jobs + n0, d_results + n0, stage);
+    hipError_t e = hipEventRecord(c->ev_join, c->stream);
+    std::swap(c->stream, c->stream2); std::swap(c->scratch, c->scratch2); std::swap(c->scratch_bytes, c->scratch2_bytes);
+    if (r) return r;
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_me_search_device: stream join: %s", hipGetErrorString(e));
+  }
   return HOP_OK;
 }
 

@@ -27,6 +27,9 @@ struct hop_ctx {
   // scratch that grows on demand (never allocated inside a *_device call once sized)
   void*  scratch; size_t scratch_bytes;
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
+  // second lane for hop_me_search_device: the two halves of a batch run on two streams so that one half's kernel tails
+  // and low-occupancy phases are filled by the other half's kernels (HOP_DUAL_STREAM=0 turns it off)
+  hipStream_t stream2; void* scratch2; size_t scratch2_bytes; hipEvent_t ev_fork, ev_join; bool dual;
   bool   have_orig;
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
   char   err[512];

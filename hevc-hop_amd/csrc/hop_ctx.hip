@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include <utility>
+#include <algorithm>
 #include "hop_dev.h"
 
 static char g_create_err[512] = "";
@@ -71,10 +72,9 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   size_t ny = (size_t)pic_w * pic_h, nc = ny >> 2;
   size_t sy = (size_t)c->stride_y * (pic_h + 2 * HOP_MARGIN_Y), sc = (size_t)c->stride_c * ((pic_h >> 1) + 2 * HOP_MARGIN_C);
   hipError_t e = hipStreamCreate(&c->stream);
-  if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
+  for (int k = 0; k < HOP_MAX_LANES - 1 && e == hipSuccess; k++) { e = hipStreamCreate(&c->xstream[k]); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming); }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-  { const char* f = getenv("HOP_DUAL_STREAM"); c->dual = !(f && f[0] == '0'); }
+  { const char* f = getenv("HOP_LANES"); c->lanes = f ? atoi(f) : 2; if (c->lanes < 1) c->lanes = 1; if (c->lanes > HOP_MAX_LANES) c->lanes = HOP_MAX_LANES; }
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_y, ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_cb, nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->org_cr, nc * 2);
@@ -109,10 +109,12 @@ void hop_ctx_destroy(hop_ctx* c) {
                    c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
+    if (c->xstream[k]) (void)hipStreamDestroy(c->xstream[k]);
+    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
+    if (c->xscratch[k]) (void)hipFree(c->xscratch[k]);
+  }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->scratch2) (void)hipFree(c->scratch2);
   free(c);
 }
 
@@ -306,18 +308,24 @@ int hop_me_search_device(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_res
   if (!c || n < 0 || stage < HOP_STAGE_INT || stage > HOP_STAGE_GT || (n && (!d_jobs || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_me_search_device: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_me_search: hop_upload_orig has not been called");
   if (n == 0) return HOP_OK;
-  // Large batches are cut in two (at a multiple of 5 PUs, so that a list of whole CUs keeps its families) and the halves
-  // run on two streams: PUs are independent, the results do not depend on the cut.
-  const int n0 = (c->dual && n >= 16384) ? (n / 10) * 5 : n;
-  if (n0 < n) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
-  int r = me_pipeline(c, n0, d_jobs, d_results, stage); if (r) return r;
-  if (n0 < n) {
-    std::swap(c->stream, c->stream2); std::swap(c->scratch, c->scratch2); std::swap(c->scratch_bytes, c->scratch2_bytes);
-    r = me_pipeline(c, n - n0, d_jobs + n0, d_results + n0, stage);
-    hipError_t e = hipEventRecord(c->ev_join, c->stream);
-    std::swap(c->stream, c->stream2); std::swap(c->scratch, c->scratch2); std::swap(c->scratch_bytes, c->scratch2_bytes);
+  // Large batches are cut into parts (at multiples of 5 PUs, so that a list of whole CUs keeps its families) that run on
+  // separate streams: PUs are independent, the results do not depend on the cut.
+  const int parts = (n >= 16384) ? c->lanes : 1;
+  const int per = ((n + parts - 1) / parts + 4) / 5 * 5;
+  if (parts > 1) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int k = 0; k < parts - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+  }
+  int r = me_pipeline(c, std::min(per, n), d_jobs, d_results, stage); if (r) return r;
+  for (int k = 0; k < parts - 1; k++) {
+    const int o = (k + 1) * per, m = std::min(per, n - o);
+    if (m <= 0) break;
+    std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+    r = me_pipeline(c, m, d_jobs + o, d_results + o, stage);
+    hipError_t e = hipEventRecord(c->ev_join[k], c->stream);
+    std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
     if (r) return r;
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join[k], 0);
     if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_me_search_device: stream join: %s", hipGetErrorString(e));
   }
   return HOP_OK;

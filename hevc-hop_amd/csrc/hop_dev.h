@@ -12,6 +12,7 @@
 // points into the top margin (an out-of-bounds read there).  Guard rows keep our reads inside one allocation;
 // they hold the sentinel and are not part of the reference layout.
 #define HOP_GUARD_ROWS 64
+#define HOP_MAX_LANES 4
 
 struct hop_ctx {
   int pic_w, pic_h, bd_y, bd_c, device;
@@ -27,9 +28,10 @@ struct hop_ctx {
   // scratch that grows on demand (never allocated inside a *_device call once sized)
   void*  scratch; size_t scratch_bytes;
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
-  // second lane for hop_me_search_device: the two halves of a batch run on two streams so that one half's kernel tails
-  // and low-occupancy phases are filled by the other half's kernels (HOP_DUAL_STREAM=0 turns it off)
-  hipStream_t stream2; void* scratch2; size_t scratch2_bytes; hipEvent_t ev_fork, ev_join; bool dual;
+  // extra lanes for hop_me_search_device: the parts of a batch run on separate streams so that one part's kernel tails
+  // and low-occupancy phases are filled by the other parts' kernels
+  hipStream_t xstream[HOP_MAX_LANES - 1]; void* xscratch[HOP_MAX_LANES - 1]; size_t xscratch_bytes[HOP_MAX_LANES - 1];
+  hipEvent_t ev_fork, ev_join[HOP_MAX_LANES - 1]; int lanes;   // HOP_LANES=1..4 (default 2)
   bool   have_orig;
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
   char   err[512];

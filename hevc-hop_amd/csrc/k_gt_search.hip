@@ -26,7 +26,7 @@
 #include "hop_dev.h"
 
 #define GT_MAXC 640
-#define GT_CHUNK 64
+#define GT_CHUNK 56               // candidates evaluated together (the parallelogram set has exactly 56)
 
 // MAXD = largest PU side of the class: 16 (one wave) or 64 (four waves)
 template <typename PT, int MAXD>
@@ -39,10 +39,9 @@ struct GtShared {
   int      csatd[GT_CHUNK];
   uint8_t  alive[GT_CHUNK];      // candidates of the chunk still below the incumbent (early termination in rounds of blocks)
   int      n_alive;
-  uint32_t cand_cost[GT_MAXC];
+  union { uint32_t cand_cost[GT_MAXC]; uint8_t flag[GT_MAXC]; };   // flag: only inside gt_enumerate, before any cost of the iteration is written
   uint16_t cand_list[GT_MAXC];
   uint16_t fixed_list[GT_CHUNK]; // the 56 combinations with d0 + d2 == d1 + d3 (parallelogram centres)
-  uint8_t  flag[GT_MAXC];
   int n_cand, n_fixed;
   unsigned long long best;
 };

@@ -305,6 +305,37 @@ def test_ss_family_cells_vs_oracle(hp):
             assert got[:4] == want[:4], ([int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
 
 
+def test_batch_split_is_invisible(hp):
+    """hop_me_search_device cuts large batches into parts that run on separate streams (HOP_LANES, default 2); one lane,
+    two lanes and three lanes must give the same bytes for the whole chain (SS + frac + GT)."""
+    W, H = 512, 384
+    Y, Cb, Cr = lenslet(W, H, 15, 7)
+    lam, lc = lambda_for_qp(32)
+    L = hp.load()
+    wctu, hctu = W // 64, H // 64
+    jobs = np.zeros(425 * wctu * hctu, hp.PU_JOB_DTYPE)
+    n = 0
+    for a in range(wctu * hctu):
+        n += L.hop_enumerate_ctu_jobs(W, H, a, 128, (ctypes.c_int * 2)(0, -60), 2, (ctypes.c_int * 4)(0, -60, -60, 0), lc,
+                                      hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME, 0, jobs.ctypes.data + n * jobs.itemsize, None, len(jobs) - n)
+    assert n == len(jobs) >= 16384
+    rects = np.array([[x, y, 64] for y in range(0, H, 64) for x in range(0, W, 64)], np.int32)
+    outs = []
+    for lanes in ("1", "2", "3"):
+        os.environ["HOP_LANES"] = lanes
+        try:
+            ctx = hp.Context(W, H)
+        finally:
+            del os.environ["HOP_LANES"]
+        ctx.upload_orig(Y, Cb, Cr)
+        ctx.ssref_reset()
+        ctx.ssref_commit(rects, Y, Cb, Cr)                  # a fully reconstructed reference
+        outs.append(ctx.me_search(jobs, 3).copy())
+        ctx.close()
+    assert int(np.sum(outs[0]["gt_flag"])) > 0
+    assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
+
+
 def test_distortion_vs_oracle(hp):
     O = oracle()
     W, H = 128, 128

@@ -184,6 +184,52 @@ def main():
     d_pj = [torch.zeros(max(1, len(ix)) * ctypes.sizeof(hp.PredJob), dtype=torch.uint8, device=dev) for ix in depth_idx]
     my_rects = rects[np.isin((rects[:, 1] // 64), my_rows)]
     d_myrects = torch.from_numpy(np.ascontiguousarray(my_rects)).to(dev)
+    # ---- rows a7 / a9 / a10 / a12 of the same CUs: 35-mode intra rough search of every CU (+ the four 4x4 blocks of
+    #      an 8x8 CU, NxN at maximum depth), and the transform-quantisation round trip (DCT, flat quantiser, dequantiser,
+    #      inverse DCT, reconstruction, SSE) of the residual of every 2Nx2N GT prediction, luma + both chroma planes ----
+    cu = np.stack([jobs["pu_x"][is2n], jobs["pu_y"][is2n], jobs["w"][is2n]], axis=1).astype(np.int32)   # (x, y, size) of every CU of my CTU rows, all depths
+    ij = []
+    for S in (64, 32, 16, 8, 4):
+        src = cu[cu[:, 2] == (8 if S == 4 else S)]
+        if S == 4:                                                # the four 4x4 blocks of each 8x8 CU
+            src = np.concatenate([src + np.array([dx, dy, 0], np.int32) for dy in (0, 4) for dx in (0, 4)])
+        a = np.zeros(len(src), hp.INTRA_JOB_DTYPE)
+        a["x"], a["y"], a["size"], a["strong"] = src[:, 0], src[:, 1], S, 1
+        U = S // 4                                                # left column, corner and above row available inside the picture
+        fl = np.zeros((len(src), 68), np.uint8)
+        fl[:, U:2 * U] = (src[:, 0] > 0)[:, None]
+        fl[:, 2 * U] = (src[:, 0] > 0) & (src[:, 1] > 0)
+        fl[:, 2 * U + 1:3 * U + 1] = (src[:, 1] > 0)[:, None]
+        a["flags"] = fl
+        ij.append(a)
+    intra_jobs = np.concatenate(ij)
+    d_intra = torch.from_numpy(intra_jobs.view(np.uint8)).to(dev)
+    d_satd = torch.zeros(len(intra_jobs) * 35, dtype=torch.int32, device=dev)
+    tu_by_depth = []
+    for d in range(4):
+        S = 64 >> d
+        src = cu[cu[:, 2] == S]
+        parts = []
+        T = min(S, 32)                                            # luma TUs: the CU, or four 32x32 for a 64x64 CU
+        for oy in range(0, S, T):
+            for ox in range(0, S, T):
+                a = np.zeros(len(src), hp.TU_JOB_DTYPE)
+                a["x"], a["y"], a["comp"], a["log2_size"], a["qp_scaled"] = src[:, 0] + ox, src[:, 1] + oy, 0, T.bit_length() - 1, QP
+                parts.append(a)
+        C = max(S // 2, 4)                                        # chroma TUs (an 8x8 CU codes one 4x4 per plane)
+        for comp in (1, 2):
+            TC = min(C, 32)
+            for oy in range(0, C, TC):
+                for ox in range(0, C, TC):
+                    a = np.zeros(len(src), hp.TU_JOB_DTYPE)
+                    a["x"], a["y"], a["comp"], a["log2_size"], a["qp_scaled"] = src[:, 0] + 2 * ox, src[:, 1] + 2 * oy, comp, TC.bit_length() - 1, QP - 1
+                    parts.append(a)
+        tu_by_depth.append(np.concatenate(parts))
+    d_tu = [torch.from_numpy(t.view(np.uint8)).to(dev) for t in tu_by_depth]
+    d_tur = [torch.zeros(len(t) * 8, dtype=torch.uint8, device=dev) for t in tu_by_depth]
+    for c3, pl in enumerate((recY, Cb, Cr)):                      # neighbours of the intra search: the reconstruction = the frozen reference
+        host_plane = np.ascontiguousarray(pl.cpu().numpy(), np.int16)
+        chk(L.hop_recon_upload(ctx.h, c3, host_plane.ctypes.data), "recon_upload")
     CH = 1 << 17                                                  # PUs per launch
     jsz, rsz = hp.PU_JOB_DTYPE.itemsize, hp.PU_RESULT_DTYPE.itemsize
 
@@ -196,6 +242,8 @@ def main():
             if k:
                 chk(L.hop_pred_jobs_from_results_device(ctx.h, k, d_idx[d].data_ptr(), d_jobs.data_ptr(), d_res.data_ptr(), d_pj[d].data_ptr()), "pred_jobs")
                 chk(L.hop_pred_inter_device(ctx.h, k, d_pj[d].data_ptr()), "pred")
+                chk(L.hop_tu_roundtrip_device(ctx.h, len(tu_by_depth[d]), d_tu[d].data_ptr(), d_tur[d].data_ptr(), None, None), "tu_roundtrip")
+        chk(L.hop_intra_rough_device(ctx.h, len(intra_jobs), d_intra.data_ptr(), d_satd.data_ptr()), "intra_rough")
         chk(L.hop_ssref_commit_cus_device(ctx.h, len(my_rects), d_myrects.data_ptr(), recY.data_ptr(), Cb.data_ptr(), Cr.data_ptr()), "commit")
 
     def barrier():
@@ -223,7 +271,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = {}
-    names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit"}
+    names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 6: "k_tu_roundtrip", 7: "k_intra_rough"}
     for kid, name in names.items():
         la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
         chk(L.hop_profile_read(ctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
@@ -260,7 +308,7 @@ def main():
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i16+f64", "data": "synthetic",
-            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + SS-ref commit, "
+            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + TU round trip of its residual (Y,Cb,Cr) + 35-mode intra rough search + SS-ref commit, "
                                    "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD/CABAC" % (W, H, PITCH, QP, n if world == 1 else -1),
                        "ctus": n_ctu, "pus_rank0": int(n), "parallelism": "ctu-rows-rr%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

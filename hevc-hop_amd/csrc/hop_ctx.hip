@@ -481,6 +481,26 @@ int hop_intra_rough(hop_ctx* c, int n, const hop_intra_job* jobs, uint32_t* satd
   return HOP_OK;
 }
 
+int hop_tu_roundtrip_device(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_results, int32_t* d_levels, const int64_t* d_level_offsets) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_results)) || (d_levels && !d_level_offsets)) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_roundtrip_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_roundtrip: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  return hop_launch_tu(c, n, d_jobs, d_results, d_levels, d_level_offsets);
+}
+
+int hop_intra_rough_device(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_satd))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_rough_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_rough: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  return hop_launch_intra(c, n, d_jobs, d_satd);
+}
+
+int hop_distortion_device(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_out))) return hop_set_err(c, HOP_ERR_ARG, "hop_distortion_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_dist(c, n, d_jobs, d_out);
+}
+
 int hop_distortion(hop_ctx* c, int n, const hop_dist_job* jobs, uint32_t* out) {
   if (!c || n < 0 || (n && (!jobs || !out))) return hop_set_err(c, HOP_ERR_ARG, "hop_distortion: bad argument");
   if (n == 0) return HOP_OK;

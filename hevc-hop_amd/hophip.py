@@ -54,6 +54,10 @@ class IntraJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("size", ctypes.c_int32), ("strong", ctypes.c_int32), ("flags", ctypes.c_uint8 * 68)]
 
 
+TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
+                         ("qp_scaled", "<i4"), ("is_i_slice", "<i4")])
+INTRA_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("size", "<i4"), ("strong", "<i4"), ("flags", "u1", (68,))])
+assert TU_JOB_DTYPE.itemsize == ctypes.sizeof(TuJob) and INTRA_JOB_DTYPE.itemsize == ctypes.sizeof(IntraJob)
 PU_JOB_DTYPE = np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("rng_left", "<i4"), ("rng_right", "<i4"),
                          ("rng_top", "<i4"), ("rng_bottom", "<i4"), ("off_x", "<i4"), ("off_y", "<i4"), ("pred_x", "<i4"), ("pred_y", "<i4"),
                          ("lambda_cost", "<u4"), ("n_amvp", "<i4"), ("amvp", "<i4", (4,)), ("flags", "<i4")])
@@ -97,6 +101,11 @@ def load():
     L.hop_pred_jobs_from_results_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
     L.hop_tu_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.hop_intra_rough.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_tu_roundtrip_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+    L.hop_intra_rough_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_distortion_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for n in ("hop_tu_roundtrip_device", "hop_intra_rough_device", "hop_distortion_device"):
+        getattr(L, n).restype = ctypes.c_int
     for n in ("hop_recon_upload", "hop_recon_download", "hop_pred_upload"):
         getattr(L, n).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         getattr(L, n).restype = ctypes.c_int

@@ -156,6 +156,7 @@ int hop_pred_jobs_from_results_device(hop_ctx* ctx, int n, const int32_t* d_inde
 /* replaces: TComRdCost::getDistPart / DistParam::DistFunc between the original and the prediction picture
  * (TLibCommon/TComRdCost.cpp:477-503). out[i] = distortion of job i. */
 int hop_distortion(hop_ctx* ctx, int n, const hop_dist_job* jobs, uint32_t* out);
+int hop_distortion_device(hop_ctx* ctx, int n, const hop_dist_job* d_jobs, uint32_t* d_out);            /* asynchronous, unchecked */
 
 /* ---- transform / quantisation round trip (rows a9, a10) and intra rough search (row a7) ---- */
 /* One transform unit: residual = original - prediction picture, forward DCT (DST-VII for use_dst on 4x4) or
@@ -178,6 +179,10 @@ typedef struct {
 typedef struct { uint32_t abs_sum; uint32_t sse; } hop_tu_result;
 /* levels_out (may be NULL): quantised levels of job i at levels_out[sum_{k<i} size_k^2 ...] (TCoeff = int32) */
 int hop_tu_roundtrip(hop_ctx* ctx, int n, const hop_tu_job* jobs, hop_tu_result* results, int32_t* levels_out);
+/* the same on device-resident job / result arrays (asynchronous on the context stream; the jobs are not range-checked).
+ * d_levels may be NULL; otherwise d_level_offsets[i] = first TCoeff of job i in d_levels. */
+int hop_tu_roundtrip_device(hop_ctx* ctx, int n, const hop_tu_job* d_jobs, hop_tu_result* d_results, int32_t* d_levels,
+                            const int64_t* d_level_offsets);
 /* whole reconstruction planes, pitch pic_w (/2): neighbours of the intra search, output of hop_tu_roundtrip */
 int hop_recon_upload(hop_ctx* ctx, int comp, const int16_t* src);
 int hop_pred_upload(hop_ctx* ctx, int comp, const int16_t* src);   /* e.g. an intra prediction made elsewhere */
@@ -194,6 +199,7 @@ typedef struct {
   uint8_t flags[68];
 } hop_intra_job;
 int hop_intra_rough(hop_ctx* ctx, int n, const hop_intra_job* jobs, uint32_t* satd_out);
+int hop_intra_rough_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);   /* asynchronous, unchecked */
 
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with

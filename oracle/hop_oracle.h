@@ -37,6 +37,25 @@ int hop_o_me_pu(const int16_t* org, int orgStride, const int16_t* refY00, int re
                 int rngL, int rngR, int rngT, int rngB, int offX, int offY,
                 int predX, int predY, int nAmvp, const int* amvpXY, uint32_t lambdaCost,
                 int fen, int useHad, int bitDepth, int stage, int64_t* out);
+/* ---- a11: rate-distortion optimised quantisation (hop_oracle_rdoq.c) ---- */
+/* the reference's estBitsSbacStruct (TLibCommon/TComTrQuant.h:59-70), same member order and sizes */
+typedef struct {
+  int significantCoeffGroupBits[2][2];
+  int significantBits[42][2];
+  int lastXBits[32];
+  int lastYBits[32];
+  int greaterOneBits[24][2];
+  int levelAbsBits[6][2];
+  int blockCbpBits[12][2];
+  int blockRootCbpBits[4][2];
+} hop_o_estbits;
+void hop_o_scan_init(void);
+const uint32_t* hop_o_scan(int scan_idx, int log2_size);
+const uint32_t* hop_o_scan_cg(int scan_idx, int log2_size);
+int hop_o_coef_scan_idx(int width, int is_luma, int is_intra, int dir);
+int hop_o_rdoq(const int32_t* src, int32_t* dst, int log2_size, int comp, int is_intra, int scan_idx, int tr_depth,
+               int qp_scaled, int bit_depth, int sign_hide, double lambda, const hop_o_estbits* eb, uint32_t* abs_sum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,7 @@
 #include "TLibCommon/TComDataCU.h"
 #include "TLibCommon/TComPrediction.h"
 #include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComSlice.h"
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncSearch.h"
 #undef private
@@ -331,6 +332,46 @@ void ref_dequant_flat(int bitDepth, int qpScaled, const int32_t* level, int32_t*
   g->trq.m_cQP.setQpParam(qpScaled);
   g->trq.setUseScalingList(false);
   g->trq.xDeQuant(bitDepth, (const TCoeff*)level, (Int*)coef, N, N, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row a11: TComTrQuant::xRateDistOptQuant (TComTrQuant.cpp:1489-1999) -- the reference's own function.  The TComDataCU
+// only has to answer isIntra / getCoefScanIdx / getTransformIdx / getCtxQtCbf / getSlice()->getPPS()->getSignHideFlag():
+// its per-partition arrays are pointed at one-element statics.  ttype: 0 TEXT_LUMA, 2 TEXT_CHROMA_U, 3 TEXT_CHROMA_V.
+// estBits: an estBitsSbacStruct image (TComTrQuant.h:59-70).  chromaDir must not be DM_CHROMA_IDX (needs a TComPic).
+// Returns the scan index the reference chose (getCoefScanIdx).
+// ---------------------------------------------------------------------------------------------
+int ref_rdoq(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, int lumaDir, int chromaDir, int trIdx,
+             int qpScaled, int bitDepthY, int bitDepthC, int signHide, double lambda, const int32_t* estBits, uint32_t* absSum)
+{
+  static Char predMode[1]; static UChar trIdxA[1], lumaDirA[1], chromaDirA[1], depthA[1];
+  static TComSlice* slice = NULL; static TComPPS* pps = NULL;
+  if (!slice) { slice = new TComSlice; pps = new TComPPS; slice->setPPS(pps); }
+  g_bitDepthY = bitDepthY; g_bitDepthC = bitDepthC;
+  TComTrQuant& t = g->trq;
+  t.init(32, true, true, true, false, false);
+  t.m_cQP.setQpParam(qpScaled);
+  t.setUseScalingList(false);
+  t.setFlatScalingList();                                   // quantiser and error-scale tables for the current bit depths
+  t.m_dLambda = lambda;
+  memcpy(t.m_pcEstBitsSbac, estBits, sizeof(estBitsSbacStruct));
+  pps->setSignHideFlag(signHide);
+  TComDataCU& cu = g->cu;
+  Char* sPred = cu.m_pePredMode; UChar* sTr = cu.m_puhTrIdx; UChar* sL = cu.m_puhLumaIntraDir; UChar* sC = cu.m_puhChromaIntraDir;
+  UChar* sD = cu.m_puhDepth; TComSlice* sS = cu.m_pcSlice;
+  predMode[0] = isIntra ? MODE_INTRA : MODE_INTER; trIdxA[0] = (UChar)trIdx; lumaDirA[0] = (UChar)lumaDir; chromaDirA[0] = (UChar)chromaDir; depthA[0] = 0;
+  cu.m_pePredMode = predMode; cu.m_puhTrIdx = trIdxA; cu.m_puhLumaIntraDir = lumaDirA; cu.m_puhChromaIntraDir = chromaDirA; cu.m_puhDepth = depthA;
+  cu.m_pcSlice = slice;
+  std::vector<Int> in(src, src + N * N), arl(N * N, 0);
+  std::vector<TCoeff> out(N * N, 0);
+  Int* parl = &arl[0];
+  UInt as = *absSum;
+  t.xRateDistOptQuant(&cu, &in[0], &out[0], parl, N, N, as, (TextType)ttype, 0);
+  *absSum = as;
+  for (int i = 0; i < N * N; i++) dst[i] = out[i];
+  const int scanIdx = (int)cu.getCoefScanIdx(0, N, ttype == 0, isIntra != 0);
+  cu.m_pePredMode = sPred; cu.m_puhTrIdx = sTr; cu.m_puhLumaIntraDir = sL; cu.m_puhChromaIntraDir = sC; cu.m_puhDepth = sD; cu.m_pcSlice = sS;
+  return scanIdx;
 }
 
 // ---------------------------------------------------------------------------------------------

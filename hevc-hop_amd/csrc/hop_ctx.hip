@@ -88,6 +88,12 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   if (e == hipSuccess) e = hipMalloc((void**)&c->rec[0], ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->rec[1], nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->rec[2], nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->rdoq_scans, HOP_RDOQ_SCAN_ENTRIES * sizeof(uint16_t));
+  if (e == hipSuccess) {
+    std::vector<uint16_t> tabs(HOP_RDOQ_SCAN_ENTRIES);
+    hop_rdoq_build_scans(tabs.data());
+    e = hipMemcpy(c->rdoq_scans, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) { hop_set_err(nullptr, HOP_ERR_DEVICE, "allocation failed: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
   c->ss_buf[0] = c->ss_alloc[0] + gy; c->ss_buf[1] = c->ss_alloc[1] + gc; c->ss_buf[2] = c->ss_alloc[2] + gc;
   c->ss00[0] = c->ss_buf[0] + (size_t)HOP_MARGIN_Y * c->stride_y + HOP_MARGIN_Y;
@@ -106,7 +112,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
-                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage };
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rdoq_scans };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
@@ -493,6 +499,40 @@ int hop_intra_rough_device(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint3
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_rough: hop_upload_orig has not been called");
   if (n == 0) return HOP_OK;
   return hop_launch_intra(c, n, d_jobs, d_satd);
+}
+
+int hop_rdoq_device(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_tables || !d_src || !d_dst || !d_abs_sum))) return hop_set_err(c, HOP_ERR_ARG, "hop_rdoq_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_rdoq(c, n, d_jobs, d_tables, d_src, d_dst, d_abs_sum);
+}
+
+int hop_rdoq(hop_ctx* c, int n, const hop_rdoq_job* jobs, int n_tables, const hop_estbits* tables, size_t n_coeff,
+             const int32_t* src, int32_t* dst, uint32_t* abs_sum) {
+  if (!c || n < 0 || (n && (!jobs || !tables || !src || !dst || !abs_sum || n_tables <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_rdoq: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_rdoq_job& j = jobs[i];
+    const size_t n2 = (size_t)1 << (2 * j.log2_size);
+    if (j.log2_size < 2 || j.log2_size > 5 || j.comp < 0 || j.comp > 2 || (j.comp && j.log2_size == 5) || j.scan_idx < 0 || j.scan_idx > 2 ||
+        j.tr_depth < 0 || j.tr_depth > 3 || j.qp_scaled < 0 || j.qp_scaled > 87 || j.bit_depth < 8 || j.bit_depth > 12 || !(j.lambda > 0.0) ||
+        j.coeff_offset < 0 || (size_t)j.coeff_offset + n2 > n_coeff || j.estbits_index < 0 || j.estbits_index >= n_tables)
+      return hop_set_err(c, HOP_ERR_ARG, "RDOQ job %d: illegal transform unit / table / offset", i);
+  }
+  const size_t bj = (size_t)n * sizeof(hop_rdoq_job), o_t = (bj + 255) & ~(size_t)255, bt = (size_t)n_tables * sizeof(hop_estbits);
+  const size_t o_s = (o_t + bt + 255) & ~(size_t)255, o_d = (o_s + n_coeff * 4 + 255) & ~(size_t)255, o_a = (o_d + n_coeff * 4 + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_a + (size_t)n * 4 + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_t, tables, bt, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_s, src, n_coeff * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(b + o_d, 0, n_coeff * 4, c->stream));
+  r = hop_launch_rdoq(c, n, (const hop_rdoq_job*)b, (const hop_estbits*)(b + o_t), (const int32_t*)(b + o_s), (int32_t*)(b + o_d), (uint32_t*)(b + o_a));
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(dst, b + o_d, n_coeff * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(abs_sum, b + o_a, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
 }
 
 int hop_distortion_device(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out) {

@@ -33,6 +33,7 @@ struct hop_ctx {
   hipStream_t xstream[HOP_MAX_LANES - 1]; void* xscratch[HOP_MAX_LANES - 1]; size_t xscratch_bytes[HOP_MAX_LANES - 1];
   hipEvent_t ev_fork, ev_join[HOP_MAX_LANES - 1]; int lanes;   // HOP_LANES=1..4 (default 2)
   bool   have_orig;
+  uint16_t* rdoq_scans;              // device: the scan tables of the RDOQ kernel (hop_rdoq_build_scans)
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
@@ -129,6 +130,9 @@ int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs);
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out);
 int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off);
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
+int hop_launch_rdoq(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum);
+void hop_rdoq_build_scans(uint16_t* tabs);
+#define HOP_RDOQ_SCAN_ENTRIES (4080 + 255)
 int hop_launch_ssref_reset(hop_ctx* c);
 int hop_launch_ssref_commit(hop_ctx* c, int n, const int32_t* d_rect4, const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr, int packed);
 int hop_set_err(hop_ctx* c, int code, const char* fmt, ...);

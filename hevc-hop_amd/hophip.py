@@ -54,6 +54,9 @@ class IntraJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("size", ctypes.c_int32), ("strong", ctypes.c_int32), ("flags", ctypes.c_uint8 * 68)]
 
 
+RDOQ_JOB_DTYPE = np.dtype([("log2_size", "<i4"), ("comp", "<i4"), ("is_intra", "<i4"), ("scan_idx", "<i4"), ("tr_depth", "<i4"), ("qp_scaled", "<i4"),
+                           ("bit_depth", "<i4"), ("sign_hide", "<i4"), ("lambda", "<f8"), ("coeff_offset", "<i8"), ("estbits_index", "<i4"), ("reserved", "<i4")])
+ESTBITS_INTS = 4 + 84 + 32 + 32 + 48 + 12 + 24 + 8       # hop_estbits as a flat int32 array
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
                          ("qp_scaled", "<i4"), ("is_i_slice", "<i4")])
 INTRA_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("size", "<i4"), ("strong", "<i4"), ("flags", "u1", (68,))])
@@ -101,6 +104,9 @@ def load():
     L.hop_pred_jobs_from_results_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
     L.hop_tu_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.hop_intra_rough.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_rdoq.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 3
+    L.hop_rdoq_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+    L.hop_rdoq.restype = L.hop_rdoq_device.restype = ctypes.c_int
     L.hop_tu_roundtrip_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
     L.hop_intra_rough_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.hop_distortion_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -229,6 +235,15 @@ class Context:
         out = np.zeros((n, 35), np.uint32)
         self._chk(self.L.hop_intra_rough(self.h, n, ctypes.addressof(arr), out.ctypes.data), "hop_intra_rough")
         return out
+
+    def rdoq(self, jobs, tables, src):
+        """jobs: RDOQ_JOB_DTYPE array; tables: (n_tables, ESTBITS_INTS) int32; src: all coefficients (int32) -> levels, abs_sum"""
+        jobs = np.ascontiguousarray(jobs, RDOQ_JOB_DTYPE); tables = np.ascontiguousarray(tables, np.int32); src = np.ascontiguousarray(src, np.int32)
+        assert tables.ndim == 2 and tables.shape[1] == ESTBITS_INTS
+        dst = np.zeros(len(src), np.int32); asum = np.zeros(len(jobs), np.uint32)
+        self._chk(self.L.hop_rdoq(self.h, len(jobs), jobs.ctypes.data, len(tables), tables.ctypes.data, len(src), src.ctypes.data, dst.ctypes.data,
+                                  asum.ctypes.data), "hop_rdoq")
+        return dst, asum
 
     def sync(self):
         self._chk(self.L.hop_sync(self.h), "hop_sync")

@@ -22,6 +22,7 @@
  */
 #ifndef HOPHIP_H
 #define HOPHIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -201,6 +202,40 @@ typedef struct {
 int hop_intra_rough(hop_ctx* ctx, int n, const hop_intra_job* jobs, uint32_t* satd_out);
 int hop_intra_rough_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);   /* asynchronous, unchecked */
 
+/* ---- rate-distortion optimised quantisation (row a11) ---- */
+/* Image of the reference's estBitsSbacStruct (TLibCommon/TComTrQuant.h:59-70): the bit estimates (15 fractional bits)
+ * TEncSbac::estBit (TLibEncoder/TEncSbac.cpp:2175-2290) derives from the CABAC context states before a TU is tested. */
+typedef struct {
+  int32_t significantCoeffGroupBits[2][2];
+  int32_t significantBits[42][2];
+  int32_t lastXBits[32];
+  int32_t lastYBits[32];
+  int32_t greaterOneBits[24][2];
+  int32_t levelAbsBits[6][2];
+  int32_t blockCbpBits[12][2];
+  int32_t blockRootCbpBits[4][2];
+} hop_estbits;
+typedef struct {
+  int32_t log2_size;       /* 2..5 (chroma: 2..4, the reference has no chroma 32x32 tables) */
+  int32_t comp;            /* 0 Y, 1 Cb, 2 Cr */
+  int32_t is_intra;        /* pcCU->isIntra */
+  int32_t scan_idx;        /* TComDataCU::getCoefScanIdx (TLibCommon/TComDataCU.cpp:4001-4056): 0 diagonal, 1 horizontal, 2 vertical */
+  int32_t tr_depth;        /* pcCU->getTransformIdx */
+  int32_t qp_scaled;       /* what setQPforQuant hands to setQpParam (TComTrQuant.cpp:192-214) */
+  int32_t bit_depth;       /* of the component */
+  int32_t sign_hide;       /* PPS sign_data_hiding */
+  double  lambda;          /* m_dLambda after selectLambda (TComTrQuant.h:153) */
+  int64_t coeff_offset;    /* first coefficient of this TU in src / dst (raster N x N, Int / TCoeff) */
+  int32_t estbits_index;   /* which table of `tables` */
+  int32_t reserved;
+} hop_rdoq_job;
+/* replaces: TComTrQuant::xRateDistOptQuant (TLibCommon/TComTrQuant.cpp:1489-1999, flat scaling list) for a batch of TUs:
+ * src = transform coefficients, dst = levels with sign, abs_sum[i] = the uiAbsSum the call adds for TU i. */
+int hop_rdoq(hop_ctx* ctx, int n, const hop_rdoq_job* jobs, int n_tables, const hop_estbits* tables, size_t n_coeff,
+             const int32_t* src, int32_t* dst, uint32_t* abs_sum);
+int hop_rdoq_device(hop_ctx* ctx, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src,
+                    int32_t* d_dst, uint32_t* d_abs_sum);                                           /* asynchronous, unchecked */
+
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
  * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and
@@ -224,7 +259,8 @@ int hop_enumerate_ctu_jobs(int pic_w, int pic_h, int ctu_addr, int search_range,
 #define HOP_K_DIST      5
 #define HOP_K_TQ        6
 #define HOP_K_INTRA     7
-#define HOP_K_COUNT     8
+#define HOP_K_RDOQ      8
+#define HOP_K_COUNT     9
 int hop_profile_enable(hop_ctx* ctx, int on);
 /* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
 int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);

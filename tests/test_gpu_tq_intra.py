@@ -113,3 +113,34 @@ def test_tu_golden_transform_identity(hp):
         n_checked += 1
     assert n_checked >= 20
     ctx.close()
+
+
+def test_rdoq_golden(hp):
+    """row a11: k_rdoq against the golden vectors made by the reference's own xRateDistOptQuant (360 TUs, every size /
+    component / scan / depth / bit depth, sign-bit hiding on and off), all TUs in ONE batch with one table per TU"""
+    from test_oracle_golden3 import rdoq_cases
+    cases = list(rdoq_cases())
+    jobs = np.zeros(len(cases), hp.RDOQ_JOB_DTYPE)
+    tables = np.stack([c["eb"] for c in cases])
+    off = 0
+    for i, c in enumerate(cases):
+        j = jobs[i]
+        j["log2_size"], j["comp"], j["is_intra"], j["scan_idx"], j["tr_depth"] = c["log2"], c["comp"], c["intra"], c["scan"], c["tr"]
+        j["qp_scaled"], j["bit_depth"], j["sign_hide"], j["lambda"], j["coeff_offset"], j["estbits_index"] = c["qp"], c["bd"], c["sh"], c["lam"], off, i
+        off += len(c["src"])
+    src = np.concatenate([c["src"] for c in cases])
+    ctx = hp.Context(64, 64)
+    dst, asum = ctx.rdoq(jobs, tables, src)
+    off = 0
+    for i, c in enumerate(cases):
+        n = len(c["src"])
+        assert int(asum[i]) == c["asum"] and np.array_equal(dst[off:off + n], c["out"]), (i, c["log2"], c["comp"], c["scan"], c["qp"], c["sh"])
+        off += n
+    # argument checking: chroma 32x32 does not exist, offsets must stay inside the coefficient array
+    bad = jobs[:1].copy(); bad["log2_size"], bad["comp"] = 5, 1
+    with pytest.raises(hp.HopError):
+        ctx.rdoq(bad, tables, src)
+    bad = jobs[:1].copy(); bad["coeff_offset"] = len(src) - 3
+    with pytest.raises(hp.HopError):
+        ctx.rdoq(bad, tables, src)
+    ctx.close()

@@ -93,6 +93,7 @@ __device__ static inline void wg_sync() {
 // The blend needs 37 bits, so its last step runs in double -- on integers < 2^53, i.e. exactly.
 // Cost per warped sample: ~25 integer + 7 double-rate VALU operations instead of 33 double-rate + 20 integer.
 // ---------------------------------------------------------------------------------------------------------------
+typedef short gt_s2 __attribute__((ext_vector_type(2)));
 struct GtAxis { int A, B, C, aq, ar; };      // N(x,y) = A*x + B*y + C ;  A = aq*D + ar, 0 <= ar < D
 
 __host__ __device__ static inline int floordiv_i(int a, int b) { int q = a / b; return (a % b != 0 && (a < 0) != (b < 0)) ? q - 1 : q; }
@@ -158,7 +159,8 @@ __device__ static inline void gt_eval(SH& sh, int na, int blk0, int bpr, int W, 
     int X[BS], rp[BS], Y[BS], rq[BS];
     gt_axis<BS>(&sh.cax[cand][0][0], &sh.ch[cand][0], px0 + offX, py + offY, offX, -m, m + W - 2, D, rcpD, X, rp);
     gt_axis<BS>(&sh.cax[cand][1][0], &sh.ch[cand][3], px0 + offX, py + offY, offY, -m, m + H - 2, D, rcpD, Y, rq);
-    int d[BS];
+    int d[BS];                                                // HAD on 8-bit content: the predicted Pel; otherwise org - Pel
+    constexpr bool PACKED = HAD && HS == 8;                   // 8-bit samples: every Hadamard intermediate fits 16 bits (<= 64 * 255)
     const int16_t* orow = sh.org + py * W + px0;
 #pragma unroll
     for (int k = 0; k < BS; k++) {
@@ -170,10 +172,41 @@ __device__ static inline void gt_eval(SH& sh, int na, int blk0, int bpr, int W, 
       const double nv = __builtin_fma((double)rq[k], (double)(u - t), (double)t * Dd);    // D^2 * v, exact
       int pel = (int)__builtin_fma(nv, invD2, 0.5);                                       // (Pel)(clip(v) + 0.5), :969-975
       pel = min(max(pel, 0), 255);                                                        // the hard-coded 8-bit clip
-      d[k] = (int)orow[k] - pel;
+      d[k] = PACKED ? pel : (int)orow[k] - pel;
     }
     int s = 0;
-    if (HAD) {
+    if (PACKED) {
+      // two samples per register (v_pk_*_i16): vertical butterflies first (a DPP move + one packed multiply-add per
+      // register and stage), then the horizontal ones; the last horizontal stage pairs the two halves of a register
+      // and is folded into the magnitude sum: |a+b| + |a-b| = 2 max(|a|,|b|)
+      constexpr int NR = BS / 2;
+      gt_s2 v[NR];
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        const gt_s2 o = *(const gt_s2*)(orow + 2 * i);          // orow is 4-byte aligned (px0 and W are multiples of 4)
+        gt_s2 pz; pz.x = (short)d[2 * i]; pz.y = (short)d[2 * i + 1];
+        v[i] = o - pz;
+      }
+      const gt_s2 sA = { (short)sgnA, (short)sgnA }, s2v = { (short)sgn2, (short)sgn2 }, s1v = { (short)sgn1, (short)sgn1 };
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        if (BS == 8) v[i] = v[i] * sA + __builtin_bit_cast(gt_s2, dpp_get<DPP_HALF_MIRROR>(__builtin_bit_cast(int, v[i])));
+        else         v[i] = v[i] * sA + __builtin_bit_cast(gt_s2, dpp_get<DPP_XOR2>(__builtin_bit_cast(int, v[i])));
+        if (BS == 8) v[i] = v[i] * s2v + __builtin_bit_cast(gt_s2, dpp_get<DPP_XOR2>(__builtin_bit_cast(int, v[i])));
+        v[i] = v[i] * s1v + __builtin_bit_cast(gt_s2, dpp_get<DPP_XOR1>(__builtin_bit_cast(int, v[i])));
+      }
+#pragma unroll
+      for (int len = NR / 2; len >= 1; len >>= 1)              // registers i and i+len hold samples 2*len apart
+#pragma unroll
+        for (int i = 0; i < NR; i += 2 * len)
+#pragma unroll
+          for (int j = i; j < i + len; j++) { const gt_s2 a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        const gt_s2 a = __builtin_elementwise_abs(v[i]);
+        s += 2 * (int)(a.x > a.y ? a.x : a.y);
+      }
+    } else if (HAD) {
       // horizontal butterflies in registers
 #pragma unroll
       for (int len = 1; len < BS; len <<= 1)

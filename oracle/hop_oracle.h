@@ -49,6 +49,27 @@ typedef struct {
   int blockCbpBits[12][2];
   int blockRootCbpBits[4][2];
 } hop_o_estbits;
+/* context states (ContextModel::m_ucState = state << 1 | MPS) of the sets residual coding uses, in the reference's set order */
+typedef struct {
+  uint8_t qt_cbf[8];        /* [luma, chroma][NUM_QT_CBF_CTX] */
+  uint8_t trans_subdiv[3];
+  uint8_t qt_root_cbf[1];
+  uint8_t sig_cg[4];        /* [luma, chroma][2] */
+  uint8_t sig[42];          /* 27 luma + 15 chroma */
+  uint8_t last_x[30];       /* [luma, chroma][15] */
+  uint8_t last_y[30];
+  uint8_t one[24];          /* 16 luma + 8 chroma */
+  uint8_t abs[6];           /* 4 luma + 2 chroma */
+  uint8_t ts[2];            /* transform_skip_flag [luma, chroma] */
+} hop_o_cabac_ctx;          /* 150 bytes */
+uint8_t hop_o_ctx_init(int qp, int initValue);
+int32_t hop_o_ctx_bits(uint8_t state, int bin);
+uint8_t hop_o_ctx_next(uint8_t state, int bin);
+int hop_o_cabac_init(hop_o_cabac_ctx* c, int slice_type, int qp);
+void hop_o_cabac_est_bits(const hop_o_cabac_ctx* c, int width, int comp, hop_o_estbits* eb);
+uint64_t hop_o_cabac_coeff_bits(hop_o_cabac_ctx* c, const int32_t* coef, int log2_size, int comp, int scan_idx, int sign_hide, int use_ts, int ts_flag);
+uint64_t hop_o_cabac_cbf_bits(hop_o_cabac_ctx* c, int comp, int tr_depth, int cbf);
+uint64_t hop_o_cabac_root_cbf_bits(hop_o_cabac_ctx* c, int cbf);
 void hop_o_scan_init(void);
 const uint32_t* hop_o_scan(int scan_idx, int log2_size);
 const uint32_t* hop_o_scan_cg(int scan_idx, int log2_size);

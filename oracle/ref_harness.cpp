@@ -43,6 +43,10 @@
 #include "TLibCommon/TComSlice.h"
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncSearch.h"
+#include "TLibEncoder/TEncSbac.h"
+#include "TLibEncoder/TEncBinCoderCABACCounter.h"
+#include "TLibCommon/TComBitCounter.h"
+#include "TLibCommon/ContextTables.h"
 #undef private
 #undef protected
 
@@ -372,6 +376,78 @@ int ref_rdoq(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, in
   const int scanIdx = (int)cu.getCoefScanIdx(0, N, ttype == 0, isIntra != 0);
   cu.m_pePredMode = sPred; cu.m_puhTrIdx = sTr; cu.m_puhLumaIntraDir = sL; cu.m_puhChromaIntraDir = sC; cu.m_puhDepth = sD; cu.m_pcSlice = sS;
   return scanIdx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CABAC bit estimator for residual coding: the reference's own TEncSbac with the counting bin coder
+// (TEncBinCABACCounter).  states[150] in the order of hop_o_cabac_ctx (oracle/hop_oracle.h): qt_cbf[8], trans_subdiv[3],
+// qt_root_cbf[1], sig_cg[4], sig[42], last_x[30], last_y[30], one[24], abs[6], ts[2].
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SbacCtx { TEncSbac sbac; TEncBinCABACCounter bin; TComBitCounter bits; TComSlice slice; TComSPS sps; TComPPS pps; bool up; SbacCtx() : up(false) {} };
+SbacCtx* gs = NULL;
+SbacCtx* sbac_get() {
+  if (!gs) { gs = new SbacCtx; gs->sbac.init(&gs->bin); gs->sbac.setBitstream(&gs->bits); gs->slice.setSPS(&gs->sps); gs->slice.setPPS(&gs->pps);
+             gs->sps.setMaxTrSize(32); gs->sbac.setSlice(&gs->slice); gs->bin.setBinCountingEnableFlag(false); }
+  return gs;
+}
+struct SetRef { ContextModel* p; int n; };
+void sbac_sets(TEncSbac& s, SetRef (&r)[10]) {
+  r[0].p = s.m_cCUQtCbfSCModel.get(0); r[0].n = 8; r[1].p = s.m_cCUTransSubdivFlagSCModel.get(0); r[1].n = 3;
+  r[2].p = s.m_cCUQtRootCbfSCModel.get(0); r[2].n = 1; r[3].p = s.m_cCUSigCoeffGroupSCModel.get(0); r[3].n = 4;
+  r[4].p = s.m_cCUSigSCModel.get(0); r[4].n = 42; r[5].p = s.m_cCuCtxLastX.get(0); r[5].n = 30; r[6].p = s.m_cCuCtxLastY.get(0); r[6].n = 30;
+  r[7].p = s.m_cCUOneSCModel.get(0); r[7].n = 24; r[8].p = s.m_cCUAbsSCModel.get(0); r[8].n = 6; r[9].p = s.m_cTransformSkipSCModel.get(0); r[9].n = 2;
+}
+void sbac_load(TEncSbac& s, const uint8_t* st) { SetRef r[10]; sbac_sets(s, r); int k = 0; for (int i = 0; i < 10; i++) for (int j = 0; j < r[i].n; j++) r[i].p[j].m_ucState = st[k++]; }
+void sbac_store(TEncSbac& s, uint8_t* st) { SetRef r[10]; sbac_sets(s, r); int k = 0; for (int i = 0; i < 10; i++) for (int j = 0; j < r[i].n; j++) st[k++] = r[i].p[j].m_ucState; }
+}
+
+// ContextModel3DBuffer::initBuffer of the ten sets with the fork's tables (TEncSbac::resetEntropy, TEncSbac.cpp:136-148)
+void ref_cabac_init(int sliceType, int qp, uint8_t* states)
+{
+  SbacCtx* c = sbac_get(); TEncSbac& s = c->sbac; SliceType t = (SliceType)sliceType;
+  ContextModel::buildNextStateTable();
+  s.m_cCUQtCbfSCModel.initBuffer(t, qp, (UChar*)INIT_QT_CBF); s.m_cCUTransSubdivFlagSCModel.initBuffer(t, qp, (UChar*)INIT_TRANS_SUBDIV_FLAG);
+  s.m_cCUQtRootCbfSCModel.initBuffer(t, qp, (UChar*)INIT_QT_ROOT_CBF); s.m_cCUSigCoeffGroupSCModel.initBuffer(t, qp, (UChar*)INIT_SIG_CG_FLAG);
+  s.m_cCUSigSCModel.initBuffer(t, qp, (UChar*)INIT_SIG_FLAG); s.m_cCuCtxLastX.initBuffer(t, qp, (UChar*)INIT_LAST); s.m_cCuCtxLastY.initBuffer(t, qp, (UChar*)INIT_LAST);
+  s.m_cCUOneSCModel.initBuffer(t, qp, (UChar*)INIT_ONE_FLAG); s.m_cCUAbsSCModel.initBuffer(t, qp, (UChar*)INIT_ABS_FLAG);
+  s.m_cTransformSkipSCModel.initBuffer(t, qp, (UChar*)INIT_TRANSFORMSKIP_FLAG);
+  sbac_store(s, states);
+}
+// TEncSbac::estBit (TEncSbac.cpp:2175-2370); est: an estBitsSbacStruct image, updated in place like the reference's
+void ref_cabac_est_bits(const uint8_t* states, int width, int ttype, int32_t* est)
+{
+  SbacCtx* c = sbac_get();
+  ContextModel::buildNextStateTable();
+  sbac_load(c->sbac, states);
+  c->sbac.estBit((estBitsSbacStruct*)est, width, width, ttype ? TEXT_CHROMA : TEXT_LUMA);   // as TEncEntropy::estimateBit hands it on (TEncEntropy.cpp:669-674)
+}
+// TEncSbac::codeCoeffNxN (:1829-2092) with the counting coder: fractional bits, contexts updated
+uint64_t ref_cabac_coeff_bits(uint8_t* states, const int32_t* coef, int N, int ttype, int isIntra, int lumaDir, int chromaDir,
+                              int signHide, int useTS, int tsFlag)
+{
+  static Char predMode[1]; static UChar trIdxA[1], lumaDirA[1], chromaDirA[1], depthA[1], tsA[3][1]; static Bool bypassA[1];
+  SbacCtx* c = sbac_get();
+  ContextModel::buildNextStateTable();
+  sbac_load(c->sbac, states);
+  c->pps.setSignHideFlag(signHide); c->pps.setUseTransformSkip(useTS != 0);
+  TComDataCU& cu = g->cu;
+  Char* sPred = cu.m_pePredMode; UChar* sTr = cu.m_puhTrIdx; UChar* sL = cu.m_puhLumaIntraDir; UChar* sC = cu.m_puhChromaIntraDir;
+  UChar* sD = cu.m_puhDepth; TComSlice* sS = cu.m_pcSlice; Bool* sB = cu.m_CUTransquantBypass;
+  UChar* sT[3] = { cu.m_puhTransformSkip[0], cu.m_puhTransformSkip[1], cu.m_puhTransformSkip[2] };
+  predMode[0] = isIntra ? MODE_INTRA : MODE_INTER; trIdxA[0] = 0; lumaDirA[0] = (UChar)lumaDir; chromaDirA[0] = (UChar)chromaDir; depthA[0] = 0; bypassA[0] = false;
+  for (int k = 0; k < 3; k++) { tsA[k][0] = (UChar)tsFlag; cu.m_puhTransformSkip[k] = tsA[k]; }
+  cu.m_pePredMode = predMode; cu.m_puhTrIdx = trIdxA; cu.m_puhLumaIntraDir = lumaDirA; cu.m_puhChromaIntraDir = chromaDirA; cu.m_puhDepth = depthA;
+  cu.m_pcSlice = &c->slice; cu.m_CUTransquantBypass = bypassA;
+  std::vector<TCoeff> in(coef, coef + N * N);
+  c->sbac.resetBits();                                       // keeps the fraction below one bit (TEncBinCABAC::resetBits)
+  const uint64_t f0 = c->bin.m_fracBits;
+  c->sbac.codeCoeffNxN(&cu, &in[0], 0, N, N, 0, (TextType)ttype);
+  const uint64_t frac = ((uint64_t)c->bits.getNumberOfWrittenBits() << 15) + c->bin.m_fracBits - f0;
+  sbac_store(c->sbac, states);
+  cu.m_pePredMode = sPred; cu.m_puhTrIdx = sTr; cu.m_puhLumaIntraDir = sL; cu.m_puhChromaIntraDir = sC; cu.m_puhDepth = sD; cu.m_pcSlice = sS;
+  cu.m_CUTransquantBypass = sB; for (int k = 0; k < 3; k++) cu.m_puhTransformSkip[k] = sT[k];
+  return frac;
 }
 
 // ---------------------------------------------------------------------------------------------

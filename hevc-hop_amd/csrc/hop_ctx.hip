@@ -535,6 +535,40 @@ int hop_rdoq(hop_ctx* c, int n, const hop_rdoq_job* jobs, int n_tables, const ho
   return HOP_OK;
 }
 
+int hop_coeff_bits_device(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int32_t* d_coef,
+                          uint64_t* d_bits, hop_cabac_ctx* d_ctx_out) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_ctx_in || !d_coef || !d_bits))) return hop_set_err(c, HOP_ERR_ARG, "hop_coeff_bits_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_coeff_bits(c, n, d_jobs, d_ctx_in, d_coef, (unsigned long long*)d_bits, d_ctx_out);
+}
+
+int hop_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, size_t n_coeff,
+                   const int32_t* coef, uint64_t* bits, hop_cabac_ctx* ctx_out) {
+  if (!c || n < 0 || (n && (!jobs || !ctx_in || !coef || !bits || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_coeff_bits: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_coeff_bits_job& j = jobs[i];
+    if (j.log2_size < 2 || j.log2_size > 5 || j.comp < 0 || j.comp > 2 || (j.comp && j.log2_size == 5) || j.scan_idx < 0 || j.scan_idx > 2 ||
+        j.ctx_index < 0 || j.ctx_index >= n_ctx || j.coeff_offset < 0 || (size_t)j.coeff_offset + ((size_t)1 << (2 * j.log2_size)) > n_coeff)
+      return hop_set_err(c, HOP_ERR_ARG, "coeff-bits job %d: illegal transform unit / context index / offset", i);
+  }
+  for (int k = 0; k < n_ctx; k++) for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+  const size_t bj = (size_t)n * sizeof(hop_coeff_bits_job), o_c = (bj + 255) & ~(size_t)255, bc = (size_t)n_ctx * sizeof(hop_cabac_ctx);
+  const size_t o_s = (o_c + bc + 255) & ~(size_t)255, o_b = (o_s + n_coeff * 4 + 255) & ~(size_t)255, o_o = (o_b + (size_t)n * 8 + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_o + (ctx_out ? (size_t)n * sizeof(hop_cabac_ctx) : 0) + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, bc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_s, coef, n_coeff * 4, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_coeff_bits(c, n, (const hop_coeff_bits_job*)b, (const hop_cabac_ctx*)(b + o_c), (const int32_t*)(b + o_s), (unsigned long long*)(b + o_b),
+                            ctx_out ? (hop_cabac_ctx*)(b + o_o) : nullptr);
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(bits, b + o_b, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (ctx_out) HIPCHK(c, hipMemcpyAsync(ctx_out, b + o_o, (size_t)n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
 int hop_distortion_device(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out) {
   if (!c || n < 0 || (n && (!d_jobs || !d_out))) return hop_set_err(c, HOP_ERR_ARG, "hop_distortion_device: bad argument");
   if (n == 0) return HOP_OK;

@@ -132,6 +132,8 @@ int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
 int hop_launch_rdoq(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum);
 void hop_rdoq_build_scans(uint16_t* tabs);
+int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx, const int32_t* d_coef,
+                          unsigned long long* d_bits, hop_cabac_ctx* d_ctx_out);
 #define HOP_RDOQ_SCAN_ENTRIES (4080 + 255)
 int hop_launch_ssref_reset(hop_ctx* c);
 int hop_launch_ssref_commit(hop_ctx* c, int n, const int32_t* d_rect4, const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr, int packed);

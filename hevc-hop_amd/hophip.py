@@ -57,6 +57,9 @@ class IntraJob(ctypes.Structure):
 RDOQ_JOB_DTYPE = np.dtype([("log2_size", "<i4"), ("comp", "<i4"), ("is_intra", "<i4"), ("scan_idx", "<i4"), ("tr_depth", "<i4"), ("qp_scaled", "<i4"),
                            ("bit_depth", "<i4"), ("sign_hide", "<i4"), ("lambda", "<f8"), ("coeff_offset", "<i8"), ("estbits_index", "<i4"), ("reserved", "<i4")])
 ESTBITS_INTS = 4 + 84 + 32 + 32 + 48 + 12 + 24 + 8       # hop_estbits as a flat int32 array
+COEFF_BITS_JOB_DTYPE = np.dtype([("log2_size", "<i4"), ("comp", "<i4"), ("scan_idx", "<i4"), ("sign_hide", "<i4"), ("use_ts", "<i4"), ("ts_flag", "<i4"),
+                                 ("ctx_index", "<i4"), ("reserved", "<i4"), ("coeff_offset", "<i8")])
+CABAC_CTX_BYTES = 152
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
                          ("qp_scaled", "<i4"), ("is_i_slice", "<i4")])
 INTRA_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("size", "<i4"), ("strong", "<i4"), ("flags", "u1", (68,))])
@@ -107,6 +110,12 @@ def load():
     L.hop_rdoq.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 3
     L.hop_rdoq_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
     L.hop_rdoq.restype = L.hop_rdoq_device.restype = ctypes.c_int
+    L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.hop_cabac_est_bits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.hop_coeff_bits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 3
+    L.hop_coeff_bits_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+    for n in ("hop_cabac_init", "hop_cabac_est_bits", "hop_coeff_bits", "hop_coeff_bits_device"):
+        getattr(L, n).restype = ctypes.c_int
     L.hop_tu_roundtrip_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
     L.hop_intra_rough_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.hop_distortion_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -244,6 +253,15 @@ class Context:
         self._chk(self.L.hop_rdoq(self.h, len(jobs), jobs.ctypes.data, len(tables), tables.ctypes.data, len(src), src.ctypes.data, dst.ctypes.data,
                                   asum.ctypes.data), "hop_rdoq")
         return dst, asum
+
+    def coeff_bits(self, jobs, ctx_in, coef, want_ctx=True):
+        """jobs: COEFF_BITS_JOB_DTYPE; ctx_in: (n_ctx, 152) uint8 snapshots; coef: all levels (int32) -> bits (uint64, Q15), ctx after each TU"""
+        jobs = np.ascontiguousarray(jobs, COEFF_BITS_JOB_DTYPE); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); coef = np.ascontiguousarray(coef, np.int32)
+        assert ctx_in.ndim == 2 and ctx_in.shape[1] == CABAC_CTX_BYTES
+        bits = np.zeros(len(jobs), np.uint64); out = np.zeros((len(jobs), CABAC_CTX_BYTES), np.uint8) if want_ctx else None
+        self._chk(self.L.hop_coeff_bits(self.h, len(jobs), jobs.ctypes.data, len(ctx_in), ctx_in.ctypes.data, len(coef), coef.ctypes.data, bits.ctypes.data,
+                                        out.ctypes.data if want_ctx else None), "hop_coeff_bits")
+        return bits, out
 
     def sync(self):
         self._chk(self.L.hop_sync(self.h), "hop_sync")

@@ -236,6 +236,38 @@ int hop_rdoq(hop_ctx* ctx, int n, const hop_rdoq_job* jobs, int n_tables, const 
 int hop_rdoq_device(hop_ctx* ctx, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src,
                     int32_t* d_dst, uint32_t* d_abs_sum);                                           /* asynchronous, unchecked */
 
+/* ---- CABAC bit estimator for residual coding (building block of rows a0 / a8 / a8b; feeds a11) ---- */
+/* Context states (ContextModel::m_ucState = state << 1 | MPS) of the sets residual coding uses, in the reference's set
+ * order (TLibEncoder/TEncSbac.cpp:76-88): qt_cbf[2][4] at 0, trans_subdiv[3] at 8, qt_root_cbf[1] at 11, sig_cg[2][2] at 12,
+ * sig[27 luma + 15 chroma] at 16, last_x[2][15] at 58, last_y[2][15] at 88, one[16 + 8] at 118, abs[4 + 2] at 142,
+ * transform_skip[2] at 148; 2 bytes of padding. */
+typedef struct { uint8_t state[152]; } hop_cabac_ctx;
+/* replaces: TEncSbac::resetEntropy for those sets (ContextModel3DBuffer::initBuffer + ContextModel::init,
+ * TLibEncoder/TEncSbac.cpp:136-148, TLibCommon/ContextModel.cpp:56-65, tables TLibCommon/ContextTables.h:340-546).
+ * slice_type: 0 B, 1 P, 2 I, 3 ISS, 4 PSS (TLibCommon/TypeDef.h:418-427). Host only. */
+int hop_cabac_init(hop_cabac_ctx* ctx, int slice_type, int qp);
+/* replaces: TEncSbac::estBit as TEncEntropy::estimateBit calls it (TLibEncoder/TEncSbac.cpp:2175-2370, TEncEntropy.cpp:669-674):
+ * the entries of the table the reference writes for this (width, component); the others are left as they are. Host only. */
+int hop_cabac_est_bits(const hop_cabac_ctx* ctx, int width, int comp, hop_estbits* est);
+typedef struct {
+  int32_t log2_size;       /* 2..5 (chroma 2..4) */
+  int32_t comp;            /* 0 Y, 1 Cb, 2 Cr */
+  int32_t scan_idx;        /* getCoefScanIdx */
+  int32_t sign_hide;       /* PPS sign_data_hiding && !cu_transquant_bypass */
+  int32_t use_ts;          /* PPS transform_skip_enabled */
+  int32_t ts_flag;         /* the TU's transform_skip_flag */
+  int32_t ctx_index;       /* which context snapshot the TU starts from */
+  int32_t reserved;
+  int64_t coeff_offset;    /* first level of the TU in coef (raster N x N, TCoeff) */
+} hop_coeff_bits_job;
+/* replaces: TEncSbac::codeCoeffNxN (TLibEncoder/TEncSbac.cpp:1829-2092) driven through the counting bin coder
+ * (TEncBinCoderCABACCounter.cpp:72-108) for a batch of TUs: bits[i] = fractional bits (15 binary places, the coder's
+ * m_fracBits) of the levels of TU i; ctx_out (may be NULL) receives the context states after TU i. */
+int hop_coeff_bits(hop_ctx* ctx, int n, const hop_coeff_bits_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, size_t n_coeff,
+                   const int32_t* coef, uint64_t* bits, hop_cabac_ctx* ctx_out);
+int hop_coeff_bits_device(hop_ctx* ctx, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int32_t* d_coef,
+                          uint64_t* d_bits, hop_cabac_ctx* d_ctx_out);                                /* asynchronous, unchecked */
+
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
  * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and
@@ -260,7 +292,8 @@ int hop_enumerate_ctu_jobs(int pic_w, int pic_h, int ctu_addr, int search_range,
 #define HOP_K_TQ        6
 #define HOP_K_INTRA     7
 #define HOP_K_RDOQ      8
-#define HOP_K_COUNT     9
+#define HOP_K_CABAC     9
+#define HOP_K_COUNT     10
 int hop_profile_enable(hop_ctx* ctx, int on);
 /* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
 int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);

@@ -52,3 +52,27 @@ def test_host_logic_without_gpu():
         assert L.hop_ctx_create(ctypes.byref(h), 64, 64, 8, 8, 0) != 0
         L.hop_last_error.restype = ctypes.c_char_p
         assert b"no HIP device" in L.hop_last_error(None) or b"device" in L.hop_last_error(None)
+
+
+def test_cabac_host_functions_vs_golden():
+    """hop_cabac_init / hop_cabac_est_bits are host logic of the library (no device needed): against the vectors made by the
+    reference's own TEncSbac (tests/golden/cabac.npz)"""
+    import ctypes
+    import numpy as np
+    from goldutil import load
+    L = _lib()
+    L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.hop_cabac_est_bits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    g = load("cabac.npz")
+    for st in range(5):
+        for qp in range(52):
+            b = np.full(152, 0xEE, np.uint8)
+            assert L.hop_cabac_init(b.ctypes.data, st, qp) == 0
+            assert np.array_equal(b[:150], g["init"][st, qp]) and b[150] == 0 and b[151] == 0
+    assert L.hop_cabac_init(b.ctypes.data, 5, 30) != 0
+    for st, (w, comp), want in zip(g["est_states"], g["est_par"], g["est_out"]):
+        s152 = np.zeros(152, np.uint8); s152[:150] = st
+        e = np.full(244, 0x5A5A, np.int32)
+        assert L.hop_cabac_est_bits(s152.ctypes.data, int(w), int(comp), e.ctypes.data) == 0
+        assert np.array_equal(e, want), (w, comp)
+    assert L.hop_cabac_est_bits(s152.ctypes.data, 32, 1, e.ctypes.data) != 0     # no chroma 32x32

@@ -144,3 +144,36 @@ def test_rdoq_golden(hp):
     with pytest.raises(hp.HopError):
         ctx.rdoq(bad, tables, src)
     ctx.close()
+
+
+def test_coeff_bits_golden(hp):
+    """CABAC bit estimator: k_coeff_bits (one lane per TU) against the reference-generated chains: every TU of a chain starts
+    from the context states the previous one left (fed back through ctx_out), bits and final states must match"""
+    g = load("cabac.npz")
+    par, coef, bits, chains, finals, init = g["par"], g["coef"], g["bits"], g["chains"], g["finals"], g["init"]
+    ctx = hp.Context(64, 64)
+    # step k of every chain in one batch: the chains are independent, the TUs of a chain are not
+    state = np.zeros((len(chains), hp.CABAC_CTX_BYTES), np.uint8)
+    for i, (sl, qp, t0, t1) in enumerate(chains):
+        state[i, :150] = init[sl, qp]
+    step = 0
+    while True:
+        act = [i for i, (sl, qp, t0, t1) in enumerate(chains) if t0 + step < t1]
+        if not act:
+            break
+        jobs = np.zeros(len(act), hp.COEFF_BITS_JOB_DTYPE)
+        for k, i in enumerate(act):
+            log2, comp, scan, sh, uts, tsf, off = (int(v) for v in par[chains[i][2] + step])
+            j = jobs[k]
+            j["log2_size"], j["comp"], j["scan_idx"], j["sign_hide"], j["use_ts"], j["ts_flag"], j["ctx_index"], j["coeff_offset"] = log2, comp, scan, sh, uts, tsf, i, off
+        b, out = ctx.coeff_bits(jobs, state, coef)
+        for k, i in enumerate(act):
+            assert int(b[k]) == int(bits[chains[i][2] + step]), (i, step)
+            state[i] = out[k]
+        step += 1
+    assert step >= 4
+    assert np.array_equal(state[:, :150], finals)
+    bad = np.zeros(1, hp.COEFF_BITS_JOB_DTYPE); bad["log2_size"], bad["ctx_index"] = 3, len(chains)
+    with pytest.raises(hp.HopError):
+        ctx.coeff_bits(bad, state, coef)
+    ctx.close()

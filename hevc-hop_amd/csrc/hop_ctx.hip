@@ -88,6 +88,8 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   if (e == hipSuccess) e = hipMalloc((void**)&c->rec[0], ny * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->rec[1], nc * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->rec[2], nc * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->entropy_bits, 128 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(c->entropy_bits, hop_entropy_bits_host(), 128 * sizeof(int32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&c->rdoq_scans, HOP_RDOQ_SCAN_ENTRIES * sizeof(uint16_t));
   if (e == hipSuccess) {
     std::vector<uint16_t> tabs(HOP_RDOQ_SCAN_ENTRIES);
@@ -112,7 +114,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
-                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rdoq_scans };
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rdoq_scans, c->entropy_bits };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
@@ -565,6 +567,45 @@ int hop_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* jobs, int n_ctx,
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(bits, b + o_b, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
   if (ctx_out) HIPCHK(c, hipMemcpyAsync(ctx_out, b + o_o, (size_t)n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_tu_rd_device(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int64_t* d_coef_offsets, size_t n_coeff,
+                     int32_t* d_levels, hop_tu_rd_result* d_results) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_ctx_in || !d_coef_offsets || !d_levels || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_rd_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_rd: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  return hop_launch_tu_rd(c, n, d_jobs, d_ctx_in, d_coef_offsets, n_coeff, d_levels, d_results);
+}
+
+int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_tu_rd_result* results, int32_t* levels_out) {
+  if (!c || n < 0 || (n && (!jobs || !ctx_in || !results || !levels_out || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_rd: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_rd: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  std::vector<int64_t> offs(n);
+  size_t tot = 0;
+  for (int i = 0; i < n; i++) {
+    const hop_tu_rd_job& j = jobs[i];
+    const int N = 1 << j.log2_size, sh = j.comp ? 1 : 0;
+    if (j.comp < 0 || j.comp > 2 || j.log2_size < 2 || j.log2_size > 5 || (j.comp && j.log2_size == 5) || j.x < 0 || j.y < 0 || ((j.x >> sh) & 3) || ((j.y >> sh) & 3) ||
+        (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || j.tr_depth < 0 || j.tr_depth > 3 ||
+        j.ctx_index < 0 || j.ctx_index >= n_ctx || j.bit_depth != (j.comp ? c->bd_c : c->bd_y) || !(j.lambda_rdoq > 0.0) || !(j.lambda_rd > 0.0))
+      return hop_set_err(c, HOP_ERR_ARG, "TU RD job %d: illegal transform unit / snapshot / parameters", i);
+    offs[i] = (int64_t)tot; tot += (size_t)N * N;
+  }
+  for (int k = 0; k < n_ctx; k++) for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+  const size_t bj = (size_t)n * sizeof(hop_tu_rd_job), o_c = (bj + 255) & ~(size_t)255, bc = (size_t)n_ctx * sizeof(hop_cabac_ctx);
+  const size_t o_o = (o_c + bc + 255) & ~(size_t)255, o_l = (o_o + (size_t)n * 8 + 255) & ~(size_t)255, o_r = (o_l + tot * 4 + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_r + (size_t)n * sizeof(hop_tu_rd_result) + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, bc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_o, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_tu_rd(c, n, (const hop_tu_rd_job*)b, (const hop_cabac_ctx*)(b + o_c), (const int64_t*)(b + o_o), tot, (int32_t*)(b + o_l), (hop_tu_rd_result*)(b + o_r));
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(results, b + o_r, (size_t)n * sizeof(hop_tu_rd_result), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(levels_out, b + o_l, tot * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }

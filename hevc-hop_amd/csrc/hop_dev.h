@@ -33,6 +33,7 @@ struct hop_ctx {
   hipStream_t xstream[HOP_MAX_LANES - 1]; void* xscratch[HOP_MAX_LANES - 1]; size_t xscratch_bytes[HOP_MAX_LANES - 1];
   hipEvent_t ev_fork, ev_join[HOP_MAX_LANES - 1]; int lanes;   // HOP_LANES=1..4 (default 2)
   bool   have_orig;
+  int32_t* entropy_bits;             // device: the 128 fractional-bit values of the CABAC states (ContextModel::m_entropyBits)
   uint16_t* rdoq_scans;              // device: the scan tables of the RDOQ kernel (hop_rdoq_build_scans)
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
   char   err[512];
@@ -132,6 +133,10 @@ int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
 int hop_launch_rdoq(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum);
 void hop_rdoq_build_scans(uint16_t* tabs);
+const int32_t* hop_entropy_bits_host(void);
+static inline const int32_t* hop_entropy_bits_device(const hop_ctx* c) { return c->entropy_bits; }
+int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
+                     int32_t* d_levels, hop_tu_rd_result* d_res);
 int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx, const int32_t* d_coef,
                           unsigned long long* d_bits, hop_cabac_ctx* d_ctx_out);
 #define HOP_RDOQ_SCAN_ENTRIES (4080 + 255)

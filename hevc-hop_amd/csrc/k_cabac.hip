@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __r
   const uint16_t* scanCG = scans + 4080 + scan_idx * 85 + co;
   int numSig = 0;
   if (live) for (int i = 0; i < nco; i++) numSig += coef[i] != 0;
+  if (live && jb.cbf_ctx_plus1) CBIN(CX_QT_CBF + jb.cbf_ctx_plus1 - 1, numSig != 0 ? 1 : 0);      // encodeQtCbf (TEncSbac.cpp:1596-1600)
   if (numSig != 0) {
     if (jb.use_ts && width == 4) CBIN(CX_TS + chroma, jb.ts_flag ? 1 : 0);
     unsigned long long cgFlag = 0;
@@ -282,9 +283,16 @@ __global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __r
   }
   if (live) {
     bits_out[j] = frac;
-    if (ctx_out) { uint8_t* dst = ctx_out[j].state; for (int i = 0; i < 152; i++) dst[i] = sh.st[i][lane]; }
+    if (ctx_out) {
+      uint8_t* dst = ctx_out[j].state;
+      for (int i = 0; i < 150; i++) dst[i] = sh.st[i][lane];
+      const unsigned left = ((unsigned)sh.st[150][lane] | ((unsigned)sh.st[151][lane] << 8)) + (unsigned)(frac & 32767ull);   // what resetBits will keep
+      dst[150] = (uint8_t)(left & 0xFF); dst[151] = (uint8_t)((left >> 8) & 0x7F);
+    }
   }
 }
+
+const int32_t* hop_entropy_bits_host(void) { return h_entropy_bits; }
 
 int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx, const int32_t* d_coef,
                           unsigned long long* d_bits, hop_cabac_ctx* d_ctx_out) {

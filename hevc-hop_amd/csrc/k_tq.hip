@@ -132,3 +132,203 @@ int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "tu_roundtrip launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+// =====================================================================================================================
+// Row a8b, leaf step: the evaluation of one component TU inside TEncSearch::xEstimateResidualQT
+// (TLibEncoder/TEncSearch.cpp:6896-7200) as a pipeline of kernels over a batch of TUs:
+//   k_turd_forward   residual = original - prediction picture, xT (:6912 first half), zero-residual distortion (:6984)
+//   k_turd_setup     TEncSbac::estBit from the TU's context snapshot (:6901-6904) + the job records of the next two stages
+//   k_rdoq           xRateDistOptQuant (second half of transformNxN)                                   [k_rdoq.hip]
+//   k_coeff_bits     cbf flag + levels through the counting coder, from the snapshot (:6957-6962)        [k_cabac.hip]
+//   k_turd_inverse   xDeQuant + xIT of the levels (:6998), distortion against the residual (:7000)
+//   k_turd_decide    integer bits, calcRdCost of coding vs. cbf = 0 (:7008-7032), the choice; levels zeroed if cbf = 0 wins
+// The default transform only: the 4x4 transform-skip retry (:7210-7440), the chroma-of-4x4-luma merging and the split
+// recursion stay with the caller.
+// =====================================================================================================================
+struct TurdFwdShared { int16_t a[32 * 32]; int16_t b[32 * 32]; int16_t T[32 * 32]; unsigned int acc; };
+
+__global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __restrict__ jobs, hop_pics pic, const int64_t* __restrict__ coef_off,
+                                                      int32_t* __restrict__ coef, uint32_t* __restrict__ zero_sse) {
+  __shared__ TurdFwdShared sh;
+  const hop_tu_rd_job jb = jobs[blockIdx.x];
+  const int tid = threadIdx.x, log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
+  const bool chroma = jb.comp != 0;
+  const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
+  const int x0 = chroma ? jb.x >> 1 : jb.x, y0 = chroma ? jb.y >> 1 : jb.y;
+  const int16_t* org = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
+  const int16_t* prd = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+  if (tid == 0) sh.acc = 0;
+  for (int i = tid; i < NN; i += 256) { int k = i >> log2N, n = i & (N - 1); sh.T[i] = (int16_t)dct_coef(32 >> log2N, k, n); }
+  __syncthreads();
+  unsigned part = 0;
+  const unsigned sshift = (unsigned)((bd - 8) << 1);
+  for (int i = tid; i < NN; i += 256) {
+    int r = i >> log2N, c = i & (N - 1);
+    const int e = (int)org[(size_t)r * pitch + c] - (int)prd[(size_t)r * pitch + c];
+    sh.a[i] = (int16_t)e;
+    part += (unsigned)(e * e) >> sshift;                          // getDistPart(zero block, residual), SSE
+  }
+  part = (unsigned)hopd_wave_sum((int)part);
+  if ((tid & 63) == 0) atomicAdd(&sh.acc, part);
+  __syncthreads();
+  const int s1 = log2N - 1 + bd - 8, s2 = log2N + 6;               // xTrMxN :788-789
+  for (int i = tid; i < NN; i += 256) {
+    int k = i >> log2N, j = i & (N - 1), sum = 0;
+    for (int n = 0; n < N; n++) sum += sh.T[k * N + n] * sh.a[j * N + n];
+    sh.b[k * N + j] = (int16_t)((sum + (1 << (s1 - 1))) >> s1);
+  }
+  __syncthreads();
+  int32_t* out = coef + coef_off[blockIdx.x];
+  for (int i = tid; i < NN; i += 256) {
+    int k = i >> log2N, j = i & (N - 1), sum = 0;
+    for (int n = 0; n < N; n++) sum += sh.T[k * N + n] * sh.b[j * N + n];
+    out[k * N + j] = (int)(int16_t)((sum + (1 << (s2 - 1))) >> s2);
+  }
+  if (tid == 0) zero_sse[blockIdx.x] = sh.acc;
+}
+
+__global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __restrict__ jobs, hop_pics pic, const int64_t* __restrict__ coef_off,
+                                                      const int32_t* __restrict__ levels, const uint32_t* __restrict__ abs_sum, uint32_t* __restrict__ nz_sse) {
+  __shared__ TurdFwdShared sh;                                     // a: dequantised / residual, b: intermediate
+  if (abs_sum[blockIdx.x] == 0) { if (threadIdx.x == 0) nz_sse[blockIdx.x] = 0; return; }
+  const hop_tu_rd_job jb = jobs[blockIdx.x];
+  const int tid = threadIdx.x, log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
+  const bool chroma = jb.comp != 0;
+  const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
+  const int x0 = chroma ? jb.x >> 1 : jb.x, y0 = chroma ? jb.y >> 1 : jb.y;
+  const int16_t* org = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
+  const int16_t* prd = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+  if (tid == 0) sh.acc = 0;
+  for (int i = tid; i < NN; i += 256) { int k = i >> log2N, n = i & (N - 1); sh.T[i] = (int16_t)dct_coef(32 >> log2N, k, n); }
+  {
+    const int per = jb.qp_scaled / 6, rem = jb.qp_scaled % 6, transformShift = 15 - bd - log2N;
+    const int dshift = 20 - 14 - transformShift, dadd = 1 << (dshift - 1), scale = c_inv_quant_scales[rem] << per;     // xDeQuant :1171-1182
+    const int32_t* lv = levels + coef_off[blockIdx.x];
+    for (int i = tid; i < NN; i += 256) sh.a[i] = (int16_t)clip16((clip16(lv[i]) * scale + dadd) >> dshift);
+  }
+  __syncthreads();
+  const int s1 = 7, s2 = 12 - (bd - 8);                            // SHIFT_INV_1ST / SHIFT_INV_2ND
+  for (int i = tid; i < NN; i += 256) {
+    int j = i >> log2N, n = i & (N - 1), sum = 0;
+    for (int k = 0; k < N; k++) sum += sh.T[k * N + n] * sh.a[k * N + j];
+    sh.b[j * N + n] = (int16_t)clip16((sum + (1 << (s1 - 1))) >> s1);
+  }
+  __syncthreads();
+  unsigned part = 0;
+  const unsigned sshift = (unsigned)((bd - 8) << 1);
+  for (int i = tid; i < NN; i += 256) {
+    int j = i >> log2N, n = i & (N - 1), sum = 0;
+    for (int k = 0; k < N; k++) sum += sh.T[k * N + n] * sh.b[k * N + j];
+    const int rr = clip16((sum + (1 << (s2 - 1))) >> s2);          // reconstructed residual sample (j, n)
+    const int e = rr - ((int)org[(size_t)j * pitch + n] - (int)prd[(size_t)j * pitch + n]);
+    part += (unsigned)(e * e) >> sshift;
+  }
+  part = (unsigned)hopd_wave_sum((int)part);
+  if ((tid & 63) == 0) atomicAdd(&sh.acc, part);
+  __syncthreads();
+  if (tid == 0) nz_sse[blockIdx.x] = sh.acc;
+}
+
+// one thread per TU: the bit-estimate table of its snapshot (TEncSbac::estBit as hop_cabac_est_bits) and the job records
+__global__ void k_turd_setup(const hop_tu_rd_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const int64_t* __restrict__ coef_off,
+                             const int32_t* __restrict__ entropy_bits, hop_estbits* __restrict__ tables, hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const hop_tu_rd_job jb = jobs[i];
+  const uint8_t* s = ctx_in[jb.ctx_index].state;
+  hop_estbits* eb = tables + i;
+  const int width = 1 << jb.log2_size, chroma = jb.comp != 0;
+  int32_t* w = (int32_t*)eb;
+  for (int k = 0; k < (int)(sizeof(hop_estbits) / 4); k++) w[k] = 0;
+  for (int k = 0; k < 12; k++) { eb->blockCbpBits[k][0] = entropy_bits[s[k] ^ 0]; eb->blockCbpBits[k][1] = entropy_bits[s[k] ^ 1]; }
+  for (int k = 0; k < 4; k++) { eb->blockRootCbpBits[k][0] = entropy_bits[s[11 + k] ^ 0]; eb->blockRootCbpBits[k][1] = entropy_bits[s[11 + k] ^ 1]; }
+  for (int k = 0; k < 2; k++) for (int b = 0; b < 2; b++) eb->significantCoeffGroupBits[k][b] = entropy_bits[s[12 + 2 * chroma + k] ^ b];
+  int firstCtx = 1, numCtx = 8;
+  if (width >= 16) { firstCtx = chroma ? 12 : 21; numCtx = chroma ? 3 : 6; }
+  else if (width == 8) { firstCtx = 9; numCtx = chroma ? 3 : 12; }
+  const int base = 16 + (chroma ? 27 : 0);
+  for (int b = 0; b < 2; b++) eb->significantBits[0][b] = entropy_bits[s[base] ^ b];
+  for (int k = firstCtx; k < firstCtx + numCtx; k++) for (int b = 0; b < 2; b++) eb->significantBits[k][b] = entropy_bits[s[base + k] ^ b];
+  const int cbt = jb.log2_size - 2;
+  const int off = chroma ? 0 : (cbt * 3 + ((cbt + 1) >> 2)), shf = chroma ? cbt : ((cbt + 3) >> 2);
+  const uint8_t* px = s + 58 + 15 * chroma; const uint8_t* py = s + 88 + 15 * chroma;
+  const int gmax = (width == 4) ? 3 : (width == 8) ? 5 : (width == 16) ? 7 : 9;       // g_uiGroupIdx[width - 1]
+  int bitsX = 0, bitsY = 0, c;
+  for (c = 0; c < gmax; c++) { const int o = off + (c >> shf); eb->lastXBits[c] = bitsX + entropy_bits[px[o] ^ 0]; bitsX += entropy_bits[px[o] ^ 1]; }
+  eb->lastXBits[c] = bitsX;
+  for (c = 0; c < gmax; c++) { const int o = off + (c >> shf); eb->lastYBits[c] = bitsY + entropy_bits[py[o] ^ 0]; bitsY += entropy_bits[py[o] ^ 1]; }
+  eb->lastYBits[c] = bitsY;
+  const int no = chroma ? 8 : 16, na = chroma ? 2 : 4, oo = 118 + (chroma ? 16 : 0), oa = 142 + (chroma ? 4 : 0);
+  for (int k = 0; k < no; k++) { eb->greaterOneBits[k][0] = entropy_bits[s[oo + k] ^ 0]; eb->greaterOneBits[k][1] = entropy_bits[s[oo + k] ^ 1]; }
+  for (int k = 0; k < na; k++) { eb->levelAbsBits[k][0] = entropy_bits[s[oa + k] ^ 0]; eb->levelAbsBits[k][1] = entropy_bits[s[oa + k] ^ 1]; }
+  hop_rdoq_job r;
+  r.log2_size = jb.log2_size; r.comp = jb.comp; r.is_intra = 0; r.scan_idx = 0; r.tr_depth = jb.tr_depth; r.qp_scaled = jb.qp_scaled;
+  r.bit_depth = jb.bit_depth; r.sign_hide = jb.sign_hide; r.lambda = jb.lambda_rdoq; r.coeff_offset = coef_off[i]; r.estbits_index = i; r.reserved = 0;
+  rq[i] = r;
+  hop_coeff_bits_job b;
+  b.log2_size = jb.log2_size; b.comp = jb.comp; b.scan_idx = 0; b.sign_hide = jb.sign_hide; b.use_ts = jb.use_ts; b.ts_flag = 0; b.ctx_index = jb.ctx_index;
+  b.cbf_ctx_plus1 = 1 + 4 * chroma + (chroma ? jb.tr_depth : (jb.tr_depth == 0 ? 1 : 0));           // getCtxQtCbf, TComDataCU.cpp:1848-1859
+  b.coeff_offset = coef_off[i];
+  cb[i] = b;
+}
+
+// one thread per TU: integer bits, the two RD costs, the choice (TEncSearch.cpp:7004-7032; calcRdCost TComRdCost.cpp:59-111)
+__global__ void k_turd_decide(const hop_tu_rd_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const int64_t* __restrict__ coef_off,
+                              const int32_t* __restrict__ entropy_bits, const uint32_t* __restrict__ abs_sum, const unsigned long long* __restrict__ frac,
+                              const uint32_t* __restrict__ zero_sse, const uint32_t* __restrict__ nz_sse, int32_t* __restrict__ levels,
+                              hop_tu_rd_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const hop_tu_rd_job jb = jobs[i];
+  const uint8_t* s = ctx_in[jb.ctx_index].state;
+  const uint32_t left = (uint32_t)s[150] | ((uint32_t)s[151] << 8);                                  // fraction below one bit the coder carries
+  const int chroma = jb.comp != 0;
+  const uint32_t zeroDist = chroma ? (uint32_t)(int)(jb.dist_weight * zero_sse[i]) : zero_sse[i];   // getDistPart, TComRdCost.cpp:493-502
+  const uint32_t nzDist = chroma ? (uint32_t)(int)(jb.dist_weight * nz_sse[i]) : nz_sse[i];
+  const uint32_t singleBits = (uint32_t)((left + frac[i]) >> 15);
+  hop_tu_rd_result r;
+  r.abs_sum = abs_sum[i]; r.zero_dist = zeroDist; r.nonzero_dist = 0; r.bits = singleBits; r.null_bits = 0; r.dist = zeroDist; r.pad = 0;
+  if (r.abs_sum) {
+    r.nonzero_dist = nzDist;
+    const double singleCost = (double)(uint32_t)floor((double)nzDist + (double)((int)(singleBits * jb.lambda_rd + .5)));
+    const int cbfCtx = 4 * chroma + (chroma ? jb.tr_depth : (jb.tr_depth == 0 ? 1 : 0));
+    r.null_bits = (uint32_t)((left + (unsigned long long)entropy_bits[s[cbfCtx] ^ 0]) >> 15);       // encodeQtCbfZero from the snapshot
+    const double nullCost = (double)(uint32_t)floor((double)zeroDist + (double)((int)(r.null_bits * jb.lambda_rd + .5)));
+    if (nullCost < singleCost) {
+      r.abs_sum = 0; r.cost = nullCost;
+      int32_t* lv = levels + coef_off[i];
+      for (int k = 0; k < (1 << (2 * jb.log2_size)); k++) lv[k] = 0;
+    } else { r.dist = nzDist; r.cost = singleCost; }
+  } else {
+    r.cost = (double)(uint32_t)floor((double)zeroDist + (double)((int)(singleBits * jb.lambda_rd + .5)));
+  }
+  r.cbf = r.abs_sum != 0;
+  res[i] = r;
+}
+
+int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
+                     int32_t* d_levels, hop_tu_rd_result* d_res) {
+  // scratch: coefficients, zero / non-zero SSE, abs sums, counted bits, the bit-estimate tables and the job records of the inner stages
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_coef = 0, o_zs = al(o_coef + n_coeff * 4), o_ns = al(o_zs + (size_t)n * 4), o_as = al(o_ns + (size_t)n * 4), o_fr = al(o_as + (size_t)n * 4);
+  const size_t o_tab = al(o_fr + (size_t)n * 8), o_rq = al(o_tab + (size_t)n * sizeof(hop_estbits)), o_cb = al(o_rq + (size_t)n * sizeof(hop_rdoq_job));
+  void* sc; int r = hop_scratch(c, al(o_cb + (size_t)n * sizeof(hop_coeff_bits_job)) + 256, &sc); if (r) return r;
+  char* b = (char*)sc;
+  int32_t* coef = (int32_t*)(b + o_coef); uint32_t* zs = (uint32_t*)(b + o_zs); uint32_t* ns = (uint32_t*)(b + o_ns); uint32_t* as = (uint32_t*)(b + o_as);
+  unsigned long long* fr = (unsigned long long*)(b + o_fr); hop_estbits* tab = (hop_estbits*)(b + o_tab);
+  hop_rdoq_job* rq = (hop_rdoq_job*)(b + o_rq); hop_coeff_bits_job* cb = (hop_coeff_bits_job*)(b + o_cb);
+  hop_pics pic = hop_make_pics(c);
+  const int pr = hop_prof_begin(c, HOP_K_TQ, (uint64_t)n);
+  hipLaunchKernelGGL(k_turd_forward, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, coef, zs);
+  hipLaunchKernelGGL(k_turd_setup, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_jobs, n, d_ctx, d_coef_off, hop_entropy_bits_device(c), tab, rq, cb);
+  hop_prof_end(c, pr);
+  r = hop_launch_rdoq(c, n, rq, tab, coef, d_levels, as); if (r) return r;
+  r = hop_launch_coeff_bits(c, n, cb, d_ctx, d_levels, fr, nullptr); if (r) return r;
+  const int pr2 = hop_prof_begin(c, HOP_K_TQ, 0);
+  hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, as, ns);
+  hipLaunchKernelGGL(k_turd_decide, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_jobs, n, d_ctx, d_coef_off, hop_entropy_bits_device(c), as, fr, zs, ns, d_levels, d_res);
+  hop_prof_end(c, pr2);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "tu_rd launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

@@ -240,7 +240,8 @@ int hop_rdoq_device(hop_ctx* ctx, int n, const hop_rdoq_job* d_jobs, const hop_e
 /* Context states (ContextModel::m_ucState = state << 1 | MPS) of the sets residual coding uses, in the reference's set
  * order (TLibEncoder/TEncSbac.cpp:76-88): qt_cbf[2][4] at 0, trans_subdiv[3] at 8, qt_root_cbf[1] at 11, sig_cg[2][2] at 12,
  * sig[27 luma + 15 chroma] at 16, last_x[2][15] at 58, last_y[2][15] at 88, one[16 + 8] at 118, abs[4 + 2] at 142,
- * transform_skip[2] at 148; 2 bytes of padding. */
+ * transform_skip[2] at 148; state[150..151] = the fraction below one bit the counting coder carries (m_fracBits & 32767,
+ * little endian): TEncBinCABAC::resetBits keeps it, so integer bit counts depend on it. */
 typedef struct { uint8_t state[152]; } hop_cabac_ctx;
 /* replaces: TEncSbac::resetEntropy for those sets (ContextModel3DBuffer::initBuffer + ContextModel::init,
  * TLibEncoder/TEncSbac.cpp:136-148, TLibCommon/ContextModel.cpp:56-65, tables TLibCommon/ContextTables.h:340-546).
@@ -257,7 +258,8 @@ typedef struct {
   int32_t use_ts;          /* PPS transform_skip_enabled */
   int32_t ts_flag;         /* the TU's transform_skip_flag */
   int32_t ctx_index;       /* which context snapshot the TU starts from */
-  int32_t reserved;
+  int32_t cbf_ctx_plus1;   /* 0: levels only; else 1 + index of the coded_block_flag context in qt_cbf[8] (component class * 4 +
+                              getCtxQtCbf): the flag (= any level non-zero) is coded first, as encodeQtCbf + encodeCoeffNxN do */
   int64_t coeff_offset;    /* first level of the TU in coef (raster N x N, TCoeff) */
 } hop_coeff_bits_job;
 /* replaces: TEncSbac::codeCoeffNxN (TLibEncoder/TEncSbac.cpp:1829-2092) driven through the counting bin coder
@@ -267,6 +269,39 @@ int hop_coeff_bits(hop_ctx* ctx, int n, const hop_coeff_bits_job* jobs, int n_ct
                    const int32_t* coef, uint64_t* bits, hop_cabac_ctx* ctx_out);
 int hop_coeff_bits_device(hop_ctx* ctx, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int32_t* d_coef,
                           uint64_t* d_bits, hop_cabac_ctx* d_ctx_out);                                /* asynchronous, unchecked */
+
+/* ---- residual quadtree, leaf step (row a8b) ---- */
+/* One component TU of TEncSearch::xEstimateResidualQT (TLibEncoder/TEncSearch.cpp:6896-7200), default transform:
+ * residual = original - prediction picture -> xT -> estBit from the snapshot -> xRateDistOptQuant -> bits of cbf flag + levels
+ * from the snapshot (integer, as getNumberOfWrittenBits) -> xDeQuant + xIT -> distortion in the residual domain -> the
+ * cbf-zero decision on TComRdCost::calcRdCost values (:7008-7032).  Not included: the 4x4 transform-skip retry (:7210-7440),
+ * the split recursion and the root-cbf decision of the caller. */
+typedef struct {
+  int32_t x, y;            /* luma position of the TU (chroma planes use x/2, y/2) */
+  int32_t comp;            /* 0 Y, 1 Cb, 2 Cr */
+  int32_t log2_size;       /* 2..5 (chroma 2..4) */
+  int32_t qp_scaled;
+  int32_t tr_depth;        /* uiTrMode */
+  int32_t ctx_index;       /* context snapshot (CI_QT_TRAFO_ROOT) */
+  int32_t sign_hide, use_ts;
+  int32_t bit_depth;       /* of the component (must equal the context's) */
+  double  lambda_rdoq;     /* TComTrQuant::m_dLambda after selectLambda */
+  double  lambda_rd;       /* TComRdCost::m_dLambda */
+  double  dist_weight;     /* chroma distortion weight of getDistPart (TLibCommon/TComRdCost.cpp:493-497); ignored for luma */
+} hop_tu_rd_job;
+typedef struct {
+  uint32_t abs_sum, cbf;   /* after the decision */
+  uint32_t dist;           /* distortion of the choice */
+  uint32_t zero_dist, nonzero_dist;
+  uint32_t bits, null_bits;/* uiSingleBits, uiNullBits (integer) */
+  uint32_t pad;
+  double   cost;           /* calcRdCost of the choice */
+} hop_tu_rd_result;
+/* levels_out: final levels of TU i at levels_out[sum_{k<i} size_k^2 ...] */
+int hop_tu_rd(hop_ctx* ctx, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_tu_rd_result* results, int32_t* levels_out);
+/* d_coef_offsets[i] = first level of TU i in d_levels (n_coeff entries in total) */
+int hop_tu_rd_device(hop_ctx* ctx, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int64_t* d_coef_offsets, size_t n_coeff,
+                     int32_t* d_levels, hop_tu_rd_result* d_results);                                 /* asynchronous, unchecked */
 
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with

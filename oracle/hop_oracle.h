@@ -37,6 +37,11 @@ int hop_o_me_pu(const int16_t* org, int orgStride, const int16_t* refY00, int re
                 int rngL, int rngR, int rngT, int rngB, int offX, int offY,
                 int predX, int predY, int nAmvp, const int* amvpXY, uint32_t lambdaCost,
                 int fen, int useHad, int bitDepth, int stage, int64_t* out);
+/* ---- a9 / a10 (hop_oracle_tq.c) ---- */
+void hop_o_fwd_transform(int bitDepth, const int16_t* block, int16_t* coeff, int N, int useDst);
+void hop_o_inv_transform(int bitDepth, const int16_t* coeff, int16_t* block, int N, int useDst);
+uint32_t hop_o_quant_flat(int bitDepth, int qpScaled, int isISlice, const int32_t* coef, int32_t* level, int N);
+void hop_o_dequant_flat(int bitDepth, int qpScaled, const int32_t* level, int32_t* coef, int N);
 /* ---- a11: rate-distortion optimised quantisation (hop_oracle_rdoq.c) ---- */
 /* the reference's estBitsSbacStruct (TLibCommon/TComTrQuant.h:59-70), same member order and sizes */
 typedef struct {
@@ -70,6 +75,9 @@ void hop_o_cabac_est_bits(const hop_o_cabac_ctx* c, int width, int comp, hop_o_e
 uint64_t hop_o_cabac_coeff_bits(hop_o_cabac_ctx* c, const int32_t* coef, int log2_size, int comp, int scan_idx, int sign_hide, int use_ts, int ts_flag);
 uint64_t hop_o_cabac_cbf_bits(hop_o_cabac_ctx* c, int comp, int tr_depth, int cbf);
 uint64_t hop_o_cabac_root_cbf_bits(hop_o_cabac_ctx* c, int cbf);
+int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,
+                double lambda_rdoq, double lambda_rd, double dist_weight, const hop_o_cabac_ctx* snap, uint32_t frac_left,
+                int32_t* levels, uint32_t* out, double* cost);
 void hop_o_scan_init(void);
 const uint32_t* hop_o_scan(int scan_idx, int log2_size);
 const uint32_t* hop_o_scan_cg(int scan_idx, int log2_size);

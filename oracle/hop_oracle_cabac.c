@@ -13,6 +13,7 @@
 #include <stddef.h>
 #include <string.h>
 #include <stdlib.h>
+#include <math.h>
 #include "hop_oracle.h"
 
 static const uint8_t next_state_mps[128] = {
@@ -310,4 +311,64 @@ uint64_t hop_o_cabac_root_cbf_bits(hop_o_cabac_ctx* c, int cbf)
   uint64_t frac = 0;
   BIN(&c->qt_root_cbf[0], cbf ? 1 : 0);
   return frac;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Row a8b, leaf step: the evaluation of ONE component TU inside TEncSearch::xEstimateResidualQT
+ * (TLibEncoder/TEncSearch.cpp:6896-7200, the default transform; the 4x4 transform-skip retry :7210-7440 and the split
+ * recursion are the caller's): estBit from the snapshot (:6901-6904), transformNxN = xT + xRateDistOptQuant (:6912), the bits
+ * of cbf flag + levels from the snapshot (:6959-6962, integer bits = (fraction left in the coder + counted) >> 15,
+ * TEncBinCoderCABACCounter.cpp:60-63 after TEncBinCABAC::resetBits), zero-residual distortion (:6984), inverse path and
+ * its distortion (:6998-7001), the cbf-zero decision on calcRdCost values (:7008-7032; TComRdCost.cpp:59-111).
+ * resi: residual block (Pel, stride N).  frac_left: m_fracBits & 32767 of the snapshot.  dist_weight: 1.0 for luma, the
+ * chroma weight of getDistPart (TComRdCost.cpp:493-497) otherwise.  out[8]: abs_sum, cbf, dist, zero_dist, nonzero_dist,
+ * single_bits, null_bits, -; *cost = the cost of the choice. levels: final levels. */
+static double calc_rd_cost(uint32_t bits, uint32_t dist, double lambda)
+{
+  double c = ((double)dist + (double)((int)(bits * lambda + .5)));
+  return (double)(uint32_t)floor(c);
+}
+static uint32_t weighted(uint32_t sse, int comp, double w) { return comp ? (uint32_t)(int)(w * sse) : sse; }
+
+int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,
+                double lambda_rdoq, double lambda_rd, double dist_weight, const hop_o_cabac_ctx* snap, uint32_t frac_left,
+                int32_t* levels, uint32_t* out, double* cost)
+{
+  const int N = 1 << log2_size, n2 = N * N;
+  if (log2_size < 2 || log2_size > 5 || (comp && log2_size == 5)) return -1;
+  int16_t c16[32 * 32], r2[32 * 32], zero[32 * 32];
+  int32_t c32[32 * 32], dq[32 * 32];
+  hop_o_estbits eb;
+  memset(&eb, 0, sizeof(eb));
+  hop_o_cabac_est_bits(snap, N, comp, &eb);
+  hop_o_fwd_transform(bit_depth, resi, c16, N, 0);
+  for (int i = 0; i < n2; i++) c32[i] = c16[i];
+  uint32_t absSum = 0;
+  memset(levels, 0, sizeof(int32_t) * (size_t)n2);
+  hop_o_rdoq(c32, levels, log2_size, comp, 0, 0, tr_depth, qp_scaled, bit_depth, sign_hide, lambda_rdoq, &eb, &absSum);
+  hop_o_cabac_ctx s = *snap;
+  uint64_t f = hop_o_cabac_cbf_bits(&s, comp, tr_depth, absSum != 0);
+  f += hop_o_cabac_coeff_bits(&s, levels, log2_size, comp, 0, sign_hide, use_ts, 0);
+  const uint32_t singleBits = (uint32_t)((frac_left + f) >> 15);
+  memset(zero, 0, sizeof(zero));
+  const uint32_t zeroDist = weighted(hop_o_sse(zero, N, resi, N, N, N, bit_depth), comp, dist_weight);
+  uint32_t dist = zeroDist, nzDist = 0, nullBits = 0;
+  double chosen = 0;
+  if (absSum) {
+    hop_o_dequant_flat(bit_depth, qp_scaled, levels, dq, N);
+    for (int i = 0; i < n2; i++) c16[i] = (int16_t)dq[i];
+    hop_o_inv_transform(bit_depth, c16, r2, N, 0);
+    nzDist = weighted(hop_o_sse(r2, N, resi, N, N, N, bit_depth), comp, dist_weight);
+    const double singleCost = calc_rd_cost(singleBits, nzDist, lambda_rd);
+    hop_o_cabac_ctx z = *snap;
+    nullBits = (uint32_t)((frac_left + hop_o_cabac_cbf_bits(&z, comp, tr_depth, 0)) >> 15);
+    const double nullCost = calc_rd_cost(nullBits, zeroDist, lambda_rd);
+    if (nullCost < singleCost) { absSum = 0; memset(levels, 0, sizeof(int32_t) * (size_t)n2); chosen = nullCost; }
+    else { dist = nzDist; chosen = singleCost; }
+  } else {
+    chosen = calc_rd_cost(singleBits, zeroDist, lambda_rd);      /* not computed by the reference at this point; reported for convenience */
+  }
+  out[0] = absSum; out[1] = absSum != 0; out[2] = dist; out[3] = zeroDist; out[4] = nzDist; out[5] = singleBits; out[6] = nullBits; out[7] = 0;
+  *cost = chosen;
+  return 0;
 }

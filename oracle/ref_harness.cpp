@@ -451,6 +451,81 @@ uint64_t ref_cabac_coeff_bits(uint8_t* states, const int32_t* coef, int N, int t
 }
 
 // ---------------------------------------------------------------------------------------------
+// row a8b, leaf step of TEncSearch::xEstimateResidualQT (TEncSearch.cpp:6896-7200) for ONE component TU, assembled from
+// the reference's own members: TEncSbac::estBit, TComTrQuant::transformNxN (xT + xRateDistOptQuant), TEncSbac::codeQtCbf /
+// codeCoeffNxN through the counting coder, TComTrQuant::invtransformNxN, TComRdCost::getDistPart, calcRdCost.  The
+// sequencing between them (load snapshot / resetBits / cbf-zero decision) is RESTATED from :6959-7032.
+// out[8] and cost as hop_o_tu_rd.
+// ---------------------------------------------------------------------------------------------
+int ref_tu_rd(const int16_t* resi, int N, int ttype, int qpScaled, int bitDepth, int trDepth, int signHide, int useTS,
+              double lambdaRdoq, double lambdaRd, double distWeight, const uint8_t* states, unsigned fracLeft,
+              int32_t* levels, uint32_t* out, double* cost)
+{
+  static Char predMode[1]; static UChar trIdxA[1], lumaDirA[1], chromaDirA[1], depthA[1], tsA[3][1], cbfA[3][1]; static Bool bypassA[1];
+  SbacCtx* c = sbac_get();
+  ContextModel::buildNextStateTable();
+  g_bitDepthY = bitDepth; g_bitDepthC = bitDepth;
+  c->pps.setSignHideFlag(signHide); c->pps.setUseTransformSkip(useTS != 0);
+  TComTrQuant& t = g->trq;
+  t.init(32, true, true, true, false, false);
+  t.setUseScalingList(false); t.setFlatScalingList();
+  t.m_cQP.setQpParam(qpScaled);
+  t.m_dLambda = lambdaRdoq;
+  g->rd.setLambda(lambdaRd);
+  if (ttype == 2) g->rd.setCbDistortionWeight(distWeight);
+  if (ttype == 3) g->rd.setCrDistortionWeight(distWeight);
+  TComDataCU& cu = g->cu;
+  Char* sPred = cu.m_pePredMode; UChar* sTr = cu.m_puhTrIdx; UChar* sL = cu.m_puhLumaIntraDir; UChar* sC = cu.m_puhChromaIntraDir;
+  UChar* sD = cu.m_puhDepth; TComSlice* sS = cu.m_pcSlice; Bool* sB = cu.m_CUTransquantBypass;
+  UChar* sT[3] = { cu.m_puhTransformSkip[0], cu.m_puhTransformSkip[1], cu.m_puhTransformSkip[2] };
+  UChar* sCbf[3] = { cu.m_puhCbf[0], cu.m_puhCbf[1], cu.m_puhCbf[2] };
+  predMode[0] = MODE_INTER; trIdxA[0] = (UChar)trDepth; lumaDirA[0] = 0; chromaDirA[0] = 0; depthA[0] = 0; bypassA[0] = false;
+  for (int k = 0; k < 3; k++) { tsA[k][0] = 0; cu.m_puhTransformSkip[k] = tsA[k]; cbfA[k][0] = 0; cu.m_puhCbf[k] = cbfA[k]; }
+  cu.m_pePredMode = predMode; cu.m_puhTrIdx = trIdxA; cu.m_puhLumaIntraDir = lumaDirA; cu.m_puhChromaIntraDir = chromaDirA; cu.m_puhDepth = depthA;
+  cu.m_pcSlice = &c->slice; cu.m_CUTransquantBypass = bypassA;
+  TextType tt = (TextType)ttype;
+  // estBit from the snapshot (:6901-6904 / :6922-6925)
+  sbac_load(c->sbac, states);
+  c->sbac.estBit(t.m_pcEstBitsSbac, N, N, ttype ? TEXT_CHROMA : TEXT_LUMA);
+  // transformNxN (:6912)
+  std::vector<Pel> r(resi, resi + N * N); std::vector<TCoeff> coef(N * N, 0); std::vector<Int> arl(N * N, 0); Int* parl = &arl[0];
+  UInt absSum = 0;
+  t.transformNxN(&cu, &r[0], N, &coef[0], parl, N, N, absSum, tt, 0, false);
+  const int ci = ttype == 0 ? 0 : ttype == 2 ? 1 : 2;
+  cbfA[ci][0] = (UChar)((absSum ? 1 : 0) << trDepth);           // setCbfSubParts( uiAbsSum ? uiSetCbf : 0, ... ), uiSetCbf = 1 << uiTrMode (:6877,6917)
+  // bits of cbf + levels from the snapshot (:6957-6962); the coder keeps the fraction below one bit across resetBits
+  sbac_load(c->sbac, states);
+  c->sbac.resetBits(); c->bin.m_fracBits = fracLeft;
+  c->sbac.codeQtCbf(&cu, 0, tt, trDepth);
+  c->sbac.codeCoeffNxN(&cu, &coef[0], 0, N, N, 0, tt);
+  const UInt singleBits = c->bin.getNumWrittenBits();
+  std::vector<Pel> zero(N * N, 0), rec(N * N, 0);
+  UInt dist = g->rd.getDistPart(bitDepth, &zero[0], N, &r[0], N, N, N, tt);      // zero-residual distortion (:6984)
+  const UInt zeroDist = dist;
+  UInt nzDist = 0, nullBits = 0; double chosen = 0;
+  if (absSum) {
+    t.invtransformNxN(false, ttype ? TEXT_CHROMA : TEXT_LUMA, REG_DCT, &rec[0], N, &coef[0], N, N, 3 + g_eTTable[ttype]);
+    nzDist = g->rd.getDistPart(bitDepth, &rec[0], N, &r[0], N, N, N, tt);
+    const Double singleCost = g->rd.calcRdCost(singleBits, nzDist);
+    sbac_load(c->sbac, states);
+    c->sbac.resetBits(); c->bin.m_fracBits = fracLeft;
+    c->sbac.codeQtCbfZero(&cu, tt, trDepth);
+    nullBits = c->bin.getNumWrittenBits();
+    const Double nullCost = g->rd.calcRdCost(nullBits, dist);
+    if (nullCost < singleCost) { absSum = 0; std::fill(coef.begin(), coef.end(), 0); chosen = nullCost; }
+    else { dist = nzDist; chosen = singleCost; }
+  } else {
+    chosen = g->rd.calcRdCost(singleBits, dist);
+  }
+  for (int i = 0; i < N * N; i++) levels[i] = coef[i];
+  out[0] = absSum; out[1] = absSum != 0; out[2] = dist; out[3] = zeroDist; out[4] = nzDist; out[5] = singleBits; out[6] = nullBits; out[7] = 0;
+  *cost = chosen;
+  cu.m_pePredMode = sPred; cu.m_puhTrIdx = sTr; cu.m_puhLumaIntraDir = sL; cu.m_puhChromaIntraDir = sC; cu.m_puhDepth = sD; cu.m_pcSlice = sS;
+  cu.m_CUTransquantBypass = sB; for (int k = 0; k < 3; k++) { cu.m_puhTransformSkip[k] = sT[k]; cu.m_puhCbf[k] = sCbf[k]; }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // intra rough search pieces (row a7): the reference's own fillReferenceSamples, getPredictorPtr, predIntraLumaAng,
 // calcHAD.  The smoothing of TComPattern::initAdiPattern (:237-312) is inline code that needs a TComDataCU/TComPic
 // graph; it is RESTATED here (marked) so that the filtered buffer exists for getPredictorPtr.

@@ -177,3 +177,39 @@ def test_coeff_bits_golden(hp):
     with pytest.raises(hp.HopError):
         ctx.coeff_bits(bad, state, coef)
     ctx.close()
+
+
+def test_tu_rd_golden(hp):
+    """row a8b leaf step through hop_tu_rd (forward transform, estBit, RDOQ, counted bits, inverse path, cbf-zero decision as a
+    pipeline of kernels) against the vectors assembled from the reference's own members: 192 TUs laid out in one picture,
+    each with its own context snapshot"""
+    from test_oracle_golden4 import tu_rd_cases
+    cases = list(tu_rd_cases())
+    W = H = 256
+    org = [np.full((H, W), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16)]
+    jobs = np.zeros(len(cases), hp.TU_RD_JOB_DTYPE)
+    for i, c in enumerate(cases):
+        N = 1 << c["log2"]; k = c["slot"]
+        if c["comp"] == 0: px, py = 32 * (k % 8), 32 * (k // 8)
+        else: px, py = 16 * (k % 8), 16 * (k // 8)
+        org[c["comp"]][py:py + N, px:px + N] = 128 + c["resi"].reshape(N, N)
+        j = jobs[i]
+        j["x"], j["y"] = (px, py) if c["comp"] == 0 else (2 * px, 2 * py)
+        j["comp"], j["log2_size"], j["qp_scaled"], j["tr_depth"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["bit_depth"] = c["comp"], c["log2"], c["qp"], c["trd"], i, c["sh"], c["uts"], 8
+        j["lambda_rdoq"], j["lambda_rd"], j["dist_weight"] = c["lamq"], c["lam"], c["w"]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(*org)
+    for comp in range(3):
+        ctx.plane_upload("pred", comp, np.full(org[comp].shape, 128, np.int16))
+    res, lv = ctx.tu_rd(jobs, np.stack([c["st"] for c in cases]))
+    off = 0
+    for i, c in enumerate(cases):
+        n = len(c["resi"])
+        got = [int(res[i][k]) for k in ("abs_sum", "cbf", "dist", "zero_dist", "nonzero_dist", "bits", "null_bits")]
+        assert got == [int(v) for v in c["out"][:7]], (i, c["log2"], c["comp"], got, c["out"])
+        assert float(res[i]["cost"]) == c["cost"] and np.array_equal(lv[off:off + n], c["levels"]), (i, c["log2"], c["comp"])
+        off += n
+    bad = jobs[:1].copy(); bad["bit_depth"] = 10
+    with pytest.raises(hp.HopError):
+        ctx.tu_rd(bad, np.stack([c["st"] for c in cases]))
+    ctx.close()

@@ -50,3 +50,29 @@ def test_cabac_tables_consistent():
         mps = s & 1
         assert O.hop_o_ctx_bits(O.hop_o_ctx_next(s, mps), mps) <= O.hop_o_ctx_bits(s, mps)
     assert abs(O.hop_o_ctx_bits(0, 0) - 32768) < 2048 and abs(O.hop_o_ctx_bits(0, 1) - 32768) < 2048
+
+
+def tu_rd_cases():
+    g = load("tu_rd.npz")
+    for i in range(len(g["par"])):
+        log2, comp, qp, trd, sh, uts, slot, off = (int(v) for v in g["par"][i])
+        n = 1 << (2 * log2)
+        yield dict(log2=log2, comp=comp, qp=qp, trd=trd, sh=sh, uts=uts, slot=slot, lamq=float(g["lam"][i][0]), lam=float(g["lam"][i][1]), w=float(g["lam"][i][2]),
+                   st=np.ascontiguousarray(g["st"][i]), resi=np.ascontiguousarray(g["resi"][off:off + n], np.int16), out=g["out"][i], cost=float(g["cost"][i]),
+                   levels=np.ascontiguousarray(g["levels"][off:off + n], np.int32))
+
+
+def test_tu_rd_oracle_vs_golden():
+    """row a8b leaf step: the composite restatement against the vectors assembled from the reference's own members"""
+    O = oracle()
+    VP = ctypes.c_void_p
+    O.hop_o_tu_rd.argtypes = [VP] + [ctypes.c_int] * 7 + [ctypes.c_double] * 3 + [VP, ctypes.c_uint32, VP, VP, VP]
+    n = coded = 0
+    for c in tu_rd_cases():
+        lv = np.zeros(len(c["resi"]), np.int32); o = np.zeros(8, np.uint32); cost = ctypes.c_double()
+        fl = int(c["st"][150]) | (int(c["st"][151]) << 8)
+        assert O.hop_o_tu_rd(c["resi"].ctypes.data, c["log2"], c["comp"], c["qp"], 8, c["trd"], c["sh"], c["uts"], c["lamq"], c["lam"], c["w"],
+                             c["st"].ctypes.data, fl, lv.ctypes.data, o.ctypes.data, ctypes.byref(cost)) == 0
+        assert np.array_equal(o, c["out"]) and cost.value == c["cost"] and np.array_equal(lv, c["levels"]), (n, c["log2"], c["comp"])
+        n += 1; coded += int(o[0] != 0)
+    assert n == 192 and coded > 60

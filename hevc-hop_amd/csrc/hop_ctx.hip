@@ -590,7 +590,8 @@ int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop
     const int N = 1 << j.log2_size, sh = j.comp ? 1 : 0;
     if (j.comp < 0 || j.comp > 2 || j.log2_size < 2 || j.log2_size > 5 || (j.comp && j.log2_size == 5) || j.x < 0 || j.y < 0 || ((j.x >> sh) & 3) || ((j.y >> sh) & 3) ||
         (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || j.tr_depth < 0 || j.tr_depth > 3 ||
-        j.ctx_index < 0 || j.ctx_index >= n_ctx || j.bit_depth != (j.comp ? c->bd_c : c->bd_y) || !(j.lambda_rdoq > 0.0) || !(j.lambda_rd > 0.0))
+        j.ctx_index < 0 || j.ctx_index >= n_ctx || j.bit_depth != (j.comp ? c->bd_c : c->bd_y) || !(j.lambda_rdoq > 0.0) || !(j.lambda_rd > 0.0) ||
+        j.scan_idx < 0 || j.scan_idx > 2 || (!j.is_intra && (j.scan_idx || j.use_dst)))
       return hop_set_err(c, HOP_ERR_ARG, "TU RD job %d: illegal transform unit / snapshot / parameters", i);
     offs[i] = (int64_t)tot; tot += (size_t)N * N;
   }
@@ -608,6 +609,38 @@ int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop
   HIPCHK(c, hipMemcpyAsync(levels_out, b + o_l, tot * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
+}
+
+int hop_intra_pred(hop_ctx* c, int n, const hop_intra_job* jobs, const int32_t* modes) {
+  if (!c || n < 0 || (n && (!jobs || !modes))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_pred: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_intra_job& j = jobs[i];
+    const int N = j.size;
+    if (!(N == 4 || N == 8 || N == 16 || N == 32 || N == 64) || j.x < 0 || j.y < 0 || (j.x & 3) || (j.y & 3) || j.x + N > c->pic_w || j.y + N > c->pic_h || modes[i] < 0 || modes[i] > 34)
+      return hop_set_err(c, HOP_ERR_ARG, "intra pred job %d: illegal block or mode", i);
+    const int U = N / 4;
+    for (int u = 0; u < 4 * U + 1; u++) if (j.flags[u]) {
+      bool ok;
+      if (u < 2 * U) ok = j.x > 0 && j.y + 4 * (2 * U - 1 - u) + 4 <= c->pic_h;
+      else if (u == 2 * U) ok = j.x > 0 && j.y > 0;
+      else ok = j.y > 0 && j.x + 4 * (u - 2 * U - 1) + 4 <= c->pic_w;
+      if (!ok) return hop_set_err(c, HOP_ERR_ARG, "intra pred job %d: neighbour unit %d flagged available but outside the picture", i, u);
+    }
+  }
+  const size_t bj = (size_t)n * sizeof(hop_intra_job), o_m = (bj + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_m + (size_t)n * 4 + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_m, modes, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_intra_pred(c, n, (const hop_intra_job*)b, (const int32_t*)(b + o_m)); if (r) return r;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+int hop_intra_pred_device(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_modes))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_pred_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_intra_pred(c, n, d_jobs, d_modes);
 }
 
 int hop_distortion_device(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out) {

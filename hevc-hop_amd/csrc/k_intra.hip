@@ -74,14 +74,11 @@ __device__ static inline int intra_sample(const IntraShared& sh, int N, int log2
 #undef LEFT
 }
 
-__global__ __launch_bounds__(256) void k_intra_rough(const hop_intra_job* __restrict__ jobs, hop_pics pic, const int16_t* __restrict__ rec_y,
-                                                     uint32_t* __restrict__ satd_out) {
-  __shared__ IntraShared sh;
-  const hop_intra_job* jp = jobs + blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// reference line of one block: fillReferenceSamples + smoothing + DC value into sh (all 256 threads; ends with a barrier)
+__device__ static inline void intra_setup(IntraShared& sh, const hop_intra_job* jp, const hop_pics& pic, const int16_t* __restrict__ rec_y, int tid) {
   const int N = jp->size, x0 = jp->x, y0 = jp->y, U = N >> 2, units = 4 * U + 1;
   const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
-  const int bd = pic.bd_y, maxVal = (1 << bd) - 1, dcDefault = 1 << (bd - 1);
+  const int bd = pic.bd_y, dcDefault = 1 << (bd - 1);
   const int16_t* rec = rec_y + (size_t)y0 * pic.pic_w + x0;
   const int pitch = pic.pic_w;
   if (tid < 35) sh.satd[tid] = 0;
@@ -150,6 +147,17 @@ __global__ __launch_bounds__(256) void k_intra_rough(const hop_intra_job* __rest
     }
   }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_intra_rough(const hop_intra_job* __restrict__ jobs, hop_pics pic, const int16_t* __restrict__ rec_y,
+                                                     uint32_t* __restrict__ satd_out) {
+  __shared__ IntraShared sh;
+  const hop_intra_job* jp = jobs + blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int N = jp->size;
+  const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
+  const int bd = pic.bd_y, maxVal = (1 << bd) - 1;
+  intra_setup(sh, jp, pic, rec_y, tid);
   // ---- 35 predictions + calcHAD ----
   if (N >= 8) {
     const int bw = N >> 3, nblk = bw * bw;
@@ -172,6 +180,31 @@ __global__ __launch_bounds__(256) void k_intra_rough(const hop_intra_job* __rest
   }
   __syncthreads();
   if (tid < 35) satd_out[(size_t)blockIdx.x * 35 + tid] = sh.satd[tid] >> (bd - 8);
+}
+
+
+// the prediction of ONE mode per block, written into the context's prediction picture (the first step of
+// TEncSearch::xIntraCodingLumaBlk, TLibEncoder/TEncSearch.cpp:1046-1049: initAdiPattern + predIntraLumaAng)
+__global__ __launch_bounds__(256) void k_intra_pred(const hop_intra_job* __restrict__ jobs, const int32_t* __restrict__ modes, hop_pics pic,
+                                                    const int16_t* __restrict__ rec_y) {
+  __shared__ IntraShared sh;
+  const hop_intra_job* jp = jobs + blockIdx.x;
+  const int tid = threadIdx.x;
+  const int N = jp->size, x0 = jp->x, y0 = jp->y;
+  const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
+  const int maxVal = (1 << pic.bd_y) - 1, mode = modes[blockIdx.x];
+  intra_setup(sh, jp, pic, rec_y, tid);
+  int16_t* dst = pic.pred_y + (size_t)y0 * pic.pic_w + x0;
+  for (int i = tid; i < N * N; i += 256) { const int r = i >> log2N, c = i & (N - 1); dst[(size_t)r * pic.pic_w + c] = (int16_t)intra_sample(sh, N, log2N, mode, c, r, maxVal); }
+}
+
+int hop_launch_intra_pred(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes) {
+  const int pr = hop_prof_begin(c, HOP_K_INTRA, (uint64_t)n);
+  hipLaunchKernelGGL(k_intra_pred, dim3(n), dim3(256), 0, c->stream, d_jobs, d_modes, hop_make_pics(c), c->rec[0]);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_pred launch: %s", hipGetErrorString(e));
+  return HOP_OK;
 }
 
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd) {

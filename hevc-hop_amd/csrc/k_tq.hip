@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __res
   const int16_t* org = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
   const int16_t* prd = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
   if (tid == 0) sh.acc = 0;
-  for (int i = tid; i < NN; i += 256) { int k = i >> log2N, n = i & (N - 1); sh.T[i] = (int16_t)dct_coef(32 >> log2N, k, n); }
+  const bool dst = jb.use_dst && N == 4 && !chroma;
+  for (int i = tid; i < NN; i += 256) { int k = i >> log2N, n = i & (N - 1); sh.T[i] = (int16_t)(dst ? c_dst4[k][n] : dct_coef(32 >> log2N, k, n)); }
   __syncthreads();
   unsigned part = 0;
   const unsigned sshift = (unsigned)((bd - 8) << 1);
@@ -188,10 +189,20 @@ __global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __res
 }
 
 __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __restrict__ jobs, hop_pics pic, const int64_t* __restrict__ coef_off,
-                                                      const int32_t* __restrict__ levels, const uint32_t* __restrict__ abs_sum, uint32_t* __restrict__ nz_sse) {
+                                                      const int32_t* __restrict__ levels, const uint32_t* __restrict__ abs_sum, uint32_t* __restrict__ nz_sse,
+                                                      int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
   __shared__ TurdFwdShared sh;                                     // a: dequantised / residual, b: intermediate
-  if (abs_sum[blockIdx.x] == 0) { if (threadIdx.x == 0) nz_sse[blockIdx.x] = 0; return; }
   const hop_tu_rd_job jb = jobs[blockIdx.x];
+  if (abs_sum[blockIdx.x] == 0) {
+    if (threadIdx.x == 0) nz_sse[blockIdx.x] = 0;
+    if (jb.is_intra) {                                             // reconstruction = prediction (TEncSearch.cpp:1118-1127,1133-1152)
+      const bool ch = jb.comp != 0; const int pt = ch ? pic.pic_w >> 1 : pic.pic_w, xx = ch ? jb.x >> 1 : jb.x, yy = ch ? jb.y >> 1 : jb.y, NNz = 1 << jb.log2_size;
+      const int16_t* pp = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)yy * pt + xx;
+      int16_t* rr = (jb.comp == 0 ? rec_y : jb.comp == 1 ? rec_cb : rec_cr) + (size_t)yy * pt + xx;
+      for (int i = threadIdx.x; i < NNz * NNz; i += 256) { const int r = i >> jb.log2_size, c2 = i & (NNz - 1); rr[(size_t)r * pt + c2] = pp[(size_t)r * pt + c2]; }
+    }
+    return;
+  }
   const int tid = threadIdx.x, log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
   const bool chroma = jb.comp != 0;
   const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
@@ -199,7 +210,8 @@ __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __res
   const int16_t* org = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
   const int16_t* prd = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
   if (tid == 0) sh.acc = 0;
-  for (int i = tid; i < NN; i += 256) { int k = i >> log2N, n = i & (N - 1); sh.T[i] = (int16_t)dct_coef(32 >> log2N, k, n); }
+  const bool dst = jb.use_dst && N == 4 && !chroma;
+  for (int i = tid; i < NN; i += 256) { int k = i >> log2N, n = i & (N - 1); sh.T[i] = (int16_t)(dst ? c_dst4[k][n] : dct_coef(32 >> log2N, k, n)); }
   {
     const int per = jb.qp_scaled / 6, rem = jb.qp_scaled % 6, transformShift = 15 - bd - log2N;
     const int dshift = 20 - 14 - transformShift, dadd = 1 << (dshift - 1), scale = c_inv_quant_scales[rem] << per;     // xDeQuant :1171-1182
@@ -220,7 +232,12 @@ __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __res
     int j = i >> log2N, n = i & (N - 1), sum = 0;
     for (int k = 0; k < N; k++) sum += sh.T[k * N + n] * sh.b[k * N + j];
     const int rr = clip16((sum + (1 << (s2 - 1))) >> s2);          // reconstructed residual sample (j, n)
-    const int e = rr - ((int)org[(size_t)j * pitch + n] - (int)prd[(size_t)j * pitch + n]);
+    int e;
+    if (jb.is_intra) {                                             // ClipY / ClipC(prediction + residual), distortion against the original (:1133-1158)
+      const int v = min((1 << bd) - 1, max(0, (int)prd[(size_t)j * pitch + n] + rr));
+      ((jb.comp == 0 ? rec_y : jb.comp == 1 ? rec_cb : rec_cr) + (size_t)y0 * pitch + x0)[(size_t)j * pitch + n] = (int16_t)v;
+      e = v - (int)org[(size_t)j * pitch + n];
+    } else e = rr - ((int)org[(size_t)j * pitch + n] - (int)prd[(size_t)j * pitch + n]);
     part += (unsigned)(e * e) >> sshift;
   }
   part = (unsigned)hopd_wave_sum((int)part);
@@ -262,11 +279,11 @@ __global__ void k_turd_setup(const hop_tu_rd_job* __restrict__ jobs, int n, cons
   for (int k = 0; k < no; k++) { eb->greaterOneBits[k][0] = entropy_bits[s[oo + k] ^ 0]; eb->greaterOneBits[k][1] = entropy_bits[s[oo + k] ^ 1]; }
   for (int k = 0; k < na; k++) { eb->levelAbsBits[k][0] = entropy_bits[s[oa + k] ^ 0]; eb->levelAbsBits[k][1] = entropy_bits[s[oa + k] ^ 1]; }
   hop_rdoq_job r;
-  r.log2_size = jb.log2_size; r.comp = jb.comp; r.is_intra = 0; r.scan_idx = 0; r.tr_depth = jb.tr_depth; r.qp_scaled = jb.qp_scaled;
+  r.log2_size = jb.log2_size; r.comp = jb.comp; r.is_intra = jb.is_intra; r.scan_idx = jb.scan_idx; r.tr_depth = jb.tr_depth; r.qp_scaled = jb.qp_scaled;
   r.bit_depth = jb.bit_depth; r.sign_hide = jb.sign_hide; r.lambda = jb.lambda_rdoq; r.coeff_offset = coef_off[i]; r.estbits_index = i; r.reserved = 0;
   rq[i] = r;
   hop_coeff_bits_job b;
-  b.log2_size = jb.log2_size; b.comp = jb.comp; b.scan_idx = 0; b.sign_hide = jb.sign_hide; b.use_ts = jb.use_ts; b.ts_flag = 0; b.ctx_index = jb.ctx_index;
+  b.log2_size = jb.log2_size; b.comp = jb.comp; b.scan_idx = jb.scan_idx; b.sign_hide = jb.sign_hide; b.use_ts = jb.use_ts; b.ts_flag = 0; b.ctx_index = jb.ctx_index;
   b.cbf_ctx_plus1 = 1 + 4 * chroma + (chroma ? jb.tr_depth : (jb.tr_depth == 0 ? 1 : 0));           // getCtxQtCbf, TComDataCU.cpp:1848-1859
   b.coeff_offset = coef_off[i];
   cb[i] = b;
@@ -288,7 +305,11 @@ __global__ void k_turd_decide(const hop_tu_rd_job* __restrict__ jobs, int n, con
   const uint32_t singleBits = (uint32_t)((left + frac[i]) >> 15);
   hop_tu_rd_result r;
   r.abs_sum = abs_sum[i]; r.zero_dist = zeroDist; r.nonzero_dist = 0; r.bits = singleBits; r.null_bits = 0; r.dist = zeroDist; r.pad = 0;
-  if (r.abs_sum) {
+  if (jb.is_intra) {                                               // xIntraCodingLumaBlk has no cbf-zero test: the block is what RDOQ made of it
+    r.dist = r.abs_sum ? nzDist : zeroDist;
+    r.nonzero_dist = r.abs_sum ? nzDist : 0;
+    r.cost = (double)(uint32_t)floor((double)r.dist + (double)((int)(singleBits * jb.lambda_rd + .5)));
+  } else if (r.abs_sum) {
     r.nonzero_dist = nzDist;
     const double singleCost = (double)(uint32_t)floor((double)nzDist + (double)((int)(singleBits * jb.lambda_rd + .5)));
     const int cbfCtx = 4 * chroma + (chroma ? jb.tr_depth : (jb.tr_depth == 0 ? 1 : 0));
@@ -325,7 +346,7 @@ int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   r = hop_launch_rdoq(c, n, rq, tab, coef, d_levels, as); if (r) return r;
   r = hop_launch_coeff_bits(c, n, cb, d_ctx, d_levels, fr, nullptr); if (r) return r;
   const int pr2 = hop_prof_begin(c, HOP_K_TQ, 0);
-  hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, as, ns);
+  hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, as, ns, c->rec[0], c->rec[1], c->rec[2]);
   hipLaunchKernelGGL(k_turd_decide, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_jobs, n, d_ctx, d_coef_off, hop_entropy_bits_device(c), as, fr, zs, ns, d_levels, d_res);
   hop_prof_end(c, pr2);
   hipError_t e = hipGetLastError();

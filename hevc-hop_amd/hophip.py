@@ -61,7 +61,8 @@ COEFF_BITS_JOB_DTYPE = np.dtype([("log2_size", "<i4"), ("comp", "<i4"), ("scan_i
                                  ("ctx_index", "<i4"), ("cbf_ctx_plus1", "<i4"), ("coeff_offset", "<i8")])
 CABAC_CTX_BYTES = 152
 TU_RD_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("qp_scaled", "<i4"), ("tr_depth", "<i4"), ("ctx_index", "<i4"),
-                            ("sign_hide", "<i4"), ("use_ts", "<i4"), ("bit_depth", "<i4"), ("lambda_rdoq", "<f8"), ("lambda_rd", "<f8"), ("dist_weight", "<f8")])
+                            ("sign_hide", "<i4"), ("use_ts", "<i4"), ("bit_depth", "<i4"), ("is_intra", "<i4"), ("scan_idx", "<i4"), ("use_dst", "<i4"), ("reserved", "<i4"),
+                            ("lambda_rdoq", "<f8"), ("lambda_rd", "<f8"), ("dist_weight", "<f8")])
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -117,6 +118,9 @@ def load():
     L.hop_tu_rd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3
     L.hop_tu_rd_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 2
     L.hop_tu_rd.restype = L.hop_tu_rd_device.restype = ctypes.c_int
+    L.hop_intra_pred.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_intra_pred_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_intra_pred.restype = L.hop_intra_pred_device.restype = ctypes.c_int
     L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.hop_cabac_est_bits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     L.hop_coeff_bits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 3
@@ -276,6 +280,11 @@ class Context:
         res = np.zeros(len(jobs), TU_RD_RESULT_DTYPE); lv = np.zeros(int(np.sum(1 << (2 * jobs["log2_size"].astype(np.int64)))), np.int32)
         self._chk(self.L.hop_tu_rd(self.h, len(jobs), jobs.ctypes.data, len(ctx_in), ctx_in.ctypes.data, res.ctypes.data, lv.ctypes.data), "hop_tu_rd")
         return res, lv
+
+    def intra_pred(self, jobs, modes):
+        n = len(jobs)
+        arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)
+        self._chk(self.L.hop_intra_pred(self.h, n, ctypes.addressof(arr), m.ctypes.data), "hop_intra_pred")
 
     def sync(self):
         self._chk(self.L.hop_sync(self.h), "hop_sync")

@@ -201,6 +201,10 @@ typedef struct {
 } hop_intra_job;
 int hop_intra_rough(hop_ctx* ctx, int n, const hop_intra_job* jobs, uint32_t* satd_out);
 int hop_intra_rough_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);   /* asynchronous, unchecked */
+/* replaces: initAdiPattern + predIntraLumaAng of TEncSearch::xIntraCodingLumaBlk (TLibEncoder/TEncSearch.cpp:1043-1049): the prediction
+ * of mode modes[i] (0 planar, 1 DC, 2..34 angular) of block i, written into the context's prediction picture (luma). */
+int hop_intra_pred(hop_ctx* ctx, int n, const hop_intra_job* jobs, const int32_t* modes);
+int hop_intra_pred_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, const int32_t* d_modes);     /* asynchronous, unchecked */
 
 /* ---- rate-distortion optimised quantisation (row a11) ---- */
 /* Image of the reference's estBitsSbacStruct (TLibCommon/TComTrQuant.h:59-70): the bit estimates (15 fractional bits)
@@ -285,6 +289,13 @@ typedef struct {
   int32_t ctx_index;       /* context snapshot (CI_QT_TRAFO_ROOT) */
   int32_t sign_hide, use_ts;
   int32_t bit_depth;       /* of the component (must equal the context's) */
+  int32_t is_intra;        /* 0: the leaf of xEstimateResidualQT described above.  1: the leaf of xIntraCodingLumaBlk / ChromaBlk after the
+                              prediction (TEncSearch.cpp:1082-1160): intra RDOQ tables, no cbf-zero decision, reconstruction = clip(prediction +
+                              residual) written to the reconstruction picture, dist = distortion of it against the original; bits = cbf flag +
+                              levels from the snapshot (what xGetIntraBitsQT counts for the block) */
+  int32_t scan_idx;        /* getCoefScanIdx; 0 unless is_intra */
+  int32_t use_dst;         /* 4x4 intra luma: DST-VII */
+  int32_t reserved;
   double  lambda_rdoq;     /* TComTrQuant::m_dLambda after selectLambda */
   double  lambda_rd;       /* TComRdCost::m_dLambda */
   double  dist_weight;     /* chroma distortion weight of getDistPart (TLibCommon/TComRdCost.cpp:493-497); ignored for luma */

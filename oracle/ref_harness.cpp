@@ -526,6 +526,65 @@ int ref_tu_rd(const int16_t* resi, int N, int ttype, int qpScaled, int bitDepth,
 }
 
 // ---------------------------------------------------------------------------------------------
+// row a8, leaf step of TEncSearch::xIntraCodingLumaBlk / ChromaBlk after the prediction (TEncSearch.cpp:1082-1160): the
+// reference's own estBit, transformNxN (intra: DST for 4x4 luma, scan by direction), invtransformNxN, ClipY/ClipC, getDistPart,
+// and the bits of cbf flag + levels from the snapshot.  lumaDir / chromaDir select transform and scan as in the reference.
+// ---------------------------------------------------------------------------------------------
+int ref_tu_intra(const int16_t* org, const int16_t* pred, int N, int ttype, int lumaDir, int chromaDir, int qpScaled, int bitDepth, int trDepth,
+                 int signHide, int useTS, double lambdaRdoq, double lambdaRd, double distWeight, const uint8_t* states, unsigned fracLeft,
+                 int32_t* levels, int16_t* recon, uint32_t* out, double* cost)
+{
+  static Char predMode[1]; static UChar trIdxA[1], lumaDirA[1], chromaDirA[1], depthA[1], tsA[3][1], cbfA[3][1]; static Bool bypassA[1];
+  SbacCtx* c = sbac_get();
+  ContextModel::buildNextStateTable();
+  g_bitDepthY = bitDepth; g_bitDepthC = bitDepth;
+  c->pps.setSignHideFlag(signHide); c->pps.setUseTransformSkip(useTS != 0);
+  TComTrQuant& t = g->trq;
+  t.init(32, true, true, true, false, false);
+  t.setUseScalingList(false); t.setFlatScalingList();
+  t.m_cQP.setQpParam(qpScaled);
+  t.m_dLambda = lambdaRdoq;
+  g->rd.setLambda(lambdaRd);
+  if (ttype == 2) g->rd.setCbDistortionWeight(distWeight);
+  if (ttype == 3) g->rd.setCrDistortionWeight(distWeight);
+  TComDataCU& cu = g->cu;
+  Char* sPred = cu.m_pePredMode; UChar* sTr = cu.m_puhTrIdx; UChar* sL = cu.m_puhLumaIntraDir; UChar* sC = cu.m_puhChromaIntraDir;
+  UChar* sD = cu.m_puhDepth; TComSlice* sS = cu.m_pcSlice; Bool* sB = cu.m_CUTransquantBypass;
+  UChar* sT[3] = { cu.m_puhTransformSkip[0], cu.m_puhTransformSkip[1], cu.m_puhTransformSkip[2] };
+  UChar* sCbf[3] = { cu.m_puhCbf[0], cu.m_puhCbf[1], cu.m_puhCbf[2] };
+  predMode[0] = MODE_INTRA; trIdxA[0] = (UChar)trDepth; lumaDirA[0] = (UChar)lumaDir; chromaDirA[0] = (UChar)chromaDir; depthA[0] = 0; bypassA[0] = false;
+  for (int k = 0; k < 3; k++) { tsA[k][0] = 0; cu.m_puhTransformSkip[k] = tsA[k]; cbfA[k][0] = 0; cu.m_puhCbf[k] = cbfA[k]; }
+  cu.m_pePredMode = predMode; cu.m_puhTrIdx = trIdxA; cu.m_puhLumaIntraDir = lumaDirA; cu.m_puhChromaIntraDir = chromaDirA; cu.m_puhDepth = depthA;
+  cu.m_pcSlice = &c->slice; cu.m_CUTransquantBypass = bypassA;
+  TextType tt = (TextType)ttype;
+  std::vector<Pel> r(N * N);
+  for (int i = 0; i < N * N; i++) r[i] = (Pel)(org[i] - pred[i]);
+  sbac_load(c->sbac, states);
+  c->sbac.estBit(t.m_pcEstBitsSbac, N, N, ttype ? TEXT_CHROMA : TEXT_LUMA);
+  std::vector<TCoeff> coef(N * N, 0); std::vector<Int> arl(N * N, 0); Int* parl = &arl[0];
+  UInt absSum = 0;
+  t.transformNxN(&cu, &r[0], N, &coef[0], parl, N, N, absSum, tt, 0, false);
+  const int ci = ttype == 0 ? 0 : ttype == 2 ? 1 : 2;
+  cbfA[ci][0] = (UChar)((absSum ? 1 : 0) << trDepth);
+  if (absSum) t.invtransformNxN(false, ttype ? TEXT_CHROMA : TEXT_LUMA, ttype ? REG_DCT : (UInt)lumaDir, &r[0], N, &coef[0], N, N, 0 + g_eTTable[ttype]);
+  else std::fill(r.begin(), r.end(), 0);
+  std::vector<Pel> rec(N * N), o(org, org + N * N);
+  for (int i = 0; i < N * N; i++) rec[i] = ttype ? ClipC(pred[i] + r[i]) : ClipY(pred[i] + r[i]);
+  const UInt dist = g->rd.getDistPart(bitDepth, &rec[0], N, &o[0], N, N, N, tt);
+  sbac_load(c->sbac, states);
+  c->sbac.resetBits(); c->bin.m_fracBits = fracLeft;
+  c->sbac.codeQtCbf(&cu, 0, tt, trDepth);
+  c->sbac.codeCoeffNxN(&cu, &coef[0], 0, N, N, 0, tt);
+  const UInt bits = c->bin.getNumWrittenBits();
+  for (int i = 0; i < N * N; i++) { levels[i] = coef[i]; recon[i] = rec[i]; }
+  out[0] = absSum; out[1] = absSum != 0; out[2] = dist; out[3] = 0; out[4] = 0; out[5] = bits; out[6] = 0; out[7] = 0;
+  *cost = g->rd.calcRdCost(bits, dist);
+  cu.m_pePredMode = sPred; cu.m_puhTrIdx = sTr; cu.m_puhLumaIntraDir = sL; cu.m_puhChromaIntraDir = sC; cu.m_puhDepth = sD; cu.m_pcSlice = sS;
+  cu.m_CUTransquantBypass = sB; for (int k = 0; k < 3; k++) { cu.m_puhTransformSkip[k] = sT[k]; cu.m_puhCbf[k] = sCbf[k]; }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // intra rough search pieces (row a7): the reference's own fillReferenceSamples, getPredictorPtr, predIntraLumaAng,
 // calcHAD.  The smoothing of TComPattern::initAdiPattern (:237-312) is inline code that needs a TComDataCU/TComPic
 // graph; it is RESTATED here (marked) so that the filtered buffer exists for getPredictorPtr.

@@ -213,3 +213,68 @@ def test_tu_rd_golden(hp):
     with pytest.raises(hp.HopError):
         ctx.tu_rd(bad, np.stack([c["st"] for c in cases]))
     ctx.close()
+
+
+def test_tu_intra_golden(hp):
+    """row a8 leaf step (xIntraCodingLumaBlk / ChromaBlk after the prediction) through hop_tu_rd with is_intra: levels, bits, distortion,
+    cost and the reconstruction written into the reconstruction picture, against the reference-assembled goldens (192 TUs)"""
+    g = load("tu_intra.npz")
+    W = H = 256
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(g["orgY"].astype(np.int16), g["orgCb"].astype(np.int16), g["orgCr"].astype(np.int16))
+    for comp, k in enumerate(("prdY", "prdCb", "prdCr")):
+        ctx.plane_upload("pred", comp, g[k].astype(np.int16))
+        ctx.plane_upload("recon", comp, np.zeros(g[k].shape, np.int16))
+    par = g["par"]
+    jobs = np.zeros(len(par), hp.TU_RD_JOB_DTYPE)
+    for i in range(len(par)):
+        log2, comp, qp, trd, sh, uts, scan, px, py, off = (int(v) for v in par[i])
+        j = jobs[i]
+        j["x"], j["y"] = (px, py) if comp == 0 else (2 * px, 2 * py)
+        j["comp"], j["log2_size"], j["qp_scaled"], j["tr_depth"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["bit_depth"] = comp, log2, qp, trd, i, sh, uts, 8
+        j["is_intra"], j["scan_idx"], j["use_dst"] = 1, scan, 1
+        j["lambda_rdoq"], j["lambda_rd"], j["dist_weight"] = (float(v) for v in g["lam"][i])
+    res, lv = ctx.tu_rd(jobs, g["st"])
+    for i in range(len(par)):
+        log2, off = int(par[i][0]), int(par[i][9])
+        got = [int(res[i][k]) for k in ("abs_sum", "cbf", "dist", "bits")]
+        assert got == [int(g["out"][i][k]) for k in (0, 1, 2, 5)], (i, par[i], got, g["out"][i])
+        assert float(res[i]["cost"]) == float(g["cost"][i]) and np.array_equal(lv[off:off + (1 << (2 * log2))], g["levels"][off:off + (1 << (2 * log2))]), (i, par[i])
+    for comp, k in enumerate(("recY", "recCb", "recCr")):
+        assert np.array_equal(ctx.recon_download(comp), g[k]), k
+    ctx.close()
+
+
+def test_intra_pred_vs_oracle(hp):
+    """hop_intra_pred: the prediction of one mode per block (xIntraCodingLumaBlk's first step) against the oracle's predictor -- the same
+    code whose SATDs are pinned to the reference for all 35 modes -- on the golden blocks (all sizes, partial availability, strong smoothing)"""
+    O = oracle()
+    g = load("intra.npz")
+    Y = g["Y"].astype(np.int16); rec = g["rec"].astype(np.int16)
+    H, W = Y.shape
+    ctx = hp.Context(W, H)
+    z = np.zeros((H // 2, W // 2), np.int16)
+    ctx.upload_orig(Y, z, z)
+    ctx.plane_upload("recon", 0, rec)
+    rng = np.random.default_rng(8)
+    IP = ctypes.POINTER(ctypes.c_int)
+    for rnd in range(3):
+        modes = rng.integers(0, 35, len(g["jobs"])).astype(np.int32)
+        if rnd == 0: modes[:] = np.arange(len(modes)) % 35
+        # blocks of one call must not overlap in the prediction picture: one job per call is the simplest way to guarantee it here
+        for (x, y, N, strong), fl, mode in zip(g["jobs"], g["flags"], modes):
+            x, y, N, strong, mode = int(x), int(y), int(N), int(strong), int(mode)
+            j = hp.IntraJob(x, y, N, strong)
+            for k in range(68):
+                j.flags[k] = int(fl[k])
+            ctx.intra_pred([j], [mode])
+            got = ctx.pred_download(0)[y:y + N, x:x + N]
+            L = (ctypes.c_int * (4 * 64 + 8))(); F = (ctypes.c_int * (4 * 64 + 8))()
+            fla = np.ascontiguousarray(fl, np.uint8)
+            O.hop_o_intra_fill_refs(p16(rec), W, x, y, N, fla.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 8, L)
+            O.hop_o_intra_smooth(L, N, 8, strong, F)
+            want = np.zeros((N, N), np.int16)
+            O.hop_o_intra_pred(L, F, N, mode, 8, p16(want))
+            assert np.array_equal(got, want), (x, y, N, mode)
+        if rnd == 0 and len(g["jobs"]) > 60: break
+    ctx.close()

@@ -7,10 +7,14 @@ One "step" = one pass of the hot path over every CTU of the frame (10 164 CTUs):
     refinement (HAD), GT/HOP 4-corner diamond search (HAD) -- for the full RD-tree PU set of every CTU
     (CU 64..8 x {2Nx2N, Nx2N, 2NxN} = 425 PUs per interior CTU, TEncCu::xCompressCU's symmetric test order),
   * the final GT predictor (luma + chroma) of every 2Nx2N PU, depth by depth,
+  * the residual-quadtree leaf of that prediction's residual (TEncSearch::xEstimateResidualQT at the largest transform
+    size): DCT, estBit, RDOQ, CABAC-counted bits, dequantiser + inverse DCT, SSE and the cbf-zero decision of every
+    Y/Cb/Cr transform unit (2.6 M TUs per frame), from the slice's initial ISS context snapshot,
+  * the 35-mode intra rough search of every CU (+ the 4x4 blocks of NxN at maximum depth),
   * the SS-reference commit (copy + border halo) of every CU of the frame.
 The SS reference is a resident, fully reconstructed picture ("frozen reference"): all CTUs are independent, so
-this measures the device-side hot path; the reference's host spine (CABAC-driven RD decisions, SURVEY 8(a) row
-a0) is not part of it and is documented as not built yet in DESIGN.md.  Inputs (pictures, PU job lists) are
+this measures the device-side hot path; the reference's host spine (the mode decision between the candidates
+and the context evolution it drives) is not part of it and is documented as not built yet in DESIGN.md.  Inputs (pictures, PU job lists) are
 resident in HBM before the timed region starts.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run): the frame's CTU rows are dealt round-robin to the
@@ -185,8 +189,7 @@ def main():
     my_rects = rects[np.isin((rects[:, 1] // 64), my_rows)]
     d_myrects = torch.from_numpy(np.ascontiguousarray(my_rects)).to(dev)
     # ---- rows a7 / a9 / a10 / a12 of the same CUs: 35-mode intra rough search of every CU (+ the four 4x4 blocks of
-    #      an 8x8 CU, NxN at maximum depth), and the transform-quantisation round trip (DCT, flat quantiser, dequantiser,
-    #      inverse DCT, reconstruction, SSE) of the residual of every 2Nx2N GT prediction, luma + both chroma planes ----
+    #      an 8x8 CU, NxN at maximum depth) ----
     cu = np.stack([jobs["pu_x"][is2n], jobs["pu_y"][is2n], jobs["w"][is2n]], axis=1).astype(np.int32)   # (x, y, size) of every CU of my CTU rows, all depths
     ij = []
     for S in (64, 32, 16, 8, 4):
@@ -205,28 +208,40 @@ def main():
     intra_jobs = np.concatenate(ij)
     d_intra = torch.from_numpy(intra_jobs.view(np.uint8)).to(dev)
     d_satd = torch.zeros(len(intra_jobs) * 35, dtype=torch.int32, device=dev)
+    # the residual quadtree leaf (row a8b + a11 + the CABAC counter) of the same CUs: forward transform, estBit, RDOQ, counted bits,
+    # inverse path, SSE and the cbf-zero decision of every component TU, all from the slice's initial ISS context snapshot
+    LAM = 0.57 * 2.0 ** ((QP - 12) / 3.0)
+    CW = 2.0 ** ((QP - (QP - 1)) / 3.0)                           # chroma distortion weight for the chroma QP the table gives at QP 32
+    snap = np.zeros((1, hp.CABAC_CTX_BYTES), np.uint8)
+    L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    chk(L.hop_cabac_init(snap.ctypes.data, 3, QP), "cabac_init")
+    d_snap = torch.from_numpy(snap).to(dev)
     tu_by_depth = []
     for d in range(4):
         S = 64 >> d
         src = cu[cu[:, 2] == S]
         parts = []
-        T = min(S, 32)                                            # luma TUs: the CU, or four 32x32 for a 64x64 CU
-        for oy in range(0, S, T):
-            for ox in range(0, S, T):
-                a = np.zeros(len(src), hp.TU_JOB_DTYPE)
-                a["x"], a["y"], a["comp"], a["log2_size"], a["qp_scaled"] = src[:, 0] + ox, src[:, 1] + oy, 0, T.bit_length() - 1, QP
-                parts.append(a)
+
+        def tus(comp, N, T, qp, lamq, w):
+            for oy in range(0, N, T):
+                for ox in range(0, N, T):
+                    a = np.zeros(len(src), hp.TU_RD_JOB_DTYPE)
+                    m = 2 if comp else 1
+                    a["x"], a["y"], a["comp"], a["log2_size"], a["qp_scaled"] = src[:, 0] + m * ox, src[:, 1] + m * oy, comp, T.bit_length() - 1, qp
+                    a["tr_depth"], a["sign_hide"], a["bit_depth"] = (1 if N > T else 0), 1, 8
+                    a["lambda_rdoq"], a["lambda_rd"], a["dist_weight"] = lamq, LAM, w
+                    parts.append(a)
+        tus(0, S, min(S, 32), QP, LAM, 1.0)                       # luma TUs: the CU, or four 32x32 for a 64x64 CU
         C = max(S // 2, 4)                                        # chroma TUs (an 8x8 CU codes one 4x4 per plane)
         for comp in (1, 2):
-            TC = min(C, 32)
-            for oy in range(0, C, TC):
-                for ox in range(0, C, TC):
-                    a = np.zeros(len(src), hp.TU_JOB_DTYPE)
-                    a["x"], a["y"], a["comp"], a["log2_size"], a["qp_scaled"] = src[:, 0] + 2 * ox, src[:, 1] + 2 * oy, comp, TC.bit_length() - 1, QP - 1
-                    parts.append(a)
+            tus(comp, C, min(C, 16), QP - 1, LAM / CW, CW)      # a 64x64 CU splits into 32x32 luma + 16x16 chroma TUs
         tu_by_depth.append(np.concatenate(parts))
     d_tu = [torch.from_numpy(t.view(np.uint8)).to(dev) for t in tu_by_depth]
-    d_tur = [torch.zeros(len(t) * 8, dtype=torch.uint8, device=dev) for t in tu_by_depth]
+    d_tur = [torch.zeros(len(t) * hp.TU_RD_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for t in tu_by_depth]
+    tu_off = [np.concatenate([[0], np.cumsum(1 << (2 * t["log2_size"].astype(np.int64)))]) for t in tu_by_depth]
+    d_tuoff = [torch.from_numpy(o[:-1].copy()).to(dev) for o in tu_off]
+    d_levels = torch.zeros(int(max(o[-1] for o in tu_off)), dtype=torch.int32, device=dev)
+    L.hop_tu_rd_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     for c3, pl in enumerate((recY, Cb, Cr)):                      # neighbours of the intra search: the reconstruction = the frozen reference
         host_plane = np.ascontiguousarray(pl.cpu().numpy(), np.int16)
         chk(L.hop_recon_upload(ctx.h, c3, host_plane.ctypes.data), "recon_upload")
@@ -242,7 +257,8 @@ def main():
             if k:
                 chk(L.hop_pred_jobs_from_results_device(ctx.h, k, d_idx[d].data_ptr(), d_jobs.data_ptr(), d_res.data_ptr(), d_pj[d].data_ptr()), "pred_jobs")
                 chk(L.hop_pred_inter_device(ctx.h, k, d_pj[d].data_ptr()), "pred")
-                chk(L.hop_tu_roundtrip_device(ctx.h, len(tu_by_depth[d]), d_tu[d].data_ptr(), d_tur[d].data_ptr(), None, None), "tu_roundtrip")
+                chk(L.hop_tu_rd_device(ctx.h, len(tu_by_depth[d]), d_tu[d].data_ptr(), d_snap.data_ptr(), d_tuoff[d].data_ptr(), int(tu_off[d][-1]),
+                                       d_levels.data_ptr(), d_tur[d].data_ptr()), "tu_rd")
         chk(L.hop_intra_rough_device(ctx.h, len(intra_jobs), d_intra.data_ptr(), d_satd.data_ptr()), "intra_rough")
         chk(L.hop_ssref_commit_cus_device(ctx.h, len(my_rects), d_myrects.data_ptr(), recY.data_ptr(), Cb.data_ptr(), Cr.data_ptr()), "commit")
 
@@ -271,7 +287,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = {}
-    names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 6: "k_tu_roundtrip", 7: "k_intra_rough"}
+    names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 6: "k_tu_rd (transform + setup + inverse + decide)", 7: "k_intra_rough", 8: "k_rdoq", 9: "k_coeff_bits"}
     for kid, name in names.items():
         la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
         chk(L.hop_profile_read(ctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
@@ -279,6 +295,11 @@ def main():
     chk(L.hop_profile_enable(ctx.h, 0), "profile_disable")
     # a result checksum so that a run can be compared with another build
     res_host = np.frombuffer(d_res.cpu().numpy().tobytes(), hp.PU_RESULT_DTYPE)
+
+    tu_crc = 0
+    for d in range(4):
+        tr = np.frombuffer(d_tur[d].cpu().numpy().tobytes(), hp.TU_RD_RESULT_DTYPE)
+        tu_crc ^= int(np.bitwise_xor.reduce((tr["bits"].astype(np.uint64) * 31 + tr["dist"] + tr["abs_sum"] * 7) * np.arange(1, len(tr) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF))
 
     if rank == 0:
         value = n_ctu * args.steps / dt
@@ -308,8 +329,8 @@ def main():
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i16+f64", "data": "synthetic",
-            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + TU round trip of its residual (Y,Cb,Cr) + 35-mode intra rough search + SS-ref commit, "
-                                   "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD/CABAC" % (W, H, PITCH, QP, n if world == 1 else -1),
+            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + residual-quadtree leaf of its residual (DCT, RDOQ, CABAC-counted bits, inverse, SSE, cbf decision; Y,Cb,Cr) + 35-mode intra rough search + SS-ref commit, "
+                                   "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD spine" % (W, H, PITCH, QP, n if world == 1 else -1),
                        "ctus": n_ctu, "pus_rank0": int(n), "parallelism": "ctu-rows-rr%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -325,6 +346,7 @@ def main():
             "kernels": prof,
             "kernels_note": "HIP-event time per launch; hop_me_search_device runs the two halves of a batch on two streams, so launches of "
                             "different kernels overlap and the totals add up to more than the step time",
+            "tu_rd_crc": tu_crc,
             "result_crc": int(np.bitwise_xor.reduce(res_host["cost"].astype(np.uint64) * np.arange(1, len(res_host) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)),
         }
         if world == 1:

@@ -506,7 +506,8 @@ int hop_intra_rough_device(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint3
 int hop_rdoq_device(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum) {
   if (!c || n < 0 || (n && (!d_jobs || !d_tables || !d_src || !d_dst || !d_abs_sum))) return hop_set_err(c, HOP_ERR_ARG, "hop_rdoq_device: bad argument");
   if (n == 0) return HOP_OK;
-  return hop_launch_rdoq(c, n, d_jobs, d_tables, d_src, d_dst, d_abs_sum);
+  void* work; int r = hop_scratch(c, hop_rdoq_work_bytes(n), &work); if (r) return r;
+  return hop_launch_rdoq(c, n, d_jobs, d_tables, d_src, d_dst, d_abs_sum, work);
 }
 
 int hop_rdoq(hop_ctx* c, int n, const hop_rdoq_job* jobs, int n_tables, const hop_estbits* tables, size_t n_coeff,
@@ -529,7 +530,8 @@ int hop_rdoq(hop_ctx* c, int n, const hop_rdoq_job* jobs, int n_tables, const ho
   HIPCHK(c, hipMemcpyAsync(b + o_t, tables, bt, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b + o_s, src, n_coeff * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_d, 0, n_coeff * 4, c->stream));
-  r = hop_launch_rdoq(c, n, (const hop_rdoq_job*)b, (const hop_estbits*)(b + o_t), (const int32_t*)(b + o_s), (int32_t*)(b + o_d), (uint32_t*)(b + o_a));
+  void* work; r = hop_scratch(c, hop_rdoq_work_bytes(n), &work); if (r) return r;
+  r = hop_launch_rdoq(c, n, (const hop_rdoq_job*)b, (const hop_estbits*)(b + o_t), (const int32_t*)(b + o_s), (int32_t*)(b + o_d), (uint32_t*)(b + o_a), work);
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(dst, b + o_d, n_coeff * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(abs_sum, b + o_a, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

@@ -333,7 +333,8 @@ int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_coef = 0, o_zs = al(o_coef + n_coeff * 4), o_ns = al(o_zs + (size_t)n * 4), o_as = al(o_ns + (size_t)n * 4), o_fr = al(o_as + (size_t)n * 4);
   const size_t o_tab = al(o_fr + (size_t)n * 8), o_rq = al(o_tab + (size_t)n * sizeof(hop_estbits)), o_cb = al(o_rq + (size_t)n * sizeof(hop_rdoq_job));
-  void* sc; int r = hop_scratch(c, al(o_cb + (size_t)n * sizeof(hop_coeff_bits_job)) + 256, &sc); if (r) return r;
+  const size_t o_wk = al(o_cb + (size_t)n * sizeof(hop_coeff_bits_job));
+  void* sc; int r = hop_scratch(c, o_wk + hop_rdoq_work_bytes(n) + 256, &sc); if (r) return r;
   char* b = (char*)sc;
   int32_t* coef = (int32_t*)(b + o_coef); uint32_t* zs = (uint32_t*)(b + o_zs); uint32_t* ns = (uint32_t*)(b + o_ns); uint32_t* as = (uint32_t*)(b + o_as);
   unsigned long long* fr = (unsigned long long*)(b + o_fr); hop_estbits* tab = (hop_estbits*)(b + o_tab);
@@ -343,7 +344,7 @@ int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   hipLaunchKernelGGL(k_turd_forward, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, coef, zs);
   hipLaunchKernelGGL(k_turd_setup, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_jobs, n, d_ctx, d_coef_off, hop_entropy_bits_device(c), tab, rq, cb);
   hop_prof_end(c, pr);
-  r = hop_launch_rdoq(c, n, rq, tab, coef, d_levels, as); if (r) return r;
+  r = hop_launch_rdoq(c, n, rq, tab, coef, d_levels, as, b + o_wk); if (r) return r;
   r = hop_launch_coeff_bits(c, n, cb, d_ctx, d_levels, fr, nullptr); if (r) return r;
   const int pr2 = hop_prof_begin(c, HOP_K_TQ, 0);
   hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, as, ns, c->rec[0], c->rec[1], c->rec[2]);

@@ -14,7 +14,7 @@ tables = rng.integers(3000, 90000, (4, hp.ESTBITS_INTS)).astype(np.int32)
 d_tab = torch.from_numpy(tables).to(dev)
 print("size   TUs     ms    MTU/s  Mcoef/s")
 for log2 in (2, 3, 4, 5):
-    N2 = 1 << (2 * log2); n = (1 << 22) // N2
+    N2 = 1 << (2 * log2); n = (1 << 26) // N2                 # one lane per TU: the device wants >= 64k TUs of a class in flight
     yy, xx = np.mgrid[0:1 << log2, 0:1 << log2]
     src = np.round(rng.laplace(0, 1, (n, 1 << log2, 1 << log2)) * (400.0 / (1.0 + 0.35 * (xx + yy)))).astype(np.int32).reshape(-1)
     jobs = np.zeros(n, hp.RDOQ_JOB_DTYPE)

@@ -1,0 +1,226 @@
+// oracle/enc_shim.cpp -- TEST INFRASTRUCTURE.  Encoder-in-the-loop check of the drop-in boundary.
+//
+// Our own definitions of the three search members of the reference's TEncSearch that the C ABI replaces:
+//   TEncSearch::xPatternSearch         TLibEncoder/TEncSearch.cpp:6262-6371   -> hop_o_ss_search    (= hop_ss_search)
+//   TEncSearch::xPatternSearchFracDIF  TLibEncoder/TEncSearch.cpp:6564-6610   -> hop_o_frac_search  (= hop_frac_search)
+//   TEncSearch::xPatternSearchGT       TLibEncoder/TEncSearch.cpp:4686-6200   -> hop_o_gt_search    (= hop_gt_search)
+// oracle/Makefile.ref links them into _ref/TAppEncoderShim in place of the reference's definitions (the reference's object
+// keeps everything else; its three symbols are weakened with objcopy, nothing of the reference is edited or copied).  The rest
+// of the encoder -- xCompressCU, AMVP, CABAC, RQT, SS-ref upkeep -- is the reference's.  If the shim encoder writes the same
+// bitstream and reconstruction as the unmodified one, then for every call the real encoder makes (real predictors, sentinel
+// regions, picture borders, every PU shape incl. AMP) the restatement returned what the reference's members return, and the
+// argument mapping of INTEGRATION.md carries everything the callee needs (tests/test_encoder_shim.py).
+// With HOP_SHIM_TRACE=<file> every call is appended to a binary trace (inputs incl. the reference window + outputs) that
+// oracle/make_golden7.py samples into tests/golden/encoder_calls.npz for the GPU replay test.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cassert>
+#include <vector>
+#include <list>
+#include <map>
+#include <string>
+#include <sstream>
+#include <iostream>
+#include <fstream>
+#include <algorithm>
+#include <stdint.h>
+// the reference's members are reached through its own headers; standard headers come first so they are unaffected
+#define private public
+#define protected public
+#include "TLibCommon/TComRdCost.h"
+#include "TLibCommon/TComPattern.h"
+#include "TLibCommon/TComDataCU.h"
+#include "TLibEncoder/TEncCfg.h"
+#include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComPrediction.h"
+#include "TLibEncoder/TEncSearch.h"
+#undef private
+#undef protected
+extern "C" {
+#include "hop_oracle.h"
+}
+
+namespace {
+FILE* trace_file() {
+  static FILE* f = NULL; static bool tried = false;
+  if (!tried) { tried = true; const char* p = getenv("HOP_SHIM_TRACE"); if (p && *p) f = fopen(p, "wb"); }
+  return f;
+}
+unsigned long g_calls[3] = { 0, 0, 0 };
+struct Report { ~Report() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: ss %lu frac %lu gt %lu\n", g_calls[0], g_calls[1], g_calls[2]); } } g_report;
+
+// one trace record: header of int32 + the original block + the reference rows the call can read
+//   kind(0 ss,1 frac,2 gt) w h nIn nOut winX0 winY0 winW winH, in[nIn], out[nOut], org[w*h], window[winW*winH]
+void trace(int kind, int w, int h, const int* in, int nIn, const int64_t* out, int nOut, const Pel* org, int orgStride,
+           const Pel* refPU, int refStride, int x0, int y0, int x1, int y1) {
+  FILE* f = trace_file(); if (!f) return;
+  const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+  int32_t hd[9] = { kind, w, h, nIn, nOut, x0, y0, ww, wh };
+  fwrite(hd, 4, 9, f); fwrite(in, 4, nIn, f); fwrite(out, 8, nOut, f);
+  for (int y = 0; y < h; y++) fwrite(org + y * orgStride, 2, w, f);
+  for (int y = y0; y <= y1; y++) fwrite(refPU + (ptrdiff_t)y * refStride + x0, 2, ww, f);
+}
+}
+
+Void TEncSearch::xPatternSearch(TComPattern* pcPatternKey, Pel* piRefY, Int iRefStride, TComMv* pcMvSrchRngLT, TComMv* pcMvSrchRngRB,
+                                TComMv& rcMv, UInt& ruiSAD, Int riOffsetX, Int riOffsetY, TComMv* ssBestCand, Bool isSSE)
+{
+  if (!isSSE) { fprintf(stderr, "hop shim: xPatternSearch outside an SS slice is not on the replaced path\n"); abort(); }
+  g_calls[0]++;
+  const int w = pcPatternKey->getROIYWidth(), h = pcPatternKey->getROIYHeight();
+  int bx = 0, by = 0; uint32_t sad = 0;
+  const int L = pcMvSrchRngLT->getHor(), R = pcMvSrchRngRB->getHor(), T = pcMvSrchRngLT->getVer(), B = pcMvSrchRngRB->getVer();
+  hop_o_ss_search(pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride, w, h, L, R, T, B, riOffsetX, riOffsetY,
+                  m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(), m_pcRdCost->m_uiCost,
+                  m_pcEncCfg->getUseFastEnc() ? 1 : 0, g_bitDepthY, &bx, &by, &sad);
+  if (trace_file()) {
+    const int in[10] = { L, R, T, B, riOffsetX, riOffsetY, m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(), (int)m_pcRdCost->m_uiCost,
+                         m_pcEncCfg->getUseFastEnc() ? 1 : 0 };
+    const int64_t out[3] = { bx, by, (int64_t)sad };
+    if (L <= R && T <= B) trace(0, w, h, in, 10, out, 3, pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride, L, T, R + w - 1, B + h - 1);
+  }
+  if (sad == 0xFFFFFFFFu) { ruiSAD = MAX_UINT; return; }         // no valid candidate: rcMv and ssBestCand stay as they were (:6356-6360)
+  rcMv.set(bx, by);
+  ssBestCand[0].set(bx, by);
+  ruiSAD = sad;
+}
+
+Void TEncSearch::xPatternSearchFracDIF(TComDataCU* pcCU, TComPattern* pcPatternKey, Pel* piRefY, Int iRefStride, TComMv* pcMvInt,
+                                       TComMv& rcMvHalf, TComMv& rcMvQter, UInt& ruiCost, Bool biPred)
+{
+  if (biPred) { fprintf(stderr, "hop shim: bi-prediction is not on the replaced path\n"); abort(); }
+  g_calls[1]++;
+  const int w = pcPatternKey->getROIYWidth(), h = pcPatternKey->getROIYHeight();
+  int half[2], qter[2];
+  const uint32_t cost = hop_o_frac_search(pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride, w, h,
+                                          pcMvInt->getHor(), pcMvInt->getVer(), m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(),
+                                          m_pcRdCost->m_uiCost, m_pcEncCfg->getUseHADME() ? 1 : 0, g_bitDepthY, half, qter);
+  if (trace_file()) {
+    const int in[6] = { pcMvInt->getHor(), pcMvInt->getVer(), m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(), (int)m_pcRdCost->m_uiCost,
+                        m_pcEncCfg->getUseHADME() ? 1 : 0 };
+    const int64_t out[5] = { half[0], half[1], qter[0], qter[1], (int64_t)cost };
+    trace(1, w, h, in, 6, out, 5, pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride,
+          pcMvInt->getHor() - 4, pcMvInt->getVer() - 4, pcMvInt->getHor() + w + 4, pcMvInt->getVer() + h + 4);
+  }
+  rcMvHalf.set(half[0], half[1]);
+  rcMvQter.set(qter[0], qter[1]);
+  ruiCost = cost;
+  m_pcRdCost->setCostScale(0);                                      // what the reference's member leaves behind (:6596)
+}
+
+Void TEncSearch::xPatternSearchGT(TComDataCU* pcCU, TComPattern* pcPatternKey, Pel* piRefY, Int iRefStride, TComMv* pcMvInt, TComMv* rcMvHalf,
+                                  TComMv* rcMvQter, TComMv* rcGT0, TComMv* rcGT1, TComMv* rcGT2, TComMv* rcGT3, Bool& gtFlag, UInt& ruiCost,
+                                  Bool biPred, TComMv* bestSSCand)
+{
+  if (biPred) { fprintf(stderr, "hop shim: bi-prediction is not on the replaced path\n"); abort(); }
+  g_calls[2]++;
+  const int w = pcPatternKey->getROIYWidth(), h = pcPatternKey->getROIYHeight();
+  int mv[2] = { pcMvInt->getHor(), pcMvInt->getVer() }, half[2] = { rcMvHalf->getHor(), rcMvHalf->getVer() }, qter[2] = { rcMvQter->getHor(), rcMvQter->getVer() };
+  const int ssBest[2] = { bestSSCand[0].getHor(), bestSSCand[0].getVer() };
+  AMVPInfo* ai = pcCU->getCUMvField(REF_PIC_LIST_0)->getAMVPInfo();
+  int amvp[2 * AMVP_MAX_NUM_CANDS_MEM];
+  for (int i = 0; i < ai->iN; i++) { amvp[2 * i] = ai->m_acMvCand[i].getHor(); amvp[2 * i + 1] = ai->m_acMvCand[i].getVer(); }
+  uint32_t cost = ruiCost; int gt[8];
+  const int in0[12] = { mv[0], mv[1], half[0], half[1], qter[0], qter[1], ssBest[0], ssBest[1], m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(),
+                        (int)m_pcRdCost->m_uiCost, (int)ruiCost };
+  const int flag = hop_o_gt_search(pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride, w, h, mv, half, qter, ssBest, ai->iN, amvp,
+                                   m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(), m_pcRdCost->m_uiCost,
+                                   m_pcEncCfg->getUseHADME() ? 1 : 0, g_bitDepthY, &cost, gt);
+  if (trace_file()) {
+    int in[12 + 2 + 2 * AMVP_MAX_NUM_CANDS_MEM]; memcpy(in, in0, sizeof(in0));
+    in[12] = m_pcEncCfg->getUseHADME() ? 1 : 0; in[13] = ai->iN;
+    for (int i = 0; i < 2 * ai->iN; i++) in[14 + i] = amvp[i];
+    const int64_t out[16] = { flag, gt[0], gt[1], gt[2], gt[3], gt[4], gt[5], gt[6], gt[7], (int64_t)cost, mv[0], mv[1], half[0], half[1], qter[0], qter[1] };
+    // every start vector's 2W x 2H patch (+ the 8-tap margins): the starts are the SS best and the AMVP candidates at integer precision
+    int x0 = in0[6], x1 = in0[6], y0 = in0[7], y1 = in0[7];
+    for (int i = 0; i < ai->iN; i++) {
+      const int ax = amvp[2 * i] >> 2, ay = amvp[2 * i + 1] >> 2;
+      if (ax < x0) x0 = ax; if (ax > x1) x1 = ax; if (ay < y0) y0 = ay; if (ay > y1) y1 = ay;
+    }
+    if (in0[0] < x0) x0 = in0[0]; if (in0[0] > x1) x1 = in0[0]; if (in0[1] < y0) y0 = in0[1]; if (in0[1] > y1) y1 = in0[1];
+    trace(2, w, h, in, 14 + 2 * ai->iN, out, 16, pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride,
+          x0 - w / 2 - 6, y0 - h / 2 - 6, x1 + w + w / 2 + 6, y1 + h + h / 2 + 6);
+  }
+  gtFlag = flag != 0;
+  rcGT0->set(gt[0], gt[1]); rcGT1->set(gt[2], gt[3]); rcGT2->set(gt[4], gt[5]); rcGT3->set(gt[6], gt[7]);
+  pcMvInt->set(mv[0], mv[1]); rcMvHalf->set(half[0], half[1]); rcMvQter->set(qter[0], qter[1]);
+  ruiCost = cost;
+}
+
+// ---- rows a6 / a9 / a10 / a11: the predictor and transform/quantisation members, same method ----
+//   TComPrediction::xPredInterLumaBlk / xPredInterChromaBlk  TLibCommon/TComPrediction.cpp:639-720, 1235-1347  -> hop_o_pred_inter (= hop_pred_inter)
+//   TComTrQuant::xT / xIT                                    TLibCommon/TComTrQuant.cpp:1341-1400              -> hop_o_fwd_transform / hop_o_inv_transform
+//   TComTrQuant::xDeQuant                                    TLibCommon/TComTrQuant.cpp:1124-1183              -> hop_o_dequant_flat
+//   TComTrQuant::xRateDistOptQuant                           TLibCommon/TComTrQuant.cpp:1489-1999              -> hop_o_rdoq (= hop_rdoq)
+namespace { unsigned long g_calls2[6] = { 0, 0, 0, 0, 0, 0 };
+struct Report2 { ~Report2() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: predY %lu predC %lu xT %lu xIT %lu dequant %lu rdoq %lu\n",
+                                                                  g_calls2[0], g_calls2[1], g_calls2[2], g_calls2[3], g_calls2[4], g_calls2[5]); } } g_report2; }
+
+Void TComPrediction::xPredInterLumaBlk(TComDataCU* cu, TComPicYuv* refPic, UInt partAddr, TComMv* mv, Int width, Int height, TComYuv*& dstPic, Bool bi,
+                                       Bool bUseGT, TComMv* mGT0, TComMv* mGT1, TComMv* mGT2, TComMv* mGT3)
+{
+  if (bi) { fprintf(stderr, "hop shim: bi-prediction is not on the replaced path\n"); abort(); }
+  g_calls2[0]++;
+  const int gt[8] = { mGT0->getHor(), mGT0->getVer(), mGT1->getHor(), mGT1->getVer(), mGT2->getHor(), mGT2->getVer(), mGT3->getHor(), mGT3->getVer() };
+  const UInt z = cu->getZorderIdxInCU() + partAddr;
+  std::vector<int16_t> y(width * height), cb(width * height / 4), cr(width * height / 4);
+  hop_o_pred_inter(refPic->getLumaAddr(cu->getAddr(), z), refPic->getStride(), refPic->getCbAddr(cu->getAddr(), z), refPic->getCrAddr(cu->getAddr(), z), refPic->getCStride(),
+                   0, 0, width, height, mv->getHor(), mv->getVer(), bUseGT ? 1 : 0, gt, g_bitDepthY, g_bitDepthC, &y[0], &cb[0], &cr[0]);
+  Pel* dst = dstPic->getLumaAddr(partAddr); const int ds = dstPic->getStride();
+  for (int r = 0; r < height; r++) memcpy(dst + r * ds, &y[r * width], width * sizeof(Pel));
+}
+
+Void TComPrediction::xPredInterChromaBlk(TComDataCU* cu, TComPicYuv* refPic, UInt partAddr, TComMv* mv, Int width, Int height, TComYuv*& dstPic, Bool bi,
+                                         Bool bUseGT, TComMv* mGT0, TComMv* mGT1, TComMv* mGT2, TComMv* mGT3)
+{
+  if (bi) { fprintf(stderr, "hop shim: bi-prediction is not on the replaced path\n"); abort(); }
+  g_calls2[1]++;
+  const int gt[8] = { mGT0->getHor(), mGT0->getVer(), mGT1->getHor(), mGT1->getVer(), mGT2->getHor(), mGT2->getVer(), mGT3->getHor(), mGT3->getVer() };
+  const UInt z = cu->getZorderIdxInCU() + partAddr;
+  std::vector<int16_t> y(width * height), cb(width * height / 4), cr(width * height / 4);
+  hop_o_pred_inter(refPic->getLumaAddr(cu->getAddr(), z), refPic->getStride(), refPic->getCbAddr(cu->getAddr(), z), refPic->getCrAddr(cu->getAddr(), z), refPic->getCStride(),
+                   0, 0, width, height, mv->getHor(), mv->getVer(), bUseGT ? 1 : 0, gt, g_bitDepthY, g_bitDepthC, &y[0], &cb[0], &cr[0]);
+  Pel* dcb = dstPic->getCbAddr(partAddr); Pel* dcr = dstPic->getCrAddr(partAddr); const int ds = dstPic->getCStride();
+  const int cw = width >> 1, ch = height >> 1;
+  for (int r = 0; r < ch; r++) { memcpy(dcb + r * ds, &cb[r * cw], cw * sizeof(Pel)); memcpy(dcr + r * ds, &cr[r * cw], cw * sizeof(Pel)); }
+}
+
+Void TComTrQuant::xT(Int bitDepth, UInt uiMode, Pel* piBlkResi, UInt uiStride, Int* psCoeff, Int iWidth, Int iHeight)
+{
+  g_calls2[2]++;
+  int16_t block[32 * 32], coeff[32 * 32];
+  for (int j = 0; j < iHeight; j++) memcpy(block + j * iWidth, piBlkResi + j * uiStride, iWidth * sizeof(int16_t));
+  hop_o_fwd_transform(bitDepth, block, coeff, iWidth, uiMode != REG_DCT && iWidth == 4);   // the mode only selects the DST for 4x4 (xTrMxN :793-799)
+  for (int j = 0; j < iWidth * iHeight; j++) psCoeff[j] = coeff[j];
+}
+
+Void TComTrQuant::xIT(Int bitDepth, UInt uiMode, Int* plCoef, Pel* pResidual, UInt uiStride, Int iWidth, Int iHeight)
+{
+  g_calls2[3]++;
+  int16_t block[32 * 32], coeff[32 * 32];
+  for (int j = 0; j < iWidth * iHeight; j++) coeff[j] = (int16_t)plCoef[j];
+  hop_o_inv_transform(bitDepth, coeff, block, iWidth, uiMode != REG_DCT && iWidth == 4);
+  for (int j = 0; j < iHeight; j++) memcpy(pResidual + j * uiStride, block + j * iWidth, iWidth * sizeof(int16_t));
+}
+
+Void TComTrQuant::xDeQuant(Int bitDepth, const TCoeff* pSrc, Int* pDes, Int iWidth, Int iHeight, Int scalingListType)
+{
+  if (getUseScalingList()) { fprintf(stderr, "hop shim: scaling lists are not on the replaced path\n"); abort(); }
+  g_calls2[4]++;
+  hop_o_dequant_flat(bitDepth, m_cQP.m_iQP, pSrc, pDes, iWidth);
+}
+
+Void TComTrQuant::xRateDistOptQuant(TComDataCU* pcCU, Int* plSrcCoeff, TCoeff* piDstCoeff, Int*& piArlDstCoeff, UInt uiWidth, UInt uiHeight, UInt& uiAbsSum,
+                                    TextType eTType, UInt uiAbsPartIdx)
+{
+  g_calls2[5]++;
+  const int log2 = g_aucConvertToBit[uiWidth] + 2, comp = eTType == TEXT_LUMA ? 0 : (eTType == TEXT_CHROMA_U ? 1 : 2);
+  const bool intra = pcCU->isIntra(uiAbsPartIdx);
+  uint32_t as = uiAbsSum;
+  hop_o_rdoq(plSrcCoeff, piDstCoeff, log2, comp, intra ? 1 : 0, (int)pcCU->getCoefScanIdx(uiAbsPartIdx, uiWidth, eTType == TEXT_LUMA, intra),
+             pcCU->getTransformIdx(uiAbsPartIdx), m_cQP.m_iQP, eTType == TEXT_LUMA ? g_bitDepthY : g_bitDepthC,
+             pcCU->getSlice()->getPPS()->getSignHideFlag() ? 1 : 0, m_dLambda, (const hop_o_estbits*)m_pcEstBitsSbac, &as);
+  uiAbsSum = as;
+}

@@ -102,7 +102,7 @@ Void TEncSearch::xPatternSearchFracDIF(TComDataCU* pcCU, TComPattern* pcPatternK
                         m_pcEncCfg->getUseHADME() ? 1 : 0 };
     const int64_t out[5] = { half[0], half[1], qter[0], qter[1], (int64_t)cost };
     trace(1, w, h, in, 6, out, 5, pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride,
-          pcMvInt->getHor() - 4, pcMvInt->getVer() - 4, pcMvInt->getHor() + w + 4, pcMvInt->getVer() + h + 4);
+          pcMvInt->getHor() - 4, pcMvInt->getVer() - 4, pcMvInt->getHor() + w + 4, pcMvInt->getVer() + h + 4);   // the members' own reach (:7818-8011)
   }
   rcMvHalf.set(half[0], half[1]);
   rcMvQter.set(qter[0], qter[1]);
@@ -129,9 +129,13 @@ Void TEncSearch::xPatternSearchGT(TComDataCU* pcCU, TComPattern* pcPatternKey, P
                                    m_pcRdCost->m_mvPredictor.getHor(), m_pcRdCost->m_mvPredictor.getVer(), m_pcRdCost->m_uiCost,
                                    m_pcEncCfg->getUseHADME() ? 1 : 0, g_bitDepthY, &cost, gt);
   if (trace_file()) {
-    int in[12 + 2 + 2 * AMVP_MAX_NUM_CANDS_MEM]; memcpy(in, in0, sizeof(in0));
+    int in[12 + 4 + 2 * AMVP_MAX_NUM_CANDS_MEM]; memcpy(in, in0, sizeof(in0));
     in[12] = m_pcEncCfg->getUseHADME() ? 1 : 0; in[13] = ai->iN;
-    for (int i = 0; i < 2 * ai->iN; i++) in[14 + i] = amvp[i];
+    // where the PU lies in the picture (the replay puts the recorded windows back there): from the SS reference's own origin
+    TComPicYuv* ssref = pcCU->getSlice()->getRefPic(REF_PIC_LIST_0, 0)->getPicYuvRec();
+    const ptrdiff_t delta = piRefY - ssref->getLumaAddr();
+    in[14] = (int)(delta % iRefStride); in[15] = (int)(delta / iRefStride);
+    for (int i = 0; i < 2 * ai->iN; i++) in[16 + i] = amvp[i];
     const int64_t out[16] = { flag, gt[0], gt[1], gt[2], gt[3], gt[4], gt[5], gt[6], gt[7], (int64_t)cost, mv[0], mv[1], half[0], half[1], qter[0], qter[1] };
     // every start vector's 2W x 2H patch (+ the 8-tap margins): the starts are the SS best and the AMVP candidates at integer precision
     int x0 = in0[6], x1 = in0[6], y0 = in0[7], y1 = in0[7];
@@ -140,8 +144,13 @@ Void TEncSearch::xPatternSearchGT(TComDataCU* pcCU, TComPattern* pcPatternKey, P
       if (ax < x0) x0 = ax; if (ax > x1) x1 = ax; if (ay < y0) y0 = ay; if (ay > y1) y1 = ay;
     }
     if (in0[0] < x0) x0 = in0[0]; if (in0[0] > x1) x1 = in0[0]; if (in0[1] < y0) y0 = in0[1]; if (in0[1] > y1) y1 = in0[1];
-    trace(2, w, h, in, 14 + 2 * ai->iN, out, 16, pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride,
-          x0 - w / 2 - 6, y0 - h / 2 - 6, x1 + w + w / 2 + 6, y1 + h + h / 2 + 6);
+    x0 -= w / 2 + 6; y0 -= h / 2 + 6; x1 += w + w / 2 + 6; y1 += h + h / 2 + 6;
+    const int mX = ssref->getLumaMargin(), mY = ssref->getLumaMargin();          // keep the dump inside the padded plane
+    if (x0 < -mX - in[14]) x0 = -mX - in[14];
+    if (y0 < -mY - in[15]) y0 = -mY - in[15];
+    if (x1 > ssref->getWidth() + mX - 1 - in[14]) x1 = ssref->getWidth() + mX - 1 - in[14];
+    if (y1 > ssref->getHeight() + mY - 1 - in[15]) y1 = ssref->getHeight() + mY - 1 - in[15];
+    trace(2, w, h, in, 16 + 2 * ai->iN, out, 16, pcPatternKey->getROIY(), pcPatternKey->getPatternLStride(), piRefY, iRefStride, x0, y0, x1, y1);
   }
   gtFlag = flag != 0;
   rcGT0->set(gt[0], gt[1]); rcGT1->set(gt[2], gt[3]); rcGT2->set(gt[4], gt[5]); rcGT3->set(gt[6], gt[7]);

@@ -55,3 +55,23 @@ def me_chain_scenarios():
         assert [crc(pl.bufY), crc(pl.bufCb), crc(pl.bufCr)] == [int(v) for v in g["planes_crc"][si]]
         sel = g["jobs"][:, 0] == si
         yield pl, Y, g["jobs"][sel], g["outs"][sel], int(g["lambda_cost"])
+
+
+def encoder_calls():
+    """tests/golden/encoder_calls.npz (oracle/make_golden7.py): the PUs sampled from a real encode of the 128x128 golden lenslet.
+    Yields (planes, Y, meta): the SS-reference luma plane holding exactly the samples the reference's members could read for this
+    PU (everything else the -1 sentinel; the padded buffer's first sample set valid, as it is once a CU has been committed,
+    TEncSearch.cpp:4605), the frame's original luma and the 44 recorded numbers (layout in make_golden7.py)."""
+    from hoputil import MARGIN_Y, lenslet
+    g = load("encoder_calls.npz")
+    W, H = int(g["W"]), int(g["H"])
+    Y, _, _ = lenslet(W, H, 16, int(g["seed"]))
+    for n, m in enumerate(g["meta"]):
+        pl = Planes(W, H)
+        px, py = int(m[0]), int(m[1])
+        for k in range(3):
+            win = g["win%d_%d" % (n, k)]; x0, y0 = (int(v) for v in g["pos%d_%d" % (n, k)])
+            ya, xa = MARGIN_Y + py + y0, MARGIN_Y + px + x0
+            pl.bufY[ya:ya + win.shape[0], xa:xa + win.shape[1]] = win
+        pl.bufY[0, 0] = 0
+        yield pl, Y, [int(v) for v in m]

@@ -383,3 +383,31 @@ def test_errors_are_reported(hp):
     with pytest.raises(hp.HopError):
         ctx.me_search(jobs, 1)
     ctx.close()
+
+
+def test_encoder_calls_replay(hp):
+    """hop_me_search on the calls of a real encode (tests/golden/encoder_calls.npz: 95 PUs of 20 shapes incl. AMP, sampled from the shim
+    encoder whose bitstream equals the unmodified reference's): each PU with the SS-reference state, predictor, AMVP list, range and
+    causality offsets the reference's xMotionEstimation handed to its three search members, against what those members returned."""
+    from goldutil import encoder_calls
+    ctx = None
+    n = 0
+    for pl, Y, m in encoder_calls():
+        if ctx is None:
+            ctx = hp.Context(pl.W, pl.H)
+            c = np.full((pl.H // 2, pl.W // 2), 128, np.int16)
+            ctx.upload_orig(Y, c, c)
+            ctx.ssref_upload(1, pl.bufCb); ctx.ssref_upload(2, pl.bufCr)
+        ctx.ssref_upload(0, pl.bufY)
+        a = np.zeros(1, hp.PU_JOB_DTYPE)
+        a[0]["pu_x"], a[0]["pu_y"], a[0]["w"], a[0]["h"] = m[0:4]
+        a[0]["rng_left"], a[0]["rng_right"], a[0]["rng_top"], a[0]["rng_bottom"], a[0]["off_x"], a[0]["off_y"], a[0]["pred_x"], a[0]["pred_y"] = m[4:12]
+        a[0]["lambda_cost"], a[0]["n_amvp"], a[0]["amvp"] = m[12], m[15], m[16:20]
+        a[0]["flags"] = (hp.HOP_FLAG_FEN if m[13] else 0) | (hp.HOP_FLAG_HADME if m[14] else 0)
+        got = _res_row(ctx.me_search(a, 3)[0])
+        assert got[0:4] == m[20:23] + [0], (m[:20], got[0:4], m[20:23])
+        assert got[4:9] == m[23:28], (m[:20], got[4:9], m[23:28])
+        assert got[9:25] == m[28:44], (m[:20], got[9:25], m[28:44])
+        n += 1
+    ctx.close()
+    assert n >= 90

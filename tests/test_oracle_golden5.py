@@ -1,0 +1,30 @@
+"""CPU: the restatement's ME chain replayed on the calls of a real encode (tests/golden/encoder_calls.npz, sampled by
+oracle/make_golden7.py from the shim encoder whose bitstream equals the reference's): 95 PUs of 20 shapes incl. the AMP shapes,
+real predictors / AMVP lists / causality offsets, SS-reference states with sentinel regions.  Also proves that the fixture holds
+every sample the members read (anything missing is a sentinel here and would change the result)."""
+import ctypes
+
+import numpy as np
+
+from goldutil import encoder_calls
+from hoputil import oracle, p16
+
+
+def test_me_chain_on_encoder_calls():
+    O = oracle()
+    n = 0
+    shapes = set()
+    for pl, Y, m in encoder_calls():
+        px, py, w, h = m[0:4]
+        l, r, t, b, ox, oy, predx, predy, lc, fen, had, namvp = m[4:16]
+        amvp = (ctypes.c_int * 4)(*m[16:20])
+        org = np.ascontiguousarray(Y[py:py + h, px:px + w])
+        out = (ctypes.c_int64 * 32)()
+        O.hop_o_me_pu(p16(org), w, pl.ptr00(0), pl.sy, px, py, w, h, l, r, t, b, ox, oy, predx, predy, namvp, amvp, lc, fen, had, 8, 3, out)
+        got = list(out)
+        assert got[0:3] == m[20:23] and got[3] == 0, (m[:20], got[:4], m[20:23])
+        assert got[4:9] == m[23:28], (m[:20], got[4:9], m[23:28])
+        want_gt = m[28:44]       # flag, gt[8], cost, mv, half, qter
+        assert got[9:25] == want_gt, (m[:20], got[9:25], want_gt)
+        shapes.add((w, h)); n += 1
+    assert n >= 90 and len(shapes) == 20

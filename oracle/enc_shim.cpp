@@ -36,6 +36,7 @@
 #include "TLibCommon/TComTrQuant.h"
 #include "TLibCommon/TComPrediction.h"
 #include "TLibEncoder/TEncSearch.h"
+#include "TLibEncoder/TEncSbac.h"
 #undef private
 #undef protected
 extern "C" {
@@ -46,6 +47,11 @@ namespace {
 FILE* trace_file() {
   static FILE* f = NULL; static bool tried = false;
   if (!tried) { tried = true; const char* p = getenv("HOP_SHIM_TRACE"); if (p && *p) f = fopen(p, "wb"); }
+  return f;
+}
+FILE* rdoq_trace_file() {          // HOP_SHIM_TRACE_RDOQ=<file>: every xRateDistOptQuant call (header, lambda, tables, coefficients in, levels out)
+  static FILE* f = NULL; static bool tried = false;
+  if (!tried) { tried = true; const char* p = getenv("HOP_SHIM_TRACE_RDOQ"); if (p && *p) f = fopen(p, "wb"); }
   return f;
 }
 unsigned long g_calls[3] = { 0, 0, 0 };
@@ -231,5 +237,86 @@ Void TComTrQuant::xRateDistOptQuant(TComDataCU* pcCU, Int* plSrcCoeff, TCoeff* p
   hop_o_rdoq(plSrcCoeff, piDstCoeff, log2, comp, intra ? 1 : 0, (int)pcCU->getCoefScanIdx(uiAbsPartIdx, uiWidth, eTType == TEXT_LUMA, intra),
              pcCU->getTransformIdx(uiAbsPartIdx), m_cQP.m_iQP, eTType == TEXT_LUMA ? g_bitDepthY : g_bitDepthC,
              pcCU->getSlice()->getPPS()->getSignHideFlag() ? 1 : 0, m_dLambda, (const hop_o_estbits*)m_pcEstBitsSbac, &as);
+  if (FILE* f = rdoq_trace_file()) {
+    const int32_t hd[10] = { log2, comp, intra ? 1 : 0, (int)pcCU->getCoefScanIdx(uiAbsPartIdx, uiWidth, eTType == TEXT_LUMA, intra), pcCU->getTransformIdx(uiAbsPartIdx), m_cQP.m_iQP,
+                             eTType == TEXT_LUMA ? g_bitDepthY : g_bitDepthC, pcCU->getSlice()->getPPS()->getSignHideFlag() ? 1 : 0, (int32_t)uiAbsSum, (int32_t)as };
+    fwrite(hd, 4, 10, f); fwrite(&m_dLambda, 8, 1, f); fwrite(m_pcEstBitsSbac, sizeof(estBitsSbacStruct), 1, f);
+    fwrite(plSrcCoeff, 4, uiWidth * uiHeight, f); fwrite(piDstCoeff, 4, uiWidth * uiHeight, f);
+  }
   uiAbsSum = as;
+}
+
+// ---- the RDOQ bit-estimate tables: TEncSbac::estBit (TLibEncoder/TEncSbac.cpp:2175-2370) -> hop_o_cabac_est_bits (= hop_cabac_est_bits) ----
+namespace { unsigned long g_calls3[1] = { 0 };
+struct Report3 { ~Report3() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: estBit %lu\n", g_calls3[0]); } } g_report3; }
+Void TEncSbac::estBit(estBitsSbacStruct* pcEstBitsSbac, Int width, Int height, TextType eTType)
+{
+  g_calls3[0]++;
+  hop_o_cabac_ctx c;
+  struct { ContextModel* p; int n; uint8_t* d; } sets[10] = {
+    { m_cCUQtCbfSCModel.get(0), 8, c.qt_cbf }, { m_cCUTransSubdivFlagSCModel.get(0), 3, c.trans_subdiv }, { m_cCUQtRootCbfSCModel.get(0), 1, c.qt_root_cbf },
+    { m_cCUSigCoeffGroupSCModel.get(0), 4, c.sig_cg }, { m_cCUSigSCModel.get(0), 42, c.sig }, { m_cCuCtxLastX.get(0), 30, c.last_x }, { m_cCuCtxLastY.get(0), 30, c.last_y },
+    { m_cCUOneSCModel.get(0), 24, c.one }, { m_cCUAbsSCModel.get(0), 6, c.abs }, { m_cTransformSkipSCModel.get(0), 2, c.ts } };
+  for (int i = 0; i < 10; i++) for (int j = 0; j < sets[i].n; j++) sets[i].d[j] = sets[i].p[j].m_ucState;
+  hop_o_cabac_est_bits(&c, width, eTType == TEXT_LUMA ? 0 : 1, (hop_o_estbits*)pcEstBitsSbac);
+}
+
+// ---- rows a7 / a12: intra reference samples and prediction, HAD and SSE ----
+//   TComPattern::fillReferenceSamples   TLibCommon/TComPattern.cpp:374-558     -> hop_o_intra_fill_refs   (luma: 4-sample units; the chroma calls keep the reference's)
+//   TComPrediction::predIntraLumaAng    TLibCommon/TComPrediction.cpp:340-372  -> hop_o_intra_pred
+//   TComRdCost::calcHAD                 TLibCommon/TComRdCost.cpp:391-442      -> hop_o_calc_had
+//   TComRdCost::getDistPart             TLibCommon/TComRdCost.cpp:477-503      -> hop_o_sse / hop_o_sad (+ the chroma weight as the reference applies it)
+extern "C" void hop_ref_orig_fill_refs(TComPattern*, Int, Pel*, Int*, Bool*, Int, Int, Int, Int, UInt, UInt, UInt, UInt, Int, Bool);   // the reference's own definition (Makefile.ref)
+namespace { unsigned long g_calls4[4] = { 0, 0, 0, 0 };
+struct Report4 { ~Report4() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: fillRefs %lu intraPred %lu calcHAD %lu distPart %lu\n",
+                                                                  g_calls4[0], g_calls4[1], g_calls4[2], g_calls4[3]); } } g_report4; }
+
+Void TComPattern::fillReferenceSamples(Int bitDepth, Pel* piRoiOrigin, Int* piAdiTemp, Bool* bNeighborFlags, Int iNumIntraNeighbor, Int iUnitSize, Int iNumUnitsInCu,
+                                       Int iTotalUnits, UInt uiCuWidth, UInt uiCuHeight, UInt uiWidth, UInt uiHeight, Int iPicStride, Bool bLMmode)
+{
+  if (iUnitSize != 4 || bLMmode || uiCuWidth != uiCuHeight) {
+    hop_ref_orig_fill_refs(this, bitDepth, piRoiOrigin, piAdiTemp, bNeighborFlags, iNumIntraNeighbor, iUnitSize, iNumUnitsInCu, iTotalUnits, uiCuWidth, uiCuHeight,
+                           uiWidth, uiHeight, iPicStride, bLMmode);
+    return;
+  }
+  g_calls4[0]++;
+  const int N = (int)uiCuWidth;
+  uint8_t flags[68]; int L[4 * 64 + 1];
+  for (int i = 0; i < iTotalUnits; i++) flags[i] = bNeighborFlags[i] ? 1 : 0;
+  hop_o_intra_fill_refs(piRoiOrigin, iPicStride, 0, 0, N, flags, bitDepth, L);
+  piAdiTemp[0] = L[2 * N];                                                  // corner, above row, left column of the (2N+1)^2 buffer
+  for (int i = 0; i < 2 * N; i++) piAdiTemp[1 + i] = L[2 * N + 1 + i];
+  for (int i = 0; i < 2 * N; i++) piAdiTemp[(1 + i) * uiWidth] = L[2 * N - 1 - i];
+}
+
+Void TComPrediction::predIntraLumaAng(TComPattern* pcTComPattern, UInt uiDirMode, Pel* piPred, UInt uiStride, Int iWidth, Int iHeight, Bool bAbove, Bool bLeft)
+{
+  if (!bAbove || !bLeft || iWidth != iHeight) { fprintf(stderr, "hop shim: predIntraLumaAng without both neighbours is not on the replaced path\n"); abort(); }
+  g_calls4[1]++;
+  const int N = iWidth, sw = 2 * N + 1;
+  int Lu[4 * 64 + 1], Lf[4 * 64 + 1];
+  const Int* u = pcTComPattern->getAdiOrgBuf(N, N, m_piYuvExt); const Int* f = u + sw * sw;
+  Lu[2 * N] = u[0]; Lf[2 * N] = f[0];
+  for (int i = 0; i < 2 * N; i++) { Lu[2 * N + 1 + i] = u[1 + i]; Lf[2 * N + 1 + i] = f[1 + i]; Lu[2 * N - 1 - i] = u[(1 + i) * sw]; Lf[2 * N - 1 - i] = f[(1 + i) * sw]; }
+  int16_t pred[64 * 64];
+  hop_o_intra_pred(Lu, Lf, N, (int)uiDirMode, g_bitDepthY, pred);
+  for (int r = 0; r < N; r++) memcpy(piPred + r * uiStride, pred + r * N, N * sizeof(Pel));
+}
+
+UInt TComRdCost::calcHAD(Int bitDepth, Pel* pi0, Int iStride0, Pel* pi1, Int iStride1, Int iWidth, Int iHeight)
+{
+  g_calls4[2]++;
+  return hop_o_calc_had(pi0, iStride0, pi1, iStride1, iWidth, iHeight, bitDepth);
+}
+
+UInt TComRdCost::getDistPart(Int bitDepth, Pel* piCur, Int iCurStride, Pel* piOrg, Int iOrgStride, UInt uiBlkWidth, UInt uiBlkHeight, TextType eText, DFunc eDFunc)
+{
+  g_calls4[3]++;
+  UInt d;
+  if (eDFunc == DF_SSE) d = hop_o_sse(piOrg, iOrgStride, piCur, iCurStride, uiBlkWidth, uiBlkHeight, bitDepth);
+  else if (eDFunc == DF_SAD) d = hop_o_sad(piOrg, iOrgStride, piCur, iCurStride, uiBlkWidth, uiBlkHeight, bitDepth, 0);
+  else { fprintf(stderr, "hop shim: getDistPart with distortion function %d is not on the replaced path\n", (int)eDFunc); abort(); }
+  if (eText == TEXT_CHROMA_U) return (UInt)((Int)(m_cbDistortionWeight * d));
+  if (eText == TEXT_CHROMA_V) return (UInt)((Int)(m_crDistortionWeight * d));
+  return d;
 }

@@ -75,3 +75,17 @@ def encoder_calls():
             pl.bufY[ya:ya + win.shape[0], xa:xa + win.shape[1]] = win
         pl.bufY[0, 0] = 0
         yield pl, Y, [int(v) for v in m]
+
+
+def encoder_rdoq_calls():
+    """tests/golden/encoder_rdoq_calls.npz (oracle/make_golden8.py): 350 xRateDistOptQuant calls of a real encode, each with the
+    context-evolved bit-estimate table the reference's estBit had just written"""
+    g = load("encoder_rdoq_calls.npz")
+    off = 0
+    for hd, lam, tab in zip(g["hd"], g["lam"], g["tab"]):
+        log2, comp, intra, scan, tr, qp, bd, sh, as_in, as_out = (int(v) for v in hd)
+        n = 1 << (2 * log2)
+        yield dict(log2=log2, comp=comp, intra=intra, scan=scan, tr=tr, qp=qp, bd=bd, sh=sh, lam=float(lam), as_in=as_in, asum=as_out,
+                   src=np.ascontiguousarray(g["src"][off:off + n], np.int32), eb=np.ascontiguousarray(tab, np.int32),
+                   out=np.ascontiguousarray(g["dst"][off:off + n], np.int32))
+        off += n

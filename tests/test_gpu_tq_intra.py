@@ -146,6 +146,28 @@ def test_rdoq_golden(hp):
     ctx.close()
 
 
+def test_rdoq_encoder_calls(hp):
+    """hop_rdoq on 350 xRateDistOptQuant calls sampled from a real encode (tests/golden/encoder_rdoq_calls.npz, oracle/make_golden8.py):
+    real transform coefficients, the context-evolved table of each call, intra scans, every size; one batch"""
+    from goldutil import encoder_rdoq_calls
+    cases = list(encoder_rdoq_calls())
+    jobs = np.zeros(len(cases), hp.RDOQ_JOB_DTYPE)
+    off = 0
+    for i, c in enumerate(cases):
+        j = jobs[i]
+        j["log2_size"], j["comp"], j["is_intra"], j["scan_idx"], j["tr_depth"] = c["log2"], c["comp"], c["intra"], c["scan"], c["tr"]
+        j["qp_scaled"], j["bit_depth"], j["sign_hide"], j["lambda"], j["coeff_offset"], j["estbits_index"] = c["qp"], c["bd"], c["sh"], c["lam"], off, i
+        off += len(c["src"])
+    ctx = hp.Context(64, 64)
+    dst, asum = ctx.rdoq(jobs, np.stack([c["eb"] for c in cases]), np.concatenate([c["src"] for c in cases]))
+    off = 0
+    for i, c in enumerate(cases):
+        n = len(c["src"])
+        assert int(asum[i]) == c["asum"] and np.array_equal(dst[off:off + n], c["out"]), (i, c["log2"], c["comp"], c["intra"])
+        off += n
+    ctx.close()
+
+
 def test_coeff_bits_golden(hp):
     """CABAC bit estimator: k_coeff_bits (one lane per TU) against the reference-generated chains: every TU of a chain starts
     from the context states the previous one left (fed back through ctx_out), bits and final states must match"""

@@ -28,3 +28,20 @@ def test_me_chain_on_encoder_calls():
         assert got[9:25] == want_gt, (m[:20], got[9:25], want_gt)
         shapes.add((w, h)); n += 1
     assert n >= 90 and len(shapes) == 20
+
+
+def test_rdoq_on_encoder_calls():
+    """350 xRateDistOptQuant calls of the same encode (tests/golden/encoder_rdoq_calls.npz), each with the table estBit had written
+    from the contexts as they stood: restatement against what the call returned inside the encoder"""
+    from goldutil import encoder_rdoq_calls
+    O = oracle()
+    O.hop_o_rdoq.restype = ctypes.c_int
+    O.hop_o_rdoq.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    n = 0
+    for c in encoder_rdoq_calls():
+        d = np.zeros(len(c["src"]), np.int32); a = ctypes.c_uint32(c["as_in"])
+        assert O.hop_o_rdoq(c["src"].ctypes.data, d.ctypes.data, c["log2"], c["comp"], c["intra"], c["scan"], c["tr"], c["qp"], c["bd"], c["sh"],
+                            c["lam"], c["eb"].ctypes.data, ctypes.byref(a)) == 0
+        assert a.value == c["asum"] and np.array_equal(d, c["out"]), (n, c["log2"], c["comp"], c["intra"])
+        n += 1
+    assert n == 350

@@ -320,3 +320,65 @@ UInt TComRdCost::getDistPart(Int bitDepth, Pel* piCur, Int iCurStride, Pel* piOr
   if (eText == TEXT_CHROMA_V) return (UInt)((Int)(m_crDistortionWeight * d));
   return d;
 }
+
+// ---- a9 transform skip, a13 SS-reference upkeep ----
+//   TComTrQuant::xTransformSkip / xITransformSkip  TLibCommon/TComTrQuant.cpp:1402-1460  -> hop_o_transform_skip / hop_o_inv_transform_skip
+//   TEncCu::xCopyYuv2SSRef                         TLibEncoder/TEncCu.cpp:1677-1715      -> hop_o_ssref_commit_cu (= hop_ssref_commit_cus) at the leaf
+#define private public
+#define protected public
+#include "TLibEncoder/TEncCu.h"
+#undef private
+#undef protected
+namespace { unsigned long g_calls5[3] = { 0, 0, 0 };
+struct Report5 { ~Report5() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: tskip %lu itskip %lu commit %lu\n", g_calls5[0], g_calls5[1], g_calls5[2]); } } g_report5; }
+
+Void TComTrQuant::xTransformSkip(Int bitDepth, Pel* piBlkResi, UInt uiStride, Int* psCoeff, Int width, Int height)
+{
+  g_calls5[0]++;
+  int16_t blk[32 * 32];
+  for (int j = 0; j < height; j++) memcpy(blk + j * width, piBlkResi + j * uiStride, width * sizeof(int16_t));
+  hop_o_transform_skip(bitDepth, blk, psCoeff, width);
+}
+
+Void TComTrQuant::xITransformSkip(Int bitDepth, Int* plCoef, Pel* pResidual, UInt uiStride, Int width, Int height)
+{
+  g_calls5[1]++;
+  int16_t blk[32 * 32];
+  hop_o_inv_transform_skip(bitDepth, plCoef, blk, width);
+  for (int j = 0; j < height; j++) memcpy(pResidual + j * uiStride, blk + j * width, width * sizeof(int16_t));
+}
+
+Void TEncCu::xCopyYuv2SSRef(TComPic* rpcPic, UInt uiCUAddr, UInt uiAbsPartIdx, UInt uiDepth, UInt uiSrcDepth, TComDataCU* pcCU, UInt uiLPelX, UInt uiTPelY)
+{
+  // the quadtree walk down to blocks that lie inside the picture and the slice segment is the caller's logic, kept as it is;
+  // the leaf -- block copy + re-extension of every border -- is the ABI call
+  const UInt size = g_uiMaxCUWidth >> uiDepth, nParts = pcCU->getPic()->getNumPartInCU(), span = nParts >> (uiDepth << 1);
+  TComSlice* slice = pcCU->getPic()->getSlice(pcCU->getPic()->getCurrSliceIdx());
+  const UInt first = rpcPic->getPicSym()->getInverseCUOrderMap(pcCU->getAddr()) * nParts + uiAbsPartIdx;
+  const UInt segStart = slice->getSliceSegmentCurStartCUAddr(), segEnd = slice->getSliceSegmentCurEndCUAddr();
+  const bool cutByStart = segStart > first && segStart < first + span, cutByEnd = segEnd > first && segEnd < first + span;
+  const UInt picW = slice->getSPS()->getPicWidthInLumaSamples(), picH = slice->getSPS()->getPicHeightInLumaSamples();
+  if (!cutByStart && !cutByEnd && uiLPelX + size - 1 < picW && uiTPelY + size - 1 < picH) {
+    g_calls5[2]++;
+    TComYuv* src = m_ppcRecoYuvBest[uiSrcDepth];
+    const UInt srcSize = g_uiMaxCUWidth >> uiSrcDepth;
+    const UInt raster = g_auiZscanToRaster[uiAbsPartIdx], perRow = rpcPic->getNumPartInWidth();
+    const UInt bx = ((raster % perRow) * 4) % srcSize, by = ((raster / perRow) * 4) % srcSize;       // the block inside the source CU, in samples (4-sample partitions)
+    std::vector<int16_t> y(size * size), cb(size * size / 4), cr(size * size / 4);
+    for (UInt r = 0; r < size; r++) memcpy(&y[r * size], src->getLumaAddr() + (by + r) * src->getStride() + bx, size * sizeof(int16_t));
+    for (UInt r = 0; r < size / 2; r++) {
+      memcpy(&cb[r * (size / 2)], src->getCbAddr() + (by / 2 + r) * src->getCStride() + bx / 2, (size / 2) * sizeof(int16_t));
+      memcpy(&cr[r * (size / 2)], src->getCrAddr() + (by / 2 + r) * src->getCStride() + bx / 2, (size / 2) * sizeof(int16_t));
+    }
+    TComPicYuv* rec = rpcPic->getPicYuvRec();
+    hop_o_ssref_commit_cu(rec->getLumaAddr(), rec->getCbAddr(), rec->getCrAddr(), rec->getWidth(), rec->getHeight(), (int)uiLPelX, (int)uiTPelY, (int)size, &y[0], &cb[0], &cr[0]);
+    rec->setBorderExtension(true);                                     // the state the reference's extendPicBorder leaves
+    return;
+  }
+  const UInt quarter = span >> 2;
+  for (UInt q = 0; q < 4; q++) {
+    const UInt idx = uiAbsPartIdx + q * quarter, x = uiLPelX + (size >> 1) * (q & 1), y = uiTPelY + (size >> 1) * (q >> 1);
+    const UInt at = rpcPic->getPicSym()->getInverseCUOrderMap(pcCU->getAddr()) * nParts + idx;
+    if (at + quarter > segStart && at < segEnd && x < picW && y < picH) xCopyYuv2SSRef(rpcPic, uiCUAddr, idx, uiDepth + 1, uiSrcDepth, pcCU, x, y);
+  }
+}

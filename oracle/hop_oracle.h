@@ -46,6 +46,8 @@ void hop_o_intra_rough(const int16_t* rec, int recStride, const int16_t* org, in
 /* ---- a9 / a10 (hop_oracle_tq.c) ---- */
 void hop_o_fwd_transform(int bitDepth, const int16_t* block, int16_t* coeff, int N, int useDst);
 void hop_o_inv_transform(int bitDepth, const int16_t* coeff, int16_t* block, int N, int useDst);
+void hop_o_transform_skip(int bitDepth, const int16_t* resi, int32_t* coef, int N);
+void hop_o_inv_transform_skip(int bitDepth, const int32_t* coef, int16_t* resi, int N);
 uint32_t hop_o_quant_flat(int bitDepth, int qpScaled, int isISlice, const int32_t* coef, int32_t* level, int N);
 void hop_o_dequant_flat(int bitDepth, int qpScaled, const int32_t* level, int32_t* coef, int N);
 /* ---- a11: rate-distortion optimised quantisation (hop_oracle_rdoq.c) ---- */

@@ -382,3 +382,81 @@ Void TEncCu::xCopyYuv2SSRef(TComPic* rpcPic, UInt uiCUAddr, UInt uiAbsPartIdx, U
     if (at + quarter > segStart && at < segEnd && x < picW && y < picH) xCopyYuv2SSRef(rpcPic, uiCUAddr, idx, uiDepth + 1, uiSrcDepth, pcCU, x, y);
   }
 }
+
+// ---- row a8b: the residual quadtree search of an SS/GT CU ----
+//   TEncSearch::xEstimateResidualQT  TLibEncoder/TEncSearch.cpp:6824-7560 (+ xEncodeResidualQT :7562-7655)  -> hop_o_rqt
+// The top-level call (from encodeResAndCalcRdInterCU, :6700) hands over the CU's residual, the quantiser / lambda / weight set and
+// the coder state; the restatement walks the whole tree and leaves what the reference's function leaves: transform depth, cbf and
+// transform-skip arrays of the CU, the per-layer coefficient and residual buffers xSetResidualQTData reads, the coder state.
+namespace { unsigned long g_calls6[1] = { 0 };
+struct Report6 { ~Report6() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: rqt %lu\n", g_calls6[0]); } } g_report6;
+struct SbacSets { ContextModel* p[10]; int n[10]; };
+SbacSets sbac_sets(TEncSbac* s) {
+  SbacSets r = { { s->m_cCUQtCbfSCModel.get(0), s->m_cCUTransSubdivFlagSCModel.get(0), s->m_cCUQtRootCbfSCModel.get(0), s->m_cCUSigCoeffGroupSCModel.get(0), s->m_cCUSigSCModel.get(0),
+                   s->m_cCuCtxLastX.get(0), s->m_cCuCtxLastY.get(0), s->m_cCUOneSCModel.get(0), s->m_cCUAbsSCModel.get(0), s->m_cTransformSkipSCModel.get(0) },
+                 { 8, 3, 1, 4, 42, 30, 30, 24, 6, 2 } };
+  return r;
+}
+void coder_get(TEncSbac* s, hop_o_coder* c) {
+  SbacSets r = sbac_sets(s); uint8_t* d = (uint8_t*)&c->ctx;
+  for (int i = 0; i < 10; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState;
+  c->frac = s->m_pcBinIf->getTEncBinCABAC()->m_fracBits;
+}
+void coder_put(TEncSbac* s, const hop_o_coder* c) {
+  SbacSets r = sbac_sets(s); const uint8_t* d = (const uint8_t*)&c->ctx;
+  for (int i = 0; i < 10; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++;
+  s->m_pcBinIf->getTEncBinCABAC()->m_fracBits = c->frac;
+}
+}
+
+Void TEncSearch::xEstimateResidualQT(TComDataCU* pcCU, UInt uiQuadrant, UInt uiAbsPartIdx, UInt absTUPartIdx, TComYuv* pcResi, const UInt uiDepth,
+                                     Double& rdCost, UInt& ruiBits, UInt& ruiDist, UInt* puiZeroDist)
+{
+  if (uiAbsPartIdx != 0 || uiDepth != pcCU->getDepth(0)) { fprintf(stderr, "hop shim: xEstimateResidualQT is replaced at the CU level only\n"); abort(); }
+  g_calls6[0]++;
+  TComSlice* sl = pcCU->getSlice();
+  hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
+  cfg.log2_cu = g_aucConvertToBit[sl->getSPS()->getMaxCUWidth() >> uiDepth] + 2;
+  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_LUMA, sl->getSPS()->getQpBDOffsetY(), 0); cfg.qp[0] = m_pcTrQuant->m_cQP.m_iQP;
+  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_CHROMA, sl->getSPS()->getQpBDOffsetC(), sl->getPPS()->getChromaCbQpOffset() + sl->getSliceQpDeltaCb()); cfg.qp[1] = m_pcTrQuant->m_cQP.m_iQP;
+  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_CHROMA, sl->getSPS()->getQpBDOffsetC(), sl->getPPS()->getChromaCrQpOffset() + sl->getSliceQpDeltaCr()); cfg.qp[2] = m_pcTrQuant->m_cQP.m_iQP;
+  cfg.bit_depth_y = g_bitDepthY; cfg.bit_depth_c = g_bitDepthC;
+  cfg.sign_hide = sl->getPPS()->getSignHideFlag() ? 1 : 0;
+  cfg.use_ts = (sl->getPPS()->getUseTransformSkip() && !pcCU->isLosslessCoded(0)) ? 1 : 0;
+  if (!m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->isLosslessCoded(0)) { fprintf(stderr, "hop shim: the residual quadtree is replaced for RDOQ + RDOQTS, lossy coding\n"); abort(); }
+  cfg.log2_max_tu = sl->getSPS()->getQuadtreeTULog2MaxSize(); cfg.log2_min_tu_in_cu = pcCU->getQuadtreeTULog2MinSizeInCU(0);
+  cfg.inter_split_flag = (sl->getSPS()->getQuadtreeTUMaxDepthInter() == 1 && pcCU->getPredictionMode(0) == MODE_INTER && pcCU->getPartitionSize(0) != SIZE_2Nx2N) ? 1 : 0;
+  cfg.lambda_rd = m_pcRdCost->m_dLambda;
+  for (int c = 0; c < 3; c++) cfg.lambda_rdoq[c] = m_pcTrQuant->m_lambdas[c];
+  cfg.dist_weight[0] = 1.0; cfg.dist_weight[1] = m_pcRdCost->m_cbDistortionWeight; cfg.dist_weight[2] = m_pcRdCost->m_crDistortionWeight;
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  std::vector<int16_t> planes[4][3];
+  for (int l = 0; l < 4; l++) {
+    st.coef[l][0] = m_ppcQTTempCoeffY[l]; st.coef[l][1] = m_ppcQTTempCoeffCb[l]; st.coef[l][2] = m_ppcQTTempCoeffCr[l];   // the reference's own layer buffers, same layout
+    for (int c = 0; c < 3; c++) { planes[l][c].assign(c ? cu * cu / 4 : cu * cu, 0); st.resi[l][c] = &planes[l][c][0]; }
+  }
+  // what the arrays hold on entry is part of the function's input where it is not overwritten (a 64x64 CU never writes depth 0)
+  memcpy(st.tr_idx, pcCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], pcCU->m_puhCbf[c], parts); memcpy(st.tskip[c], pcCU->m_puhTransformSkip[c], parts); }
+  for (int l = 0; l < 4; l++) {                                      // and so do the residual layers
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int y = 0; y < cu; y++) memcpy(st.resi[l][0] + y * cu, t.getLumaAddr() + y * t.getStride(), cu * sizeof(Pel));
+    for (int y = 0; y < cu / 2; y++) { memcpy(st.resi[l][1] + y * (cu / 2), t.getCbAddr() + y * t.getCStride(), (cu / 2) * sizeof(Pel));
+                                       memcpy(st.resi[l][2] + y * (cu / 2), t.getCrAddr() + y * t.getCStride(), (cu / 2) * sizeof(Pel)); }
+  }
+  hop_o_coder coder; coder_get(m_pcRDGoOnSbacCoder, &coder);
+  m_pcRDGoOnSbacCoder->store(m_pppcRDSbacCoder[uiDepth][CI_QT_TRAFO_ROOT]);
+  double cost = 0; uint32_t bits = 0, dist = 0, zd = 0;
+  hop_o_rqt(&cfg, pcResi->getLumaAddr(), pcResi->getStride(), pcResi->getCbAddr(), pcResi->getCrAddr(), pcResi->getCStride(), &coder, &st, &cost, &bits, &dist, &zd);
+  rdCost += cost; ruiBits += bits; ruiDist += dist; if (puiZeroDist) *puiZeroDist += zd;
+  memcpy(pcCU->m_puhTrIdx, st.tr_idx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(pcCU->m_puhCbf[c], st.cbf[c], parts); memcpy(pcCU->m_puhTransformSkip[c], st.tskip[c], parts); }
+  for (int l = 0; l < 4; l++) {
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int y = 0; y < cu; y++) memcpy(t.getLumaAddr() + y * t.getStride(), st.resi[l][0] + y * cu, cu * sizeof(Pel));
+    for (int y = 0; y < cu / 2; y++) { memcpy(t.getCbAddr() + y * t.getCStride(), st.resi[l][1] + y * (cu / 2), (cu / 2) * sizeof(Pel));
+                                       memcpy(t.getCrAddr() + y * t.getCStride(), st.resi[l][2] + y * (cu / 2), (cu / 2) * sizeof(Pel)); }
+  }
+  coder_put(m_pcRDGoOnSbacCoder, &coder);
+}

@@ -83,6 +83,26 @@ void hop_o_cabac_est_bits(const hop_o_cabac_ctx* c, int width, int comp, hop_o_e
 uint64_t hop_o_cabac_coeff_bits(hop_o_cabac_ctx* c, const int32_t* coef, int log2_size, int comp, int scan_idx, int sign_hide, int use_ts, int ts_flag);
 uint64_t hop_o_cabac_cbf_bits(hop_o_cabac_ctx* c, int comp, int tr_depth, int cbf);
 uint64_t hop_o_cabac_root_cbf_bits(hop_o_cabac_ctx* c, int cbf);
+uint64_t hop_o_cabac_subdiv_bits(hop_o_cabac_ctx* c, int ctx, int flag);
+double hop_o_calc_rd_cost(uint32_t bits, uint32_t dist, double lambda);
+/* ---- a8b: the residual quadtree of one SS/GT ("inter") CU (hop_oracle_rqt.c) ---- */
+typedef struct { hop_o_cabac_ctx ctx; uint64_t frac; } hop_o_coder;   /* TEncSbac contexts + TEncBinCABACCounter::m_fracBits */
+typedef struct {
+  int log2_cu;                      /* 3..6 */
+  int qp[3];                        /* what setQPforQuant hands to setQpParam for Y, Cb, Cr */
+  int bit_depth_y, bit_depth_c;
+  int sign_hide, use_ts;            /* PPS sign_data_hiding, transform_skip_enabled (RDOQTS on) */
+  int log2_max_tu, log2_min_tu_in_cu;
+  int inter_split_flag;             /* QuadtreeTUMaxDepthInter == 1 && partition != 2Nx2N (TEncSearch.cpp:6831) */
+  double lambda_rd, lambda_rdoq[3], dist_weight[3];
+} hop_o_rqt_cfg;
+typedef struct {                    /* everything the caller reads afterwards; partitions = 4x4 units of the CU in z-order */
+  uint8_t tr_idx[256], cbf[3][256], tskip[3][256];
+  int32_t* coef[4][3];              /* [layer = log2_max_tu - log2 size][comp]: TU of partition p at 16*p (chroma (16*p)>>2), N x N raster */
+  int16_t* resi[4][3];              /* [layer][comp]: reconstructed residual planes of the CU (pitch = CU size, chroma half) */
+} hop_o_rqt_state;
+void hop_o_rqt(const hop_o_rqt_cfg* cfg, const int16_t* resiY, int strideY, const int16_t* resiCb, const int16_t* resiCr, int strideC,
+               hop_o_coder* coder, hop_o_rqt_state* st, double* cost, uint32_t* bits, uint32_t* dist, uint32_t* zero_dist);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,
                 double lambda_rdoq, double lambda_rd, double dist_weight, const hop_o_cabac_ctx* snap, uint32_t frac_left,
                 int32_t* levels, uint32_t* out, double* cost);

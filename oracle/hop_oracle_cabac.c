@@ -306,6 +306,13 @@ uint64_t hop_o_cabac_cbf_bits(hop_o_cabac_ctx* c, int comp, int tr_depth, int cb
   BIN(&c->qt_cbf[4 * chroma + ctx], cbf ? 1 : 0);
   return frac;
 }
+/* TEncSbac::codeTransformSubdivFlag (TEncSbac.cpp:756-759): context = 5 - log2 of the transform size */
+uint64_t hop_o_cabac_subdiv_bits(hop_o_cabac_ctx* c, int ctx, int flag)
+{
+  uint64_t frac = 0;
+  BIN(&c->trans_subdiv[ctx], flag ? 1 : 0);
+  return frac;
+}
 uint64_t hop_o_cabac_root_cbf_bits(hop_o_cabac_ctx* c, int cbf)
 {
   uint64_t frac = 0;
@@ -328,6 +335,7 @@ static double calc_rd_cost(uint32_t bits, uint32_t dist, double lambda)
   double c = ((double)dist + (double)((int)(bits * lambda + .5)));
   return (double)(uint32_t)floor(c);
 }
+double hop_o_calc_rd_cost(uint32_t bits, uint32_t dist, double lambda) { return calc_rd_cost(bits, dist, lambda); }
 static uint32_t weighted(uint32_t sse, int comp, double w) { return comp ? (uint32_t)(int)(w * sse) : sse; }
 
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

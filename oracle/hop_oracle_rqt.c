@@ -1,0 +1,269 @@
+/* hop_oracle_rqt.c -- CPU restatement of the residual quadtree search of one SS/GT ("inter") CU.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Follows TEncSearch::xEstimateResidualQT (TLibEncoder/TEncSearch.cpp:6824-7560) with xEncodeResidualQT (:7562-7655):
+ * per node the full-block evaluation of Y, Cb, Cr (estBit, transformNxN = xT + xRateDistOptQuant, bits of cbf flag + levels
+ * counted from the node's entry state, inverse path, cbf-zero decision :6959-7200), the 4x4 transform-skip retry
+ * (:7210-7440), the node's own bits (:7443-7466), the four children evaluated one after the other on the coder state the
+ * previous one left (:7480-7485), the recount of the whole subtree in syntax order (:7503-7511) and the split decision
+ * (:7514-7522).  Costs are TComRdCost::calcRdCost values; bit counts are the counting coder's integer bits, fraction carried
+ * as the reference's TEncBinCABAC::resetBits does.
+ *
+ * Pinned in the loop: oracle/enc_shim.cpp puts this function in place of the reference's xEstimateResidualQT inside the
+ * reference encoder, which must then write the unmodified encoder's bitstream (tests/test_encoder_shim.py). */
+#include <stdlib.h>
+#include <string.h>
+#include "hop_oracle.h"
+
+typedef struct {
+  const hop_o_rqt_cfg* cfg;
+  const int16_t* resi[3]; int stride[3];
+  hop_o_coder* cur;                 /* m_pcRDGoOnSbacCoder */
+  hop_o_coder root[4], test[4];     /* m_pppcRDSbacCoder[depth][CI_QT_TRAFO_ROOT / _TEST], by transform depth */
+  hop_o_rqt_state* st;
+  int parts;                        /* 4x4 partitions in the CU */
+} Rqt;
+
+static int zx(int p) { int x = 0; for (int b = 0; b < 4; b++) x |= ((p >> (2 * b)) & 1) << b; return 4 * x; }       /* partition -> luma position in the CU */
+static int zy(int p) { int y = 0; for (int b = 0; b < 4; b++) y |= ((p >> (2 * b + 1)) & 1) << b; return 4 * y; }
+static void reset_bits(hop_o_coder* c) { c->frac &= 32767; }                       /* TEncBinCABAC::resetBits keeps the fraction */
+static uint32_t written(const hop_o_coder* c) { return (uint32_t)(c->frac >> 15); }
+static void set_parts(uint8_t* a, int first, int count, int v) { memset(a + first, v, (size_t)count); }
+static int bit_depth(const Rqt* r, int comp) { return comp ? r->cfg->bit_depth_c : r->cfg->bit_depth_y; }
+static uint32_t weighted(const Rqt* r, int comp, uint32_t sse) { return comp ? (uint32_t)(int)(r->cfg->dist_weight[comp] * sse) : sse; }
+
+/* encodeQtCbf + encodeCoeffNxN of one component TU on the current coder (:6959-6962) */
+static void code_cbf_and_coeff(Rqt* r, int comp, int trMode, int part, const int32_t* coef, int log2)
+{
+  hop_o_coder* c = r->cur;
+  c->frac += hop_o_cabac_cbf_bits(&c->ctx, comp, trMode, (r->st->cbf[comp][part] >> trMode) & 1);
+  c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef, log2, comp, 0, r->cfg->sign_hide, r->cfg->use_ts, r->st->tskip[comp][part]);
+}
+
+/* transformNxN (TComTrQuant.cpp:1204-1258) of one component with the tables of the current coder state */
+static uint32_t transform_quant(Rqt* r, int comp, int log2, const int16_t* res, int stride, int trMode, int skip, int32_t* coef)
+{
+  const int N = 1 << log2, bd = bit_depth(r, comp);
+  int16_t blk[32 * 32], c16[32 * 32]; int32_t c32[32 * 32];
+  hop_o_estbits eb; memset(&eb, 0, sizeof(eb));
+  hop_o_cabac_est_bits(&r->cur->ctx, N, comp ? 1 : 0, &eb);
+  for (int y = 0; y < N; y++) memcpy(blk + y * N, res + y * stride, (size_t)N * sizeof(int16_t));
+  if (skip) hop_o_transform_skip(bd, blk, c32, N);
+  else { hop_o_fwd_transform(bd, blk, c16, N, 0); for (int i = 0; i < N * N; i++) c32[i] = c16[i]; }
+  uint32_t absSum = 0;
+  memset(coef, 0, sizeof(int32_t) * (size_t)(N * N));
+  hop_o_rdoq(c32, coef, log2, comp, 0, 0, trMode, r->cfg->qp[comp], bd, r->cfg->sign_hide, r->cfg->lambda_rdoq[comp], &eb, &absSum);
+  return absSum;
+}
+
+/* invtransformNxN (:1260-1310) into the layer's residual plane; returns the distortion against the residual */
+static uint32_t inverse_and_dist(Rqt* r, int comp, int log2, const int32_t* coef, int skip, int16_t* out, int ostride, const int16_t* res, int stride)
+{
+  const int N = 1 << log2, bd = bit_depth(r, comp);
+  int32_t dq[32 * 32]; int16_t c16[32 * 32], blk[32 * 32];
+  hop_o_dequant_flat(bd, r->cfg->qp[comp], coef, dq, N);
+  if (skip) hop_o_inv_transform_skip(bd, dq, blk, N);
+  else { for (int i = 0; i < N * N; i++) c16[i] = (int16_t)dq[i]; hop_o_inv_transform(bd, c16, blk, N, 0); }
+  for (int y = 0; y < N; y++) memcpy(out + y * ostride, blk + y * N, (size_t)N * sizeof(int16_t));
+  return weighted(r, comp, hop_o_sse(out, ostride, res, stride, N, N, bd));
+}
+
+static void encode_tree(Rqt* r, int part, int trMode, int log2, int subdivAndCbf, int comp);
+
+static void node(Rqt* r, int part, int trMode, int log2, double* rdCost, uint32_t* ruiBits, uint32_t* ruiDist, uint32_t* zeroDist)
+{
+  const hop_o_rqt_cfg* g = r->cfg; hop_o_rqt_state* st = r->st;
+  const int nparts = r->parts >> (2 * trMode);                       /* partitions of this node */
+  int checkFull = (g->inter_split_flag && trMode == 0 && log2 > g->log2_min_tu_in_cu) ? 0 : (log2 <= g->log2_max_tu);
+  const int checkSplit = log2 > g->log2_min_tu_in_cu;
+  int codeChroma = 1, trModeC = trMode, log2C = log2 - 1;
+  if (log2 == 2) { log2C++; trModeC--; codeChroma = (part % (r->parts >> (2 * trModeC))) == 0; }
+  const int npartsC = r->parts >> (2 * trModeC);
+  const int setCbf = 1 << trMode;
+  double singleCost = 1.7e+308; uint32_t singleBits = 0, singleDist = 0;
+  uint32_t absSum[3] = { 0, 0, 0 }; int bestSkip[3] = { 0, 0, 0 };
+  r->root[trMode] = *r->cur;
+  const int px = zx(part), py = zy(part);
+  const int layer = g->log2_max_tu - log2, cu = 1 << g->log2_cu;
+
+  if (checkFull) {
+    int32_t* coef[3] = { st->coef[layer][0] + 16 * part, st->coef[layer][1] + ((16 * part) >> 2), st->coef[layer][2] + ((16 * part) >> 2) };
+    const int lg[3] = { log2, log2C, log2C };
+    const int16_t* res[3] = { r->resi[0] + py * r->stride[0] + px, r->resi[1] + (py >> 1) * r->stride[1] + (px >> 1), r->resi[2] + (py >> 1) * r->stride[2] + (px >> 1) };
+    int16_t* rec[3] = { st->resi[layer][0] + py * cu + px, st->resi[layer][1] + (py >> 1) * (cu >> 1) + (px >> 1), st->resi[layer][2] + (py >> 1) * (cu >> 1) + (px >> 1) };
+    const int rs[3] = { cu, cu >> 1, cu >> 1 };
+    const int ncomp = codeChroma ? 3 : 1;
+    set_parts(st->tr_idx, part, nparts, trMode);
+    double minCost[3] = { 1.7e+308, 1.7e+308, 1.7e+308 };
+    const int checkSkip[3] = { g->use_ts && log2 == 2, g->use_ts && log2C == 2, g->use_ts && log2C == 2 };
+    set_parts(st->tskip[0], part, nparts, 0);
+    if (codeChroma) { set_parts(st->tskip[1], part, npartsC, 0); set_parts(st->tskip[2], part, npartsC, 0); }
+    /* transforms + quantisation: the coder stands at the entry state for all three (:6901-6952) */
+    for (int c = 0; c < ncomp; c++) absSum[c] = transform_quant(r, c, lg[c], res[c], r->stride[c], trMode, 0, coef[c]);
+    set_parts(st->cbf[0], part, nparts, absSum[0] ? setCbf : 0);
+    if (codeChroma) { set_parts(st->cbf[1], part, npartsC, absSum[1] ? setCbf : 0); set_parts(st->cbf[2], part, npartsC, absSum[2] ? setCbf : 0); }
+    /* bits of each component from the entry state (:6957-6977) */
+    uint32_t sBits[3] = { 0, 0, 0 };
+    for (int c = 0; c < ncomp; c++) {
+      if (c) *r->cur = r->root[trMode];
+      reset_bits(r->cur);
+      code_cbf_and_coeff(r, c, trMode, part, coef[c], lg[c]);
+      sBits[c] = written(r->cur);
+    }
+    uint32_t distC[3] = { 0, 0, 0 };
+    int16_t zero[32 * 32]; memset(zero, 0, sizeof(zero));
+    for (int c = 0; c < ncomp; c++) {
+      const int N = 1 << lg[c];
+      distC[c] = weighted(r, c, hop_o_sse(zero, N, res[c], r->stride[c], N, N, bit_depth(r, c)));
+      if (zeroDist) *zeroDist += distC[c];
+      if (absSum[c]) {
+        const uint32_t nz = inverse_and_dist(r, c, lg[c], coef[c], 0, rec[c], rs[c], res[c], r->stride[c]);
+        const double sc = hop_o_calc_rd_cost(sBits[c], nz, g->lambda_rd);
+        *r->cur = r->root[trMode]; reset_bits(r->cur);
+        r->cur->frac += hop_o_cabac_cbf_bits(&r->cur->ctx, c, trMode, 0);
+        const double nc = hop_o_calc_rd_cost(written(r->cur), distC[c], g->lambda_rd);
+        if (nc < sc) { absSum[c] = 0; memset(coef[c], 0, sizeof(int32_t) * (size_t)(N * N)); if (checkSkip[c]) minCost[c] = nc; }
+        else { distC[c] = nz; if (checkSkip[c]) minCost[c] = sc; }
+      } else if (checkSkip[c]) {
+        *r->cur = r->root[trMode]; reset_bits(r->cur);
+        r->cur->frac += hop_o_cabac_cbf_bits(&r->cur->ctx, c, trMode, 0);
+        minCost[c] = hop_o_calc_rd_cost(written(r->cur), distC[c], g->lambda_rd);
+      }
+      if (!absSum[c]) for (int y = 0; y < N; y++) memset(rec[c] + y * rs[c], 0, (size_t)N * sizeof(int16_t));
+    }
+    set_parts(st->cbf[0], part, nparts, absSum[0] ? setCbf : 0);
+    if (codeChroma) { set_parts(st->cbf[1], part, npartsC, absSum[1] ? setCbf : 0); set_parts(st->cbf[2], part, npartsC, absSum[2] ? setCbf : 0); }
+
+    /* transform-skip retry, luma (:7210-7292) */
+    if (checkSkip[0]) {
+      int32_t best[16]; int16_t bestRes[16];
+      memcpy(best, coef[0], sizeof(best));
+      for (int y = 0; y < 4; y++) memcpy(bestRes + 4 * y, rec[0] + y * rs[0], 8);
+      *r->cur = r->root[trMode];
+      set_parts(st->tskip[0], part, nparts, 1);
+      const uint32_t as = transform_quant(r, 0, 2, res[0], r->stride[0], trMode, 1, coef[0]);
+      set_parts(st->cbf[0], part, nparts, as ? setCbf : 0);
+      uint32_t nz = 0; double sc = 0;
+      if (as) {
+        reset_bits(r->cur);
+        code_cbf_and_coeff(r, 0, trMode, part, coef[0], 2);
+        const uint32_t b = written(r->cur);
+        nz = inverse_and_dist(r, 0, 2, coef[0], 1, rec[0], rs[0], res[0], r->stride[0]);
+        sc = hop_o_calc_rd_cost(b, nz, g->lambda_rd);
+      }
+      if (!as || minCost[0] < sc) {
+        set_parts(st->tskip[0], part, nparts, 0);
+        memcpy(coef[0], best, sizeof(best));
+        for (int y = 0; y < 4; y++) memcpy(rec[0] + y * rs[0], bestRes + 4 * y, 8);
+      } else { distC[0] = nz; absSum[0] = as; bestSkip[0] = 1; }
+      set_parts(st->cbf[0], part, nparts, absSum[0] ? setCbf : 0);
+    }
+    /* transform-skip retry, chroma (:7294-7437): both planes are transformed first, then each is counted from the entry state */
+    if (codeChroma && checkSkip[1]) {
+      int32_t best[3][16]; int16_t bestRes[3][16]; uint32_t as[3] = { 0, 0, 0 };
+      for (int c = 1; c < 3; c++) { memcpy(best[c], coef[c], sizeof(best[c])); for (int y = 0; y < 4; y++) memcpy(bestRes[c] + 4 * y, rec[c] + y * rs[c], 8); }
+      *r->cur = r->root[trMode];
+      set_parts(st->tskip[1], part, npartsC, 1); set_parts(st->tskip[2], part, npartsC, 1);
+      for (int c = 1; c < 3; c++) as[c] = transform_quant(r, c, 2, res[c], r->stride[c], trMode, 1, coef[c]);
+      set_parts(st->cbf[1], part, npartsC, as[1] ? setCbf : 0); set_parts(st->cbf[2], part, npartsC, as[2] ? setCbf : 0);
+      for (int c = 1; c < 3; c++) {
+        uint32_t nz = 0; double sc = 0;
+        if (as[c]) {
+          if (c == 2) *r->cur = r->root[trMode];
+          reset_bits(r->cur);
+          code_cbf_and_coeff(r, c, trMode, part, coef[c], 2);
+          const uint32_t b = written(r->cur);
+          nz = inverse_and_dist(r, c, 2, coef[c], 1, rec[c], rs[c], res[c], r->stride[c]);
+          sc = hop_o_calc_rd_cost(b, nz, g->lambda_rd);
+        }
+        if (!as[c] || minCost[c] < sc) {
+          set_parts(st->tskip[c], part, npartsC, 0);
+          memcpy(coef[c], best[c], sizeof(best[c]));
+          for (int y = 0; y < 4; y++) memcpy(rec[c] + y * rs[c], bestRes[c] + 4 * y, 8);
+        } else { distC[c] = nz; absSum[c] = as[c]; bestSkip[c] = 1; }
+      }
+      set_parts(st->cbf[1], part, npartsC, absSum[1] ? setCbf : 0); set_parts(st->cbf[2], part, npartsC, absSum[2] ? setCbf : 0);
+    }
+
+    /* the node coded as one TU, from the entry state (:7439-7466) */
+    *r->cur = r->root[trMode]; reset_bits(r->cur);
+    hop_o_coder* c = r->cur;
+    if (log2 > g->log2_min_tu_in_cu) c->frac += hop_o_cabac_subdiv_bits(&c->ctx, 5 - log2, 0);
+    if (codeChroma) {
+      c->frac += hop_o_cabac_cbf_bits(&c->ctx, 1, trMode, (st->cbf[1][part] >> trMode) & 1);
+      c->frac += hop_o_cabac_cbf_bits(&c->ctx, 2, trMode, (st->cbf[2][part] >> trMode) & 1);
+    }
+    c->frac += hop_o_cabac_cbf_bits(&c->ctx, 0, trMode, (st->cbf[0][part] >> trMode) & 1);
+    for (int k = 0; k < ncomp; k++)
+      c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef[k], lg[k], k, 0, g->sign_hide, g->use_ts, st->tskip[k][part]);
+    singleBits = written(c);
+    singleDist = distC[0] + distC[1] + distC[2];
+    singleCost = hop_o_calc_rd_cost(singleBits, singleDist, g->lambda_rd);
+  }
+
+  if (checkSplit) {
+    if (checkFull) { r->test[trMode] = *r->cur; *r->cur = r->root[trMode]; }
+    uint32_t subDist = 0, subBits = 0; double subCost = 0.0;
+    const int q = nparts >> 2;
+    for (int k = 0; k < 4; k++) node(r, part + k * q, trMode + 1, log2 - 1, &subCost, &subBits, &subDist, checkFull ? NULL : zeroDist);
+    int any[3] = { 0, 0, 0 };
+    for (int c = 0; c < 3; c++) for (int k = 0; k < 4; k++) any[c] |= (st->cbf[c][part + k * q] >> (trMode + 1)) & 1;
+    for (int c = 0; c < 3; c++) for (int k = 0; k < nparts; k++) st->cbf[c][part + k] |= (uint8_t)(any[c] << trMode);
+    *r->cur = r->root[trMode]; reset_bits(r->cur);
+    encode_tree(r, part, trMode, log2, 1, 0);
+    encode_tree(r, part, trMode, log2, 0, 0);
+    encode_tree(r, part, trMode, log2, 0, 1);
+    encode_tree(r, part, trMode, log2, 0, 2);
+    subBits = written(r->cur);
+    subCost = hop_o_calc_rd_cost(subBits, subDist, g->lambda_rd);
+    if (any[0] || any[1] || any[2] || !checkFull) {
+      if (subCost < singleCost) { *rdCost += subCost; *ruiBits += subBits; *ruiDist += subDist; return; }
+    }
+    set_parts(st->tskip[0], part, nparts, bestSkip[0]);
+    if (codeChroma) { set_parts(st->tskip[1], part, npartsC, bestSkip[1]); set_parts(st->tskip[2], part, npartsC, bestSkip[2]); }
+    *r->cur = r->test[trMode];
+  }
+  *rdCost += singleCost; *ruiBits += singleBits; *ruiDist += singleDist;
+  set_parts(st->tr_idx, part, nparts, trMode);
+  set_parts(st->cbf[0], part, nparts, absSum[0] ? setCbf : 0);
+  if (codeChroma) { set_parts(st->cbf[1], part, npartsC, absSum[1] ? setCbf : 0); set_parts(st->cbf[2], part, npartsC, absSum[2] ? setCbf : 0); }
+}
+
+/* xEncodeResidualQT (:7562-7655): the subtree as the arrays describe it, flags first (subdivAndCbf) then one component's levels */
+static void encode_tree(Rqt* r, int part, int curTrMode, int log2, int subdivAndCbf, int comp)
+{
+  const hop_o_rqt_cfg* g = r->cfg; hop_o_rqt_state* st = r->st; hop_o_coder* c = r->cur;
+  const int trMode = st->tr_idx[part], subdiv = curTrMode != trMode;
+  if (subdivAndCbf && log2 <= g->log2_max_tu && log2 > g->log2_min_tu_in_cu) c->frac += hop_o_cabac_subdiv_bits(&c->ctx, 5 - log2, subdiv);
+  if (subdivAndCbf) {
+    const int first = curTrMode == 0;
+    if (first || log2 > 2) {
+      if (first || ((st->cbf[1][part] >> (curTrMode - 1)) & 1)) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 1, curTrMode, (st->cbf[1][part] >> curTrMode) & 1);
+      if (first || ((st->cbf[2][part] >> (curTrMode - 1)) & 1)) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 2, curTrMode, (st->cbf[2][part] >> curTrMode) & 1);
+    }
+  }
+  if (!subdiv) {
+    const int layer = g->log2_max_tu - log2;
+    int codeChroma = 1, trModeC = trMode, log2C = log2 - 1;
+    if (log2 == 2) { log2C++; trModeC--; codeChroma = (part % (r->parts >> (2 * trModeC))) == 0; }
+    if (subdivAndCbf) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 0, trMode, (st->cbf[0][part] >> trMode) & 1);
+    else {
+      if (comp == 0 && ((st->cbf[0][part] >> trMode) & 1))
+        c->frac += hop_o_cabac_coeff_bits(&c->ctx, st->coef[layer][0] + 16 * part, log2, 0, 0, g->sign_hide, g->use_ts, st->tskip[0][part]);
+      if (codeChroma && comp && ((st->cbf[comp][part] >> trMode) & 1))
+        c->frac += hop_o_cabac_coeff_bits(&c->ctx, st->coef[layer][comp] + ((16 * part) >> 2), log2C, comp, 0, g->sign_hide, g->use_ts, st->tskip[comp][part]);
+    }
+  } else if (subdivAndCbf || ((st->cbf[comp][part] >> curTrMode) & 1)) {
+    const int q = (r->parts >> (2 * curTrMode)) >> 2;
+    for (int k = 0; k < 4; k++) encode_tree(r, part + k * q, curTrMode + 1, log2 - 1, subdivAndCbf, comp);
+  }
+}
+
+void hop_o_rqt(const hop_o_rqt_cfg* cfg, const int16_t* resiY, int strideY, const int16_t* resiCb, const int16_t* resiCr, int strideC,
+               hop_o_coder* coder, hop_o_rqt_state* st, double* cost, uint32_t* bits, uint32_t* dist, uint32_t* zero_dist)
+{
+  Rqt r; memset(&r, 0, sizeof(r));
+  r.cfg = cfg; r.resi[0] = resiY; r.resi[1] = resiCb; r.resi[2] = resiCr; r.stride[0] = strideY; r.stride[1] = r.stride[2] = strideC;
+  r.cur = coder; r.st = st; r.parts = 1 << (2 * (cfg->log2_cu - 2));
+  *cost = 0; *bits = 0; *dist = 0; if (zero_dist) *zero_dist = 0;
+  node(&r, 0, 0, cfg->log2_cu, cost, bits, dist, zero_dist);
+}

@@ -581,6 +581,59 @@ int hop_tu_rd_device(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   return hop_launch_tu_rd(c, n, d_jobs, d_ctx_in, d_coef_offsets, n_coeff, d_levels, d_results);
 }
 
+int hop_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_rqt_result* results, int32_t* coef_out, hop_cabac_ctx* ctx_out) {
+  if (!c || n < 0 || (n && (!jobs || !ctx_in || !results || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_rqt: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  std::vector<size_t> coff(n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const hop_rqt_job& j = jobs[i];
+    const int S = 1 << j.log2_cu;
+    bool ok = j.log2_cu >= 3 && j.log2_cu <= 6 && j.x >= 0 && j.y >= 0 && (j.x & (S - 1)) == 0 && (j.y & (S - 1)) == 0 && j.x + S <= c->pic_w && j.y + S <= c->pic_h &&
+              j.ctx_index >= 0 && j.ctx_index < n_ctx && j.log2_max_tu >= 2 && j.log2_max_tu <= 5 && j.log2_min_tu_in_cu >= 2 && j.log2_min_tu_in_cu <= j.log2_max_tu &&
+              j.log2_cu - j.log2_min_tu_in_cu <= 3 && j.log2_cu - j.log2_max_tu <= 1 && j.lambda_rd > 0.0;
+    for (int k = 0; k < 3 && ok; k++) ok = j.qp_scaled[k] >= 0 && j.qp_scaled[k] <= 87 && j.lambda_rdoq[k] > 0.0;
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "RQT job %d: illegal CU / transform-tree limits / snapshot / parameters", i);
+    coff[i + 1] = coff[i] + (size_t)S * S * 3 / 2;
+  }
+  for (int k = 0; k < n_ctx; k++) for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+  // one pass per class of CUs (same size and transform-tree limits): the walk over the tree is the same for all of them
+  std::vector<char> done(n, 0);
+  for (int first = 0; first < n; first++) {
+    if (done[first]) continue;
+    const hop_rqt_job& f = jobs[first];
+    std::vector<int> idx; std::vector<hop_rqt_job> cls;
+    for (int i = first; i < n; i++) {
+      const hop_rqt_job& j = jobs[i];
+      if (!done[i] && j.log2_cu == f.log2_cu && j.log2_max_tu == f.log2_max_tu && j.log2_min_tu_in_cu == f.log2_min_tu_in_cu && !j.inter_split_flag == !f.inter_split_flag &&
+          !j.sign_hide == !f.sign_hide && !j.use_ts == !f.use_ts) { done[i] = 1; idx.push_back(i); cls.push_back(j); }
+    }
+    const int m = (int)idx.size();
+    const size_t cu3 = ((size_t)3 << (2 * f.log2_cu)) / 2;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_j = 0, o_c = al((size_t)m * sizeof(hop_rqt_job)), o_r = al(o_c + (size_t)n_ctx * sizeof(hop_cabac_ctx)), o_o = al(o_r + (size_t)m * sizeof(hop_rqt_result));
+    const size_t o_x = al(o_o + (size_t)m * cu3 * 4), o_w = al(o_x + (size_t)m * sizeof(hop_cabac_ctx)), wb = hop_rqt_work_bytes(f.log2_cu, m);
+    void* st; int r = hop_stage(c, o_w + wb + 256, &st); if (r) return r;
+    char* b = (char*)st;
+    HIPCHK(c, hipMemcpyAsync(b + o_j, cls.data(), (size_t)m * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, (size_t)n_ctx * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
+    r = hop_launch_rqt_class(c, f.log2_cu, f.log2_max_tu, f.log2_min_tu_in_cu, f.inter_split_flag ? 1 : 0, f.sign_hide ? 1 : 0, f.use_ts ? 1 : 0, m, (const hop_rqt_job*)(b + o_j),
+                             (const hop_cabac_ctx*)(b + o_c), (hop_rqt_result*)(b + o_r), (int32_t*)(b + o_o), (hop_cabac_ctx*)(b + o_x), b + o_w, wb);
+    if (r) return r;
+    std::vector<hop_rqt_result> rr(m); std::vector<int32_t> co((size_t)m * cu3); std::vector<hop_cabac_ctx> cx(m);
+    HIPCHK(c, hipMemcpyAsync(rr.data(), b + o_r, (size_t)m * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(co.data(), b + o_o, (size_t)m * cu3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cx.data(), b + o_x, (size_t)m * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < m; t++) {
+      results[idx[t]] = rr[t];
+      if (coef_out) memcpy(coef_out + coff[idx[t]], co.data() + (size_t)t * cu3, cu3 * 4);
+      if (ctx_out) ctx_out[idx[t]] = cx[t];
+    }
+  }
+  return HOP_OK;
+}
+
 int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_tu_rd_result* results, int32_t* levels_out) {
   if (!c || n < 0 || (n && (!jobs || !ctx_in || !results || !levels_out || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_rd: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_rd: hop_upload_orig has not been called");
@@ -593,7 +646,8 @@ int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop
     if (j.comp < 0 || j.comp > 2 || j.log2_size < 2 || j.log2_size > 5 || (j.comp && j.log2_size == 5) || j.x < 0 || j.y < 0 || ((j.x >> sh) & 3) || ((j.y >> sh) & 3) ||
         (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || j.tr_depth < 0 || j.tr_depth > 3 ||
         j.ctx_index < 0 || j.ctx_index >= n_ctx || j.bit_depth != (j.comp ? c->bd_c : c->bd_y) || !(j.lambda_rdoq > 0.0) || !(j.lambda_rd > 0.0) ||
-        j.scan_idx < 0 || j.scan_idx > 2 || (!j.is_intra && (j.scan_idx || j.use_dst)))
+        j.scan_idx < 0 || j.scan_idx > 2 || (!j.is_intra && (j.scan_idx || j.use_dst)) || (j.flags & ~3) ||
+        ((j.flags & HOP_TU_RD_TS) && (j.is_intra || j.log2_size != 2 || !j.use_ts)))
       return hop_set_err(c, HOP_ERR_ARG, "TU RD job %d: illegal transform unit / snapshot / parameters", i);
     offs[i] = (int64_t)tot; tot += (size_t)N * N;
   }

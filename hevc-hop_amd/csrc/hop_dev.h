@@ -135,6 +135,11 @@ int hop_launch_intra_pred(hop_ctx* c, int n, const hop_intra_job* d_jobs, const 
 int hop_launch_rdoq(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum,
                     void* d_work /* hop_rdoq_work_bytes(n) */);
 size_t hop_rdoq_work_bytes(int n);
+int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
+                     int32_t* d_levels, hop_tu_rd_result* d_res);
+size_t hop_rqt_work_bytes(int log2_cu, int n);
+int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
+                         const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_res, int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, void* buf, size_t buf_bytes);
 void hop_rdoq_build_scans(uint16_t* tabs);
 const int32_t* hop_entropy_bits_host(void);
 static inline const int32_t* hop_entropy_bits_device(const hop_ctx* c) { return c->entropy_bits; }

@@ -141,28 +141,19 @@ struct CabacLds { uint8_t st[152][64]; uint16_t absCoeff[16][64]; };
 #define CBIN(idx, b) do { const int i_ = (idx); const uint8_t s_ = sh.st[i_][lane]; const int b_ = (b); frac += (unsigned long long)c_entropy_bits[s_ ^ b_]; \
                           sh.st[i_][lane] = ((s_ & 1) == b_) ? c_next_mps[s_] : c_next_lps[s_]; } while (0)
 
-__global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in,
-                                                   const uint16_t* __restrict__ scans, const int32_t* __restrict__ coef_all,
-                                                   unsigned long long* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out) {
-  __shared__ CabacLds sh;
-  const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
-  const bool live = j < n;
-  const hop_coeff_bits_job jb = jobs[live ? j : 0];
-  {
-    const uint8_t* src = ctx_in[jb.ctx_index].state;
-    for (int i = 0; i < 152; i++) sh.st[i][lane] = src[i];
-  }
+// counted bits of one TU on the lane's context states: the coded_block_flag if asked for (encodeQtCbf), then codeCoeffNxN
+__device__ static unsigned long long cb_code_tu(CabacLds& sh, const int lane, const int32_t* __restrict__ coef, const int log2, const int chroma, const int scan_idx,
+                                                const int sign_hide, const int use_ts, const int ts_flag, const int cbf_ctx_plus1, const uint16_t* __restrict__ scans) {
   unsigned long long frac = 0;
-  const int log2 = jb.log2_size, width = 1 << log2, nco = width * width, chroma = jb.comp != 0, scan_idx = jb.scan_idx;
-  const int32_t* coef = coef_all + jb.coeff_offset;
+  const int width = 1 << log2, nco = width * width;
   const int so = (log2 == 2) ? 0 : (log2 == 3) ? 16 : (log2 == 4) ? 80 : 336, co = (log2 == 2) ? 0 : (log2 == 3) ? 1 : (log2 == 4) ? 5 : 21;
   const uint16_t* scan = scans + scan_idx * 1360 + so;
   const uint16_t* scanCG = scans + 4080 + scan_idx * 85 + co;
   int numSig = 0;
-  if (live) for (int i = 0; i < nco; i++) numSig += coef[i] != 0;
-  if (live && jb.cbf_ctx_plus1) CBIN(CX_QT_CBF + jb.cbf_ctx_plus1 - 1, numSig != 0 ? 1 : 0);      // encodeQtCbf (TEncSbac.cpp:1596-1600)
+  for (int i = 0; i < nco; i++) numSig += coef[i] != 0;
+  if (cbf_ctx_plus1) CBIN(CX_QT_CBF + cbf_ctx_plus1 - 1, numSig != 0 ? 1 : 0);      // encodeQtCbf (TEncSbac.cpp:1596-1600)
   if (numSig != 0) {
-    if (jb.use_ts && width == 4) CBIN(CX_TS + chroma, jb.ts_flag ? 1 : 0);
+    if (use_ts && width == 4) CBIN(CX_TS + chroma, ts_flag ? 1 : 0);
     unsigned long long cgFlag = 0;
     const int numBlkSide = width >> 2;
     int scanPosLast = -1, posLast;
@@ -258,7 +249,7 @@ __global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __r
           else if ((c1 < 3) && (c1 > 0)) c1++;
         }
         if (c1 == 0 && firstC2 != -1) CBIN(CX_ABS + (chroma ? 4 : 0) + ctxSet, sh.absCoeff[firstC2][lane] > 2);
-        if (jb.sign_hide && signHidden) frac += 32768ull * (unsigned long long)(numNonZero - 1);
+        if (sign_hide && signHidden) frac += 32768ull * (unsigned long long)(numNonZero - 1);
         else frac += 32768ull * (unsigned long long)numNonZero;
         int firstCoeff2 = 1;
         if (c1 == 0 || numNonZero > 8) {
@@ -281,6 +272,22 @@ __global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __r
       }
     }
   }
+  return frac;
+}
+
+__global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                   const uint16_t* __restrict__ scans, const int32_t* __restrict__ coef_all,
+                                                   unsigned long long* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
+  const bool live = j < n;
+  const hop_coeff_bits_job jb = jobs[live ? j : 0];
+  {
+    const uint8_t* src = ctx_in[jb.ctx_index].state;
+    for (int i = 0; i < 152; i++) sh.st[i][lane] = src[i];
+  }
+  const unsigned long long frac = live ? cb_code_tu(sh, lane, coef_all + jb.coeff_offset, jb.log2_size, jb.comp != 0, jb.scan_idx, jb.sign_hide, jb.use_ts, jb.ts_flag,
+                                                   jb.cbf_ctx_plus1, scans) : 0ull;
   if (live) {
     bits_out[j] = frac;
     if (ctx_out) {
@@ -303,3 +310,5 @@ int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, c
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "coeff_bits launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+#include "k_rqt.inl"

@@ -1,0 +1,316 @@
+// k_rqt.inl -- residual quadtree search of SS/GT ("inter") CUs, SURVEY 8(a) row a8b (included by k_cabac.hip: it shares the counting coder).
+// Replaces TEncSearch::xEstimateResidualQT (TLibEncoder/TEncSearch.cpp:6824-7560) with xEncodeResidualQT (:7562-7655) for a batch of CUs.
+//
+// Inside one CU the search is a chain: every node starts from the coder state its predecessor left (m_pcRDGoOnSbacCoder), the RDOQ
+// tables and every bit count depend on it, and a parent recounts its whole subtree.  The parallelism is across CUs (an RD search tests
+// hundreds of CU candidates per CTU): the host walks the quadtree of the CU class in the reference's order, and every step is a batch
+// over all CUs of the class:
+//   k_rqt_begin    store the entry state (CI_QT_TRAFO_ROOT), emit the node's Y/Cb/Cr transform units as leaf jobs (+ their 4x4
+//                  transform-skip variants)
+//   hop_launch_tu_rd  the leaf pipeline of k_tq.hip: residual, xT, estBit, RDOQ, bits from the entry state, inverse path, cbf-zero decision
+//   k_rqt_single   transform-skip decisions (:7210-7437), the node coded as one TU from the entry state (:7439-7466), its cost; a leaf
+//                  adds itself to its parent's sums, an inner node parks the state (CI_QT_TRAFO_TEST) and rewinds for its children
+//   k_rqt_close    cbf of the children folded upwards, the subtree recounted in syntax order from the entry state (:7503-7511), the
+//                  split decision (:7514-7522)
+// One lane per CU in the k_rqt_* kernels; context states of a lane in LDS as in k_coeff_bits.  Coefficients of every evaluated node stay in
+// per-CU layer buffers (layer = log2 max TU - log2 size, TU of 4x4 partition p at 16 p, chroma at (16 p) >> 2: the reference's
+// m_ppcQTTempCoeff layout) until the root has decided; k_rqt_final gathers the chosen ones.
+
+struct RqtClass { int log2_cu, log2_max_tu, log2_min_tu, inter_split, sign_hide, use_ts; };
+struct RqtNode { int part, d, log2, code_chroma, check_full, check_split, add_zero, ts_y, ts_c; };
+struct RqtWork {                                                      // per CU: what the reference keeps in locals of the recursion, by transform depth
+  double   single_cost[4]; uint32_t single_bits[4], single_dist[4], abs_sum[4][3];
+  double   sub_cost[5]; uint32_t sub_bits[5], sub_dist[5];            // what the children of depth d have added up (index 0: the CU's result)
+  uint32_t zero_dist; uint8_t best_skip[4][4];
+};
+
+__device__ static inline int rqt_zx(int p) { int x = 0; for (int b = 0; b < 4; b++) x |= ((p >> (2 * b)) & 1) << b; return 4 * x; }
+__device__ static inline int rqt_zy(int p) { int y = 0; for (int b = 0; b < 4; b++) y |= ((p >> (2 * b + 1)) & 1) << b; return 4 * y; }
+__device__ static inline double rqt_cost(uint32_t bits, uint32_t dist, double lambda) { return (double)(uint32_t)floor((double)dist + (double)((int)(bits * lambda + .5))); }
+__device__ static inline size_t rqt_coef_base(const RqtClass& k, int i) { return (size_t)i * (size_t)(6 << (2 * k.log2_cu)); }
+__device__ static inline size_t rqt_coef_at(const RqtClass& k, int i, int layer, int comp, int part) {
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  return rqt_coef_base(k, i) + (size_t)layer * (cu2 + (cu2 >> 1)) + (comp == 0 ? 0 : comp == 1 ? cu2 : cu2 + (cu2 >> 2)) + (comp ? (size_t)((16 * part) >> 2) : (size_t)(16 * part));
+}
+
+__global__ void k_rqt_init(const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, hop_cabac_ctx* __restrict__ cur,
+                           RqtWork* __restrict__ work, hop_rqt_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  cur[i] = ctx_in[jobs[i].ctx_index];
+  RqtWork w; memset(&w, 0, sizeof(w));
+  work[i] = w;
+  hop_rqt_result* r = res + i;
+  r->cost = 0; r->bits = r->dist = r->zero_dist = r->pad = 0;
+  for (int p = 0; p < 256; p++) { r->tr_idx[p] = 0; for (int c = 0; c < 3; c++) { r->cbf[c][p] = 0; r->tskip[c][p] = 0; } }
+}
+
+// entry of a node: CI_QT_TRAFO_ROOT <- the coder; the node's transform units as leaf jobs
+__global__ void k_rqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, int bd_y, int bd_c, const hop_cabac_ctx* __restrict__ cur,
+                            hop_cabac_ctx* __restrict__ root, hop_rqt_result* __restrict__ res, RqtWork* __restrict__ work, hop_tu_rd_job* __restrict__ tuj,
+                            int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2, int64_t* __restrict__ off2, size_t ts_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  root[i] = cur[i];
+  const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d);
+  if (!nd.check_full) { work[i].single_cost[nd.d] = 1.7e+308; work[i].sub_dist[nd.d + 1] = 0; work[i].sub_cost[nd.d + 1] = 0; work[i].sub_bits[nd.d + 1] = 0; return; }
+  const hop_rqt_job jb = jobs[i];
+  hop_rqt_result* r = res + i;
+  const int dC = nd.log2 == 2 ? nd.d - 1 : nd.d, npartsC = parts >> (2 * dC), log2C = nd.log2 == 2 ? 2 : nd.log2 - 1;
+  for (int p = 0; p < nparts; p++) { r->tr_idx[nd.part + p] = (uint8_t)nd.d; r->tskip[0][nd.part + p] = 0; }
+  if (nd.code_chroma) for (int p = 0; p < npartsC; p++) { r->tskip[1][nd.part + p] = 0; r->tskip[2][nd.part + p] = 0; }
+  const int ncomp = nd.code_chroma ? 3 : 1, layer = k.log2_max_tu - nd.log2;
+  const int nts = nd.ts_y + 2 * nd.ts_c;
+  int t = 0;
+  for (int c = 0; c < ncomp; c++) {
+    hop_tu_rd_job j;
+    j.x = jb.x + rqt_zx(nd.part); j.y = jb.y + rqt_zy(nd.part); j.comp = c; j.log2_size = c ? log2C : nd.log2; j.qp_scaled = jb.qp_scaled[c]; j.tr_depth = nd.d;
+    j.ctx_index = i; j.sign_hide = k.sign_hide; j.use_ts = k.use_ts; j.bit_depth = c ? bd_c : bd_y; j.is_intra = 0; j.scan_idx = 0; j.use_dst = 0; j.flags = 0;
+    j.lambda_rdoq = jb.lambda_rdoq[c]; j.lambda_rd = jb.lambda_rd; j.dist_weight = c ? jb.dist_weight[c - 1] : 1.0;
+    tuj[ncomp * i + c] = j;
+    off[ncomp * i + c] = (int64_t)rqt_coef_at(k, i, layer, c, nd.part);
+    if (c == 0 ? nd.ts_y : nd.ts_c) {
+      j.flags = HOP_TU_RD_TS | HOP_TU_RD_KEEP;
+      tuj2[nts * i + t] = j;
+      off2[nts * i + t] = (int64_t)(ts_base + (size_t)i * 48 + (size_t)c * 16);
+      t++;
+    }
+  }
+}
+
+#define RQ_LOAD(src) do { const uint8_t* s_ = (src).state; for (int q_ = 0; q_ < 152; q_++) sh.st[q_][lane] = s_[q_]; } while (0)
+#define RQ_LEFT() ((unsigned)sh.st[150][lane] | ((unsigned)sh.st[151][lane] << 8))
+__device__ static inline void rqt_store(CabacLds& sh, int lane, unsigned long long frac_total, hop_cabac_ctx* dst) {
+  for (int q = 0; q < 150; q++) dst->state[q] = sh.st[q][lane];
+  const unsigned left = (unsigned)(frac_total & 32767ull);
+  dst->state[150] = (uint8_t)(left & 0xFF); dst->state[151] = (uint8_t)(left >> 8);
+}
+__device__ static inline int rqt_cbf_ctx(int comp, int d) { return CX_QT_CBF + (comp ? 4 + d : (d == 0 ? 1 : 0)); }     // getCtxQtCbf, TComDataCU.cpp:1848-1859
+
+__global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
+                                                   const hop_cabac_ctx* __restrict__ root, hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
+                                                   RqtWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2,
+                                                   int32_t* __restrict__ coef, size_t ts_base, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;                                                // no barrier in this kernel
+  const hop_rqt_job jb = jobs[i];
+  hop_rqt_result* r = res + i; RqtWork* w = work + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), d = nd.d;
+  const int dC = nd.log2 == 2 ? d - 1 : d, npartsC = parts >> (2 * dC), log2C = nd.log2 == 2 ? 2 : nd.log2 - 1;
+  const int ncomp = nd.code_chroma ? 3 : 1, layer = k.log2_max_tu - nd.log2, nts = nd.ts_y + 2 * nd.ts_c;
+  uint32_t absSum[3] = { 0, 0, 0 }, distC[3] = { 0, 0, 0 }; double minCost[3] = { 0, 0, 0 }; int skip[3] = { 0, 0, 0 };
+  for (int c = 0; c < ncomp; c++) {
+    const hop_tu_rd_result t = tr[ncomp * i + c];
+    absSum[c] = t.abs_sum; distC[c] = t.dist; minCost[c] = t.cost;
+    if (nd.add_zero) w->zero_dist += t.zero_dist;
+  }
+  // transform-skip retry: the variant replaces the block unless it has no level or the best cost so far is smaller (:7258, :7389, :7421)
+  int t2 = 0;
+  for (int c = 0; c < ncomp; c++) {
+    if (!(c == 0 ? nd.ts_y : nd.ts_c)) continue;
+    const hop_tu_rd_result t = tr2[nts * i + t2]; t2++;
+    if (t.abs_sum && !(minCost[c] < t.cost)) {
+      int32_t* dst = coef + rqt_coef_at(k, i, layer, c, nd.part); const int32_t* src = coef + ts_base + (size_t)i * 48 + (size_t)c * 16;
+      for (int q = 0; q < 16; q++) dst[q] = src[q];
+      distC[c] = t.nonzero_dist; absSum[c] = t.abs_sum; skip[c] = 1;
+    }
+  }
+  const uint8_t setCbf = (uint8_t)(1 << d);
+  for (int p = 0; p < nparts; p++) { r->cbf[0][nd.part + p] = absSum[0] ? setCbf : 0; r->tskip[0][nd.part + p] = (uint8_t)skip[0]; }
+  if (nd.code_chroma) for (int p = 0; p < npartsC; p++) {
+    r->cbf[1][nd.part + p] = absSum[1] ? setCbf : 0; r->cbf[2][nd.part + p] = absSum[2] ? setCbf : 0;
+    r->tskip[1][nd.part + p] = (uint8_t)skip[1]; r->tskip[2][nd.part + p] = (uint8_t)skip[2];
+  }
+  // the node as one transform unit, from the entry state (:7439-7466)
+  RQ_LOAD(root[i]);
+  unsigned long long frac = RQ_LEFT();                                // resetBits keeps the fraction
+  if (nd.log2 > k.log2_min_tu) CBIN(CX_TRANS_SUBDIV + 5 - nd.log2, 0);
+  if (nd.code_chroma) { CBIN(rqt_cbf_ctx(1, d), absSum[1] ? 1 : 0); CBIN(rqt_cbf_ctx(2, d), absSum[2] ? 1 : 0); }
+  CBIN(rqt_cbf_ctx(0, d), absSum[0] ? 1 : 0);
+  for (int c = 0; c < ncomp; c++)
+    frac += cb_code_tu(sh, lane, coef + rqt_coef_at(k, i, layer, c, nd.part), c ? log2C : nd.log2, c != 0, 0, k.sign_hide, k.use_ts, skip[c], 0, scans);
+  const uint32_t singleBits = (uint32_t)(frac >> 15), singleDist = distC[0] + distC[1] + distC[2];
+  const double singleCost = rqt_cost(singleBits, singleDist, jb.lambda_rd);
+  rqt_store(sh, lane, frac, cur + i);
+  if (nd.check_split) {
+    test[i] = cur[i]; cur[i] = root[i];
+    w->single_cost[d] = singleCost; w->single_bits[d] = singleBits; w->single_dist[d] = singleDist;
+    for (int c = 0; c < 3; c++) { w->abs_sum[d][c] = absSum[c]; w->best_skip[d][c] = (uint8_t)skip[c]; }
+    w->sub_dist[d + 1] = 0; w->sub_cost[d + 1] = 0; w->sub_bits[d + 1] = 0;
+  } else {
+    w->sub_cost[d] += singleCost; w->sub_bits[d] += singleBits; w->sub_dist[d] += singleDist;
+  }
+}
+
+// xEncodeResidualQT on the lane's coder: the subtree below (part, d0) as the arrays describe it; flags (subdiv_and_cbf) or one component's levels
+__device__ static unsigned long long rqt_encode_tree(CabacLds& sh, const int lane, const RqtClass& k, const int i, const hop_rqt_result* r, const int32_t* coef,
+                                                     const int part0, const int d0, const int log2_0, const int subdiv_and_cbf, const int comp, const uint16_t* scans) {
+  unsigned long long frac = 0;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  int sp_part[4], sp_k[4]; int sp = 0;
+  sp_part[0] = part0; sp_k[0] = -1;
+  while (sp >= 0) {
+    const int part = sp_part[sp], cd = d0 + sp, log2 = log2_0 - sp;
+    if (sp_k[sp] < 0) {
+      const int trMode = r->tr_idx[part], subdiv = cd != trMode;
+      if (subdiv_and_cbf && log2 <= k.log2_max_tu && log2 > k.log2_min_tu) CBIN(CX_TRANS_SUBDIV + 5 - log2, subdiv);
+      if (subdiv_and_cbf) {
+        const int first = cd == 0;
+        if (first || log2 > 2) {
+          if (first || ((r->cbf[1][part] >> (cd - 1)) & 1)) CBIN(rqt_cbf_ctx(1, cd), (r->cbf[1][part] >> cd) & 1);
+          if (first || ((r->cbf[2][part] >> (cd - 1)) & 1)) CBIN(rqt_cbf_ctx(2, cd), (r->cbf[2][part] >> cd) & 1);
+        }
+      }
+      if (!subdiv) {
+        const int layer = k.log2_max_tu - log2;
+        int codeChroma = 1, log2C = log2 - 1;
+        if (log2 == 2) { log2C = 2; codeChroma = (part % (parts >> (2 * (trMode - 1)))) == 0; }
+        if (subdiv_and_cbf) CBIN(rqt_cbf_ctx(0, trMode), (r->cbf[0][part] >> trMode) & 1);
+        else {
+          if (comp == 0 && ((r->cbf[0][part] >> trMode) & 1))
+            frac += cb_code_tu(sh, lane, coef + rqt_coef_at(k, i, layer, 0, part), log2, 0, 0, k.sign_hide, k.use_ts, r->tskip[0][part], 0, scans);
+          if (codeChroma && comp && ((r->cbf[comp][part] >> trMode) & 1))
+            frac += cb_code_tu(sh, lane, coef + rqt_coef_at(k, i, layer, comp, part), log2C, 1, 0, k.sign_hide, k.use_ts, r->tskip[comp][part], 0, scans);
+        }
+        sp--; continue;
+      }
+      if (!(subdiv_and_cbf || ((r->cbf[comp][part] >> cd) & 1))) { sp--; continue; }
+      sp_k[sp] = 0;
+    }
+    if (sp_k[sp] < 4) {
+      const int q = (parts >> (2 * cd)) >> 2, kk = sp_k[sp]++;
+      sp_part[sp + 1] = part + kk * q; sp_k[sp + 1] = -1; sp++;
+    } else sp--;
+  }
+  return frac;
+}
+
+__global__ __launch_bounds__(64) void k_rqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
+                                                  const hop_cabac_ctx* __restrict__ root, const hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
+                                                  RqtWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const hop_rqt_job jb = jobs[i];
+  hop_rqt_result* r = res + i; RqtWork* w = work + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), d = nd.d, nparts = parts >> (2 * d), q = nparts >> 2;
+  int any[3] = { 0, 0, 0 };
+  for (int c = 0; c < 3; c++) for (int kk = 0; kk < 4; kk++) any[c] |= (r->cbf[c][nd.part + kk * q] >> (d + 1)) & 1;
+  for (int c = 0; c < 3; c++) for (int p = 0; p < nparts; p++) r->cbf[c][nd.part + p] |= (uint8_t)(any[c] << d);
+  RQ_LOAD(root[i]);
+  unsigned long long frac = RQ_LEFT();
+  frac += rqt_encode_tree(sh, lane, k, i, r, coef, nd.part, d, nd.log2, 1, 0, scans);
+  frac += rqt_encode_tree(sh, lane, k, i, r, coef, nd.part, d, nd.log2, 0, 0, scans);
+  frac += rqt_encode_tree(sh, lane, k, i, r, coef, nd.part, d, nd.log2, 0, 1, scans);
+  frac += rqt_encode_tree(sh, lane, k, i, r, coef, nd.part, d, nd.log2, 0, 2, scans);
+  const uint32_t subBits = (uint32_t)(frac >> 15), subDist = w->sub_dist[d + 1];
+  const double subCost = rqt_cost(subBits, subDist, jb.lambda_rd);
+  if ((any[0] || any[1] || any[2] || !nd.check_full) && subCost < w->single_cost[d]) {
+    w->sub_cost[d] += subCost; w->sub_bits[d] += subBits; w->sub_dist[d] += subDist;
+    rqt_store(sh, lane, frac, cur + i);
+    return;
+  }
+  const int dC = nd.log2 == 2 ? d - 1 : d, npartsC = parts >> (2 * dC);
+  const uint8_t setCbf = (uint8_t)(1 << d);
+  for (int p = 0; p < nparts; p++) { r->tskip[0][nd.part + p] = w->best_skip[d][0]; r->tr_idx[nd.part + p] = (uint8_t)d; r->cbf[0][nd.part + p] = w->abs_sum[d][0] ? setCbf : 0; }
+  if (nd.code_chroma) for (int p = 0; p < npartsC; p++) {
+    r->tskip[1][nd.part + p] = w->best_skip[d][1]; r->tskip[2][nd.part + p] = w->best_skip[d][2];
+    r->cbf[1][nd.part + p] = w->abs_sum[d][1] ? setCbf : 0; r->cbf[2][nd.part + p] = w->abs_sum[d][2] ? setCbf : 0;
+  }
+  cur[i] = test[i];
+  w->sub_cost[d] += w->single_cost[d]; w->sub_bits[d] += w->single_bits[d]; w->sub_dist[d] += w->single_dist[d];
+}
+
+// results of the root + the chosen transform units' levels in the CU's coefficient layout (what xSetResidualQTData copies, :7658-7777)
+__global__ __launch_bounds__(64) void k_rqt_final(RqtClass k, int n, const RqtWork* __restrict__ work, hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef,
+                                                  int32_t* __restrict__ out, const hop_cabac_ctx* __restrict__ cur, hop_cabac_ctx* __restrict__ ctx_out) {
+  const int i = blockIdx.x, tid = threadIdx.x;
+  if (i >= n) return;
+  hop_rqt_result* r = res + i;
+  if (tid == 0) { r->cost = work[i].sub_cost[0]; r->bits = work[i].sub_bits[0]; r->dist = work[i].sub_dist[0]; r->zero_dist = work[i].zero_dist; if (ctx_out) ctx_out[i] = cur[i]; }
+  if (!out) return;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  int32_t* o = out + (size_t)i * (cu2 + (cu2 >> 1));
+  // a TU's block is contiguous from its first partition on (16 luma / 4 + 4 chroma coefficients per partition), so copying partition by
+  // partition from the layer of the partition's transform depth copies every chosen block whole
+  for (int t = tid; t < parts * 16; t += 64) {
+    const int p = t >> 4, q = t & 15, layer = k.log2_max_tu - (k.log2_cu - r->tr_idx[p]);
+    o[t] = coef[rqt_coef_at(k, i, layer, 0, p) + q];
+    if (q < 4) {
+      o[cu2 + 4 * p + q] = coef[rqt_coef_at(k, i, layer, 1, p) + q];
+      o[cu2 + (cu2 >> 2) + 4 * p + q] = coef[rqt_coef_at(k, i, layer, 2, p) + q];
+    }
+  }
+}
+
+// ---- host orchestration ----
+static int rqt_run_class(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job* d_jobs, const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_res, int32_t* d_coef_out,
+                         hop_cabac_ctx* d_ctx_out, char* buf, size_t buf_bytes) {
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu), n_coeff = (size_t)n * (6 * cu2 + 48), ts_base = (size_t)n * 6 * cu2;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
+  hop_cabac_ctx* cur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx));
+  hop_cabac_ctx* root[4]; hop_cabac_ctx* test[4];
+  for (int d = 0; d < 4; d++) { root[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); test[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); }
+  RqtWork* work = (RqtWork*)take((size_t)n * sizeof(RqtWork));
+  hop_tu_rd_job* tuj = (hop_tu_rd_job*)take((size_t)3 * n * sizeof(hop_tu_rd_job)); hop_tu_rd_job* tuj2 = (hop_tu_rd_job*)take((size_t)3 * n * sizeof(hop_tu_rd_job));
+  int64_t* off = (int64_t*)take((size_t)3 * n * 8); int64_t* off2 = (int64_t*)take((size_t)3 * n * 8);
+  hop_tu_rd_result* tr = (hop_tu_rd_result*)take((size_t)3 * n * sizeof(hop_tu_rd_result)); hop_tu_rd_result* tr2 = (hop_tu_rd_result*)take((size_t)3 * n * sizeof(hop_tu_rd_result));
+  int32_t* coef = (int32_t*)take(n_coeff * 4);
+  if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "rqt: work buffer too small");
+  const int g64 = (n + 63) / 64, g256 = (n + 255) / 256;
+  hipLaunchKernelGGL(k_rqt_init, dim3(g256), dim3(256), 0, c->stream, d_jobs, n, d_ctx_in, cur, work, d_res);
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  int rc = HOP_OK;
+  // the reference's recursion (:6824-7560), one batch step per node
+  struct Rec { static int go(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job* d_jobs, hop_rqt_result* d_res, hop_cabac_ctx* cur, hop_cabac_ctx** root, hop_cabac_ctx** test,
+                             RqtWork* work, hop_tu_rd_job* tuj, hop_tu_rd_job* tuj2, int64_t* off, int64_t* off2, hop_tu_rd_result* tr, hop_tu_rd_result* tr2, int32_t* coef,
+                             size_t n_coeff, size_t ts_base, int parts, int part, int d, int log2, int zero_open) {
+    RqtNode nd; nd.part = part; nd.d = d; nd.log2 = log2;
+    nd.check_full = (k.inter_split && d == 0 && log2 > k.log2_min_tu) ? 0 : (log2 <= k.log2_max_tu);
+    nd.check_split = log2 > k.log2_min_tu;
+    nd.code_chroma = 1;
+    if (log2 == 2) nd.code_chroma = (part % (parts >> (2 * (d - 1)))) == 0;
+    nd.add_zero = zero_open && nd.check_full;
+    nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
+    nd.ts_c = (k.use_ts && nd.check_full && nd.code_chroma && (log2 == 2 || log2 == 3)) ? 1 : 0;
+    const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, ncomp = nd.code_chroma ? 3 : 1, nts = nd.ts_y + 2 * nd.ts_c;
+    hipLaunchKernelGGL(k_rqt_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, d_jobs, n, c->bd_y, c->bd_c, cur, root[d], d_res, work, tuj, off, tuj2, off2, ts_base);
+    if (nd.check_full) {
+      int r = hop_launch_tu_rd(c, n * ncomp, tuj, root[d], off, n_coeff, coef, tr); if (r) return r;
+      if (nts) { r = hop_launch_tu_rd(c, n * nts, tuj2, root[d], off2, n_coeff, coef, tr2); if (r) return r; }
+      hipLaunchKernelGGL(k_rqt_single, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, tr, tr2, coef, ts_base, c->rdoq_scans);
+    }
+    if (nd.check_split) {
+      const int q = (parts >> (2 * d)) >> 2;
+      for (int kk = 0; kk < 4; kk++) {
+        const int r = go(c, k, n, d_jobs, d_res, cur, root, test, work, tuj, tuj2, off, off2, tr, tr2, coef, n_coeff, ts_base, parts, part + kk * q, d + 1, log2 - 1, zero_open && !nd.check_full);
+        if (r) return r;
+      }
+      hipLaunchKernelGGL(k_rqt_close, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, coef, c->rdoq_scans);
+    }
+    return HOP_OK;
+  } };
+  rc = Rec::go(c, k, n, d_jobs, d_res, cur, root, test, work, tuj, tuj2, off, off2, tr, tr2, coef, n_coeff, ts_base, parts, 0, 0, k.log2_cu, 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_rqt_final, dim3(n), dim3(64), 0, c->stream, k, n, work, d_res, coef, d_coef_out, cur, d_ctx_out);
+  (void)g64;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "rqt launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+size_t hop_rqt_work_bytes(int log2_cu, int n) {
+  const size_t cu2 = (size_t)1 << (2 * log2_cu);
+  return (size_t)n * (9 * sizeof(hop_cabac_ctx) + sizeof(RqtWork) + 6 * (sizeof(hop_tu_rd_job) + 8 + sizeof(hop_tu_rd_result)) + (6 * cu2 + 48) * 4) + 64 * 256;
+}
+
+// one homogeneous class of CUs (same size and transform-tree limits); d_* device pointers, buf = hop_rqt_work_bytes
+int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
+                         const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_res, int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, void* buf, size_t buf_bytes) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = inter_split; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  return rqt_run_class(c, k, n, d_jobs, d_ctx_in, d_res, d_coef_out, d_ctx_out, (char*)buf, buf_bytes);
+}

@@ -172,6 +172,13 @@ __global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __res
   part = (unsigned)hopd_wave_sum((int)part);
   if ((tid & 63) == 0) atomicAdd(&sh.acc, part);
   __syncthreads();
+  int32_t* out = coef + coef_off[blockIdx.x];
+  if (jb.flags & HOP_TU_RD_TS) {                                     // xTransformSkip, TComTrQuant.cpp:1402-1420 (shift >= 0 for bit depths <= 13)
+    const int shift = 15 - bd - log2N;
+    for (int i = tid; i < NN; i += 256) out[i] = (int)sh.a[i] * (1 << shift);
+    if (tid == 0) zero_sse[blockIdx.x] = sh.acc;
+    return;
+  }
   const int s1 = log2N - 1 + bd - 8, s2 = log2N + 6;               // xTrMxN :788-789
   for (int i = tid; i < NN; i += 256) {
     int k = i >> log2N, j = i & (N - 1), sum = 0;
@@ -179,7 +186,6 @@ __global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __res
     sh.b[k * N + j] = (int16_t)((sum + (1 << (s1 - 1))) >> s1);
   }
   __syncthreads();
-  int32_t* out = coef + coef_off[blockIdx.x];
   for (int i = tid; i < NN; i += 256) {
     int k = i >> log2N, j = i & (N - 1), sum = 0;
     for (int n = 0; n < N; n++) sum += sh.T[k * N + n] * sh.b[j * N + n];
@@ -219,6 +225,24 @@ __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __res
     for (int i = tid; i < NN; i += 256) sh.a[i] = (int16_t)clip16((clip16(lv[i]) * scale + dadd) >> dshift);
   }
   __syncthreads();
+  if ((jb.flags & HOP_TU_RD_TS) && !jb.is_intra) {                   // xITransformSkip, TComTrQuant.cpp:1442-1460; the dequantised value is an Int here (no 16-bit clip in between)
+    const int per = jb.qp_scaled / 6, rem = jb.qp_scaled % 6, transformShift = 15 - bd - log2N;
+    const int dshift = 20 - 14 - transformShift, dadd = 1 << (dshift - 1), scale = c_inv_quant_scales[rem] << per;
+    const int32_t* lv = levels + coef_off[blockIdx.x];
+    unsigned part = 0; const unsigned sshift = (unsigned)((bd - 8) << 1);
+    for (int i = tid; i < NN; i += 256) {
+      const int j = i >> log2N, n = i & (N - 1);
+      const int dq = clip16((clip16(lv[i]) * scale + dadd) >> dshift);
+      const int rr = (int)(int16_t)((dq + (1 << (transformShift - 1))) >> transformShift);
+      const int e = rr - ((int)org[(size_t)j * pitch + n] - (int)prd[(size_t)j * pitch + n]);
+      part += (unsigned)(e * e) >> sshift;
+    }
+    part = (unsigned)hopd_wave_sum((int)part);
+    if ((tid & 63) == 0) atomicAdd(&sh.acc, part);
+    __syncthreads();
+    if (tid == 0) nz_sse[blockIdx.x] = sh.acc;
+    return;
+  }
   const int s1 = 7, s2 = 12 - (bd - 8);                            // SHIFT_INV_1ST / SHIFT_INV_2ND
   for (int i = tid; i < NN; i += 256) {
     int j = i >> log2N, n = i & (N - 1), sum = 0;
@@ -283,7 +307,7 @@ __global__ void k_turd_setup(const hop_tu_rd_job* __restrict__ jobs, int n, cons
   r.bit_depth = jb.bit_depth; r.sign_hide = jb.sign_hide; r.lambda = jb.lambda_rdoq; r.coeff_offset = coef_off[i]; r.estbits_index = i; r.reserved = 0;
   rq[i] = r;
   hop_coeff_bits_job b;
-  b.log2_size = jb.log2_size; b.comp = jb.comp; b.scan_idx = jb.scan_idx; b.sign_hide = jb.sign_hide; b.use_ts = jb.use_ts; b.ts_flag = 0; b.ctx_index = jb.ctx_index;
+  b.log2_size = jb.log2_size; b.comp = jb.comp; b.scan_idx = jb.scan_idx; b.sign_hide = jb.sign_hide; b.use_ts = jb.use_ts; b.ts_flag = (jb.flags & HOP_TU_RD_TS) ? 1 : 0; b.ctx_index = jb.ctx_index;
   b.cbf_ctx_plus1 = 1 + 4 * chroma + (chroma ? jb.tr_depth : (jb.tr_depth == 0 ? 1 : 0));           // getCtxQtCbf, TComDataCU.cpp:1848-1859
   b.coeff_offset = coef_off[i];
   cb[i] = b;
@@ -315,7 +339,8 @@ __global__ void k_turd_decide(const hop_tu_rd_job* __restrict__ jobs, int n, con
     const int cbfCtx = 4 * chroma + (chroma ? jb.tr_depth : (jb.tr_depth == 0 ? 1 : 0));
     r.null_bits = (uint32_t)((left + (unsigned long long)entropy_bits[s[cbfCtx] ^ 0]) >> 15);       // encodeQtCbfZero from the snapshot
     const double nullCost = (double)(uint32_t)floor((double)zeroDist + (double)((int)(r.null_bits * jb.lambda_rd + .5)));
-    if (nullCost < singleCost) {
+    if (jb.flags & HOP_TU_RD_KEEP) { r.dist = nzDist; r.cost = singleCost; }       // the transform-skip retry compares this cost itself (:7258-7262)
+    else if (nullCost < singleCost) {
       r.abs_sum = 0; r.cost = nullCost;
       int32_t* lv = levels + coef_off[i];
       for (int k = 0; k < (1 << (2 * jb.log2_size)); k++) lv[k] = 0;

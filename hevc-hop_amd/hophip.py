@@ -61,8 +61,13 @@ COEFF_BITS_JOB_DTYPE = np.dtype([("log2_size", "<i4"), ("comp", "<i4"), ("scan_i
                                  ("ctx_index", "<i4"), ("cbf_ctx_plus1", "<i4"), ("coeff_offset", "<i8")])
 CABAC_CTX_BYTES = 152
 TU_RD_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("qp_scaled", "<i4"), ("tr_depth", "<i4"), ("ctx_index", "<i4"),
-                            ("sign_hide", "<i4"), ("use_ts", "<i4"), ("bit_depth", "<i4"), ("is_intra", "<i4"), ("scan_idx", "<i4"), ("use_dst", "<i4"), ("reserved", "<i4"),
+                            ("sign_hide", "<i4"), ("use_ts", "<i4"), ("bit_depth", "<i4"), ("is_intra", "<i4"), ("scan_idx", "<i4"), ("use_dst", "<i4"), ("flags", "<i4"),
                             ("lambda_rdoq", "<f8"), ("lambda_rd", "<f8"), ("dist_weight", "<f8")])
+RQT_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("log2_cu", "<i4"), ("qp_scaled", "<i4", (3,)), ("ctx_index", "<i4"), ("sign_hide", "<i4"), ("use_ts", "<i4"),
+                          ("log2_max_tu", "<i4"), ("log2_min_tu_in_cu", "<i4"), ("inter_split_flag", "<i4"), ("lambda_rd", "<f8"), ("lambda_rdoq", "<f8", (3,)),
+                          ("dist_weight", "<f8", (2,))])
+RQT_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("bits", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("pad", "<u4"), ("tr_idx", "u1", (256,)), ("cbf", "u1", (3, 256)),
+                             ("tskip", "u1", (3, 256))])
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -280,6 +285,15 @@ class Context:
         res = np.zeros(len(jobs), TU_RD_RESULT_DTYPE); lv = np.zeros(int(np.sum(1 << (2 * jobs["log2_size"].astype(np.int64)))), np.int32)
         self._chk(self.L.hop_tu_rd(self.h, len(jobs), jobs.ctypes.data, len(ctx_in), ctx_in.ctypes.data, res.ctypes.data, lv.ctypes.data), "hop_tu_rd")
         return res, lv
+
+    def rqt(self, jobs, ctx_in):
+        """jobs: RQT_JOB_DTYPE; ctx_in: (n_ctx, 152) uint8 -> results (RQT_RESULT_DTYPE), chosen levels (1.5 * size^2 per CU, job order), coder states out"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); ctx_in = np.ascontiguousarray(ctx_in, np.uint8)
+        res = np.zeros(len(jobs), RQT_RESULT_DTYPE); co = np.zeros(int(np.sum(3 << (2 * jobs["log2_cu"].astype(np.int64) - 1))), np.int32)
+        cx = np.zeros((len(jobs), CABAC_CTX_BYTES), np.uint8)
+        self.L.hop_rqt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+        self._chk(self.L.hop_rqt(self.h, len(jobs), jobs.ctypes.data, len(ctx_in), ctx_in.ctypes.data, res.ctypes.data, co.ctypes.data, cx.ctypes.data), "hop_rqt")
+        return res, co, cx
 
     def intra_pred(self, jobs, modes):
         n = len(jobs)

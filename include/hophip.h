@@ -280,6 +280,8 @@ int hop_coeff_bits_device(hop_ctx* ctx, int n, const hop_coeff_bits_job* d_jobs,
  * from the snapshot (integer, as getNumberOfWrittenBits) -> xDeQuant + xIT -> distortion in the residual domain -> the
  * cbf-zero decision on TComRdCost::calcRdCost values (:7008-7032).  Not included: the 4x4 transform-skip retry (:7210-7440),
  * the split recursion and the root-cbf decision of the caller. */
+#define HOP_TU_RD_TS   1   /* the 4x4 transform-skip variant of the residual quadtree (:7210-7440): xTransformSkip / xITransformSkip, transform_skip_flag = 1 in the bits */
+#define HOP_TU_RD_KEEP 2   /* no cbf-zero decision: levels, bits and distortion of coding the block are returned as they are */
 typedef struct {
   int32_t x, y;            /* luma position of the TU (chroma planes use x/2, y/2) */
   int32_t comp;            /* 0 Y, 1 Cb, 2 Cr */
@@ -295,7 +297,7 @@ typedef struct {
                               levels from the snapshot (what xGetIntraBitsQT counts for the block) */
   int32_t scan_idx;        /* getCoefScanIdx; 0 unless is_intra */
   int32_t use_dst;         /* 4x4 intra luma: DST-VII */
-  int32_t reserved;
+  int32_t flags;           /* HOP_TU_RD_* */
   double  lambda_rdoq;     /* TComTrQuant::m_dLambda after selectLambda */
   double  lambda_rd;       /* TComRdCost::m_dLambda */
   double  dist_weight;     /* chroma distortion weight of getDistPart (TLibCommon/TComRdCost.cpp:493-497); ignored for luma */
@@ -313,6 +315,36 @@ int hop_tu_rd(hop_ctx* ctx, int n, const hop_tu_rd_job* jobs, int n_ctx, const h
 /* d_coef_offsets[i] = first level of TU i in d_levels (n_coeff entries in total) */
 int hop_tu_rd_device(hop_ctx* ctx, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int64_t* d_coef_offsets, size_t n_coeff,
                      int32_t* d_levels, hop_tu_rd_result* d_results);                                 /* asynchronous, unchecked */
+
+/* ---- residual quadtree of an SS/GT ("inter") CU (row a8b) ---- */
+/* replaces: TEncSearch::xEstimateResidualQT (TLibEncoder/TEncSearch.cpp:6824-7560) with xEncodeResidualQT (:7562-7655) as
+ * encodeResAndCalcRdInterCU calls it (:6700) for a batch of CUs: the full search over transform sizes -- per node Y/Cb/Cr through
+ * transformNxN with RDOQ, counted bits, inverse path, cbf-zero decision, the 4x4 transform-skip retry, the node's own cost; the
+ * four children on the coder state the previous one left; the subtree recounted in syntax order; the split decision.  The
+ * residual is original - prediction picture of the context.  RDOQ and RDOQTS on, no lossless coding, flat scaling lists. */
+typedef struct {
+  int32_t x, y, log2_cu;           /* CU position (luma) and size, 3..6 */
+  int32_t qp_scaled[3];            /* what setQPforQuant hands to setQpParam for Y, Cb, Cr */
+  int32_t ctx_index;               /* coder state on entry (m_pcRDGoOnSbacCoder) */
+  int32_t sign_hide, use_ts;       /* PPS sign_data_hiding, transform_skip_enabled */
+  int32_t log2_max_tu, log2_min_tu_in_cu;   /* SPS QuadtreeTULog2MaxSize, TComDataCU::getQuadtreeTULog2MinSizeInCU */
+  int32_t inter_split_flag;        /* QuadtreeTUMaxDepthInter == 1 && partition != 2Nx2N (:6831) */
+  double  lambda_rd;               /* TComRdCost::m_dLambda */
+  double  lambda_rdoq[3];          /* TComTrQuant::m_lambdas */
+  double  dist_weight[2];          /* TComRdCost::m_cbDistortionWeight, m_crDistortionWeight */
+} hop_rqt_job;
+typedef struct {
+  double   cost;                   /* what the call adds to rdCost, ruiBits, ruiDist, *puiZeroDist */
+  uint32_t bits, dist, zero_dist, pad;
+  uint8_t  tr_idx[256];            /* per 4x4 partition of the CU, z-order: TComDataCU::getTransformIdx */
+  uint8_t  cbf[3][256];            /* getCbf(Y / Cb / Cr): one bit per transform depth */
+  uint8_t  tskip[3][256];          /* getTransformSkip */
+} hop_rqt_result;
+/* coef_out (may be NULL): per CU, job after job, 1.5 * size^2 levels = the chosen transform units in the CU's coefficient layout
+ * (Y, then Cb, then Cr; the TU of partition p at 16 p, chroma at 4 p; what xSetResidualQTData copies into getCoeffY/Cb/Cr).
+ * ctx_out (may be NULL): the coder state after the CU. */
+int hop_rqt(hop_ctx* ctx, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_rqt_result* results, int32_t* coef_out,
+            hop_cabac_ctx* ctx_out);
 
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with

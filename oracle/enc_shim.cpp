@@ -446,10 +446,24 @@ Void TEncSearch::xEstimateResidualQT(TComDataCU* pcCU, UInt uiQuadrant, UInt uiA
                                        memcpy(st.resi[l][2] + y * (cu / 2), t.getCrAddr() + y * t.getCStride(), (cu / 2) * sizeof(Pel)); }
   }
   hop_o_coder coder; coder_get(m_pcRDGoOnSbacCoder, &coder);
+  const hop_o_coder coder_in = coder;
   m_pcRDGoOnSbacCoder->store(m_pppcRDSbacCoder[uiDepth][CI_QT_TRAFO_ROOT]);
   double cost = 0; uint32_t bits = 0, dist = 0, zd = 0;
   hop_o_rqt(&cfg, pcResi->getLumaAddr(), pcResi->getStride(), pcResi->getCbAddr(), pcResi->getCrAddr(), pcResi->getCStride(), &coder, &st, &cost, &bits, &dist, &zd);
   rdCost += cost; ruiBits += bits; ruiDist += dist; if (puiZeroDist) *puiZeroDist += zd;
+  {                                                                 // HOP_SHIM_TRACE_RQT=<file>: cfg, coder in / out, residual planes, results, arrays, chosen levels
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_RQT"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) {
+      fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&coder_in, sizeof(coder_in), 1, f); fwrite(&coder, sizeof(coder), 1, f);
+      for (int y = 0; y < cu; y++) fwrite(pcResi->getLumaAddr() + y * pcResi->getStride(), 2, cu, f);
+      for (int y = 0; y < cu / 2; y++) fwrite(pcResi->getCbAddr() + y * pcResi->getCStride(), 2, cu / 2, f);
+      for (int y = 0; y < cu / 2; y++) fwrite(pcResi->getCrAddr() + y * pcResi->getCStride(), 2, cu / 2, f);
+      const uint32_t o4[4] = { bits, dist, zd, 0 }; fwrite(&cost, 8, 1, f); fwrite(o4, 4, 4, f);
+      fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+      std::vector<int32_t> fin(cu * cu * 3 / 2); hop_o_rqt_final_coeffs(&cfg, &st, &fin[0]); fwrite(&fin[0], 4, fin.size(), f);
+    }
+  }
   memcpy(pcCU->m_puhTrIdx, st.tr_idx, parts);
   for (int c = 0; c < 3; c++) { memcpy(pcCU->m_puhCbf[c], st.cbf[c], parts); memcpy(pcCU->m_puhTransformSkip[c], st.tskip[c], parts); }
   for (int l = 0; l < 4; l++) {

@@ -103,6 +103,7 @@ typedef struct {                    /* everything the caller reads afterwards; p
 } hop_o_rqt_state;
 void hop_o_rqt(const hop_o_rqt_cfg* cfg, const int16_t* resiY, int strideY, const int16_t* resiCb, const int16_t* resiCr, int strideC,
                hop_o_coder* coder, hop_o_rqt_state* st, double* cost, uint32_t* bits, uint32_t* dist, uint32_t* zero_dist);
+void hop_o_rqt_final_coeffs(const hop_o_rqt_cfg* cfg, const hop_o_rqt_state* st, int32_t* out);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,
                 double lambda_rdoq, double lambda_rd, double dist_weight, const hop_o_cabac_ctx* snap, uint32_t frac_left,
                 int32_t* levels, uint32_t* out, double* cost);

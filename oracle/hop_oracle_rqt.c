@@ -267,3 +267,17 @@ void hop_o_rqt(const hop_o_rqt_cfg* cfg, const int16_t* resiY, int strideY, cons
   *cost = 0; *bits = 0; *dist = 0; if (zero_dist) *zero_dist = 0;
   node(&r, 0, 0, cfg->log2_cu, cost, bits, dist, zero_dist);
 }
+
+/* the chosen transform units' levels in the CU's coefficient layout -- what xSetResidualQTData (:7658-7777) copies into
+ * getCoeffY/Cb/Cr: a TU's block is contiguous from its first partition on (16 luma, 4 + 4 chroma levels per partition), so
+ * taking every partition from the layer of its transform depth takes every chosen block whole.  out: 1.5 * size^2 ints. */
+void hop_o_rqt_final_coeffs(const hop_o_rqt_cfg* cfg, const hop_o_rqt_state* st, int32_t* out)
+{
+  const int cu2 = 1 << (2 * cfg->log2_cu), parts = cu2 >> 4;
+  for (int p = 0; p < parts; p++) {
+    const int layer = cfg->log2_max_tu - (cfg->log2_cu - st->tr_idx[p]);
+    memcpy(out + 16 * p, st->coef[layer][0] + 16 * p, 16 * sizeof(int32_t));
+    memcpy(out + cu2 + 4 * p, st->coef[layer][1] + 4 * p, 4 * sizeof(int32_t));
+    memcpy(out + cu2 + (cu2 >> 2) + 4 * p, st->coef[layer][2] + 4 * p, 4 * sizeof(int32_t));
+  }
+}

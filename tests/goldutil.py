@@ -89,3 +89,20 @@ def encoder_rdoq_calls():
                    src=np.ascontiguousarray(g["src"][off:off + n], np.int32), eb=np.ascontiguousarray(tab, np.int32),
                    out=np.ascontiguousarray(g["dst"][off:off + n], np.int32))
         off += n
+
+
+RQT_CFG = np.dtype([("log2_cu", "<i4"), ("qp", "<i4", (3,)), ("bit_depth_y", "<i4"), ("bit_depth_c", "<i4"), ("sign_hide", "<i4"), ("use_ts", "<i4"), ("log2_max_tu", "<i4"),
+                    ("log2_min_tu_in_cu", "<i4"), ("inter_split_flag", "<i4"), ("pad", "<i4"), ("lambda_rd", "<f8"), ("lambda_rdoq", "<f8", (3,)), ("dist_weight", "<f8", (3,))])
+
+
+def encoder_rqt_calls():
+    """tests/golden/encoder_rqt_calls.npz (oracle/make_golden9.py): xEstimateResidualQT calls of two real encodes (plain lenslet and the
+    sharp-edged frame on which transform skip wins): cfg (hop_o_rqt_cfg image), coder in / out (150 states + fraction), residual planes,
+    cost / bits / dist / zero_dist, tr_idx | cbf[3] | tskip[3] (7 x 256), the chosen levels"""
+    g = load("encoder_rqt_calls.npz")
+    ro = fo = 0
+    for i in range(len(g["cost"])):
+        cfg = g["cfg"][i]; cu = 1 << int(cfg["log2_cu"]); n = cu * cu * 3 // 2
+        yield dict(cfg=cfg, cin=g["cin"][i], cout=g["cout"][i], resi=np.ascontiguousarray(g["resi"][ro:ro + n]), cost=float(g["cost"][i]),
+                   bits=int(g["o4"][i][0]), dist=int(g["o4"][i][1]), zero_dist=int(g["o4"][i][2]), arr=g["arr"][i], fin=np.ascontiguousarray(g["fin"][fo:fo + n]))
+        ro += n; fo += n

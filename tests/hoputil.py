@@ -57,6 +57,21 @@ def lenslet(W, H, pitch=15, seed=2, bitdepth=8):
     return Y, Cb, Cr
 
 
+def sharp_frame(W, H, seed):
+    """lenslet with isolated black / white samples and one-sample lines on top: content on which the 4x4 transform-skip variant wins
+    (the plain lenslets never choose it)"""
+    Y, Cb, Cr = lenslet(W, H, 16, seed)
+    rng = np.random.default_rng(seed + 1000)
+    Y, Cb, Cr = Y.copy(), Cb.copy(), Cr.copy()
+    m = rng.random((H, W)) < 0.08
+    Y[m] = rng.choice([0, 255], size=int(m.sum()))
+    Y[10:H - 10:7, :] = 255 - Y[10:H - 10:7, :]
+    mc = rng.random((H // 2, W // 2)) < 0.08
+    Cb[mc] = rng.choice([16, 240], size=int(mc.sum()))
+    Cr[mc] = rng.choice([16, 240], size=int(mc.sum()))
+    return Y, Cb, Cr
+
+
 class Planes:
     """SS-reference planes in the reference's own layout: margins 80/40, stride = W + 160 / W/2 + 80."""
 

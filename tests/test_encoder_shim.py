@@ -14,7 +14,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from hoputil import ROOT, lenslet
+from hoputil import ROOT, lenslet, sharp_frame
 
 REF = "/root/reference"
 SHIM = os.path.join(ROOT, "oracle", "_ref", "TAppEncoderShim")
@@ -29,8 +29,8 @@ def _shim():
     return SHIM
 
 
-def encode(exe, W, H, seed, td, extra_env=None):
-    Y, Cb, Cr = lenslet(W, H, 16, seed)
+def encode(exe, W, H, seed, td, extra_env=None, sharp=False):
+    Y, Cb, Cr = sharp_frame(W, H, seed) if sharp else lenslet(W, H, 16, seed)
     with open(os.path.join(td, "in.yuv"), "wb") as f:
         f.write(Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes())
     env = dict(os.environ, HOP_SHIM_REPORT="1", **(extra_env or {}))
@@ -57,3 +57,23 @@ def test_shim_encoder_writes_the_reference_bitstream(W, H, seed):
     for k in ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "intraPred", "calcHAD", "distPart", "tskip", "commit", "rqt"):
         assert calls.get(k, 0) > 50, (k, calls)
     assert bit == gold["bin_md5"] and rec == gold["rec_md5"], calls
+
+
+def test_shim_encoder_on_sharp_content():
+    """a frame on which the 4x4 transform-skip variant wins in nearly every residual quadtree (the lenslets never choose it): the shim
+    encoder against the unmodified reference encoder, both run here"""
+    exe = _shim()
+    ref = os.path.join(ROOT, "oracle", "_ref", "TAppEncoderRef")
+    with tempfile.TemporaryDirectory() as ta, tempfile.TemporaryDirectory() as tb:
+        a = encode(ref, 64, 64, 77, ta, sharp=True)
+        b = encode(exe, 64, 64, 77, tb, sharp=True, extra_env={"HOP_SHIM_TRACE_RQT": os.path.join(tb, "rqt.bin")})
+        raw = open(os.path.join(tb, "rqt.bin"), "rb").read()
+    assert a[:3] == b[:3]
+    # the trace of the residual-quadtree calls (layout: oracle/make_golden9.py) must show the transform-skip arrays in use
+    o = n = ts = 0
+    while o < len(raw):
+        cu = 1 << int(np.frombuffer(raw, "<i4", 1, o)[0])
+        o += 104 + 160 + 160 + cu * cu * 3 + 8 + 16
+        ts += int(np.frombuffer(raw, "u1", 768, o + 1024).any()); n += 1
+        o += 256 * 7 + cu * cu * 6
+    assert n > 300 and ts > n // 2, (n, ts)

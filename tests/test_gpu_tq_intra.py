@@ -300,3 +300,49 @@ def test_intra_pred_vs_oracle(hp):
             assert np.array_equal(got, want), (x, y, N, mode)
         if rnd == 0 and len(g["jobs"]) > 60: break
     ctx.close()
+
+
+def test_rqt_encoder_calls(hp):
+    """row a8b through hop_rqt: the whole residual-quadtree search (transform sizes, transform-skip retry, context chaining, subtree recount,
+    split decision) on 73 xEstimateResidualQT calls recorded inside the encoder (tests/golden/encoder_rqt_calls.npz: plain lenslet + the
+    sharp-edged frame on which transform skip wins), every CU size, all in one call: cost, bits, distortions, the transform depth / cbf /
+    transform-skip arrays, the chosen levels and the coder state left behind"""
+    from goldutil import encoder_rqt_calls
+    cases = list(encoder_rqt_calls())
+    W, H = 512, 64 * ((len(cases) + 7) // 8)
+    org = [np.full((H, W), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16)]
+    jobs = np.zeros(len(cases), hp.RQT_JOB_DTYPE)
+    snaps = np.zeros((len(cases), hp.CABAC_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; cu = 1 << int(cfg["log2_cu"]); n2 = cu * cu
+        x, y = 64 * (i % 8), 64 * (i // 8)
+        org[0][y:y + cu, x:x + cu] += c["resi"][:n2].reshape(cu, cu)
+        org[1][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2] += c["resi"][n2:n2 + n2 // 4].reshape(cu // 2, cu // 2)
+        org[2][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2] += c["resi"][n2 + n2 // 4:].reshape(cu // 2, cu // 2)
+        j = jobs[i]
+        j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x, y, int(cfg["log2_cu"]), cfg["qp"], i
+        j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"], j["inter_split_flag"] = cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"], cfg["inter_split_flag"]
+        j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = cfg["lambda_rd"], cfg["lambda_rdoq"], cfg["dist_weight"][1:]
+        snaps[i, :150] = c["cin"]["ctx"]
+        left = int(c["cin"]["frac"]) & 32767
+        snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(*org)
+    for comp in range(3):
+        ctx.plane_upload("pred", comp, np.full(org[comp].shape, 128, np.int16))
+    res, co, cx = ctx.rqt(jobs, snaps)
+    off = 0; ts = 0
+    for i, c in enumerate(cases):
+        cu = 1 << int(c["cfg"]["log2_cu"]); n = cu * cu * 3 // 2; parts = cu * cu // 16
+        r = res[i]
+        assert (float(r["cost"]), int(r["bits"]), int(r["dist"]), int(r["zero_dist"])) == (c["cost"], c["bits"], c["dist"], c["zero_dist"]), (i, cu, r["cost"], r["bits"], r["dist"], c["cost"], c["bits"], c["dist"])
+        got = np.concatenate([r["tr_idx"][None, :], r["cbf"], r["tskip"]])
+        assert np.array_equal(got[:, :parts], c["arr"].reshape(7, 256)[:, :parts]), (i, cu)
+        assert np.array_equal(co[off:off + n], c["fin"]), (i, cu)
+        assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), (i, cu)
+        ts += int(got[4:, :parts].any()); off += n
+    assert ts >= 15
+    bad = jobs[:1].copy(); bad["x"] = 4
+    with pytest.raises(hp.HopError):
+        ctx.rqt(bad, snaps)
+    ctx.close()

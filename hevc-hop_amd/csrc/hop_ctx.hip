@@ -114,13 +114,14 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
-                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rdoq_scans, c->entropy_bits };
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
     if (c->xstream[k]) (void)hipStreamDestroy(c->xstream[k]);
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
     if (c->xscratch[k]) (void)hipFree(c->xscratch[k]);
+    if (c->xrqt_buf[k]) (void)hipFree(c->xrqt_buf[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   free(c);
@@ -578,7 +579,55 @@ int hop_tu_rd_device(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   if (!c || n < 0 || (n && (!d_jobs || !d_ctx_in || !d_coef_offsets || !d_levels || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_rd_device: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_rd: hop_upload_orig has not been called");
   if (n == 0) return HOP_OK;
-  return hop_launch_tu_rd(c, n, d_jobs, d_ctx_in, d_coef_offsets, n_coeff, d_levels, d_results);
+  return hop_launch_tu_rd(c, n, d_jobs, d_ctx_in, d_coef_offsets, n_coeff, d_levels, d_results, 0);
+}
+
+int hop_rqt_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_results, int32_t* d_coef_out,
+                   hop_cabac_ctx* d_ctx_out) {
+  if (!c || n < 0 || !cls || (n && (!d_jobs || !d_ctx_in || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_rqt: hop_upload_orig has not been called");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_device: illegal CU class");
+  if (n == 0) return HOP_OK;
+  const size_t wb = hop_rqt_work_bytes(cls->log2_cu, n);
+  if (wb > c->rqt_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
+    c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
+    c->rqt_bytes = wb + wb / 8;
+  }
+  return hop_launch_rqt_class(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->inter_split_flag ? 1 : 0, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, n, d_jobs,
+                              d_ctx_in, d_results, d_coef_out, d_ctx_out, c->rqt_buf, c->rqt_bytes);
+}
+
+int hop_rqt_device_classes(hop_ctx* c, int n_classes, const int* n, const hop_rqt_job* const* d_jobs, const hop_rqt_job* cls, const hop_cabac_ctx* d_ctx_in,
+                           hop_rqt_result* const* d_results, int32_t* const* d_coef_out, hop_cabac_ctx* const* d_ctx_out) {
+  if (!c || n_classes < 0 || (n_classes && (!n || !d_jobs || !cls || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_device_classes: bad argument");
+  if (n_classes == 0) return HOP_OK;
+  // classes are independent chains of small kernels: each runs on its own stream (with its own scratch and state buffers)
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+  bool used[HOP_MAX_LANES - 1] = { false, false, false };
+  int rc = HOP_OK;
+  for (int i = 0; i < n_classes && rc == HOP_OK; i++) {
+    const int lane = i % HOP_MAX_LANES;
+    if (lane == 0) { rc = hop_rqt_device(c, n[i], d_jobs[i], cls + i, d_ctx_in, d_results[i], d_coef_out ? d_coef_out[i] : nullptr, d_ctx_out ? d_ctx_out[i] : nullptr); continue; }
+    const int k = lane - 1;
+    std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    rc = hop_rqt_device(c, n[i], d_jobs[i], cls + i, d_ctx_in, d_results[i], d_coef_out ? d_coef_out[i] : nullptr, d_ctx_out ? d_ctx_out[i] : nullptr);
+    std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    used[k] = true;
+  }
+  for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
+    if (!used[k]) continue;
+    hipError_t e = hipEventRecord(c->ev_join[k], c->xstream[k]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join[k], 0);
+    if (e != hipSuccess && rc == HOP_OK) rc = hop_set_err(c, HOP_ERR_DEVICE, "hop_rqt_device_classes: stream join: %s", hipGetErrorString(e));
+  }
+  return rc;
 }
 
 int hop_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_rqt_result* results, int32_t* coef_out, hop_cabac_ctx* ctx_out) {
@@ -612,13 +661,12 @@ int hop_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cab
     const size_t cu3 = ((size_t)3 << (2 * f.log2_cu)) / 2;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_j = 0, o_c = al((size_t)m * sizeof(hop_rqt_job)), o_r = al(o_c + (size_t)n_ctx * sizeof(hop_cabac_ctx)), o_o = al(o_r + (size_t)m * sizeof(hop_rqt_result));
-    const size_t o_x = al(o_o + (size_t)m * cu3 * 4), o_w = al(o_x + (size_t)m * sizeof(hop_cabac_ctx)), wb = hop_rqt_work_bytes(f.log2_cu, m);
-    void* st; int r = hop_stage(c, o_w + wb + 256, &st); if (r) return r;
+    const size_t o_x = al(o_o + (size_t)m * cu3 * 4), o_w = al(o_x + (size_t)m * sizeof(hop_cabac_ctx));
+    void* st; int r = hop_stage(c, o_w + 256, &st); if (r) return r;
     char* b = (char*)st;
     HIPCHK(c, hipMemcpyAsync(b + o_j, cls.data(), (size_t)m * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, (size_t)n_ctx * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
-    r = hop_launch_rqt_class(c, f.log2_cu, f.log2_max_tu, f.log2_min_tu_in_cu, f.inter_split_flag ? 1 : 0, f.sign_hide ? 1 : 0, f.use_ts ? 1 : 0, m, (const hop_rqt_job*)(b + o_j),
-                             (const hop_cabac_ctx*)(b + o_c), (hop_rqt_result*)(b + o_r), (int32_t*)(b + o_o), (hop_cabac_ctx*)(b + o_x), b + o_w, wb);
+    r = hop_rqt_device(c, m, (const hop_rqt_job*)(b + o_j), &f, (const hop_cabac_ctx*)(b + o_c), (hop_rqt_result*)(b + o_r), (int32_t*)(b + o_o), (hop_cabac_ctx*)(b + o_x));
     if (r) return r;
     std::vector<hop_rqt_result> rr(m); std::vector<int32_t> co((size_t)m * cu3); std::vector<hop_cabac_ctx> cx(m);
     HIPCHK(c, hipMemcpyAsync(rr.data(), b + o_r, (size_t)m * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, c->stream));
@@ -659,7 +707,7 @@ int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop
   HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, bc, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b + o_o, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-  r = hop_launch_tu_rd(c, n, (const hop_tu_rd_job*)b, (const hop_cabac_ctx*)(b + o_c), (const int64_t*)(b + o_o), tot, (int32_t*)(b + o_l), (hop_tu_rd_result*)(b + o_r));
+  r = hop_launch_tu_rd(c, n, (const hop_tu_rd_job*)b, (const hop_cabac_ctx*)(b + o_c), (const int64_t*)(b + o_o), tot, (int32_t*)(b + o_l), (hop_tu_rd_result*)(b + o_r), 0);
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(results, b + o_r, (size_t)n * sizeof(hop_tu_rd_result), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(levels_out, b + o_l, tot * 4, hipMemcpyDeviceToHost, c->stream));

@@ -28,6 +28,8 @@ struct hop_ctx {
   // scratch that grows on demand (never allocated inside a *_device call once sized)
   void*  scratch; size_t scratch_bytes;
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
+  void*  rqt_buf; size_t rqt_bytes;     // state of the residual-quadtree search (k_rqt.inl); separate from scratch, which its leaf pipeline uses
+  void*  xrqt_buf[HOP_MAX_LANES - 1]; size_t xrqt_bytes[HOP_MAX_LANES - 1];
   // extra lanes for hop_me_search_device: the parts of a batch run on separate streams so that one part's kernel tails
   // and low-occupancy phases are filled by the other parts' kernels
   hipStream_t xstream[HOP_MAX_LANES - 1]; void* xscratch[HOP_MAX_LANES - 1]; size_t xscratch_bytes[HOP_MAX_LANES - 1];
@@ -136,7 +138,7 @@ int hop_launch_rdoq(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_est
                     void* d_work /* hop_rdoq_work_bytes(n) */);
 size_t hop_rdoq_work_bytes(int n);
 int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
-                     int32_t* d_levels, hop_tu_rd_result* d_res);
+                     int32_t* d_levels, hop_tu_rd_result* d_res, int size_hint);
 size_t hop_rqt_work_bytes(int log2_cu, int n);
 int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
                          const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_res, int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, void* buf, size_t buf_bytes);

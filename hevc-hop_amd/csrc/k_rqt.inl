@@ -280,8 +280,9 @@ static int rqt_run_class(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job
     const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, ncomp = nd.code_chroma ? 3 : 1, nts = nd.ts_y + 2 * nd.ts_c;
     hipLaunchKernelGGL(k_rqt_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, d_jobs, n, c->bd_y, c->bd_c, cur, root[d], d_res, work, tuj, off, tuj2, off2, ts_base);
     if (nd.check_full) {
-      int r = hop_launch_tu_rd(c, n * ncomp, tuj, root[d], off, n_coeff, coef, tr); if (r) return r;
-      if (nts) { r = hop_launch_tu_rd(c, n * nts, tuj2, root[d], off2, n_coeff, coef, tr2); if (r) return r; }
+      const int hint = log2 <= 3 ? 1 : (log2 == 5 ? 2 : 0);          // 16x16 luma comes with 8x8 chroma
+      int r = hop_launch_tu_rd(c, n * ncomp, tuj, root[d], off, n_coeff, coef, tr, hint); if (r) return r;
+      if (nts) { r = hop_launch_tu_rd(c, n * nts, tuj2, root[d], off2, n_coeff, coef, tr2, 1); if (r) return r; }
       hipLaunchKernelGGL(k_rqt_single, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, tr, tr2, coef, ts_base, c->rdoq_scans);
     }
     if (nd.check_split) {

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __res
                                                       int32_t* __restrict__ coef, uint32_t* __restrict__ zero_sse) {
   __shared__ TurdFwdShared sh;
   const hop_tu_rd_job jb = jobs[blockIdx.x];
+  if (jb.log2_size <= 3) return;                                   // k_turd_forward_small takes it
   const int tid = threadIdx.x, log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
   const bool chroma = jb.comp != 0;
   const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __res
                                                       int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
   __shared__ TurdFwdShared sh;                                     // a: dequantised / residual, b: intermediate
   const hop_tu_rd_job jb = jobs[blockIdx.x];
+  if (jb.log2_size <= 3) return;                                   // k_turd_inverse_small takes it
   if (abs_sum[blockIdx.x] == 0) {
     if (threadIdx.x == 0) nz_sse[blockIdx.x] = 0;
     if (jb.is_intra) {                                             // reconstruction = prediction (TEncSearch.cpp:1118-1127,1133-1152)
@@ -268,6 +270,100 @@ __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __res
   if ((tid & 63) == 0) atomicAdd(&sh.acc, part);
   __syncthreads();
   if (tid == 0) nz_sse[blockIdx.x] = sh.acc;
+}
+
+// ---- the same two stages for 4x4 and 8x8 TUs: one WAVE per TU (a lane per sample), four TUs per workgroup, no workgroup barrier ----
+// (a 256-thread workgroup per 16-sample TU spends its time being scheduled: the residual quadtree of 8x8 CUs is 2 M such TUs per frame)
+struct TurdSmallShared { int16_t a[4][64]; int16_t b[4][64]; };
+__device__ static inline int turd_t(bool dst, int log2N, int k, int n) { return dst ? c_dst4[k][n] : dct_coef(32 >> log2N, k, n); }
+
+__global__ __launch_bounds__(256) void k_turd_forward_small(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const int64_t* __restrict__ coef_off,
+                                                            int32_t* __restrict__ coef, uint32_t* __restrict__ zero_sse) {
+  __shared__ TurdSmallShared sh;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + w;
+  if (j >= n) return;
+  const hop_tu_rd_job jb = jobs[j];
+  if (jb.log2_size > 3) return;
+  const int log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
+  const bool chroma = jb.comp != 0, live = lane < NN;
+  const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
+  const int x0 = chroma ? jb.x >> 1 : jb.x, y0 = chroma ? jb.y >> 1 : jb.y;
+  const int16_t* org = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
+  const int16_t* prd = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+  const bool dst = jb.use_dst && N == 4 && !chroma;
+  const int r = lane >> log2N, c = lane & (N - 1);                 // as sample: row r, column c; as coefficient: k = r, j = c
+  int e = 0;
+  if (live) e = (int)org[(size_t)r * pitch + c] - (int)prd[(size_t)r * pitch + c];
+  sh.a[w][lane] = (int16_t)e;
+  const unsigned zs = (unsigned)hopd_wave_sum((int)((unsigned)(e * e) >> (unsigned)((bd - 8) << 1)));
+  if (lane == 0) zero_sse[j] = zs;
+  int32_t* out = coef + coef_off[j];
+  if (jb.flags & HOP_TU_RD_TS) { if (live) out[lane] = e * (1 << (15 - bd - log2N)); return; }      // xTransformSkip
+  __builtin_amdgcn_wave_barrier();
+  const int s1 = log2N - 1 + bd - 8, s2 = log2N + 6;
+  int t[8];
+  for (int q = 0; q < N; q++) t[q] = turd_t(dst, log2N, r, q);     // row k = r of the transform matrix
+  int sum = 0;
+  if (live) for (int q = 0; q < N; q++) sum += t[q] * sh.a[w][c * N + q];
+  sh.b[w][r * N + c] = (int16_t)((sum + (1 << (s1 - 1))) >> s1);
+  __builtin_amdgcn_wave_barrier();
+  sum = 0;
+  if (live) { for (int q = 0; q < N; q++) sum += t[q] * sh.b[w][c * N + q]; out[r * N + c] = (int)(int16_t)((sum + (1 << (s2 - 1))) >> s2); }
+}
+
+__global__ __launch_bounds__(256) void k_turd_inverse_small(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const int64_t* __restrict__ coef_off,
+                                                            const int32_t* __restrict__ levels, const uint32_t* __restrict__ abs_sum, uint32_t* __restrict__ nz_sse,
+                                                            int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
+  __shared__ TurdSmallShared sh;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + w;
+  if (j >= n) return;
+  const hop_tu_rd_job jb = jobs[j];
+  if (jb.log2_size > 3) return;
+  const int log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
+  const bool chroma = jb.comp != 0, live = lane < NN;
+  const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
+  const int x0 = chroma ? jb.x >> 1 : jb.x, y0 = chroma ? jb.y >> 1 : jb.y;
+  const int16_t* org = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
+  const int16_t* prd = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+  int16_t* rec = (jb.comp == 0 ? rec_y : jb.comp == 1 ? rec_cb : rec_cr) + (size_t)y0 * pitch + x0;
+  const int r = lane >> log2N, c = lane & (N - 1);
+  if (abs_sum[j] == 0) {
+    if (lane == 0) nz_sse[j] = 0;
+    if (jb.is_intra && live) rec[(size_t)r * pitch + c] = prd[(size_t)r * pitch + c];       // reconstruction = prediction
+    return;
+  }
+  const bool dst = jb.use_dst && N == 4 && !chroma;
+  const int per = jb.qp_scaled / 6, rem = jb.qp_scaled % 6, transformShift = 15 - bd - log2N;
+  const int dshift = 20 - 14 - transformShift, dadd = 1 << (dshift - 1), scale = c_inv_quant_scales[rem] << per;     // xDeQuant :1171-1182
+  const int32_t* lv = levels + coef_off[j];
+  const int dq = live ? clip16((clip16(lv[lane]) * scale + dadd) >> dshift) : 0;
+  int rr;
+  if ((jb.flags & HOP_TU_RD_TS) && !jb.is_intra) rr = (int)(int16_t)((dq + (1 << (transformShift - 1))) >> transformShift);      // xITransformSkip
+  else {
+    sh.a[w][lane] = (int16_t)dq;
+    __builtin_amdgcn_wave_barrier();
+    const int s1 = 7, s2 = 12 - (bd - 8);
+    // lane (j2 = r, n2 = c): b[j2][n2] = sum_k T[k][n2] a[k][j2], then rr(j2, n2) = sum_k T[k][n2] b[k][j2]
+    int t[8];
+    for (int q = 0; q < N; q++) t[q] = turd_t(dst, log2N, q, c);   // column n = c of the transform matrix
+    int sum = 0;
+    if (live) for (int q = 0; q < N; q++) sum += t[q] * sh.a[w][q * N + r];
+    sh.b[w][r * N + c] = (int16_t)clip16((sum + (1 << (s1 - 1))) >> s1);
+    __builtin_amdgcn_wave_barrier();
+    sum = 0;
+    if (live) for (int q = 0; q < N; q++) sum += t[q] * sh.b[w][q * N + r];
+    rr = clip16((sum + (1 << (s2 - 1))) >> s2);                    // reconstructed residual sample (row r, column c)
+  }
+  int e = 0;
+  if (live) {
+    if (jb.is_intra) {
+      const int v = min((1 << bd) - 1, max(0, (int)prd[(size_t)r * pitch + c] + rr));
+      rec[(size_t)r * pitch + c] = (int16_t)v;
+      e = v - (int)org[(size_t)r * pitch + c];
+    } else e = rr - ((int)org[(size_t)r * pitch + c] - (int)prd[(size_t)r * pitch + c]);
+  }
+  const unsigned ns = (unsigned)hopd_wave_sum((int)((unsigned)(e * e) >> (unsigned)((bd - 8) << 1)));
+  if (lane == 0) nz_sse[j] = ns;
 }
 
 // one thread per TU: the bit-estimate table of its snapshot (TEncSbac::estBit as hop_cabac_est_bits) and the job records
@@ -352,8 +448,9 @@ __global__ void k_turd_decide(const hop_tu_rd_job* __restrict__ jobs, int n, con
   res[i] = r;
 }
 
+// size_hint: 0 = transform sizes unknown / mixed, 1 = every TU is 4x4 or 8x8 (one wave per TU), 2 = every TU is 16x16 or 32x32
 int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
-                     int32_t* d_levels, hop_tu_rd_result* d_res) {
+                     int32_t* d_levels, hop_tu_rd_result* d_res, int size_hint) {
   // scratch: coefficients, zero / non-zero SSE, abs sums, counted bits, the bit-estimate tables and the job records of the inner stages
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_coef = 0, o_zs = al(o_coef + n_coeff * 4), o_ns = al(o_zs + (size_t)n * 4), o_as = al(o_ns + (size_t)n * 4), o_fr = al(o_as + (size_t)n * 4);
@@ -366,13 +463,15 @@ int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   hop_rdoq_job* rq = (hop_rdoq_job*)(b + o_rq); hop_coeff_bits_job* cb = (hop_coeff_bits_job*)(b + o_cb);
   hop_pics pic = hop_make_pics(c);
   const int pr = hop_prof_begin(c, HOP_K_TQ, (uint64_t)n);
-  hipLaunchKernelGGL(k_turd_forward, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, coef, zs);
+  if (size_hint != 1) hipLaunchKernelGGL(k_turd_forward, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, coef, zs);
+  if (size_hint != 2) hipLaunchKernelGGL(k_turd_forward_small, dim3((n + 3) / 4), dim3(256), 0, c->stream, d_jobs, n, pic, d_coef_off, coef, zs);
   hipLaunchKernelGGL(k_turd_setup, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_jobs, n, d_ctx, d_coef_off, hop_entropy_bits_device(c), tab, rq, cb);
   hop_prof_end(c, pr);
   r = hop_launch_rdoq(c, n, rq, tab, coef, d_levels, as, b + o_wk); if (r) return r;
   r = hop_launch_coeff_bits(c, n, cb, d_ctx, d_levels, fr, nullptr); if (r) return r;
   const int pr2 = hop_prof_begin(c, HOP_K_TQ, 0);
-  hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, as, ns, c->rec[0], c->rec[1], c->rec[2]);
+  if (size_hint != 1) hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, as, ns, c->rec[0], c->rec[1], c->rec[2]);
+  if (size_hint != 2) hipLaunchKernelGGL(k_turd_inverse_small, dim3((n + 3) / 4), dim3(256), 0, c->stream, d_jobs, n, pic, d_coef_off, d_levels, as, ns, c->rec[0], c->rec[1], c->rec[2]);
   hipLaunchKernelGGL(k_turd_decide, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_jobs, n, d_ctx, d_coef_off, hop_entropy_bits_device(c), as, fr, zs, ns, d_levels, d_res);
   hop_prof_end(c, pr2);
   hipError_t e = hipGetLastError();

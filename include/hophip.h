@@ -345,6 +345,14 @@ typedef struct {
  * ctx_out (may be NULL): the coder state after the CU. */
 int hop_rqt(hop_ctx* ctx, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_rqt_result* results, int32_t* coef_out,
             hop_cabac_ctx* ctx_out);
+/* device-resident form: all n CUs of ONE class -- the size and the transform-tree limits / flags of *cls (a host copy of any of the jobs);
+ * ctx_index of a job indexes d_ctx_in; asynchronous, unchecked */
+int hop_rqt_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_results,
+                   int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out);
+/* several classes at once (e.g. the CUs of every depth of a frame): class i = n[i] jobs at d_jobs[i] with the parameters of cls[i]; the
+ * classes run concurrently on the context's streams and are joined on its main stream */
+int hop_rqt_device_classes(hop_ctx* ctx, int n_classes, const int* n, const hop_rqt_job* const* d_jobs, const hop_rqt_job* cls, const hop_cabac_ctx* d_ctx_in,
+                           hop_rqt_result* const* d_results, int32_t* const* d_coef_out, hop_cabac_ctx* const* d_ctx_out);
 
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with

@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--width", type=int, default=FRAME_W)     # smaller frames only for rehearsal; the JSON names them
     ap.add_argument("--height", type=int, default=FRAME_H)
     ap.add_argument("--cpu-ctus", type=int, default=10, help="CTUs of the bounded cpu_baseline sample")
+    ap.add_argument("--rqt", action="store_true", help="run the whole residual-quadtree search (hop_rqt_device, row a8b) of every 2Nx2N CU instead of its leaf step "
+                    "at the largest transform size; the JSON's config.workload says which")
     args = ap.parse_args()
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,6 +247,20 @@ def main():
     for c3, pl in enumerate((recY, Cb, Cr)):                      # neighbours of the intra search: the reconstruction = the frozen reference
         host_plane = np.ascontiguousarray(pl.cpu().numpy(), np.int16)
         chk(L.hop_recon_upload(ctx.h, c3, host_plane.ctypes.data), "recon_upload")
+    # --rqt: the full transform-size search of the same CUs (three levels of transform units, transform-skip retry, context chaining, recount)
+    if args.rqt:
+        d_rq, d_rqr, rq_cls = [], [], []
+        for d in range(4):
+            S = 64 >> d
+            src = cu[cu[:, 2] == S]
+            a = np.zeros(len(src), hp.RQT_JOB_DTYPE)
+            a["x"], a["y"], a["log2_cu"], a["ctx_index"] = src[:, 0], src[:, 1], 6 - d, 0
+            a["qp_scaled"] = (QP, QP - 1, QP - 1); a["sign_hide"] = 1; a["use_ts"] = 1; a["log2_max_tu"] = 5; a["log2_min_tu_in_cu"] = (4, 3, 2, 2)[d]
+            a["lambda_rd"] = LAM; a["lambda_rdoq"] = (LAM, LAM / CW, LAM / CW); a["dist_weight"] = (CW, CW)
+            rq_cls.append(a[:1].copy())
+            d_rq.append(torch.from_numpy(a.view(np.uint8)).to(dev))
+            d_rqr.append(torch.zeros(len(a) * hp.RQT_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        L.hop_rqt_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
     CH = 1 << 17                                                  # PUs per launch
     jsz, rsz = hp.PU_JOB_DTYPE.itemsize, hp.PU_RESULT_DTYPE.itemsize
 
@@ -257,8 +273,12 @@ def main():
             if k:
                 chk(L.hop_pred_jobs_from_results_device(ctx.h, k, d_idx[d].data_ptr(), d_jobs.data_ptr(), d_res.data_ptr(), d_pj[d].data_ptr()), "pred_jobs")
                 chk(L.hop_pred_inter_device(ctx.h, k, d_pj[d].data_ptr()), "pred")
-                chk(L.hop_tu_rd_device(ctx.h, len(tu_by_depth[d]), d_tu[d].data_ptr(), d_snap.data_ptr(), d_tuoff[d].data_ptr(), int(tu_off[d][-1]),
-                                       d_levels.data_ptr(), d_tur[d].data_ptr()), "tu_rd")
+                if args.rqt:
+                    chk(L.hop_rqt_device(ctx.h, len(rq_cls[d]) and int(d_rq[d].numel() // hp.RQT_JOB_DTYPE.itemsize), d_rq[d].data_ptr(), rq_cls[d].ctypes.data, d_snap.data_ptr(),
+                                         d_rqr[d].data_ptr(), None, None), "rqt")
+                else:
+                    chk(L.hop_tu_rd_device(ctx.h, len(tu_by_depth[d]), d_tu[d].data_ptr(), d_snap.data_ptr(), d_tuoff[d].data_ptr(), int(tu_off[d][-1]),
+                                           d_levels.data_ptr(), d_tur[d].data_ptr()), "tu_rd")
         chk(L.hop_intra_rough_device(ctx.h, len(intra_jobs), d_intra.data_ptr(), d_satd.data_ptr()), "intra_rough")
         chk(L.hop_ssref_commit_cus_device(ctx.h, len(my_rects), d_myrects.data_ptr(), recY.data_ptr(), Cb.data_ptr(), Cr.data_ptr()), "commit")
 
@@ -298,6 +318,10 @@ def main():
 
     tu_crc = 0
     for d in range(4):
+        if args.rqt:
+            rr = np.frombuffer(d_rqr[d].cpu().numpy().tobytes(), hp.RQT_RESULT_DTYPE)
+            tu_crc ^= int(np.bitwise_xor.reduce((rr["bits"].astype(np.uint64) * 31 + rr["dist"] + rr["tr_idx"][:, 0].astype(np.uint64) * 7) * np.arange(1, len(rr) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF))
+            continue
         tr = np.frombuffer(d_tur[d].cpu().numpy().tobytes(), hp.TU_RD_RESULT_DTYPE)
         tu_crc ^= int(np.bitwise_xor.reduce((tr["bits"].astype(np.uint64) * 31 + tr["dist"] + tr["abs_sum"] * 7) * np.arange(1, len(tr) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF))
 
@@ -329,8 +353,10 @@ def main():
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i16+f64", "data": "synthetic",
-            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + residual-quadtree leaf of its residual (DCT, RDOQ, CABAC-counted bits, inverse, SSE, cbf decision; Y,Cb,Cr) + 35-mode intra rough search + SS-ref commit, "
-                                   "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD spine" % (W, H, PITCH, QP, n if world == 1 else -1),
+            "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + %s + 35-mode intra rough search + SS-ref commit, "
+                                   "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD spine" % (W, H, PITCH, QP,
+                                   "the whole residual-quadtree search of its residual (three transform sizes, transform-skip retry, context chaining, recount; Y,Cb,Cr)" if args.rqt else
+                                   "residual-quadtree leaf of its residual (DCT, RDOQ, CABAC-counted bits, inverse, SSE, cbf decision; Y,Cb,Cr)", n if world == 1 else -1),
                        "ctus": n_ctu, "pus_rank0": int(n), "parallelism": "ctu-rows-rr%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -135,10 +135,11 @@ __global__ __launch_bounds__(64) void k_rdoq(const hop_rdoq_job* __restrict__ jo
   __shared__ uint16_t s_scanCG[3][CGN];
   __shared__ double s_cgSig[CGN][64];                                     // cost of the coded_sub_block_flag of each group, one column per lane
   const int lane = threadIdx.x;
+  const int count = *count_ptr;
+  if (blockIdx.x * 64 >= count) return;                                   // nothing of this size class for this block (uniform)
   for (int i = lane; i < 3 * N2; i += 64) s_scan[i / N2][i % N2] = rq_scan(scans, i / N2, LOG2)[i % N2];
   for (int i = lane; i < 3 * CGN; i += 64) s_scanCG[i / CGN][i % CGN] = rq_scan_cg(scans, i / CGN, LOG2)[i % CGN];
   __syncthreads();
-  const int count = *count_ptr;
   // this block's slice of the work area: arrays [scan position][lane], so that the lanes of a step touch consecutive words
   double* const wd = (double*)(work + (size_t)blockIdx.x * ((size_t)N2 * 64 * RQ_WORK_PER_COEF));
   double* const wcc = wd + lane; double* const wcs = wd + (size_t)N2 * 64 + lane;

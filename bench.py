@@ -261,7 +261,7 @@ def main():
             d_rq.append(torch.from_numpy(a.view(np.uint8)).to(dev))
             d_rqr.append(torch.zeros(len(a) * hp.RQT_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev))
         L.hop_rqt_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
-    CH = 1 << 17                                                  # PUs per launch
+    CH = int(os.environ.get("HOP_BENCH_CH", max(n, 1)))               # PUs per hop_me_search_device call: the whole frame (the library cuts it into stream lanes); 128 k chunks cost 6 %
     jsz, rsz = hp.PU_JOB_DTYPE.itemsize, hp.PU_RESULT_DTYPE.itemsize
 
     def step():

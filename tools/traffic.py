@@ -22,8 +22,8 @@ wt, wl = fold(sys.argv[2], "WRITE_SIZE")
 out = {"_doc": "HBM traffic per kernel group from rocprofv3 PMC passes of `python3 bench.py --steps 1 --warmup 0 --cpu-ctus 0` on MI355X "
                "(separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, each with --kernel-trace only). bytes = counter x 1024 (counter unit KiB). "
                "The gfx950 x2 correction of FETCH_SIZE applies to 16-B-per-lane streaming reads; these kernels read 2-4 B per lane "
-               "(uncalibrated width), so the raw value is kept. per_launch = per profiled region of bench.py (one part of a "
-               "hop_me_search_device batch: 65536 PUs, ~154 CTUs, with the default 2 stream lanes); k_gt_search covers k_gt_prep + both "
+               "(uncalibrated width), so the raw value is kept. per_launch = per profiled region of bench.py (one part of the frame's "
+               "hop_me_search_device call: half of the 4.3 M PUs = 5082 CTUs with the default 2 stream lanes); k_gt_search covers k_gt_prep + both "
                "k_gt_search instantiations, k_ss_search covers the prep kernels + k_ss_family + k_ss_search + k_ss_finalize.", "kernels": {}}
 for g in ("k_gt_search", "k_ss_search", "k_frac", "k_pred_inter", "k_ssref_commit"):
     n = max(1, fl[g])

@@ -106,3 +106,35 @@ def encoder_rqt_calls():
         yield dict(cfg=cfg, cin=g["cin"][i], cout=g["cout"][i], resi=np.ascontiguousarray(g["resi"][ro:ro + n]), cost=float(g["cost"][i]),
                    bits=int(g["o4"][i][0]), dist=int(g["o4"][i][1]), zero_dist=int(g["o4"][i][2]), arr=g["arr"][i], fin=np.ascontiguousarray(g["fin"][fo:fo + n]))
         ro += n; fo += n
+
+
+class _OCoder(ctypes.Structure):
+    _fields_ = [("ctx", ctypes.c_uint8 * 150), ("pad", ctypes.c_uint8 * 2), ("frac", ctypes.c_uint64)]
+
+
+class _OState(ctypes.Structure):
+    _fields_ = [("tr_idx", ctypes.c_uint8 * 256), ("cbf", ctypes.c_uint8 * 768), ("tskip", ctypes.c_uint8 * 768), ("coef", ctypes.c_void_p * 12), ("resi", ctypes.c_void_p * 12)]
+
+
+def oracle_rqt(cfg, ctx150, frac, resi):
+    """hop_o_rqt on one CU.  cfg: RQT_CFG record; ctx150: 150 context states; frac: fraction the coder carries; resi: Y | Cb | Cr residual,
+    flat int16.  Returns (cost, bits, dist, zero_dist), arrays (7 x 256: tr_idx, cbf[3], tskip[3]), chosen levels, (ctx out, frac out & 32767)."""
+    O = oracle()
+    c = np.zeros(1, RQT_CFG); c[0] = cfg
+    cu = 1 << int(c[0]["log2_cu"]); n2 = cu * cu
+    coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), np.ascontiguousarray(ctx150, np.uint8).tobytes() + b"\0\0" + int(frac).to_bytes(8, "little"), 160)
+    st = _OState()
+    coefs = [[np.zeros(n2 if k == 0 else n2 // 4, np.int32) for k in range(3)] for _ in range(4)]
+    resis = [[np.zeros(n2 if k == 0 else n2 // 4, np.int16) for k in range(3)] for _ in range(4)]
+    for l in range(4):
+        for k in range(3):
+            st.coef[3 * l + k] = coefs[l][k].ctypes.data; st.resi[3 * l + k] = resis[l][k].ctypes.data
+    resi = np.ascontiguousarray(resi, np.int16)
+    ry, rcb, rcr = resi[:n2], resi[n2:n2 + n2 // 4], resi[n2 + n2 // 4:]
+    cost = ctypes.c_double(); bits = ctypes.c_uint32(); dist = ctypes.c_uint32(); zd = ctypes.c_uint32()
+    O.hop_o_rqt(c.ctypes.data_as(ctypes.c_void_p), ry.ctypes.data_as(ctypes.c_void_p), cu, rcb.ctypes.data_as(ctypes.c_void_p), rcr.ctypes.data_as(ctypes.c_void_p), cu // 2,
+                ctypes.byref(coder), ctypes.byref(st), ctypes.byref(cost), ctypes.byref(bits), ctypes.byref(dist), ctypes.byref(zd))
+    arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
+    fin = np.zeros(n2 * 3 // 2, np.int32)
+    O.hop_o_rqt_final_coeffs(c.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), fin.ctypes.data_as(ctypes.c_void_p))
+    return (cost.value, bits.value, dist.value, zd.value), arr, fin, (np.frombuffer(bytes(coder.ctx), np.uint8).copy(), int(coder.frac) & 32767)

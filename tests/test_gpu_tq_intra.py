@@ -346,3 +346,61 @@ def test_rqt_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.rqt(bad, snaps)
     ctx.close()
+
+
+def test_rqt_random_vs_oracle(hp):
+    """hop_rqt against the restatement (pinned inside the reference encoder) where the recorded calls do not go: 8 and 10 bit, QP 20..42,
+    sign hiding and transform skip on and off, the inter_split_flag tree, every CU size, smooth and spiky residuals, context states of all
+    five slice types with a non-zero carried fraction"""
+    import ctypes
+    from goldutil import oracle_rqt, RQT_CFG
+    for bd in (8, 10):
+        rng = np.random.default_rng(40 + bd)
+        W, H = 512, 256
+        org = [np.full((H, W), 1 << (bd - 1), np.int16), np.full((H // 2, W // 2), 1 << (bd - 1), np.int16), np.full((H // 2, W // 2), 1 << (bd - 1), np.int16)]
+        n = 32
+        jobs = np.zeros(n, hp.RQT_JOB_DTYPE); cfgs = np.zeros(n, RQT_CFG); snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); resis = []
+        ctx = hp.Context(W, H, bd)
+        ctx.L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        for i in range(n):
+            lg = 3 + (i % 4); cu = 1 << lg; n2 = cu * cu
+            x, y = 64 * (i % 8), 64 * (i // 8)
+            amp = float(rng.choice([4, 12, 40])) * (1 << (bd - 8))
+            yy, xx = np.mgrid[0:cu, 0:cu]
+            ry = amp * np.sin(xx * rng.uniform(0.1, 0.9) + rng.uniform(0, 3)) * np.cos(yy * rng.uniform(0.1, 0.9)) + rng.normal(0, amp / 4, (cu, cu))
+            if rng.random() < 0.5:                                                     # spikes: transform skip territory
+                m = rng.random((cu, cu)) < 0.06; ry[m] += rng.choice([-1, 1], int(m.sum())) * 6 * amp
+            ry = np.clip(np.rint(ry), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16)
+            rc = [np.clip(np.rint(ry[::2, ::2] * s + rng.normal(0, amp / 6, (cu // 2, cu // 2))), -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16) for s in (0.5, -0.4)]
+            resis.append(np.concatenate([ry.ravel(), rc[0].ravel(), rc[1].ravel()]))
+            org[0][y:y + cu, x:x + cu] += ry; org[1][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2] += rc[0]; org[2][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2] += rc[1]
+            qp = int(rng.integers(20, 43)) + 6 * (bd - 8); lam = 0.57 * 2.0 ** ((qp - 6 * (bd - 8) - 12) / 3.0); w = float(rng.choice([1.0, 1.26, 1.59]))
+            c = cfgs[i]
+            c["log2_cu"], c["qp"], c["bit_depth_y"], c["bit_depth_c"] = lg, (qp, qp - 1, qp - 2), bd, bd
+            c["sign_hide"], c["use_ts"], c["log2_max_tu"] = int(rng.integers(0, 2)), int(rng.integers(0, 2)), 5
+            c["inter_split_flag"] = int(rng.random() < 0.25)
+            # getQuadtreeTULog2MinSizeInCU: three levels (QuadtreeTUMaxDepthInter 3), or one forced split (MaxDepthInter 1, partition != 2Nx2N)
+            c["log2_min_tu_in_cu"] = min(lg - 1, 5) if c["inter_split_flag"] else max(2, lg - 2)
+            c["lambda_rd"], c["lambda_rdoq"], c["dist_weight"] = lam, (lam, lam / w, lam / w), (1.0, w, w)
+            j = jobs[i]
+            j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x, y, lg, c["qp"], i
+            j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"], j["inter_split_flag"] = c["sign_hide"], c["use_ts"], 5, c["log2_min_tu_in_cu"], c["inter_split_flag"]
+            j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = lam, c["lambda_rdoq"], (w, w)
+            assert ctx.L.hop_cabac_init(snaps[i].ctypes.data, int(rng.integers(0, 5)), int(rng.integers(20, 45))) == 0
+            left = int(rng.integers(0, 32768)); snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        ctx.upload_orig(*org)
+        for comp in range(3):
+            ctx.plane_upload("pred", comp, np.full(org[comp].shape, 1 << (bd - 1), np.int16))
+        res, co, cx = ctx.rqt(jobs, snaps)
+        off = 0; deep = ts = 0
+        for i in range(n):
+            want, arr, fin, (ocx, ofr) = oracle_rqt(cfgs[i], snaps[i, :150], int(snaps[i, 150]) | (int(snaps[i, 151]) << 8), resis[i])
+            cu = 1 << int(cfgs[i]["log2_cu"]); m = cu * cu * 3 // 2; parts = cu * cu // 16
+            r = res[i]
+            assert (float(r["cost"]), int(r["bits"]), int(r["dist"]), int(r["zero_dist"])) == want, (bd, i, cfgs[i], r["cost"], r["bits"], r["dist"], want)
+            got = np.concatenate([r["tr_idx"][None, :], r["cbf"], r["tskip"]])
+            assert np.array_equal(got[:, :parts], arr[:, :parts]) and np.array_equal(co[off:off + m], fin), (bd, i, cfgs[i])
+            assert np.array_equal(cx[i, :150], ocx) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == ofr, (bd, i)
+            deep += int(arr[0, :parts].max() >= 2); ts += int(arr[4:, :parts].any()); off += m
+        assert deep >= 2 and ts >= 2, (bd, deep, ts)
+        ctx.close()

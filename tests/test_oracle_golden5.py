@@ -50,34 +50,13 @@ def test_rdoq_on_encoder_calls():
 def test_rqt_on_encoder_calls():
     """row a8b: the restatement of xEstimateResidualQT (oracle/hop_oracle_rqt.c) on 73 calls recorded inside the encoder: cost, bits,
     distortions, transform depth / cbf / transform-skip arrays, the chosen levels and the coder state it leaves"""
-    from goldutil import encoder_rqt_calls, RQT_CFG
-    O = oracle()
-    class Coder(ctypes.Structure):
-        _fields_ = [("ctx", ctypes.c_uint8 * 150), ("pad", ctypes.c_uint8 * 2), ("frac", ctypes.c_uint64)]
-    class State(ctypes.Structure):
-        _fields_ = [("tr_idx", ctypes.c_uint8 * 256), ("cbf", ctypes.c_uint8 * 768), ("tskip", ctypes.c_uint8 * 768), ("coef", ctypes.c_void_p * 12), ("resi", ctypes.c_void_p * 12)]
+    from goldutil import encoder_rqt_calls, oracle_rqt
     n = ts = 0
     for c in encoder_rqt_calls():
-        cfg = np.zeros(1, RQT_CFG); cfg[0] = c["cfg"]
-        cu = 1 << int(cfg[0]["log2_cu"]); n2 = cu * cu
-        coder = Coder(); ctypes.memmove(ctypes.byref(coder), c["cin"].tobytes(), 160)
-        st = State()
-        coefs = [[np.zeros(n2 if k == 0 else n2 // 4, np.int32) for k in range(3)] for _ in range(4)]
-        resis = [[np.zeros(n2 if k == 0 else n2 // 4, np.int16) for k in range(3)] for _ in range(4)]
-        for l in range(4):
-            for k in range(3):
-                st.coef[3 * l + k] = coefs[l][k].ctypes.data; st.resi[3 * l + k] = resis[l][k].ctypes.data
-        ry, rcb, rcr = c["resi"][:n2], c["resi"][n2:n2 + n2 // 4], c["resi"][n2 + n2 // 4:]
-        cost = ctypes.c_double(); bits = ctypes.c_uint32(); dist = ctypes.c_uint32(); zd = ctypes.c_uint32()
-        O.hop_o_rqt(cfg.ctypes.data_as(ctypes.c_void_p), ry.ctypes.data_as(ctypes.c_void_p), cu, rcb.ctypes.data_as(ctypes.c_void_p), rcr.ctypes.data_as(ctypes.c_void_p), cu // 2,
-                    ctypes.byref(coder), ctypes.byref(st), ctypes.byref(cost), ctypes.byref(bits), ctypes.byref(dist), ctypes.byref(zd))
-        assert (cost.value, bits.value, dist.value, zd.value) == (c["cost"], c["bits"], c["dist"], c["zero_dist"]), n
-        parts = n2 // 16
-        got = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256)
-        assert np.array_equal(got[:, :parts], c["arr"].reshape(7, 256)[:, :parts]), n
-        fin = np.zeros(n2 * 3 // 2, np.int32)
-        O.hop_o_rqt_final_coeffs(cfg.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), fin.ctypes.data_as(ctypes.c_void_p))
-        assert np.array_equal(fin, c["fin"]), n
-        assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and (coder.frac & 32767) == (int(c["cout"]["frac"]) & 32767), n
-        ts += int(got[4:, :parts].any()); n += 1
+        res, arr, fin, (cx, fr) = oracle_rqt(c["cfg"], c["cin"]["ctx"], int(c["cin"]["frac"]), c["resi"])
+        parts = (1 << (2 * int(c["cfg"]["log2_cu"]))) // 16
+        assert res == (c["cost"], c["bits"], c["dist"], c["zero_dist"]), n
+        assert np.array_equal(arr[:, :parts], c["arr"].reshape(7, 256)[:, :parts]) and np.array_equal(fin, c["fin"]), n
+        assert np.array_equal(cx, c["cout"]["ctx"]) and fr == (int(c["cout"]["frac"]) & 32767), n
+        ts += int(arr[4:, :parts].any()); n += 1
     assert n == 73 and ts >= 15

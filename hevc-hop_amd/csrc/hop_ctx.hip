@@ -682,6 +682,57 @@ int hop_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cab
   return HOP_OK;
 }
 
+int hop_rqt_finish(hop_ctx* c, int n, const hop_rqt_job* jobs, hop_rqt_result* results, int32_t* coef, const hop_cabac_ctx* ctx_after, hop_cu_final* finals) {
+  if (!c || n < 0 || (n && (!jobs || !results || !coef || !ctx_after || !finals))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_finish: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_rqt_finish: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  std::vector<size_t> coff(n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const hop_rqt_job& j = jobs[i];
+    const int S = 1 << j.log2_cu;
+    const bool ok = j.log2_cu >= 3 && j.log2_cu <= 6 && j.x >= 0 && j.y >= 0 && (j.x & (S - 1)) == 0 && (j.y & (S - 1)) == 0 && j.x + S <= c->pic_w && j.y + S <= c->pic_h &&
+                    j.log2_max_tu >= 2 && j.log2_max_tu <= 5 && j.log2_min_tu_in_cu >= 2 && j.log2_min_tu_in_cu <= j.log2_max_tu && j.log2_cu - j.log2_min_tu_in_cu <= 3 &&
+                    j.log2_cu - j.log2_max_tu <= 1 && j.lambda_rd > 0.0;
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "RQT finish job %d: illegal CU / transform-tree limits / parameters", i);
+    coff[i + 1] = coff[i] + (size_t)S * S * 3 / 2;
+  }
+  std::vector<char> done(n, 0);
+  for (int first = 0; first < n; first++) {
+    if (done[first]) continue;
+    const hop_rqt_job& f = jobs[first];
+    std::vector<int> idx; std::vector<hop_rqt_job> cls; std::vector<hop_rqt_result> rr; std::vector<hop_cabac_ctx> cx;
+    for (int i = first; i < n; i++) {
+      const hop_rqt_job& j = jobs[i];
+      if (!done[i] && j.log2_cu == f.log2_cu && j.log2_max_tu == f.log2_max_tu && j.log2_min_tu_in_cu == f.log2_min_tu_in_cu && !j.use_ts == !f.use_ts) {
+        done[i] = 1; idx.push_back(i); cls.push_back(j); rr.push_back(results[i]); cx.push_back(ctx_after[i]);
+      }
+    }
+    const int m = (int)idx.size();
+    const size_t cu3 = ((size_t)3 << (2 * f.log2_cu)) / 2;
+    std::vector<int32_t> co((size_t)m * cu3);
+    for (int t = 0; t < m; t++) memcpy(co.data() + (size_t)t * cu3, coef + coff[idx[t]], cu3 * 4);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_j = 0, o_r = al((size_t)m * sizeof(hop_rqt_job)), o_o = al(o_r + (size_t)m * sizeof(hop_rqt_result)), o_x = al(o_o + (size_t)m * cu3 * 4);
+    const size_t o_f = al(o_x + (size_t)m * sizeof(hop_cabac_ctx)), o_w = al(o_f + (size_t)m * sizeof(hop_cu_final));
+    void* st; int r = hop_stage(c, o_w + hop_rqt_finish_work_bytes(f.log2_cu, f.log2_max_tu, f.log2_min_tu_in_cu, m) + 256, &st); if (r) return r;
+    char* b = (char*)st;
+    HIPCHK(c, hipMemcpyAsync(b + o_j, cls.data(), (size_t)m * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_r, rr.data(), (size_t)m * sizeof(hop_rqt_result), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_o, co.data(), (size_t)m * cu3 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_x, cx.data(), (size_t)m * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
+    r = hop_launch_rqt_finish(c, f.log2_cu, f.log2_max_tu, f.log2_min_tu_in_cu, f.use_ts ? 1 : 0, m, (const hop_rqt_job*)(b + o_j), (hop_rqt_result*)(b + o_r), (int32_t*)(b + o_o),
+                              (const hop_cabac_ctx*)(b + o_x), (hop_cu_final*)(b + o_f), b + o_w);
+    if (r) return r;
+    std::vector<hop_cu_final> ff(m);
+    HIPCHK(c, hipMemcpyAsync(rr.data(), b + o_r, (size_t)m * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(co.data(), b + o_o, (size_t)m * cu3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ff.data(), b + o_f, (size_t)m * sizeof(hop_cu_final), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < m; t++) { results[idx[t]] = rr[t]; finals[idx[t]] = ff[t]; memcpy(coef + coff[idx[t]], co.data() + (size_t)t * cu3, cu3 * 4); }
+  }
+  return HOP_OK;
+}
+
 int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop_cabac_ctx* ctx_in, hop_tu_rd_result* results, int32_t* levels_out) {
   if (!c || n < 0 || (n && (!jobs || !ctx_in || !results || !levels_out || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_tu_rd: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_tu_rd: hop_upload_orig has not been called");

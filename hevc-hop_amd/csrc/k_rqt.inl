@@ -315,3 +315,109 @@ int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = inter_split; k.sign_hide = sign_hide; k.use_ts = use_ts;
   return rqt_run_class(c, k, n, d_jobs, d_ctx_in, d_res, d_coef_out, d_ctx_out, (char*)buf, buf_bytes);
 }
+
+// =====================================================================================================================
+// The tail of TEncSearch::encodeResAndCalcRdInterCU around the quadtree (TLibEncoder/TEncSearch.cpp:6700-6723, :6804-6812), without the
+// CU-level syntax bits in between (xAddSymbolBitsInter stays with the caller): the root-cbf-zero test on the coder as the quadtree left it,
+// the arrays and levels cleared if the zero residual wins, the reconstruction Clip(prediction + residual of the chosen transform units)
+// into the context's reconstruction picture and its distortion against the original.
+//   k_fin_decide   one lane per CU: bits of a zero rqt_root_cbf, calcRdCost against the quadtree's cost
+//   k_fin_emit     one lane per CU: a table of transform-unit jobs, one slot per node of the CU's tree and component; the slots of the chosen
+//                  nodes are live (size, cbf, transform skip), the others empty
+//   k_turd_inverse(_small) in reconstruction mode: xDeQuant + xIT / xITransformSkip, Clip(prediction + residual), SSE against the original
+//   k_fin_sum      one lane per CU: the three distortions (getDistPart weights the chroma planes once per plane)
+// =====================================================================================================================
+__global__ void k_fin_decide(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ after, const int32_t* __restrict__ entropy_bits,
+                             hop_rqt_result* __restrict__ res, hop_cu_final* __restrict__ fin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* s = after[i].state;
+  const unsigned left = (unsigned)s[150] | ((unsigned)s[151] << 8);
+  const uint32_t zeroBits = (uint32_t)((left + (unsigned long long)entropy_bits[s[CX_ROOT_CBF] ^ 0]) >> 15);     // encodeQtRootCbfZero
+  hop_rqt_result* r = res + i;
+  const double zeroCost = rqt_cost(zeroBits, r->zero_dist, jobs[i].lambda_rd);
+  const int root = !(zeroCost < r->cost);
+  if (!root) {
+    const int parts = 1 << (2 * (k.log2_cu - 2));
+    for (int p = 0; p < parts; p++) { r->tr_idx[p] = 0; for (int c = 0; c < 3; c++) { r->cbf[c][p] = 0; r->tskip[c][p] = 0; } }
+  }
+  fin[i].root_cbf = (uint32_t)root;
+}
+
+__global__ __launch_bounds__(256) void k_fin_zero(RqtClass k, int n, const hop_cu_final* __restrict__ fin, int32_t* __restrict__ coef) {
+  const int i = blockIdx.x;
+  if (i >= n || fin[i].root_cbf) return;
+  const size_t m = ((size_t)3 << (2 * k.log2_cu)) / 2;
+  for (size_t q = threadIdx.x; q < m; q += 256) coef[(size_t)i * m + q] = 0;
+}
+
+__global__ void k_fin_emit(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, int bd_y, int bd_c, int d0, int d1, int nj, const hop_rqt_result* __restrict__ res,
+                           const hop_cu_final* __restrict__ fin, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, uint32_t* __restrict__ abs_flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const hop_rqt_job jb = jobs[i];
+  const hop_rqt_result* r = res + i;
+  const int root = (int)fin[i].root_cbf, parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu), base = (size_t)i * (cu2 + (cu2 >> 1));
+  int q = 0;
+  for (int d = d0; d <= d1; d++) {
+    const int log2 = k.log2_cu - d, np = parts >> (2 * d);
+    for (int node = 0; node < (1 << (2 * d)); node++) {
+      const int part = node * np;
+      const bool chosen = root ? (r->tr_idx[part] == d) : (d == d0);
+      for (int c = 0; c < 3; c++, q++) {
+        hop_tu_rd_job j; memset(&j, 0, sizeof(j));
+        const bool have = chosen && (c == 0 || log2 > 2 || (part & 3) == 0);      // a 4x4 luma TU shares the chroma block of its 8x8 parent (first sibling)
+        j.log2_size = have ? (c ? (log2 == 2 ? 2 : log2 - 1) : log2) : 0;
+        j.x = jb.x + rqt_zx(part); j.y = jb.y + rqt_zy(part); j.comp = c; j.qp_scaled = jb.qp_scaled[c]; j.bit_depth = c ? bd_c : bd_y; j.is_intra = 1;
+        j.flags = (root && r->tskip[c][part]) ? HOP_TU_RD_TS : 0; j.use_ts = k.use_ts;
+        tuj[(size_t)i * nj + q] = j;
+        off[(size_t)i * nj + q] = (int64_t)(base + (c == 0 ? (size_t)(16 * part) : cu2 + (size_t)(c - 1) * (cu2 >> 2) + (size_t)(4 * part)));
+        abs_flag[(size_t)i * nj + q] = (root && have) ? (uint32_t)((r->cbf[c][part] >> d) & 1) : 0u;
+      }
+    }
+  }
+}
+
+__global__ void k_fin_sum(const hop_rqt_job* __restrict__ jobs, int n, int nj, const hop_tu_rd_job* __restrict__ tuj, const uint32_t* __restrict__ sse, hop_cu_final* __restrict__ fin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long s3[3] = { 0, 0, 0 };
+  for (int q = 0; q < nj; q++) if (tuj[(size_t)i * nj + q].log2_size >= 2) s3[q % 3] += sse[(size_t)i * nj + q];
+  const hop_rqt_job jb = jobs[i];
+  fin[i].dist[0] = (uint32_t)s3[0];
+  fin[i].dist[1] = (uint32_t)(int)(jb.dist_weight[0] * (uint32_t)s3[1]);           // getDistPart, TComRdCost.cpp:493-497
+  fin[i].dist[2] = (uint32_t)(int)(jb.dist_weight[1] * (uint32_t)s3[2]);
+}
+
+static int rqt_jobs_per_cu(int log2_cu, int log2_max_tu, int log2_min_tu, int* d0, int* d1) {
+  *d0 = log2_cu > log2_max_tu ? log2_cu - log2_max_tu : 0; *d1 = log2_cu - log2_min_tu;
+  int nodes = 0; for (int d = *d0; d <= *d1; d++) nodes += 1 << (2 * d);
+  return 3 * nodes;
+}
+size_t hop_rqt_finish_work_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n) {
+  int d0, d1; const int nj = rqt_jobs_per_cu(log2_cu, log2_max_tu, log2_min_tu, &d0, &d1);
+  return (size_t)n * nj * (sizeof(hop_tu_rd_job) + 8 + 4 + 4) + 4 * 256;
+}
+// one class of CUs; d_res / d_coef are updated in place (cleared where the zero residual wins), the reconstruction goes to the context's picture
+int hop_launch_rqt_finish(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int use_ts, int n, const hop_rqt_job* d_jobs, hop_rqt_result* d_res, int32_t* d_coef,
+                          const hop_cabac_ctx* d_after, hop_cu_final* d_fin, void* buf) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = 0; k.use_ts = use_ts;
+  int d0, d1; const int nj = rqt_jobs_per_cu(log2_cu, log2_max_tu, log2_min_tu, &d0, &d1);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t nt = (size_t)n * nj;
+  char* b = (char*)buf; size_t o = 0;
+  hop_tu_rd_job* tuj = (hop_tu_rd_job*)(b + o); o = al(o + nt * sizeof(hop_tu_rd_job));
+  int64_t* off = (int64_t*)(b + o); o = al(o + nt * 8);
+  uint32_t* af = (uint32_t*)(b + o); o = al(o + nt * 4);
+  uint32_t* sse = (uint32_t*)(b + o);
+  const int g256 = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fin_decide, dim3(g256), dim3(256), 0, c->stream, k, d_jobs, n, d_after, hop_entropy_bits_device(c), d_res, d_fin);
+  hipLaunchKernelGGL(k_fin_zero, dim3(n), dim3(256), 0, c->stream, k, n, d_fin, d_coef);
+  hipLaunchKernelGGL(k_fin_emit, dim3(g256), dim3(256), 0, c->stream, k, d_jobs, n, c->bd_y, c->bd_c, d0, d1, nj, d_res, d_fin, tuj, off, af);
+  int r = hop_launch_tu_recon(c, (int)nt, tuj, off, d_coef, af, sse); if (r) return r;
+  hipLaunchKernelGGL(k_fin_sum, dim3(g256), dim3(256), 0, c->stream, d_jobs, n, nj, tuj, sse, d_fin);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "rqt finish launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

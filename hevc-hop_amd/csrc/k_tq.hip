@@ -202,13 +202,24 @@ __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __res
   const hop_tu_rd_job jb = jobs[blockIdx.x];
   if (jb.log2_size <= 3) return;                                   // k_turd_inverse_small takes it
   if (abs_sum[blockIdx.x] == 0) {
-    if (threadIdx.x == 0) nz_sse[blockIdx.x] = 0;
-    if (jb.is_intra) {                                             // reconstruction = prediction (TEncSearch.cpp:1118-1127,1133-1152)
-      const bool ch = jb.comp != 0; const int pt = ch ? pic.pic_w >> 1 : pic.pic_w, xx = ch ? jb.x >> 1 : jb.x, yy = ch ? jb.y >> 1 : jb.y, NNz = 1 << jb.log2_size;
-      const int16_t* pp = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)yy * pt + xx;
-      int16_t* rr = (jb.comp == 0 ? rec_y : jb.comp == 1 ? rec_cb : rec_cr) + (size_t)yy * pt + xx;
-      for (int i = threadIdx.x; i < NNz * NNz; i += 256) { const int r = i >> jb.log2_size, c2 = i & (NNz - 1); rr[(size_t)r * pt + c2] = pp[(size_t)r * pt + c2]; }
+    if (!jb.is_intra) { if (threadIdx.x == 0) nz_sse[blockIdx.x] = 0; return; }
+    // reconstruction = prediction (TEncSearch.cpp:1118-1127,1133-1152); its distortion against the original is reported like a coded block's
+    const bool ch = jb.comp != 0; const int pt = ch ? pic.pic_w >> 1 : pic.pic_w, xx = ch ? jb.x >> 1 : jb.x, yy = ch ? jb.y >> 1 : jb.y, NNz = 1 << jb.log2_size;
+    const int16_t* pp = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)yy * pt + xx;
+    const int16_t* oo = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)yy * pt + xx;
+    int16_t* rr = (jb.comp == 0 ? rec_y : jb.comp == 1 ? rec_cb : rec_cr) + (size_t)yy * pt + xx;
+    if (threadIdx.x == 0) sh.acc = 0;
+    __syncthreads();
+    unsigned part0 = 0; const unsigned ss0 = (unsigned)(((ch ? pic.bd_c : pic.bd_y) - 8) << 1);
+    for (int i = threadIdx.x; i < NNz * NNz; i += 256) {
+      const int r = i >> jb.log2_size, c2 = i & (NNz - 1);
+      const int v = pp[(size_t)r * pt + c2], e = v - (int)oo[(size_t)r * pt + c2];
+      rr[(size_t)r * pt + c2] = (int16_t)v; part0 += (unsigned)(e * e) >> ss0;
     }
+    part0 = (unsigned)hopd_wave_sum((int)part0);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh.acc, part0);
+    __syncthreads();
+    if (threadIdx.x == 0) nz_sse[blockIdx.x] = sh.acc;
     return;
   }
   const int tid = threadIdx.x, log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256) void k_turd_inverse_small(const hop_tu_rd_job*
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + w;
   if (j >= n) return;
   const hop_tu_rd_job jb = jobs[j];
-  if (jb.log2_size > 3) return;
+  if (jb.log2_size > 3 || jb.log2_size < 2) return;                // < 2: an empty slot of a job table (k_rqt.inl)
   const int log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
   const bool chroma = jb.comp != 0, live = lane < NN;
   const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
@@ -328,8 +339,11 @@ __global__ __launch_bounds__(256) void k_turd_inverse_small(const hop_tu_rd_job*
   int16_t* rec = (jb.comp == 0 ? rec_y : jb.comp == 1 ? rec_cb : rec_cr) + (size_t)y0 * pitch + x0;
   const int r = lane >> log2N, c = lane & (N - 1);
   if (abs_sum[j] == 0) {
-    if (lane == 0) nz_sse[j] = 0;
-    if (jb.is_intra && live) rec[(size_t)r * pitch + c] = prd[(size_t)r * pitch + c];       // reconstruction = prediction
+    if (!jb.is_intra) { if (lane == 0) nz_sse[j] = 0; return; }
+    int e0 = 0;                                                    // reconstruction = prediction; its distortion against the original
+    if (live) { const int v = prd[(size_t)r * pitch + c]; rec[(size_t)r * pitch + c] = (int16_t)v; e0 = v - (int)org[(size_t)r * pitch + c]; }
+    const unsigned z0 = (unsigned)hopd_wave_sum((int)((unsigned)(e0 * e0) >> (unsigned)((bd - 8) << 1)));
+    if (lane == 0) nz_sse[j] = z0;
     return;
   }
   const bool dst = jb.use_dst && N == 4 && !chroma;
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(256) void k_turd_inverse_small(const hop_tu_rd_job*
   const int32_t* lv = levels + coef_off[j];
   const int dq = live ? clip16((clip16(lv[lane]) * scale + dadd) >> dshift) : 0;
   int rr;
-  if ((jb.flags & HOP_TU_RD_TS) && !jb.is_intra) rr = (int)(int16_t)((dq + (1 << (transformShift - 1))) >> transformShift);      // xITransformSkip
+  if (jb.flags & HOP_TU_RD_TS) rr = (int)(int16_t)((dq + (1 << (transformShift - 1))) >> transformShift);      // xITransformSkip
   else {
     sh.a[w][lane] = (int16_t)dq;
     __builtin_amdgcn_wave_barrier();
@@ -476,5 +490,18 @@ int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   hop_prof_end(c, pr2);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "tu_rd launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+// the inverse path alone in reconstruction mode (is_intra jobs: Clip(prediction + residual) into the reconstruction picture, SSE against the
+// original); slots with log2_size < 2 are empty
+int hop_launch_tu_recon(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const int64_t* d_coef_off, const int32_t* d_levels, const uint32_t* d_abs_sum, uint32_t* d_sse) {
+  hop_pics pic = hop_make_pics(c);
+  const int pr = hop_prof_begin(c, HOP_K_TQ, (uint64_t)n);
+  hipLaunchKernelGGL(k_turd_inverse, dim3(n), dim3(256), 0, c->stream, d_jobs, pic, d_coef_off, d_levels, d_abs_sum, d_sse, c->rec[0], c->rec[1], c->rec[2]);
+  hipLaunchKernelGGL(k_turd_inverse_small, dim3((n + 3) / 4), dim3(256), 0, c->stream, d_jobs, n, pic, d_coef_off, d_levels, d_abs_sum, d_sse, c->rec[0], c->rec[1], c->rec[2]);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "tu recon launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }

@@ -295,6 +295,15 @@ class Context:
         self._chk(self.L.hop_rqt(self.h, len(jobs), jobs.ctypes.data, len(ctx_in), ctx_in.ctypes.data, res.ctypes.data, co.ctypes.data, cx.ctypes.data), "hop_rqt")
         return res, co, cx
 
+    def rqt_finish(self, jobs, res, coef, ctx_after):
+        """the tail of encodeResAndCalcRdInterCU on the outputs of rqt(): returns (results, levels) updated in place where the zero residual
+        wins, and per CU (root_cbf, dist Y, Cb, Cr); the reconstruction is in the context's reconstruction picture"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); res = np.ascontiguousarray(res, RQT_RESULT_DTYPE).copy(); coef = np.ascontiguousarray(coef, np.int32).copy()
+        cx = np.ascontiguousarray(ctx_after, np.uint8); fin = np.zeros((len(jobs), 4), np.uint32)
+        self.L.hop_rqt_finish.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+        self._chk(self.L.hop_rqt_finish(self.h, len(jobs), jobs.ctypes.data, res.ctypes.data, coef.ctypes.data, cx.ctypes.data, fin.ctypes.data), "hop_rqt_finish")
+        return res, coef, fin
+
     def intra_pred(self, jobs, modes):
         n = len(jobs)
         arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)

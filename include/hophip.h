@@ -354,6 +354,17 @@ int hop_rqt_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt
 int hop_rqt_device_classes(hop_ctx* ctx, int n_classes, const int* n, const hop_rqt_job* const* d_jobs, const hop_rqt_job* cls, const hop_cabac_ctx* d_ctx_in,
                            hop_rqt_result* const* d_results, int32_t* const* d_coef_out, hop_cabac_ctx* const* d_ctx_out);
 
+/* replaces: the tail of TEncSearch::encodeResAndCalcRdInterCU around the quadtree (TLibEncoder/TEncSearch.cpp:6700-6723, :6804-6812) without
+ * the CU-level syntax bits in between (xAddSymbolBitsInter stays with the caller): the root-cbf-zero test -- bits of a zero rqt_root_cbf on
+ * the coder as the quadtree left it (ctx_after = hop_rqt's ctx_out) against the quadtree's cost --, results / coef cleared in place where
+ * the zero residual wins, the reconstruction Clip(prediction + residual of the chosen transform units) written into the context's
+ * reconstruction picture (hop_recon_download), and its distortion against the original. */
+typedef struct {
+  uint32_t root_cbf;               /* getQtRootCbf after the test */
+  uint32_t dist[3];                /* getDistPart of the reconstruction: Y, Cb, Cr (the chroma planes weighted) */
+} hop_cu_final;
+int hop_rqt_finish(hop_ctx* ctx, int n, const hop_rqt_job* jobs, hop_rqt_result* results, int32_t* coef, const hop_cabac_ctx* ctx_after, hop_cu_final* finals);
+
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
  * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and

@@ -309,6 +309,7 @@ UInt TComRdCost::calcHAD(Int bitDepth, Pel* pi0, Int iStride0, Pel* pi1, Int iSt
   return hop_o_calc_had(pi0, iStride0, pi1, iStride1, iWidth, iHeight, bitDepth);
 }
 
+namespace { int g_fin_pending = 0; }   // set by the residual-quadtree shim: the next three getDistPart calls are the final Y / Cb / Cr distortions of that CU (:6807-6810)
 UInt TComRdCost::getDistPart(Int bitDepth, Pel* piCur, Int iCurStride, Pel* piOrg, Int iOrgStride, UInt uiBlkWidth, UInt uiBlkHeight, TextType eText, DFunc eDFunc)
 {
   g_calls4[3]++;
@@ -316,9 +317,20 @@ UInt TComRdCost::getDistPart(Int bitDepth, Pel* piCur, Int iCurStride, Pel* piOr
   if (eDFunc == DF_SSE) d = hop_o_sse(piOrg, iOrgStride, piCur, iCurStride, uiBlkWidth, uiBlkHeight, bitDepth);
   else if (eDFunc == DF_SAD) d = hop_o_sad(piOrg, iOrgStride, piCur, iCurStride, uiBlkWidth, uiBlkHeight, bitDepth, 0);
   else { fprintf(stderr, "hop shim: getDistPart with distortion function %d is not on the replaced path\n", (int)eDFunc); abort(); }
-  if (eText == TEXT_CHROMA_U) return (UInt)((Int)(m_cbDistortionWeight * d));
-  if (eText == TEXT_CHROMA_V) return (UInt)((Int)(m_crDistortionWeight * d));
-  return d;
+  UInt out = d;
+  if (eText == TEXT_CHROMA_U) out = (UInt)((Int)(m_cbDistortionWeight * d));
+  if (eText == TEXT_CHROMA_V) out = (UInt)((Int)(m_crDistortionWeight * d));
+  if (g_fin_pending > 0) {                                          // HOP_SHIM_TRACE_FIN=<file>: width, distortion, reconstruction, original of the three final calls
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_FIN"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) {
+      const int32_t hd[2] = { (int32_t)uiBlkWidth, (int32_t)out }; fwrite(hd, 4, 2, f);
+      for (UInt y = 0; y < uiBlkHeight; y++) fwrite(piCur + y * iCurStride, 2, uiBlkWidth, f);
+      for (UInt y = 0; y < uiBlkHeight; y++) fwrite(piOrg + y * iOrgStride, 2, uiBlkWidth, f);
+    }
+    g_fin_pending--;
+  }
+  return out;
 }
 
 // ---- a9 transform skip, a13 SS-reference upkeep ----
@@ -473,4 +485,5 @@ Void TEncSearch::xEstimateResidualQT(TComDataCU* pcCU, UInt uiQuadrant, UInt uiA
                                        memcpy(t.getCrAddr() + y * t.getCStride(), st.resi[l][2] + y * (cu / 2), (cu / 2) * sizeof(Pel)); }
   }
   coder_put(m_pcRDGoOnSbacCoder, &coder);
+  g_fin_pending = 3;
 }

@@ -281,3 +281,42 @@ void hop_o_rqt_final_coeffs(const hop_o_rqt_cfg* cfg, const hop_o_rqt_state* st,
     memcpy(out + cu2 + (cu2 >> 2) + 4 * p, st->coef[layer][2] + 4 * p, 4 * sizeof(int32_t));
   }
 }
+
+/* The tail of TEncSearch::encodeResAndCalcRdInterCU around the quadtree (TLibEncoder/TEncSearch.cpp:6700-6723, :6804-6812), without the
+ * CU-level syntax bits in between (xAddSymbolBitsInter, the caller's): the root-cbf-zero test -- bits of a zero rqt_root_cbf counted on the
+ * coder as xEstimateResidualQT left it, against the quadtree's cost --, the arrays cleared if it wins, the reconstruction
+ * Clip(prediction + residual of the chosen transform units) and its distortion against the original (chroma weighted per plane).
+ * coder: the state after hop_o_rqt; cost / zero_dist: its results.  pred / org / rec: CU planes, pitch = CU size (chroma half).
+ * Returns the root cbf (0: the zero residual won); dist3: Y, Cb, Cr distortion of the reconstruction. */
+int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
+                          const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef)
+{
+  const int cu = 1 << cfg->log2_cu, cu2 = cu * cu, parts = cu2 >> 4;
+  hop_o_coder c = *coder;
+  c.frac &= 32767;
+  c.frac += hop_o_cabac_root_cbf_bits(&c.ctx, 0);
+  const double zeroCost = hop_o_calc_rd_cost((uint32_t)(c.frac >> 15), zero_dist, cfg->lambda_rd);
+  const int root = !(zeroCost < cost);
+  if (!root) {
+    memset(st->tr_idx, 0, (size_t)parts);
+    for (int k = 0; k < 3; k++) { memset(st->cbf[k], 0, (size_t)parts); memset(st->tskip[k], 0, (size_t)parts); }
+    if (final_coef) memset(final_coef, 0, sizeof(int32_t) * (size_t)(cu2 + cu2 / 2));
+  } else if (final_coef) hop_o_rqt_final_coeffs(cfg, st, final_coef);
+  for (int k = 0; k < 3; k++) {
+    const int w = k ? cu >> 1 : cu, bd = k ? cfg->bit_depth_c : cfg->bit_depth_y, maxv = (1 << bd) - 1;
+    for (int y = 0; y < w; y++) for (int x = 0; x < w; x++) {
+      int r = 0;
+      if (root) {                                                    /* xSetResidualQTData, spatial: the layer of the partition's transform depth */
+        const int px = k ? 2 * x : x, py = k ? 2 * y : y;
+        int p = 0; for (int b = 0; b < 4; b++) p |= (((px >> 2) >> b) & 1) << (2 * b) | (((py >> 2) >> b) & 1) << (2 * b + 1);
+        const int layer = cfg->log2_max_tu - (cfg->log2_cu - st->tr_idx[p]);
+        r = st->resi[layer][k][y * w + x];
+      }
+      int v = pred[k][y * w + x] + r;
+      rec[k][y * w + x] = (int16_t)(v < 0 ? 0 : v > maxv ? maxv : v);
+    }
+    const uint32_t sse = hop_o_sse(rec[k], w, org[k], w, w, w, bd);
+    dist3[k] = k ? (uint32_t)(int)(cfg->dist_weight[k] * sse) : sse;
+  }
+  return root;
+}

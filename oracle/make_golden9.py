@@ -3,7 +3,8 @@
 tests/golden/encoder_rqt_calls.npz: the shim encoder (oracle/enc_shim.cpp; its bitstream equals the unmodified reference's,
 tests/test_encoder_shim.py) runs the 128x128 golden lenslet and a 64x64 sharp-edged frame (on which the 4x4 transform-skip variant wins)
 with HOP_SHIM_TRACE_RQT; per CU size 14 + up to 6 calls are kept (the deepest transform trees first): parameters, coder state in / out, residual planes, cost / bits / distortion, the transform depth,
-cbf and transform-skip arrays and the chosen levels.  Replayed by tests/test_oracle_golden5.py (restatement) and
+cbf and transform-skip arrays and the chosen levels, plus what encodeResAndCalcRdInterCU
+made of it afterwards (HOP_SHIM_TRACE_FIN: reconstruction, original and the three final distortions).  Replayed by tests/test_oracle_golden5.py (restatement) and
 tests/test_gpu_tq_intra.py::test_rqt_encoder_calls (hop_rqt on the GPU).  Needs /root/reference (build container)."""
 import os, struct, subprocess, sys, tempfile
 import numpy as np
@@ -21,11 +22,11 @@ def calls(W, H, frame):
     Y, Cb, Cr = frame
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "in.yuv"), "wb").write(Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes())
-        tr = os.path.join(td, "rqt.bin")
+        tr = os.path.join(td, "rqt.bin"); tf = os.path.join(td, "fin.bin")
         r = subprocess.run([exe, "-c", "/root/reference/cfg/3DHencoder_intra_main.cfg", "-i", "in.yuv", "-wdt", str(W), "-hgt", str(H), "-fr", "30", "-f", "1",
-                            "-q", "32", "--MIsize=16", "-b", "s.bin", "-o", "rec.yuv"], cwd=td, capture_output=True, text=True, env=dict(os.environ, HOP_SHIM_TRACE_RQT=tr))
+                            "-q", "32", "--MIsize=16", "-b", "s.bin", "-o", "rec.yuv"], cwd=td, capture_output=True, text=True, env=dict(os.environ, HOP_SHIM_TRACE_RQT=tr, HOP_SHIM_TRACE_FIN=tf))
         assert r.returncode == 0, r.stderr[-2000:]
-        b = open(tr, "rb").read()
+        b = open(tr, "rb").read(); fb = open(tf, "rb").read()
     recs, o = [], 0
     while o < len(b):
         cfg = np.frombuffer(b, CFG, 1, o)[0]; o += 104
@@ -38,6 +39,18 @@ def calls(W, H, frame):
         arr = np.frombuffer(b, "u1", 256 * 7, o).copy(); o += 256 * 7
         fin = np.frombuffer(b, "<i4", n * 3 // 2, o).copy(); o += n * 6
         recs.append(dict(cfg=cfg, cin=cin, cout=cout, resi=resi, cost=cost, o4=o4, arr=arr, fin=fin))
+    # the three final getDistPart calls of encodeResAndCalcRdInterCU after each quadtree (:6807-6810): reconstruction, original, distortion
+    fo = 0
+    for r in recs:
+        cu = 1 << int(r["cfg"]["log2_cu"]); rec, org, d3 = [], [], []
+        for k in range(3):
+            w, dist = struct.unpack_from("<2i", fb, fo); fo += 8
+            assert w == (cu >> 1 if k else cu), (w, cu, k)
+            rec.append(np.frombuffer(fb, "<i2", w * w, fo).copy()); fo += 2 * w * w
+            org.append(np.frombuffer(fb, "<i2", w * w, fo).copy()); fo += 2 * w * w
+            d3.append(dist)
+        r["rec"], r["org"], r["d3"] = np.concatenate(rec), np.concatenate(org), d3
+    assert fo == len(fb)
     print(len(recs), "calls")
     return recs
 
@@ -53,8 +66,10 @@ def main():
         parts = 1 << (2 * (lg - 2))
         L.sort(key=lambda r: -(int(r["arr"][:parts].max()) * 1000 + int(np.count_nonzero(r["fin"]))))       # deepest trees, most levels first
         ts = [r for r in L if r["arr"][1024:].any()][:4]                  # calls in which the transform-skip variant won somewhere
-        pick = ts + L[:PER_SIZE - 4 - len(ts)] + [L[i] for i in rng.permutation(len(L))[:4]]
-        print("size", 1 << lg, len(L), "calls, max depth", [int(r["arr"][:parts].max()) for r in pick][:6], "transform skip", sum(int(r["arr"][1024:].any()) for r in pick))
+        # calls after which the zero residual won the root test although the quadtree had levels (the reconstruction is the prediction)
+        zr = [r for r in L if r["arr"][256:1024].any() and np.array_equal(r["rec"], (r["org"] - r["resi"]).astype(np.int16))][:3]
+        pick = ts + zr + L[:PER_SIZE - 4 - len(ts) - len(zr)] + [L[i] for i in rng.permutation(len(L))[:4]]
+        print("size", 1 << lg, len(L), "calls,", len(zr), "root-zero wins kept, max depth", [int(r["arr"][:parts].max()) for r in pick][:6], "transform skip", sum(int(r["arr"][1024:].any()) for r in pick))
         keep += pick
         S = [r for r in sharp if int(r["cfg"]["log2_cu"]) == lg and r["arr"][1024:].any()]
         keep += [S[i] for i in rng.permutation(len(S))[:6]]
@@ -62,7 +77,8 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "encoder_rqt_calls.npz")
     np.savez_compressed(path, cfg=np.array([r["cfg"] for r in keep]), cin=np.array([r["cin"] for r in keep]), cout=np.array([r["cout"] for r in keep]),
                         resi=np.concatenate([r["resi"] for r in keep]), cost=np.array([r["cost"] for r in keep]), o4=np.array([r["o4"] for r in keep], np.uint32),
-                        arr=np.stack([r["arr"] for r in keep]), fin=np.concatenate([r["fin"] for r in keep]))
+                        arr=np.stack([r["arr"] for r in keep]), fin=np.concatenate([r["fin"] for r in keep]),
+                        rec=np.concatenate([r["rec"] for r in keep]), org=np.concatenate([r["org"] for r in keep]), d3=np.array([r["d3"] for r in keep], np.uint32))
     print(len(keep), "calls ->", path, os.path.getsize(path), "bytes")
 
 

@@ -104,7 +104,8 @@ def encoder_rqt_calls():
     for i in range(len(g["cost"])):
         cfg = g["cfg"][i]; cu = 1 << int(cfg["log2_cu"]); n = cu * cu * 3 // 2
         yield dict(cfg=cfg, cin=g["cin"][i], cout=g["cout"][i], resi=np.ascontiguousarray(g["resi"][ro:ro + n]), cost=float(g["cost"][i]),
-                   bits=int(g["o4"][i][0]), dist=int(g["o4"][i][1]), zero_dist=int(g["o4"][i][2]), arr=g["arr"][i], fin=np.ascontiguousarray(g["fin"][fo:fo + n]))
+                   bits=int(g["o4"][i][0]), dist=int(g["o4"][i][1]), zero_dist=int(g["o4"][i][2]), arr=g["arr"][i], fin=np.ascontiguousarray(g["fin"][fo:fo + n]),
+                   rec=np.ascontiguousarray(g["rec"][ro:ro + n]), org=np.ascontiguousarray(g["org"][ro:ro + n]), d3=[int(v) for v in g["d3"][i]])
         ro += n; fo += n
 
 
@@ -116,7 +117,7 @@ class _OState(ctypes.Structure):
     _fields_ = [("tr_idx", ctypes.c_uint8 * 256), ("cbf", ctypes.c_uint8 * 768), ("tskip", ctypes.c_uint8 * 768), ("coef", ctypes.c_void_p * 12), ("resi", ctypes.c_void_p * 12)]
 
 
-def oracle_rqt(cfg, ctx150, frac, resi):
+def oracle_rqt(cfg, ctx150, frac, resi, pred=None, org=None):
     """hop_o_rqt on one CU.  cfg: RQT_CFG record; ctx150: 150 context states; frac: fraction the coder carries; resi: Y | Cb | Cr residual,
     flat int16.  Returns (cost, bits, dist, zero_dist), arrays (7 x 256: tr_idx, cbf[3], tskip[3]), chosen levels, (ctx out, frac out & 32767)."""
     O = oracle()
@@ -137,4 +138,18 @@ def oracle_rqt(cfg, ctx150, frac, resi):
     arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
     fin = np.zeros(n2 * 3 // 2, np.int32)
     O.hop_o_rqt_final_coeffs(c.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), fin.ctypes.data_as(ctypes.c_void_p))
-    return (cost.value, bits.value, dist.value, zd.value), arr, fin, (np.frombuffer(bytes(coder.ctx), np.uint8).copy(), int(coder.frac) & 32767)
+    out = (cost.value, bits.value, dist.value, zd.value), arr, fin, (np.frombuffer(bytes(coder.ctx), np.uint8).copy(), int(coder.frac) & 32767)
+    if pred is None:
+        return out
+    # the tail of encodeResAndCalcRdInterCU: root-cbf-zero test on the coder as the quadtree left it, reconstruction, final distortions
+    P3 = ctypes.c_void_p * 3
+    pr = [np.ascontiguousarray(a, np.int16) for a in (pred[:n2], pred[n2:n2 + n2 // 4], pred[n2 + n2 // 4:])]
+    og = [np.ascontiguousarray(a, np.int16) for a in (org[:n2], org[n2:n2 + n2 // 4], org[n2 + n2 // 4:])]
+    rc = [np.zeros(n2, np.int16), np.zeros(n2 // 4, np.int16), np.zeros(n2 // 4, np.int16)]
+    d3 = (ctypes.c_uint32 * 3)(); fin2 = np.zeros(n2 * 3 // 2, np.int32)
+    O.hop_o_inter_cu_finish.restype = ctypes.c_int
+    O.hop_o_inter_cu_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    root = O.hop_o_inter_cu_finish(c.ctypes.data, ctypes.addressof(st), ctypes.addressof(coder), cost.value, zd.value, P3(*[a.ctypes.data for a in pr]), P3(*[a.ctypes.data for a in og]),
+                                   P3(*[a.ctypes.data for a in rc]), d3, fin2.ctypes.data)
+    arr2 = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
+    return out + (dict(root=root, rec=np.concatenate(rc), d3=list(d3), arr=arr2, fin=fin2),)

@@ -346,6 +346,40 @@ def test_rqt_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.rqt(bad, snaps)
     ctx.close()
+    # the tail of encodeResAndCalcRdInterCU (hop_rqt_finish) on the same calls, now with the encoder's own prediction and original: the
+    # root-cbf-zero test, the reconstruction and the three final distortions the encoder computed (:6807-6810)
+    org = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+    prd = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+    for i, c in enumerate(cases):
+        cu = 1 << int(c["cfg"]["log2_cu"]); n2 = cu * cu
+        x, y = 64 * (i % 8), 64 * (i // 8)
+        o, p = c["org"], (c["org"] - c["resi"]).astype(np.int16)
+        for k, (a, b, w) in enumerate(((0, n2, cu), (n2, n2 + n2 // 4, cu // 2), (n2 + n2 // 4, n2 * 3 // 2, cu // 2))):
+            xx, yy = (x, y) if k == 0 else (x // 2, y // 2)
+            org[k][yy:yy + w, xx:xx + w] = o[a:b].reshape(w, w); prd[k][yy:yy + w, xx:xx + w] = p[a:b].reshape(w, w)
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(*org)
+    for comp in range(3):
+        ctx.plane_upload("pred", comp, prd[comp]); ctx.plane_upload("recon", comp, np.zeros(org[comp].shape, np.int16))
+    res2, co2, cx2 = ctx.rqt(jobs, snaps)
+    assert np.array_equal(res2["bits"], res["bits"]) and np.array_equal(co2, co)           # the residual is the same, so is the quadtree
+    res3, co3, fin = ctx.rqt_finish(jobs, res2, co2, cx2)
+    rec = [ctx.recon_download(k) for k in range(3)]
+    off = 0; zeros = 0
+    for i, c in enumerate(cases):
+        cu = 1 << int(c["cfg"]["log2_cu"]); n2 = cu * cu; parts = n2 // 16
+        x, y = 64 * (i % 8), 64 * (i // 8)
+        assert [int(v) for v in fin[i, 1:]] == c["d3"], (i, cu, fin[i], c["d3"])
+        got = np.concatenate([rec[0][y:y + cu, x:x + cu].ravel(), rec[1][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2].ravel(), rec[2][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2].ravel()])
+        assert np.array_equal(got, c["rec"]), (i, cu, int(fin[i, 0]))
+        if fin[i, 0] == 0:
+            zeros += 1
+            assert not res3[i]["cbf"][:, :parts].any() and not res3[i]["tr_idx"][:parts].any() and not co3[off:off + n2 * 3 // 2].any()
+        else:
+            assert np.array_equal(co3[off:off + n2 * 3 // 2], c["fin"]) and np.array_equal(res3[i]["cbf"], res2[i]["cbf"])
+        off += n2 * 3 // 2
+    assert zeros >= 3
+    ctx.close()
 
 
 def test_rqt_random_vs_oracle(hp):

@@ -51,12 +51,16 @@ def test_rqt_on_encoder_calls():
     """row a8b: the restatement of xEstimateResidualQT (oracle/hop_oracle_rqt.c) on 73 calls recorded inside the encoder: cost, bits,
     distortions, transform depth / cbf / transform-skip arrays, the chosen levels and the coder state it leaves"""
     from goldutil import encoder_rqt_calls, oracle_rqt
-    n = ts = 0
+    n = ts = zeros = 0
     for c in encoder_rqt_calls():
-        res, arr, fin, (cx, fr) = oracle_rqt(c["cfg"], c["cin"]["ctx"], int(c["cin"]["frac"]), c["resi"])
+        pred = (c["org"] - c["resi"]).astype(np.int16)
+        res, arr, fin, (cx, fr), tail = oracle_rqt(c["cfg"], c["cin"]["ctx"], int(c["cin"]["frac"]), c["resi"], pred, c["org"])
+        # what encodeResAndCalcRdInterCU made of it: root-cbf-zero test, reconstruction, the three final distortions
+        assert np.array_equal(tail["rec"], c["rec"]) and tail["d3"] == c["d3"], (n, tail["root"], tail["d3"], c["d3"])
+        zeros += int(tail["root"] == 0)
         parts = (1 << (2 * int(c["cfg"]["log2_cu"]))) // 16
         assert res == (c["cost"], c["bits"], c["dist"], c["zero_dist"]), n
         assert np.array_equal(arr[:, :parts], c["arr"].reshape(7, 256)[:, :parts]) and np.array_equal(fin, c["fin"]), n
         assert np.array_equal(cx, c["cout"]["ctx"]) and fr == (int(c["cout"]["frac"]) & 32767), n
         ts += int(arr[4:, :parts].any()); n += 1
-    assert n == 73 and ts >= 15
+    assert n == 73 and ts >= 15 and zeros >= 1, zeros

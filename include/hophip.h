@@ -278,8 +278,8 @@ int hop_coeff_bits_device(hop_ctx* ctx, int n, const hop_coeff_bits_job* d_jobs,
 /* One component TU of TEncSearch::xEstimateResidualQT (TLibEncoder/TEncSearch.cpp:6896-7200), default transform:
  * residual = original - prediction picture -> xT -> estBit from the snapshot -> xRateDistOptQuant -> bits of cbf flag + levels
  * from the snapshot (integer, as getNumberOfWrittenBits) -> xDeQuant + xIT -> distortion in the residual domain -> the
- * cbf-zero decision on TComRdCost::calcRdCost values (:7008-7032).  Not included: the 4x4 transform-skip retry (:7210-7440),
- * the split recursion and the root-cbf decision of the caller. */
+ * cbf-zero decision on TComRdCost::calcRdCost values (:7008-7032).  flags select the 4x4 transform-skip variant of the retry
+ * (:7210-7440); the retry's decision, the split recursion and the subtree recount are hop_rqt, the root-cbf decision hop_rqt_finish. */
 #define HOP_TU_RD_TS   1   /* the 4x4 transform-skip variant of the residual quadtree (:7210-7440): xTransformSkip / xITransformSkip, transform_skip_flag = 1 in the bits */
 #define HOP_TU_RD_KEEP 2   /* no cbf-zero decision: levels, bits and distortion of coding the block are returned as they are */
 typedef struct {

@@ -426,9 +426,21 @@ def test_rqt_random_vs_oracle(hp):
         for comp in range(3):
             ctx.plane_upload("pred", comp, np.full(org[comp].shape, 1 << (bd - 1), np.int16))
         res, co, cx = ctx.rqt(jobs, snaps)
-        off = 0; deep = ts = 0
+        for comp in range(3):
+            ctx.plane_upload("recon", comp, np.zeros(org[comp].shape, np.int16))
+        res3, co3, fin3 = ctx.rqt_finish(jobs, res, co, cx)
+        rec = [ctx.recon_download(k) for k in range(3)]
+        off = 0; deep = ts = zeros = 0
         for i in range(n):
-            want, arr, fin, (ocx, ofr) = oracle_rqt(cfgs[i], snaps[i, :150], int(snaps[i, 150]) | (int(snaps[i, 151]) << 8), resis[i])
+            cu = 1 << int(cfgs[i]["log2_cu"]); n2 = cu * cu; x, y = int(jobs[i]["x"]), int(jobs[i]["y"])
+            o_i = np.concatenate([org[0][y:y + cu, x:x + cu].ravel(), org[1][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2].ravel(), org[2][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2].ravel()])
+            want, arr, fin, (ocx, ofr), tail = oracle_rqt(cfgs[i], snaps[i, :150], int(snaps[i, 150]) | (int(snaps[i, 151]) << 8), resis[i], (o_i - resis[i]).astype(np.int16), o_i)
+            # hop_rqt_finish: root-cbf-zero test, reconstruction, final distortions, cleared arrays / levels
+            got_rec = np.concatenate([rec[0][y:y + cu, x:x + cu].ravel(), rec[1][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2].ravel(), rec[2][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2].ravel()])
+            assert int(fin3[i, 0]) == tail["root"] and [int(v) for v in fin3[i, 1:]] == tail["d3"] and np.array_equal(got_rec, tail["rec"]), (bd, i, cfgs[i], fin3[i], tail["root"], tail["d3"])
+            g3 = np.concatenate([res3[i]["tr_idx"][None, :], res3[i]["cbf"], res3[i]["tskip"]])
+            assert np.array_equal(g3[:, :n2 // 16], tail["arr"][:, :n2 // 16]) and np.array_equal(co3[off:off + n2 * 3 // 2], tail["fin"]), (bd, i)
+            zeros += int(tail["root"] == 0)
             cu = 1 << int(cfgs[i]["log2_cu"]); m = cu * cu * 3 // 2; parts = cu * cu // 16
             r = res[i]
             assert (float(r["cost"]), int(r["bits"]), int(r["dist"]), int(r["zero_dist"])) == want, (bd, i, cfgs[i], r["cost"], r["bits"], r["dist"], want)
@@ -436,5 +448,5 @@ def test_rqt_random_vs_oracle(hp):
             assert np.array_equal(got[:, :parts], arr[:, :parts]) and np.array_equal(co[off:off + m], fin), (bd, i, cfgs[i])
             assert np.array_equal(cx[i, :150], ocx) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == ofr, (bd, i)
             deep += int(arr[0, :parts].max() >= 2); ts += int(arr[4:, :parts].any()); off += m
-        assert deep >= 2 and ts >= 2, (bd, deep, ts)
+        assert deep >= 2 and ts >= 2 and zeros >= 1, (bd, deep, ts, zeros)
         ctx.close()

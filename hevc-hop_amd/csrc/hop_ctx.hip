@@ -682,6 +682,24 @@ int hop_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, int n_ctx, const hop_cab
   return HOP_OK;
 }
 
+int hop_rqt_finish_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, hop_rqt_result* d_results, int32_t* d_coef, const hop_cabac_ctx* d_ctx_after,
+                          hop_cu_final* d_finals) {
+  if (!c || n < 0 || !cls || (n && (!d_jobs || !d_results || !d_coef || !d_ctx_after || !d_finals))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_finish_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_rqt_finish: hop_upload_orig has not been called");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_finish_device: illegal CU class");
+  if (n == 0) return HOP_OK;
+  const size_t wb = hop_rqt_finish_work_bytes(cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, n);
+  if (wb > c->rqt_bytes) {                                         // the quadtree's state buffer is free again once its kernels are queued (same stream)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
+    c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
+    c->rqt_bytes = wb + wb / 8;
+  }
+  return hop_launch_rqt_finish(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->use_ts ? 1 : 0, n, d_jobs, d_results, d_coef, d_ctx_after, d_finals, c->rqt_buf);
+}
+
 int hop_rqt_finish(hop_ctx* c, int n, const hop_rqt_job* jobs, hop_rqt_result* results, int32_t* coef, const hop_cabac_ctx* ctx_after, hop_cu_final* finals) {
   if (!c || n < 0 || (n && (!jobs || !results || !coef || !ctx_after || !finals))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_finish: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_rqt_finish: hop_upload_orig has not been called");

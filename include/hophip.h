@@ -364,6 +364,9 @@ typedef struct {
   uint32_t dist[3];                /* getDistPart of the reconstruction: Y, Cb, Cr (the chroma planes weighted) */
 } hop_cu_final;
 int hop_rqt_finish(hop_ctx* ctx, int n, const hop_rqt_job* jobs, hop_rqt_result* results, int32_t* coef, const hop_cabac_ctx* ctx_after, hop_cu_final* finals);
+/* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
+int hop_rqt_finish_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, hop_rqt_result* d_results, int32_t* d_coef,
+                          const hop_cabac_ctx* d_ctx_after, hop_cu_final* d_finals);
 
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with

@@ -487,3 +487,62 @@ Void TEncSearch::xEstimateResidualQT(TComDataCU* pcCU, UInt uiQuadrant, UInt uiA
   coder_put(m_pcRDGoOnSbacCoder, &coder);
   g_fin_pending = 3;
 }
+
+// ---- the CU-level syntax bits of an SS/GT CU: TEncSearch::xAddSymbolBitsInter (TLibEncoder/TEncSearch.cpp:7779-7810) -> hop_o_inter_cu_bits ----
+namespace { unsigned long g_calls7[1] = { 0 };
+struct Report7 { ~Report7() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: cuBits %lu\n", g_calls7[0]); } } g_report7;
+struct CuSets { ContextModel* p[9]; int n[9]; };
+CuSets cu_sets(TEncSbac* s) {
+  CuSets r = { { s->m_cCUSkipFlagSCModel.get(0), s->m_cCUMergeFlagExtSCModel.get(0), s->m_cCUMergeIdxExtSCModel.get(0), s->m_cCUPartSizeSCModel.get(0), s->m_cCUPredModeSCModel.get(0),
+                 s->m_cCUMvdSCModel.get(0), s->m_cMVPIdxSCModel.get(0), s->m_cCUGTFlagExtSCModel.get(0), s->m_cCUGTSCModel.get(0) }, { 3, 1, 1, 4, 1, 2, 1, 1, 2 } };
+  return r;
+}
+}
+
+Void TEncSearch::xAddSymbolBitsInter(TComDataCU* pcCU, UInt uiQp, UInt uiTrMode, UInt& ruiBits, TComYuv*& rpcYuvRec, TComYuv* pcYuvPred, TComYuv*& rpcYuvResi)
+{
+  g_calls7[0]++;
+  TComSlice* sl = pcCU->getSlice();
+  const UInt depth = pcCU->getDepth(0);
+  if (sl->getPPS()->getTransquantBypassEnableFlag() || sl->getPPS()->getUseDQP() || sl->getNumRefIdx(REF_PIC_LIST_0) != 1 || sl->getNumRefIdx(REF_PIC_LIST_1) > 0 || sl->isIntra()) {
+    fprintf(stderr, "hop shim: xAddSymbolBitsInter is replaced for one SS reference, no transquant bypass, no delta QP\n"); abort();
+  }
+  hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
+  cfg.log2_cu = g_aucConvertToBit[sl->getSPS()->getMaxCUWidth() >> depth] + 2;
+  cfg.sign_hide = sl->getPPS()->getSignHideFlag() ? 1 : 0; cfg.use_ts = sl->getPPS()->getUseTransformSkip() ? 1 : 0;
+  cfg.log2_max_tu = sl->getSPS()->getQuadtreeTULog2MaxSize(); cfg.log2_min_tu_in_cu = pcCU->getQuadtreeTULog2MinSizeInCU(0);
+  cfg.inter_split_flag = (sl->getSPS()->getQuadtreeTUMaxDepthInter() == 1 && pcCU->getPartitionSize(0) != SIZE_2Nx2N) ? 1 : 0;
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  memcpy(st.tr_idx, pcCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], pcCU->m_puhCbf[c], parts); memcpy(st.tskip[c], pcCU->m_puhTransformSkip[c], parts); }
+  std::vector<int32_t> coef(cu * cu * 3 / 2);
+  memcpy(&coef[0], pcCU->getCoeffY(), cu * cu * 4); memcpy(&coef[cu * cu], pcCU->getCoeffCb(), cu * cu); memcpy(&coef[cu * cu + cu * cu / 4], pcCU->getCoeffCr(), cu * cu);
+  hop_o_cu_syntax y; memset(&y, 0, sizeof(y));
+  const PartSize ps = pcCU->getPartitionSize(0);
+  y.part_size = (int)ps; y.n_pu = ps == SIZE_2Nx2N ? 1 : (ps == SIZE_NxN ? 4 : 2);
+  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = (int)pcCU->getCtxSkipFlag(0);
+  y.amp_acc = sl->getSPS()->getAMPAcc(depth) ? 1 : 0; y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth; y.max_merge_cand = (int)sl->getMaxNumMergeCand();
+  const UInt puOffset = (g_auiPUOffset[UInt(ps)] << ((sl->getSPS()->getMaxCUDepth() - depth) << 1)) >> 4;
+  for (int p = 0; p < y.n_pu; p++) {
+    const UInt idx = p * puOffset;
+    y.pu[p].merge_flag = pcCU->getMergeFlag(idx) ? 1 : 0; y.pu[p].merge_idx = (int)pcCU->getMergeIndex(idx);
+    if (!y.pu[p].merge_flag && pcCU->getInterDir(idx) != 1) { fprintf(stderr, "hop shim: a PU that is not predicted from list 0\n"); abort(); }
+    const TComMv d = pcCU->getCUMvField(REF_PIC_LIST_0)->getMvd(idx);
+    y.pu[p].mvd[0] = d.getHor(); y.pu[p].mvd[1] = d.getVer(); y.pu[p].mvp_idx = pcCU->getMVPIdx(REF_PIC_LIST_0, idx);
+    y.pu[p].gt_flag = pcCU->getGTFlag(idx) ? 1 : 0;
+    const TComMv g0 = pcCU->getCUGT0Field(REF_PIC_LIST_0)->getMv(idx), g1 = pcCU->getCUGT1Field(REF_PIC_LIST_0)->getMv(idx), g2 = pcCU->getCUGT2Field(REF_PIC_LIST_0)->getMv(idx),
+                g3 = pcCU->getCUGT3Field(REF_PIC_LIST_0)->getMv(idx);
+    const int gt[8] = { g0.getHor(), g0.getVer(), g1.getHor(), g1.getVer(), g2.getHor(), g2.getVer(), g3.getHor(), g3.getVer() };
+    memcpy(y.pu[p].gt, gt, sizeof(gt));
+  }
+  TEncSbac* sb = m_pcRDGoOnSbacCoder;
+  hop_o_coder coder; coder_get(sb, &coder);
+  uint8_t cuctx[16]; { CuSets r = cu_sets(sb); uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  int skipped = 0;
+  const uint32_t bits = hop_o_inter_cu_bits(&cfg, &y, &st, &coef[0], &coder, cuctx, &skipped);
+  if (skipped && !y.skip_flag) pcCU->setSkipFlagSubParts(true, 0, depth);
+  coder_put(sb, &coder);
+  { CuSets r = cu_sets(sb); const uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
+  ruiBits += bits;
+}

@@ -104,6 +104,14 @@ typedef struct {                    /* everything the caller reads afterwards; p
 void hop_o_rqt(const hop_o_rqt_cfg* cfg, const int16_t* resiY, int strideY, const int16_t* resiCb, const int16_t* resiCr, int strideC,
                hop_o_coder* coder, hop_o_rqt_state* st, double* cost, uint32_t* bits, uint32_t* dist, uint32_t* zero_dist);
 void hop_o_rqt_final_coeffs(const hop_o_rqt_cfg* cfg, const hop_o_rqt_state* st, int32_t* out);
+typedef struct {
+  int part_size;                  /* PartSize: 0 2Nx2N, 1 2NxN, 2 Nx2N, 3 NxN, 4 2NxnU, 5 2NxnD, 6 nLx2N, 7 nRx2N */
+  int n_pu, skip_flag, skip_ctx;  /* isSkipped, getCtxSkipFlag */
+  int amp_acc, is_min_cu, max_merge_cand;
+  struct { int merge_flag, merge_idx, mvd[2], mvp_idx, gt_flag, gt[8]; } pu[4];
+} hop_o_cu_syntax;
+uint32_t hop_o_inter_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_cu_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* coder, uint8_t cu_ctx[16],
+                             int* skipped);
 int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
                           const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

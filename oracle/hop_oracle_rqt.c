@@ -320,3 +320,124 @@ int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const h
   }
   return root;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The CU-level syntax of an SS/GT ("inter") CU, counted: TEncSearch::xAddSymbolBitsInter (TLibEncoder/TEncSearch.cpp:7779-7810) =
+ * skip flag, and either the merge index (skipped CU) or prediction mode, partition size (TEncSbac.cpp:469-566), per PU the merge
+ * flag / index or MVD (:944-1048), MVP index (:434-467), GT flag (:654-677) and the GT corner vectors (codeGT :1051-1330: corners 0..2,
+ * coded like MVDs with their own two contexts), the root cbf and the transform tree in bitstream order (TEncEntropy::encodeCoeff
+ * :633-660, xEncodeTransform :219-394).  One reference list with one picture, no transquant bypass, no delta QP.
+ * cu_ctx: the CU-level context states used here -- skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag,
+ * gt[2] (16 bytes, this order); coder: the residual sets + the fraction, both updated.  coef: the CU's levels in the layout of
+ * hop_o_rqt_final_coeffs.  Returns the integer bits (what getNumberOfWrittenBits adds to ruiBits). */
+typedef struct { hop_o_coder* c; uint8_t* cu; } Syn;
+#define CU_SKIP 0
+#define CU_MERGE_FLAG 3
+#define CU_MERGE_IDX 4
+#define CU_PART 5
+#define CU_PRED 9
+#define CU_MVD 10
+#define CU_MVP 12
+#define CU_GTF 13
+#define CU_GT 14
+static void bin(Syn* s, int idx, int b) { s->c->frac += (uint64_t)hop_o_ctx_bits(s->cu[idx], b); s->cu[idx] = hop_o_ctx_next(s->cu[idx], b); }
+static void ep(Syn* s, int n) { s->c->frac += (uint64_t)32768 * (uint64_t)n; }
+static int eg_bins(uint32_t sym, int k) { int n = 0; while (sym >= (1u << k)) { n++; sym -= 1u << k; k++; } return n + 1 + k; }   /* xWriteEpExGolomb :354-374 */
+static void vec_like_mvd(Syn* s, int base, const int* v, int ncomp)
+{                                                                       /* codeMvd / codeGT: != 0 flags, > 1 flags, then remainder + sign in bypass */
+  for (int i = 0; i < ncomp; i++) bin(s, base, v[i] != 0);
+  for (int i = 0; i < ncomp; i++) if (v[i]) bin(s, base + 1, abs(v[i]) > 1);
+  for (int i = 0; i < ncomp; i++) if (v[i]) { if (abs(v[i]) > 1) ep(s, eg_bins((uint32_t)abs(v[i]) - 2, 1)); ep(s, 1); }
+}
+static void merge_index(Syn* s, int idx, int num)
+{
+  if (num <= 1) return;
+  for (int ui = 0; ui < num - 1; ui++) { const int sym = ui == idx ? 0 : 1; if (ui == 0) bin(s, CU_MERGE_IDX, sym); else ep(s, 1); if (!sym) break; }
+}
+static void part_size(Syn* s, const hop_o_cu_syntax* y, int log2_cu)
+{
+  const int e = y->part_size;
+  if (e == 0) { bin(s, CU_PART, 1); return; }
+  if (e == 1 || e == 4 || e == 5) {                                   /* 2NxN, 2NxnU, 2NxnD */
+    bin(s, CU_PART, 0); bin(s, CU_PART + 1, 1);
+    if (y->amp_acc) { if (e == 1) bin(s, CU_PART + 3, 1); else { bin(s, CU_PART + 3, 0); ep(s, 1); } }
+    return;
+  }
+  if (e == 2 || e == 6 || e == 7) {                                   /* Nx2N, nLx2N, nRx2N */
+    bin(s, CU_PART, 0); bin(s, CU_PART + 1, 0);
+    if (y->is_min_cu && log2_cu != 3) bin(s, CU_PART + 2, 1);
+    if (y->amp_acc) { if (e == 2) bin(s, CU_PART + 3, 1); else { bin(s, CU_PART + 3, 0); ep(s, 1); } }
+    return;
+  }
+  if (y->is_min_cu && log2_cu != 3) { bin(s, CU_PART, 0); bin(s, CU_PART + 1, 0); bin(s, CU_PART + 2, 0); }      /* NxN */
+}
+/* xEncodeTransform */
+static void transform_tree(const hop_o_rqt_cfg* g, const hop_o_cu_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* c, int part, int trIdx, int log2,
+                           int* bakPart)
+{
+  const int parts = 1 << (2 * (g->log2_cu - 2)), cu2 = 1 << (2 * g->log2_cu);
+  const int subdiv = st->tr_idx[part] > trIdx;
+  int cbfY = (st->cbf[0][part] >> trIdx) & 1, cbfU = (st->cbf[1][part] >> trIdx) & 1, cbfV = (st->cbf[2][part] >> trIdx) & 1;
+  if (log2 == 2) {
+    const int pn = parts >> (2 * (trIdx - 1));
+    if (part % pn == 0) *bakPart = part;
+    else if (part % pn == pn - 1) { cbfU = (st->cbf[1][*bakPart] >> trIdx) & 1; cbfV = (st->cbf[2][*bakPart] >> trIdx) & 1; }
+  }
+  if (g->inter_split_flag && trIdx == 0) { /* QuadtreeTUMaxDepthInter == 1, partition != 2Nx2N: the split is inferred */ }
+  else if (log2 > g->log2_max_tu) { }
+  else if (log2 == 2) { }
+  else if (log2 == g->log2_min_tu_in_cu) { }
+  else c->frac += hop_o_cabac_subdiv_bits(&c->ctx, 5 - log2, subdiv);
+  const int first = trIdx == 0;
+  if (first || log2 > 2) {
+    if (first || ((st->cbf[1][part] >> (trIdx - 1)) & 1)) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 1, trIdx, (st->cbf[1][part] >> trIdx) & 1);
+    if (first || ((st->cbf[2][part] >> (trIdx - 1)) & 1)) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 2, trIdx, (st->cbf[2][part] >> trIdx) & 1);
+  }
+  if (subdiv) {
+    const int q = (parts >> (2 * trIdx)) >> 2;
+    for (int k = 0; k < 4; k++) transform_tree(g, y, st, coef, c, part + k * q, trIdx + 1, log2 - 1, bakPart);
+    return;
+  }
+  if (!(trIdx == 0 && !((st->cbf[1][part]) & 1) && !((st->cbf[2][part]) & 1)))
+    c->frac += hop_o_cabac_cbf_bits(&c->ctx, 0, st->tr_idx[part], (st->cbf[0][part] >> st->tr_idx[part]) & 1);
+  if (cbfY) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + 16 * part, log2, 0, 0, g->sign_hide, g->use_ts, st->tskip[0][part]);
+  if (log2 > 2) {
+    if (cbfU) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + 4 * part, log2 - 1, 1, 0, g->sign_hide, g->use_ts, st->tskip[1][part]);
+    if (cbfV) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + (cu2 >> 2) + 4 * part, log2 - 1, 2, 0, g->sign_hide, g->use_ts, st->tskip[2][part]);
+  } else {
+    const int pn = parts >> (2 * (trIdx - 1));
+    if (part % pn == pn - 1) {
+      if (cbfU) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + 4 * *bakPart, 2, 1, 0, g->sign_hide, g->use_ts, st->tskip[1][*bakPart]);
+      if (cbfV) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + (cu2 >> 2) + 4 * *bakPart, 2, 2, 0, g->sign_hide, g->use_ts, st->tskip[2][*bakPart]);
+    }
+  }
+}
+
+uint32_t hop_o_inter_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_cu_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* coder, uint8_t cu_ctx[16],
+                             int* skipped)
+{
+  Syn s = { coder, cu_ctx };
+  const int root = (st->cbf[0][0] & 1) || (st->cbf[1][0] & 1) || (st->cbf[2][0] & 1);
+  coder->frac &= 32767;                                                 /* resetBits */
+  if (y->pu[0].merge_flag && y->part_size == 0 && !root) {
+    *skipped = 1;
+    bin(&s, CU_SKIP + y->skip_ctx, 1);
+    merge_index(&s, y->pu[0].merge_idx, y->max_merge_cand);
+    return (uint32_t)(coder->frac >> 15);
+  }
+  *skipped = y->skip_flag;
+  bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);
+  bin(&s, CU_PRED, 0);                                                  /* MODE_INTER */
+  part_size(&s, y, cfg->log2_cu);
+  for (int p = 0; p < y->n_pu; p++) {
+    bin(&s, CU_MERGE_FLAG, y->pu[p].merge_flag ? 1 : 0);
+    if (y->pu[p].merge_flag) { merge_index(&s, y->pu[p].merge_idx, y->max_merge_cand); continue; }
+    vec_like_mvd(&s, CU_MVD, y->pu[p].mvd, 2);
+    bin(&s, CU_MVP, y->pu[p].mvp_idx ? 1 : 0);                          /* xWriteUnaryMaxSymbol with one candidate bit */
+    bin(&s, CU_GTF, y->pu[p].gt_flag ? 1 : 0);
+    if (y->pu[p].gt_flag) vec_like_mvd(&s, CU_GT, y->pu[p].gt, 6);      /* corners 0..2 (IT_GT_AFFINE) */
+  }
+  if (!(y->pu[0].merge_flag && y->part_size == 0)) coder->frac += hop_o_cabac_root_cbf_bits(&coder->ctx, root);
+  if (root) { int bak = 0; transform_tree(cfg, y, st, coef, coder, 0, 0, cfg->log2_cu, &bak); }
+  return (uint32_t)(coder->frac >> 15);
+}

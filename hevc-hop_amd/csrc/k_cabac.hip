@@ -136,7 +136,7 @@ int hop_cabac_est_bits(const hop_cabac_ctx* ctx, int width, int comp, hop_estbit
 } // extern "C"
 
 // ---- device: counted bits of codeCoeffNxN, one lane per TU ----
-struct CabacLds { uint8_t st[152][64]; uint16_t absCoeff[16][64]; };
+struct CabacLds { uint8_t st[168][64]; uint16_t absCoeff[16][64]; };      // rows 0..151: hop_cabac_ctx; 152..167: the CU-level sets of hop_cabac_cu_ctx (k_rqt.inl)
 
 #define CBIN(idx, b) do { const int i_ = (idx); const uint8_t s_ = sh.st[i_][lane]; const int b_ = (b); frac += (unsigned long long)c_entropy_bits[s_ ^ b_]; \
                           sh.st[i_][lane] = ((s_ & 1) == b_) ? c_next_mps[s_] : c_next_lps[s_]; } while (0)

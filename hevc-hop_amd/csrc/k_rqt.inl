@@ -421,3 +421,142 @@ int hop_launch_rqt_finish(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "rqt finish launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+// =====================================================================================================================
+// The CU-level syntax of an SS/GT CU, counted: TEncSearch::xAddSymbolBitsInter (TLibEncoder/TEncSearch.cpp:7779-7810) = skip flag and either the
+// merge index (skipped CU) or prediction mode, partition size (TEncSbac.cpp:469-566), per PU merge flag / index or MVD (:944-1048), MVP index
+// (:434-467), GT flag (:654-677), GT corner vectors (codeGT :1051-1330: corners 0..2, coded like MVDs on their own two contexts), root cbf and the
+// transform tree in bitstream order (TEncEntropy::encodeCoeff :633-660, xEncodeTransform :219-394).  One lane per CU; rows 152.. of the lane's LDS
+// states hold the CU-level sets (hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2]).
+// =====================================================================================================================
+#define CUX 152
+#define CU_SKIP (CUX + 0)
+#define CU_MERGE_FLAG (CUX + 3)
+#define CU_MERGE_IDX (CUX + 4)
+#define CU_PART (CUX + 5)
+#define CU_PRED (CUX + 9)
+#define CU_MVD (CUX + 10)
+#define CU_MVP (CUX + 12)
+#define CU_GTF (CUX + 13)
+#define CU_GT (CUX + 14)
+#define CEP(nbins) do { frac += 32768ull * (unsigned long long)(nbins); } while (0)
+
+__device__ static inline int cu_eg_bins(unsigned sym, int kk) { int nb = 0; while (sym >= (1u << kk)) { nb++; sym -= 1u << kk; kk++; } return nb + 1 + kk; }   // xWriteEpExGolomb
+__device__ static unsigned long long cu_vec(CabacLds& sh, const int lane, const int base, const int32_t* v, const int ncomp) {    // codeMvd / codeGT
+  unsigned long long frac = 0;
+  for (int i = 0; i < ncomp; i++) CBIN(base, v[i] != 0);
+  for (int i = 0; i < ncomp; i++) if (v[i]) CBIN(base + 1, (v[i] < 0 ? -v[i] : v[i]) > 1);
+  for (int i = 0; i < ncomp; i++) if (v[i]) { const int a = v[i] < 0 ? -v[i] : v[i]; if (a > 1) CEP(cu_eg_bins((unsigned)a - 2, 1)); CEP(1); }
+  return frac;
+}
+__device__ static unsigned long long cu_merge_index(CabacLds& sh, const int lane, const int idx, const int num) {
+  unsigned long long frac = 0;
+  if (num <= 1) return 0;
+  for (int ui = 0; ui < num - 1; ui++) { const int sym = ui == idx ? 0 : 1; if (ui == 0) CBIN(CU_MERGE_IDX, sym); else CEP(1); if (!sym) break; }
+  return frac;
+}
+
+__global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ res,
+                                                const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
+                                                uint32_t* __restrict__ bits_out, uint32_t* __restrict__ skipped_out, hop_cabac_ctx* __restrict__ ctx_out,
+                                                hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const int ci = jobs[i].ctx_index;
+  RQ_LOAD(ctx_in[ci]);
+  for (int q = 0; q < 16; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
+  const hop_cu_syntax y = syn[i];
+  const hop_rqt_result* r = res + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  const int32_t* cf = coef + (size_t)i * (cu2 + (cu2 >> 1));
+  const int root = ((r->cbf[0][0] | r->cbf[1][0] | r->cbf[2][0]) & 1);
+  unsigned long long frac = RQ_LEFT();                               // resetBits keeps the fraction
+  uint32_t skipped;
+  if (y.pu[0].merge_flag && y.part_size == 0 && !root) {
+    skipped = 1;
+    CBIN(CU_SKIP + y.skip_ctx, 1);
+    frac += cu_merge_index(sh, lane, y.pu[0].merge_idx, y.max_merge_cand);
+  } else {
+    skipped = (uint32_t)(y.skip_flag != 0);
+    CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
+    CBIN(CU_PRED, 0);                                                // MODE_INTER
+    const int e = y.part_size;                                       // codePartSize
+    if (e == 0) CBIN(CU_PART, 1);
+    else if (e == 1 || e == 4 || e == 5) {
+      CBIN(CU_PART, 0); CBIN(CU_PART + 1, 1);
+      if (y.amp_acc) { if (e == 1) CBIN(CU_PART + 3, 1); else { CBIN(CU_PART + 3, 0); CEP(1); } }
+    } else if (e == 2 || e == 6 || e == 7) {
+      CBIN(CU_PART, 0); CBIN(CU_PART + 1, 0);
+      if (y.is_min_cu && k.log2_cu != 3) CBIN(CU_PART + 2, 1);
+      if (y.amp_acc) { if (e == 2) CBIN(CU_PART + 3, 1); else { CBIN(CU_PART + 3, 0); CEP(1); } }
+    } else if (y.is_min_cu && k.log2_cu != 3) { CBIN(CU_PART, 0); CBIN(CU_PART + 1, 0); CBIN(CU_PART + 2, 0); }
+    for (int p = 0; p < y.n_pu; p++) {                               // encodePUWise
+      CBIN(CU_MERGE_FLAG, y.pu[p].merge_flag ? 1 : 0);
+      if (y.pu[p].merge_flag) { frac += cu_merge_index(sh, lane, y.pu[p].merge_idx, y.max_merge_cand); continue; }
+      frac += cu_vec(sh, lane, CU_MVD, y.pu[p].mvd, 2);
+      CBIN(CU_MVP, y.pu[p].mvp_idx ? 1 : 0);
+      CBIN(CU_GTF, y.pu[p].gt_flag ? 1 : 0);
+      if (y.pu[p].gt_flag) frac += cu_vec(sh, lane, CU_GT, y.pu[p].gt, 6);
+    }
+    if (!(y.pu[0].merge_flag && y.part_size == 0)) CBIN(CX_ROOT_CBF, root);
+    if (root) {
+      // xEncodeTransform: pre-order walk; flags on the way down, luma cbf + levels at the leaves (chroma of four 4x4 luma TUs after the last of them)
+      int sp_part[4], sp_k[4]; int sp = 0, bak = 0;
+      sp_part[0] = 0; sp_k[0] = -1;
+      while (sp >= 0) {
+        const int part = sp_part[sp], trIdx = sp, log2 = k.log2_cu - sp;
+        if (sp_k[sp] < 0) {
+          const int subdiv = r->tr_idx[part] > trIdx;
+          const int cbfY = (r->cbf[0][part] >> trIdx) & 1; int cbfU = (r->cbf[1][part] >> trIdx) & 1, cbfV = (r->cbf[2][part] >> trIdx) & 1;
+          if (log2 == 2) {
+            const int pn = parts >> (2 * (trIdx - 1));
+            if (part % pn == 0) bak = part;
+            else if (part % pn == pn - 1) { cbfU = (r->cbf[1][bak] >> trIdx) & 1; cbfV = (r->cbf[2][bak] >> trIdx) & 1; }
+          }
+          if (!((k.inter_split && trIdx == 0) || log2 > k.log2_max_tu || log2 == 2 || log2 == k.log2_min_tu)) CBIN(CX_TRANS_SUBDIV + 5 - log2, subdiv);
+          const int first = trIdx == 0;
+          if (first || log2 > 2) {
+            if (first || ((r->cbf[1][part] >> (trIdx - 1)) & 1)) CBIN(rqt_cbf_ctx(1, trIdx), (r->cbf[1][part] >> trIdx) & 1);
+            if (first || ((r->cbf[2][part] >> (trIdx - 1)) & 1)) CBIN(rqt_cbf_ctx(2, trIdx), (r->cbf[2][part] >> trIdx) & 1);
+          }
+          if (!subdiv) {
+            if (!(trIdx == 0 && !(r->cbf[1][part] & 1) && !(r->cbf[2][part] & 1))) CBIN(rqt_cbf_ctx(0, r->tr_idx[part]), (r->cbf[0][part] >> r->tr_idx[part]) & 1);
+            if (cbfY) frac += cb_code_tu(sh, lane, cf + 16 * part, log2, 0, 0, k.sign_hide, k.use_ts, r->tskip[0][part], 0, scans);
+            if (log2 > 2) {
+              if (cbfU) frac += cb_code_tu(sh, lane, cf + cu2 + 4 * part, log2 - 1, 1, 0, k.sign_hide, k.use_ts, r->tskip[1][part], 0, scans);
+              if (cbfV) frac += cb_code_tu(sh, lane, cf + cu2 + (cu2 >> 2) + 4 * part, log2 - 1, 1, 0, k.sign_hide, k.use_ts, r->tskip[2][part], 0, scans);
+            } else {
+              const int pn = parts >> (2 * (trIdx - 1));
+              if (part % pn == pn - 1) {
+                if (cbfU) frac += cb_code_tu(sh, lane, cf + cu2 + 4 * bak, 2, 1, 0, k.sign_hide, k.use_ts, r->tskip[1][bak], 0, scans);
+                if (cbfV) frac += cb_code_tu(sh, lane, cf + cu2 + (cu2 >> 2) + 4 * bak, 2, 1, 0, k.sign_hide, k.use_ts, r->tskip[2][bak], 0, scans);
+              }
+            }
+            sp--; continue;
+          }
+          sp_k[sp] = 0;
+        }
+        if (sp_k[sp] < 4) { const int q = (parts >> (2 * trIdx)) >> 2, kk = sp_k[sp]++; sp_part[sp + 1] = part + kk * q; sp_k[sp + 1] = -1; sp++; }
+        else sp--;
+      }
+    }
+  }
+  bits_out[i] = (uint32_t)(frac >> 15);
+  skipped_out[i] = skipped;
+  if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
+  if (cu_out) for (int q = 0; q < 16; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
+}
+
+int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
+                       const hop_cu_syntax* d_syn, const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
+                       uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = inter_split; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
+  hipLaunchKernelGGL(k_cu_bits, dim3((n + 63) / 64), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_skipped, d_ctx_out, d_cu_out, c->rdoq_scans);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "cu_bits launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

@@ -68,6 +68,8 @@ RQT_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("log2_cu", "<i4"), ("qp_s
                           ("dist_weight", "<f8", (2,))])
 RQT_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("bits", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("pad", "<u4"), ("tr_idx", "u1", (256,)), ("cbf", "u1", (3, 256)),
                              ("tskip", "u1", (3, 256))])
+CU_SYNTAX_DTYPE = np.dtype([("part_size", "<i4"), ("n_pu", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("amp_acc", "<i4"), ("is_min_cu", "<i4"), ("max_merge_cand", "<i4"),
+                            ("pu", [("merge_flag", "<i4"), ("merge_idx", "<i4"), ("mvd", "<i4", (2,)), ("mvp_idx", "<i4"), ("gt_flag", "<i4"), ("gt", "<i4", (8,))], (4,))])
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -303,6 +305,16 @@ class Context:
         self.L.hop_rqt_finish.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
         self._chk(self.L.hop_rqt_finish(self.h, len(jobs), jobs.ctypes.data, res.ctypes.data, coef.ctypes.data, cx.ctypes.data, fin.ctypes.data), "hop_rqt_finish")
         return res, coef, fin
+
+    def inter_cu_bits(self, jobs, syntax, res, coef, ctx_in, cu_ctx_in):
+        """CU-level syntax bits (xAddSymbolBitsInter): returns bits, skipped, coder states (n, 152) and CU-level states (n, 16) afterwards"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, CU_SYNTAX_DTYPE); res = np.ascontiguousarray(res, RQT_RESULT_DTYPE)
+        coef = np.ascontiguousarray(coef, np.int32); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); bits = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32); cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, 16), np.uint8)
+        self.L.hop_inter_cu_bits.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 6
+        self._chk(self.L.hop_inter_cu_bits(self.h, n, jobs.ctypes.data, syntax.ctypes.data, res.ctypes.data, coef.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data,
+                                           bits.ctypes.data, sk.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_inter_cu_bits")
+        return bits, sk, cx, cu
 
     def intra_pred(self, jobs, modes):
         n = len(jobs)

@@ -368,6 +368,25 @@ int hop_rqt_finish(hop_ctx* ctx, int n, const hop_rqt_job* jobs, hop_rqt_result*
 int hop_rqt_finish_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, hop_rqt_result* d_results, int32_t* d_coef,
                           const hop_cabac_ctx* d_ctx_after, hop_cu_final* d_finals);
 
+/* ---- CU-level syntax bits of an SS/GT ("inter") CU (first piece of row a0) ---- */
+/* replaces: TEncSearch::xAddSymbolBitsInter (TLibEncoder/TEncSearch.cpp:7779-7810) through the counting coder: skip flag and either the merge index
+ * (a merged 2Nx2N CU without residual is a skipped CU) or prediction mode, partition size (TEncSbac::codePartSize TEncSbac.cpp:469-566), per PU the merge
+ * flag / index or MVD (codeMvd :944-1048), MVP index (:434-467), GT flag (:654-677) and the GT corner vectors (codeGT :1051-1330: corners 0..2, coded like
+ * MVDs on their own two contexts), the root cbf and the transform tree in bitstream order (TEncEntropy::encodeCoeff :633-660, xEncodeTransform :219-394).
+ * One reference list with one picture, no transquant bypass, no delta QP. */
+typedef struct { uint8_t state[16]; } hop_cabac_cu_ctx;   /* m_ucState of: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2] */
+typedef struct {
+  int32_t part_size;               /* PartSize: 0 2Nx2N, 1 2NxN, 2 Nx2N, 3 NxN, 4 2NxnU, 5 2NxnD, 6 nLx2N, 7 nRx2N */
+  int32_t n_pu, skip_flag, skip_ctx;   /* isSkipped, getCtxSkipFlag (skipped CUs left + above) */
+  int32_t amp_acc, is_min_cu, max_merge_cand;   /* SPS getAMPAcc(depth), depth == max CU depth, slice MaxNumMergeCand */
+  struct { int32_t merge_flag, merge_idx, mvd[2], mvp_idx, gt_flag, gt[8]; } pu[4];
+} hop_cu_syntax;
+/* jobs: the class fields and ctx_index of hop_rqt_job are used (ctx_index indexes ctx_in and cu_ctx_in); results / coef: the arrays and levels as
+ * hop_rqt / hop_rqt_finish leave them.  bits[i]: what the call adds to ruiBits; skipped[i]: isSkipped afterwards; ctx_out / cu_ctx_out (may be NULL):
+ * the coder after the CU (what the caller stores as CI_TEMP_BEST). */
+int hop_inter_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
+                      const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, uint32_t* skipped, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
+
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
  * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and

@@ -540,7 +540,17 @@ Void TEncSearch::xAddSymbolBitsInter(TComDataCU* pcCU, UInt uiQp, UInt uiTrMode,
   hop_o_coder coder; coder_get(sb, &coder);
   uint8_t cuctx[16]; { CuSets r = cu_sets(sb); uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
   int skipped = 0;
+  const hop_o_coder coder_in = coder; uint8_t cu_in[16]; memcpy(cu_in, cuctx, 16);
   const uint32_t bits = hop_o_inter_cu_bits(&cfg, &y, &st, &coef[0], &coder, cuctx, &skipped);
+  {                                                                 // HOP_SHIM_TRACE_CUBITS=<file>: cfg, syntax, arrays, levels, coder / CU contexts in and out, bits, skipped
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_CUBITS"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) {
+      fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&y, sizeof(y), 1, f); fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+      fwrite(&coef[0], 4, coef.size(), f); fwrite(&coder_in, sizeof(coder_in), 1, f); fwrite(cu_in, 1, 16, f); fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 16, f);
+      const int32_t o2[2] = { (int32_t)bits, skipped }; fwrite(o2, 4, 2, f);
+    }
+  }
   if (skipped && !y.skip_flag) pcCU->setSkipFlagSubParts(true, 0, depth);
   coder_put(sb, &coder);
   { CuSets r = cu_sets(sb); const uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }

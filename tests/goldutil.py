@@ -153,3 +153,19 @@ def oracle_rqt(cfg, ctx150, frac, resi, pred=None, org=None):
                                    P3(*[a.ctypes.data for a in rc]), d3, fin2.ctypes.data)
     arr2 = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
     return out + (dict(root=root, rec=np.concatenate(rc), d3=list(d3), arr=arr2, fin=fin2),)
+
+
+CU_SYN = np.dtype([("part_size", "<i4"), ("n_pu", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("amp_acc", "<i4"), ("is_min_cu", "<i4"), ("max_merge_cand", "<i4"),
+                   ("pu", [("merge_flag", "<i4"), ("merge_idx", "<i4"), ("mvd", "<i4", (2,)), ("mvp_idx", "<i4"), ("gt_flag", "<i4"), ("gt", "<i4", (8,))], (4,))])
+
+
+def encoder_cubits_calls():
+    """tests/golden/encoder_cubits_calls.npz (oracle/make_golden10.py): xAddSymbolBitsInter calls of two real encodes: cfg, syntax elements (hop_o_cu_syntax
+    image), tr_idx | cbf[3] | tskip[3], the CU's levels, coder (150 states + fraction) and the 16 CU-level context states in and out, bits, skip decision"""
+    g = load("encoder_cubits_calls.npz")
+    o = 0
+    for i in range(len(g["bits"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu * 3 // 2
+        yield dict(cfg=g["cfg"][i], syn=g["syn"][i], arr=g["arr"][i], coef=np.ascontiguousarray(g["coef"][o:o + n]), cin=g["cin"][i], cuin=g["cuin"][i], cout=g["cout"][i],
+                   cuout=g["cuout"][i], bits=int(g["bits"][i]), skipped=int(g["skipped"][i]))
+        o += n

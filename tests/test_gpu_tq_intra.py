@@ -450,3 +450,33 @@ def test_rqt_random_vs_oracle(hp):
             deep += int(arr[0, :parts].max() >= 2); ts += int(arr[4:, :parts].any()); off += m
         assert deep >= 2 and ts >= 2 and zeros >= 1, (bd, deep, ts, zeros)
         ctx.close()
+
+
+def test_cu_bits_encoder_calls(hp):
+    """hop_inter_cu_bits (first piece of row a0: the CU-level syntax of an SS/GT CU through the lane-wise counting coder) on 57 xAddSymbolBitsInter calls
+    recorded inside the encoder: every partition shape incl. AMP, merge / skip cases, MVDs, GT flags and vectors, transform trees with and without
+    transform skip: bits, the skip decision, all residual and CU-level context states afterwards"""
+    from goldutil import encoder_cubits_calls
+    cases = list(encoder_cubits_calls())
+    n = len(cases)
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.CU_SYNTAX_DTYPE); res = np.zeros(n, hp.RQT_RESULT_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, 16), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; j = jobs[i]
+        j["log2_cu"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"], j["inter_split_flag"] = (
+            int(cfg["log2_cu"]), i, cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"], cfg["inter_split_flag"])
+        j["lambda_rd"] = 1.0; j["lambda_rdoq"] = 1.0
+        syn[i] = c["syn"]
+        a = c["arr"].reshape(7, 256); res[i]["tr_idx"] = a[0]; res[i]["cbf"] = a[1:4]; res[i]["tskip"] = a[4:7]
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i] = c["cuin"]
+    ctx = hp.Context(64, 64)
+    bits, sk, cx, cu = ctx.inter_cu_bits(jobs, syn, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
+    for i, c in enumerate(cases):
+        assert (int(bits[i]), int(sk[i])) == (c["bits"], c["skipped"]), (i, int(c["cfg"]["log2_cu"]), int(c["syn"]["part_size"]), bits[i], c["bits"])
+        assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), i
+        assert np.array_equal(cu[i], c["cuout"]), i
+    bad = syn.copy(); bad[0]["part_size"] = 9
+    with pytest.raises(hp.HopError):
+        ctx.inter_cu_bits(jobs, bad, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
+    ctx.close()

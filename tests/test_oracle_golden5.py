@@ -64,3 +64,23 @@ def test_rqt_on_encoder_calls():
         assert np.array_equal(cx, c["cout"]["ctx"]) and fr == (int(c["cout"]["frac"]) & 32767), n
         ts += int(arr[4:, :parts].any()); n += 1
     assert n == 73 and ts >= 15 and zeros >= 1, zeros
+
+
+def test_cu_bits_on_encoder_calls():
+    """the CU-level syntax bits of an SS/GT CU (restatement of xAddSymbolBitsInter: skip, merge, partition, MVD, MVP index, GT flag and vectors, root cbf,
+    transform tree in bitstream order) on 57 calls recorded inside the encoder: bits, the skip decision and every context state afterwards"""
+    from goldutil import encoder_cubits_calls, RQT_CFG, CU_SYN, _OCoder, _OState
+    O = oracle()
+    O.hop_o_inter_cu_bits.restype = ctypes.c_uint32
+    n = 0; shapes = set()
+    for c in encoder_cubits_calls():
+        cfg = np.zeros(1, RQT_CFG); cfg[0] = c["cfg"]; syn = np.zeros(1, CU_SYN); syn[0] = c["syn"]
+        st = _OState(); ctypes.memmove(ctypes.byref(st), c["arr"].tobytes(), 256 * 7)
+        coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), c["cin"].tobytes(), 160)
+        cu = c["cuin"].copy(); sk = ctypes.c_int(0)
+        bits = O.hop_o_inter_cu_bits(cfg.ctypes.data_as(ctypes.c_void_p), syn.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), c["coef"].ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.byref(coder), cu.ctypes.data_as(ctypes.c_void_p), ctypes.byref(sk))
+        assert (bits, sk.value) == (c["bits"], c["skipped"]), (n, bits, c["bits"])
+        assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
+        shapes.add(int(syn[0]["part_size"])); n += 1
+    assert n == 57 and len(shapes) >= 7

@@ -104,6 +104,20 @@ int hop_cabac_init(hop_cabac_ctx* ctx, int slice_type, int qp) {
   return HOP_OK;
 }
 
+// CU-level sets of hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2]; rows B, P, I, ISS, PSS
+// (TLibCommon/ContextTables.h:140-310, 472-482)
+static const uint8_t h_cu_init[5][16] = {
+  { 197, 185, 201, 154, 137, 154, 139, 154, 154, 134, 169, 198, 168, 154, 169, 198 },
+  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198 },
+  { CNU, CNU, CNU, CNU, CNU, 184, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU },
+  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198 },
+  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198 } };
+int hop_cabac_cu_init(hop_cabac_cu_ctx* ctx, int slice_type, int qp) {
+  if (!ctx || slice_type < 0 || slice_type > 4) return HOP_ERR_ARG;
+  for (int i = 0; i < 16; i++) ctx->state[i] = h_ctx_init(qp, h_cu_init[slice_type][i]);
+  return HOP_OK;
+}
+
 int hop_cabac_est_bits(const hop_cabac_ctx* ctx, int width, int comp, hop_estbits* eb) {
   if (!ctx || !eb || (width != 4 && width != 8 && width != 16 && width != 32) || comp < 0 || comp > 2 || (comp && width == 32)) return HOP_ERR_ARG;
   static const uint8_t grp[32] = { 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8,8,8,8,8,8,8,8,9,9,9,9,9,9,9,9 };

@@ -384,6 +384,8 @@ typedef struct {
 /* jobs: the class fields and ctx_index of hop_rqt_job are used (ctx_index indexes ctx_in and cu_ctx_in); results / coef: the arrays and levels as
  * hop_rqt / hop_rqt_finish leave them.  bits[i]: what the call adds to ruiBits; skipped[i]: isSkipped afterwards; ctx_out / cu_ctx_out (may be NULL):
  * the coder after the CU (what the caller stores as CI_TEMP_BEST). */
+/* replaces: TEncSbac::resetEntropy for those sets (initBuffer with TLibCommon/ContextTables.h:140-310, 472-482); slice_type as hop_cabac_init. Host only. */
+int hop_cabac_cu_init(hop_cabac_cu_ctx* ctx, int slice_type, int qp);
 int hop_inter_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
                       const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, uint32_t* skipped, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
 

@@ -76,3 +76,18 @@ def test_cabac_host_functions_vs_golden():
         assert L.hop_cabac_est_bits(s152.ctypes.data, int(w), int(comp), e.ctypes.data) == 0
         assert np.array_equal(e, want), (w, comp)
     assert L.hop_cabac_est_bits(s152.ctypes.data, 32, 1, e.ctypes.data) != 0     # no chroma 32x32
+
+
+def test_cabac_cu_init_vs_golden():
+    """hop_cabac_cu_init (host logic): the CU-level context sets of hop_cabac_cu_ctx against the states the reference's own ContextModel3DBuffer::initBuffer
+    produced for every slice type and QP (tests/golden/cabac_cu.npz, made by oracle/make_golden4.py through ref_cabac_cu_init)"""
+    import numpy as np
+    from goldutil import load
+    L = _lib()
+    L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    g = load("cabac_cu.npz")["init"]
+    for st in range(5):
+        for qp in range(52):
+            b = np.full(16, 0xEE, np.uint8)
+            assert L.hop_cabac_cu_init(b.ctypes.data, st, qp) == 0 and np.array_equal(b, g[st, qp]), (st, qp)
+    assert L.hop_cabac_cu_init(b.ctypes.data, 7, 30) != 0

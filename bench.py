@@ -249,7 +249,11 @@ def main():
         chk(L.hop_recon_upload(ctx.h, c3, host_plane.ctypes.data), "recon_upload")
     # --rqt: the full transform-size search of the same CUs (three levels of transform units, transform-skip retry, context chaining, recount)
     if args.rqt:
-        d_rq, d_rqr, rq_cls, d_rqc, d_rqx, d_rqf = [], [], [], [], [], []
+        d_rq, d_rqr, rq_cls, d_rqc, d_rqx, d_rqf, d_rqs, d_rqb = [], [], [], [], [], [], [], []
+        cu_snap = np.zeros((1, 16), np.uint8)
+        L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        chk(L.hop_cabac_cu_init(cu_snap.ctypes.data, 3, QP), "cabac_cu_init")
+        d_cusnap = torch.from_numpy(cu_snap).to(dev)
         for d in range(4):
             S = 64 >> d
             src = cu[cu[:, 2] == S]
@@ -263,8 +267,14 @@ def main():
             d_rqc.append(torch.zeros(len(a) * S * S * 3 // 2, dtype=torch.int32, device=dev))            # chosen levels
             d_rqx.append(torch.zeros(len(a) * hp.CABAC_CTX_BYTES, dtype=torch.uint8, device=dev))       # coder state after the quadtree
             d_rqf.append(torch.zeros(len(a) * 4, dtype=torch.int32, device=dev))                        # root cbf + final distortions
+            sy = np.zeros(len(a), hp.CU_SYNTAX_DTYPE)                                                   # synthetic CU syntax: 2Nx2N, no merge, an MVD, GT flag with small vectors
+            sy["n_pu"], sy["max_merge_cand"], sy["amp_acc"], sy["is_min_cu"] = 1, 5, int(S >= 16), int(S == 8)
+            sy["pu"]["mvd"][:, 0] = (-17, 5); sy["pu"]["gt_flag"][:, 0] = 1; sy["pu"]["gt"][:, 0] = (1, 0, -1, 2, 0, 1, 0, 0)
+            d_rqs.append(torch.from_numpy(sy.view(np.uint8)).to(dev))
+            d_rqb.append(torch.zeros(len(a) * 2, dtype=torch.int32, device=dev))                        # bits, skipped
         L.hop_rqt_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
         L.hop_rqt_finish_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
+        L.hop_inter_cu_bits_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 11
     CH = int(os.environ.get("HOP_BENCH_CH", max(n, 1)))               # PUs per hop_me_search_device call: the whole frame (the library cuts it into stream lanes); 128 k chunks cost 6 %
     jsz, rsz = hp.PU_JOB_DTYPE.itemsize, hp.PU_RESULT_DTYPE.itemsize
 
@@ -282,6 +292,9 @@ def main():
                     chk(L.hop_rqt_device(ctx.h, nq, d_rq[d].data_ptr(), rq_cls[d].ctypes.data, d_snap.data_ptr(), d_rqr[d].data_ptr(), d_rqc[d].data_ptr(), d_rqx[d].data_ptr()), "rqt")
                     # root-cbf-zero test, reconstruction into the context's picture, final distortions (tail of encodeResAndCalcRdInterCU)
                     chk(L.hop_rqt_finish_device(ctx.h, nq, d_rq[d].data_ptr(), rq_cls[d].ctypes.data, d_rqr[d].data_ptr(), d_rqc[d].data_ptr(), d_rqx[d].data_ptr(), d_rqf[d].data_ptr()), "rqt_finish")
+                    # the CU-level syntax bits from the slice's initial coder state (xAddSymbolBitsInter)
+                    chk(L.hop_inter_cu_bits_device(ctx.h, nq, d_rq[d].data_ptr(), rq_cls[d].ctypes.data, d_rqs[d].data_ptr(), d_rqr[d].data_ptr(), d_rqc[d].data_ptr(), d_snap.data_ptr(),
+                                                   d_cusnap.data_ptr(), d_rqb[d].data_ptr(), d_rqb[d].data_ptr() + 4 * nq, None, None), "cu_bits")
                 else:
                     chk(L.hop_tu_rd_device(ctx.h, len(tu_by_depth[d]), d_tu[d].data_ptr(), d_snap.data_ptr(), d_tuoff[d].data_ptr(), int(tu_off[d][-1]),
                                            d_levels.data_ptr(), d_tur[d].data_ptr()), "tu_rd")
@@ -327,6 +340,7 @@ def main():
         if args.rqt:
             rr = np.frombuffer(d_rqr[d].cpu().numpy().tobytes(), hp.RQT_RESULT_DTYPE)
             ff = d_rqf[d].cpu().numpy().reshape(-1, 4).astype(np.uint64)
+            ff[:, 0] += d_rqb[d].cpu().numpy()[:len(ff)].astype(np.uint64) * 5
             tu_crc ^= int(np.bitwise_xor.reduce((rr["bits"].astype(np.uint64) * 31 + rr["dist"] + rr["tr_idx"][:, 0].astype(np.uint64) * 7 + ff[:, 0] * 3 + ff[:, 1] + ff[:, 2] + ff[:, 3]) *
                                                 np.arange(1, len(rr) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF))
             continue
@@ -363,7 +377,7 @@ def main():
             "dtype": "i16+f64", "data": "synthetic",
             "config": {"workload": "synthetic lenslet %dx%d pitch %d, QP%d, HOP on: SS+-128 (FEN) + frac (HAD) + GT search + GT predictor + %s + 35-mode intra rough search + SS-ref commit, "
                                    "full symmetric RD-tree PU set (%d PUs/frame), frozen SS reference, no host RD spine" % (W, H, PITCH, QP,
-                                   "the whole residual-quadtree search of its residual (three transform sizes, transform-skip retry, context chaining, recount; Y,Cb,Cr) + root-cbf test, reconstruction and final distortion" if args.rqt else
+                                   "the whole residual-quadtree search of its residual (three transform sizes, transform-skip retry, context chaining, recount; Y,Cb,Cr) + root-cbf test, reconstruction, final distortion and the CU-level syntax bits = encodeResAndCalcRdInterCU of the candidate" if args.rqt else
                                    "residual-quadtree leaf of its residual (DCT, RDOQ, CABAC-counted bits, inverse, SSE, cbf decision; Y,Cb,Cr)", n if world == 1 else -1),
                        "ctus": n_ctu, "pus_rank0": int(n), "parallelism": "ctu-rows-rr%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

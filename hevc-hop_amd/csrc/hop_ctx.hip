@@ -751,6 +751,18 @@ int hop_rqt_finish(hop_ctx* c, int n, const hop_rqt_job* jobs, hop_rqt_result* r
   return HOP_OK;
 }
 
+int hop_inter_cu_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results, const int32_t* d_coef,
+                             const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out,
+                             hop_cabac_cu_ctx* d_cu_ctx_out) {
+  if (!c || n < 0 || !cls || (n && (!d_jobs || !d_syntax || !d_results || !d_coef || !d_ctx_in || !d_cu_ctx_in || !d_bits || !d_skipped)))
+    return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_bits_device: bad argument");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_bits_device: illegal CU class");
+  if (n == 0) return HOP_OK;
+  return hop_launch_cu_bits(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->inter_split_flag ? 1 : 0, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, n, d_jobs, d_syntax,
+                            d_results, d_coef, d_ctx_in, d_cu_ctx_in, d_bits, d_skipped, d_ctx_out, d_cu_ctx_out);
+}
+
 int hop_inter_cu_bits(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
                       const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, uint32_t* skipped, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out) {
   if (!c || n < 0 || (n && (!jobs || !syntax || !results || !coef || !ctx_in || !cu_ctx_in || !bits || !skipped || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_bits: bad argument");

@@ -389,6 +389,11 @@ int hop_cabac_cu_init(hop_cabac_cu_ctx* ctx, int slice_type, int qp);
 int hop_inter_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
                       const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, uint32_t* skipped, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
 
+/* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
+int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
+                             const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,
+                             hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);
+
 /* ---- CTU-level host logic ---- */
 /* replaces: the PU enumeration of TEncCu::xCompressCU for an ISS slice (TLibEncoder/TEncCu.cpp:451-637) with
  * TComDataCU::getPartOffset (TLibCommon/TComDataCU.cpp:2251-2296, incl. the SIZE_nLx2N offY quirk) and

@@ -582,6 +582,34 @@ int hop_tu_rd_device(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
   return hop_launch_tu_rd(c, n, d_jobs, d_ctx_in, d_coef_offsets, n_coeff, d_levels, d_results, 0);
 }
 
+int hop_intra_modes_device(hop_ctx* c, int n, const hop_intra_modes_job* d_jobs, const uint32_t* d_satd, hop_intra_modes_result* d_results) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_satd || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_modes_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_intra_modes(c, n, d_jobs, d_satd, d_results);
+}
+
+int hop_intra_modes(hop_ctx* c, int n, const hop_intra_modes_job* jobs, const uint32_t* satd, hop_intra_modes_result* results) {
+  if (!c || n < 0 || (n && (!jobs || !satd || !results))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_modes: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_intra_modes_job& j = jobs[i];
+    bool ok = j.pred_num >= 0 && j.pred_num <= 3 && j.mpm_cand >= 0 && j.mpm_cand <= j.pred_num && j.num_full_rd >= 1 && j.num_full_rd <= 8 && j.ctx_state >= 0 && j.ctx_state <= 127 &&
+              j.frac_left >= 0 && j.frac_left < 32768 && j.sqrt_lambda > 0.0;
+    for (int k = 0; k < j.pred_num && ok; k++) ok = j.preds[k] >= 0 && j.preds[k] < 35;
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "intra modes job %d: illegal predictors / list size / context", i);
+  }
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_s = al((size_t)n * sizeof(hop_intra_modes_job)), o_r = al(o_s + (size_t)n * 35 * 4);
+  void* st; int r = hop_stage(c, o_r + (size_t)n * sizeof(hop_intra_modes_result) + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, (size_t)n * sizeof(hop_intra_modes_job), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_s, satd, (size_t)n * 35 * 4, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_intra_modes(c, n, (const hop_intra_modes_job*)b, (const uint32_t*)(b + o_s), (hop_intra_modes_result*)(b + o_r)); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(results, b + o_r, (size_t)n * sizeof(hop_intra_modes_result), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
 int hop_rqt_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_results, int32_t* d_coef_out,
                    hop_cabac_ctx* d_ctx_out) {
   if (!c || n < 0 || !cls || (n && (!d_jobs || !d_ctx_in || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_device: bad argument");

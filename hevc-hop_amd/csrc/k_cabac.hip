@@ -325,4 +325,50 @@ int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, c
   return HOP_OK;
 }
 
+// ---- the mode-decision half of the intra rough search (rest of row a7): TEncSearch::estIntraPredQT :2440-2493 ----
+// per block: for the 35 modes bits of the luma direction from the CI_CURR_BEST state (xModeBitsIntra :7734 = codeIntraDirLumaAng TEncSbac.cpp:770-831),
+// cost = SATD + bits * sqrt(lambda) in double (:2461), the sorted candidate list (xUpdateCandList :7747-7767), the MPMs appended if missing (:2466-2488).
+__global__ void k_intra_modes(const hop_intra_modes_job* __restrict__ jobs, int n, const uint32_t* __restrict__ satd, hop_intra_modes_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const hop_intra_modes_job jb = jobs[i];
+  const uint32_t* sd = satd + (size_t)i * 35;
+  uint32_t modes[11]; double costs[8];
+  const int nf = jb.num_full_rd;
+  for (int q = 0; q < 11; q++) modes[q] = 0;
+  for (int q = 0; q < 8; q++) costs[q] = 1.7e+308;
+  const unsigned left = (unsigned)jb.frac_left & 32767u;
+  for (int mode = 0; mode < 35; mode++) {
+    int idx = -1;
+    for (int q = 0; q < jb.pred_num; q++) if (mode == jb.preds[q]) idx = q;
+    const unsigned long long frac = left + (unsigned long long)c_entropy_bits[jb.ctx_state ^ (idx != -1 ? 1 : 0)] + 32768ull * (unsigned long long)(idx == -1 ? 5 : (idx ? 2 : 1));
+    const double cost = (double)sd[mode] + (double)(uint32_t)(frac >> 15) * jb.sqrt_lambda;
+    int shift = 0;
+    while (shift < nf && cost < costs[nf - 1 - shift]) shift++;
+    if (shift) {
+      for (int q = 1; q < shift; q++) { modes[nf - q] = modes[nf - 1 - q]; costs[nf - q] = costs[nf - 1 - q]; }
+      modes[nf - shift] = (uint32_t)mode; costs[nf - shift] = cost;
+    }
+  }
+  int cnt = nf;
+  for (int j = 0; j < jb.mpm_cand; j++) {
+    bool inc = false;
+    for (int q = 0; q < cnt; q++) inc |= (jb.preds[j] == (int)modes[q]);
+    if (!inc) modes[cnt++] = (uint32_t)jb.preds[j];
+  }
+  hop_intra_modes_result r;
+  r.n = (uint32_t)cnt;
+  for (int q = 0; q < 11; q++) r.modes[q] = modes[q];
+  for (int q = 0; q < 8; q++) r.costs[q] = costs[q];
+  res[i] = r;
+}
+int hop_launch_intra_modes(hop_ctx* c, int n, const hop_intra_modes_job* d_jobs, const uint32_t* d_satd, hop_intra_modes_result* d_res) {
+  const int pr = hop_prof_begin(c, HOP_K_INTRA, 0);
+  hipLaunchKernelGGL(k_intra_modes, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, d_satd, d_res);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_modes launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
 #include "k_rqt.inl"

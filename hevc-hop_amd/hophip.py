@@ -70,6 +70,8 @@ RQT_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("bits", "<u4"), ("dist", "<u4"), 
                              ("tskip", "u1", (3, 256))])
 CU_SYNTAX_DTYPE = np.dtype([("part_size", "<i4"), ("n_pu", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("amp_acc", "<i4"), ("is_min_cu", "<i4"), ("max_merge_cand", "<i4"),
                             ("pu", [("merge_flag", "<i4"), ("merge_idx", "<i4"), ("mvd", "<i4", (2,)), ("mvp_idx", "<i4"), ("gt_flag", "<i4"), ("gt", "<i4", (8,))], (4,))])
+INTRA_MODES_JOB_DTYPE = np.dtype([("preds", "<i4", (3,)), ("pred_num", "<i4"), ("mpm_cand", "<i4"), ("num_full_rd", "<i4"), ("ctx_state", "<i4"), ("frac_left", "<i4"), ("sqrt_lambda", "<f8")])
+INTRA_MODES_RESULT_DTYPE = np.dtype([("n", "<u4"), ("modes", "<u4", (11,)), ("costs", "<f8", (8,))])
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -315,6 +317,12 @@ class Context:
         self._chk(self.L.hop_inter_cu_bits(self.h, n, jobs.ctypes.data, syntax.ctypes.data, res.ctypes.data, coef.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data,
                                            bits.ctypes.data, sk.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_inter_cu_bits")
         return bits, sk, cx, cu
+
+    def intra_modes(self, jobs, satd):
+        jobs = np.ascontiguousarray(jobs, INTRA_MODES_JOB_DTYPE); satd = np.ascontiguousarray(satd, np.uint32); res = np.zeros(len(jobs), INTRA_MODES_RESULT_DTYPE)
+        self.L.hop_intra_modes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_intra_modes(self.h, len(jobs), jobs.ctypes.data, satd.ctypes.data, res.ctypes.data), "hop_intra_modes")
+        return res
 
     def intra_pred(self, jobs, modes):
         n = len(jobs)

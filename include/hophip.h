@@ -316,6 +316,22 @@ int hop_tu_rd(hop_ctx* ctx, int n, const hop_tu_rd_job* jobs, int n_ctx, const h
 int hop_tu_rd_device(hop_ctx* ctx, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx_in, const int64_t* d_coef_offsets, size_t n_coeff,
                      int32_t* d_levels, hop_tu_rd_result* d_results);                                 /* asynchronous, unchecked */
 
+/* ---- the mode-decision half of the intra rough search (rest of row a7) ---- */
+/* replaces: the candidate selection of TEncSearch::estIntraPredQT (TLibEncoder/TEncSearch.cpp:2440-2493) on the 35 SATDs of hop_intra_rough: per mode
+ * xModeBitsIntra (:7734-7745: the luma direction through the counting coder from the CI_CURR_BEST state -- TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:770-831),
+ * cost = SATD + bits * sqrt(lambda) in double, the sorted list of xUpdateCandList (:7747-7767), the most probable modes appended if missing (:2466-2488). */
+typedef struct {
+  int32_t preds[3], pred_num;      /* TComDataCU::getIntraDirLumaPredictor */
+  int32_t mpm_cand;                /* how many of them the list must contain (numCand, :2468-2473) */
+  int32_t num_full_rd;             /* g_aucIntraModeNumFast of the block size: 3 or 8 */
+  int32_t ctx_state, frac_left;    /* m_ucState of the prev_intra_luma_pred_flag context and the fraction the coder carries, at CI_CURR_BEST */
+  double  sqrt_lambda;             /* TComRdCost::getSqrtLambda */
+} hop_intra_modes_job;
+typedef struct { uint32_t n, modes[11]; double costs[8]; } hop_intra_modes_result;   /* uiRdModeList (n entries), CandCostList (num_full_rd entries) */
+/* satd: 35 values per job, as hop_intra_rough returns them */
+int hop_intra_modes(hop_ctx* ctx, int n, const hop_intra_modes_job* jobs, const uint32_t* satd, hop_intra_modes_result* results);
+int hop_intra_modes_device(hop_ctx* ctx, int n, const hop_intra_modes_job* d_jobs, const uint32_t* d_satd, hop_intra_modes_result* d_results);   /* asynchronous, unchecked */
+
 /* ---- residual quadtree of an SS/GT ("inter") CU (row a8b) ---- */
 /* replaces: TEncSearch::xEstimateResidualQT (TLibEncoder/TEncSearch.cpp:6824-7560) with xEncodeResidualQT (:7562-7655) as
  * encodeResAndCalcRdInterCU calls it (:6700) for a batch of CUs: the full search over transform sizes -- per node Y/Cb/Cr through

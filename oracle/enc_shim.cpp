@@ -556,3 +556,33 @@ Void TEncSearch::xAddSymbolBitsInter(TComDataCU* pcCU, UInt uiQp, UInt uiTrMode,
   { CuSets r = cu_sets(sb); const uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
   ruiBits += bits;
 }
+
+// ---- the mode-decision half of the intra rough search: TEncSearch::xModeBitsIntra (:7734-7745) -> hop_o_intra_mode_bits, xUpdateCandList (:7747-7767) -> hop_o_cand_update ----
+namespace { unsigned long g_calls8[2] = { 0, 0 };
+struct Report8 { ~Report8() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: modeBits %lu candList %lu\n", g_calls8[0], g_calls8[1]); } } g_report8; }
+
+UInt TEncSearch::xModeBitsIntra(TComDataCU* pcCU, UInt uiMode, UInt uiPU, UInt uiPartOffset, UInt uiDepth, UInt uiInitTrDepth)
+{
+  g_calls8[0]++;
+  m_pcRDGoOnSbacCoder->loadIntraDirModeLuma(m_pppcRDSbacCoder[uiDepth][CI_CURR_BEST]);
+  pcCU->setLumaIntraDirSubParts(uiMode, uiPartOffset, uiDepth + uiInitTrDepth);
+  Int preds[3] = { -1, -1, -1 };
+  const Int predNum = pcCU->getIntraDirLumaPredictor(uiPartOffset, preds);
+  ContextModel* cm = m_pcRDGoOnSbacCoder->m_cCUIntraPredSCModel.get(0);
+  uint8_t st = cm->m_ucState; uint64_t frac = m_pcRDGoOnSbacCoder->m_pcBinIf->getTEncBinCABAC()->m_fracBits;
+  const uint32_t bits = hop_o_intra_mode_bits(&st, &frac, (int)uiMode, preds, predNum);
+  {                                                                 // HOP_SHIM_TRACE_MODEBITS=<file>: state, fraction, mode, predictors -> bits
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_MODEBITS"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) { const int32_t rec[8] = { cm->m_ucState, (int32_t)(m_pcRDGoOnSbacCoder->m_pcBinIf->getTEncBinCABAC()->m_fracBits & 32767), (int32_t)uiMode, preds[0], preds[1], preds[2], predNum, (int32_t)bits };
+             fwrite(rec, 4, 8, f); }
+  }
+  cm->m_ucState = st; m_pcRDGoOnSbacCoder->m_pcBinIf->getTEncBinCABAC()->m_fracBits = frac;
+  return bits;
+}
+
+UInt TEncSearch::xUpdateCandList(UInt uiMode, Double uiCost, UInt uiFastCandNum, UInt* CandModeList, Double* CandCostList)
+{
+  g_calls8[1]++;
+  return (UInt)hop_o_cand_update((int)uiMode, uiCost, (int)uiFastCandNum, CandModeList, CandCostList);
+}

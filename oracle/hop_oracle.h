@@ -43,6 +43,10 @@ void hop_o_intra_smooth(const int* L, int N, int bitDepth, int strong, int* F);
 void hop_o_intra_pred(const int* Lunf, const int* Lfil, int N, int mode, int bitDepth, int16_t* pred);
 void hop_o_intra_rough(const int16_t* rec, int recStride, const int16_t* org, int orgStride, int x, int y, int N,
                        const uint8_t* flags, int bitDepth, int strong, uint32_t satd[35]);
+uint32_t hop_o_intra_mode_bits(uint8_t* ctx_state, uint64_t* frac, int mode, const int preds[3], int pred_num);
+int hop_o_cand_update(int mode, double cost, int n, uint32_t* modes, double* costs);
+int hop_o_intra_cand_list(const uint32_t satd[35], uint8_t ctx_state, uint32_t frac_left, double sqrt_lambda, const int preds[3], int pred_num, int mpm_cand,
+                          int num_full_rd, uint32_t* out_modes, double* out_costs);
 /* ---- a9 / a10 (hop_oracle_tq.c) ---- */
 void hop_o_fwd_transform(int bitDepth, const int16_t* block, int16_t* coeff, int N, int useDst);
 void hop_o_inv_transform(int bitDepth, const int16_t* coeff, int16_t* block, int N, int useDst);

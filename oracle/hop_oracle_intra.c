@@ -176,3 +176,54 @@ void hop_o_intra_rough(const int16_t* rec, int recStride, const int16_t* org, in
     satd[m] = hop_o_calc_had(org + (ptrdiff_t)y * orgStride + x, orgStride, pred, N, N, N, bitDepth);
   }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The mode-decision half of the rough search of TEncSearch::estIntraPredQT (TLibEncoder/TEncSearch.cpp:2440-2493):
+ * xModeBitsIntra (:7734-7745) = bits of the luma intra direction through the counting coder from the CI_CURR_BEST state
+ * (TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:770-831: prev_intra_luma_pred_flag on its context, then the MPM index or the
+ * 5-bit remainder in bypass), cost = SATD + bits * sqrt(lambda) in double (:2461), xUpdateCandList (:7747-7767) and the MPMs
+ * appended if missing (:2466-2488). */
+uint8_t hop_o_ctx_next(uint8_t state, int bin);
+int32_t hop_o_ctx_bits(uint8_t state, int bin);
+
+uint32_t hop_o_intra_mode_bits(uint8_t* ctx_state, uint64_t* frac, int mode, const int preds[3], int pred_num)
+{
+  int idx = -1;
+  for (int i = 0; i < pred_num; i++) if (mode == preds[i]) idx = i;
+  *frac &= 32767;                                                       /* resetBits */
+  *frac += (uint64_t)hop_o_ctx_bits(*ctx_state, idx != -1); *ctx_state = hop_o_ctx_next(*ctx_state, idx != -1);
+  *frac += (uint64_t)32768 * (uint64_t)(idx == -1 ? 5 : (idx ? 2 : 1));
+  return (uint32_t)(*frac >> 15);
+}
+
+int hop_o_cand_update(int mode, double cost, int n, uint32_t* modes, double* costs)
+{
+  int shift = 0;
+  while (shift < n && cost < costs[n - 1 - shift]) shift++;
+  if (!shift) return 0;
+  for (int i = 1; i < shift; i++) { modes[n - i] = modes[n - 1 - i]; costs[n - i] = costs[n - 1 - i]; }
+  modes[n - shift] = (uint32_t)mode; costs[n - shift] = cost;
+  return 1;
+}
+
+/* satd[35] from the rough search; ctx_state / frac_left: prev_intra_luma_pred_flag context and the coder's fraction at CI_CURR_BEST;
+ * preds / pred_num: getIntraDirLumaPredictor; mpm_cand: how many of them the list must contain (numCand, :2468-2473).
+ * out_modes[num_full_rd + 3], out_costs[num_full_rd]; returns the number of modes for the full RD. */
+int hop_o_intra_cand_list(const uint32_t satd[35], uint8_t ctx_state, uint32_t frac_left, double sqrt_lambda, const int preds[3], int pred_num, int mpm_cand,
+                          int num_full_rd, uint32_t* out_modes, double* out_costs)
+{
+  for (int i = 0; i < num_full_rd; i++) { out_costs[i] = 1.7e+308; out_modes[i] = 0; }
+  for (int mode = 0; mode < 35; mode++) {
+    uint8_t s = ctx_state; uint64_t f = frac_left;
+    const uint32_t bits = hop_o_intra_mode_bits(&s, &f, mode, preds, pred_num);
+    const double cost = (double)satd[mode] + (double)bits * sqrt_lambda;
+    hop_o_cand_update(mode, cost, num_full_rd, out_modes, out_costs);
+  }
+  int n = num_full_rd;
+  for (int j = 0; j < mpm_cand; j++) {
+    int inc = 0;
+    for (int i = 0; i < n; i++) inc |= (preds[j] == (int)out_modes[i]);
+    if (!inc) out_modes[n++] = (uint32_t)preds[j];
+  }
+  return n;
+}

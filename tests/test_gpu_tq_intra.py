@@ -480,3 +480,36 @@ def test_cu_bits_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.inter_cu_bits(jobs, bad, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
     ctx.close()
+
+
+def test_intra_modes_vs_oracle(hp):
+    """hop_intra_modes (mode bits + cost + candidate list + MPM append of the intra rough search) against the restatement, whose pieces stand in for
+    xModeBitsIntra / xUpdateCandList inside the reference encoder: 4000 random blocks, both list sizes, 0..3 most probable modes, ties in the costs"""
+    import ctypes
+    from hoputil import oracle
+    O = oracle()
+    O.hop_o_intra_cand_list.restype = ctypes.c_int
+    O.hop_o_intra_cand_list.argtypes = [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(12)
+    n = 4000
+    jobs = np.zeros(n, hp.INTRA_MODES_JOB_DTYPE)
+    satd = rng.integers(0, 5000, (n, 35)).astype(np.uint32)
+    satd[::7] = rng.integers(0, 12, (len(satd[::7]), 35))                       # many equal costs: the insertion order decides
+    for i in range(n):
+        j = jobs[i]
+        pn = int(rng.integers(0, 4)); j["pred_num"] = pn
+        j["preds"] = [-1, -1, -1]; j["preds"][:pn] = rng.permutation(35)[:pn]
+        j["mpm_cand"] = int(rng.integers(0, pn + 1)); j["num_full_rd"] = int(rng.choice([3, 8]))
+        j["ctx_state"], j["frac_left"], j["sqrt_lambda"] = int(rng.integers(0, 126)), int(rng.integers(0, 32768)), float(rng.choice([7.6097, 4.8, 12.08]))
+    ctx = hp.Context(64, 64)
+    res = ctx.intra_modes(jobs, satd)
+    for i in range(n):
+        j = jobs[i]
+        modes = (ctypes.c_uint32 * 11)(); costs = (ctypes.c_double * 8)(); preds = (ctypes.c_int * 3)(*[int(v) for v in j["preds"]])
+        cnt = O.hop_o_intra_cand_list(satd[i].ctypes.data, int(j["ctx_state"]), int(j["frac_left"]), float(j["sqrt_lambda"]), preds, int(j["pred_num"]), int(j["mpm_cand"]),
+                                      int(j["num_full_rd"]), modes, costs)
+        assert int(res[i]["n"]) == cnt and list(res[i]["modes"][:cnt]) == list(modes)[:cnt] and list(res[i]["costs"][:int(j["num_full_rd"])]) == list(costs)[:int(j["num_full_rd"])], i
+    bad = jobs[:1].copy(); bad["num_full_rd"] = 9
+    with pytest.raises(hp.HopError):
+        ctx.intra_modes(bad, satd[:1])
+    ctx.close()

@@ -84,3 +84,25 @@ def test_cu_bits_on_encoder_calls():
         assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
         shapes.add(int(syn[0]["part_size"])); n += 1
     assert n == 57 and len(shapes) >= 7
+
+
+def test_intra_mode_bits_on_encoder_calls():
+    """xModeBitsIntra: 600 calls recorded inside the encoder (state of the prev_intra_luma_pred_flag context, carried fraction, mode, most probable modes)
+    against the restatement; plus the candidate-list logic on a hand-checkable case"""
+    from goldutil import load
+    O = oracle()
+    O.hop_o_intra_mode_bits.restype = ctypes.c_uint32
+    rec = load("encoder_modebits_calls.npz")["rec"]
+    kinds = set()
+    for st, fr, mode, p0, p1, p2, pn, bits in rec:
+        s = ctypes.c_uint8(int(st)); f = ctypes.c_uint64(int(fr)); preds = (ctypes.c_int * 3)(int(p0), int(p1), int(p2))
+        assert O.hop_o_intra_mode_bits(ctypes.byref(s), ctypes.byref(f), int(mode), preds, int(pn)) == int(bits)
+        kinds.add(int(mode) in (int(p0), int(p1), int(p2)))
+    assert kinds == {True, False}
+    satd = (ctypes.c_uint32 * 35)(*[1000 + 10 * m for m in range(35)]); satd[20] = 5; satd[7] = 6
+    modes = (ctypes.c_uint32 * 11)(); costs = (ctypes.c_double * 8)(); preds = (ctypes.c_int * 3)(0, 1, 26)
+    O.hop_o_intra_cand_list.restype = ctypes.c_int
+    O.hop_o_intra_cand_list.argtypes = [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    n = O.hop_o_intra_cand_list(satd, 60, 100, 7.6, preds, 3, 3, 3, modes, costs)
+    # the two cheap modes, then mode 0 (the most probable mode with the shortest code among the rest); the missing most probable modes 1 and 26 appended
+    assert n == 5 and list(modes)[:5] == [20, 7, 0, 1, 26] and costs[0] < costs[1] < costs[2]

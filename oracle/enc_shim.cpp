@@ -586,3 +586,63 @@ UInt TEncSearch::xUpdateCandList(UInt uiMode, Double uiCost, UInt uiFastCandNum,
   g_calls8[1]++;
   return (UInt)hop_o_cand_update((int)uiMode, uiCost, (int)uiFastCandNum, CandModeList, CandCostList);
 }
+
+// ---- the bits of an intra CU's quadtree: TEncSearch::xGetIntraBitsQT (TLibEncoder/TEncSearch.cpp:957-980) -> hop_o_intra_cu_bits ----
+namespace { unsigned long g_calls9[1] = { 0 };
+struct Report9 { ~Report9() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: intraBits %lu\n", g_calls9[0]); } } g_report9;
+struct CuSets2 { ContextModel* p[11]; int n[11]; };
+CuSets2 cu_sets2(TEncSbac* s) {
+  CuSets2 r = { { s->m_cCUSkipFlagSCModel.get(0), s->m_cCUMergeFlagExtSCModel.get(0), s->m_cCUMergeIdxExtSCModel.get(0), s->m_cCUPartSizeSCModel.get(0), s->m_cCUPredModeSCModel.get(0),
+                  s->m_cCUMvdSCModel.get(0), s->m_cMVPIdxSCModel.get(0), s->m_cCUGTFlagExtSCModel.get(0), s->m_cCUGTSCModel.get(0), s->m_cCUIntraPredSCModel.get(0),
+                  s->m_cCUChromaPredSCModel.get(0) }, { 3, 1, 1, 4, 1, 2, 1, 1, 2, 1, 2 } };
+  return r;
+}
+}
+
+UInt TEncSearch::xGetIntraBitsQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPartIdx, Bool bLuma, Bool bChroma, Bool bRealCoeff)
+{
+  g_calls9[0]++;
+  TComSlice* sl = pcCU->getSlice();
+  if (bRealCoeff || sl->getSPS()->getUsePCM() || sl->getPPS()->getTransquantBypassEnableFlag() || sl->isIntra()) {
+    fprintf(stderr, "hop shim: xGetIntraBitsQT is replaced for the layer coefficients, no PCM, no transquant bypass, ISS slices\n"); abort();
+  }
+  const UInt depth = pcCU->getDepth(0);
+  hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
+  cfg.log2_cu = g_aucConvertToBit[sl->getSPS()->getMaxCUWidth() >> depth] + 2;
+  cfg.sign_hide = sl->getPPS()->getSignHideFlag() ? 1 : 0; cfg.use_ts = sl->getPPS()->getUseTransformSkip() ? 1 : 0;
+  cfg.log2_max_tu = sl->getSPS()->getQuadtreeTULog2MaxSize(); cfg.log2_min_tu_in_cu = pcCU->getQuadtreeTULog2MinSizeInCU(0);
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  memcpy(st.tr_idx, pcCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], pcCU->m_puhCbf[c], parts); memcpy(st.tskip[c], pcCU->m_puhTransformSkip[c], parts); }
+  for (int l = 0; l < 4; l++) { st.coef[l][0] = m_ppcQTTempCoeffY[l]; st.coef[l][1] = m_ppcQTTempCoeffCb[l]; st.coef[l][2] = m_ppcQTTempCoeffCr[l]; }
+  hop_o_intra_syntax y; memset(&y, 0, sizeof(y));
+  y.part_nxn = pcCU->getPartitionSize(0) == SIZE_NxN ? 1 : 0;
+  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = (int)pcCU->getCtxSkipFlag(0); y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth;
+  for (int p = 0; p < (y.part_nxn ? 4 : 1); p++) {
+    const UInt idx = p * (parts >> 2);
+    y.luma_dir[p] = pcCU->getLumaIntraDir(idx);
+    Int pr[3] = { -1, -1, -1 }; y.pred_num[p] = pcCU->getIntraDirLumaPredictor(idx, pr);
+    for (int k = 0; k < 3; k++) y.preds[p][k] = pr[k];
+  }
+  y.chroma_is_dm = pcCU->getChromaIntraDir(0) == DM_CHROMA_IDX; y.chroma_dir = pcCU->getChromaIntraDir(0);
+  TEncSbac* sb = m_pcRDGoOnSbacCoder;
+  hop_o_coder coder; coder_get(sb, &coder);
+  uint8_t cuctx[20] = { 0 }; { CuSets2 r = cu_sets2(sb); uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  const hop_o_coder coder_in = coder; uint8_t cu_in[20]; memcpy(cu_in, cuctx, 20);
+  const uint32_t bits = hop_o_intra_cu_bits(&cfg, &y, &st, (int)uiTrDepth, (int)uiAbsPartIdx, bLuma ? 1 : 0, bChroma ? 1 : 0, &coder, cuctx);
+  {                                                                 // HOP_SHIM_TRACE_INTRABITS=<file>
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_INTRABITS"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) {
+      const int32_t nd[4] = { (int32_t)uiTrDepth, (int32_t)uiAbsPartIdx, bLuma ? 1 : 0, bChroma ? 1 : 0 };
+      fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&y, sizeof(y), 1, f); fwrite(nd, 4, 4, f); fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+      for (int l = 0; l < 4; l++) { fwrite(st.coef[l][0], 4, cu * cu, f); fwrite(st.coef[l][1], 4, cu * cu / 4, f); fwrite(st.coef[l][2], 4, cu * cu / 4, f); }
+      fwrite(&coder_in, sizeof(coder_in), 1, f); fwrite(cu_in, 1, 20, f); fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 20, f);
+      const int32_t b1 = (int32_t)bits; fwrite(&b1, 4, 1, f);
+    }
+  }
+  coder_put(sb, &coder);
+  { CuSets2 r = cu_sets2(sb); const uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
+  return bits;
+}

@@ -116,6 +116,14 @@ typedef struct {
 } hop_o_cu_syntax;
 uint32_t hop_o_inter_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_cu_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* coder, uint8_t cu_ctx[16],
                              int* skipped);
+typedef struct {
+  int part_nxn;                    /* 0: 2Nx2N, 1: NxN */
+  int skip_flag, skip_ctx, is_min_cu;
+  int luma_dir[4], preds[4][3], pred_num[4];   /* per PU: getLumaIntraDir, getIntraDirLumaPredictor */
+  int chroma_is_dm, chroma_dir;    /* chroma direction == DM_CHROMA_IDX; otherwise the direction itself (selects the scan) */
+} hop_o_intra_syntax;
+uint32_t hop_o_intra_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, int tr_depth, int part, int b_luma, int b_chroma,
+                             hop_o_coder* coder, uint8_t cu_ctx[20]);
 int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
                           const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

@@ -441,3 +441,85 @@ uint32_t hop_o_inter_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_cu_syntax* y,
   if (root) { int bak = 0; transform_tree(cfg, y, st, coef, coder, 0, 0, cfg->log2_cu, &bak); }
   return (uint32_t)(coder->frac >> 15);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The bits of an intra CU's quadtree as the intra search counts them: TEncSearch::xGetIntraBitsQT (TLibEncoder/TEncSearch.cpp:957-980) =
+ * xEncIntraHeader (:887-954: skip flag, prediction mode, partition size, the luma directions of the CU or of the PU that starts at this
+ * node, the chroma direction), xEncSubdivCbfQT (:764-830: split flags if luma, chroma cbfs if chroma, luma cbf at the leaves) and
+ * xEncCoeffQT (:833-884) of the asked components, from the node (tr_depth, part) downwards, with the levels of the layer buffers.
+ * cu_ctx: hop_cabac_cu_ctx (20 bytes: ... [16] prev_intra_luma_pred_flag, [17..18] chroma prediction).  No PCM, no transquant bypass. */
+#define CU_IPRED 16
+#define CU_CPRED 17
+static void intra_dir(Syn* s, int dir, const int* preds, int pred_num)
+{                                                                       /* codeIntraDirLumaAng for one PU, TEncSbac.cpp:770-831 */
+  int idx = -1;
+  for (int i = 0; i < pred_num; i++) if (dir == preds[i]) idx = i;
+  bin(s, CU_IPRED, idx != -1);
+  ep(s, idx == -1 ? 5 : (idx ? 2 : 1));
+}
+static int tu_scan(const hop_o_intra_syntax* y, int parts, int part, int width, int comp)
+{
+  const int dir = comp ? (y->chroma_is_dm ? y->luma_dir[0] : y->chroma_dir) : y->luma_dir[y->part_nxn ? part / (parts >> 2) : 0];
+  return hop_o_coef_scan_idx(width, comp == 0, 1, dir);
+}
+static void intra_subdiv_cbf(const hop_o_rqt_cfg* g, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, hop_o_coder* c, int parts, int trDepth, int part, int bLuma, int bChroma)
+{
+  const int trMode = st->tr_idx[part], subdiv = trMode > trDepth, log2 = g->log2_cu - trDepth;
+  if (y->part_nxn && trDepth == 0) { }
+  else if (log2 > g->log2_max_tu) { }
+  else if (log2 == 2) { }
+  else if (log2 == g->log2_min_tu_in_cu) { }
+  else if (bLuma) c->frac += hop_o_cabac_subdiv_bits(&c->ctx, 5 - log2, subdiv);
+  if (bChroma && log2 > 2) {
+    if (trDepth == 0 || ((st->cbf[1][part] >> (trDepth - 1)) & 1)) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 1, trDepth, (st->cbf[1][part] >> trDepth) & 1);
+    if (trDepth == 0 || ((st->cbf[2][part] >> (trDepth - 1)) & 1)) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 2, trDepth, (st->cbf[2][part] >> trDepth) & 1);
+  }
+  if (subdiv) {
+    const int q = (parts >> (2 * trDepth)) >> 2;
+    for (int k = 0; k < 4; k++) intra_subdiv_cbf(g, y, st, c, parts, trDepth + 1, part + k * q, bLuma, bChroma);
+    return;
+  }
+  if (bLuma) c->frac += hop_o_cabac_cbf_bits(&c->ctx, 0, trMode, (st->cbf[0][part] >> trMode) & 1);
+}
+static void intra_coeff(const hop_o_rqt_cfg* g, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, hop_o_coder* c, int parts, int trDepth, int part, int comp)
+{
+  const int trMode = st->tr_idx[part], log2 = g->log2_cu - trDepth;
+  if (trMode > trDepth) {
+    const int q = (parts >> (2 * trDepth)) >> 2;
+    for (int k = 0; k < 4; k++) intra_coeff(g, y, st, c, parts, trDepth + 1, part + k * q, comp);
+    return;
+  }
+  int d = trDepth;
+  if (comp && log2 == 2) { d--; if (part % (parts >> (2 * d)) != 0) return; }
+  const int lg = g->log2_cu - d - (comp ? 1 : 0), layer = g->log2_max_tu - log2;
+  const int32_t* coef = st->coef[layer][comp] + (comp ? (16 * part) >> 2 : 16 * part);
+  c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef, lg, comp, tu_scan(y, parts, part, 1 << lg, comp), g->sign_hide, g->use_ts, st->tskip[comp][part]);
+}
+
+uint32_t hop_o_intra_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, int tr_depth, int part, int b_luma, int b_chroma,
+                             hop_o_coder* coder, uint8_t cu_ctx[20])
+{
+  Syn s = { coder, cu_ctx };
+  const int parts = 1 << (2 * (cfg->log2_cu - 2));
+  coder->frac &= 32767;                                                 /* resetBits */
+  if (b_luma) {
+    if (part == 0) {
+      bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);             /* not an I slice: skip flag, prediction mode */
+      bin(&s, CU_PRED, 1);
+      if (y->is_min_cu) bin(&s, CU_PART, y->part_nxn ? 0 : 1);          /* codePartSize, intra */
+    }
+    if (!y->part_nxn) { if (part == 0) intra_dir(&s, y->luma_dir[0], y->preds[0], y->pred_num[0]); }
+    else {
+      const int q = parts >> 2;
+      if (tr_depth == 0) for (int p = 0; p < 4; p++) intra_dir(&s, y->luma_dir[p], y->preds[p], y->pred_num[p]);
+      else if (part % q == 0) intra_dir(&s, y->luma_dir[part / q], y->preds[part / q], y->pred_num[part / q]);
+    }
+  }
+  if (b_chroma && part == 0) {                                          /* codeIntraDirChroma, TEncSbac.cpp:833-862 */
+    if (y->chroma_is_dm) bin(&s, CU_CPRED, 0); else { bin(&s, CU_CPRED, 1); ep(&s, 2); }
+  }
+  intra_subdiv_cbf(cfg, y, st, coder, parts, tr_depth, part, b_luma, b_chroma);
+  if (b_luma) intra_coeff(cfg, y, st, coder, parts, tr_depth, part, 0);
+  if (b_chroma) { intra_coeff(cfg, y, st, coder, parts, tr_depth, part, 1); intra_coeff(cfg, y, st, coder, parts, tr_depth, part, 2); }
+  return (uint32_t)(coder->frac >> 15);
+}

@@ -250,7 +250,7 @@ def main():
     # --rqt: the full transform-size search of the same CUs (three levels of transform units, transform-skip retry, context chaining, recount)
     if args.rqt:
         d_rq, d_rqr, rq_cls, d_rqc, d_rqx, d_rqf, d_rqs, d_rqb = [], [], [], [], [], [], [], []
-        cu_snap = np.zeros((1, 16), np.uint8)
+        cu_snap = np.zeros((1, hp.CABAC_CU_CTX_BYTES), np.uint8)
         L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         chk(L.hop_cabac_cu_init(cu_snap.ctypes.data, 3, QP), "cabac_cu_init")
         d_cusnap = torch.from_numpy(cu_snap).to(dev)

@@ -147,6 +147,9 @@ int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu
                        const hop_cu_syntax* d_syn, const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
                        uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);
 int hop_launch_intra_modes(hop_ctx* c, int n, const hop_intra_modes_job* d_jobs, const uint32_t* d_satd, hop_intra_modes_result* d_res);
+int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn,
+                             const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, uint32_t* d_bits,
+                             hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);
 size_t hop_rqt_work_bytes(int log2_cu, int n);
 int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
                          const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_res, int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, void* buf, size_t buf_bytes);

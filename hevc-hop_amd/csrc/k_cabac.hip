@@ -104,17 +104,18 @@ int hop_cabac_init(hop_cabac_ctx* ctx, int slice_type, int qp) {
   return HOP_OK;
 }
 
-// CU-level sets of hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2]; rows B, P, I, ISS, PSS
-// (TLibCommon/ContextTables.h:140-310, 472-482)
-static const uint8_t h_cu_init[5][16] = {
-  { 197, 185, 201, 154, 137, 154, 139, 154, 154, 134, 169, 198, 168, 154, 169, 198 },
-  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198 },
-  { CNU, CNU, CNU, CNU, CNU, 184, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU },
-  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198 },
-  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198 } };
+// CU-level sets of hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2], intra_pred, chroma_pred[2];
+// rows B, P, I, ISS, PSS (TLibCommon/ContextTables.h:140-310, 472-482)
+static const uint8_t h_cu_init[5][20] = {
+  { 197, 185, 201, 154, 137, 154, 139, 154, 154, 134, 169, 198, 168, 154, 169, 198, 183, 152, 139, CNU },
+  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198, 154, 152, 139, CNU },
+  { CNU, CNU, CNU, CNU, CNU, 184, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, 184,  63, 139, CNU },
+  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198, 154, 152, 139, CNU },
+  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198, 154, 152, 139, CNU } };
 int hop_cabac_cu_init(hop_cabac_cu_ctx* ctx, int slice_type, int qp) {
   if (!ctx || slice_type < 0 || slice_type > 4) return HOP_ERR_ARG;
-  for (int i = 0; i < 16; i++) ctx->state[i] = h_ctx_init(qp, h_cu_init[slice_type][i]);
+  for (int i = 0; i < 19; i++) ctx->state[i] = h_ctx_init(qp, h_cu_init[slice_type][i]);
+  ctx->state[19] = 0;
   return HOP_OK;
 }
 
@@ -150,7 +151,7 @@ int hop_cabac_est_bits(const hop_cabac_ctx* ctx, int width, int comp, hop_estbit
 } // extern "C"
 
 // ---- device: counted bits of codeCoeffNxN, one lane per TU ----
-struct CabacLds { uint8_t st[168][64]; uint16_t absCoeff[16][64]; };      // rows 0..151: hop_cabac_ctx; 152..167: the CU-level sets of hop_cabac_cu_ctx (k_rqt.inl)
+struct CabacLds { uint8_t st[172][64]; uint16_t absCoeff[16][64]; };      // rows 0..151: hop_cabac_ctx; 152..171: the CU-level sets of hop_cabac_cu_ctx (k_rqt.inl)
 
 #define CBIN(idx, b) do { const int i_ = (idx); const uint8_t s_ = sh.st[i_][lane]; const int b_ = (b); frac += (unsigned long long)c_entropy_bits[s_ ^ b_]; \
                           sh.st[i_][lane] = ((s_ & 1) == b_) ? c_next_mps[s_] : c_next_lps[s_]; } while (0)

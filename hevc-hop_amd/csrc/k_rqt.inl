@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]);
-  for (int q = 0; q < 16; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
+  for (int q = 0; q < 20; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
   const hop_cu_syntax y = syn[i];
   const hop_rqt_result* r = res + i;
   const int parts = 1 << (2 * (k.log2_cu - 2));
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt
   bits_out[i] = (uint32_t)(frac >> 15);
   skipped_out[i] = skipped;
   if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
-  if (cu_out) for (int q = 0; q < 16; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
+  if (cu_out) for (int q = 0; q < 20; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
 }
 
 int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
@@ -558,5 +558,112 @@ int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "cu_bits launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+// =====================================================================================================================
+// The bits of an intra CU's quadtree as the intra search counts them: TEncSearch::xGetIntraBitsQT (TLibEncoder/TEncSearch.cpp:957-980) = xEncIntraHeader
+// (:887-954), xEncSubdivCbfQT (:764-830), xEncCoeffQT (:833-884), from the node (tr_depth, part) downwards.  One lane per job.
+// =====================================================================================================================
+#define CU_IPRED (CUX + 16)
+#define CU_CPRED (CUX + 17)
+__device__ static inline int icu_scan(const hop_intra_cu_syntax& y, int parts, int part, int log2w, int comp) {      // TComDataCU::getCoefScanIdx, intra
+  const int dir = comp ? (y.chroma_is_dm ? y.luma_dir[0] : y.chroma_dir) : y.luma_dir[y.part_nxn ? part / (parts >> 2) : 0];
+  const bool multi = comp ? (log2w == 2 || log2w == 1) : (log2w == 2 || log2w == 3);                                 // sizes with direction-dependent scans
+  if (!multi) return 0;
+  const int dv = dir - 26, dh = dir - 10;
+  return (dv < 0 ? -dv : dv) < 5 ? 1 : ((dh < 0 ? -dh : dh) < 5 ? 2 : 0);
+}
+__device__ static unsigned long long icu_dir(CabacLds& sh, const int lane, const int dir, const int32_t* preds, const int pred_num) {   // codeIntraDirLumaAng, one PU
+  unsigned long long frac = 0;
+  int idx = -1;
+  for (int q = 0; q < pred_num; q++) if (dir == preds[q]) idx = q;
+  CBIN(CU_IPRED, idx != -1);
+  CEP(idx == -1 ? 5 : (idx ? 2 : 1));
+  return frac;
+}
+
+__global__ __launch_bounds__(64) void k_intra_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                      const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                      const hop_cabac_cu_ctx* __restrict__ cu_in, uint32_t* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out,
+                                                      hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const int ci = jobs[i].ctx_index;
+  RQ_LOAD(ctx_in[ci]);
+  for (int q = 0; q < 20; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
+  const hop_intra_cu_syntax y = syn[i];
+  const hop_rqt_result* r = res + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  const int32_t* cf = coef + (size_t)i * (cu2 + (cu2 >> 1));
+  unsigned long long frac = RQ_LEFT();
+  // xEncIntraHeader
+  if (y.b_luma) {
+    if (y.part == 0) {
+      CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
+      CBIN(CU_PRED, 1);                                              // MODE_INTRA
+      if (y.is_min_cu) CBIN(CU_PART, y.part_nxn ? 0 : 1);
+    }
+    if (!y.part_nxn) { if (y.part == 0) frac += icu_dir(sh, lane, y.luma_dir[0], y.preds[0], y.pred_num[0]); }
+    else {
+      const int q4 = parts >> 2;
+      if (y.tr_depth == 0) { for (int p = 0; p < 4; p++) frac += icu_dir(sh, lane, y.luma_dir[p], y.preds[p], y.pred_num[p]); }
+      else if (y.part % q4 == 0) frac += icu_dir(sh, lane, y.luma_dir[y.part / q4], y.preds[y.part / q4], y.pred_num[y.part / q4]);
+    }
+  }
+  if (y.b_chroma && y.part == 0) { if (y.chroma_is_dm) CBIN(CU_CPRED, 0); else { CBIN(CU_CPRED, 1); CEP(2); } }
+  // xEncSubdivCbfQT, then xEncCoeffQT per component: pass 0 = flags, passes 1..3 = levels of Y, Cb, Cr
+  for (int pass = 0; pass < 4; pass++) {
+    if (pass == 1 && !y.b_luma) continue;
+    if (pass >= 2 && !y.b_chroma) continue;
+    int sp_part[4], sp_k[4]; int sp = 0;
+    sp_part[0] = y.part; sp_k[0] = -1;
+    while (sp >= 0) {
+      const int part = sp_part[sp], trDepth = y.tr_depth + sp, log2 = k.log2_cu - trDepth;
+      if (sp_k[sp] < 0) {
+        const int trMode = r->tr_idx[part], subdiv = trMode > trDepth;
+        if (pass == 0) {
+          if (!((y.part_nxn && trDepth == 0) || log2 > k.log2_max_tu || log2 == 2 || log2 == k.log2_min_tu) && y.b_luma) CBIN(CX_TRANS_SUBDIV + 5 - log2, subdiv);
+          if (y.b_chroma && log2 > 2) {
+            if (trDepth == 0 || ((r->cbf[1][part] >> (trDepth - 1)) & 1)) CBIN(rqt_cbf_ctx(1, trDepth), (r->cbf[1][part] >> trDepth) & 1);
+            if (trDepth == 0 || ((r->cbf[2][part] >> (trDepth - 1)) & 1)) CBIN(rqt_cbf_ctx(2, trDepth), (r->cbf[2][part] >> trDepth) & 1);
+          }
+        }
+        if (!subdiv) {
+          if (pass == 0) { if (y.b_luma) CBIN(rqt_cbf_ctx(0, trMode), (r->cbf[0][part] >> trMode) & 1); }
+          else {
+            const int comp = pass - 1;
+            int d = trDepth; bool code = true;
+            if (comp && log2 == 2) { d--; code = (part % (parts >> (2 * d))) == 0; }
+            if (code) {
+              const int lg = k.log2_cu - d - (comp ? 1 : 0);
+              const int32_t* cp = cf + (comp == 0 ? (size_t)(16 * part) : cu2 + (size_t)(comp - 1) * (cu2 >> 2) + (size_t)(4 * part));
+              frac += cb_code_tu(sh, lane, cp, lg, comp != 0, icu_scan(y, parts, part, lg, comp), k.sign_hide, k.use_ts, r->tskip[comp][part], 0, scans);
+            }
+          }
+          sp--; continue;
+        }
+        sp_k[sp] = 0;
+      }
+      if (sp_k[sp] < 4) { const int q = (parts >> (2 * trDepth)) >> 2, kk = sp_k[sp]++; sp_part[sp + 1] = part + kk * q; sp_k[sp + 1] = -1; sp++; }
+      else sp--;
+    }
+  }
+  bits_out[i] = (uint32_t)(frac >> 15);
+  if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
+  if (cu_out) for (int q = 0; q < 20; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
+}
+
+int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn,
+                             const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, uint32_t* d_bits,
+                             hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
+  hipLaunchKernelGGL(k_intra_cu_bits, dim3((n + 63) / 64), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_ctx_out, d_cu_out, c->rdoq_scans);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_cu_bits launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }

@@ -68,10 +68,13 @@ RQT_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("log2_cu", "<i4"), ("qp_s
                           ("dist_weight", "<f8", (2,))])
 RQT_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("bits", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("pad", "<u4"), ("tr_idx", "u1", (256,)), ("cbf", "u1", (3, 256)),
                              ("tskip", "u1", (3, 256))])
+CABAC_CU_CTX_BYTES = 20
 CU_SYNTAX_DTYPE = np.dtype([("part_size", "<i4"), ("n_pu", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("amp_acc", "<i4"), ("is_min_cu", "<i4"), ("max_merge_cand", "<i4"),
                             ("pu", [("merge_flag", "<i4"), ("merge_idx", "<i4"), ("mvd", "<i4", (2,)), ("mvp_idx", "<i4"), ("gt_flag", "<i4"), ("gt", "<i4", (8,))], (4,))])
 INTRA_MODES_JOB_DTYPE = np.dtype([("preds", "<i4", (3,)), ("pred_num", "<i4"), ("mpm_cand", "<i4"), ("num_full_rd", "<i4"), ("ctx_state", "<i4"), ("frac_left", "<i4"), ("sqrt_lambda", "<f8")])
 INTRA_MODES_RESULT_DTYPE = np.dtype([("n", "<u4"), ("modes", "<u4", (11,)), ("costs", "<f8", (8,))])
+INTRA_CU_SYNTAX_DTYPE = np.dtype([("part_nxn", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("is_min_cu", "<i4"), ("luma_dir", "<i4", (4,)), ("preds", "<i4", (4, 3)),
+                                  ("pred_num", "<i4", (4,)), ("chroma_is_dm", "<i4"), ("chroma_dir", "<i4"), ("tr_depth", "<i4"), ("part", "<i4"), ("b_luma", "<i4"), ("b_chroma", "<i4")])
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -309,10 +312,10 @@ class Context:
         return res, coef, fin
 
     def inter_cu_bits(self, jobs, syntax, res, coef, ctx_in, cu_ctx_in):
-        """CU-level syntax bits (xAddSymbolBitsInter): returns bits, skipped, coder states (n, 152) and CU-level states (n, 16) afterwards"""
+        """CU-level syntax bits (xAddSymbolBitsInter): returns bits, skipped, coder states (n, 152) and CU-level states (n, 20) afterwards"""
         jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, CU_SYNTAX_DTYPE); res = np.ascontiguousarray(res, RQT_RESULT_DTYPE)
         coef = np.ascontiguousarray(coef, np.int32); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
-        n = len(jobs); bits = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32); cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, 16), np.uint8)
+        n = len(jobs); bits = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32); cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, CABAC_CU_CTX_BYTES), np.uint8)
         self.L.hop_inter_cu_bits.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 6
         self._chk(self.L.hop_inter_cu_bits(self.h, n, jobs.ctypes.data, syntax.ctypes.data, res.ctypes.data, coef.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data,
                                            bits.ctypes.data, sk.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_inter_cu_bits")
@@ -323,6 +326,16 @@ class Context:
         self.L.hop_intra_modes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self._chk(self.L.hop_intra_modes(self.h, len(jobs), jobs.ctypes.data, satd.ctypes.data, res.ctypes.data), "hop_intra_modes")
         return res
+
+    def intra_cu_bits(self, jobs, syntax, res, coef, ctx_in, cu_ctx_in):
+        """xGetIntraBitsQT: returns bits, coder states (n, 152) and CU-level states (n, 20) afterwards"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, INTRA_CU_SYNTAX_DTYPE); res = np.ascontiguousarray(res, RQT_RESULT_DTYPE)
+        coef = np.ascontiguousarray(coef, np.int32); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); bits = np.zeros(n, np.uint32); cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, CABAC_CU_CTX_BYTES), np.uint8)
+        self.L.hop_intra_cu_bits.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 5
+        self._chk(self.L.hop_intra_cu_bits(self.h, n, jobs.ctypes.data, syntax.ctypes.data, res.ctypes.data, coef.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data,
+                                           bits.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_intra_cu_bits")
+        return bits, cx, cu
 
     def intra_pred(self, jobs, modes):
         n = len(jobs)

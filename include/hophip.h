@@ -390,7 +390,8 @@ int hop_rqt_finish_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const 
  * flag / index or MVD (codeMvd :944-1048), MVP index (:434-467), GT flag (:654-677) and the GT corner vectors (codeGT :1051-1330: corners 0..2, coded like
  * MVDs on their own two contexts), the root cbf and the transform tree in bitstream order (TEncEntropy::encodeCoeff :633-660, xEncodeTransform :219-394).
  * One reference list with one picture, no transquant bypass, no delta QP. */
-typedef struct { uint8_t state[16]; } hop_cabac_cu_ctx;   /* m_ucState of: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2] */
+typedef struct { uint8_t state[20]; } hop_cabac_cu_ctx;   /* m_ucState of: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2],
+                                                              prev_intra_luma_pred_flag, chroma_pred[2], one unused byte */
 typedef struct {
   int32_t part_size;               /* PartSize: 0 2Nx2N, 1 2NxN, 2 Nx2N, 3 NxN, 4 2NxnU, 5 2NxnD, 6 nLx2N, 7 nRx2N */
   int32_t n_pu, skip_flag, skip_ctx;   /* isSkipped, getCtxSkipFlag (skipped CUs left + above) */
@@ -405,6 +406,20 @@ int hop_cabac_cu_init(hop_cabac_cu_ctx* ctx, int slice_type, int qp);
 int hop_inter_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
                       const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, uint32_t* skipped, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
 
+/* replaces: TEncSearch::xGetIntraBitsQT (TLibEncoder/TEncSearch.cpp:957-980) through the counting coder: xEncIntraHeader (:887-954: skip flag, prediction mode,
+ * partition size, the luma directions of the CU -- or of the PU that starts at this node --, the chroma direction), xEncSubdivCbfQT (:764-830) and xEncCoeffQT
+ * (:833-884) of the asked components from the node (tr_depth, part) downwards.  coef: the levels of the current tree in the CU layout (what the layer buffers hold
+ * for the transform units the tr_idx array describes).  No PCM, no transquant bypass, not an I slice (the skip flag and prediction mode are coded). */
+typedef struct {
+  int32_t part_nxn;                /* 0: 2Nx2N, 1: NxN */
+  int32_t skip_flag, skip_ctx, is_min_cu;
+  int32_t luma_dir[4], preds[4][3], pred_num[4];   /* per PU: getLumaIntraDir, getIntraDirLumaPredictor */
+  int32_t chroma_is_dm, chroma_dir;   /* chroma direction == DM_CHROMA_IDX; otherwise the direction (it selects the coefficient scan) */
+  int32_t tr_depth, part;          /* the node: transform depth and first 4x4 partition (z-order inside the CU) */
+  int32_t b_luma, b_chroma;        /* what to count */
+} hop_intra_cu_syntax;
+int hop_intra_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
+                      const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -49,7 +49,7 @@ def main():
             b = np.zeros(150, np.uint8); O.hop_o_cabac_init(b.ctypes.data, st, qp)
             assert np.array_equal(b, init[st, qp])
     # the CU-level sets of an SS/GT CU's syntax (hop_cabac_cu_ctx): every slice type x QP -> tests/golden/cabac_cu.npz
-    cu_init = np.zeros((5, 52, 16), np.uint8)
+    cu_init = np.zeros((5, 52, 19), np.uint8)
     R.ref_cabac_cu_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     for st in range(5):
         for qp in range(52):

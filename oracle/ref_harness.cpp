@@ -414,18 +414,20 @@ void ref_cabac_init(int sliceType, int qp, uint8_t* states)
   s.m_cTransformSkipSCModel.initBuffer(t, qp, (UChar*)INIT_TRANSFORMSKIP_FLAG);
   sbac_store(s, states);
 }
-// the CU-level sets an SS/GT CU's syntax uses, in the order of hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2]
-void ref_cabac_cu_init(int sliceType, int qp, uint8_t* states16)
+// the CU-level sets in the order of hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2], intra_pred, chroma_pred[2]
+void ref_cabac_cu_init(int sliceType, int qp, uint8_t* states19)
 {
   SbacCtx* c = sbac_get(); TEncSbac& s = c->sbac; SliceType t = (SliceType)sliceType;
   s.m_cCUSkipFlagSCModel.initBuffer(t, qp, (UChar*)INIT_SKIP_FLAG); s.m_cCUMergeFlagExtSCModel.initBuffer(t, qp, (UChar*)INIT_MERGE_FLAG_EXT);
   s.m_cCUMergeIdxExtSCModel.initBuffer(t, qp, (UChar*)INIT_MERGE_IDX_EXT); s.m_cCUPartSizeSCModel.initBuffer(t, qp, (UChar*)INIT_PART_SIZE);
   s.m_cCUPredModeSCModel.initBuffer(t, qp, (UChar*)INIT_PRED_MODE); s.m_cCUMvdSCModel.initBuffer(t, qp, (UChar*)INIT_MVD); s.m_cMVPIdxSCModel.initBuffer(t, qp, (UChar*)INIT_MVP_IDX);
   s.m_cCUGTFlagExtSCModel.initBuffer(t, qp, (UChar*)INIT_GT_FLAG_EXT); s.m_cCUGTSCModel.initBuffer(t, qp, (UChar*)INIT_GT);
-  ContextModel* p[9] = { s.m_cCUSkipFlagSCModel.get(0), s.m_cCUMergeFlagExtSCModel.get(0), s.m_cCUMergeIdxExtSCModel.get(0), s.m_cCUPartSizeSCModel.get(0), s.m_cCUPredModeSCModel.get(0),
-                         s.m_cCUMvdSCModel.get(0), s.m_cMVPIdxSCModel.get(0), s.m_cCUGTFlagExtSCModel.get(0), s.m_cCUGTSCModel.get(0) };
-  const int n[9] = { 3, 1, 1, 4, 1, 2, 1, 1, 2 };
-  int k = 0; for (int i = 0; i < 9; i++) for (int j = 0; j < n[i]; j++) states16[k++] = p[i][j].m_ucState;
+  s.m_cCUIntraPredSCModel.initBuffer(t, qp, (UChar*)INIT_INTRA_PRED_MODE); s.m_cCUChromaPredSCModel.initBuffer(t, qp, (UChar*)INIT_CHROMA_PRED_MODE);
+  ContextModel* p[11] = { s.m_cCUSkipFlagSCModel.get(0), s.m_cCUMergeFlagExtSCModel.get(0), s.m_cCUMergeIdxExtSCModel.get(0), s.m_cCUPartSizeSCModel.get(0), s.m_cCUPredModeSCModel.get(0),
+                         s.m_cCUMvdSCModel.get(0), s.m_cMVPIdxSCModel.get(0), s.m_cCUGTFlagExtSCModel.get(0), s.m_cCUGTSCModel.get(0), s.m_cCUIntraPredSCModel.get(0),
+                         s.m_cCUChromaPredSCModel.get(0) };
+  const int n[11] = { 3, 1, 1, 4, 1, 2, 1, 1, 2, 1, 2 };
+  int k = 0; for (int i = 0; i < 11; i++) for (int j = 0; j < n[i]; j++) states19[k++] = p[i][j].m_ucState;
 }
 // TEncSbac::estBit (TEncSbac.cpp:2175-2370); est: an estBitsSbacStruct image, updated in place like the reference's
 void ref_cabac_est_bits(const uint8_t* states, int width, int ttype, int32_t* est)

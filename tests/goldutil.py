@@ -169,3 +169,19 @@ def encoder_cubits_calls():
         yield dict(cfg=g["cfg"][i], syn=g["syn"][i], arr=g["arr"][i], coef=np.ascontiguousarray(g["coef"][o:o + n]), cin=g["cin"][i], cuin=g["cuin"][i], cout=g["cout"][i],
                    cuout=g["cuout"][i], bits=int(g["bits"][i]), skipped=int(g["skipped"][i]))
         o += n
+
+
+INTRA_SYN = np.dtype([("part_nxn", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("is_min_cu", "<i4"), ("luma_dir", "<i4", (4,)), ("preds", "<i4", (4, 3)), ("pred_num", "<i4", (4,)),
+                      ("chroma_is_dm", "<i4"), ("chroma_dir", "<i4")])
+
+
+def encoder_intrabits_calls():
+    """tests/golden/encoder_intrabits_calls.npz (oracle/make_golden12.py): xGetIntraBitsQT calls of two real encodes: cfg, syntax (hop_o_intra_syntax image), node
+    (tr_depth, part, luma, chroma), tr_idx | cbf[3] | tskip[3], levels of the current tree in the CU layout, coder / CU-level contexts in and out, bits"""
+    g = load("encoder_intrabits_calls.npz")
+    o = 0
+    for i in range(len(g["bits"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu * 3 // 2
+        yield dict(cfg=g["cfg"][i], syn=g["syn"][i], nd=[int(v) for v in g["nd"][i]], arr=g["arr"][i], coef=np.ascontiguousarray(g["coef"][o:o + n]), cin=g["cin"][i],
+                   cuin=g["cuin"][i], cout=g["cout"][i], cuout=g["cuout"][i], bits=int(g["bits"][i]))
+        o += n

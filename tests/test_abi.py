@@ -88,6 +88,6 @@ def test_cabac_cu_init_vs_golden():
     g = load("cabac_cu.npz")["init"]
     for st in range(5):
         for qp in range(52):
-            b = np.full(16, 0xEE, np.uint8)
-            assert L.hop_cabac_cu_init(b.ctypes.data, st, qp) == 0 and np.array_equal(b, g[st, qp]), (st, qp)
+            b = np.full(20, 0xEE, np.uint8)
+            assert L.hop_cabac_cu_init(b.ctypes.data, st, qp) == 0 and np.array_equal(b[:19], g[st, qp]) and b[19] == 0, (st, qp)
     assert L.hop_cabac_cu_init(b.ctypes.data, 7, 30) != 0

@@ -460,7 +460,7 @@ def test_cu_bits_encoder_calls(hp):
     cases = list(encoder_cubits_calls())
     n = len(cases)
     jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.CU_SYNTAX_DTYPE); res = np.zeros(n, hp.RQT_RESULT_DTYPE)
-    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, 16), np.uint8)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
     for i, c in enumerate(cases):
         cfg = c["cfg"]; j = jobs[i]
         j["log2_cu"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"], j["inter_split_flag"] = (
@@ -469,13 +469,13 @@ def test_cu_bits_encoder_calls(hp):
         syn[i] = c["syn"]
         a = c["arr"].reshape(7, 256); res[i]["tr_idx"] = a[0]; res[i]["cbf"] = a[1:4]; res[i]["tskip"] = a[4:7]
         snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
-        cus[i] = c["cuin"]
+        cus[i, :16] = c["cuin"]
     ctx = hp.Context(64, 64)
     bits, sk, cx, cu = ctx.inter_cu_bits(jobs, syn, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
     for i, c in enumerate(cases):
         assert (int(bits[i]), int(sk[i])) == (c["bits"], c["skipped"]), (i, int(c["cfg"]["log2_cu"]), int(c["syn"]["part_size"]), bits[i], c["bits"])
         assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), i
-        assert np.array_equal(cu[i], c["cuout"]), i
+        assert np.array_equal(cu[i, :16], c["cuout"]) and not cu[i, 16:].any(), i
     bad = syn.copy(); bad[0]["part_size"] = 9
     with pytest.raises(hp.HopError):
         ctx.inter_cu_bits(jobs, bad, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
@@ -512,4 +512,34 @@ def test_intra_modes_vs_oracle(hp):
     bad = jobs[:1].copy(); bad["num_full_rd"] = 9
     with pytest.raises(hp.HopError):
         ctx.intra_modes(bad, satd[:1])
+    ctx.close()
+
+
+def test_intra_cu_bits_encoder_calls(hp):
+    """hop_intra_cu_bits (xGetIntraBitsQT through the lane-wise counting coder: intra CU header with the luma directions against their most probable modes, chroma
+    direction, split / cbf tree, levels with the direction-dependent scans) on 87 calls recorded inside the encoder: 2Nx2N and NxN, every node depth, luma-only /
+    chroma-only / both: bits and all residual and CU-level context states afterwards"""
+    from goldutil import encoder_intrabits_calls
+    cases = list(encoder_intrabits_calls())
+    n = len(cases)
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); res = np.zeros(n, hp.RQT_RESULT_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; j = jobs[i]
+        j["log2_cu"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = int(cfg["log2_cu"]), i, cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"]
+        j["lambda_rd"] = 1.0; j["lambda_rdoq"] = 1.0
+        for k in ("part_nxn", "skip_flag", "skip_ctx", "is_min_cu", "luma_dir", "preds", "pred_num", "chroma_is_dm", "chroma_dir"): syn[i][k] = c["syn"][k]
+        syn[i]["tr_depth"], syn[i]["part"], syn[i]["b_luma"], syn[i]["b_chroma"] = c["nd"]
+        a = c["arr"].reshape(7, 256); res[i]["tr_idx"] = a[0]; res[i]["cbf"] = a[1:4]; res[i]["tskip"] = a[4:7]
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i] = c["cuin"]
+    ctx = hp.Context(64, 64)
+    bits, cx, cu = ctx.intra_cu_bits(jobs, syn, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
+    for i, c in enumerate(cases):
+        assert int(bits[i]) == c["bits"], (i, int(c["cfg"]["log2_cu"]), c["nd"], int(bits[i]), c["bits"])
+        assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), i
+        assert np.array_equal(cu[i], c["cuout"]), i
+    bad = syn.copy(); bad[0]["part"] = 3
+    with pytest.raises(hp.HopError):
+        ctx.intra_cu_bits(jobs, bad, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
     ctx.close()

@@ -106,3 +106,27 @@ def test_intra_mode_bits_on_encoder_calls():
     n = O.hop_o_intra_cand_list(satd, 60, 100, 7.6, preds, 3, 3, 3, modes, costs)
     # the two cheap modes, then mode 0 (the most probable mode with the shortest code among the rest); the missing most probable modes 1 and 26 appended
     assert n == 5 and list(modes)[:5] == [20, 7, 0, 1, 26] and costs[0] < costs[1] < costs[2]
+
+
+def test_intra_cu_bits_on_encoder_calls():
+    """xGetIntraBitsQT (intra CU header, split / cbf tree, levels from a node downwards): the restatement on 87 calls recorded inside the encoder, fed with the
+    levels of the current tree in the CU layout (every layer pointer at the same array): bits and every context state afterwards"""
+    from goldutil import encoder_intrabits_calls, RQT_CFG, INTRA_SYN, _OCoder, _OState
+    O = oracle()
+    O.hop_o_intra_cu_bits.restype = ctypes.c_uint32
+    n = 0; kinds = set()
+    for c in encoder_intrabits_calls():
+        cfg = np.zeros(1, RQT_CFG); cfg[0] = c["cfg"]; syn = np.zeros(1, INTRA_SYN); syn[0] = c["syn"]
+        cu2 = 1 << (2 * int(cfg[0]["log2_cu"]))
+        st = _OState(); ctypes.memmove(ctypes.byref(st), c["arr"].tobytes(), 256 * 7)
+        planes = [np.ascontiguousarray(c["coef"][:cu2]), np.ascontiguousarray(c["coef"][cu2:cu2 + cu2 // 4]), np.ascontiguousarray(c["coef"][cu2 + cu2 // 4:])]
+        for l in range(4):
+            for k in range(3): st.coef[3 * l + k] = planes[k].ctypes.data
+        coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), c["cin"].tobytes(), 160)
+        cu = c["cuin"].copy()
+        bits = O.hop_o_intra_cu_bits(cfg.ctypes.data_as(ctypes.c_void_p), syn.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), c["nd"][0], c["nd"][1], c["nd"][2], c["nd"][3],
+                                     ctypes.byref(coder), cu.ctypes.data_as(ctypes.c_void_p))
+        assert bits == c["bits"], (n, bits, c["bits"])
+        assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
+        kinds.add((int(syn[0]["part_nxn"]), c["nd"][2], c["nd"][3])); n += 1
+    assert n == 87 and len(kinds) >= 4

@@ -969,6 +969,38 @@ int hop_intra_pred(hop_ctx* c, int n, const hop_intra_job* jobs, const int32_t* 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
+int hop_intra_pred_chroma(hop_ctx* c, int n, const hop_intra_job* jobs, const int32_t* modes) {
+  if (!c || n < 0 || (n && (!jobs || !modes))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_pred_chroma: bad argument");
+  if (n == 0) return HOP_OK;
+  const int cw = c->pic_w >> 1, ch = c->pic_h >> 1;
+  for (int i = 0; i < n; i++) {
+    const hop_intra_job& j = jobs[i];
+    const int N = j.size, x = j.x >> 1, y = j.y >> 1;
+    if (!(N == 4 || N == 8 || N == 16 || N == 32) || j.x < 0 || j.y < 0 || (j.x & 7) || (j.y & 7) || x + N > cw || y + N > ch || modes[i] < 0 || modes[i] > 34)
+      return hop_set_err(c, HOP_ERR_ARG, "chroma intra pred job %d: illegal block or mode", i);
+    const int U = N / 2;
+    for (int u = 0; u < 4 * U + 1; u++) if (j.flags[u]) {
+      bool ok;
+      if (u < 2 * U) ok = x > 0 && y + 2 * (2 * U - 1 - u) + 2 <= ch;
+      else if (u == 2 * U) ok = x > 0 && y > 0;
+      else ok = y > 0 && x + 2 * (u - 2 * U - 1) + 2 <= cw;
+      if (!ok) return hop_set_err(c, HOP_ERR_ARG, "chroma intra pred job %d: neighbour unit %d flagged available but outside the picture", i, u);
+    }
+  }
+  const size_t bj = (size_t)n * sizeof(hop_intra_job), o_m = (bj + 255) & ~(size_t)255;
+  void* st; int r = hop_stage(c, o_m + (size_t)n * 4 + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b, jobs, bj, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_m, modes, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_intra_pred_chroma(c, n, (const hop_intra_job*)b, (const int32_t*)(b + o_m)); if (r) return r;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+int hop_intra_pred_chroma_device(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_modes))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_pred_chroma_device: bad argument");
+  if (n == 0) return HOP_OK;
+  return hop_launch_intra_pred_chroma(c, n, d_jobs, d_modes);
+}
 int hop_intra_pred_device(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes) {
   if (!c || n < 0 || (n && (!d_jobs || !d_modes))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_pred_device: bad argument");
   if (n == 0) return HOP_OK;

@@ -134,6 +134,7 @@ int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_o
 int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off);
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
 int hop_launch_intra_pred(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes);
+int hop_launch_intra_pred_chroma(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes);
 int hop_launch_rdoq(hop_ctx* c, int n, const hop_rdoq_job* d_jobs, const hop_estbits* d_tables, const int32_t* d_src, int32_t* d_dst, uint32_t* d_abs_sum,
                     void* d_work /* hop_rdoq_work_bytes(n) */);
 size_t hop_rdoq_work_bytes(int n);

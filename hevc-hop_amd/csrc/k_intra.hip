@@ -29,15 +29,16 @@ struct IntraShared {
 };
 
 // one predicted sample of mode `mode` at column x, row y
-__device__ static inline int intra_sample(const IntraShared& sh, int N, int log2N, int mode, int x, int y, int maxVal) {
+// luma: the smoothed line where the mode asks for it and the edge filters of small blocks; chroma (predIntraChromaAng, TComPrediction.cpp:375-390): neither
+__device__ static inline int intra_sample(const IntraShared& sh, int N, int log2N, int mode, int x, int y, int maxVal, bool luma = true) {
   int diff = min(abs(mode - 10), abs(mode - 26));
-  const bool filt = (mode != 1) && diff > c_intra_filter[log2N - 2];
+  const bool filt = luma && (mode != 1) && diff > c_intra_filter[log2N - 2];
   const int* L = sh.L[filt ? 1 : 0];
   const int* top = L + 2 * N + 1;                       // top[i], i = -1 .. 2N-1
 #define LEFT(i) (L[2 * N - 1 - (i)])
   if (mode == 0)                                        // planar (closed form of :1486-1503)
     return ((N - 1 - x) * LEFT(y) + (x + 1) * top[N] + (N - 1 - y) * top[x] + (y + 1) * LEFT(N) + N) >> (log2N + 1);
-  const bool edge = N <= 16;                            // bFilter, :358-366
+  const bool edge = luma && N <= 16;                    // bFilter, :358-366
   if (mode == 1) {                                      // DC + xDCPredFiltering
     const int dcv = sh.dc;
     if (!edge) return dcv;
@@ -74,23 +75,25 @@ __device__ static inline int intra_sample(const IntraShared& sh, int N, int log2
 #undef LEFT
 }
 
-// reference line of one block: fillReferenceSamples + smoothing + DC value into sh (all 256 threads; ends with a barrier)
-__device__ static inline void intra_setup(IntraShared& sh, const hop_intra_job* jp, const hop_pics& pic, const int16_t* __restrict__ rec_y, int tid) {
-  const int N = jp->size, x0 = jp->x, y0 = jp->y, U = N >> 2, units = 4 * U + 1;
+// reference line of one block: fillReferenceSamples + smoothing + DC value into sh (all 256 threads; ends with a barrier).
+// rec / pitch / bd: the plane the neighbours come from; us: samples per availability flag (4 luma, 2 chroma: TComPattern.cpp:325-331);
+// org: the original plane for the rough search (may be null); luma: build the smoothed line too.
+__device__ static inline void intra_setup_plane(IntraShared& sh, const hop_intra_job* jp, const int16_t* __restrict__ rec_plane, int pitch, int bd, int us, int x0, int y0,
+                                                const int16_t* __restrict__ org_plane, bool luma, int tid) {
+  const int N = jp->size, U = N / us, units = 4 * U + 1;
   const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
-  const int bd = pic.bd_y, dcDefault = 1 << (bd - 1);
-  const int16_t* rec = rec_y + (size_t)y0 * pic.pic_w + x0;
-  const int pitch = pic.pic_w;
+  const int dcDefault = 1 << (bd - 1);
+  const int16_t* rec = rec_plane + (size_t)y0 * pitch + x0;
   if (tid < 35) sh.satd[tid] = 0;
-  for (int i = tid; i < N * N; i += 256) { int r = i / N, c = i - r * N; sh.org[i] = pic.org_y[(size_t)(y0 + r) * pitch + x0 + c]; }
+  if (org_plane) for (int i = tid; i < N * N; i += 256) { int r = i / N, c = i - r * N; sh.org[i] = org_plane[(size_t)(y0 + r) * pitch + x0 + c]; }
   // ---- fillReferenceSamples :374-558 : gather the available units, DC elsewhere ----
-  for (int i = tid; i < units * 4; i += 256) {
-    const int u = i >> 2, s = i & 3;
+  for (int i = tid; i < units * us; i += 256) {
+    const int u = i / us, s = i - u * us;
     int v = dcDefault;
     if (jp->flags[u]) {
-      if (u < 2 * U) { const int j = 2 * U - 1 - u; v = rec[(ptrdiff_t)(4 * j + (3 - s)) * pitch - 1]; }   // left / below-left, stored upwards
-      else if (u == 2 * U) v = rec[-(ptrdiff_t)pitch - 1];                                               // corner (4 copies)
-      else v = rec[-(ptrdiff_t)pitch + 4 * (u - 2 * U - 1) + s];                                         // above / above-right
+      if (u < 2 * U) { const int j = 2 * U - 1 - u; v = rec[(ptrdiff_t)(us * j + (us - 1 - s)) * pitch - 1]; }   // left / below-left, stored upwards
+      else if (u == 2 * U) v = rec[-(ptrdiff_t)pitch - 1];                                                     // corner (a whole unit of copies)
+      else v = rec[-(ptrdiff_t)pitch + us * (u - 2 * U - 1) + s];                                              // above / above-right
     }
     sh.line[i] = v;
   }
@@ -105,11 +108,11 @@ __device__ static inline void intra_setup(IntraShared& sh, const hop_intra_job* 
           if (cur == 0) {
             int nxt = 1;
             while (nxt < units && !jp->flags[nxt]) nxt++;
-            const int ref = sh.line[nxt * 4];
-            while (cur < nxt) { for (int i = 0; i < 4; i++) sh.line[cur * 4 + i] = ref; cur++; }
+            const int ref = sh.line[nxt * us];
+            while (cur < nxt) { for (int i = 0; i < us; i++) sh.line[cur * us + i] = ref; cur++; }
           } else {
-            const int ref = sh.line[cur * 4 - 1];
-            for (int i = 0; i < 4; i++) sh.line[cur * 4 + i] = ref;
+            const int ref = sh.line[cur * us - 1];
+            for (int i = 0; i < us; i++) sh.line[cur * us + i] = ref;
             cur++;
           }
         } else cur++;
@@ -119,17 +122,17 @@ __device__ static inline void intra_setup(IntraShared& sh, const hop_intra_job* 
   __syncthreads();
   const int n = 4 * N + 1;
   for (int i = tid; i < n; i += 256)                    // copy out :547-556
-    sh.L[0][i] = i < 2 * N ? sh.line[i] : i == 2 * N ? sh.line[2 * U * 4] : sh.line[(2 * U + 1) * 4 + (i - 2 * N - 1)];
+    sh.L[0][i] = i < 2 * N ? sh.line[i] : i == 2 * N ? sh.line[2 * U * us] : sh.line[(2 * U + 1) * us + (i - 2 * N - 1)];
   __syncthreads();
   // ---- smoothing, TComPattern.cpp:237-299 ----
   {
     const int* L = sh.L[0];
     bool strong = false;
-    if (jp->strong && N >= 32) {
+    if (luma && jp->strong && N >= 32) {
       const int bl = L[0], tl = L[2 * N], tr = L[n - 1], thr = 1 << (bd - 5);
       strong = abs(bl + tl - 2 * L[N]) < thr && abs(tl + tr - 2 * L[3 * N]) < thr;
     }
-    for (int i = tid; i < n; i += 256) {
+    if (luma) for (int i = tid; i < n; i += 256) {
       int v;
       if (i == 0 || i == n - 1) v = L[i];
       else if (strong) {
@@ -147,6 +150,9 @@ __device__ static inline void intra_setup(IntraShared& sh, const hop_intra_job* 
     }
   }
   __syncthreads();
+}
+__device__ static inline void intra_setup(IntraShared& sh, const hop_intra_job* jp, const hop_pics& pic, const int16_t* __restrict__ rec_y, int tid) {
+  intra_setup_plane(sh, jp, rec_y, pic.pic_w, pic.bd_y, 4, jp->x, jp->y, pic.org_y, true, tid);
 }
 
 __global__ __launch_bounds__(256) void k_intra_rough(const hop_intra_job* __restrict__ jobs, hop_pics pic, const int16_t* __restrict__ rec_y,
@@ -196,6 +202,31 @@ __global__ __launch_bounds__(256) void k_intra_pred(const hop_intra_job* __restr
   intra_setup(sh, jp, pic, rec_y, tid);
   int16_t* dst = pic.pred_y + (size_t)y0 * pic.pic_w + x0;
   for (int i = tid; i < N * N; i += 256) { const int r = i >> log2N, c = i & (N - 1); dst[(size_t)r * pic.pic_w + c] = (int16_t)intra_sample(sh, N, log2N, mode, c, r, maxVal); }
+}
+
+// the chroma prediction of xIntraCodingChromaBlk (TLibEncoder/TEncSearch.cpp:1200-1215: initAdiPatternChroma + predIntraChromaAng) for both planes: block i of
+// size jobs[i].size at the chroma position (x / 2, y / 2), availability per 2-sample unit, mode modes[i] (the caller resolves DM_CHROMA_IDX to the luma mode)
+__global__ __launch_bounds__(256) void k_intra_pred_chroma(const hop_intra_job* __restrict__ jobs, const int32_t* __restrict__ modes, hop_pics pic,
+                                                           const int16_t* __restrict__ rec_cb, const int16_t* __restrict__ rec_cr) {
+  __shared__ IntraShared sh;
+  const int bi = blockIdx.x >> 1, comp = 1 + (blockIdx.x & 1);
+  const hop_intra_job* jp = jobs + bi;
+  const int tid = threadIdx.x;
+  const int N = jp->size, x0 = jp->x >> 1, y0 = jp->y >> 1, pitch = pic.pic_w >> 1;
+  const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+  const int maxVal = (1 << pic.bd_c) - 1, mode = modes[bi];
+  intra_setup_plane(sh, jp, comp == 1 ? rec_cb : rec_cr, pitch, pic.bd_c, 2, x0, y0, nullptr, false, tid);
+  int16_t* dst = (comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+  for (int i = tid; i < N * N; i += 256) { const int r = i >> log2N, c = i & (N - 1); dst[(size_t)r * pitch + c] = (int16_t)intra_sample(sh, N, log2N, mode, c, r, maxVal, false); }
+}
+
+int hop_launch_intra_pred_chroma(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes) {
+  const int pr = hop_prof_begin(c, HOP_K_INTRA, (uint64_t)n);
+  hipLaunchKernelGGL(k_intra_pred_chroma, dim3(2 * n), dim3(256), 0, c->stream, d_jobs, d_modes, hop_make_pics(c), c->rec[1], c->rec[2]);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_pred_chroma launch: %s", hipGetErrorString(e));
+  return HOP_OK;
 }
 
 int hop_launch_intra_pred(hop_ctx* c, int n, const hop_intra_job* d_jobs, const int32_t* d_modes) {

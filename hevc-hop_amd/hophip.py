@@ -342,5 +342,11 @@ class Context:
         arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)
         self._chk(self.L.hop_intra_pred(self.h, n, ctypes.addressof(arr), m.ctypes.data), "hop_intra_pred")
 
+    def intra_pred_chroma(self, jobs, modes):
+        n = len(jobs)
+        arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)
+        self.L.hop_intra_pred_chroma.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_intra_pred_chroma(self.h, n, ctypes.addressof(arr), m.ctypes.data), "hop_intra_pred_chroma")
+
     def sync(self):
         self._chk(self.L.hop_sync(self.h), "hop_sync")

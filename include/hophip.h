@@ -205,6 +205,12 @@ int hop_intra_rough_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, uin
  * of mode modes[i] (0 planar, 1 DC, 2..34 angular) of block i, written into the context's prediction picture (luma). */
 int hop_intra_pred(hop_ctx* ctx, int n, const hop_intra_job* jobs, const int32_t* modes);
 int hop_intra_pred_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, const int32_t* d_modes);     /* asynchronous, unchecked */
+/* replaces: initAdiPatternChroma + predIntraChromaAng of TEncSearch::xIntraCodingChromaBlk (TLibEncoder/TEncSearch.cpp:1200-1215; TComPattern.cpp:315-372,
+ * TComPrediction.cpp:375-390) for both chroma planes: block i has size jobs[i].size (4..32) at the chroma position (x / 2, y / 2), flags give the availability
+ * per 2-sample unit in the same order as for luma (68 entries are enough: 2 * size + 1), mode modes[i] is the direction actually used (the caller resolves
+ * DM_CHROMA_IDX to the luma direction).  No reference smoothing, no edge filters.  Written into the context's prediction picture (Cb, Cr). */
+int hop_intra_pred_chroma(hop_ctx* ctx, int n, const hop_intra_job* jobs, const int32_t* modes);
+int hop_intra_pred_chroma_device(hop_ctx* ctx, int n, const hop_intra_job* d_jobs, const int32_t* d_modes);   /* asynchronous, unchecked */
 
 /* ---- rate-distortion optimised quantisation (row a11) ---- */
 /* Image of the reference's estBitsSbacStruct (TLibCommon/TComTrQuant.h:59-70): the bit estimates (15 fractional bits)

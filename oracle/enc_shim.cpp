@@ -274,7 +274,7 @@ struct Report4 { ~Report4() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "ho
 Void TComPattern::fillReferenceSamples(Int bitDepth, Pel* piRoiOrigin, Int* piAdiTemp, Bool* bNeighborFlags, Int iNumIntraNeighbor, Int iUnitSize, Int iNumUnitsInCu,
                                        Int iTotalUnits, UInt uiCuWidth, UInt uiCuHeight, UInt uiWidth, UInt uiHeight, Int iPicStride, Bool bLMmode)
 {
-  if (iUnitSize != 4 || bLMmode || uiCuWidth != uiCuHeight) {
+  if ((iUnitSize != 4 && iUnitSize != 2) || bLMmode || uiCuWidth != uiCuHeight) {
     hop_ref_orig_fill_refs(this, bitDepth, piRoiOrigin, piAdiTemp, bNeighborFlags, iNumIntraNeighbor, iUnitSize, iNumUnitsInCu, iTotalUnits, uiCuWidth, uiCuHeight,
                            uiWidth, uiHeight, iPicStride, bLMmode);
     return;
@@ -283,7 +283,7 @@ Void TComPattern::fillReferenceSamples(Int bitDepth, Pel* piRoiOrigin, Int* piAd
   const int N = (int)uiCuWidth;
   uint8_t flags[68]; int L[4 * 64 + 1];
   for (int i = 0; i < iTotalUnits; i++) flags[i] = bNeighborFlags[i] ? 1 : 0;
-  hop_o_intra_fill_refs(piRoiOrigin, iPicStride, 0, 0, N, flags, bitDepth, L);
+  hop_o_intra_fill_refs_u(piRoiOrigin, iPicStride, 0, 0, N, iUnitSize, flags, bitDepth, L);          // 4-sample units for luma, 2-sample units for the chroma planes
   piAdiTemp[0] = L[2 * N];                                                  // corner, above row, left column of the (2N+1)^2 buffer
   for (int i = 0; i < 2 * N; i++) piAdiTemp[1 + i] = L[2 * N + 1 + i];
   for (int i = 0; i < 2 * N; i++) piAdiTemp[(1 + i) * uiWidth] = L[2 * N - 1 - i];
@@ -645,4 +645,20 @@ UInt TEncSearch::xGetIntraBitsQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPar
   coder_put(sb, &coder);
   { CuSets2 r = cu_sets2(sb); const uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
   return bits;
+}
+
+// ---- chroma intra prediction: TComPrediction::predIntraChromaAng (TLibCommon/TComPrediction.cpp:375-390) -> hop_o_intra_pred_chroma ----
+namespace { unsigned long g_calls10[1] = { 0 };
+struct Report10 { ~Report10() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: chromaPred %lu\n", g_calls10[0]); } } g_report10; }
+Void TComPrediction::predIntraChromaAng(Int* piSrc, UInt uiDirMode, Pel* piPred, UInt uiStride, Int iWidth, Int iHeight, Bool bAbove, Bool bLeft)
+{
+  if (iWidth != iHeight) { fprintf(stderr, "hop shim: predIntraChromaAng on a non-square block\n"); abort(); }
+  g_calls10[0]++;
+  const int N = iWidth, sw = 2 * N + 1;
+  int L[4 * 64 + 1];
+  L[2 * N] = piSrc[0];
+  for (int i = 0; i < 2 * N; i++) { L[2 * N + 1 + i] = piSrc[1 + i]; L[2 * N - 1 - i] = piSrc[(1 + i) * sw]; }
+  int16_t pred[64 * 64];
+  hop_o_intra_pred_chroma(L, N, (int)uiDirMode, g_bitDepthC, pred);
+  for (int r = 0; r < N; r++) memcpy(piPred + r * uiStride, pred + r * N, N * sizeof(Pel));
 }

@@ -39,6 +39,8 @@ int hop_o_me_pu(const int16_t* org, int orgStride, const int16_t* refY00, int re
                 int fen, int useHad, int bitDepth, int stage, int64_t* out);
 /* ---- a7 (hop_oracle_intra.c): reference samples L[4N+1] = left column bottom-up, corner, above row left-to-right ---- */
 void hop_o_intra_fill_refs(const int16_t* rec, int stride, int x, int y, int N, const uint8_t* flags, int bitDepth, int* L);
+void hop_o_intra_fill_refs_u(const int16_t* rec, int stride, int x, int y, int N, int unit, const uint8_t* flags, int bitDepth, int* L);
+void hop_o_intra_pred_chroma(const int* L, int N, int mode, int bitDepth, int16_t* pred);
 void hop_o_intra_smooth(const int* L, int N, int bitDepth, int strong, int* F);
 void hop_o_intra_pred(const int* Lunf, const int* Lfil, int N, int mode, int bitDepth, int16_t* pred);
 void hop_o_intra_rough(const int16_t* rec, int recStride, const int16_t* org, int orgStride, int x, int y, int N,

@@ -23,22 +23,23 @@
 uint32_t hop_o_calc_had(const int16_t* a, int sa, const int16_t* b, int sb, int w, int h, int bitDepth);
 
 /* fillReferenceSamples, TComPattern.cpp:374-558 (unit size 4 = g_uiMaxCUWidth >> g_uiMaxCUDepth) */
-void hop_o_intra_fill_refs(const int16_t* rec, int stride, int x, int y, int N, const uint8_t* flags, int bitDepth, int* L)
+/* unit: samples per availability flag -- 4 for luma, 2 for the chroma planes (g_uiMaxCUWidth >> g_uiMaxCUDepth, halved: TComPattern.cpp:325-331) */
+void hop_o_intra_fill_refs_u(const int16_t* rec, int stride, int x, int y, int N, int unit, const uint8_t* flags, int bitDepth, int* L)
 {
-  const int U = N / 4, units = 4 * U + 1, dc = 1 << (bitDepth - 1);
+  const int U = N / unit, units = 4 * U + 1, dc = 1 << (bitDepth - 1);
   const int16_t* org = rec + (ptrdiff_t)y * stride + x;
   int navail = 0;
   for (int u = 0; u < units; u++) navail += flags[u] ? 1 : 0;
   if (navail == 0) { for (int i = 0; i <= 4 * N; i++) L[i] = dc; return; }
   /* line buffer in unit order; the corner owns a whole unit */
   int line[5 * 64 + 8], ok[4 * 16 + 1];
-  for (int i = 0; i < units * 4; i++) line[i] = dc;
+  for (int i = 0; i < units * unit; i++) line[i] = dc;
   for (int u = 0; u < units; u++) ok[u] = flags[u] != 0;
-  if (ok[2 * U]) for (int i = 0; i < 4; i++) line[2 * U * 4 + i] = org[-stride - 1];
+  if (ok[2 * U]) for (int i = 0; i < unit; i++) line[2 * U * unit + i] = org[-stride - 1];
   for (int u = 0; u < 2 * U; u++)                     /* left + below-left: unit 2U-1-j holds rows 4j..4j+3, stored upwards */
-    if (ok[u]) { int j = 2 * U - 1 - u; for (int i = 0; i < 4; i++) line[u * 4 + 3 - i] = org[(ptrdiff_t)(4 * j + i) * stride - 1]; }
+    if (ok[u]) { int j = 2 * U - 1 - u; for (int i = 0; i < unit; i++) line[u * unit + unit - 1 - i] = org[(ptrdiff_t)(unit * j + i) * stride - 1]; }
   for (int u = 2 * U + 1; u < units; u++)             /* above + above-right */
-    if (ok[u]) { int j = u - 2 * U - 1; for (int i = 0; i < 4; i++) line[u * 4 + i] = org[-stride + 4 * j + i]; }
+    if (ok[u]) { int j = u - 2 * U - 1; for (int i = 0; i < unit; i++) line[u * unit + i] = org[-stride + unit * j + i]; }
   /* substitution, :505-545 */
   int cur = 0;
   while (cur < units) {
@@ -46,20 +47,25 @@ void hop_o_intra_fill_refs(const int16_t* rec, int stride, int x, int y, int N, 
       if (cur == 0) {
         int nxt = 1;
         while (nxt < units && !ok[nxt]) nxt++;
-        int ref = line[nxt * 4];
-        while (cur < nxt) { for (int i = 0; i < 4; i++) line[cur * 4 + i] = ref; cur++; }
+        int ref = line[nxt * unit];
+        while (cur < nxt) { for (int i = 0; i < unit; i++) line[cur * unit + i] = ref; cur++; }
       } else {
-        int ref = line[cur * 4 - 1];
-        for (int i = 0; i < 4; i++) line[cur * 4 + i] = ref;
+        int ref = line[cur * unit - 1];
+        for (int i = 0; i < unit; i++) line[cur * unit + i] = ref;
         cur++;
       }
     } else cur++;
   }
   /* copy out, :547-556: left part as is, corner once, top part */
   for (int i = 0; i < 2 * N; i++) L[i] = line[i];
-  L[2 * N] = line[2 * U * 4];
-  for (int i = 0; i < 2 * N; i++) L[2 * N + 1 + i] = line[(2 * U + 1) * 4 + i];
+  L[2 * N] = line[2 * U * unit];
+  for (int i = 0; i < 2 * N; i++) L[2 * N + 1 + i] = line[(2 * U + 1) * unit + i];
 }
+void hop_o_intra_fill_refs(const int16_t* rec, int stride, int x, int y, int N, const uint8_t* flags, int bitDepth, int* L)
+{
+  hop_o_intra_fill_refs_u(rec, stride, x, y, N, 4, flags, bitDepth, L);
+}
+
 
 /* reference smoothing, TComPattern::initAdiPattern :237-299: [1 2 1], or the bilinear "strong" filter for 32x32 */
 void hop_o_intra_smooth(const int* L, int N, int bitDepth, int strong, int* F)
@@ -85,11 +91,11 @@ static const int kAng[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 }, kInvAng[9] = { 0,
 
 /* predIntraLumaAng, TComPrediction.cpp:340-372, with bAbove = bLeft = true (initAdiPattern :213-214).
  * pred is N x N contiguous. */
-void hop_o_intra_pred(const int* Lunf, const int* Lfil, int N, int mode, int bitDepth, int16_t* pred)
+static void intra_pred_core(const int* Lunf, const int* Lfil, int N, int mode, int bitDepth, int16_t* pred, int luma)
 {
   const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
   int diff = abs(mode - 10) < abs(mode - 26) ? abs(mode - 10) : abs(mode - 26);
-  int filt = diff > kIntraFilter[log2N - 2];
+  int filt = luma && diff > kIntraFilter[log2N - 2];
   if (mode == 1) filt = 0;
   const int* L = filt ? Lfil : Lunf;
   const int* top = L + 2 * N + 1;                      /* top[i], i = -1 .. 2N-1 (top[-1] = corner) */
@@ -105,7 +111,7 @@ void hop_o_intra_pred(const int* Lunf, const int* Lfil, int N, int mode, int bit
     }
     return;
   }
-  const int useEdge = N <= 16;                         /* bFilter of xPredIntraAng, :358-366 */
+  const int useEdge = luma && N <= 16;                 /* bFilter of xPredIntraAng, :358-366; the chroma planes never filter (:375-390) */
   if (mode == 1) {                                     /* DC, :130-167 + :1521-1541 */
     int sum = 0;
     for (int i = 0; i < N; i++) sum += top[i] + LEFT(i);
@@ -160,6 +166,10 @@ void hop_o_intra_pred(const int* Lunf, const int* Lfil, int N, int mode, int bit
   else memcpy(pred, tmp, (size_t)N * N * sizeof(int16_t));
 #undef LEFT
 }
+
+void hop_o_intra_pred(const int* Lunf, const int* Lfil, int N, int mode, int bitDepth, int16_t* pred) { intra_pred_core(Lunf, Lfil, N, mode, bitDepth, pred, 1); }
+/* predIntraChromaAng, TComPrediction.cpp:375-390: the unfiltered line, no edge filters, no DC filtering */
+void hop_o_intra_pred_chroma(const int* L, int N, int mode, int bitDepth, int16_t* pred) { intra_pred_core(L, L, N, mode, bitDepth, pred, 0); }
 
 /* The distortion half of the rough mode search of estIntraPredQT, TEncSearch.cpp:2430-2461: reference samples,
  * smoothing, 35 predictions, calcHAD against the original.  rec = reconstruction picture (sample (0,0)), org =

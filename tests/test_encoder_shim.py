@@ -1,6 +1,6 @@
 """CPU, build container only: encoder-in-the-loop check of the drop-in boundary (rows a1-a6, a9-a11 and the argument mapping of
 INTEGRATION.md).  oracle/_ref/TAppEncoderShim is the reference encoder with the members the C ABI replaces -- xPatternSearch,
-xPatternSearchFracDIF, xPatternSearchGT, xPredInterLumaBlk / ChromaBlk, xT, xIT, xDeQuant, xRateDistOptQuant, TEncSbac::estBit, fillReferenceSamples (luma), predIntraLumaAng, calcHAD, getDistPart, xTransformSkip / xITransformSkip, xCopyYuv2SSRef, xEstimateResidualQT (the whole residual quadtree search), xAddSymbolBitsInter (the CU-level syntax bits), xModeBitsIntra, xUpdateCandList, xGetIntraBitsQT -- taken from
+xPatternSearchFracDIF, xPatternSearchGT, xPredInterLumaBlk / ChromaBlk, xT, xIT, xDeQuant, xRateDistOptQuant, TEncSbac::estBit, fillReferenceSamples (luma), predIntraLumaAng, calcHAD, getDistPart, xTransformSkip / xITransformSkip, xCopyYuv2SSRef, xEstimateResidualQT (the whole residual quadtree search), xAddSymbolBitsInter (the CU-level syntax bits), xModeBitsIntra, xUpdateCandList, xGetIntraBitsQT, predIntraChromaAng (and fillReferenceSamples for the chroma planes too) -- taken from
 oracle/enc_shim.cpp, which forwards them to the CPU restatement; everything else is the reference's own object code.  It must
 write the bitstream and the reconstruction the unmodified reference wrote (tests/golden/encoder_hop_qp32.json): then for every
 call a real encode makes (real predictors and AMVP lists, sentinel regions, picture borders, AMP shapes, transform skip) the
@@ -54,7 +54,7 @@ def test_shim_encoder_writes_the_reference_bitstream(W, H, seed):
             t = ln.split(":")[1].split()
             calls.update({t[i]: int(t[i + 1]) for i in range(0, len(t), 2)})
     # the replaced members really ran (a silent fall-through to the reference's definitions would also give the same bytes)
-    for k in ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "intraPred", "calcHAD", "distPart", "tskip", "commit", "rqt", "cuBits", "modeBits", "candList", "intraBits"):
+    for k in ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "intraPred", "calcHAD", "distPart", "tskip", "commit", "rqt", "cuBits", "modeBits", "candList", "intraBits", "chromaPred"):
         assert calls.get(k, 0) > 50, (k, calls)
     assert bit == gold["bin_md5"] and rec == gold["rec_md5"], calls
 

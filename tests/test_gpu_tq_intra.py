@@ -543,3 +543,45 @@ def test_intra_cu_bits_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.intra_cu_bits(jobs, bad, res, np.concatenate([c["coef"] for c in cases]), snaps, cus)
     ctx.close()
+
+
+def test_intra_pred_chroma_vs_oracle(hp):
+    """hop_intra_pred_chroma (initAdiPatternChroma + predIntraChromaAng for both planes) against the restatement that stands in for fillReferenceSamples /
+    predIntraChromaAng inside the reference encoder: every chroma block size, all 35 directions, random availability per 2-sample unit, picture borders"""
+    O = oracle()
+    rng = np.random.default_rng(21)
+    W, H = 256, 192
+    Y, Cb, Cr = lenslet(W, H, 15, 3)
+    rec = [Y, (Cb + rng.integers(-3, 4, Cb.shape)).clip(0, 255).astype(np.int16), (Cr + rng.integers(-3, 4, Cr.shape)).clip(0, 255).astype(np.int16)]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, Cb, Cr)
+    for k in range(3):
+        ctx.plane_upload("recon", k, rec[k])
+    n = 0
+    for N in (4, 8, 16, 32):
+        for trial in range(40):
+            cx, cy = int(rng.integers(0, (W // 2 - N) // 4 + 1)) * 4, int(rng.integers(0, (H // 2 - N) // 4 + 1)) * 4
+            U = N // 2
+            fl = np.zeros(68, np.uint8)
+            for u in range(4 * U + 1):
+                if u < 2 * U: ok = cx > 0 and cy + 2 * (2 * U - 1 - u) + 2 <= H // 2
+                elif u == 2 * U: ok = cx > 0 and cy > 0
+                else: ok = cy > 0 and cx + 2 * (u - 2 * U - 1) + 2 <= W // 2
+                fl[u] = int(ok and rng.random() < 0.8)
+            mode = int(rng.integers(0, 35)) if trial >= 35 else trial
+            j = hp.IntraJob(2 * cx, 2 * cy, N, 0)
+            for k in range(68): j.flags[k] = int(fl[k])
+            ctx.intra_pred_chroma([j], [mode])
+            for comp in (1, 2):
+                got = ctx.pred_download(comp)[cy:cy + N, cx:cx + N]
+                L = (ctypes.c_int * (4 * 64 + 8))()
+                O.hop_o_intra_fill_refs_u(p16(rec[comp]), W // 2, cx, cy, N, 2, fl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 8, L)
+                want = np.zeros((N, N), np.int16)
+                O.hop_o_intra_pred_chroma(L, N, mode, 8, p16(want))
+                assert np.array_equal(got, want), (N, cx, cy, mode, comp)
+            n += 1
+    assert n == 160
+    bad = hp.IntraJob(4, 0, 8, 0)
+    with pytest.raises(hp.HopError):
+        ctx.intra_pred_chroma([bad], [3])
+    ctx.close()

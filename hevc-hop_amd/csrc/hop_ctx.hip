@@ -923,7 +923,7 @@ int hop_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* jobs, int n_ctx, const hop
         (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || j.tr_depth < 0 || j.tr_depth > 3 ||
         j.ctx_index < 0 || j.ctx_index >= n_ctx || j.bit_depth != (j.comp ? c->bd_c : c->bd_y) || !(j.lambda_rdoq > 0.0) || !(j.lambda_rd > 0.0) ||
         j.scan_idx < 0 || j.scan_idx > 2 || (!j.is_intra && (j.scan_idx || j.use_dst)) || (j.flags & ~3) ||
-        ((j.flags & HOP_TU_RD_TS) && (j.is_intra || j.log2_size != 2 || !j.use_ts)))
+        ((j.flags & HOP_TU_RD_TS) && (j.log2_size != 2 || !j.use_ts)))
       return hop_set_err(c, HOP_ERR_ARG, "TU RD job %d: illegal transform unit / snapshot / parameters", i);
     offs[i] = (int64_t)tot; tot += (size_t)N * N;
   }

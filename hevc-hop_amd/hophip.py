@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libhophip.so")
 
 HOP_STAGE_INT, HOP_STAGE_FRAC, HOP_STAGE_GT = 1, 2, 3
 HOP_FLAG_FEN, HOP_FLAG_HADME = 1, 2
+HOP_TU_RD_TS, HOP_TU_RD_KEEP = 1, 2
 HOP_DIST_SAD, HOP_DIST_SSE, HOP_DIST_HADS = 0, 1, 2
 
 

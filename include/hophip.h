@@ -286,7 +286,8 @@ int hop_coeff_bits_device(hop_ctx* ctx, int n, const hop_coeff_bits_job* d_jobs,
  * from the snapshot (integer, as getNumberOfWrittenBits) -> xDeQuant + xIT -> distortion in the residual domain -> the
  * cbf-zero decision on TComRdCost::calcRdCost values (:7008-7032).  flags select the 4x4 transform-skip variant of the retry
  * (:7210-7440); the retry's decision, the split recursion and the subtree recount are hop_rqt, the root-cbf decision hop_rqt_finish. */
-#define HOP_TU_RD_TS   1   /* the 4x4 transform-skip variant of the residual quadtree (:7210-7440): xTransformSkip / xITransformSkip, transform_skip_flag = 1 in the bits */
+#define HOP_TU_RD_TS   1   /* the 4x4 transform-skip variant (residual quadtree :7210-7440; intra retry of xRecurIntraCodingQT :1431-1470): xTransformSkip /
+                              xITransformSkip instead of the transform, transform_skip_flag = 1 in the bits */
 #define HOP_TU_RD_KEEP 2   /* no cbf-zero decision: levels, bits and distortion of coding the block are returned as they are */
 typedef struct {
   int32_t x, y;            /* luma position of the TU (chroma planes use x/2, y/2) */

@@ -131,6 +131,9 @@ int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const h
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,
                 double lambda_rdoq, double lambda_rd, double dist_weight, const hop_o_cabac_ctx* snap, uint32_t frac_left,
                 int32_t* levels, uint32_t* out, double* cost);
+int hop_o_tu_intra_ts(const int16_t* org, const int16_t* pred, int log2_size, int comp, int scan_idx, int use_dst, int qp_scaled, int bit_depth,
+                      int tr_depth, int sign_hide, int use_ts, int ts_flag, double lambda_rdoq, double lambda_rd, double dist_weight,
+                      const hop_o_cabac_ctx* snap, uint32_t frac_left, int32_t* levels, int16_t* recon, uint32_t* out, double* cost);
 int hop_o_tu_intra(const int16_t* org, const int16_t* pred, int log2_size, int comp, int scan_idx, int use_dst, int qp_scaled, int bit_depth,
                    int tr_depth, int sign_hide, int use_ts, double lambda_rdoq, double lambda_rd, double dist_weight,
                    const hop_o_cabac_ctx* snap, uint32_t frac_left, int32_t* levels, int16_t* recon, uint32_t* out, double* cost);

@@ -386,9 +386,10 @@ int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int
  * scan by intra direction, RDOQ with the intra tables), inverse path, reconstruction clip, distortion against the original.
  * org / pred / recon: N x N, stride N.  out[8]: abs_sum, cbf, dist, -, -, bits of cbf flag + levels from the snapshot (what
  * xGetIntraBitsQT will count for this block, :1340-1359 via xEncCoeffQT), -, -. */
-int hop_o_tu_intra(const int16_t* org, const int16_t* pred, int log2_size, int comp, int scan_idx, int use_dst, int qp_scaled, int bit_depth,
-                   int tr_depth, int sign_hide, int use_ts, double lambda_rdoq, double lambda_rd, double dist_weight,
-                   const hop_o_cabac_ctx* snap, uint32_t frac_left, int32_t* levels, int16_t* recon, uint32_t* out, double* cost)
+/* ts_flag: the 4x4 transform-skip variant (pcCU->getTransformSkip of the block: xTransformSkip / xITransformSkip instead of the transform, the flag coded as 1) */
+int hop_o_tu_intra_ts(const int16_t* org, const int16_t* pred, int log2_size, int comp, int scan_idx, int use_dst, int qp_scaled, int bit_depth,
+                      int tr_depth, int sign_hide, int use_ts, int ts_flag, double lambda_rdoq, double lambda_rd, double dist_weight,
+                      const hop_o_cabac_ctx* snap, uint32_t frac_left, int32_t* levels, int16_t* recon, uint32_t* out, double* cost)
 {
   const int N = 1 << log2_size, n2 = N * N;
   if (log2_size < 2 || log2_size > 5 || (comp && log2_size == 5)) return -1;
@@ -399,19 +400,19 @@ int hop_o_tu_intra(const int16_t* org, const int16_t* pred, int log2_size, int c
   hop_o_estbits eb;
   memset(&eb, 0, sizeof(eb));
   hop_o_cabac_est_bits(snap, N, comp, &eb);
-  hop_o_fwd_transform(bit_depth, resi, c16, N, dst);
-  for (int i = 0; i < n2; i++) c32[i] = c16[i];
+  if (ts_flag) hop_o_transform_skip(bit_depth, resi, c32, N);
+  else { hop_o_fwd_transform(bit_depth, resi, c16, N, dst); for (int i = 0; i < n2; i++) c32[i] = c16[i]; }
   uint32_t absSum = 0;
   memset(levels, 0, sizeof(int32_t) * (size_t)n2);
   hop_o_rdoq(c32, levels, log2_size, comp, 1, scan_idx, tr_depth, qp_scaled, bit_depth, sign_hide, lambda_rdoq, &eb, &absSum);
   hop_o_cabac_ctx s = *snap;
   uint64_t f = hop_o_cabac_cbf_bits(&s, comp, tr_depth, absSum != 0);
-  f += hop_o_cabac_coeff_bits(&s, levels, log2_size, comp, scan_idx, sign_hide, use_ts, 0);
+  f += hop_o_cabac_coeff_bits(&s, levels, log2_size, comp, scan_idx, sign_hide, use_ts, ts_flag);
   const uint32_t bits = (uint32_t)((frac_left + f) >> 15);
   if (absSum) {
     hop_o_dequant_flat(bit_depth, qp_scaled, levels, dq, N);
-    for (int i = 0; i < n2; i++) c16[i] = (int16_t)dq[i];
-    hop_o_inv_transform(bit_depth, c16, r2, N, dst);
+    if (ts_flag) hop_o_inv_transform_skip(bit_depth, dq, r2, N);
+    else { for (int i = 0; i < n2; i++) c16[i] = (int16_t)dq[i]; hop_o_inv_transform(bit_depth, c16, r2, N, dst); }
   } else memset(r2, 0, sizeof(int16_t) * (size_t)n2);
   const int maxVal = (1 << bit_depth) - 1;
   for (int i = 0; i < n2; i++) { int v = pred[i] + r2[i]; recon[i] = (int16_t)(v < 0 ? 0 : v > maxVal ? maxVal : v); }
@@ -419,4 +420,11 @@ int hop_o_tu_intra(const int16_t* org, const int16_t* pred, int log2_size, int c
   out[0] = absSum; out[1] = absSum != 0; out[2] = dist; out[3] = 0; out[4] = 0; out[5] = bits; out[6] = 0; out[7] = 0;
   *cost = calc_rd_cost(bits, dist, lambda_rd);
   return 0;
+}
+int hop_o_tu_intra(const int16_t* org, const int16_t* pred, int log2_size, int comp, int scan_idx, int use_dst, int qp_scaled, int bit_depth,
+                   int tr_depth, int sign_hide, int use_ts, double lambda_rdoq, double lambda_rd, double dist_weight,
+                   const hop_o_cabac_ctx* snap, uint32_t frac_left, int32_t* levels, int16_t* recon, uint32_t* out, double* cost)
+{
+  return hop_o_tu_intra_ts(org, pred, log2_size, comp, scan_idx, use_dst, qp_scaled, bit_depth, tr_depth, sign_hide, use_ts, 0, lambda_rdoq, lambda_rd, dist_weight,
+                           snap, frac_left, levels, recon, out, cost);
 }

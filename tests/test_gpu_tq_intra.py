@@ -585,3 +585,53 @@ def test_intra_pred_chroma_vs_oracle(hp):
     with pytest.raises(hp.HopError):
         ctx.intra_pred_chroma([bad], [3])
     ctx.close()
+
+
+def test_tu_intra_transform_skip_vs_oracle(hp):
+    """the intra leaf with the 4x4 transform-skip variant (xIntraCodingLumaBlk / ChromaBlk with getTransformSkip set, as xRecurIntraCodingQT's retry calls it):
+    hop_tu_rd with is_intra + HOP_TU_RD_TS against the restatement (whose members stand in for the reference's inside the encoder): levels, bits, distortion,
+    cost, reconstruction"""
+    O = oracle()
+    O.hop_o_tu_intra_ts.restype = ctypes.c_int
+    rng = np.random.default_rng(31)
+    W = H = 128
+    n = 200
+    org = [rng.integers(0, 256, (H, W)).astype(np.int16), rng.integers(0, 256, (H // 2, W // 2)).astype(np.int16), rng.integers(0, 256, (H // 2, W // 2)).astype(np.int16)]
+    prd = [np.clip(o + rng.integers(-4, 5, o.shape) + (rng.random(o.shape) < 0.1) * rng.integers(-90, 91, o.shape), 0, 255).astype(np.int16) for o in org]
+    jobs = np.zeros(n, hp.TU_RD_JOB_DTYPE); snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8)
+    ctx = hp.Context(W, H)
+    ctx.L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    used = set()
+    for i in range(n):
+        comp = int(rng.integers(0, 3))
+        while True:
+            bx, by = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+            if (comp, bx, by) not in used: used.add((comp, bx, by)); break
+        j = jobs[i]
+        j["x"], j["y"] = (4 * bx, 4 * by) if comp == 0 else (8 * bx, 8 * by)
+        qp = int(rng.integers(22, 40)); lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+        j["comp"], j["log2_size"], j["qp_scaled"], j["tr_depth"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["bit_depth"] = comp, 2, qp, int(rng.integers(0, 3)), i, int(rng.integers(0, 2)), 1, 8
+        j["is_intra"], j["scan_idx"], j["use_dst"], j["flags"] = 1, int(rng.integers(0, 3)), 1, hp.HOP_TU_RD_TS if i % 4 else 0
+        j["lambda_rdoq"], j["lambda_rd"], j["dist_weight"] = lam, lam, (1.0 if comp == 0 else 1.26)
+        assert ctx.L.hop_cabac_init(snaps[i].ctypes.data, int(rng.integers(0, 5)), qp) == 0
+        left = int(rng.integers(0, 32768)); snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+    ctx.upload_orig(*org)
+    for comp in range(3):
+        ctx.plane_upload("pred", comp, prd[comp]); ctx.plane_upload("recon", comp, np.zeros(org[comp].shape, np.int16))
+    res, lv = ctx.tu_rd(jobs, snaps)
+    rec = [ctx.recon_download(k) for k in range(3)]
+    nz = 0
+    for i in range(n):
+        j = jobs[i]; comp = int(j["comp"]); x, y = (int(j["x"]), int(j["y"])) if comp == 0 else (int(j["x"]) // 2, int(j["y"]) // 2)
+        o = np.ascontiguousarray(org[comp][y:y + 4, x:x + 4]); p = np.ascontiguousarray(prd[comp][y:y + 4, x:x + 4])
+        levels = np.zeros(16, np.int32); recon = np.zeros(16, np.int16); out = (ctypes.c_uint32 * 8)(); cost = ctypes.c_double()
+        st = (ctypes.c_uint8 * 150)(*snaps[i, :150].tolist())
+        O.hop_o_tu_intra_ts(p16(o), p16(p), 2, comp, int(j["scan_idx"]), 1, int(j["qp_scaled"]), 8, int(j["tr_depth"]), int(j["sign_hide"]), 1, int(bool(j["flags"])),
+                            ctypes.c_double(float(j["lambda_rdoq"])), ctypes.c_double(float(j["lambda_rd"])), ctypes.c_double(float(j["dist_weight"])), st,
+                            ctypes.c_uint32(int(snaps[i, 150]) | (int(snaps[i, 151]) << 8)), levels.ctypes.data_as(ctypes.c_void_p), p16(recon), out, ctypes.byref(cost))
+        got = [int(res[i][k]) for k in ("abs_sum", "cbf", "dist", "bits")]
+        assert got == [out[0], out[1], out[2], out[5]] and float(res[i]["cost"]) == cost.value, (i, comp, int(j["flags"]), got, list(out))
+        assert np.array_equal(lv[16 * i:16 * i + 16], levels) and np.array_equal(rec[comp][y:y + 4, x:x + 4].ravel(), recon), (i, comp, int(j["flags"]))
+        nz += int(out[0] != 0 and int(j["flags"]) != 0)
+    assert nz > 60
+    ctx.close()

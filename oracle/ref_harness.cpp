@@ -378,6 +378,44 @@ int ref_rdoq(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, in
   return scanIdx;
 }
 
+// row a10: TComTrQuant::xQuant, the non-RDOQ branch (TComTrQuant.cpp:1022-1119) -- the reference's own function with RDOQ switched off.  The branch takes its shift
+// from the slice's QP base (ADAPTIVE_QP_SELECTION, :1032-1063) and its scale from m_cQP: both are set from the same qpScaled here (a CU at the slice QP).
+// ttype: 0 TEXT_LUMA, 2 TEXT_CHROMA_U, 3 TEXT_CHROMA_V.  Sign-bit hiding off.  Returns uiAcSum.
+unsigned ref_quant_flat(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, int isISlice, int qpScaled, int bitDepthY, int bitDepthC)
+{
+  static Char predMode[1]; static UChar trIdxA[1], lumaDirA[1], chromaDirA[1], depthA[1], tsA[3][1];
+  static TComSlice* slice = NULL; static TComPPS* pps = NULL; static TComSPS* sps = NULL;
+  if (!slice) { slice = new TComSlice; pps = new TComPPS; sps = new TComSPS; slice->setPPS(pps); slice->setSPS(sps); }
+  g_bitDepthY = bitDepthY; g_bitDepthC = bitDepthC;
+  TComTrQuant& t = g->trq;
+  t.init(32, false, false, true, false, false);
+  t.m_cQP.setQpParam(qpScaled);
+  t.setUseScalingList(false);
+  t.setFlatScalingList();
+  pps->setSignHideFlag(0); pps->setChromaCbQpOffset(0); pps->setChromaCrQpOffset(0);
+  sps->setQpBDOffsetY(0); sps->setQpBDOffsetC(0);
+  slice->setSliceType(isISlice ? I_SLICE : P_SLICE);
+  // the slice QP base that maps to qpScaled: luma directly; chroma through g_aucChromaScale (identity below 30, so the tests keep chroma QPs there or use the inverse)
+  int base = qpScaled;
+  if (ttype != 0) { base = -1; for (int q = 0; q <= 57; q++) if ((int)g_aucChromaScale[q] == qpScaled) { base = q; break; } if (base < 0) return 0xFFFFFFFFu; }
+  slice->setSliceQpBase(base); slice->setSliceQpDeltaCb(0); slice->setSliceQpDeltaCr(0);
+  TComDataCU& cu = g->cu;
+  Char* sPred = cu.m_pePredMode; UChar* sTr = cu.m_puhTrIdx; UChar* sL = cu.m_puhLumaIntraDir; UChar* sC = cu.m_puhChromaIntraDir; UChar* sD = cu.m_puhDepth; TComSlice* sS = cu.m_pcSlice;
+  UChar* sT[3] = { cu.m_puhTransformSkip[0], cu.m_puhTransformSkip[1], cu.m_puhTransformSkip[2] };
+  predMode[0] = isIntra ? MODE_INTRA : MODE_INTER; trIdxA[0] = 0; lumaDirA[0] = 0; chromaDirA[0] = 0; depthA[0] = 0; tsA[0][0] = tsA[1][0] = tsA[2][0] = 0;
+  cu.m_pePredMode = predMode; cu.m_puhTrIdx = trIdxA; cu.m_puhLumaIntraDir = lumaDirA; cu.m_puhChromaIntraDir = chromaDirA; cu.m_puhDepth = depthA; cu.m_pcSlice = slice;
+  for (int k = 0; k < 3; k++) cu.m_puhTransformSkip[k] = tsA[k];
+  std::vector<Int> in(src, src + N * N), arl(N * N, 0);
+  std::vector<TCoeff> out(N * N, 0);
+  Int* parl = &arl[0];
+  UInt as = 0;
+  t.xQuant(&cu, &in[0], &out[0], parl, N, N, as, (TextType)ttype, 0);
+  for (int i = 0; i < N * N; i++) dst[i] = out[i];
+  cu.m_pePredMode = sPred; cu.m_puhTrIdx = sTr; cu.m_puhLumaIntraDir = sL; cu.m_puhChromaIntraDir = sC; cu.m_puhDepth = sD; cu.m_pcSlice = sS;
+  for (int k = 0; k < 3; k++) cu.m_puhTransformSkip[k] = sT[k];
+  return as;
+}
+
 // ---------------------------------------------------------------------------------------------
 // CABAC bit estimator for residual coding: the reference's own TEncSbac with the counting bin coder
 // (TEncBinCABACCounter).  states[150] in the order of hop_o_cabac_ctx (oracle/hop_oracle.h): qt_cbf[8], trans_subdiv[3],

@@ -64,3 +64,16 @@ def test_intra_rough_golden():
         fl = np.ascontiguousarray(fl)
         O.hop_o_intra_rough(p16(rec), W, p16(Y), W, int(x), int(y), int(N), fl.ctypes.data_as(VP), 8, int(strong), s)
         assert list(s) == [int(v) for v in want], (int(x), int(y), int(N))
+
+
+def test_flat_quantiser_golden():
+    """row a10, forward side: hop_o_quant_flat against 400 blocks quantised by the reference's own xQuant with RDOQ off (tests/golden/quant_flat.npz,
+    oracle/make_golden13.py): every size, 8 / 10 bit, I and non-I rounding offsets"""
+    import ctypes
+    g = load("quant_flat.npz")
+    O = oracle(); O.hop_o_quant_flat.restype = ctypes.c_uint32
+    for N, bd, qp, isI, asum, off in g["par"]:
+        N, off = int(N), int(off)
+        src = np.ascontiguousarray(g["src"][off:off + N * N], np.int32); d = np.zeros(N * N, np.int32)
+        a = O.hop_o_quant_flat(int(bd), int(qp), int(isI), src.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p), N)
+        assert a == int(asum) and np.array_equal(d, g["out"][off:off + N * N]), (N, bd, qp, isI)

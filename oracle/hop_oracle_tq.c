@@ -4,9 +4,10 @@
  *
  * Reference: zinsayon/HEVC-HOP (HM-15.0 fork), paths relative to /root/reference/source/Lib.
  * Pinned against the reference's own xTrMxN / xITrMxN (TLibCommon/TComTrQuant.cpp:786,829, free functions with
- * external linkage, called through oracle/_ref/libref_harness.so) and TComTrQuant::xDeQuant (:1124-1183);
- * the forward flat quantiser (xQuant non-RDOQ branch, :1071-1107) is restated from the text only: it needs a
- * full TComDataCU/TComSlice graph in the reference, so that one function is "parity unpinned" (tests say so).
+ * external linkage, called through oracle/_ref/libref_harness.so), TComTrQuant::xDeQuant (:1124-1183) and, for the
+ * forward flat quantiser, TComTrQuant::xQuant with RDOQ switched off (:1022-1119, ref_quant_flat of the harness).
+ * The transform-skip pair and every other function here also stand in for the reference's members inside the
+ * reference encoder (oracle/enc_shim.cpp).
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,7 +1,7 @@
 """CPU: oracle transforms / dequantiser / intra rough search against the golden vectors produced by the REFERENCE's
 own xTrMxN, xITrMxN, xDeQuant, fillReferenceSamples, predIntraLumaAng and calcHAD (oracle/make_golden2.py).
-The forward flat quantiser (xQuant non-RDOQ branch) has no reference-generated vector: parity unpinned for that
-one function (it is checked against the dequantiser through the round-trip property below)."""
+The forward flat quantiser is checked against vectors of the reference's xQuant with RDOQ off (oracle/make_golden13.py) and through the
+round-trip property below."""
 import ctypes
 
 import numpy as np
@@ -36,7 +36,7 @@ def test_transforms_and_dequant_golden():
 
 
 def test_flat_quantiser_properties():
-    """unpinned function: sign symmetry, monotonicity in |coef|, and |dequant(quant(c)) - c| bounded by one step"""
+    """sign symmetry, monotonicity in |coef|, and |dequant(quant(c)) - c| bounded by one step"""
     O = oracle()
     O.hop_o_quant_flat.restype = ctypes.c_uint32
     rng = np.random.default_rng(3)

@@ -647,6 +647,117 @@ UInt TEncSearch::xGetIntraBitsQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPar
   return bits;
 }
 
+// ---- the luma transform tree of an intra PU: TEncSearch::xRecurIntraCodingQT, bLumaOnly (TLibEncoder/TEncSearch.cpp:1361-1710) -> hop_o_intra_rqt ----
+// The call from estIntraPredQT (:2524 per candidate mode with bCheckFirst, :2587 for the best one without) hands over the PU; the restatement
+// walks the tree and leaves what the reference leaves: transform depth / cbf / transform-skip arrays, the level and reconstruction layers
+// xSetIntraResultQT reads, the reconstruction picture, the coder state.  Neighbour availability of every node comes from the reference's
+// own TComPattern helpers (it depends on positions only).
+namespace { unsigned long g_calls11[1] = { 0 };
+struct Report11 { ~Report11() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: intraRqt %lu\n", g_calls11[0]); } } g_report11; }
+
+Void TEncSearch::xRecurIntraCodingQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPartIdx, Bool bLumaOnly, TComYuv* pcOrgYuv, TComYuv* pcPredYuv, TComYuv* pcResiYuv,
+                                     UInt& ruiDistY, UInt& ruiDistC, Bool bCheckFirst, Double& dRDCost)
+{
+  TComSlice* sl = pcCU->getSlice();
+  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() ||
+      sl->getSPS()->getUsePCM()) {
+    fprintf(stderr, "hop shim: xRecurIntraCodingQT is replaced for luma-only trees, RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+  }
+  g_calls11[0]++;
+  const UInt depth = pcCU->getDepth(0);
+  hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
+  cfg.log2_cu = g_aucConvertToBit[sl->getSPS()->getMaxCUWidth() >> depth] + 2;
+  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_LUMA, sl->getSPS()->getQpBDOffsetY(), 0); cfg.qp[0] = m_pcTrQuant->m_cQP.m_iQP;
+  cfg.bit_depth_y = g_bitDepthY; cfg.bit_depth_c = g_bitDepthC;
+  cfg.sign_hide = sl->getPPS()->getSignHideFlag() ? 1 : 0; cfg.use_ts = sl->getPPS()->getUseTransformSkip() ? 1 : 0;
+  cfg.log2_max_tu = sl->getSPS()->getQuadtreeTULog2MaxSize(); cfg.log2_min_tu_in_cu = pcCU->getQuadtreeTULog2MinSizeInCU(uiAbsPartIdx);
+  cfg.lambda_rd = m_pcRdCost->m_dLambda;
+  for (int c = 0; c < 3; c++) cfg.lambda_rdoq[c] = m_pcTrQuant->m_lambdas[c];
+  cfg.dist_weight[0] = 1.0; cfg.dist_weight[1] = m_pcRdCost->m_cbDistortionWeight; cfg.dist_weight[2] = m_pcRdCost->m_crDistortionWeight;
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
+  hop_o_intra_syntax y; memset(&y, 0, sizeof(y));
+  y.part_nxn = pcCU->getPartitionSize(0) == SIZE_NxN ? 1 : 0;
+  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = (int)pcCU->getCtxSkipFlag(0); y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth;
+  for (int p = 0; p < (y.part_nxn ? 4 : 1); p++) {
+    const UInt idx = p * (parts >> 2);
+    y.luma_dir[p] = pcCU->getLumaIntraDir(idx);
+    Int pr[3] = { -1, -1, -1 }; y.pred_num[p] = pcCU->getIntraDirLumaPredictor(idx, pr);
+    for (int k = 0; k < 3; k++) y.preds[p][k] = pr[k];
+  }
+  y.chroma_is_dm = pcCU->getChromaIntraDir(0) == DM_CHROMA_IDX; y.chroma_dir = pcCU->getChromaIntraDir(0);
+  // neighbour flags of every node below this one (TComPattern::initAdiPattern, TComPattern.cpp:199-211)
+  std::vector<uint8_t> avail((size_t)341 * HOP_O_AVAIL_PITCH, 0);
+  for (UInt d = uiTrDepth; cfg.log2_cu - (int)d >= 2 && cfg.log2_cu - (int)d >= cfg.log2_min_tu_in_cu; d++) {
+    const int log2 = cfg.log2_cu - (int)d; if (log2 > 5) continue;
+    const int np = 1 << (2 * (log2 - 2)), units = (1 << log2) / 4, first = (int)uiAbsPartIdx, count = parts >> (2 * uiTrDepth);
+    for (int p = first; p < first + count; p += np) {
+      UInt lt, rt, lb; Bool fl[4 * MAX_NUM_SPU_W + 1]; memset(fl, 0, sizeof(fl));
+      pcCU->deriveLeftRightTopIdxAdi(lt, rt, (UInt)p, d); pcCU->deriveLeftBottomIdxAdi(lb, (UInt)p, d);
+      TComPattern* pt = pcCU->getPattern();
+      fl[units * 2] = pt->isAboveLeftAvailable(pcCU, lt);
+      pt->isAboveAvailable(pcCU, lt, rt, fl + units * 2 + 1); pt->isAboveRightAvailable(pcCU, lt, rt, fl + units * 3 + 1);
+      pt->isLeftAvailable(pcCU, lt, lb, fl + units * 2 - 1); pt->isBelowLeftAvailable(pcCU, lt, lb, fl + units - 1);
+      uint8_t* a = &avail[(size_t)hop_o_intra_node_index((int)d, log2, p) * HOP_O_AVAIL_PITCH];
+      for (int i = 0; i < 4 * units + 1; i++) a[i] = fl[i] ? 1 : 0;
+    }
+  }
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  std::vector<int16_t> planes[4];
+  for (int l = 0; l < 4; l++) {
+    st.coef[l][0] = m_ppcQTTempCoeffY[l]; st.coef[l][1] = m_ppcQTTempCoeffCb[l]; st.coef[l][2] = m_ppcQTTempCoeffCr[l];
+    planes[l].assign(cu * cu, 0); st.resi[l][0] = &planes[l][0];
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int r = 0; r < cu; r++) memcpy(st.resi[l][0] + r * cu, t.getLumaAddr() + r * t.getStride(), cu * sizeof(Pel));
+  }
+  memcpy(st.tr_idx, pcCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], pcCU->m_puhCbf[c], parts); memcpy(st.tskip[c], pcCU->m_puhTransformSkip[c], parts); }
+  TComPicYuv* recPic = pcCU->getPic()->getPicYuvRec();
+  hop_o_intra_rqt_in in; memset(&in, 0, sizeof(in));
+  in.org = pcOrgYuv->getLumaAddr(); in.org_stride = pcOrgYuv->getStride();
+  in.rec = recPic->getLumaAddr(pcCU->getAddr(), pcCU->getZorderIdxInCU()); in.rec_stride = recPic->getStride();
+  in.avail = &avail[0]; in.strong = sl->getSPS()->getUseStrongIntraSmoothing() ? 1 : 0; in.check_first = bCheckFirst ? 1 : 0;
+  in.ts_fast = m_pcEncCfg->getUseTransformSkipFast() ? 1 : 0;
+  TEncSbac* sb = m_pcRDGoOnSbacCoder;
+  hop_o_coder coder; coder_get(sb, &coder);
+  uint8_t cuctx[20] = { 0 }; { CuSets2 r = cu_sets2(sb); uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  // trace input: HOP_SHIM_TRACE_IRQT=<file>
+  static FILE* f = NULL; static bool tried = false;
+  if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_IRQT"); if (pth && *pth) f = fopen(pth, "wb"); }
+  const int W = 2 * cu + 1;
+  const int px = (int)pcCU->getCUPelX(), py = (int)pcCU->getCUPelY(), pw = recPic->getWidth(), ph = recPic->getHeight();
+  if (f) {
+    const int32_t nd[8] = { (int32_t)uiTrDepth, (int32_t)uiAbsPartIdx, in.check_first, in.ts_fast, in.strong, 0, 0, 0 };
+    fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&y, sizeof(y), 1, f); fwrite(nd, 4, 8, f); fwrite(&avail[0], 1, avail.size(), f);
+    for (int r = 0; r < cu; r++) fwrite(in.org + r * in.org_stride, 2, cu, f);
+    std::vector<int16_t> win((size_t)W * W, 0);                       // the picture around the CU, from (-1, -1); outside the picture: 0 (never read)
+    for (int r = 0; r < W; r++) for (int c = 0; c < W; c++) {
+      const int X = px - 1 + c, Y = py - 1 + r;
+      if (X >= 0 && Y >= 0 && X < pw && Y < ph) win[(size_t)r * W + c] = in.rec[(ptrdiff_t)(r - 1) * in.rec_stride + (c - 1)];
+    }
+    fwrite(&win[0], 2, win.size(), f);
+    fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+    fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 20, f);
+  }
+  double cost = 0; uint32_t dist = 0;
+  hop_o_intra_rqt(&cfg, &y, &in, (int)uiTrDepth, (int)uiAbsPartIdx, &coder, cuctx, &st, &cost, &dist);
+  dRDCost += cost; ruiDistY += dist;
+  if (f) {
+    const uint32_t o2[2] = { dist, 0 }; fwrite(&cost, 8, 1, f); fwrite(o2, 4, 2, f);
+    fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+    fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 20, f);
+    for (int r = 0; r < cu; r++) fwrite(in.rec + (ptrdiff_t)r * in.rec_stride, 2, cu, f);
+    std::vector<int32_t> fin(cu * cu * 3 / 2); hop_o_rqt_final_coeffs(&cfg, &st, &fin[0]); fwrite(&fin[0], 4, cu * cu, f);
+  }
+  memcpy(pcCU->m_puhTrIdx, st.tr_idx, parts);
+  memcpy(pcCU->m_puhCbf[0], st.cbf[0], parts); memcpy(pcCU->m_puhTransformSkip[0], st.tskip[0], parts);
+  for (int l = 0; l < 4; l++) {
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int r = 0; r < cu; r++) memcpy(t.getLumaAddr() + r * t.getStride(), st.resi[l][0] + r * cu, cu * sizeof(Pel));
+  }
+  coder_put(sb, &coder);
+  { CuSets2 r = cu_sets2(sb); const uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
+}
+
 // ---- chroma intra prediction: TComPrediction::predIntraChromaAng (TLibCommon/TComPrediction.cpp:375-390) -> hop_o_intra_pred_chroma ----
 namespace { unsigned long g_calls10[1] = { 0 };
 struct Report10 { ~Report10() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: chromaPred %lu\n", g_calls10[0]); } } g_report10; }

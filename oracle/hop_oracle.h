@@ -126,6 +126,20 @@ typedef struct {
 } hop_o_intra_syntax;
 uint32_t hop_o_intra_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, int tr_depth, int part, int b_luma, int b_chroma,
                              hop_o_coder* coder, uint8_t cu_ctx[20]);
+/* row a8: the luma transform tree of one intra PU (xRecurIntraCodingQT, luma only).  st->resi[layer][0] are the reconstruction layer planes
+ * (m_pcQTTempTComYuv, pitch = CU size), st->coef[layer][0] the level layers; avail holds the neighbour flags of every node of the CU's quadtree. */
+#define HOP_O_AVAIL_PITCH 36
+typedef struct {
+  const int16_t* org; int org_stride;   /* luma original, at the CU origin */
+  int16_t* rec; int rec_stride;         /* reconstruction picture at the CU origin: neighbours read at negative offsets, blocks written as the search goes */
+  const uint8_t* avail;                 /* [hop_o_intra_node_index(tr_depth, log2_size, part)][HOP_O_AVAIL_PITCH]: 4 * (size / 4) + 1 flags, bottom-left first */
+  int strong;                           /* SPS strong_intra_smoothing */
+  int check_first;                      /* bCheckFirst */
+  int ts_fast;                          /* TransformSkipFast: transform skip tried in NxN CUs only */
+} hop_o_intra_rqt_in;
+int hop_o_intra_node_index(int tr_depth, int log2_size, int part);
+void hop_o_intra_rqt(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, const hop_o_intra_rqt_in* in, int tr_depth, int part,
+                     hop_o_coder* coder, uint8_t cu_ctx[20], hop_o_rqt_state* st, double* cost, uint32_t* dist);
 int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
                           const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

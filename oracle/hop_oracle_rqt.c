@@ -12,6 +12,7 @@
  * reference encoder, which must then write the unmodified encoder's bitstream (tests/test_encoder_shim.py). */
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 #include "hop_oracle.h"
 
 typedef struct {
@@ -522,4 +523,132 @@ uint32_t hop_o_intra_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax*
   if (b_luma) intra_coeff(cfg, y, st, coder, parts, tr_depth, part, 0);
   if (b_chroma) { intra_coeff(cfg, y, st, coder, parts, tr_depth, part, 1); intra_coeff(cfg, y, st, coder, parts, tr_depth, part, 2); }
   return (uint32_t)(coder->frac >> 15);
+}
+
+/* ---- row a8: the luma transform tree of one intra PU, TEncSearch::xRecurIntraCodingQT with bLumaOnly (TLibEncoder/TEncSearch.cpp:1361-1710) ----
+ * Per node: the block coded as one TU (xIntraCodingLumaBlk :1003-1161 = reference samples from the reconstruction picture, prediction,
+ * residual, estBit on the current coder state, transform / RDOQ, inverse path, reconstruction into the layer plane and into the
+ * picture, SSE), for 4x4 blocks also as a transform-skip block (:1424-1523; the better one kept, the first restored from the
+ * stash of xStoreIntraResultQT / xLoadIntraResultQT :1786-1955), its bits through xGetIntraBitsQT (= hop_o_intra_cu_bits); then the
+ * four children on the state the previous one left, their bits recounted from the node's entry state (:1576-1640), and the cheaper
+ * alternative kept - the picture gets the single block's reconstruction back when it wins (:1642-1700).  RDpenalty = 0. */
+typedef struct { hop_o_coder c; uint8_t cu[20]; } ISnap;
+typedef struct {
+  const hop_o_rqt_cfg* cfg; const hop_o_intra_syntax* syn; const hop_o_intra_rqt_in* in; hop_o_rqt_state* st;
+  hop_o_coder* coder; uint8_t* cu;
+} Irq;
+static ISnap isnap(const Irq* r) { ISnap s; s.c = *r->coder; memcpy(s.cu, r->cu, 20); return s; }
+static void irestore(Irq* r, const ISnap* s) { *r->coder = s->c; memcpy(r->cu, s->cu, 20); }
+int hop_o_intra_node_index(int tr_depth, int log2_size, int part)
+{
+  static const int first[5] = { 0, 1, 5, 21, 85 };
+  return first[tr_depth] + (part >> (2 * (log2_size - 2)));
+}
+
+static void intra_luma_leaf(Irq* r, int trDepth, int part, int tsFlag, uint32_t* dist)
+{
+  const hop_o_rqt_cfg* g = r->cfg;
+  const int log2 = g->log2_cu - trDepth, N = 1 << log2, cu = 1 << g->log2_cu, layer = g->log2_max_tu - log2, nparts = 1 << (2 * (log2 - 2));
+  const int parts = 1 << (2 * (g->log2_cu - 2)), x = zx(part), y = zy(part);
+  const int dir = r->syn->luma_dir[r->syn->part_nxn ? part / (parts >> 2) : 0];
+  int L[4 * 32 + 1], F[4 * 32 + 1];
+  int16_t org[32 * 32], pred[32 * 32], rec[32 * 32];
+  hop_o_intra_fill_refs_u(r->in->rec, r->in->rec_stride, x, y, N, 4, r->in->avail + (size_t)hop_o_intra_node_index(trDepth, log2, part) * HOP_O_AVAIL_PITCH, g->bit_depth_y, L);
+  hop_o_intra_smooth(L, N, g->bit_depth_y, r->in->strong, F);
+  hop_o_intra_pred(L, F, N, dir, g->bit_depth_y, pred);
+  for (int j = 0; j < N; j++) memcpy(org + j * N, r->in->org + (size_t)(y + j) * r->in->org_stride + x, sizeof(int16_t) * (size_t)N);
+  set_parts(r->st->tr_idx, part, nparts, trDepth);
+  uint32_t out[8]; double c;
+  int32_t* coef = r->st->coef[layer][0] + 16 * part;
+  hop_o_tu_intra_ts(org, pred, log2, 0, hop_o_coef_scan_idx(N, 1, 1, dir), 1, g->qp[0], g->bit_depth_y, trDepth, g->sign_hide, g->use_ts, tsFlag,
+                    g->lambda_rdoq[0], g->lambda_rd, 1.0, &r->coder->ctx, 0, coef, rec, out, &c);
+  set_parts(r->st->cbf[0], part, nparts, (out[0] ? 1 : 0) << trDepth);
+  for (int j = 0; j < N; j++) {
+    memcpy(r->st->resi[layer][0] + (size_t)(y + j) * cu + x, rec + j * N, sizeof(int16_t) * (size_t)N);
+    memcpy(r->in->rec + (ptrdiff_t)(y + j) * r->in->rec_stride + x, rec + j * N, sizeof(int16_t) * (size_t)N);
+  }
+  *dist += out[2];
+}
+
+static void intra_node(Irq* r, int trDepth, int part, double* rdCost, uint32_t* distY)
+{
+  const hop_o_rqt_cfg* g = r->cfg;
+  hop_o_rqt_state* st = r->st;
+  const int log2 = g->log2_cu - trDepth, N = 1 << log2, cu = 1 << g->log2_cu, layer = g->log2_max_tu - log2, nparts = 1 << (2 * (log2 - 2));
+  const int full = log2 <= g->log2_max_tu;
+  int split = log2 > g->log2_min_tu_in_cu;
+  if (r->in->check_first && full) split = 0;                           /* HHI_RQT_INTRA_SPEEDUP, :1387-1399 */
+  const double MAXD = 1.7e+308;                                        /* MAX_DOUBLE */
+  double singleCost = MAXD;
+  uint32_t singleDist = 0, singleCbf = 0;
+  int best = 0;
+  const int ts = g->use_ts && N == 4 && (!r->in->ts_fast || r->syn->part_nxn);
+  ISnap root, test, tbest;
+  memset(&root, 0, sizeof(root)); memset(&test, 0, sizeof(test)); memset(&tbest, 0, sizeof(tbest));
+  if (full) {
+    if (ts) {
+      root = isnap(r);
+      int32_t keepCoef[16]; int16_t keepRec[16];
+      for (int modeId = 0; modeId < 2; modeId++) {
+        uint32_t d = 0; double c;
+        set_parts(st->tskip[0], part, nparts, modeId);
+        intra_luma_leaf(r, trDepth, part, modeId, &d);
+        const uint32_t cbf = (st->cbf[0][part] >> trDepth) & 1;
+        if (modeId == 1 && cbf == 0) c = MAXD;
+        else c = hop_o_calc_rd_cost(hop_o_intra_cu_bits(g, r->syn, st, trDepth, part, 1, 0, r->coder, r->cu), d, g->lambda_rd);
+        if (c < singleCost) {
+          singleCost = c; singleDist = d; singleCbf = cbf; best = modeId;
+          if (best == 0) {
+            memcpy(keepCoef, st->coef[layer][0] + 16 * part, sizeof(keepCoef));
+            for (int j = 0; j < 4; j++) memcpy(keepRec + 4 * j, st->resi[layer][0] + (size_t)(zy(part) + j) * cu + zx(part), 8);
+            tbest = isnap(r);
+          }
+        }
+        if (modeId == 0) irestore(r, &root);
+      }
+      set_parts(st->tskip[0], part, nparts, best);
+      if (best == 0) {
+        memcpy(st->coef[layer][0] + 16 * part, keepCoef, sizeof(keepCoef));
+        for (int j = 0; j < 4; j++) {
+          memcpy(st->resi[layer][0] + (size_t)(zy(part) + j) * cu + zx(part), keepRec + 4 * j, 8);
+          memcpy(r->in->rec + (ptrdiff_t)(zy(part) + j) * r->in->rec_stride + zx(part), keepRec + 4 * j, 8);
+        }
+        set_parts(st->cbf[0], part, nparts, (int)(singleCbf << trDepth));
+        irestore(r, &tbest);
+      }
+    } else {
+      set_parts(st->tskip[0], part, nparts, 0);
+      if (split) root = isnap(r);
+      intra_luma_leaf(r, trDepth, part, 0, &singleDist);
+      if (split) singleCbf = (st->cbf[0][part] >> trDepth) & 1;
+      singleCost = hop_o_calc_rd_cost(hop_o_intra_cu_bits(g, r->syn, st, trDepth, part, 1, 0, r->coder, r->cu), singleDist, g->lambda_rd);
+    }
+  }
+  if (split) {
+    if (full) { test = isnap(r); irestore(r, &root); } else root = isnap(r);
+    double splitCost = 0.0; uint32_t splitDist = 0, splitCbf = 0;
+    const int q = nparts >> 2;
+    for (int i = 0; i < 4; i++) {
+      intra_node(r, trDepth + 1, part + i * q, &splitCost, &splitDist);
+      splitCbf |= (st->cbf[0][part + i * q] >> (trDepth + 1)) & 1;
+    }
+    for (int o = 0; o < nparts; o++) st->cbf[0][part + o] |= (uint8_t)(splitCbf << trDepth);
+    irestore(r, &root);
+    splitCost = hop_o_calc_rd_cost(hop_o_intra_cu_bits(g, r->syn, st, trDepth, part, 1, 0, r->coder, r->cu), splitDist, g->lambda_rd);
+    if (splitCost < singleCost) { *distY += splitDist; *rdCost += splitCost; return; }
+    irestore(r, &test);
+    set_parts(st->tr_idx, part, nparts, trDepth);
+    set_parts(st->cbf[0], part, nparts, (int)(singleCbf << trDepth));
+    set_parts(st->tskip[0], part, nparts, best);
+    for (int j = 0; j < N; j++)
+      memcpy(r->in->rec + (ptrdiff_t)(zy(part) + j) * r->in->rec_stride + zx(part), st->resi[layer][0] + (size_t)(zy(part) + j) * cu + zx(part), sizeof(int16_t) * (size_t)N);
+  }
+  *distY += singleDist; *rdCost += singleCost;
+}
+
+void hop_o_intra_rqt(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, const hop_o_intra_rqt_in* in, int tr_depth, int part,
+                     hop_o_coder* coder, uint8_t cu_ctx[20], hop_o_rqt_state* st, double* cost, uint32_t* dist)
+{
+  Irq r = { cfg, syn, in, st, coder, cu_ctx };
+  intra_node(&r, tr_depth, part, cost, dist);
 }

@@ -185,3 +185,53 @@ def encoder_intrabits_calls():
         yield dict(cfg=g["cfg"][i], syn=g["syn"][i], nd=[int(v) for v in g["nd"][i]], arr=g["arr"][i], coef=np.ascontiguousarray(g["coef"][o:o + n]), cin=g["cin"][i],
                    cuin=g["cuin"][i], cout=g["cout"][i], cuout=g["cuout"][i], bits=int(g["bits"][i]))
         o += n
+
+
+def encoder_irqt_calls():
+    """tests/golden/encoder_irqt_calls.npz (oracle/make_golden14.py): xRecurIntraCodingQT calls (luma tree of an intra PU) of two real encodes: cfg, syntax, nd =
+    (tr_depth, part, bCheckFirst, TransformSkipFast, strong smoothing), neighbour flags [341][36], the CU's luma original, the reconstruction picture from (-1, -1)
+    of the CU ((2 cu + 1)^2), arrays / coder (160 B) / CU contexts in and out, cost, distortion, the CU's picture block and the chosen luma levels after"""
+    g = load("encoder_irqt_calls.npz")
+    o1 = o2 = 0
+    for i in range(len(g["cost"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu; W = 2 * cu + 1
+        yield dict(cfg=g["cfg"][i], syn=g["syn"][i], nd=[int(v) for v in g["nd"][i]], avail=g["avail"][i], org=np.ascontiguousarray(g["org"][o1:o1 + n]),
+                   win=np.ascontiguousarray(g["win"][o2:o2 + W * W]), ain=g["ain"][i], cin=g["cin"][i], cuin=g["cuin"][i], cost=float(g["cost"][i]), dist=int(g["dist"][i]),
+                   aout=g["aout"][i], cout=g["cout"][i], cuout=g["cuout"][i], rec=np.ascontiguousarray(g["rec"][o1:o1 + n]), fin=np.ascontiguousarray(g["fin"][o1:o1 + n]))
+        o1 += n; o2 += W * W
+
+
+class _OIntraIn(ctypes.Structure):
+    _fields_ = [("org", ctypes.c_void_p), ("org_stride", ctypes.c_int), ("rec", ctypes.c_void_p), ("rec_stride", ctypes.c_int), ("avail", ctypes.c_void_p),
+                ("strong", ctypes.c_int), ("check_first", ctypes.c_int), ("ts_fast", ctypes.c_int)]
+
+
+def oracle_intra_rqt(cfg, syn, nd, avail, org, win, arr_in, coder160, cu20):
+    """hop_o_intra_rqt on one PU.  win: the reconstruction picture from (-1, -1) of the CU, (2 cu + 1)^2 (written as the search goes).  Returns cost, dist,
+    arrays (7 x 256), coder (160 bytes), CU contexts, the window after, the chosen luma levels (CU layout)."""
+    O = oracle()
+    c = np.zeros(1, RQT_CFG); c[0] = cfg
+    y = np.zeros(1, INTRA_SYN); y[0] = syn
+    cu = 1 << int(c[0]["log2_cu"]); n2 = cu * cu; W = 2 * cu + 1
+    coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), np.ascontiguousarray(coder160).tobytes(), 160)
+    cuctx = np.ascontiguousarray(cu20, np.uint8).copy()
+    st = _OState()
+    a = np.ascontiguousarray(arr_in, np.uint8).reshape(-1)
+    ctypes.memmove(ctypes.addressof(st), a.tobytes(), 1792)            # tr_idx, cbf[3], tskip[3] lead the struct
+    coefs = [[np.zeros(n2 if k == 0 else n2 // 4, np.int32) for k in range(3)] for _ in range(4)]
+    recs = [np.zeros(n2, np.int16) for _ in range(4)]
+    for l in range(4):
+        for k in range(3):
+            st.coef[3 * l + k] = coefs[l][k].ctypes.data
+        st.resi[3 * l] = recs[l].ctypes.data
+    win = np.ascontiguousarray(win, np.int16).copy(); org = np.ascontiguousarray(org, np.int16); avail = np.ascontiguousarray(avail, np.uint8)
+    inp = _OIntraIn(org.ctypes.data, cu, win.ctypes.data + 2 * (W + 1), W, avail.ctypes.data, nd[4], nd[2], nd[3])
+    cost = ctypes.c_double(0.0); dist = ctypes.c_uint32(0)
+    O.hop_o_intra_rqt.restype = None
+    O.hop_o_intra_rqt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    O.hop_o_intra_rqt(c.ctypes.data, y.ctypes.data, ctypes.addressof(inp), nd[0], nd[1], ctypes.addressof(coder), cuctx.ctypes.data, ctypes.addressof(st),
+                      ctypes.addressof(cost), ctypes.addressof(dist))
+    arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
+    fin = np.zeros(n2 * 3 // 2, np.int32)
+    O.hop_o_rqt_final_coeffs(c.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), fin.ctypes.data_as(ctypes.c_void_p))
+    return cost.value, dist.value, arr, np.frombuffer(bytes(coder), np.uint8).copy(), cuctx, win, fin[:n2].copy()

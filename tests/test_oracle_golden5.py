@@ -130,3 +130,22 @@ def test_intra_cu_bits_on_encoder_calls():
         assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
         kinds.add((int(syn[0]["part_nxn"]), c["nd"][2], c["nd"][3])); n += 1
     assert n == 87 and len(kinds) >= 4
+
+
+def test_intra_rqt_on_encoder_calls():
+    """xRecurIntraCodingQT, luma only (the transform tree of an intra PU with its 4x4 transform-skip retry, reconstruction into the picture as it goes, bits via
+    xGetIntraBitsQT): the restatement on 47 calls recorded inside the encoder - cost, distortion, depth / cbf / transform-skip arrays, coder and CU-level context
+    states, the picture block and the chosen levels afterwards"""
+    from goldutil import encoder_irqt_calls, oracle_intra_rqt
+    n = 0; kinds = set()
+    for c in encoder_irqt_calls():
+        cu = 1 << int(c["cfg"]["log2_cu"]); W = 2 * cu + 1
+        cost, dist, arr, coder, cuctx, win, fin = oracle_intra_rqt(c["cfg"], c["syn"], c["nd"], c["avail"], c["org"], c["win"], c["ain"], c["cin"].tobytes(), c["cuin"])
+        assert cost == c["cost"] and dist == c["dist"], (n, cost, c["cost"], dist, c["dist"])
+        assert np.array_equal(arr.reshape(-1)[[*range(256), *range(256, 512), *range(1024, 1280)]], c["aout"][[*range(256), *range(256, 512), *range(1024, 1280)]]), n
+        assert coder.tobytes() == c["cout"].tobytes() and np.array_equal(cuctx, c["cuout"]), n
+        assert np.array_equal(win.reshape(W, W)[1:1 + cu, 1:1 + cu].reshape(-1), c["rec"]), n
+        parts = (cu // 4) ** 2; p0 = c["nd"][1]; np_ = parts >> (2 * c["nd"][0])
+        assert np.array_equal(fin[16 * p0:16 * (p0 + np_)], c["fin"][16 * p0:16 * (p0 + np_)]), n
+        kinds.add((cu, int(c["syn"]["part_nxn"]), c["nd"][2], int(arr[0, p0:p0 + np_].max()), int(arr[4, p0:p0 + np_].any()))); n += 1
+    assert n == 47 and len(kinds) >= 12 and any(k[4] for k in kinds) and any(k[3] >= 2 for k in kinds), kinds

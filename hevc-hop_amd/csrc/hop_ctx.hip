@@ -839,6 +839,92 @@ int hop_intra_cu_bits(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intr
   return HOP_OK;
 }
 
+int hop_intra_rqt_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, int tr_depth, int check_first, const hop_intra_cu_syntax* d_syntax,
+                         const hop_intra_rqt_opt* d_opts, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, hop_rqt_result* d_results, int32_t* d_coef_out,
+                         hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out) {
+  if (!c || n < 0 || !cls || (n && (!d_jobs || !d_syntax || !d_opts || !d_ctx_in || !d_cu_ctx_in || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_rqt_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_rqt: hop_upload_orig has not been called");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1 || tr_depth < 0 || tr_depth > 1 || cls->log2_cu - tr_depth < cls->log2_min_tu_in_cu)
+    return hop_set_err(c, HOP_ERR_ARG, "hop_intra_rqt_device: illegal PU class");
+  if (n == 0) return HOP_OK;
+  const size_t wb = hop_intra_rqt_work_bytes(cls->log2_cu, n);
+  if (wb > c->rqt_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
+    c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
+    c->rqt_bytes = wb + wb / 8;
+  }
+  return hop_launch_intra_rqt(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, tr_depth, check_first ? 1 : 0, n, d_jobs, d_syntax,
+                              d_opts, d_ctx_in, d_cu_ctx_in, d_results, d_coef_out, d_ctx_out, d_cu_ctx_out, c->rqt_buf, c->rqt_bytes);
+}
+
+int hop_intra_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, int n_ctx, const hop_cabac_ctx* ctx_in,
+                  const hop_cabac_cu_ctx* cu_ctx_in, hop_rqt_result* results, int32_t* coef_out, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out) {
+  if (!c || n < 0 || (n && (!jobs || !syntax || !opts || !ctx_in || !cu_ctx_in || !results || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_rqt: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_rqt: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  std::vector<size_t> coff(n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const hop_rqt_job& j = jobs[i]; const hop_intra_cu_syntax& y = syntax[i];
+    const int S = 1 << j.log2_cu, parts = 1 << (2 * (j.log2_cu - 2));
+    bool ok = j.log2_cu >= 3 && j.log2_cu <= 6 && j.x >= 0 && j.y >= 0 && (j.x & (S - 1)) == 0 && (j.y & (S - 1)) == 0 && j.x + S <= c->pic_w && j.y + S <= c->pic_h &&
+              j.ctx_index >= 0 && j.ctx_index < n_ctx && j.log2_max_tu >= 2 && j.log2_max_tu <= 5 && j.log2_min_tu_in_cu >= 2 && j.log2_min_tu_in_cu <= j.log2_max_tu &&
+              j.log2_cu - j.log2_min_tu_in_cu <= 3 && j.log2_cu - j.log2_max_tu <= 1 && j.lambda_rd > 0.0 && j.qp_scaled[0] >= 0 && j.qp_scaled[0] <= 87 && j.lambda_rdoq[0] > 0.0 &&
+              y.skip_ctx >= 0 && y.skip_ctx <= 2 && (y.tr_depth == 0 || y.tr_depth == 1) && !y.part_nxn == !y.tr_depth && y.part >= 0 && y.part < parts &&
+              (y.part % (parts >> (2 * y.tr_depth))) == 0 && j.log2_cu - y.tr_depth >= j.log2_min_tu_in_cu;
+    for (int p = 0; p < (y.part_nxn ? 4 : 1) && ok; p++) ok = y.luma_dir[p] >= 0 && y.luma_dir[p] < 35 && y.pred_num[p] >= 0 && y.pred_num[p] <= 3;
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "intra RQT job %d: illegal CU / PU node / transform-tree limits / syntax elements / snapshot / parameters", i);
+    coff[i + 1] = coff[i] + (((size_t)3 << (2 * j.log2_cu)) >> 1);
+  }
+  for (int k = 0; k < n_ctx; k++) {
+    for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+    for (int i = 0; i < 19; i++) if (cu_ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "CU context snapshot %d: state %d out of range", k, i);
+  }
+  std::vector<char> done(n, 0);
+  for (int first = 0; first < n; first++) {
+    if (done[first]) continue;
+    const hop_rqt_job& f = jobs[first]; const int d0 = syntax[first].tr_depth, cf = opts[first].check_first ? 1 : 0;
+    std::vector<int> idx; std::vector<hop_rqt_job> cls; std::vector<hop_intra_cu_syntax> sy; std::vector<hop_intra_rqt_opt> op;
+    for (int i = first; i < n; i++) {
+      const hop_rqt_job& j = jobs[i];
+      if (!done[i] && j.log2_cu == f.log2_cu && j.log2_max_tu == f.log2_max_tu && j.log2_min_tu_in_cu == f.log2_min_tu_in_cu && !j.sign_hide == !f.sign_hide && !j.use_ts == !f.use_ts &&
+          syntax[i].tr_depth == d0 && (opts[i].check_first ? 1 : 0) == cf) { done[i] = 1; idx.push_back(i); cls.push_back(j); sy.push_back(syntax[i]); op.push_back(opts[i]); }
+    }
+    const int m = (int)idx.size();
+    const size_t cu3 = ((size_t)3 << (2 * f.log2_cu)) / 2;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_j = 0, o_y = al((size_t)m * sizeof(hop_rqt_job)), o_p = al(o_y + (size_t)m * sizeof(hop_intra_cu_syntax)), o_c = al(o_p + (size_t)m * sizeof(hop_intra_rqt_opt));
+    const size_t o_u = al(o_c + (size_t)n_ctx * sizeof(hop_cabac_ctx)), o_r = al(o_u + (size_t)n_ctx * sizeof(hop_cabac_cu_ctx)), o_o = al(o_r + (size_t)m * sizeof(hop_rqt_result));
+    const size_t o_x = al(o_o + (size_t)m * cu3 * 4), o_v = al(o_x + (size_t)m * sizeof(hop_cabac_ctx)), o_e = al(o_v + (size_t)m * sizeof(hop_cabac_cu_ctx));
+    void* st; int r = hop_stage(c, o_e + 256, &st); if (r) return r;
+    char* b = (char*)st;
+    HIPCHK(c, hipMemcpyAsync(b + o_j, cls.data(), (size_t)m * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_y, sy.data(), (size_t)m * sizeof(hop_intra_cu_syntax), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_p, op.data(), (size_t)m * sizeof(hop_intra_rqt_opt), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, (size_t)n_ctx * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_u, cu_ctx_in, (size_t)n_ctx * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b + o_o, 0, (size_t)m * cu3 * 4, c->stream));
+    r = hop_intra_rqt_device(c, m, (const hop_rqt_job*)(b + o_j), &f, d0, cf, (const hop_intra_cu_syntax*)(b + o_y), (const hop_intra_rqt_opt*)(b + o_p), (const hop_cabac_ctx*)(b + o_c),
+                             (const hop_cabac_cu_ctx*)(b + o_u), (hop_rqt_result*)(b + o_r), (int32_t*)(b + o_o), (hop_cabac_ctx*)(b + o_x), (hop_cabac_cu_ctx*)(b + o_v));
+    if (r) return r;
+    std::vector<hop_rqt_result> rr(m); std::vector<int32_t> co((size_t)m * cu3); std::vector<hop_cabac_ctx> cx(m); std::vector<hop_cabac_cu_ctx> cv(m);
+    HIPCHK(c, hipMemcpyAsync(rr.data(), b + o_r, (size_t)m * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(co.data(), b + o_o, (size_t)m * cu3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cx.data(), b + o_x, (size_t)m * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cv.data(), b + o_v, (size_t)m * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < m; t++) {
+      results[idx[t]] = rr[t];
+      if (coef_out) memcpy(coef_out + coff[idx[t]], co.data() + (size_t)t * cu3, cu3 * 4);
+      if (ctx_out) ctx_out[idx[t]] = cx[t];
+      if (cu_ctx_out) cu_ctx_out[idx[t]] = cv[t];
+    }
+  }
+  return HOP_OK;
+}
+
 int hop_inter_cu_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results, const int32_t* d_coef,
                              const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out,
                              hop_cabac_cu_ctx* d_cu_ctx_out) {

@@ -141,6 +141,10 @@ size_t hop_rdoq_work_bytes(int n);
 int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
                      int32_t* d_levels, hop_tu_rd_result* d_res, int size_hint);
 int hop_launch_tu_recon(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const int64_t* d_coef_off, const int32_t* d_levels, const uint32_t* d_abs_sum, uint32_t* d_sse);
+size_t hop_intra_rqt_work_bytes(int log2_cu, int n);
+int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int tr_depth0, int check_first, int n, const hop_rqt_job* d_jobs,
+                         const hop_intra_cu_syntax* d_syn, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, hop_rqt_result* d_res,
+                         int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* buf, size_t buf_bytes);
 size_t hop_rqt_finish_work_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n);
 int hop_launch_rqt_finish(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int use_ts, int n, const hop_rqt_job* d_jobs, hop_rqt_result* d_res, int32_t* d_coef,
                           const hop_cabac_ctx* d_after, hop_cu_final* d_fin, void* buf);

@@ -583,6 +583,68 @@ __device__ static unsigned long long icu_dir(CabacLds& sh, const int lane, const
   return frac;
 }
 
+// the counting itself, from the node (tr0, part0) downwards; levels either in the CU layout (cf) or in the layer buffers of the quadtree searches (layered, CU i)
+__device__ __noinline__ static unsigned long long icu_count(CabacLds& sh, const int lane, const RqtClass& k, const hop_intra_cu_syntax& y, const int tr0, const int part0, const int b_luma,
+                                               const int b_chroma, const hop_rqt_result* r, const int32_t* cf, const int32_t* layered, const int i, const uint16_t* scans) {
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  unsigned long long frac = 0;
+  // xEncIntraHeader
+  if (b_luma) {
+    if (part0 == 0) {
+      CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
+      CBIN(CU_PRED, 1);                                              // MODE_INTRA
+      if (y.is_min_cu) CBIN(CU_PART, y.part_nxn ? 0 : 1);
+    }
+    if (!y.part_nxn) { if (part0 == 0) frac += icu_dir(sh, lane, y.luma_dir[0], y.preds[0], y.pred_num[0]); }
+    else {
+      const int q4 = parts >> 2;
+      if (tr0 == 0) { for (int p = 0; p < 4; p++) frac += icu_dir(sh, lane, y.luma_dir[p], y.preds[p], y.pred_num[p]); }
+      else if (part0 % q4 == 0) frac += icu_dir(sh, lane, y.luma_dir[part0 / q4], y.preds[part0 / q4], y.pred_num[part0 / q4]);
+    }
+  }
+  if (b_chroma && part0 == 0) { if (y.chroma_is_dm) CBIN(CU_CPRED, 0); else { CBIN(CU_CPRED, 1); CEP(2); } }
+  // xEncSubdivCbfQT, then xEncCoeffQT per component: pass 0 = flags, passes 1..3 = levels of Y, Cb, Cr
+  for (int pass = 0; pass < 4; pass++) {
+    if (pass == 1 && !b_luma) continue;
+    if (pass >= 2 && !b_chroma) continue;
+    int sp_part[4], sp_k[4]; int sp = 0;
+    sp_part[0] = part0; sp_k[0] = -1;
+    while (sp >= 0) {
+      const int part = sp_part[sp], trDepth = tr0 + sp, log2 = k.log2_cu - trDepth;
+      if (sp_k[sp] < 0) {
+        const int trMode = r->tr_idx[part], subdiv = trMode > trDepth;
+        if (pass == 0) {
+          if (!((y.part_nxn && trDepth == 0) || log2 > k.log2_max_tu || log2 == 2 || log2 == k.log2_min_tu) && b_luma) CBIN(CX_TRANS_SUBDIV + 5 - log2, subdiv);
+          if (b_chroma && log2 > 2) {
+            if (trDepth == 0 || ((r->cbf[1][part] >> (trDepth - 1)) & 1)) CBIN(rqt_cbf_ctx(1, trDepth), (r->cbf[1][part] >> trDepth) & 1);
+            if (trDepth == 0 || ((r->cbf[2][part] >> (trDepth - 1)) & 1)) CBIN(rqt_cbf_ctx(2, trDepth), (r->cbf[2][part] >> trDepth) & 1);
+          }
+        }
+        if (!subdiv) {
+          if (pass == 0) { if (b_luma) CBIN(rqt_cbf_ctx(0, trMode), (r->cbf[0][part] >> trMode) & 1); }
+          else {
+            const int comp = pass - 1;
+            int d = trDepth; bool code = true;
+            if (comp && log2 == 2) { d--; code = (part % (parts >> (2 * d))) == 0; }
+            if (code) {
+              const int lg = k.log2_cu - d - (comp ? 1 : 0);
+              const int32_t* cp = layered ? layered + rqt_coef_at(k, i, k.log2_max_tu - log2, comp, part)
+                                              : cf + (comp == 0 ? (size_t)(16 * part) : cu2 + (size_t)(comp - 1) * (cu2 >> 2) + (size_t)(4 * part));
+              frac += cb_code_tu(sh, lane, cp, lg, comp != 0, icu_scan(y, parts, part, lg, comp), k.sign_hide, k.use_ts, r->tskip[comp][part], 0, scans);
+            }
+          }
+          sp--; continue;
+        }
+        sp_k[sp] = 0;
+      }
+      if (sp_k[sp] < 4) { const int q = (parts >> (2 * trDepth)) >> 2, kk = sp_k[sp]++; sp_part[sp + 1] = part + kk * q; sp_k[sp + 1] = -1; sp++; }
+      else sp--;
+    }
+  }
+  return frac;
+}
+
 __global__ __launch_bounds__(64) void k_intra_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
                                                       const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
                                                       const hop_cabac_cu_ctx* __restrict__ cu_in, uint32_t* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out,
@@ -595,62 +657,10 @@ __global__ __launch_bounds__(64) void k_intra_cu_bits(RqtClass k, int n, const h
   for (int q = 0; q < 20; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
   const hop_intra_cu_syntax y = syn[i];
   const hop_rqt_result* r = res + i;
-  const int parts = 1 << (2 * (k.log2_cu - 2));
   const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
   const int32_t* cf = coef + (size_t)i * (cu2 + (cu2 >> 1));
   unsigned long long frac = RQ_LEFT();
-  // xEncIntraHeader
-  if (y.b_luma) {
-    if (y.part == 0) {
-      CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
-      CBIN(CU_PRED, 1);                                              // MODE_INTRA
-      if (y.is_min_cu) CBIN(CU_PART, y.part_nxn ? 0 : 1);
-    }
-    if (!y.part_nxn) { if (y.part == 0) frac += icu_dir(sh, lane, y.luma_dir[0], y.preds[0], y.pred_num[0]); }
-    else {
-      const int q4 = parts >> 2;
-      if (y.tr_depth == 0) { for (int p = 0; p < 4; p++) frac += icu_dir(sh, lane, y.luma_dir[p], y.preds[p], y.pred_num[p]); }
-      else if (y.part % q4 == 0) frac += icu_dir(sh, lane, y.luma_dir[y.part / q4], y.preds[y.part / q4], y.pred_num[y.part / q4]);
-    }
-  }
-  if (y.b_chroma && y.part == 0) { if (y.chroma_is_dm) CBIN(CU_CPRED, 0); else { CBIN(CU_CPRED, 1); CEP(2); } }
-  // xEncSubdivCbfQT, then xEncCoeffQT per component: pass 0 = flags, passes 1..3 = levels of Y, Cb, Cr
-  for (int pass = 0; pass < 4; pass++) {
-    if (pass == 1 && !y.b_luma) continue;
-    if (pass >= 2 && !y.b_chroma) continue;
-    int sp_part[4], sp_k[4]; int sp = 0;
-    sp_part[0] = y.part; sp_k[0] = -1;
-    while (sp >= 0) {
-      const int part = sp_part[sp], trDepth = y.tr_depth + sp, log2 = k.log2_cu - trDepth;
-      if (sp_k[sp] < 0) {
-        const int trMode = r->tr_idx[part], subdiv = trMode > trDepth;
-        if (pass == 0) {
-          if (!((y.part_nxn && trDepth == 0) || log2 > k.log2_max_tu || log2 == 2 || log2 == k.log2_min_tu) && y.b_luma) CBIN(CX_TRANS_SUBDIV + 5 - log2, subdiv);
-          if (y.b_chroma && log2 > 2) {
-            if (trDepth == 0 || ((r->cbf[1][part] >> (trDepth - 1)) & 1)) CBIN(rqt_cbf_ctx(1, trDepth), (r->cbf[1][part] >> trDepth) & 1);
-            if (trDepth == 0 || ((r->cbf[2][part] >> (trDepth - 1)) & 1)) CBIN(rqt_cbf_ctx(2, trDepth), (r->cbf[2][part] >> trDepth) & 1);
-          }
-        }
-        if (!subdiv) {
-          if (pass == 0) { if (y.b_luma) CBIN(rqt_cbf_ctx(0, trMode), (r->cbf[0][part] >> trMode) & 1); }
-          else {
-            const int comp = pass - 1;
-            int d = trDepth; bool code = true;
-            if (comp && log2 == 2) { d--; code = (part % (parts >> (2 * d))) == 0; }
-            if (code) {
-              const int lg = k.log2_cu - d - (comp ? 1 : 0);
-              const int32_t* cp = cf + (comp == 0 ? (size_t)(16 * part) : cu2 + (size_t)(comp - 1) * (cu2 >> 2) + (size_t)(4 * part));
-              frac += cb_code_tu(sh, lane, cp, lg, comp != 0, icu_scan(y, parts, part, lg, comp), k.sign_hide, k.use_ts, r->tskip[comp][part], 0, scans);
-            }
-          }
-          sp--; continue;
-        }
-        sp_k[sp] = 0;
-      }
-      if (sp_k[sp] < 4) { const int q = (parts >> (2 * trDepth)) >> 2, kk = sp_k[sp]++; sp_part[sp + 1] = part + kk * q; sp_k[sp + 1] = -1; sp++; }
-      else sp--;
-    }
-  }
+  frac += icu_count(sh, lane, k, y, y.tr_depth, y.part, y.b_luma, y.b_chroma, r, cf, nullptr, i, scans);
   bits_out[i] = (uint32_t)(frac >> 15);
   if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
   if (cu_out) for (int q = 0; q < 20; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
@@ -665,5 +675,255 @@ int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_cu_bits launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+// =====================================================================================================================
+// The luma transform tree of an intra PU: TEncSearch::xRecurIntraCodingQT with bLumaOnly (TLibEncoder/TEncSearch.cpp:1361-1710), for a batch of PUs of one
+// class (CU size, transform-tree limits, first transform depth, bCheckFirst).  The same shape as the residual quadtree above - a chain inside a PU, a batch
+// across PUs, the host walking the tree - with the intra leaf per node (xIntraCodingLumaBlk :1003-1161):
+//   k_irqt_begin   entry state stored (CI_QT_TRAFO_ROOT), depth / transform-skip arrays set, the node's prediction job (reference samples from the context's
+//                  reconstruction picture by the caller's neighbour flags) and leaf job(s) emitted
+//   hop_launch_intra_pred, hop_launch_tu_rd (is_intra: residual, DST / DCT or transform skip, estBit on the entry state, RDOQ, inverse path, Clip(prediction +
+//                  residual) into the reconstruction picture, SSE); for 4x4 nodes first the transform-skip variant, its block parked by k_irqt_copy
+//   k_irqt_single  one lane per PU: the node's bits through xGetIntraBitsQT (icu_count) from the entry state, its cost; the 4x4 transform-skip decision
+//                  (:1424-1523); a node without children adds itself to its parent's sums, one with children parks the state (CI_QT_TRAFO_TEST) and rewinds
+//   k_irqt_close   cbf of the children folded upwards, the subtree recounted from the entry state, the split decision (:1576-1700); k_irqt_copy puts the
+//                  single block's reconstruction (kept in a per-PU layer plane, m_pcQTTempTComYuv) back into the picture where it wins
+// The PUs of one call must not lie in each other's neighbourhood (the picture is read and written as the search goes, as in the reference).
+// =====================================================================================================================
+struct IrqWork { double single_cost[4]; double sub_cost[5]; uint32_t single_dist[4], single_cbf[4], sub_dist[5]; uint8_t best[4], restore[4]; };
+__host__ __device__ static inline int irq_node_index(int d, int log2, int part) { const int first[5] = { 0, 1, 5, 21, 85 }; return first[d] + (part >> (2 * (log2 - 2))); }
+#define IRQ_CU_LOAD(src) do { for (int q_ = 0; q_ < 20; q_++) sh.st[CUX + q_][lane] = (src).state[q_]; } while (0)
+#define IRQ_CU_STORE(dst) do { for (int q_ = 0; q_ < 20; q_++) (dst).state[q_] = sh.st[CUX + q_][lane]; } while (0)
+
+__global__ void k_irqt_init(const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
+                            hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, IrqWork* __restrict__ work, hop_rqt_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  cur[i] = ctx_in[jobs[i].ctx_index]; cucur[i] = cu_in[jobs[i].ctx_index];
+  IrqWork w; memset(&w, 0, sizeof(w));
+  work[i] = w;
+  hop_rqt_result* r = res + i;
+  r->cost = 0; r->bits = r->dist = r->zero_dist = r->pad = 0;
+  for (int p = 0; p < 256; p++) { r->tr_idx[p] = 0; for (int c = 0; c < 3; c++) { r->cbf[c][p] = 0; r->tskip[c][p] = 0; } }
+}
+
+__global__ void k_irqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, const hop_intra_rqt_opt* __restrict__ opt,
+                             int n, int bd_y, const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ root,
+                             hop_cabac_cu_ctx* __restrict__ curoot, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, hop_intra_job* __restrict__ pj,
+                             int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2,
+                             int64_t* __restrict__ off2, size_t ts_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  root[i] = cur[i]; curoot[i] = cucur[i];
+  IrqWork* w = work + i;
+  if (nd.check_split) { w->sub_cost[nd.d + 1] = 0; w->sub_dist[nd.d + 1] = 0; }
+  w->restore[nd.d] = 0;
+  if (!nd.check_full) { w->single_cost[nd.d] = 1.7e+308; return; }
+  const hop_rqt_job jb = jobs[i];
+  const hop_intra_cu_syntax y = syn[i];
+  hop_rqt_result* r = res + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), part = y.part + nd.part, N = 1 << nd.log2;
+  for (int p = 0; p < nparts; p++) { r->tr_idx[part + p] = (uint8_t)nd.d; r->tskip[0][part + p] = 0; }
+  const int dir = y.luma_dir[y.part_nxn ? part / (parts >> 2) : 0];
+  hop_intra_job q;
+  q.x = jb.x + rqt_zx(part); q.y = jb.y + rqt_zy(part); q.size = N; q.strong = opt[i].strong;
+  const unsigned long long av = opt[i].avail[irq_node_index(nd.d, nd.log2, part)];
+  for (int u = 0; u < 68; u++) q.flags[u] = (u < 4 * (N / 4) + 1) ? (uint8_t)((av >> u) & 1ull) : 0;
+  pj[i] = q; modes[i] = dir;
+  hop_tu_rd_job j;
+  j.x = q.x; j.y = q.y; j.comp = 0; j.log2_size = nd.log2; j.qp_scaled = jb.qp_scaled[0]; j.tr_depth = nd.d; j.ctx_index = i; j.sign_hide = k.sign_hide; j.use_ts = k.use_ts;
+  j.bit_depth = bd_y; j.is_intra = 1; j.scan_idx = icu_scan(y, parts, part, nd.log2, 0); j.use_dst = 1; j.flags = 0;
+  j.lambda_rdoq = jb.lambda_rdoq[0]; j.lambda_rd = jb.lambda_rd; j.dist_weight = 1.0;
+  tuj[i] = j; off[i] = (int64_t)rqt_coef_at(k, i, k.log2_max_tu - nd.log2, 0, part);
+  if (nd.ts_y) {
+    j.flags = HOP_TU_RD_TS;
+    if (opt[i].ts_fast && !y.part_nxn) j.log2_size = 0;                 // TransformSkipFast: not tried for this CU (an empty slot of the leaf batch)
+    tuj2[i] = j; off2[i] = (int64_t)(ts_base + (size_t)i * 16);
+  }
+}
+
+// mode 0: the node's block, picture -> layer plane; 1: the 4x4 block, picture -> transform-skip park; 2: layer plane -> picture where the single block has won
+__global__ __launch_bounds__(256) void k_irqt_copy(int mode, RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
+                                                   const IrqWork* __restrict__ work, int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ recl, int16_t* __restrict__ park) {
+  const int i = blockIdx.x;
+  if (mode == 2 && !work[i].restore[nd.d]) return;
+  const int part = syn[i].part + nd.part, N = 1 << nd.log2, cu = 1 << k.log2_cu, x0 = rqt_zx(part), y0 = rqt_zy(part);
+  int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
+  int16_t* lay = recl + ((size_t)i * 4 + (size_t)(k.log2_max_tu - nd.log2)) * ((size_t)cu * cu) + (size_t)y0 * cu + x0;
+  for (int e = threadIdx.x; e < N * N; e += 256) {
+    const int rr = e >> nd.log2, cc = e & (N - 1);
+    if (mode == 0) lay[(size_t)rr * cu + cc] = pic[(size_t)rr * pitch + cc];
+    else if (mode == 1) park[(size_t)i * 16 + e] = pic[(size_t)rr * pitch + cc];
+    else pic[(size_t)rr * pitch + cc] = lay[(size_t)rr * cu + cc];
+  }
+}
+
+__global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                    const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur,
+                                                    const hop_cabac_ctx* __restrict__ root, const hop_cabac_cu_ctx* __restrict__ curoot, hop_cabac_ctx* __restrict__ test,
+                                                    hop_cabac_cu_ctx* __restrict__ cutest, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work,
+                                                    const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base,
+                                                    int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const hop_intra_cu_syntax y = syn[i];
+  const double lambda = jobs[i].lambda_rd;
+  hop_rqt_result* r = res + i;
+  IrqWork* w = work + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), part = y.part + nd.part;
+  // the block as the transform left it
+  const uint32_t dist0 = tr[i].dist, cbf0 = tr[i].abs_sum ? 1u : 0u;
+  for (int p = 0; p < nparts; p++) r->cbf[0][part + p] = (uint8_t)(cbf0 << nd.d);
+  RQ_LOAD(root[i]); IRQ_CU_LOAD(curoot[i]);
+  unsigned long long frac = RQ_LEFT();
+  frac += icu_count(sh, lane, k, y, nd.d, part, 1, 0, r, nullptr, coef, i, scans);
+  double cost = rqt_cost((uint32_t)(frac >> 15), dist0, lambda);
+  uint32_t dist = dist0, cbf = cbf0; int best = 0;
+  const bool ts_on = nd.ts_y && !(opt[i].ts_fast && !y.part_nxn);
+  if (ts_on) {
+    const uint32_t cbf1 = tr2[i].abs_sum ? 1u : 0u;
+    if (cbf1) {                                                         // modeId 1 with a zero block is never taken (:1463-1466)
+      rqt_store(sh, lane, frac, cur + i); IRQ_CU_STORE(cucur[i]);        // CI_TEMP_BEST
+      int32_t* lv = coef + rqt_coef_at(k, i, k.log2_max_tu - 2, 0, part); int32_t* tv = coef + ts_base + (size_t)i * 16;
+      for (int e = 0; e < 16; e++) { const int32_t t = lv[e]; lv[e] = tv[e]; tv[e] = t; }
+      for (int p = 0; p < nparts; p++) { r->tskip[0][part + p] = 1; r->cbf[0][part + p] = (uint8_t)(1u << nd.d); }
+      RQ_LOAD(root[i]); IRQ_CU_LOAD(curoot[i]);
+      unsigned long long f1 = RQ_LEFT();
+      f1 += icu_count(sh, lane, k, y, nd.d, part, 1, 0, r, nullptr, coef, i, scans);
+      const double cost1 = rqt_cost((uint32_t)(f1 >> 15), tr2[i].dist, lambda);
+      if (cost1 < cost) {
+        cost = cost1; dist = tr2[i].dist; cbf = 1; best = 1; frac = f1;
+        int16_t* pic = rec + (size_t)(jobs[i].y + rqt_zy(part)) * pitch + jobs[i].x + rqt_zx(part);
+        for (int e = 0; e < 16; e++) pic[(size_t)(e >> 2) * pitch + (e & 3)] = park[(size_t)i * 16 + e];
+      } else {                                                          // xLoadIntraResultQT: levels, arrays and the coder of the first variant
+        for (int e = 0; e < 16; e++) { const int32_t t = lv[e]; lv[e] = tv[e]; tv[e] = t; }
+        for (int p = 0; p < nparts; p++) { r->tskip[0][part + p] = 0; r->cbf[0][part + p] = (uint8_t)(cbf0 << nd.d); }
+        RQ_LOAD(cur[i]); IRQ_CU_LOAD(cucur[i]); frac = RQ_LEFT();
+      }
+    }
+  }
+  w->single_cost[nd.d] = cost; w->single_dist[nd.d] = dist; w->single_cbf[nd.d] = cbf; w->best[nd.d] = (uint8_t)best;
+  if (nd.check_split) { rqt_store(sh, lane, frac, test + i); IRQ_CU_STORE(cutest[i]); cur[i] = root[i]; cucur[i] = curoot[i]; }
+  else { rqt_store(sh, lane, frac, cur + i); IRQ_CU_STORE(cucur[i]); w->sub_cost[nd.d] += cost; w->sub_dist[nd.d] += dist; }
+}
+
+__global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
+                                                   hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, const hop_cabac_ctx* __restrict__ root,
+                                                   const hop_cabac_cu_ctx* __restrict__ curoot, const hop_cabac_ctx* __restrict__ test, const hop_cabac_cu_ctx* __restrict__ cutest,
+                                                   hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const hop_intra_cu_syntax y = syn[i];
+  hop_rqt_result* r = res + i;
+  IrqWork* w = work + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), part = y.part + nd.part, q = nparts >> 2;
+  uint32_t scbf = 0;
+  for (int kk = 0; kk < 4; kk++) scbf |= (r->cbf[0][part + kk * q] >> (nd.d + 1)) & 1u;
+  for (int p = 0; p < nparts; p++) r->cbf[0][part + p] |= (uint8_t)(scbf << nd.d);
+  RQ_LOAD(root[i]); IRQ_CU_LOAD(curoot[i]);
+  unsigned long long frac = RQ_LEFT();
+  frac += icu_count(sh, lane, k, y, nd.d, part, 1, 0, r, nullptr, coef, i, scans);
+  const double split = rqt_cost((uint32_t)(frac >> 15), w->sub_dist[nd.d + 1], jobs[i].lambda_rd);
+  if (split < w->single_cost[nd.d]) {
+    rqt_store(sh, lane, frac, cur + i); IRQ_CU_STORE(cucur[i]);
+    w->sub_cost[nd.d] += split; w->sub_dist[nd.d] += w->sub_dist[nd.d + 1];
+    return;
+  }
+  cur[i] = test[i]; cucur[i] = cutest[i];
+  for (int p = 0; p < nparts; p++) { r->tr_idx[part + p] = (uint8_t)nd.d; r->cbf[0][part + p] = (uint8_t)(w->single_cbf[nd.d] << nd.d); r->tskip[0][part + p] = w->best[nd.d]; }
+  w->restore[nd.d] = 1;
+  w->sub_cost[nd.d] += w->single_cost[nd.d]; w->sub_dist[nd.d] += w->single_dist[nd.d];
+}
+
+__global__ __launch_bounds__(64) void k_irqt_final(RqtClass k, int d0, int n, const hop_intra_cu_syntax* __restrict__ syn, const IrqWork* __restrict__ work,
+                                                   hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, int32_t* __restrict__ coef_out,
+                                                   const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ ctx_out,
+                                                   hop_cabac_cu_ctx* __restrict__ cu_out) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), np = parts >> (2 * d0), p0 = syn[i].part;
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  hop_rqt_result* r = res + i;
+  if (t == 0) { r->cost = work[i].sub_cost[d0]; r->dist = work[i].sub_dist[d0]; if (ctx_out) ctx_out[i] = cur[i]; if (cu_out) cu_out[i] = cucur[i]; }
+  if (!coef_out) return;
+  for (int e = t; e < 16 * np; e += 64) {
+    const int p = p0 + (e >> 4), layer = k.log2_max_tu - (k.log2_cu - r->tr_idx[p]);
+    coef_out[(size_t)i * (cu2 + (cu2 >> 1)) + (size_t)16 * p0 + e] = coef[rqt_coef_at(k, i, layer, 0, p) + (e & 15)];
+  }
+}
+
+size_t hop_intra_rqt_work_bytes(int log2_cu, int n) {
+  const size_t cu2 = (size_t)1 << (2 * log2_cu);
+  return (size_t)n * (9 * (sizeof(hop_cabac_ctx) + sizeof(hop_cabac_cu_ctx) + 16) + sizeof(IrqWork) + sizeof(hop_intra_job) + 4 + 2 * (sizeof(hop_tu_rd_job) + 8 + sizeof(hop_tu_rd_result)) +
+                     (6 * cu2 + 16) * 4 + 4 * cu2 * 2 + 32) + 64 * 256;
+}
+
+// one class of PUs: CU size, transform-tree limits, the transform depth the PU starts at (0: 2Nx2N, 1: NxN) and bCheckFirst; buf = hop_intra_rqt_work_bytes
+int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int tr_depth0, int check_first, int n, const hop_rqt_job* d_jobs,
+                         const hop_intra_cu_syntax* d_syn, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, hop_rqt_result* d_res,
+                         int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* vbuf, size_t buf_bytes) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  char* buf = (char*)vbuf;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu), n_coeff = (size_t)n * (6 * cu2 + 16), ts_base = (size_t)n * 6 * cu2;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
+  struct St { hop_cabac_ctx* a; hop_cabac_cu_ctx* b; };
+  auto take_st = [&]() { St s; s.a = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); s.b = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx)); return s; };
+  struct Bufs {
+    St cur, root[4], test[4]; IrqWork* work; hop_intra_job* pj; int32_t* modes; hop_tu_rd_job *tuj, *tuj2; int64_t *off, *off2; hop_tu_rd_result *tr, *tr2; int32_t* coef;
+    int16_t *recl, *park; size_t n_coeff, ts_base;
+  } B;
+  B.cur = take_st();
+  for (int d = 0; d < 4; d++) { B.root[d] = take_st(); B.test[d] = take_st(); }
+  B.work = (IrqWork*)take((size_t)n * sizeof(IrqWork));
+  B.pj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job)); B.modes = (int32_t*)take((size_t)n * 4);
+  B.tuj = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job)); B.tuj2 = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job));
+  B.off = (int64_t*)take((size_t)n * 8); B.off2 = (int64_t*)take((size_t)n * 8);
+  B.tr = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result)); B.tr2 = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result));
+  B.coef = (int32_t*)take(n_coeff * 4);
+  B.recl = (int16_t*)take((size_t)n * 4 * cu2 * 2); B.park = (int16_t*)take((size_t)n * 32);
+  B.n_coeff = n_coeff; B.ts_base = ts_base;
+  if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra rqt: work buffer too small");
+  hipLaunchKernelGGL(k_irqt_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, d_ctx_in, d_cu_in, B.cur.a, B.cur.b, B.work, d_res);
+  struct Rec { static int go(hop_ctx* c, const RqtClass& k, int n, int check_first, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn, const hop_intra_rqt_opt* d_opt,
+                             hop_rqt_result* d_res, Bufs& B, int rel, int d, int log2) {
+    RqtNode nd; memset(&nd, 0, sizeof(nd));
+    nd.part = rel; nd.d = d; nd.log2 = log2;
+    nd.check_full = log2 <= k.log2_max_tu;
+    nd.check_split = log2 > k.log2_min_tu && !(check_first && nd.check_full);
+    nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
+    const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, pitch = c->pic_w;
+    hipLaunchKernelGGL(k_irqt_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, c->bd_y, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, d_res, B.work,
+                       B.pj, B.modes, B.tuj, B.off, B.tuj2, B.off2, B.ts_base);
+    if (nd.check_full) {
+      int r = hop_launch_intra_pred(c, n, B.pj, B.modes); if (r) return r;
+      const int hint = log2 <= 3 ? 1 : (log2 == 5 ? 2 : 0);
+      if (nd.ts_y) {
+        r = hop_launch_tu_rd(c, n, B.tuj2, B.root[d].a, B.off2, B.n_coeff, B.coef, B.tr2, 1); if (r) return r;
+        hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 1, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park);
+      }
+      r = hop_launch_tu_rd(c, n, B.tuj, B.root[d].a, B.off, B.n_coeff, B.coef, B.tr, hint); if (r) return r;
+      if (nd.check_split) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 0, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park);
+      hipLaunchKernelGGL(k_irqt_single, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b,
+                         d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base, c->rec[0], pitch, B.park, c->rdoq_scans);
+    }
+    if (nd.check_split) {
+      const int q = ((1 << (2 * (k.log2_cu - 2))) >> (2 * d)) >> 2;
+      for (int kk = 0; kk < 4; kk++) { const int r = go(c, k, n, check_first, d_jobs, d_syn, d_opt, d_res, B, rel + kk * q, d + 1, log2 - 1); if (r) return r; }
+      hipLaunchKernelGGL(k_irqt_close, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b, d_res,
+                         B.work, B.coef, c->rdoq_scans);
+      if (nd.check_full) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 2, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park);
+    }
+    return HOP_OK;
+  } };
+  const int rc = Rec::go(c, k, n, check_first, d_jobs, d_syn, d_opt, d_res, B, 0, tr_depth0, k.log2_cu - tr_depth0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_irqt_final, dim3(n), dim3(64), 0, c->stream, k, tr_depth0, n, d_syn, B.work, d_res, B.coef, d_coef_out, B.cur.a, B.cur.b, d_ctx_out, d_cu_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra rqt launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }

@@ -76,6 +76,7 @@ INTRA_MODES_JOB_DTYPE = np.dtype([("preds", "<i4", (3,)), ("pred_num", "<i4"), (
 INTRA_MODES_RESULT_DTYPE = np.dtype([("n", "<u4"), ("modes", "<u4", (11,)), ("costs", "<f8", (8,))])
 INTRA_CU_SYNTAX_DTYPE = np.dtype([("part_nxn", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("is_min_cu", "<i4"), ("luma_dir", "<i4", (4,)), ("preds", "<i4", (4, 3)),
                                   ("pred_num", "<i4", (4,)), ("chroma_is_dm", "<i4"), ("chroma_dir", "<i4"), ("tr_depth", "<i4"), ("part", "<i4"), ("b_luma", "<i4"), ("b_chroma", "<i4")])
+INTRA_RQT_OPT_DTYPE = np.dtype([("check_first", "<i4"), ("ts_fast", "<i4"), ("strong", "<i4"), ("pad", "<i4"), ("avail", "<u8", (341,))])   # hop_intra_rqt_opt
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -337,6 +338,18 @@ class Context:
         self._chk(self.L.hop_intra_cu_bits(self.h, n, jobs.ctypes.data, syntax.ctypes.data, res.ctypes.data, coef.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data,
                                            bits.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_intra_cu_bits")
         return bits, cx, cu
+
+    def intra_rqt(self, jobs, syntax, opts, ctx_in, cu_ctx_in):
+        """xRecurIntraCodingQT (luma): returns results (RQT_RESULT_DTYPE), chosen levels (1.5 size^2 per job, the PU's luma partitions filled), coder states (n, 152)
+        and CU-level states (n, 20) afterwards; the context's reconstruction picture holds the chosen trees"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, INTRA_CU_SYNTAX_DTYPE); opts = np.ascontiguousarray(opts, INTRA_RQT_OPT_DTYPE)
+        ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); res = np.zeros(n, RQT_RESULT_DTYPE); cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, CABAC_CU_CTX_BYTES), np.uint8)
+        coef = np.zeros(int(sum((3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs)), np.int32)
+        self.L.hop_intra_rqt.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 6
+        self._chk(self.L.hop_intra_rqt(self.h, n, jobs.ctypes.data, syntax.ctypes.data, opts.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data, res.ctypes.data,
+                                       coef.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_intra_rqt")
+        return res, coef, cx, cu
 
     def intra_pred(self, jobs, modes):
         n = len(jobs)

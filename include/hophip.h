@@ -427,6 +427,31 @@ typedef struct {
 } hop_intra_cu_syntax;
 int hop_intra_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, int n_ctx,
                       const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
+/* ---- luma transform tree of an intra PU (rest of row a8) ---- */
+/* replaces: TEncSearch::xRecurIntraCodingQT with bLumaOnly (TLibEncoder/TEncSearch.cpp:1361-1710) as estIntraPredQT calls it per candidate mode (:2524, bCheckFirst)
+ * and for the chosen one (:2587), for a batch of PUs: per node xIntraCodingLumaBlk (:1003-1161: reference samples from the context's reconstruction picture,
+ * prediction, residual, DST / DCT with RDOQ on the current coder state, inverse path, reconstruction written back into the picture, SSE), for 4x4 nodes also the
+ * transform-skip variant (:1424-1523), the bits through xGetIntraBitsQT (:957-980), the four children, the recount and the split decision (:1576-1700).
+ * jobs: CU position / size / QP / lambdas / transform-tree limits and ctx_index (into ctx_in and cu_ctx_in) of hop_rqt_job; syntax: the CU's syntax elements, with
+ * (tr_depth, part) = the node the PU starts at (0, 0 for 2Nx2N; 1, k * parts / 4 for PU k of NxN); b_luma / b_chroma are not read.  RDOQ and RDOQTS on, RDpenalty 0,
+ * no PCM / transquant bypass, not an I slice.  The reconstruction picture is read (neighbours) and written (the PU's blocks) as the search goes: the PUs of one call
+ * must not lie in each other's neighbourhood (up to 2 * size to the right / below, one sample left / above); afterwards it holds the chosen tree's reconstruction. */
+typedef struct {
+  int32_t  check_first;            /* bCheckFirst: no split below a node that can be coded as one TU (HHI_RQT_INTRA_SPEEDUP) */
+  int32_t  ts_fast;                /* TransformSkipFast: transform skip tried in NxN CUs only */
+  int32_t  strong;                 /* SPS strong_intra_smoothing */
+  int32_t  pad;
+  uint64_t avail[341];             /* neighbour availability of every node of the CU's quadtree: node (transform depth d, size 2^l, first partition p) at
+                                      {0, 1, 5, 21, 85}[d] + (p >> (2 * (l - 2))); bit u = flags[u] of hop_intra_job (TComPattern::initAdiPattern, TComPattern.cpp:199-211) */
+} hop_intra_rqt_opt;
+/* results: cost / dist = what the call adds to dRDCost / ruiDistY; the arrays hold the PU's partitions (luma).  coef_out (may be NULL): per job 1.5 * size^2 entries,
+ * the chosen luma levels of the PU's partitions in the CU layout (other entries untouched).  ctx_out / cu_ctx_out (may be NULL): the coder after the PU. */
+int hop_intra_rqt(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, int n_ctx, const hop_cabac_ctx* ctx_in,
+                  const hop_cabac_cu_ctx* cu_ctx_in, hop_rqt_result* results, int32_t* coef_out, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
+/* device-resident form: all n PUs of ONE class -- CU size and transform-tree limits / flags of *cls, the first transform depth, bCheckFirst; asynchronous, unchecked */
+int hop_intra_rqt_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, int tr_depth, int check_first, const hop_intra_cu_syntax* d_syntax,
+                         const hop_intra_rqt_opt* d_opts, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, hop_rqt_result* d_results, int32_t* d_coef_out,
+                         hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -635,3 +635,59 @@ def test_tu_intra_transform_skip_vs_oracle(hp):
         nz += int(out[0] != 0 and int(j["flags"]) != 0)
     assert nz > 60
     ctx.close()
+
+
+def test_intra_rqt_encoder_calls(hp):
+    """hop_intra_rqt (xRecurIntraCodingQT, luma: the transform tree of an intra PU - prediction from the reconstruction picture, leaf step, 4x4 transform-skip retry,
+    bits via xGetIntraBitsQT, children on the state the previous one left, recount, split decision, the picture restored where the single block wins) on the 47 calls
+    recorded inside the encoder, each in its own tile of one picture (its recorded neighbourhood around it): cost, distortion, depth / cbf / transform-skip arrays,
+    chosen levels, coder and CU-level context states, and the reconstruction picture afterwards"""
+    from goldutil import encoder_irqt_calls
+    cases = list(encoder_irqt_calls())
+    n = len(cases); T = 192; G = 7; W = H = T * G
+    assert n <= G * G
+    Y = np.zeros((H, W), np.int16); R = np.zeros((H, W), np.int16)
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(n, hp.INTRA_RQT_OPT_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; j = jobs[i]; cu = 1 << int(cfg["log2_cu"]); Wn = 2 * cu + 1
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        Y[y0:y0 + cu, x0:x0 + cu] = c["org"].reshape(cu, cu)
+        R[y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn] = c["win"].reshape(Wn, Wn)
+        j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x0, y0, int(cfg["log2_cu"]), cfg["qp"], i
+        j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"]
+        j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = cfg["lambda_rd"], cfg["lambda_rdoq"], cfg["dist_weight"][1:]
+        for k in ("part_nxn", "skip_flag", "skip_ctx", "is_min_cu", "luma_dir", "preds", "pred_num", "chroma_is_dm", "chroma_dir"): syn[i][k] = c["syn"][k]
+        syn[i]["tr_depth"], syn[i]["part"], syn[i]["b_luma"] = c["nd"][0], c["nd"][1], 1
+        opts[i]["check_first"], opts[i]["ts_fast"], opts[i]["strong"] = c["nd"][2], c["nd"][3], c["nd"][4]
+        av = c["avail"].reshape(341, 36).astype(np.uint64)
+        opts[i]["avail"] = (av << np.arange(36, dtype=np.uint64)[None, :]).sum(axis=1)
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i] = c["cuin"]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16))
+    ctx.plane_upload("recon", 0, R)
+    res, coef, cx, cu_out = ctx.intra_rqt(jobs, syn, opts, snaps, cus)
+    R2 = ctx.recon_download(0)
+    o = 0; kinds = set()
+    for i, c in enumerate(cases):
+        cu = 1 << int(c["cfg"]["log2_cu"]); parts = (cu // 4) ** 2; p0 = c["nd"][1]; np_ = parts >> (2 * c["nd"][0])
+        tag = (i, cu, c["nd"][:3])
+        assert float(res[i]["cost"]) == c["cost"] and int(res[i]["dist"]) == c["dist"], (tag, float(res[i]["cost"]), c["cost"], int(res[i]["dist"]), c["dist"])
+        a = c["aout"].reshape(7, 256)
+        assert np.array_equal(res[i]["tr_idx"][p0:p0 + np_], a[0, p0:p0 + np_]) and np.array_equal(res[i]["cbf"][0][p0:p0 + np_], a[1, p0:p0 + np_]), tag
+        assert np.array_equal(res[i]["tskip"][0][p0:p0 + np_], a[4, p0:p0 + np_]), tag
+        assert np.array_equal(coef[o + 16 * p0:o + 16 * (p0 + np_)], c["fin"][16 * p0:16 * (p0 + np_)]), tag
+        assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), tag
+        assert np.array_equal(cu_out[i], c["cuout"]), tag
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        assert np.array_equal(R2[y0:y0 + cu, x0:x0 + cu].reshape(-1), c["rec"]), tag
+        R[y0:y0 + cu, x0:x0 + cu] = c["rec"].reshape(cu, cu)
+        kinds.add((cu, c["nd"][0], c["nd"][2], int(a[0, p0:p0 + np_].max()), int(a[4, p0:p0 + np_].any())))
+        o += cu * cu * 3 // 2
+    assert np.array_equal(R, R2)                                       # nothing outside the PUs' CUs was touched
+    assert len(kinds) >= 12 and any(k[4] for k in kinds)
+    bad = syn.copy(); bad[0]["part"] = 3
+    with pytest.raises(hp.HopError):
+        ctx.intra_rqt(jobs, bad, opts, snaps, cus)
+    ctx.close()

@@ -5,6 +5,7 @@ import importlib.util
 import os
 
 import numpy as np
+from scipy.ndimage import gaussian_filter
 import pytest
 
 from goldutil import load
@@ -691,3 +692,96 @@ def test_intra_rqt_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.intra_rqt(jobs, bad, opts, snaps, cus)
     ctx.close()
+
+
+def _irqt_random_cases(hp, L, bd):
+    """72 random PUs, each in its own 192 x 192 tile (CU at +64): pictures, jobs, syntax, options, restatement configs, snapshots, availability tables"""
+    from goldutil import RQT_CFG
+    rng = np.random.default_rng(70 + bd)
+    T = 192; G = 9; W = H = T * G; n = 72
+    mid = 1 << (bd - 1); top = (1 << bd) - 1
+    Y = np.full((H, W), mid, np.int16)
+    R = rng.integers(0, top + 1, (H, W)).astype(np.int16)          # whatever lies around (and, before it is coded, inside) the CUs
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(n, hp.INTRA_RQT_OPT_DTYPE); cfgs = np.zeros(n, RQT_CFG)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8); avs = []
+    L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    for i in range(n):
+        lg = 3 + (i % 4); cu = 1 << lg
+        nxn = int(lg == 3 and rng.random() < 0.6)
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        # a smooth random field over the CU and its neighbourhood (references further away predict worse: splitting pays), the picture around the CU = the field plus
+        # coding noise; on half of the PUs isolated spikes on top (transform-skip territory)
+        amp = float(rng.choice([20, 50, 90])) * (1 << (bd - 8)); Wn = 2 * cu + 1
+        f = gaussian_filter(rng.normal(0, 1, (Wn + 16, Wn + 16)), float(rng.choice([1.5, 3, 6])))[8:-8, 8:-8]
+        f = mid + amp * f / max(1e-9, float(np.abs(f).max()))
+        if rng.random() < 0.5:
+            m = rng.random(f.shape) < 0.05; f[m] += rng.choice([-1, 1], int(m.sum())) * 2.5 * amp
+        f = np.clip(np.rint(f), 0, top).astype(np.int16)
+        Y[y0:y0 + cu, x0:x0 + cu] = f[1:1 + cu, 1:1 + cu]
+        R[y0 - 1:y0 + 2 * cu, x0 - 1:x0 + 2 * cu] = np.clip(f + rng.integers(-2, 3, f.shape), 0, top)
+        qp = int(rng.integers(20, 43)) + 6 * (bd - 8); lam = 0.57 * 2.0 ** ((qp - 6 * (bd - 8) - 12) / 3.0)
+        c = cfgs[i]
+        c["log2_cu"], c["qp"], c["bit_depth_y"], c["bit_depth_c"] = lg, (qp, qp, qp), bd, bd
+        c["sign_hide"], c["use_ts"], c["log2_max_tu"] = int(rng.integers(0, 2)), int(rng.random() < 0.7), 5
+        c["log2_min_tu_in_cu"] = max(2, min(lg - nxn, 5) - int(rng.integers(0, 3)))
+        c["lambda_rd"], c["lambda_rdoq"], c["dist_weight"] = lam, (lam, lam, lam), (1.0, 1.0, 1.0)
+        j = jobs[i]
+        j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x0, y0, lg, c["qp"], i
+        j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = c["sign_hide"], c["use_ts"], 5, c["log2_min_tu_in_cu"]
+        j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = lam, c["lambda_rdoq"], (1.0, 1.0)
+        s = syn[i]
+        s["part_nxn"], s["skip_flag"], s["skip_ctx"], s["is_min_cu"] = nxn, 0, int(rng.integers(0, 3)), int(lg == 3)
+        s["luma_dir"] = rng.integers(0, 35, 4)
+        for p in range(4):
+            s["preds"][p] = rng.choice(35, 3, replace=False); s["pred_num"][p] = 3
+            if rng.random() < 0.4: s["luma_dir"][p] = s["preds"][p][int(rng.integers(0, 3))]
+        s["chroma_is_dm"], s["chroma_dir"] = 1, 36
+        s["tr_depth"], s["part"], s["b_luma"] = nxn, (int(rng.integers(0, 4)) * ((cu // 4) ** 2 // 4) if nxn else 0), 1
+        opts[i]["check_first"], opts[i]["ts_fast"], opts[i]["strong"] = int(rng.random() < 0.4), int(rng.random() < 0.3), int(rng.integers(0, 2))
+        av = (rng.random((341, 36)) < (0.85 if rng.random() < 0.8 else 0.3)).astype(np.uint8); avs.append(av)
+        opts[i]["avail"] = (av.astype(np.uint64) << np.arange(36, dtype=np.uint64)[None, :]).sum(axis=1)
+        assert L.hop_cabac_init(snaps[i].ctypes.data, int(rng.integers(0, 5)), int(rng.integers(20, 45))) == 0
+        assert L.hop_cabac_cu_init(cus[i].ctypes.data, int(rng.integers(0, 5)), int(rng.integers(20, 45))) == 0
+        left = int(rng.integers(0, 32768)); snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+    return W, H, Y, R, jobs, syn, opts, cfgs, snaps, cus, avs
+
+
+def test_intra_rqt_random_vs_oracle(hp):
+    """hop_intra_rqt against the restatement (pinned inside the reference encoder) where the recorded calls do not go: 8 and 10 bit, QP 20..42, sign hiding / transform
+    skip / TransformSkipFast / strong smoothing on and off, every CU size, 2Nx2N and the four PUs of NxN, bCheckFirst on and off, deeper trees than the encoder's
+    configuration allows, random neighbour availability per node, smooth and sharp content, context states of all slice types with a carried fraction.  72 PUs per bit
+    depth in one call (several classes), each in its own tile."""
+    import ctypes
+    from goldutil import oracle_intra_rqt, RQT_CFG, INTRA_SYN
+    for bd in (8, 10):
+        W, H, Y, R, jobs, syn, opts, cfgs, snaps, cus, avs = _irqt_random_cases(hp, hp.load(), bd)
+        n = len(jobs); mid = 1 << (bd - 1)
+        ctx = hp.Context(W, H, bd)
+        ctx.upload_orig(Y, np.full((H // 2, W // 2), mid, np.int16), np.full((H // 2, W // 2), mid, np.int16))
+        ctx.plane_upload("recon", 0, R)
+        res, coef, cx, cu_out = ctx.intra_rqt(jobs, syn, opts, snaps, cus)
+        R2 = ctx.recon_download(0)
+        o = 0; deep = ts = single_over_split = 0
+        for i in range(n):
+            c = cfgs[i]; cu = 1 << int(c["log2_cu"]); Wn = 2 * cu + 1; parts = (cu // 4) ** 2
+            x0, y0 = int(jobs[i]["x"]), int(jobs[i]["y"]); d0, p0 = int(syn[i]["tr_depth"]), int(syn[i]["part"]); np_ = parts >> (2 * d0)
+            osyn = np.zeros(1, INTRA_SYN)
+            for k in INTRA_SYN.names: osyn[0][k] = syn[i][k]
+            coder = snaps[i, :150].tobytes() + b"\0\0" + (int(snaps[i, 150]) | (int(snaps[i, 151]) << 8)).to_bytes(8, "little")
+            nd = [d0, p0, int(opts[i]["check_first"]), int(opts[i]["ts_fast"]), int(opts[i]["strong"])]
+            cost, dist, arr, ocoder, ocu, win, fin = oracle_intra_rqt(c, osyn[0], nd, avs[i], Y[y0:y0 + cu, x0:x0 + cu], R[y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn], np.zeros(1792, np.uint8),
+                                                                      np.frombuffer(coder, np.uint8), cus[i])
+            tag = (bd, i, cu, nd, int(c["log2_min_tu_in_cu"]))
+            assert float(res[i]["cost"]) == cost and int(res[i]["dist"]) == dist, (tag, float(res[i]["cost"]), cost, int(res[i]["dist"]), dist)
+            assert np.array_equal(res[i]["tr_idx"][p0:p0 + np_], arr[0, p0:p0 + np_]) and np.array_equal(res[i]["cbf"][0][p0:p0 + np_], arr[1, p0:p0 + np_]), tag
+            assert np.array_equal(res[i]["tskip"][0][p0:p0 + np_], arr[4, p0:p0 + np_]), tag
+            assert np.array_equal(coef[o + 16 * p0:o + 16 * (p0 + np_)], fin[16 * p0:16 * (p0 + np_)]), tag
+            assert np.array_equal(cx[i, :150], ocoder[:150]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int.from_bytes(ocoder[152:160].tobytes(), "little") & 32767), tag
+            assert np.array_equal(cu_out[i], ocu), tag
+            R[y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn] = win.reshape(Wn, Wn)
+            deep += int(arr[0, p0:p0 + np_].max() >= d0 + 2); ts += int(arr[4, p0:p0 + np_].any())
+            lg = int(c["log2_cu"]); single_over_split += int(arr[0, p0] == d0 and lg - d0 > int(c["log2_min_tu_in_cu"]) and not nd[2] and lg - d0 <= 5)
+            o += cu * cu * 3 // 2
+        assert np.array_equal(R, R2), bd
+        assert deep >= 4 and ts >= 3 and single_over_split >= 4, (bd, deep, ts, single_over_split)
+        ctx.close()

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""tools/irqt_prof.py -- throughput of hop_intra_rqt_device (rest of row a8: the luma transform tree of an intra PU) per CU size (developer tool, GPU box).
+One call = every third CU of a 7680x5376 frame in both directions (the PUs of a call must not lie in each other's neighbourhood); 2Nx2N PUs, the final pass
+(bCheckFirst off) and the candidate pass (bCheckFirst on).  Jobs, options, snapshots, results and levels stay in HBM."""
+import ctypes, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import torch
+from scipy.ndimage import gaussian_filter
+from bench import _hophip
+hp = _hophip()
+W, H = 7680, 5376
+rng = np.random.default_rng(5)
+f = gaussian_filter(rng.normal(0, 1, (H // 4, W // 4)).astype(np.float32), 2.0)
+f = np.kron(f / np.abs(f).max(), np.ones((4, 4), np.float32))
+Y = np.clip(128 + 90 * gaussian_filter(f, 1.5) + rng.normal(0, 2, (H, W)), 0, 255).astype(np.int16)
+ctx = hp.Context(W, H)
+ctx.upload_orig(Y, np.full((H // 2, W // 2), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16))
+snap = np.zeros((1, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((1, hp.CABAC_CU_CTX_BYTES), np.uint8)
+ctx.L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; ctx.L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+ctx.L.hop_cabac_init(snap.ctypes.data, 3, 32); ctx.L.hop_cabac_cu_init(cus.ctypes.data, 3, 32)
+LAM = 0.57 * 2.0 ** ((32 - 12) / 3.0)
+dev = torch.device("cuda", 0)
+ctx.L.hop_intra_rqt_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
+print("CU   bCheckFirst    PUs  device s   kPU/s  Msamples/s   mean depth  cbf")
+for lg in (3, 4, 5, 6):
+    S = 1 << lg
+    xs, ys = np.meshgrid(np.arange(S, W - 2 * S, 3 * S), np.arange(S, H - 2 * S, 3 * S))
+    n = xs.size
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(n, hp.INTRA_RQT_OPT_DTYPE)
+    jobs["x"], jobs["y"], jobs["log2_cu"], jobs["ctx_index"] = xs.ravel(), ys.ravel(), lg, 0
+    jobs["qp_scaled"] = (32, 31, 31); jobs["sign_hide"] = 1; jobs["use_ts"] = 1; jobs["log2_max_tu"] = 5
+    jobs["log2_min_tu_in_cu"] = {3: 2, 4: 2, 5: 3, 6: 4}[lg]
+    jobs["lambda_rd"] = LAM; jobs["lambda_rdoq"] = (LAM, LAM, LAM); jobs["dist_weight"] = (1.0, 1.0)
+    syn["is_min_cu"] = int(lg == 3); syn["luma_dir"] = rng.integers(0, 35, (n, 4)); syn["preds"] = (0, 1, 26); syn["pred_num"] = 3; syn["chroma_is_dm"] = 1; syn["b_luma"] = 1
+    opts["strong"] = 1; opts["avail"] = (1 << 33) - 1
+    dj = torch.from_numpy(jobs.view(np.uint8)).to(dev); dy = torch.from_numpy(syn.view(np.uint8)).to(dev); do = torch.from_numpy(opts.view(np.uint8)).to(dev)
+    ds = torch.from_numpy(snap).to(dev); du = torch.from_numpy(cus).to(dev)
+    dr = torch.zeros(n * hp.RQT_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev); dc = torch.zeros(n * S * S * 3 // 2, dtype=torch.int32, device=dev)
+    for cf in (0, 1):
+        for it in range(3):
+            ctx.plane_upload("recon", 0, Y)                            # neighbours: the content itself
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ctx._chk(ctx.L.hop_intra_rqt_device(ctx.h, n, dj.data_ptr(), jobs[:1].ctypes.data, 0, cf, dy.data_ptr(), do.data_ptr(), ds.data_ptr(), du.data_ptr(), dr.data_ptr(),
+                                                dc.data_ptr(), None, None), "intra_rqt_device")
+            ctx.sync(); dt = time.perf_counter() - t0
+        res = np.frombuffer(dr.cpu().numpy().tobytes(), hp.RQT_RESULT_DTYPE)
+        print("%2dx%-2d %6d %10d %8.4f %8.1f %10.1f %10.2f  %3.0f%%" % (S, S, cf, n, dt, n / dt / 1e3, n * S * S / dt / 1e6,
+              float(np.mean([r["tr_idx"][:S * S // 16].mean() for r in res[:2000]])), 100.0 * float(np.mean(res["cbf"][:, 0, 0] != 0))))
+ctx.close()

@@ -647,33 +647,22 @@ UInt TEncSearch::xGetIntraBitsQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPar
   return bits;
 }
 
-// ---- the luma transform tree of an intra PU: TEncSearch::xRecurIntraCodingQT, bLumaOnly (TLibEncoder/TEncSearch.cpp:1361-1710) -> hop_o_intra_rqt ----
-// The call from estIntraPredQT (:2524 per candidate mode with bCheckFirst, :2587 for the best one without) hands over the PU; the restatement
-// walks the tree and leaves what the reference leaves: transform depth / cbf / transform-skip arrays, the level and reconstruction layers
-// xSetIntraResultQT reads, the reconstruction picture, the coder state.  Neighbour availability of every node comes from the reference's
-// own TComPattern helpers (it depends on positions only).
-namespace { unsigned long g_calls11[1] = { 0 };
-struct Report11 { ~Report11() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: intraRqt %lu\n", g_calls11[0]); } } g_report11; }
-
-Void TEncSearch::xRecurIntraCodingQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPartIdx, Bool bLumaOnly, TComYuv* pcOrgYuv, TComYuv* pcPredYuv, TComYuv* pcResiYuv,
-                                     UInt& ruiDistY, UInt& ruiDistC, Bool bCheckFirst, Double& dRDCost)
+// what both intra shims hand to the restatement: quantiser / lambda / tree limits, the CU's syntax elements, the neighbour flags of every node from (uiTrDepth, uiAbsPartIdx) downwards
+// (TComPattern::initAdiPattern, TComPattern.cpp:199-211: position-only)
+namespace {
+void intra_env(TEncSearch* self, TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPartIdx, hop_o_rqt_cfg& cfg_out, hop_o_intra_syntax& y_out, std::vector<uint8_t>& avail_out)
 {
   TComSlice* sl = pcCU->getSlice();
-  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() ||
-      sl->getSPS()->getUsePCM()) {
-    fprintf(stderr, "hop shim: xRecurIntraCodingQT is replaced for luma-only trees, RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
-  }
-  g_calls11[0]++;
   const UInt depth = pcCU->getDepth(0);
   hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
   cfg.log2_cu = g_aucConvertToBit[sl->getSPS()->getMaxCUWidth() >> depth] + 2;
-  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_LUMA, sl->getSPS()->getQpBDOffsetY(), 0); cfg.qp[0] = m_pcTrQuant->m_cQP.m_iQP;
+  self->m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_LUMA, sl->getSPS()->getQpBDOffsetY(), 0); cfg.qp[0] = self->m_pcTrQuant->m_cQP.m_iQP;
   cfg.bit_depth_y = g_bitDepthY; cfg.bit_depth_c = g_bitDepthC;
   cfg.sign_hide = sl->getPPS()->getSignHideFlag() ? 1 : 0; cfg.use_ts = sl->getPPS()->getUseTransformSkip() ? 1 : 0;
   cfg.log2_max_tu = sl->getSPS()->getQuadtreeTULog2MaxSize(); cfg.log2_min_tu_in_cu = pcCU->getQuadtreeTULog2MinSizeInCU(uiAbsPartIdx);
-  cfg.lambda_rd = m_pcRdCost->m_dLambda;
-  for (int c = 0; c < 3; c++) cfg.lambda_rdoq[c] = m_pcTrQuant->m_lambdas[c];
-  cfg.dist_weight[0] = 1.0; cfg.dist_weight[1] = m_pcRdCost->m_cbDistortionWeight; cfg.dist_weight[2] = m_pcRdCost->m_crDistortionWeight;
+  cfg.lambda_rd = self->m_pcRdCost->m_dLambda;
+  for (int c = 0; c < 3; c++) cfg.lambda_rdoq[c] = self->m_pcTrQuant->m_lambdas[c];
+  cfg.dist_weight[0] = 1.0; cfg.dist_weight[1] = self->m_pcRdCost->m_cbDistortionWeight; cfg.dist_weight[2] = self->m_pcRdCost->m_crDistortionWeight;
   const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
   hop_o_intra_syntax y; memset(&y, 0, sizeof(y));
   y.part_nxn = pcCU->getPartitionSize(0) == SIZE_NxN ? 1 : 0;
@@ -701,6 +690,35 @@ Void TEncSearch::xRecurIntraCodingQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAb
       for (int i = 0; i < 4 * units + 1; i++) a[i] = fl[i] ? 1 : 0;
     }
   }
+  cfg_out = cfg; y_out = y; avail_out.swap(avail);
+}
+}
+
+// ---- the luma transform tree of an intra PU: TEncSearch::xRecurIntraCodingQT, bLumaOnly (TLibEncoder/TEncSearch.cpp:1361-1710) -> hop_o_intra_rqt ----
+// The call from estIntraPredQT (:2524 per candidate mode with bCheckFirst, :2587 for the best one without) hands over the PU; the restatement
+// walks the tree and leaves what the reference leaves: transform depth / cbf / transform-skip arrays, the level and reconstruction layers
+// xSetIntraResultQT reads, the reconstruction picture, the coder state.  Neighbour availability of every node comes from the reference's
+// own TComPattern helpers (it depends on positions only).
+extern "C" void hop_ref_orig_recur_intra(TEncSearch*, TComDataCU*, UInt, UInt, Bool, TComYuv*, TComYuv*, TComYuv*, UInt&, UInt&, Bool, Double&);   // the reference's own definitions (Makefile.ref)
+extern "C" void hop_ref_orig_est_intra(TEncSearch*, TComDataCU*, TComYuv*, TComYuv*, TComYuv*, TComYuv*, UInt&, Bool);
+namespace { bool hand_back(const char* name) { const char* e = getenv("HOP_SHIM_ORIG"); return e && strstr(e, name); } }
+namespace { unsigned long g_calls11[1] = { 0 };
+struct Report11 { ~Report11() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: intraRqt %lu\n", g_calls11[0]); } } g_report11; }
+
+Void TEncSearch::xRecurIntraCodingQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPartIdx, Bool bLumaOnly, TComYuv* pcOrgYuv, TComYuv* pcPredYuv, TComYuv* pcResiYuv,
+                                     UInt& ruiDistY, UInt& ruiDistC, Bool bCheckFirst, Double& dRDCost)
+{
+  static const bool orig = hand_back("xRecurIntraCodingQT");
+  if (orig) { hop_ref_orig_recur_intra(this, pcCU, uiTrDepth, uiAbsPartIdx, bLumaOnly, pcOrgYuv, pcPredYuv, pcResiYuv, ruiDistY, ruiDistC, bCheckFirst, dRDCost); return; }
+  TComSlice* sl = pcCU->getSlice();
+  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() ||
+      sl->getSPS()->getUsePCM()) {
+    fprintf(stderr, "hop shim: xRecurIntraCodingQT is replaced for luma-only trees, RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+  }
+  g_calls11[0]++;
+  hop_o_rqt_cfg cfg; hop_o_intra_syntax y; std::vector<uint8_t> avail;
+  intra_env(this, pcCU, uiTrDepth, uiAbsPartIdx, cfg, y, avail);
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
   hop_o_rqt_state st; memset(&st, 0, sizeof(st));
   std::vector<int16_t> planes[4];
   for (int l = 0; l < 4; l++) {
@@ -756,6 +774,108 @@ Void TEncSearch::xRecurIntraCodingQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAb
   }
   coder_put(sb, &coder);
   { CuSets2 r = cu_sets2(sb); const uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
+}
+
+// ---- the luma intra search of a CU: TEncSearch::estIntraPredQT, bLumaOnly (TLibEncoder/TEncSearch.cpp:2386-2710) -> hop_o_intra_luma_search ----
+// xCheckRDCostIntra hands over the CU; the restatement derives the most probable modes, runs the rough search, the candidate and the final transform trees per PU
+// and leaves what the reference leaves: luma directions, transform depth / cbf / transform-skip arrays, the luma levels in the CU's coefficient buffer, the
+// reconstruction in pcRecoYuv and (all but the last PU: the decided block; the last PU: whatever the final pass wrote) in the picture, the total distortion.
+namespace { unsigned long g_calls12[1] = { 0 };
+struct Report12 { ~Report12() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: intraSearch %lu\n", g_calls12[0]); } } g_report12; }
+
+Void TEncSearch::estIntraPredQT(TComDataCU* pcCU, TComYuv* pcOrgYuv, TComYuv* pcPredYuv, TComYuv* pcResiYuv, TComYuv* pcRecoYuv, UInt& ruiDistC, Bool bLumaOnly)
+{
+  static const bool orig = hand_back("estIntraPredQT");
+  if (orig) { hop_ref_orig_est_intra(this, pcCU, pcOrgYuv, pcPredYuv, pcResiYuv, pcRecoYuv, ruiDistC, bLumaOnly); return; }
+  TComSlice* sl = pcCU->getSlice();
+  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() ||
+      sl->getSPS()->getUsePCM()) {
+    fprintf(stderr, "hop shim: estIntraPredQT is replaced for luma-only searches, RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+  }
+  g_calls12[0]++;
+  const UInt uiDepth = pcCU->getDepth(0);
+  const UInt d0 = pcCU->getPartitionSize(0) == SIZE_2Nx2N ? 0 : 1, npu = pcCU->getNumPartitions(), q = pcCU->getTotalNumPart() >> 2;
+  pcCU->setQPSubParts(sl->getPPS()->getUseDQP() ? pcCU->getQP(0) : sl->getSliceQp(), 0, uiDepth);
+  hop_o_rqt_cfg cfg; hop_o_intra_syntax y; std::vector<uint8_t> avail((size_t)341 * HOP_O_AVAIL_PITCH, 0);
+  for (UInt pu = 0; pu < npu; pu++) {
+    std::vector<uint8_t> a1; intra_env(this, pcCU, d0, pu * q, cfg, y, a1);
+    for (size_t i = 0; i < avail.size(); i++) avail[i] |= a1[i];
+  }
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4), N = cu >> d0;
+  hop_o_intra_search_in sin; memset(&sin, 0, sizeof(sin));
+  std::vector<uint8_t> rough(4 * 68, 0);
+  for (UInt pu = 0; pu < npu; pu++) {
+    const UInt part = pu * q; UInt tp;
+    TComDataCU* l = pcCU->getPULeft(tp, pcCU->getZorderIdxInCU() + part);
+    sin.left_dir[pu] = l ? (l->isIntra(tp) ? l->getLumaIntraDir(tp) : DC_IDX) : DC_IDX;
+    TComDataCU* a = pcCU->getPUAbove(tp, pcCU->getZorderIdxInCU() + part, true, true);
+    sin.above_dir[pu] = a ? (a->isIntra(tp) ? a->getLumaIntraDir(tp) : DC_IDX) : DC_IDX;
+    UInt lt, rt, lb; Bool fl[4 * MAX_NUM_SPU_W + 1]; memset(fl, 0, sizeof(fl));
+    const int units = N / 4;
+    pcCU->deriveLeftRightTopIdxAdi(lt, rt, part, d0); pcCU->deriveLeftBottomIdxAdi(lb, part, d0);
+    TComPattern* pt = pcCU->getPattern();
+    fl[units * 2] = pt->isAboveLeftAvailable(pcCU, lt);
+    pt->isAboveAvailable(pcCU, lt, rt, fl + units * 2 + 1); pt->isAboveRightAvailable(pcCU, lt, rt, fl + units * 3 + 1);
+    pt->isLeftAvailable(pcCU, lt, lb, fl + units * 2 - 1); pt->isBelowLeftAvailable(pcCU, lt, lb, fl + units - 1);
+    for (int i = 0; i < 4 * units + 1; i++) rough[68 * pu + i] = fl[i] ? 1 : 0;
+  }
+  sin.rough_flags = &rough[0]; sin.sqrt_lambda = m_pcRdCost->getSqrtLambda(); sin.num_full_rd = g_aucIntraModeNumFast[pcCU->getIntraSizeIdx(0)];
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  std::vector<int16_t> planes[4];
+  for (int l = 0; l < 4; l++) {
+    st.coef[l][0] = m_ppcQTTempCoeffY[l]; st.coef[l][1] = m_ppcQTTempCoeffCb[l]; st.coef[l][2] = m_ppcQTTempCoeffCr[l];
+    planes[l].assign(cu * cu, 0); st.resi[l][0] = &planes[l][0];
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int r = 0; r < cu; r++) memcpy(st.resi[l][0] + r * cu, t.getLumaAddr() + r * t.getStride(), cu * sizeof(Pel));
+  }
+  memcpy(st.tr_idx, pcCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], pcCU->m_puhCbf[c], parts); memcpy(st.tskip[c], pcCU->m_puhTransformSkip[c], parts); }
+  TComPicYuv* recPic = pcCU->getPic()->getPicYuvRec();
+  hop_o_intra_rqt_in in; memset(&in, 0, sizeof(in));
+  in.org = pcOrgYuv->getLumaAddr(); in.org_stride = pcOrgYuv->getStride();
+  in.rec = recPic->getLumaAddr(pcCU->getAddr(), pcCU->getZorderIdxInCU()); in.rec_stride = recPic->getStride();
+  in.avail = &avail[0]; in.strong = sl->getSPS()->getUseStrongIntraSmoothing() ? 1 : 0; in.ts_fast = m_pcEncCfg->getUseTransformSkipFast() ? 1 : 0;
+  TEncSbac* best = m_pppcRDSbacCoder[uiDepth][CI_CURR_BEST];
+  hop_o_coder coder; coder_get(best, &coder);
+  uint8_t cuctx[20] = { 0 }; { CuSets2 r = cu_sets2(best); uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  static FILE* f = NULL; static bool tried = false;                 // HOP_SHIM_TRACE_ISEARCH=<file>
+  if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_ISEARCH"); if (pth && *pth) f = fopen(pth, "wb"); }
+  const int W = 2 * cu + 1;
+  const int px = (int)pcCU->getCUPelX(), py = (int)pcCU->getCUPelY(), pw = recPic->getWidth(), ph = recPic->getHeight();
+  if (f) {
+    const int32_t nd[4] = { in.ts_fast, in.strong, sin.num_full_rd, 0 };
+    fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&y, sizeof(y), 1, f); fwrite(nd, 4, 4, f); fwrite(sin.left_dir, 4, 4, f); fwrite(sin.above_dir, 4, 4, f); fwrite(&sin.sqrt_lambda, 8, 1, f);
+    fwrite(&rough[0], 1, rough.size(), f); fwrite(&avail[0], 1, avail.size(), f);
+    for (int r = 0; r < cu; r++) fwrite(in.org + r * in.org_stride, 2, cu, f);
+    std::vector<int16_t> win((size_t)W * W, 0);
+    for (int r = 0; r < W; r++) for (int c = 0; c < W; c++) {
+      const int X = px - 1 + c, Y = py - 1 + r;
+      if (X >= 0 && Y >= 0 && X < pw && Y < ph) win[(size_t)r * W + c] = in.rec[(ptrdiff_t)(r - 1) * in.rec_stride + (c - 1)];
+    }
+    fwrite(&win[0], 2, win.size(), f);
+    fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 20, f);
+  }
+  int bestDir[4] = { 0, 0, 0, 0 }, ncand[4] = { 0, 0, 0, 0 }; uint32_t distY = 0;
+  std::vector<int16_t> reco((size_t)cu * cu, 0);
+  hop_o_intra_luma_search(&cfg, &y, &in, &sin, &coder, cuctx, &st, bestDir, pcCU->getCoeffY(), &reco[0], &distY, ncand);
+  if (f) {
+    fwrite(bestDir, 4, 4, f); fwrite(ncand, 4, 4, f); fwrite(&distY, 4, 1, f);
+    fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+    fwrite(pcCU->getCoeffY(), 4, cu * cu, f); fwrite(&reco[0], 2, cu * cu, f);
+    for (int r = 0; r < cu; r++) fwrite(in.rec + (ptrdiff_t)r * in.rec_stride, 2, cu, f);
+  }
+  for (int l = 0; l < 4; l++) {
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int r = 0; r < cu; r++) memcpy(t.getLumaAddr() + r * t.getStride(), st.resi[l][0] + r * cu, cu * sizeof(Pel));
+  }
+  for (int r = 0; r < cu; r++) memcpy(pcRecoYuv->getLumaAddr() + r * pcRecoYuv->getStride(), &reco[(size_t)r * cu], cu * sizeof(Pel));
+  memcpy(pcCU->m_puhTrIdx, st.tr_idx, parts); memcpy(pcCU->m_puhTransformSkip[0], st.tskip[0], parts);
+  for (int p = 0; p < parts; p++) pcCU->m_puhCbf[0][p] = (UChar)(npu > 1 ? (st.cbf[0][p] & ~1) : st.cbf[0][p]);   // as the PU loop leaves them (:2662-2663) ...
+  for (UInt pu = 0; pu < npu; pu++) { pcCU->setLumaIntraDirSubParts(bestDir[pu], pu * q, uiDepth + d0); pcCU->copyToPic(uiDepth, pu, d0); }
+  memcpy(pcCU->m_puhCbf[0], st.cbf[0], parts);                                                                     // ... then the combined cbf of an NxN CU (:2667-2685)
+  m_pcRDGoOnSbacCoder->load(best);
+  ruiDistC = 0;
+  pcCU->getTotalDistortion() = distY;
 }
 
 // ---- chroma intra prediction: TComPrediction::predIntraChromaAng (TLibCommon/TComPrediction.cpp:375-390) -> hop_o_intra_pred_chroma ----

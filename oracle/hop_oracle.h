@@ -140,6 +140,20 @@ typedef struct {
 int hop_o_intra_node_index(int tr_depth, int log2_size, int part);
 void hop_o_intra_rqt(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, const hop_o_intra_rqt_in* in, int tr_depth, int part,
                      hop_o_coder* coder, uint8_t cu_ctx[20], hop_o_rqt_state* st, double* cost, uint32_t* dist);
+/* row a8: the luma intra search of one CU (estIntraPredQT, luma only): rough search, candidate list, the candidates through hop_o_intra_rqt, the final pass.
+ * coder_in / cu_ctx_in: the CI_CURR_BEST state (every tree starts from it; the coder is unchanged afterwards).  syn: partition, skip flag / context, is_min_cu
+ * (directions and predictors are derived here).  coef_y: the CU's luma levels (getCoeffY layout), reco_y: the CU's luma reconstruction (pitch = CU size),
+ * st arrays: tr_idx / cbf[0] / tskip[0] of the CU afterwards; best_dir[pu]; n_cand_out[pu] (may be NULL): candidates tested. */
+typedef struct {
+  int left_dir[4], above_dir[4];  /* per PU: the luma direction getIntraDirLumaPredictor sees left / above when that neighbour lies outside the CU (DC = 1 when it is
+                                     unavailable, not intra, or above the CTU row); ignored where the neighbour is a PU of this CU */
+  const uint8_t* rough_flags;     /* [PU][68]: neighbour flags of the PU's block (the rough search; 64x64 needs 65) */
+  double sqrt_lambda;             /* TComRdCost::getSqrtLambda */
+  int num_full_rd;                /* g_aucIntraModeNumFast of the PU size: 8 for 4x4 and 8x8, 3 above */
+} hop_o_intra_search_in;
+void hop_o_intra_luma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, const hop_o_intra_rqt_in* in, const hop_o_intra_search_in* sin,
+                             const hop_o_coder* coder_in, const uint8_t cu_ctx_in[20], hop_o_rqt_state* st, int best_dir[4], int32_t* coef_y, int16_t* reco_y,
+                             uint32_t* dist_y, int* n_cand_out);
 int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
                           const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

@@ -652,3 +652,81 @@ void hop_o_intra_rqt(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, co
   Irq r = { cfg, syn, in, st, coder, cu_ctx };
   intra_node(&r, tr_depth, part, cost, dist);
 }
+
+/* ---- row a8: the luma intra search of one CU, TEncSearch::estIntraPredQT with bLumaOnly (TLibEncoder/TEncSearch.cpp:2386-2710) ----
+ * Per PU (1 or 4, in order): the most probable modes (TComDataCU::getIntraDirLumaPredictor, TComDataCU.cpp:1772-1830, from the directions
+ * left and above: a PU of this CU once it is decided, the caller's value otherwise), the 35-mode rough search and candidate list
+ * (:2430-2493), every candidate through the transform tree with bCheckFirst from the CI_CURR_BEST state (:2507-2553), the best one
+ * again with the full tree (:2555-2590), the better of the two kept the way xSetIntraResultQT does (levels into the CU layout,
+ * reconstruction into the CU's plane, arrays aside); the decided PU's reconstruction goes into the picture unless it is the last
+ * (:2603-2660), the cbf of an NxN CU is combined at depth 0 (:2667-2685).  The picture block of the last PU is left as the final
+ * pass wrote it, as in the reference. */
+static void luma_mpm(int left, int above, int preds[3], int* mode)
+{
+  if (left == above) {
+    *mode = 1;
+    if (left > 1) { preds[0] = left; preds[1] = ((left + 29) % 32) + 2; preds[2] = ((left - 1) % 32) + 2; }
+    else { preds[0] = 0; preds[1] = 1; preds[2] = 26; }
+  } else {
+    *mode = 2;
+    preds[0] = left; preds[1] = above;
+    preds[2] = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1);
+  }
+}
+
+void hop_o_intra_luma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn_in, const hop_o_intra_rqt_in* in, const hop_o_intra_search_in* sin,
+                             const hop_o_coder* coder_in, const uint8_t cu_ctx_in[20], hop_o_rqt_state* st, int best_dir[4], int32_t* coef_y, int16_t* reco_y,
+                             uint32_t* dist_y, int* n_cand_out)
+{
+  const int cu = 1 << cfg->log2_cu, parts = 1 << (2 * (cfg->log2_cu - 2)), nxn = syn_in->part_nxn ? 1 : 0, npu = nxn ? 4 : 1, d0 = nxn;
+  const int q = parts >> (2 * d0), N = cu >> d0;
+  hop_o_intra_syntax syn = *syn_in;
+  uint32_t overall = 0;
+  uint8_t keep_tr[256], keep_cbf[256], keep_ts[256];
+  for (int pu = 0; pu < npu; pu++) {
+    const int part = pu * q, x = zx(part), y = zy(part);
+    /* most probable modes */
+    const int left = (nxn && (pu & 1)) ? best_dir[pu - 1] : sin->left_dir[pu], above = (nxn && (pu & 2)) ? best_dir[pu - 2] : sin->above_dir[pu];
+    int preds[3], mpm_mode;
+    luma_mpm(left, above, preds, &mpm_mode);
+    for (int k = 0; k < 3; k++) syn.preds[pu][k] = preds[k];
+    syn.pred_num[pu] = 3;
+    /* rough search, candidate list */
+    uint32_t satd[35], modes[16]; double costs[16];
+    hop_o_intra_rough(in->rec, in->rec_stride, in->org, in->org_stride, x, y, N, sin->rough_flags + 68 * pu, cfg->bit_depth_y, in->strong, satd);
+    int n = hop_o_intra_cand_list(satd, cu_ctx_in[16], (uint32_t)(coder_in->frac & 32767), sin->sqrt_lambda, preds, 3, mpm_mode, sin->num_full_rd, modes, costs);
+    if (n_cand_out) n_cand_out[pu] = n;
+    /* candidates with bCheckFirst, then the best one with the full tree */
+    double bestCost = 1.7e+308; uint32_t bestDist = 0; int bestMode = 0;
+    hop_o_intra_rqt_in rin = *in;
+    for (int pass = 0; pass <= n; pass++) {
+      const int mode = pass < n ? (int)modes[pass] : bestMode;
+      syn.luma_dir[pu] = mode;
+      rin.check_first = pass < n ? 1 : 0;
+      hop_o_coder coder = *coder_in; uint8_t cuc[20]; memcpy(cuc, cu_ctx_in, 20);
+      double cost = 0.0; uint32_t dist = 0;
+      hop_o_intra_rqt(cfg, &syn, &rin, d0, part, &coder, cuc, st, &cost, &dist);
+      if (cost < bestCost) {
+        bestMode = mode; bestDist = dist; bestCost = cost;
+        for (int p = part; p < part + q; p++) {                          /* xSetIntraResultQT */
+          const int layer = cfg->log2_max_tu - (cfg->log2_cu - st->tr_idx[p]);
+          memcpy(coef_y + 16 * p, st->coef[layer][0] + 16 * p, 16 * sizeof(int32_t));
+          for (int j = 0; j < 4; j++) memcpy(reco_y + (size_t)(zy(p) + j) * cu + zx(p), st->resi[layer][0] + (size_t)(zy(p) + j) * cu + zx(p), 4 * sizeof(int16_t));
+        }
+        memcpy(keep_tr + part, st->tr_idx + part, (size_t)q); memcpy(keep_cbf + part, st->cbf[0] + part, (size_t)q); memcpy(keep_ts + part, st->tskip[0] + part, (size_t)q);
+      }
+    }
+    overall += bestDist;
+    memcpy(st->tr_idx + part, keep_tr + part, (size_t)q); memcpy(st->cbf[0] + part, keep_cbf + part, (size_t)q); memcpy(st->tskip[0] + part, keep_ts + part, (size_t)q);
+    if (pu != npu - 1)
+      for (int j = 0; j < N; j++) memcpy(in->rec + (ptrdiff_t)(y + j) * in->rec_stride + x, reco_y + (size_t)(y + j) * cu + x, sizeof(int16_t) * (size_t)N);
+    best_dir[pu] = bestMode;
+    syn.luma_dir[pu] = bestMode;
+  }
+  if (npu > 1) {
+    uint32_t comb = 0;
+    for (int pu = 0; pu < 4; pu++) comb |= (st->cbf[0][pu * q] >> 1) & 1;
+    for (int p = 0; p < parts; p++) st->cbf[0][p] |= (uint8_t)comb;
+  }
+  *dist_y = overall;
+}

@@ -41,12 +41,21 @@ def encode(exe, W, H, seed, td, extra_env=None, sharp=False):
     return md5("in.yuv"), md5("s.bin"), md5("rec.yuv"), r.stderr
 
 
+LOW = ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "distPart", "commit", "rqt", "cuBits", "intraBits", "chromaPred")
+# the composite restatements stand in for members that call other replaced members; HOP_SHIM_ORIG hands the named composites back to the reference's own
+# definitions, so every level of the stack is reached (and counted) by some run
+LEVELS = {"": LOW + ("intraSearch",),
+          "estIntraPredQT": LOW + ("intraRqt", "modeBits", "candList", "intraPred", "calcHAD"),
+          "estIntraPredQT,xRecurIntraCodingQT": LOW + ("modeBits", "candList", "intraPred", "calcHAD", "tskip")}
+
+
+@pytest.mark.parametrize("orig", list(LEVELS))
 @pytest.mark.parametrize("W,H,seed", [(64, 64, 1234), (128, 128, 1234)])
-def test_shim_encoder_writes_the_reference_bitstream(W, H, seed):
+def test_shim_encoder_writes_the_reference_bitstream(W, H, seed, orig):
     exe = _shim()
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_hop_qp32.json")))["%dx%d_seed%d" % (W, H, seed)]
     with tempfile.TemporaryDirectory() as td:
-        inp, bit, rec, err = encode(exe, W, H, seed, td)
+        inp, bit, rec, err = encode(exe, W, H, seed, td, extra_env={"HOP_SHIM_ORIG": orig})
     assert inp == gold["input_md5"]
     calls = {}
     for ln in err.splitlines():
@@ -54,8 +63,10 @@ def test_shim_encoder_writes_the_reference_bitstream(W, H, seed):
             t = ln.split(":")[1].split()
             calls.update({t[i]: int(t[i + 1]) for i in range(0, len(t), 2)})
     # the replaced members really ran (a silent fall-through to the reference's definitions would also give the same bytes)
-    for k in ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "intraPred", "calcHAD", "distPart", "commit", "rqt", "cuBits", "modeBits", "candList", "intraBits", "chromaPred", "intraRqt"):
-        assert calls.get(k, 0) > 50, (k, calls)   # (xTransformSkip itself is left with a few chroma calls: both kinds of tree run inside the restatement)
+    for k in LEVELS[orig]:
+        assert calls.get(k, 0) > 50, (k, calls)
+    for k in ("intraSearch", "intraRqt"):
+        if k not in LEVELS[orig]: assert calls.get(k, 0) == 0, (k, calls)
     assert bit == gold["bin_md5"] and rec == gold["rec_md5"], calls
 
 

@@ -235,3 +235,51 @@ def oracle_intra_rqt(cfg, syn, nd, avail, org, win, arr_in, coder160, cu20):
     fin = np.zeros(n2 * 3 // 2, np.int32)
     O.hop_o_rqt_final_coeffs(c.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st), fin.ctypes.data_as(ctypes.c_void_p))
     return cost.value, dist.value, arr, np.frombuffer(bytes(coder), np.uint8).copy(), cuctx, win, fin[:n2].copy()
+
+
+def encoder_isearch_calls():
+    """tests/golden/encoder_isearch_calls.npz (oracle/make_golden15.py): estIntraPredQT calls (luma intra search of a CU) of two real encodes: cfg, syntax constants, nd =
+    (TransformSkipFast, strong smoothing, candidates for the full RD), dirs = left[4] | above[4] directions outside the CU, sqrt(lambda), neighbour flags of the PUs
+    [4][68] and of every node [341][36], the CU's luma original, the reconstruction picture from (-1, -1) of the CU, the CI_CURR_BEST coder (160 B) and CU contexts;
+    after: best directions, candidates tested, distortion, arrays, the CU's luma levels, its reconstruction plane, its picture block"""
+    g = load("encoder_isearch_calls.npz")
+    o1 = o2 = 0
+    for i in range(len(g["dist"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu; W = 2 * cu + 1
+        yield dict(cfg=g["cfg"][i], syn=g["syn"][i], nd=[int(v) for v in g["nd"][i]], dirs=g["dirs"][i], sql=float(g["sql"][i]), rough=g["rough"][i], avail=g["avail"][i],
+                   org=np.ascontiguousarray(g["org"][o1:o1 + n]), win=np.ascontiguousarray(g["win"][o2:o2 + W * W]), cin=g["cin"][i], cuin=g["cuin"][i], best=g["best"][i],
+                   ncand=g["ncand"][i], dist=int(g["dist"][i]), aout=g["aout"][i], coef=np.ascontiguousarray(g["coef"][o1:o1 + n]),
+                   reco=np.ascontiguousarray(g["reco"][o1:o1 + n]), rec=np.ascontiguousarray(g["rec"][o1:o1 + n]))
+        o1 += n; o2 += W * W
+
+
+class _OSearchIn(ctypes.Structure):
+    _fields_ = [("left_dir", ctypes.c_int * 4), ("above_dir", ctypes.c_int * 4), ("rough_flags", ctypes.c_void_p), ("sqrt_lambda", ctypes.c_double), ("num_full_rd", ctypes.c_int)]
+
+
+def oracle_intra_luma_search(cfg, syn, nd, dirs, sqrt_lambda, rough, avail, org, win, coder160, cu20):
+    """hop_o_intra_luma_search on one CU.  Returns best directions, candidates tested, distortion, arrays (7 x 256), luma levels, reconstruction plane, the window after."""
+    O = oracle()
+    c = np.zeros(1, RQT_CFG); c[0] = cfg
+    y = np.zeros(1, INTRA_SYN); y[0] = syn
+    cu = 1 << int(c[0]["log2_cu"]); n2 = cu * cu; W = 2 * cu + 1
+    coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), np.ascontiguousarray(coder160).tobytes(), 160)
+    cuctx = np.ascontiguousarray(cu20, np.uint8).copy()
+    st = _OState()
+    coefs = [[np.zeros(n2 if k == 0 else n2 // 4, np.int32) for k in range(3)] for _ in range(4)]
+    recs = [np.zeros(n2, np.int16) for _ in range(4)]
+    for l in range(4):
+        for k in range(3):
+            st.coef[3 * l + k] = coefs[l][k].ctypes.data
+        st.resi[3 * l] = recs[l].ctypes.data
+    win = np.ascontiguousarray(win, np.int16).copy(); org = np.ascontiguousarray(org, np.int16); avail = np.ascontiguousarray(avail, np.uint8); rough = np.ascontiguousarray(rough, np.uint8)
+    inp = _OIntraIn(org.ctypes.data, cu, win.ctypes.data + 2 * (W + 1), W, avail.ctypes.data, nd[1], 0, nd[0])
+    sin = _OSearchIn((ctypes.c_int * 4)(*[int(v) for v in dirs[:4]]), (ctypes.c_int * 4)(*[int(v) for v in dirs[4:]]), rough.ctypes.data, sqrt_lambda, nd[2])
+    best = (ctypes.c_int * 4)(); ncand = (ctypes.c_int * 4)(); dist = ctypes.c_uint32(0)
+    coef_y = np.zeros(n2, np.int32); reco = np.zeros(n2, np.int16)
+    O.hop_o_intra_luma_search.restype = None
+    O.hop_o_intra_luma_search.argtypes = [ctypes.c_void_p] * 12
+    O.hop_o_intra_luma_search(c.ctypes.data, y.ctypes.data, ctypes.addressof(inp), ctypes.addressof(sin), ctypes.addressof(coder), cuctx.ctypes.data, ctypes.addressof(st),
+                              ctypes.addressof(best), coef_y.ctypes.data, reco.ctypes.data, ctypes.addressof(dist), ctypes.addressof(ncand))
+    arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
+    return list(best), list(ncand), dist.value, arr, coef_y, reco, win

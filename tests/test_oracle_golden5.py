@@ -149,3 +149,22 @@ def test_intra_rqt_on_encoder_calls():
         assert np.array_equal(fin[16 * p0:16 * (p0 + np_)], c["fin"][16 * p0:16 * (p0 + np_)]), n
         kinds.add((cu, int(c["syn"]["part_nxn"]), c["nd"][2], int(arr[0, p0:p0 + np_].max()), int(arr[4, p0:p0 + np_].any()))); n += 1
     assert n == 47 and len(kinds) >= 12 and any(k[4] for k in kinds) and any(k[3] >= 2 for k in kinds), kinds
+
+
+def test_intra_luma_search_on_encoder_calls():
+    """estIntraPredQT, luma only (per PU: most probable modes, 35-mode rough search, candidate list, every candidate through the transform tree with bCheckFirst, the
+    best one with the full tree, results kept the way xSetIntraResultQT keeps them): the restatement on 43 calls recorded inside the encoder - directions, number of
+    candidates, distortion, arrays, the CU's luma levels, its reconstruction plane and what the picture holds afterwards"""
+    from goldutil import encoder_isearch_calls, oracle_intra_luma_search
+    n = 0; kinds = set()
+    for c in encoder_isearch_calls():
+        cu = 1 << int(c["cfg"]["log2_cu"]); W = 2 * cu + 1; parts = (cu // 4) ** 2; npu = 4 if c["syn"]["part_nxn"] else 1
+        best, ncand, dist, arr, coef, reco, win = oracle_intra_luma_search(c["cfg"], c["syn"], c["nd"], c["dirs"], c["sql"], c["rough"], c["avail"], c["org"], c["win"],
+                                                                          c["cin"].tobytes(), c["cuin"])
+        assert best[:npu] == [int(v) for v in c["best"][:npu]] and ncand[:npu] == [int(v) for v in c["ncand"][:npu]] and dist == c["dist"], (n, best, c["best"], dist, c["dist"])
+        a = c["aout"].reshape(7, 256)
+        assert np.array_equal(arr[[0, 1, 4], :parts], a[[0, 1, 4], :parts]), n
+        assert np.array_equal(coef, c["coef"]) and np.array_equal(reco, c["reco"]), n
+        assert np.array_equal(win.reshape(W, W)[1:1 + cu, 1:1 + cu].reshape(-1), c["rec"]), n
+        kinds.add((cu, npu, ncand[0], int(arr[0, :parts].max()), int(arr[4, :parts].any()))); n += 1
+    assert n == 43 and len(kinds) >= 12 and any(k[4] for k in kinds) and any(k[1] == 4 for k in kinds), kinds

@@ -927,3 +927,138 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra rqt launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+// =====================================================================================================================
+// The luma intra search of a CU: TEncSearch::estIntraPredQT with bLumaOnly (TLibEncoder/TEncSearch.cpp:2386-2710) for a batch of CUs of one class, PU after PU:
+//   k_is_prep     most probable modes (getIntraDirLumaPredictor, TComDataCU.cpp:1772-1830: a decided PU of this CU or the caller's direction), the rough-search
+//                 and candidate-list jobs of the PU
+//   hop_launch_intra + hop_launch_intra_modes   35 SATDs, mode bits from the CI_CURR_BEST state, the candidate list (:2430-2493)
+//   per candidate (bCheckFirst) and once more for the best (:2507-2590): k_is_pick (the direction of this pass), hop_launch_intra_rqt from the CI_CURR_BEST
+//                 state, k_is_keep (a better cost: arrays, levels and the PU's picture block kept aside - xSetIntraResultQT)
+//   k_is_commit   the kept arrays back, the decided block into the picture unless it is the last PU (:2603-2660), the cbf of an NxN CU combined (:2667-2685)
+// CUs with fewer candidates than the class maximum repeat their last candidate in the spare passes (the result is ignored; the final pass follows anyway).
+// =====================================================================================================================
+struct IsWork { double best_cost; uint32_t best_dist; int32_t best_mode; uint8_t tr[256], cbf[256], ts[256]; };
+
+__global__ void k_is_prep(RqtClass k, int pu, int nxn, const hop_rqt_job* __restrict__ jobs, const hop_intra_search_job* __restrict__ sj, const hop_intra_rqt_opt* __restrict__ opt, int n,
+                          const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_intra_search_result* __restrict__ sres,
+                          hop_intra_cu_syntax* __restrict__ syn, hop_intra_job* __restrict__ rj, hop_intra_modes_job* __restrict__ mj, IsWork* __restrict__ work) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * nxn), part = pu * q, N = (1 << k.log2_cu) >> nxn;
+  const int left = (nxn && (pu & 1)) ? sres[i].best_dir[pu - 1] : sj[i].left_dir[pu], above = (nxn && (pu & 2)) ? sres[i].best_dir[pu - 2] : sj[i].above_dir[pu];
+  int p0, p1, p2, mpm;
+  if (left == above) { mpm = 1; if (left > 1) { p0 = left; p1 = ((left + 29) % 32) + 2; p2 = ((left - 1) % 32) + 2; } else { p0 = 0; p1 = 1; p2 = 26; } }
+  else { mpm = 2; p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
+  hop_intra_cu_syntax* y = syn + i;
+  y->preds[pu][0] = p0; y->preds[pu][1] = p1; y->preds[pu][2] = p2; y->pred_num[pu] = 3;
+  y->tr_depth = nxn; y->part = part; y->b_luma = 1; y->b_chroma = 0;
+  hop_intra_job r;
+  r.x = jobs[i].x + rqt_zx(part); r.y = jobs[i].y + rqt_zy(part); r.size = N; r.strong = opt[i].strong;
+  for (int u = 0; u < 68; u++) r.flags[u] = sj[i].rough_flags[pu][u];
+  rj[i] = r;
+  hop_intra_modes_job m;
+  m.preds[0] = p0; m.preds[1] = p1; m.preds[2] = p2; m.pred_num = 3; m.mpm_cand = mpm; m.num_full_rd = sj[i].num_full_rd;
+  const int ci = jobs[i].ctx_index;
+  m.ctx_state = cu_in[ci].state[16]; m.frac_left = (int)ctx_in[ci].state[150] | ((int)ctx_in[ci].state[151] << 8); m.sqrt_lambda = sj[i].sqrt_lambda;
+  mj[i] = m;
+  work[i].best_cost = 1.7e+308; work[i].best_dist = 0; work[i].best_mode = 0;
+}
+
+// pass < n_max: candidate `pass` of the list (the last one again where the list is shorter); pass == n_max: the best mode so far
+__global__ void k_is_pick(int pu, int pass, int n_max, int n, const hop_intra_modes_result* __restrict__ mres, const IsWork* __restrict__ work, hop_intra_cu_syntax* __restrict__ syn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cnt = (int)mres[i].n;
+  syn[i].luma_dir[pu] = pass == n_max ? work[i].best_mode : (int)mres[i].modes[pass < cnt ? pass : cnt - 1];
+}
+
+__global__ __launch_bounds__(64) void k_is_keep(RqtClass k, int pu, int nxn, int pass, int n_max, const hop_rqt_job* __restrict__ jobs, int n,
+                                                const hop_intra_modes_result* __restrict__ mres, const hop_intra_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ tmp,
+                                                const int32_t* __restrict__ coef_tmp, const int16_t* __restrict__ rec, int pitch, IsWork* __restrict__ work,
+                                                int32_t* __restrict__ coef_out, int16_t* __restrict__ reco_out) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  const bool active = pass == n_max || pass < (int)mres[i].n;
+  if (!active || !(tmp[i].cost < work[i].best_cost)) return;           // uniform per block; best_cost is written after the barrier below
+  const int cu = 1 << k.log2_cu, parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * nxn), part = pu * q, N = cu >> nxn, x0 = rqt_zx(part), y0 = rqt_zy(part);
+  const size_t cu2 = (size_t)cu * cu, cb = (size_t)i * (cu2 + (cu2 >> 1));
+  for (int e = t; e < q; e += 64) { work[i].tr[part + e] = tmp[i].tr_idx[part + e]; work[i].cbf[part + e] = tmp[i].cbf[0][part + e]; work[i].ts[part + e] = tmp[i].tskip[0][part + e]; }
+  for (int e = t; e < 16 * q; e += 64) coef_out[cb + (size_t)16 * part + e] = coef_tmp[cb + (size_t)16 * part + e];
+  const int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
+  for (int e = t; e < N * N; e += 64) { const int rr = e / N, cc = e % N; reco_out[(size_t)i * cu2 + (size_t)(y0 + rr) * cu + x0 + cc] = pic[(size_t)rr * pitch + cc]; }
+  __syncthreads();
+  if (t == 0) { work[i].best_cost = tmp[i].cost; work[i].best_dist = tmp[i].dist; work[i].best_mode = syn[i].luma_dir[pu]; }
+}
+
+__global__ __launch_bounds__(64) void k_is_commit(RqtClass k, int pu, int nxn, const hop_rqt_job* __restrict__ jobs, int n, const IsWork* __restrict__ work,
+                                                  const hop_intra_modes_result* __restrict__ mres, hop_intra_cu_syntax* __restrict__ syn, hop_rqt_result* __restrict__ res,
+                                                  hop_intra_search_result* __restrict__ sres, int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ reco_out) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int cu = 1 << k.log2_cu, parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * nxn), part = pu * q, N = cu >> nxn, x0 = rqt_zx(part), y0 = rqt_zy(part), npu = nxn ? 4 : 1;
+  for (int e = t; e < q; e += 64) { res[i].tr_idx[part + e] = work[i].tr[part + e]; res[i].cbf[0][part + e] = work[i].cbf[part + e]; res[i].tskip[0][part + e] = work[i].ts[part + e]; }
+  if (pu != npu - 1) {
+    int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
+    for (int e = t; e < N * N; e += 64) { const int rr = e / N, cc = e % N; pic[(size_t)rr * pitch + cc] = reco_out[(size_t)i * ((size_t)cu * cu) + (size_t)(y0 + rr) * cu + x0 + cc]; }
+  }
+  if (t == 0) {
+    sres[i].best_dir[pu] = work[i].best_mode; sres[i].n_cand[pu] = (int)mres[i].n; syn[i].luma_dir[pu] = work[i].best_mode;
+    sres[i].dist = (pu ? sres[i].dist : 0u) + work[i].best_dist;
+    res[i].dist = sres[i].dist; res[i].cost = 0; res[i].bits = 0;
+  }
+  if (npu > 1 && pu == npu - 1) {
+    __syncthreads();
+    unsigned comb = 0;
+    for (int p = 0; p < 4; p++) comb |= (res[i].cbf[0][p * q] >> 1) & 1u;
+    __syncthreads();
+    for (int e = t; e < parts; e += 64) res[i].cbf[0][e] |= (uint8_t)comb;
+  }
+}
+
+size_t hop_intra_search_work_bytes(int log2_cu, int n) {
+  const size_t cu2 = (size_t)1 << (2 * log2_cu);
+  return hop_intra_rqt_work_bytes(log2_cu, n) + (size_t)n * (sizeof(hop_intra_cu_syntax) + sizeof(hop_intra_job) + sizeof(hop_intra_modes_job) + sizeof(hop_intra_modes_result) + 35 * 4 +
+                                                             sizeof(IsWork) + sizeof(hop_rqt_result) + (cu2 + (cu2 >> 1)) * 4) + 16 * 256;
+}
+
+// one class of CUs: size, transform-tree limits / flags, partition (2Nx2N or NxN) and the candidate count of the PU size; buf = hop_intra_search_work_bytes
+int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int nxn, int num_full_rd, int n, const hop_rqt_job* d_jobs,
+                            const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_intra_search_job* d_sj, const hop_cabac_ctx* d_ctx_in,
+                            const hop_cabac_cu_ctx* d_cu_in, hop_intra_search_result* d_sres, hop_rqt_result* d_res, int32_t* d_coef_out, int16_t* d_reco_out, void* vbuf,
+                            size_t buf_bytes) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t cu2 = (size_t)1 << (2 * log2_cu), rq = al(hop_intra_rqt_work_bytes(log2_cu, n));
+  char* buf = (char*)vbuf;
+  size_t o = rq;
+  auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
+  hop_intra_cu_syntax* syn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax));
+  hop_intra_job* rj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job));
+  hop_intra_modes_job* mj = (hop_intra_modes_job*)take((size_t)n * sizeof(hop_intra_modes_job));
+  hop_intra_modes_result* mres = (hop_intra_modes_result*)take((size_t)n * sizeof(hop_intra_modes_result));
+  uint32_t* satd = (uint32_t*)take((size_t)n * 35 * 4);
+  IsWork* work = (IsWork*)take((size_t)n * sizeof(IsWork));
+  hop_rqt_result* tmp = (hop_rqt_result*)take((size_t)n * sizeof(hop_rqt_result));
+  int32_t* coef_tmp = (int32_t*)take((size_t)n * (cu2 + (cu2 >> 1)) * 4);
+  if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra search: work buffer too small");
+  hipError_t e = hipMemcpyAsync(syn, d_syn_in, (size_t)n * sizeof(hop_intra_cu_syntax), hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search: %s", hipGetErrorString(e));
+  const int g256 = (n + 255) / 256, npu = nxn ? 4 : 1, n_max = num_full_rd + 2, pitch = c->pic_w;
+  e = hipMemsetAsync(d_res, 0, (size_t)n * sizeof(hop_rqt_result), c->stream);
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search: %s", hipGetErrorString(e));
+  for (int pu = 0; pu < npu; pu++) {
+    hipLaunchKernelGGL(k_is_prep, dim3(g256), dim3(256), 0, c->stream, k, pu, nxn, d_jobs, d_sj, d_opt, n, d_ctx_in, d_cu_in, d_sres, syn, rj, mj, work);
+    int r = hop_launch_intra(c, n, rj, satd); if (r) return r;
+    r = hop_launch_intra_modes(c, n, mj, satd, mres); if (r) return r;
+    for (int pass = 0; pass <= n_max; pass++) {
+      hipLaunchKernelGGL(k_is_pick, dim3(g256), dim3(256), 0, c->stream, pu, pass, n_max, n, mres, work, syn);
+      r = hop_launch_intra_rqt(c, log2_cu, log2_max_tu, log2_min_tu, sign_hide, use_ts, nxn, pass < n_max ? 1 : 0, n, d_jobs, syn, d_opt, d_ctx_in, d_cu_in, tmp, coef_tmp, nullptr,
+                               nullptr, buf, rq);
+      if (r) return r;
+      hipLaunchKernelGGL(k_is_keep, dim3(n), dim3(64), 0, c->stream, k, pu, nxn, pass, n_max, d_jobs, n, mres, syn, tmp, coef_tmp, c->rec[0], pitch, work, d_coef_out, d_reco_out);
+    }
+    hipLaunchKernelGGL(k_is_commit, dim3(n), dim3(64), 0, c->stream, k, pu, nxn, d_jobs, n, work, mres, syn, d_res, d_sres, c->rec[0], pitch, d_reco_out);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

@@ -77,6 +77,9 @@ INTRA_MODES_RESULT_DTYPE = np.dtype([("n", "<u4"), ("modes", "<u4", (11,)), ("co
 INTRA_CU_SYNTAX_DTYPE = np.dtype([("part_nxn", "<i4"), ("skip_flag", "<i4"), ("skip_ctx", "<i4"), ("is_min_cu", "<i4"), ("luma_dir", "<i4", (4,)), ("preds", "<i4", (4, 3)),
                                   ("pred_num", "<i4", (4,)), ("chroma_is_dm", "<i4"), ("chroma_dir", "<i4"), ("tr_depth", "<i4"), ("part", "<i4"), ("b_luma", "<i4"), ("b_chroma", "<i4")])
 INTRA_RQT_OPT_DTYPE = np.dtype([("check_first", "<i4"), ("ts_fast", "<i4"), ("strong", "<i4"), ("pad", "<i4"), ("avail", "<u8", (341,))])   # hop_intra_rqt_opt
+INTRA_SEARCH_JOB_DTYPE = np.dtype([("left_dir", "<i4", (4,)), ("above_dir", "<i4", (4,)), ("rough_flags", "u1", (4, 68)), ("sqrt_lambda", "<f8"), ("num_full_rd", "<i4"),
+                                   ("pad", "<i4")])                                                   # hop_intra_search_job
+INTRA_SEARCH_RESULT_DTYPE = np.dtype([("best_dir", "<i4", (4,)), ("n_cand", "<i4", (4,)), ("dist", "<u4"), ("pad", "<u4")])
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
@@ -350,6 +353,18 @@ class Context:
         self._chk(self.L.hop_intra_rqt(self.h, n, jobs.ctypes.data, syntax.ctypes.data, opts.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data, res.ctypes.data,
                                        coef.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_intra_rqt")
         return res, coef, cx, cu
+
+    def intra_luma_search(self, jobs, syntax, opts, sjobs, ctx_in, cu_ctx_in):
+        """estIntraPredQT (luma): returns search results (INTRA_SEARCH_RESULT_DTYPE), arrays (RQT_RESULT_DTYPE), levels (1.5 size^2 per job, luma filled) and the CUs'
+        luma reconstruction planes (size^2 per job); the context's reconstruction picture is updated as the reference updates it"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, INTRA_CU_SYNTAX_DTYPE); opts = np.ascontiguousarray(opts, INTRA_RQT_OPT_DTYPE)
+        sjobs = np.ascontiguousarray(sjobs, INTRA_SEARCH_JOB_DTYPE); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); sres = np.zeros(n, INTRA_SEARCH_RESULT_DTYPE); res = np.zeros(n, RQT_RESULT_DTYPE)
+        coef = np.zeros(int(sum((3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs)), np.int32); reco = np.zeros(int(sum(1 << (2 * int(j["log2_cu"])) for j in jobs)), np.int16)
+        self.L.hop_intra_luma_search.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 6
+        self._chk(self.L.hop_intra_luma_search(self.h, n, jobs.ctypes.data, syntax.ctypes.data, opts.ctypes.data, sjobs.ctypes.data, len(ctx_in), ctx_in.ctypes.data,
+                                               cu_ctx_in.ctypes.data, sres.ctypes.data, res.ctypes.data, coef.ctypes.data, reco.ctypes.data), "hop_intra_luma_search")
+        return sres, res, coef, reco
 
     def intra_pred(self, jobs, modes):
         n = len(jobs)

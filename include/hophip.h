@@ -452,6 +452,32 @@ int hop_intra_rqt(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_
 int hop_intra_rqt_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, int tr_depth, int check_first, const hop_intra_cu_syntax* d_syntax,
                          const hop_intra_rqt_opt* d_opts, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, hop_rqt_result* d_results, int32_t* d_coef_out,
                          hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);
+/* ---- luma intra search of a CU (row a8) ---- */
+/* replaces: TEncSearch::estIntraPredQT with bLumaOnly (TLibEncoder/TEncSearch.cpp:2386-2710) as xCheckRDCostIntra calls it, for a batch of CUs: per PU (one, or the four
+ * of NxN in order) the most probable modes (TComDataCU::getIntraDirLumaPredictor, TComDataCU.cpp:1772-1830), the 35-mode rough search with the candidate list
+ * (:2430-2493 = hop_intra_rough + hop_intra_modes), every candidate through the transform tree with bCheckFirst (:2507-2553 = hop_intra_rqt), the best one again with the
+ * full tree (:2555-2590), the better result kept as xSetIntraResultQT keeps it; the decided PU's reconstruction goes into the picture unless it is the last PU
+ * (:2603-2660; the last PU's picture block is left as the final pass wrote it, as in the reference), the cbf of an NxN CU is combined at depth 0 (:2667-2685).
+ * jobs / opts: as for hop_intra_rqt (check_first is not read); syntax: part_nxn, skip_flag, skip_ctx, is_min_cu (directions and predictors are derived here);
+ * ctx_in / cu_ctx_in[jobs[i].ctx_index]: the CI_CURR_BEST state every tree and the mode bits start from.  The CUs of one call must not lie in each other's neighbourhood. */
+typedef struct {
+  int32_t left_dir[4], above_dir[4];   /* per PU: the luma direction getIntraDirLumaPredictor sees left / above where that neighbour lies outside the CU (1 = DC when it
+                                          is unavailable, not intra, or above the CTU row); not read where the neighbour is a PU of this CU */
+  uint8_t rough_flags[4][68];          /* per PU: flags of hop_intra_job for the PU's block (the rough search) */
+  double  sqrt_lambda;                 /* TComRdCost::getSqrtLambda */
+  int32_t num_full_rd;                 /* g_aucIntraModeNumFast of the PU size: 8 for 4x4 and 8x8, 3 above */
+  int32_t pad;
+} hop_intra_search_job;
+typedef struct { int32_t best_dir[4], n_cand[4]; uint32_t dist, pad; } hop_intra_search_result;   /* getLumaIntraDir per PU, candidates tested, getTotalDistortion */
+/* results: the tr_idx / cbf[0] / tskip[0] arrays of the CU (dist = the same distortion); coef_out: per job 1.5 * size^2 entries, the luma part = getCoeffY;
+ * reco_out: per job size^2 samples, the CU's luma reconstruction (pcRecoYuv) */
+int hop_intra_luma_search(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, const hop_intra_search_job* sjobs,
+                          int n_ctx, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, hop_intra_search_result* sresults, hop_rqt_result* results,
+                          int32_t* coef_out, int16_t* reco_out);
+/* device-resident form: all n CUs of ONE class -- size, transform-tree limits / flags of *cls, partition (part_nxn) and num_full_rd; asynchronous, unchecked */
+int hop_intra_luma_search_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, int part_nxn, int num_full_rd, const hop_intra_cu_syntax* d_syntax,
+                                 const hop_intra_rqt_opt* d_opts, const hop_intra_search_job* d_sjobs, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in,
+                                 hop_intra_search_result* d_sresults, hop_rqt_result* d_results, int32_t* d_coef_out, int16_t* d_reco_out);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -785,3 +785,56 @@ def test_intra_rqt_random_vs_oracle(hp):
         assert np.array_equal(R, R2), bd
         assert deep >= 4 and ts >= 3 and single_over_split >= 4, (bd, deep, ts, single_over_split)
         ctx.close()
+
+
+def test_intra_luma_search_encoder_calls(hp):
+    """hop_intra_luma_search (estIntraPredQT, luma: most probable modes, rough search, candidate list, candidate and final transform trees, the better result kept, the
+    decided PU's block into the picture, NxN cbf combined) on the 43 calls recorded inside the encoder, each in its own tile of one picture: directions, candidates
+    tested, distortion, arrays, the CU's luma levels, its reconstruction plane and the picture afterwards"""
+    from goldutil import encoder_isearch_calls
+    cases = list(encoder_isearch_calls())
+    n = len(cases); T = 192; G = 7; W = H = T * G
+    assert n <= G * G
+    Y = np.zeros((H, W), np.int16); R = np.zeros((H, W), np.int16)
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(n, hp.INTRA_RQT_OPT_DTYPE); sj = np.zeros(n, hp.INTRA_SEARCH_JOB_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; j = jobs[i]; cu = 1 << int(cfg["log2_cu"]); Wn = 2 * cu + 1
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        Y[y0:y0 + cu, x0:x0 + cu] = c["org"].reshape(cu, cu)
+        R[y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn] = c["win"].reshape(Wn, Wn)
+        j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x0, y0, int(cfg["log2_cu"]), cfg["qp"], i
+        j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"]
+        j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = cfg["lambda_rd"], cfg["lambda_rdoq"], cfg["dist_weight"][1:]
+        for k in ("part_nxn", "skip_flag", "skip_ctx", "is_min_cu", "chroma_is_dm", "chroma_dir"): syn[i][k] = c["syn"][k]
+        opts[i]["ts_fast"], opts[i]["strong"] = c["nd"][0], c["nd"][1]
+        av = c["avail"].reshape(341, 36).astype(np.uint64)
+        opts[i]["avail"] = (av << np.arange(36, dtype=np.uint64)[None, :]).sum(axis=1)
+        sj[i]["left_dir"], sj[i]["above_dir"], sj[i]["rough_flags"], sj[i]["sqrt_lambda"], sj[i]["num_full_rd"] = c["dirs"][:4], c["dirs"][4:], c["rough"].reshape(4, 68), c["sql"], c["nd"][2]
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i] = c["cuin"]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16))
+    ctx.plane_upload("recon", 0, R)
+    sres, res, coef, reco = ctx.intra_luma_search(jobs, syn, opts, sj, snaps, cus)
+    R2 = ctx.recon_download(0)
+    o = ro = 0; kinds = set()
+    for i, c in enumerate(cases):
+        cu = 1 << int(c["cfg"]["log2_cu"]); parts = (cu // 4) ** 2; npu = 4 if c["syn"]["part_nxn"] else 1
+        tag = (i, cu, npu)
+        assert [int(v) for v in sres[i]["best_dir"][:npu]] == [int(v) for v in c["best"][:npu]], (tag, sres[i]["best_dir"], c["best"])
+        assert [int(v) for v in sres[i]["n_cand"][:npu]] == [int(v) for v in c["ncand"][:npu]] and int(sres[i]["dist"]) == c["dist"], (tag, sres[i], c["ncand"], c["dist"])
+        a = c["aout"].reshape(7, 256)
+        assert np.array_equal(res[i]["tr_idx"][:parts], a[0, :parts]) and np.array_equal(res[i]["cbf"][0][:parts], a[1, :parts]) and np.array_equal(res[i]["tskip"][0][:parts], a[4, :parts]), tag
+        assert np.array_equal(coef[o:o + cu * cu], c["coef"]) and np.array_equal(reco[ro:ro + cu * cu], c["reco"]), tag
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        assert np.array_equal(R2[y0:y0 + cu, x0:x0 + cu].reshape(-1), c["rec"]), tag
+        R[y0:y0 + cu, x0:x0 + cu] = c["rec"].reshape(cu, cu)
+        kinds.add((cu, npu, int(c["ncand"][0]), int(a[0, :parts].max()), int(a[4, :parts].any())))
+        o += cu * cu * 3 // 2; ro += cu * cu
+    assert np.array_equal(R, R2)
+    assert len(kinds) >= 12 and any(k[4] for k in kinds) and any(k[1] == 4 for k in kinds)
+    bad = sj.copy(); bad[0]["left_dir"][0] = 35
+    with pytest.raises(hp.HopError):
+        ctx.intra_luma_search(jobs, syn, opts, bad, snaps, cus)
+    ctx.close()

@@ -857,7 +857,7 @@ int hop_intra_rqt_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop
     c->rqt_bytes = wb + wb / 8;
   }
   return hop_launch_intra_rqt(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, tr_depth, check_first ? 1 : 0, n, d_jobs, d_syntax,
-                              d_opts, d_ctx_in, d_cu_ctx_in, d_results, d_coef_out, d_ctx_out, d_cu_ctx_out, c->rqt_buf, c->rqt_bytes);
+                              d_opts, d_ctx_in, d_cu_ctx_in, d_results, d_coef_out, d_ctx_out, d_cu_ctx_out, c->rqt_buf, c->rqt_bytes, nullptr);
 }
 
 int hop_intra_rqt(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, int n_ctx, const hop_cabac_ctx* ctx_in,

@@ -144,7 +144,7 @@ int hop_launch_tu_recon(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const in
 size_t hop_intra_rqt_work_bytes(int log2_cu, int n);
 int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int tr_depth0, int check_first, int n, const hop_rqt_job* d_jobs,
                          const hop_intra_cu_syntax* d_syn, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, hop_rqt_result* d_res,
-                         int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* buf, size_t buf_bytes);
+                         int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* buf, size_t buf_bytes, const uint8_t* d_active);
 size_t hop_intra_search_work_bytes(int log2_cu, int n);
 int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int nxn, int num_full_rd, int n, const hop_rqt_job* d_jobs,
                             const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_intra_search_job* d_sj, const hop_cabac_ctx* d_ctx_in,

@@ -295,8 +295,9 @@ __global__ __launch_bounds__(64) void k_coeff_bits(const hop_coeff_bits_job* __r
                                                    unsigned long long* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out) {
   __shared__ CabacLds sh;
   const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
-  const bool live = j < n;
-  const hop_coeff_bits_job jb = jobs[live ? j : 0];
+  const bool inb = j < n;
+  const hop_coeff_bits_job jb = jobs[inb ? j : 0];
+  const bool live = inb && jb.log2_size >= 2;                         // < 2: an empty slot of a job table (k_rqt.inl)
   {
     const uint8_t* src = ctx_in[jb.ctx_index].state;
     for (int i = 0; i < 152; i++) sh.st[i][lane] = src[i];

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_intra_pred(const hop_intra_job* __restr
   const hop_intra_job* jp = jobs + blockIdx.x;
   const int tid = threadIdx.x;
   const int N = jp->size, x0 = jp->x, y0 = jp->y;
+  if (N == 0) return;                                                  // an empty slot of a batch (hop_intra_luma_search: a CU without a candidate in this pass)
   const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
   const int maxVal = (1 << pic.bd_y) - 1, mode = modes[blockIdx.x];
   intra_setup(sh, jp, pic, rec_y, tid);

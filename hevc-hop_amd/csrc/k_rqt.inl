@@ -713,9 +713,14 @@ __global__ void k_irqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restri
                              int n, int bd_y, const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ root,
                              hop_cabac_cu_ctx* __restrict__ curoot, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, hop_intra_job* __restrict__ pj,
                              int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2,
-                             int64_t* __restrict__ off2, size_t ts_base) {
+                             int64_t* __restrict__ off2, size_t ts_base, const uint8_t* __restrict__ active) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (active && !active[i]) {                                           // an idle PU of this pass: empty slots in the prediction and leaf batches
+    hop_intra_job q0; memset(&q0, 0, sizeof(q0)); pj[i] = q0; modes[i] = 0;
+    hop_tu_rd_job j0; memset(&j0, 0, sizeof(j0)); tuj[i] = j0; off[i] = 0; if (nd.ts_y) { tuj2[i] = j0; off2[i] = 0; }
+    return;
+  }
   root[i] = cur[i]; curoot[i] = cucur[i];
   IrqWork* w = work + i;
   if (nd.check_split) { w->sub_cost[nd.d + 1] = 0; w->sub_dist[nd.d + 1] = 0; }
@@ -746,8 +751,10 @@ __global__ void k_irqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restri
 
 // mode 0: the node's block, picture -> layer plane; 1: the 4x4 block, picture -> transform-skip park; 2: layer plane -> picture where the single block has won
 __global__ __launch_bounds__(256) void k_irqt_copy(int mode, RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
-                                                   const IrqWork* __restrict__ work, int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ recl, int16_t* __restrict__ park) {
+                                                   const IrqWork* __restrict__ work, int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ recl, int16_t* __restrict__ park,
+                                                   const uint8_t* __restrict__ active) {
   const int i = blockIdx.x;
+  if (active && !active[i]) return;
   if (mode == 2 && !work[i].restore[nd.d]) return;
   const int part = syn[i].part + nd.part, N = 1 << nd.log2, cu = 1 << k.log2_cu, x0 = rqt_zx(part), y0 = rqt_zy(part);
   int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
@@ -765,10 +772,11 @@ __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, cons
                                                     const hop_cabac_ctx* __restrict__ root, const hop_cabac_cu_ctx* __restrict__ curoot, hop_cabac_ctx* __restrict__ test,
                                                     hop_cabac_cu_ctx* __restrict__ cutest, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work,
                                                     const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base,
-                                                    int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
+                                                    int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans,
+                                                    const uint8_t* __restrict__ active) {
   __shared__ CabacLds sh;
   const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
-  if (i >= n) return;
+  if (i >= n || (active && !active[i])) return;
   const hop_intra_cu_syntax y = syn[i];
   const double lambda = jobs[i].lambda_rd;
   hop_rqt_result* r = res + i;
@@ -813,10 +821,11 @@ __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, cons
 __global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
                                                    hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, const hop_cabac_ctx* __restrict__ root,
                                                    const hop_cabac_cu_ctx* __restrict__ curoot, const hop_cabac_ctx* __restrict__ test, const hop_cabac_cu_ctx* __restrict__ cutest,
-                                                   hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
+                                                   hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans,
+                                                   const uint8_t* __restrict__ active) {
   __shared__ CabacLds sh;
   const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
-  if (i >= n) return;
+  if (i >= n || (active && !active[i])) return;
   const hop_intra_cu_syntax y = syn[i];
   hop_rqt_result* r = res + i;
   IrqWork* w = work + i;
@@ -842,8 +851,9 @@ __global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const
 __global__ __launch_bounds__(64) void k_irqt_final(RqtClass k, int d0, int n, const hop_intra_cu_syntax* __restrict__ syn, const IrqWork* __restrict__ work,
                                                    hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, int32_t* __restrict__ coef_out,
                                                    const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ ctx_out,
-                                                   hop_cabac_cu_ctx* __restrict__ cu_out) {
+                                                   hop_cabac_cu_ctx* __restrict__ cu_out, const uint8_t* __restrict__ active) {
   const int i = blockIdx.x, t = threadIdx.x;
+  if (active && !active[i]) return;
   const int parts = 1 << (2 * (k.log2_cu - 2)), np = parts >> (2 * d0), p0 = syn[i].part;
   const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
   hop_rqt_result* r = res + i;
@@ -864,7 +874,8 @@ size_t hop_intra_rqt_work_bytes(int log2_cu, int n) {
 // one class of PUs: CU size, transform-tree limits, the transform depth the PU starts at (0: 2Nx2N, 1: NxN) and bCheckFirst; buf = hop_intra_rqt_work_bytes
 int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int tr_depth0, int check_first, int n, const hop_rqt_job* d_jobs,
                          const hop_intra_cu_syntax* d_syn, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, hop_rqt_result* d_res,
-                         int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* vbuf, size_t buf_bytes) {
+                         int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* vbuf, size_t buf_bytes,
+                         const uint8_t* d_active /* may be NULL: PUs that sit this call out */) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   char* buf = (char*)vbuf;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -875,7 +886,7 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
   auto take_st = [&]() { St s; s.a = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); s.b = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx)); return s; };
   struct Bufs {
     St cur, root[4], test[4]; IrqWork* work; hop_intra_job* pj; int32_t* modes; hop_tu_rd_job *tuj, *tuj2; int64_t *off, *off2; hop_tu_rd_result *tr, *tr2; int32_t* coef;
-    int16_t *recl, *park; size_t n_coeff, ts_base;
+    int16_t *recl, *park; size_t n_coeff, ts_base; const uint8_t* active;
   } B;
   B.cur = take_st();
   for (int d = 0; d < 4; d++) { B.root[d] = take_st(); B.test[d] = take_st(); }
@@ -886,7 +897,7 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
   B.tr = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result)); B.tr2 = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result));
   B.coef = (int32_t*)take(n_coeff * 4);
   B.recl = (int16_t*)take((size_t)n * 4 * cu2 * 2); B.park = (int16_t*)take((size_t)n * 32);
-  B.n_coeff = n_coeff; B.ts_base = ts_base;
+  B.n_coeff = n_coeff; B.ts_base = ts_base; B.active = d_active;
   if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra rqt: work buffer too small");
   hipLaunchKernelGGL(k_irqt_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, d_ctx_in, d_cu_in, B.cur.a, B.cur.b, B.work, d_res);
   struct Rec { static int go(hop_ctx* c, const RqtClass& k, int n, int check_first, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn, const hop_intra_rqt_opt* d_opt,
@@ -898,31 +909,31 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
     nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
     const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, pitch = c->pic_w;
     hipLaunchKernelGGL(k_irqt_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, c->bd_y, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, d_res, B.work,
-                       B.pj, B.modes, B.tuj, B.off, B.tuj2, B.off2, B.ts_base);
+                       B.pj, B.modes, B.tuj, B.off, B.tuj2, B.off2, B.ts_base, B.active);
     if (nd.check_full) {
       int r = hop_launch_intra_pred(c, n, B.pj, B.modes); if (r) return r;
       const int hint = log2 <= 3 ? 1 : (log2 == 5 ? 2 : 0);
       if (nd.ts_y) {
         r = hop_launch_tu_rd(c, n, B.tuj2, B.root[d].a, B.off2, B.n_coeff, B.coef, B.tr2, 1); if (r) return r;
-        hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 1, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park);
+        hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 1, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
       }
       r = hop_launch_tu_rd(c, n, B.tuj, B.root[d].a, B.off, B.n_coeff, B.coef, B.tr, hint); if (r) return r;
-      if (nd.check_split) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 0, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park);
+      if (nd.check_split) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 0, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
       hipLaunchKernelGGL(k_irqt_single, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b,
-                         d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base, c->rec[0], pitch, B.park, c->rdoq_scans);
+                         d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base, c->rec[0], pitch, B.park, c->rdoq_scans, B.active);
     }
     if (nd.check_split) {
       const int q = ((1 << (2 * (k.log2_cu - 2))) >> (2 * d)) >> 2;
       for (int kk = 0; kk < 4; kk++) { const int r = go(c, k, n, check_first, d_jobs, d_syn, d_opt, d_res, B, rel + kk * q, d + 1, log2 - 1); if (r) return r; }
       hipLaunchKernelGGL(k_irqt_close, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b, d_res,
-                         B.work, B.coef, c->rdoq_scans);
-      if (nd.check_full) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 2, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park);
+                         B.work, B.coef, c->rdoq_scans, B.active);
+      if (nd.check_full) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 2, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
     }
     return HOP_OK;
   } };
   const int rc = Rec::go(c, k, n, check_first, d_jobs, d_syn, d_opt, d_res, B, 0, tr_depth0, k.log2_cu - tr_depth0);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_irqt_final, dim3(n), dim3(64), 0, c->stream, k, tr_depth0, n, d_syn, B.work, d_res, B.coef, d_coef_out, B.cur.a, B.cur.b, d_ctx_out, d_cu_out);
+  hipLaunchKernelGGL(k_irqt_final, dim3(n), dim3(64), 0, c->stream, k, tr_depth0, n, d_syn, B.work, d_res, B.coef, d_coef_out, B.cur.a, B.cur.b, d_ctx_out, d_cu_out, d_active);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra rqt launch: %s", hipGetErrorString(e));
   return HOP_OK;
@@ -936,7 +947,7 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
 //   per candidate (bCheckFirst) and once more for the best (:2507-2590): k_is_pick (the direction of this pass), hop_launch_intra_rqt from the CI_CURR_BEST
 //                 state, k_is_keep (a better cost: arrays, levels and the PU's picture block kept aside - xSetIntraResultQT)
 //   k_is_commit   the kept arrays back, the decided block into the picture unless it is the last PU (:2603-2660), the cbf of an NxN CU combined (:2667-2685)
-// CUs with fewer candidates than the class maximum repeat their last candidate in the spare passes (the result is ignored; the final pass follows anyway).
+// CUs with fewer candidates than the class maximum sit the spare passes out (empty slots in every batch of the pass).
 // =====================================================================================================================
 struct IsWork { double best_cost; uint32_t best_dist; int32_t best_mode; uint8_t tr[256], cbf[256], ts[256]; };
 
@@ -965,11 +976,13 @@ __global__ void k_is_prep(RqtClass k, int pu, int nxn, const hop_rqt_job* __rest
   work[i].best_cost = 1.7e+308; work[i].best_dist = 0; work[i].best_mode = 0;
 }
 
-// pass < n_max: candidate `pass` of the list (the last one again where the list is shorter); pass == n_max: the best mode so far
-__global__ void k_is_pick(int pu, int pass, int n_max, int n, const hop_intra_modes_result* __restrict__ mres, const IsWork* __restrict__ work, hop_intra_cu_syntax* __restrict__ syn) {
+// pass < n_max: candidate `pass` of the list (CUs whose list is shorter sit the pass out); pass == n_max: the best mode so far
+__global__ void k_is_pick(int pu, int pass, int n_max, int n, const hop_intra_modes_result* __restrict__ mres, const IsWork* __restrict__ work, hop_intra_cu_syntax* __restrict__ syn,
+                          uint8_t* __restrict__ active) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int cnt = (int)mres[i].n;
+  active[i] = (pass == n_max || pass < cnt) ? 1 : 0;
   syn[i].luma_dir[pu] = pass == n_max ? work[i].best_mode : (int)mres[i].modes[pass < cnt ? pass : cnt - 1];
 }
 
@@ -1017,7 +1030,7 @@ __global__ __launch_bounds__(64) void k_is_commit(RqtClass k, int pu, int nxn, c
 size_t hop_intra_search_work_bytes(int log2_cu, int n) {
   const size_t cu2 = (size_t)1 << (2 * log2_cu);
   return hop_intra_rqt_work_bytes(log2_cu, n) + (size_t)n * (sizeof(hop_intra_cu_syntax) + sizeof(hop_intra_job) + sizeof(hop_intra_modes_job) + sizeof(hop_intra_modes_result) + 35 * 4 +
-                                                             sizeof(IsWork) + sizeof(hop_rqt_result) + (cu2 + (cu2 >> 1)) * 4) + 16 * 256;
+                                                             sizeof(IsWork) + sizeof(hop_rqt_result) + (cu2 + (cu2 >> 1)) * 4 + 1) + 16 * 256;
 }
 
 // one class of CUs: size, transform-tree limits / flags, partition (2Nx2N or NxN) and the candidate count of the PU size; buf = hop_intra_search_work_bytes
@@ -1039,6 +1052,7 @@ int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_m
   IsWork* work = (IsWork*)take((size_t)n * sizeof(IsWork));
   hop_rqt_result* tmp = (hop_rqt_result*)take((size_t)n * sizeof(hop_rqt_result));
   int32_t* coef_tmp = (int32_t*)take((size_t)n * (cu2 + (cu2 >> 1)) * 4);
+  uint8_t* active = (uint8_t*)take((size_t)n);
   if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra search: work buffer too small");
   hipError_t e = hipMemcpyAsync(syn, d_syn_in, (size_t)n * sizeof(hop_intra_cu_syntax), hipMemcpyDeviceToDevice, c->stream);
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search: %s", hipGetErrorString(e));
@@ -1050,9 +1064,9 @@ int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_m
     int r = hop_launch_intra(c, n, rj, satd); if (r) return r;
     r = hop_launch_intra_modes(c, n, mj, satd, mres); if (r) return r;
     for (int pass = 0; pass <= n_max; pass++) {
-      hipLaunchKernelGGL(k_is_pick, dim3(g256), dim3(256), 0, c->stream, pu, pass, n_max, n, mres, work, syn);
+      hipLaunchKernelGGL(k_is_pick, dim3(g256), dim3(256), 0, c->stream, pu, pass, n_max, n, mres, work, syn, active);
       r = hop_launch_intra_rqt(c, log2_cu, log2_max_tu, log2_min_tu, sign_hide, use_ts, nxn, pass < n_max ? 1 : 0, n, d_jobs, syn, d_opt, d_ctx_in, d_cu_in, tmp, coef_tmp, nullptr,
-                               nullptr, buf, rq);
+                               nullptr, buf, rq, active);
       if (r) return r;
       hipLaunchKernelGGL(k_is_keep, dim3(n), dim3(64), 0, c->stream, k, pu, nxn, pass, n_max, d_jobs, n, mres, syn, tmp, coef_tmp, c->rec[0], pitch, work, d_coef_out, d_reco_out);
     }

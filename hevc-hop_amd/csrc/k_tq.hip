@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_turd_forward_small(const hop_tu_rd_job*
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + w;
   if (j >= n) return;
   const hop_tu_rd_job jb = jobs[j];
-  if (jb.log2_size > 3) return;
+  if (jb.log2_size > 3 || jb.log2_size < 2) return;                // < 2: an empty slot of a job table (k_rqt.inl)
   const int log2N = jb.log2_size, N = 1 << log2N, NN = N * N;
   const bool chroma = jb.comp != 0, live = lane < NN;
   const int bd = chroma ? pic.bd_c : pic.bd_y, pitch = chroma ? pic.pic_w >> 1 : pic.pic_w;

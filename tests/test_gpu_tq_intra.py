@@ -838,3 +838,45 @@ def test_intra_luma_search_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.intra_luma_search(jobs, syn, opts, bad, snaps, cus)
     ctx.close()
+
+
+def test_intra_luma_search_random_vs_oracle(hp):
+    """hop_intra_luma_search against the restatement (pinned inside the reference encoder) on the random CUs of test_intra_rqt_random_vs_oracle (8 and 10 bit, every CU size,
+    NxN, deeper trees, random availability) with random neighbour directions and rough-search flags: 72 CUs per bit depth in one call (several classes)"""
+    from goldutil import oracle_intra_luma_search, INTRA_SYN
+    for bd in (8, 10):
+        W, H, Y, R, jobs, syn, opts, cfgs, snaps, cus, avs = _irqt_random_cases(hp, hp.load(), bd)
+        n = len(jobs); mid = 1 << (bd - 1)
+        rng = np.random.default_rng(90 + bd)
+        sj = np.zeros(n, hp.INTRA_SEARCH_JOB_DTYPE)
+        sj["left_dir"] = rng.integers(0, 35, (n, 4)); sj["above_dir"] = rng.integers(0, 35, (n, 4))
+        same = rng.random(n) < 0.3; sj["above_dir"][same] = sj["left_dir"][same]
+        sj["rough_flags"] = rng.random((n, 4, 68)) < 0.8
+        for i in range(n):
+            sj[i]["sqrt_lambda"] = float(np.sqrt(jobs[i]["lambda_rd"])); sj[i]["num_full_rd"] = 8 if ((1 << int(jobs[i]["log2_cu"])) >> int(syn[i]["part_nxn"])) <= 8 else 3
+        ctx = hp.Context(W, H, bd)
+        ctx.upload_orig(Y, np.full((H // 2, W // 2), mid, np.int16), np.full((H // 2, W // 2), mid, np.int16))
+        ctx.plane_upload("recon", 0, R)
+        sres, res, coef, reco = ctx.intra_luma_search(jobs, syn, opts, sj, snaps, cus)
+        R2 = ctx.recon_download(0)
+        o = ro = 0; final_better = nxn_n = 0
+        for i in range(n):
+            c = cfgs[i]; cu = 1 << int(c["log2_cu"]); Wn = 2 * cu + 1; parts = (cu // 4) ** 2; npu = 4 if syn[i]["part_nxn"] else 1
+            x0, y0 = int(jobs[i]["x"]), int(jobs[i]["y"])
+            osyn = np.zeros(1, INTRA_SYN)
+            for k in INTRA_SYN.names: osyn[0][k] = syn[i][k]
+            coder = snaps[i, :150].tobytes() + b"\0\0" + (int(snaps[i, 150]) | (int(snaps[i, 151]) << 8)).to_bytes(8, "little")
+            nd = [int(opts[i]["ts_fast"]), int(opts[i]["strong"]), int(sj[i]["num_full_rd"])]
+            best, ncand, dist, arr, ocoef, oreco, win = oracle_intra_luma_search(c, osyn[0], nd, np.concatenate([sj[i]["left_dir"], sj[i]["above_dir"]]), float(sj[i]["sqrt_lambda"]),
+                                                                                 sj[i]["rough_flags"], avs[i], Y[y0:y0 + cu, x0:x0 + cu], R[y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn],
+                                                                                 np.frombuffer(coder, np.uint8), cus[i])
+            tag = (bd, i, cu, npu)
+            assert [int(v) for v in sres[i]["best_dir"][:npu]] == best[:npu] and [int(v) for v in sres[i]["n_cand"][:npu]] == ncand[:npu] and int(sres[i]["dist"]) == dist, (tag, sres[i], best, ncand, dist)
+            assert np.array_equal(res[i]["tr_idx"][:parts], arr[0, :parts]) and np.array_equal(res[i]["cbf"][0][:parts], arr[1, :parts]) and np.array_equal(res[i]["tskip"][0][:parts], arr[4, :parts]), tag
+            assert np.array_equal(coef[o:o + cu * cu], ocoef) and np.array_equal(reco[ro:ro + cu * cu], oreco), tag
+            R[y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn] = win.reshape(Wn, Wn)
+            final_better += int(not np.array_equal(oreco.reshape(cu, cu), win.reshape(Wn, Wn)[1:1 + cu, 1:1 + cu])); nxn_n += int(npu == 4)
+            o += cu * cu * 3 // 2; ro += cu * cu
+        assert np.array_equal(R, R2), bd
+        assert nxn_n >= 4, (bd, nxn_n, final_better)
+        ctx.close()

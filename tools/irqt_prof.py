@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/irqt_prof.py -- throughput of hop_intra_rqt_device (rest of row a8: the luma transform tree of an intra PU) per CU size (developer tool, GPU box).
 One call = every third CU of a 7680x5376 frame in both directions (the PUs of a call must not lie in each other's neighbourhood); 2Nx2N PUs, the final pass
-(bCheckFirst off) and the candidate pass (bCheckFirst on).  Jobs, options, snapshots, results and levels stay in HBM."""
+(bCheckFirst off) and the candidate pass (bCheckFirst on); then the whole luma search of a CU (hop_intra_luma_search_device).  Jobs, options, snapshots, results and levels stay in HBM."""
 import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,4 +48,33 @@ for lg in (3, 4, 5, 6):
         res = np.frombuffer(dr.cpu().numpy().tobytes(), hp.RQT_RESULT_DTYPE)
         print("%2dx%-2d %6d %10d %8.4f %8.1f %10.1f %10.2f  %3.0f%%" % (S, S, cf, n, dt, n / dt / 1e3, n * S * S / dt / 1e6,
               float(np.mean([r["tr_idx"][:S * S // 16].mean() for r in res[:2000]])), 100.0 * float(np.mean(res["cbf"][:, 0, 0] != 0))))
+# the whole luma search of a CU (hop_intra_luma_search_device = estIntraPredQT): rough search, candidate list, 4..10 candidate trees, the final tree
+print("CU   part     CUs  device s   kCU/s  Msamples/s   candidates")
+ctx.L.hop_intra_luma_search_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 9
+for lg, nxn in ((3, 1), (3, 0), (4, 0), (5, 0), (6, 0)):
+    S = 1 << lg
+    xs, ys = np.meshgrid(np.arange(S, W - 2 * S, 3 * S), np.arange(S, H - 2 * S, 3 * S))
+    n = xs.size
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(n, hp.INTRA_RQT_OPT_DTYPE); sj = np.zeros(n, hp.INTRA_SEARCH_JOB_DTYPE)
+    jobs["x"], jobs["y"], jobs["log2_cu"], jobs["ctx_index"] = xs.ravel(), ys.ravel(), lg, 0
+    jobs["qp_scaled"] = (32, 31, 31); jobs["sign_hide"] = 1; jobs["use_ts"] = 1; jobs["log2_max_tu"] = 5
+    jobs["log2_min_tu_in_cu"] = {3: 2, 4: 2, 5: 3, 6: 4}[lg]
+    jobs["lambda_rd"] = LAM; jobs["lambda_rdoq"] = (LAM, LAM, LAM); jobs["dist_weight"] = (1.0, 1.0)
+    syn["is_min_cu"] = int(lg == 3); syn["part_nxn"] = nxn; syn["chroma_is_dm"] = 1
+    opts["strong"] = 1; opts["avail"] = (1 << 33) - 1
+    nf = 8 if (S >> nxn) <= 8 else 3
+    sj["left_dir"] = 1; sj["above_dir"] = 26; sj["rough_flags"] = 1; sj["sqrt_lambda"] = np.sqrt(LAM); sj["num_full_rd"] = nf
+    dj = torch.from_numpy(jobs.view(np.uint8)).to(dev); dy = torch.from_numpy(syn.view(np.uint8)).to(dev); do = torch.from_numpy(opts.view(np.uint8)).to(dev)
+    dsj = torch.from_numpy(sj.view(np.uint8)).to(dev); ds = torch.from_numpy(snap).to(dev); du = torch.from_numpy(cus).to(dev)
+    dq = torch.zeros(n * hp.INTRA_SEARCH_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    dr = torch.zeros(n * hp.RQT_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev); dc = torch.zeros(n * S * S * 3 // 2, dtype=torch.int32, device=dev)
+    dk = torch.zeros(n * S * S, dtype=torch.int16, device=dev)
+    for it in range(3):
+        ctx.plane_upload("recon", 0, Y)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx._chk(ctx.L.hop_intra_luma_search_device(ctx.h, n, dj.data_ptr(), jobs[:1].ctypes.data, nxn, nf, dy.data_ptr(), do.data_ptr(), dsj.data_ptr(), ds.data_ptr(), du.data_ptr(),
+                                                    dq.data_ptr(), dr.data_ptr(), dc.data_ptr(), dk.data_ptr()), "intra_luma_search_device")
+        ctx.sync(); dt = time.perf_counter() - t0
+    sr = np.frombuffer(dq.cpu().numpy().tobytes(), hp.INTRA_SEARCH_RESULT_DTYPE)
+    print("%2dx%-2d %5s %8d %8.4f %8.1f %10.1f %10.2f" % (S, S, "NxN" if nxn else "2Nx2N", n, dt, n / dt / 1e3, n * S * S / dt / 1e6, float(sr["n_cand"][:, 0].mean())))
 ctx.close()

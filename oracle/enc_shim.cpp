@@ -878,6 +878,88 @@ Void TEncSearch::estIntraPredQT(TComDataCU* pcCU, TComYuv* pcOrgYuv, TComYuv* pc
   pcCU->getTotalDistortion() = distY;
 }
 
+// ---- the chroma intra search of a CU: TEncSearch::estIntraPredChromaQT (TLibEncoder/TEncSearch.cpp:2720-2785) -> hop_o_intra_chroma_search ----
+extern "C" void hop_ref_orig_est_chroma(TEncSearch*, TComDataCU*, TComYuv*, TComYuv*, TComYuv*, TComYuv*, UInt);
+namespace { unsigned long g_calls13[1] = { 0 };
+struct Report13 { ~Report13() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: chromaSearch %lu\n", g_calls13[0]); } } g_report13; }
+
+Void TEncSearch::estIntraPredChromaQT(TComDataCU* pcCU, TComYuv* pcOrgYuv, TComYuv* pcPredYuv, TComYuv* pcResiYuv, TComYuv* pcRecoYuv, UInt uiPreCalcDistC)
+{
+  static const bool orig = hand_back("estIntraPredChromaQT");
+  if (orig) { hop_ref_orig_est_chroma(this, pcCU, pcOrgYuv, pcPredYuv, pcResiYuv, pcRecoYuv, uiPreCalcDistC); return; }
+  TComSlice* sl = pcCU->getSlice();
+  if (m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() || sl->getSPS()->getUsePCM()) {
+    fprintf(stderr, "hop shim: estIntraPredChromaQT is replaced for RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+  }
+  g_calls13[0]++;
+  const UInt uiDepth = pcCU->getDepth(0);
+  hop_o_rqt_cfg cfg; hop_o_intra_syntax y; std::vector<uint8_t> avail;
+  intra_env(this, pcCU, 0, 0, cfg, y, avail);
+  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_CHROMA, sl->getSPS()->getQpBDOffsetC(), sl->getPPS()->getChromaCbQpOffset() + sl->getSliceQpDeltaCb()); cfg.qp[1] = m_pcTrQuant->m_cQP.m_iQP;
+  m_pcTrQuant->setQPforQuant(pcCU->getQP(0), TEXT_CHROMA, sl->getSPS()->getQpBDOffsetC(), sl->getPPS()->getChromaCrQpOffset() + sl->getSliceQpDeltaCr()); cfg.qp[2] = m_pcTrQuant->m_cQP.m_iQP;
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4), half = cu / 2;
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  std::vector<int16_t> planes[4][3];
+  for (int l = 0; l < 4; l++) {
+    st.coef[l][0] = m_ppcQTTempCoeffY[l]; st.coef[l][1] = m_ppcQTTempCoeffCb[l]; st.coef[l][2] = m_ppcQTTempCoeffCr[l];
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int c = 1; c < 3; c++) {
+      planes[l][c].assign(half * half, 0); st.resi[l][c] = &planes[l][c][0];
+      const Pel* src = c == 1 ? t.getCbAddr() : t.getCrAddr();
+      for (int r = 0; r < half; r++) memcpy(st.resi[l][c] + r * half, src + r * t.getCStride(), half * sizeof(Pel));
+    }
+  }
+  memcpy(st.tr_idx, pcCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], pcCU->m_puhCbf[c], parts); memcpy(st.tskip[c], pcCU->m_puhTransformSkip[c], parts); }
+  TComPicYuv* recPic = pcCU->getPic()->getPicYuvRec();
+  hop_o_intra_chroma_in in; memset(&in, 0, sizeof(in));
+  in.org_cb = pcOrgYuv->getCbAddr(); in.org_cr = pcOrgYuv->getCrAddr(); in.org_stride = pcOrgYuv->getCStride();
+  in.rec_cb = recPic->getCbAddr(pcCU->getAddr(), pcCU->getZorderIdxInCU()); in.rec_cr = recPic->getCrAddr(pcCU->getAddr(), pcCU->getZorderIdxInCU()); in.rec_stride = recPic->getCStride();
+  in.avail = &avail[0]; in.ts_fast = m_pcEncCfg->getUseTransformSkipFast() ? 1 : 0;
+  TEncSbac* best = m_pppcRDSbacCoder[uiDepth][CI_CURR_BEST];
+  hop_o_coder coder; coder_get(best, &coder);
+  uint8_t cuctx[20] = { 0 }; { CuSets2 r = cu_sets2(best); uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  static FILE* f = NULL; static bool tried = false;                 // HOP_SHIM_TRACE_CSEARCH=<file>
+  if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_CSEARCH"); if (pth && *pth) f = fopen(pth, "wb"); }
+  const int W = cu + 1;                                             // chroma window: (2 * half + 1)^2 from (-1, -1)
+  const int px = (int)pcCU->getCUPelX() / 2, py = (int)pcCU->getCUPelY() / 2, pw = recPic->getWidth() / 2, ph = recPic->getHeight() / 2;
+  if (f) {
+    const int32_t nd[4] = { in.ts_fast, 0, 0, 0 };
+    fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&y, sizeof(y), 1, f); fwrite(nd, 4, 4, f); fwrite(&avail[0], 1, avail.size(), f);
+    for (int c = 0; c < 2; c++) for (int r = 0; r < half; r++) fwrite((c ? in.org_cr : in.org_cb) + r * in.org_stride, 2, half, f);
+    for (int c = 0; c < 2; c++) {
+      std::vector<int16_t> win((size_t)W * W, 0);
+      const int16_t* rp = c ? in.rec_cr : in.rec_cb;
+      for (int r = 0; r < W; r++) for (int cc = 0; cc < W; cc++) {
+        const int X = px - 1 + cc, Y = py - 1 + r;
+        if (X >= 0 && Y >= 0 && X < pw && Y < ph) win[(size_t)r * W + cc] = rp[(ptrdiff_t)(r - 1) * in.rec_stride + (cc - 1)];
+      }
+      fwrite(&win[0], 2, win.size(), f);
+    }
+    fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+    fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 20, f);
+  }
+  int bestMode = 0; uint32_t bestDist = 0;
+  std::vector<int16_t> rcb((size_t)half * half, 0), rcr((size_t)half * half, 0);
+  hop_o_intra_chroma_search(&cfg, &y, &in, &coder, cuctx, &st, &bestMode, &bestDist, pcCU->getCoeffCb(), pcCU->getCoeffCr(), &rcb[0], &rcr[0]);
+  if (f) {
+    const int32_t o2[2] = { bestMode, (int32_t)bestDist }; fwrite(o2, 4, 2, f);
+    fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+    fwrite(pcCU->getCoeffCb(), 4, half * half, f); fwrite(pcCU->getCoeffCr(), 4, half * half, f); fwrite(&rcb[0], 2, rcb.size(), f); fwrite(&rcr[0], 2, rcr.size(), f);
+    for (int c = 0; c < 2; c++) for (int r = 0; r < half; r++) fwrite((c ? in.rec_cr : in.rec_cb) + (ptrdiff_t)r * in.rec_stride, 2, half, f);
+  }
+  for (int l = 0; l < 4; l++) {
+    TComYuv& t = m_pcQTTempTComYuv[l];
+    for (int c = 1; c < 3; c++) { Pel* dst = c == 1 ? t.getCbAddr() : t.getCrAddr(); for (int r = 0; r < half; r++) memcpy(dst + r * t.getCStride(), st.resi[l][c] + r * half, half * sizeof(Pel)); }
+  }
+  for (int r = 0; r < half; r++) { memcpy(pcRecoYuv->getCbAddr() + r * pcRecoYuv->getCStride(), &rcb[(size_t)r * half], half * sizeof(Pel));
+                                   memcpy(pcRecoYuv->getCrAddr() + r * pcRecoYuv->getCStride(), &rcr[(size_t)r * half], half * sizeof(Pel)); }
+  for (int c = 1; c < 3; c++) { memcpy(pcCU->m_puhCbf[c], st.cbf[c], parts); memcpy(pcCU->m_puhTransformSkip[c], st.tskip[c], parts); }
+  pcCU->setChromIntraDirSubParts(bestMode, 0, uiDepth);
+  pcCU->getTotalDistortion() += bestDist - uiPreCalcDistC;
+  m_pcRDGoOnSbacCoder->load(best);
+}
+
 // ---- chroma intra prediction: TComPrediction::predIntraChromaAng (TLibCommon/TComPrediction.cpp:375-390) -> hop_o_intra_pred_chroma ----
 namespace { unsigned long g_calls10[1] = { 0 };
 struct Report10 { ~Report10() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: chromaPred %lu\n", g_calls10[0]); } } g_report10; }

@@ -154,6 +154,17 @@ typedef struct {
 void hop_o_intra_luma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, const hop_o_intra_rqt_in* in, const hop_o_intra_search_in* sin,
                              const hop_o_coder* coder_in, const uint8_t cu_ctx_in[20], hop_o_rqt_state* st, int best_dir[4], int32_t* coef_y, int16_t* reco_y,
                              uint32_t* dist_y, int* n_cand_out);
+/* row a8: the chroma intra search of one CU (estIntraPredChromaQT).  st: tr_idx and tskip[0] as the luma search left them (input), cbf[1..2] / tskip[1..2] afterwards;
+ * coef[layer][1..2] / resi[layer][1..2]: level layers and reconstruction layer planes (pitch = half the CU size).  best_mode: 0 / 26 / 10 / 1 / 34 or 36 (DM_CHROMA_IDX);
+ * coef_cb / coef_cr: the CU's chroma levels (getCoeffCb/Cr layout: TU of partition p at 4 p), reco_cb / reco_cr: its chroma reconstruction (pitch = half the CU size). */
+typedef struct {
+  const int16_t* org_cb; const int16_t* org_cr; int org_stride;   /* chroma originals at the CU origin */
+  int16_t* rec_cb; int16_t* rec_cr; int rec_stride;               /* chroma reconstruction pictures at the CU origin (read and written as the search goes) */
+  const uint8_t* avail;                                           /* the node table of hop_o_intra_rqt_in (the same flags, per 2-sample unit here) */
+  int ts_fast;
+} hop_o_intra_chroma_in;
+void hop_o_intra_chroma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn, const hop_o_intra_chroma_in* in, const hop_o_coder* coder_in, const uint8_t cu_ctx_in[20],
+                               hop_o_rqt_state* st, int* best_mode, uint32_t* best_dist, int32_t* coef_cb, int32_t* coef_cr, int16_t* reco_cb, int16_t* reco_cr);
 int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
                           const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

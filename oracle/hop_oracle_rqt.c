@@ -730,3 +730,154 @@ void hop_o_intra_luma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax*
   }
   *dist_y = overall;
 }
+
+/* ---- row a8: the chroma intra search of one CU, TEncSearch::estIntraPredChromaQT (TLibEncoder/TEncSearch.cpp:2720-2785) ----
+ * The five allowed chroma directions (TComDataCU::getAllowedChromaDir, TComDataCU.cpp:1746-1764), each through xRecurIntraChromaCodingQT (:2130-2277: the chroma
+ * blocks of the luma tree's transform units in order - xIntraCodingChromaBlk :1164-1330 = prediction from the chroma reconstruction picture, residual, estBit on
+ * the current coder state, transform / RDOQ with the chroma quantiser and lambda, inverse path, reconstruction into the layer plane and the picture, weighted SSE
+ * - with the transform-skip retry per component for 4x4 blocks, :2176-2247, whose bit counts (xGetIntraBitsQTChroma :982-1001) move the coder on), then the
+ * chroma bits of the CU from the CI_CURR_BEST state (xGetIntraBitsQT, chroma only) and the cost; the best one kept as xSetIntraResultChromaQT keeps it. */
+typedef struct {
+  const hop_o_rqt_cfg* cfg; const hop_o_intra_syntax* syn; const hop_o_intra_chroma_in* in; hop_o_rqt_state* st;
+  hop_o_coder* coder; uint8_t* cu;
+} Icq;
+
+static void chroma_blk(Icq* r, int orgDepth, int part, int comp, int tsFlag, uint32_t* dist)
+{
+  const hop_o_rqt_cfg* g = r->cfg;
+  const int parts = 1 << (2 * (g->log2_cu - 2)), log2Luma = g->log2_cu - orgDepth, layer = g->log2_max_tu - log2Luma;
+  int d = orgDepth;
+  if (log2Luma == 2) d--;
+  const int lg = g->log2_cu - d - 1, N = 1 << lg, half = 1 << (g->log2_cu - 1), nparts = parts >> (2 * d);
+  const int x = zx(part) >> 1, y = zy(part) >> 1;
+  int dir = r->syn->chroma_is_dm ? r->syn->luma_dir[0] : r->syn->chroma_dir;
+  int16_t* rec = comp == 1 ? r->in->rec_cb : r->in->rec_cr;
+  const int16_t* orgp = comp == 1 ? r->in->org_cb : r->in->org_cr;
+  int L[4 * 32 + 1];
+  int16_t org[32 * 32], pred[32 * 32], out_rec[32 * 32];
+  hop_o_intra_fill_refs_u(rec, r->in->rec_stride, x, y, N, 2, r->in->avail + (size_t)hop_o_intra_node_index(d, g->log2_cu - d, part) * HOP_O_AVAIL_PITCH, g->bit_depth_c, L);
+  hop_o_intra_pred_chroma(L, N, dir, g->bit_depth_c, pred);
+  for (int j = 0; j < N; j++) memcpy(org + j * N, orgp + (size_t)(y + j) * r->in->org_stride + x, sizeof(int16_t) * (size_t)N);
+  uint32_t out[8]; double c;
+  int32_t* coef = r->st->coef[layer][comp] + ((16 * part) >> 2);
+  hop_o_tu_intra_ts(org, pred, lg, comp, tu_scan(r->syn, parts, part, N, comp), 0, g->qp[comp], g->bit_depth_c, orgDepth, g->sign_hide, g->use_ts, tsFlag,
+                    g->lambda_rdoq[comp], g->lambda_rd, g->dist_weight[comp], &r->coder->ctx, 0, coef, out_rec, out, &c);
+  set_parts(r->st->cbf[comp], part, nparts, (out[0] ? 1 : 0) << orgDepth);
+  for (int j = 0; j < N; j++) {
+    memcpy(r->st->resi[layer][comp] + (size_t)(y + j) * half + x, out_rec + j * N, sizeof(int16_t) * (size_t)N);
+    memcpy(rec + (ptrdiff_t)(y + j) * r->in->rec_stride + x, out_rec + j * N, sizeof(int16_t) * (size_t)N);
+  }
+  *dist += out[2];
+}
+
+static void chroma_node(Icq* r, int trDepth, int part, uint32_t* dist)
+{
+  const hop_o_rqt_cfg* g = r->cfg;
+  hop_o_rqt_state* st = r->st;
+  const int parts = 1 << (2 * (g->log2_cu - 2));
+  if (st->tr_idx[part] != trDepth) {
+    const int q = (parts >> (2 * trDepth)) >> 2;
+    uint32_t su = 0, sv = 0;
+    for (int k = 0; k < 4; k++) {
+      chroma_node(r, trDepth + 1, part + k * q, dist);
+      su |= (st->cbf[1][part + k * q] >> (trDepth + 1)) & 1; sv |= (st->cbf[2][part + k * q] >> (trDepth + 1)) & 1;
+    }
+    for (int o = 0; o < 4 * q; o++) { st->cbf[1][part + o] |= (uint8_t)(su << trDepth); st->cbf[2][part + o] |= (uint8_t)(sv << trDepth); }
+    return;
+  }
+  const int log2 = g->log2_cu - trDepth;
+  int actual = trDepth;
+  if (log2 == 2) { actual--; if (part % (parts >> (2 * actual)) != 0) return; }
+  const int nparts = parts >> (2 * actual), layer = g->log2_max_tu - log2, half = 1 << (g->log2_cu - 1);
+  int ts = g->use_ts && log2 <= 3;
+  if (r->in->ts_fast) {
+    ts = ts && log2 < 3;
+    if (ts) { int nb = 0; for (int p = part; p < part + 4; p++) nb += st->tskip[0][p]; ts = ts && nb > 0; }
+  }
+  if (!ts) {
+    set_parts(st->tskip[1], part, nparts, 0); set_parts(st->tskip[2], part, nparts, 0);
+    chroma_blk(r, trDepth, part, 1, 0, dist); chroma_blk(r, trDepth, part, 2, 0, dist);
+    return;
+  }
+  const double MAXD = 1.7e+308;
+  hop_o_coder root = *r->coder;
+  const int x = zx(part) >> 1, y = zy(part) >> 1;
+  for (int comp = 1; comp <= 2; comp++) {
+    double single = MAXD; int best = 0; uint32_t sdist = 0, scbf = 0;
+    hop_o_coder tbest = root;
+    int32_t keepCoef[16]; int16_t keepRec[16];
+    int16_t* rec = comp == 1 ? r->in->rec_cb : r->in->rec_cr;
+    int32_t* coef = st->coef[layer][comp] + ((16 * part) >> 2);
+    for (int mode = 0; mode < 2; mode++) {
+      set_parts(st->tskip[comp], part, nparts, mode);
+      uint32_t d = 0; double c;
+      chroma_blk(r, trDepth, part, comp, mode, &d);
+      const uint32_t cbf = (st->cbf[comp][part] >> trDepth) & 1;
+      if (mode == 1 && cbf == 0) c = MAXD;
+      else {
+        reset_bits(r->coder);
+        intra_coeff(g, r->syn, st, r->coder, parts, trDepth, part, comp);
+        c = hop_o_calc_rd_cost(written(r->coder), d, g->lambda_rd);
+      }
+      if (c < single) {
+        single = c; sdist = d; best = mode; scbf = cbf;
+        if (best == 0) {
+          memcpy(keepCoef, coef, sizeof(keepCoef));
+          for (int j = 0; j < 4; j++) memcpy(keepRec + 4 * j, st->resi[layer][comp] + (size_t)(y + j) * half + x, 8);
+          tbest = *r->coder;
+        }
+      }
+      if (mode == 0) *r->coder = root;
+    }
+    if (best == 0) {
+      memcpy(coef, keepCoef, sizeof(keepCoef));
+      for (int j = 0; j < 4; j++) {
+        memcpy(st->resi[layer][comp] + (size_t)(y + j) * half + x, keepRec + 4 * j, 8);
+        memcpy(rec + (ptrdiff_t)(y + j) * r->in->rec_stride + x, keepRec + 4 * j, 8);
+      }
+      set_parts(st->cbf[comp], part, nparts, (int)(scbf << trDepth));
+      *r->coder = tbest;
+    }
+    set_parts(st->tskip[comp], part, nparts, best);
+    *dist += sdist;
+    if (comp == 1) root = *r->coder;
+  }
+}
+
+void hop_o_intra_chroma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* syn_in, const hop_o_intra_chroma_in* in, const hop_o_coder* coder_in, const uint8_t cu_ctx_in[20],
+                               hop_o_rqt_state* st, int* best_mode, uint32_t* best_dist, int32_t* coef_cb, int32_t* coef_cr, int16_t* reco_cb, int16_t* reco_cr)
+{
+  const int parts = 1 << (2 * (cfg->log2_cu - 2)), half = 1 << (cfg->log2_cu - 1);
+  hop_o_intra_syntax syn = *syn_in;
+  int list[5] = { 0, 26, 10, 1, 36 };
+  for (int i = 0; i < 4; i++) if (syn.luma_dir[0] == list[i]) { list[i] = 34; break; }
+  double bestCost = 1.7e+308;
+  uint8_t keep[4][256];
+  *best_mode = 0; *best_dist = 0;
+  for (int m = 0; m < 5; m++) {
+    hop_o_coder coder = *coder_in; uint8_t cuc[20]; memcpy(cuc, cu_ctx_in, 20);
+    syn.chroma_is_dm = list[m] == 36; syn.chroma_dir = list[m];
+    Icq r = { cfg, &syn, in, st, &coder, cuc };
+    uint32_t dist = 0;
+    chroma_node(&r, 0, 0, &dist);
+    if (cfg->use_ts) { coder = *coder_in; memcpy(cuc, cu_ctx_in, 20); }
+    const uint32_t bits = hop_o_intra_cu_bits(cfg, &syn, st, 0, 0, 0, 1, &coder, cuc);
+    const double cost = hop_o_calc_rd_cost(bits, dist, cfg->lambda_rd);
+    if (cost < bestCost) {
+      bestCost = cost; *best_dist = dist; *best_mode = list[m];
+      for (int p = 0; p < parts; p++) {                                 /* xSetIntraResultChromaQT, :2280-2345 */
+        const int d = st->tr_idx[p], log2 = cfg->log2_cu - d, layer = cfg->log2_max_tu - log2;
+        int dd = d; if (log2 == 2) dd--;
+        const int np = parts >> (2 * dd), first = p - p % np, lgc = cfg->log2_cu - dd - 1, N = 1 << lgc;
+        if (p != first) continue;
+        for (int comp = 1; comp <= 2; comp++) {
+          memcpy((comp == 1 ? coef_cb : coef_cr) + 4 * p, st->coef[layer][comp] + 4 * p, sizeof(int32_t) * (size_t)N * N);
+          for (int j = 0; j < N; j++)
+            memcpy((comp == 1 ? reco_cb : reco_cr) + (size_t)((zy(p) >> 1) + j) * half + (zx(p) >> 1), st->resi[layer][comp] + (size_t)((zy(p) >> 1) + j) * half + (zx(p) >> 1), sizeof(int16_t) * (size_t)N);
+        }
+      }
+      memcpy(keep[0], st->cbf[1], (size_t)parts); memcpy(keep[1], st->cbf[2], (size_t)parts); memcpy(keep[2], st->tskip[1], (size_t)parts); memcpy(keep[3], st->tskip[2], (size_t)parts);
+    }
+  }
+  memcpy(st->cbf[1], keep[0], (size_t)parts); memcpy(st->cbf[2], keep[1], (size_t)parts); memcpy(st->tskip[1], keep[2], (size_t)parts); memcpy(st->tskip[2], keep[3], (size_t)parts);
+}

@@ -41,12 +41,12 @@ def encode(exe, W, H, seed, td, extra_env=None, sharp=False):
     return md5("in.yuv"), md5("s.bin"), md5("rec.yuv"), r.stderr
 
 
-LOW = ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "distPart", "commit", "rqt", "cuBits", "intraBits", "chromaPred")
+LOW = ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "distPart", "commit", "rqt", "cuBits", "intraBits")
 # the composite restatements stand in for members that call other replaced members; HOP_SHIM_ORIG hands the named composites back to the reference's own
 # definitions, so every level of the stack is reached (and counted) by some run
-LEVELS = {"": LOW + ("intraSearch",),
-          "estIntraPredQT": LOW + ("intraRqt", "modeBits", "candList", "intraPred", "calcHAD"),
-          "estIntraPredQT,xRecurIntraCodingQT": LOW + ("modeBits", "candList", "intraPred", "calcHAD", "tskip")}
+LEVELS = {"": ("ss", "frac", "gt", "predY", "predC", "distPart", "commit", "rqt", "cuBits", "intraSearch", "chromaSearch"),   # transforms, RDOQ, estBit, prediction: all inside the composites here
+          "estIntraPredQT,estIntraPredChromaQT": LOW + ("intraRqt", "modeBits", "candList", "intraPred", "calcHAD", "chromaPred"),
+          "estIntraPredQT,estIntraPredChromaQT,xRecurIntraCodingQT": LOW + ("modeBits", "candList", "intraPred", "calcHAD", "chromaPred", "tskip")}
 
 
 @pytest.mark.parametrize("orig", list(LEVELS))
@@ -65,7 +65,7 @@ def test_shim_encoder_writes_the_reference_bitstream(W, H, seed, orig):
     # the replaced members really ran (a silent fall-through to the reference's definitions would also give the same bytes)
     for k in LEVELS[orig]:
         assert calls.get(k, 0) > 50, (k, calls)
-    for k in ("intraSearch", "intraRqt"):
+    for k in ("intraSearch", "chromaSearch", "intraRqt"):
         if k not in LEVELS[orig]: assert calls.get(k, 0) == 0, (k, calls)
     assert bit == gold["bin_md5"] and rec == gold["rec_md5"], calls
 

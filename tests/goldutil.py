@@ -283,3 +283,51 @@ def oracle_intra_luma_search(cfg, syn, nd, dirs, sqrt_lambda, rough, avail, org,
                               ctypes.addressof(best), coef_y.ctypes.data, reco.ctypes.data, ctypes.addressof(dist), ctypes.addressof(ncand))
     arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
     return list(best), list(ncand), dist.value, arr, coef_y, reco, win
+
+
+def encoder_csearch_calls():
+    """tests/golden/encoder_csearch_calls.npz (oracle/make_golden16.py): estIntraPredChromaQT calls (chroma intra search of a CU) of two real encodes: cfg, syntax (the luma
+    directions decided before), nd = (TransformSkipFast, -, -, -), neighbour flags of every node [341][36], chroma originals Cb | Cr, the chroma reconstruction pictures
+    from (-1, -1) of the CU ((size + 1)^2 each), arrays in, the CI_CURR_BEST coder and CU contexts; after: direction, distortion, arrays, chroma levels Cb | Cr,
+    reconstruction planes Cb | Cr, picture blocks Cb | Cr"""
+    g = load("encoder_csearch_calls.npz")
+    o1 = o2 = 0
+    for i in range(len(g["dist"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu // 2; W = cu + 1
+        yield dict(cfg=g["cfg"][i], syn=g["syn"][i], nd=[int(v) for v in g["nd"][i]], avail=g["avail"][i], org=np.ascontiguousarray(g["org"][o1:o1 + n]),
+                   win=np.ascontiguousarray(g["win"][o2:o2 + 2 * W * W]), ain=g["ain"][i], cin=g["cin"][i], cuin=g["cuin"][i], mode=int(g["mode"][i]), dist=int(g["dist"][i]),
+                   aout=g["aout"][i], coef=np.ascontiguousarray(g["coef"][o1:o1 + n]), reco=np.ascontiguousarray(g["reco"][o1:o1 + n]), rec=np.ascontiguousarray(g["rec"][o1:o1 + n]))
+        o1 += n; o2 += 2 * W * W
+
+
+class _OChromaIn(ctypes.Structure):
+    _fields_ = [("org_cb", ctypes.c_void_p), ("org_cr", ctypes.c_void_p), ("org_stride", ctypes.c_int), ("rec_cb", ctypes.c_void_p), ("rec_cr", ctypes.c_void_p),
+                ("rec_stride", ctypes.c_int), ("avail", ctypes.c_void_p), ("ts_fast", ctypes.c_int)]
+
+
+def oracle_intra_chroma_search(cfg, syn, ts_fast, avail, org, win, arr_in, coder160, cu20):
+    """hop_o_intra_chroma_search on one CU.  org: Cb | Cr originals (half size squared each); win: Cb | Cr reconstruction pictures from (-1, -1), (size + 1)^2 each.
+    Returns direction, distortion, arrays (7 x 256), levels Cb | Cr, reconstruction planes Cb | Cr, the windows after."""
+    O = oracle()
+    c = np.zeros(1, RQT_CFG); c[0] = cfg
+    y = np.zeros(1, INTRA_SYN); y[0] = syn
+    cu = 1 << int(c[0]["log2_cu"]); n2 = cu * cu; h2 = n2 // 4; half = cu // 2; W = cu + 1
+    coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), np.ascontiguousarray(coder160).tobytes(), 160)
+    cuctx = np.ascontiguousarray(cu20, np.uint8).copy()
+    st = _OState()
+    ctypes.memmove(ctypes.addressof(st), np.ascontiguousarray(arr_in, np.uint8).reshape(-1).tobytes(), 1792)
+    coefs = [[np.zeros(n2 if k == 0 else h2, np.int32) for k in range(3)] for _ in range(4)]
+    recs = [[np.zeros(n2 if k == 0 else h2, np.int16) for k in range(3)] for _ in range(4)]
+    for l in range(4):
+        for k in range(3):
+            st.coef[3 * l + k] = coefs[l][k].ctypes.data; st.resi[3 * l + k] = recs[l][k].ctypes.data
+    win = np.ascontiguousarray(win, np.int16).copy(); org = np.ascontiguousarray(org, np.int16); avail = np.ascontiguousarray(avail, np.uint8)
+    inp = _OChromaIn(org.ctypes.data, org.ctypes.data + 2 * h2, half, win.ctypes.data + 2 * (W + 1), win.ctypes.data + 2 * W * W + 2 * (W + 1), W, avail.ctypes.data, ts_fast)
+    mode = ctypes.c_int(0); dist = ctypes.c_uint32(0)
+    coef = np.zeros(2 * h2, np.int32); reco = np.zeros(2 * h2, np.int16)
+    O.hop_o_intra_chroma_search.restype = None
+    O.hop_o_intra_chroma_search.argtypes = [ctypes.c_void_p] * 12
+    O.hop_o_intra_chroma_search(c.ctypes.data, y.ctypes.data, ctypes.addressof(inp), ctypes.addressof(coder), cuctx.ctypes.data, ctypes.addressof(st), ctypes.addressof(mode),
+                                ctypes.addressof(dist), coef.ctypes.data, coef.ctypes.data + 4 * h2, reco.ctypes.data, reco.ctypes.data + 2 * h2)
+    arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
+    return mode.value, dist.value, arr, coef, reco, win

@@ -168,3 +168,22 @@ def test_intra_luma_search_on_encoder_calls():
         assert np.array_equal(win.reshape(W, W)[1:1 + cu, 1:1 + cu].reshape(-1), c["rec"]), n
         kinds.add((cu, npu, ncand[0], int(arr[0, :parts].max()), int(arr[4, :parts].any()))); n += 1
     assert n == 43 and len(kinds) >= 12 and any(k[4] for k in kinds) and any(k[1] == 4 for k in kinds), kinds
+
+
+def test_intra_chroma_search_on_encoder_calls():
+    """estIntraPredChromaQT (the five allowed chroma directions through xRecurIntraChromaCodingQT along the luma tree, the transform-skip retry per component, the chroma
+    bits of the CU, the best kept): the restatement on 44 calls recorded inside the encoder - direction, distortion, cbf / transform-skip arrays, the CU's chroma
+    levels, its reconstruction planes and what the chroma pictures hold afterwards"""
+    from goldutil import encoder_csearch_calls, oracle_intra_chroma_search
+    n = 0; kinds = set()
+    for c in encoder_csearch_calls():
+        cu = 1 << int(c["cfg"]["log2_cu"]); W = cu + 1; half = cu // 2; parts = (cu // 4) ** 2
+        mode, dist, arr, coef, reco, win = oracle_intra_chroma_search(c["cfg"], c["syn"], c["nd"][0], c["avail"], c["org"], c["win"], c["ain"], c["cin"].tobytes(), c["cuin"])
+        assert mode == c["mode"] and dist == c["dist"], (n, mode, c["mode"], dist, c["dist"])
+        a = c["aout"].reshape(7, 256)
+        assert np.array_equal(arr[[2, 3, 5, 6], :parts], a[[2, 3, 5, 6], :parts]), n
+        assert np.array_equal(coef, c["coef"]) and np.array_equal(reco, c["reco"]), n
+        w2 = win.reshape(2, W, W)[:, 1:1 + half, 1:1 + half]
+        assert np.array_equal(w2.reshape(-1), c["rec"]), n
+        kinds.add((cu, mode, int(arr[5:7, :parts].any()), int(arr[0, :parts].max()))); n += 1
+    assert n == 44 and len(kinds) >= 15 and any(k[2] for k in kinds) and len(set(k[1] for k in kinds)) >= 4, kinds

@@ -1016,6 +1016,97 @@ int hop_intra_luma_search(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_
   return HOP_OK;
 }
 
+int hop_intra_chroma_search_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_intra_cu_syntax* d_syntax, const hop_intra_rqt_opt* d_opts,
+                                   const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, hop_rqt_result* d_results, hop_intra_chroma_result* d_cresults,
+                                   int32_t* d_coef_out, int16_t* d_reco_out) {
+  if (!c || n < 0 || !cls || (n && (!d_jobs || !d_syntax || !d_opts || !d_ctx_in || !d_cu_ctx_in || !d_results || !d_cresults || !d_coef_out || !d_reco_out)))
+    return hop_set_err(c, HOP_ERR_ARG, "hop_intra_chroma_search_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_chroma_search: hop_upload_orig has not been called");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_chroma_search_device: illegal CU class");
+  if (n == 0) return HOP_OK;
+  const size_t wb = hop_intra_chroma_work_bytes(cls->log2_cu, n);
+  if (wb > c->rqt_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
+    c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
+    c->rqt_bytes = wb + wb / 8;
+  }
+  return hop_launch_intra_chroma_search(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, n, d_jobs, d_syntax, d_opts, d_ctx_in,
+                                        d_cu_ctx_in, d_results, d_cresults, d_coef_out, d_reco_out, c->rqt_buf, c->rqt_bytes);
+}
+
+int hop_intra_chroma_search(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, int n_ctx, const hop_cabac_ctx* ctx_in,
+                            const hop_cabac_cu_ctx* cu_ctx_in, hop_rqt_result* results, hop_intra_chroma_result* cresults, int32_t* coef_out, int16_t* reco_out) {
+  if (!c || n < 0 || (n && (!jobs || !syntax || !opts || !ctx_in || !cu_ctx_in || !results || !cresults || !coef_out || !reco_out || n_ctx <= 0)))
+    return hop_set_err(c, HOP_ERR_ARG, "hop_intra_chroma_search: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_chroma_search: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  std::vector<size_t> coff(n + 1, 0), roff(n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const hop_rqt_job& j = jobs[i]; const hop_intra_cu_syntax& y = syntax[i];
+    const int S = 1 << j.log2_cu, parts = 1 << (2 * (j.log2_cu - 2));
+    bool ok = j.log2_cu >= 3 && j.log2_cu <= 6 && j.x >= 0 && j.y >= 0 && (j.x & (S - 1)) == 0 && (j.y & (S - 1)) == 0 && j.x + S <= c->pic_w && j.y + S <= c->pic_h &&
+              j.ctx_index >= 0 && j.ctx_index < n_ctx && j.log2_max_tu >= 2 && j.log2_max_tu <= 5 && j.log2_min_tu_in_cu >= 2 && j.log2_min_tu_in_cu <= j.log2_max_tu &&
+              j.log2_cu - j.log2_min_tu_in_cu <= 3 && j.log2_cu - j.log2_max_tu <= 1 && j.lambda_rd > 0.0 && y.luma_dir[0] >= 0 && y.luma_dir[0] < 35;
+    for (int k = 1; k < 3 && ok; k++) ok = j.qp_scaled[k] >= 0 && j.qp_scaled[k] <= 87 && j.lambda_rdoq[k] > 0.0;
+    // the luma tree must be a legal tree of the class: every depth within the limits, quadrants consistent
+    for (int p = 0; p < parts && ok; p++) {
+      const int d = results[i].tr_idx[p], lg = j.log2_cu - d;
+      ok = d >= 0 && d <= 3 && lg >= j.log2_min_tu_in_cu && lg <= j.log2_max_tu && results[i].tr_idx[p - p % (parts >> (2 * d))] == d && results[i].tskip[0][p] <= 1;
+    }
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "intra chroma search job %d: illegal CU / transform-tree limits / luma tree / snapshot / parameters", i);
+    coff[i + 1] = coff[i] + (((size_t)3 << (2 * j.log2_cu)) >> 1); roff[i + 1] = roff[i] + ((size_t)1 << (2 * j.log2_cu - 1));
+  }
+  for (int k = 0; k < n_ctx; k++) {
+    for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+    for (int i = 0; i < 19; i++) if (cu_ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "CU context snapshot %d: state %d out of range", k, i);
+  }
+  std::vector<char> done(n, 0);
+  for (int first = 0; first < n; first++) {
+    if (done[first]) continue;
+    const hop_rqt_job& f = jobs[first];
+    std::vector<int> idx; std::vector<hop_rqt_job> cls; std::vector<hop_intra_cu_syntax> sy; std::vector<hop_intra_rqt_opt> op; std::vector<hop_rqt_result> rr;
+    for (int i = first; i < n; i++) {
+      const hop_rqt_job& j = jobs[i];
+      if (!done[i] && j.log2_cu == f.log2_cu && j.log2_max_tu == f.log2_max_tu && j.log2_min_tu_in_cu == f.log2_min_tu_in_cu && !j.sign_hide == !f.sign_hide && !j.use_ts == !f.use_ts) {
+        done[i] = 1; idx.push_back(i); cls.push_back(j); sy.push_back(syntax[i]); op.push_back(opts[i]); rr.push_back(results[i]);
+      }
+    }
+    const int m = (int)idx.size();
+    const size_t cu2 = (size_t)1 << (2 * f.log2_cu), cu3 = cu2 + (cu2 >> 1), h2x2 = cu2 >> 1;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_j = 0, o_y = al((size_t)m * sizeof(hop_rqt_job)), o_p = al(o_y + (size_t)m * sizeof(hop_intra_cu_syntax)), o_c = al(o_p + (size_t)m * sizeof(hop_intra_rqt_opt));
+    const size_t o_u = al(o_c + (size_t)n_ctx * sizeof(hop_cabac_ctx)), o_r = al(o_u + (size_t)n_ctx * sizeof(hop_cabac_cu_ctx)), o_q = al(o_r + (size_t)m * sizeof(hop_rqt_result));
+    const size_t o_o = al(o_q + (size_t)m * sizeof(hop_intra_chroma_result)), o_k = al(o_o + (size_t)m * cu3 * 4), o_e = al(o_k + (size_t)m * h2x2 * 2);
+    void* st; int r = hop_stage(c, o_e + 256, &st); if (r) return r;
+    char* b = (char*)st;
+    HIPCHK(c, hipMemcpyAsync(b + o_j, cls.data(), (size_t)m * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_y, sy.data(), (size_t)m * sizeof(hop_intra_cu_syntax), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_p, op.data(), (size_t)m * sizeof(hop_intra_rqt_opt), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, (size_t)n_ctx * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_u, cu_ctx_in, (size_t)n_ctx * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_r, rr.data(), (size_t)m * sizeof(hop_rqt_result), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b + o_q, 0, o_e - o_q, c->stream));
+    r = hop_intra_chroma_search_device(c, m, (const hop_rqt_job*)(b + o_j), &f, (const hop_intra_cu_syntax*)(b + o_y), (const hop_intra_rqt_opt*)(b + o_p), (const hop_cabac_ctx*)(b + o_c),
+                                       (const hop_cabac_cu_ctx*)(b + o_u), (hop_rqt_result*)(b + o_r), (hop_intra_chroma_result*)(b + o_q), (int32_t*)(b + o_o), (int16_t*)(b + o_k));
+    if (r) return r;
+    std::vector<hop_intra_chroma_result> cr(m); std::vector<int32_t> co((size_t)m * cu3); std::vector<int16_t> rk((size_t)m * h2x2);
+    HIPCHK(c, hipMemcpyAsync(rr.data(), b + o_r, (size_t)m * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cr.data(), b + o_q, (size_t)m * sizeof(hop_intra_chroma_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(co.data(), b + o_o, (size_t)m * cu3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rk.data(), b + o_k, (size_t)m * h2x2 * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < m; t++) {
+      results[idx[t]] = rr[t]; cresults[idx[t]] = cr[t];
+      memcpy(coef_out + coff[idx[t]] + cu2, co.data() + (size_t)t * cu3 + cu2, (cu2 >> 1) * 4);
+      memcpy(reco_out + roff[idx[t]], rk.data() + (size_t)t * h2x2, h2x2 * 2);
+    }
+  }
+  return HOP_OK;
+}
+
 int hop_inter_cu_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results, const int32_t* d_coef,
                              const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out,
                              hop_cabac_cu_ctx* d_cu_ctx_out) {

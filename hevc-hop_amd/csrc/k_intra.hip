@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void k_intra_pred_chroma(const hop_intra_job* 
   const hop_intra_job* jp = jobs + bi;
   const int tid = threadIdx.x;
   const int N = jp->size, x0 = jp->x >> 1, y0 = jp->y >> 1, pitch = pic.pic_w >> 1;
+  if (N == 0) return;                                                  // an empty slot of a batch (hop_intra_chroma_search: a CU without a transform unit at this node)
   const int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
   const int maxVal = (1 << pic.bd_c) - 1, mode = modes[bi];
   intra_setup_plane(sh, jp, comp == 1 ? rec_cb : rec_cr, pitch, pic.bd_c, 2, x0, y0, nullptr, false, tid);

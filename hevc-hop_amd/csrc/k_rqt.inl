@@ -1076,3 +1076,251 @@ int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_m
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+// =====================================================================================================================
+// The chroma intra search of a CU: TEncSearch::estIntraPredChromaQT (TLibEncoder/TEncSearch.cpp:2720-2785) with xRecurIntraChromaCodingQT (:2130-2277) for a batch of
+// CUs of one class.  Per allowed direction (k_ic_mode) the host walks every node a luma tree of the class can have; at a node the CUs whose tree has a transform unit
+// there take part (the others are empty slots of the batches):
+//   k_ic_begin     prediction job (both planes; flags of the node, per 2-sample unit) and the leaf jobs of the component - for blocks that may skip the transform also
+//                  the transform-skip variant -, the coder of the CU as snapshot (CI_QT_TRAFO_ROOT)
+//   hop_launch_intra_pred_chroma (once per node), hop_launch_tu_rd (is_intra; the transform-skip variant first, its block parked by k_ic_park)
+//   k_ic_single    one lane per CU: cbf, distortion; for transform-skip candidates the two costs from xGetIntraBitsQTChroma (levels of the block through the counting
+//                  coder), the better variant kept and the coder moved on (:2176-2247) - Cb first, Cr from the state Cb left
+//   k_ic_fold      cbf of the children folded upwards (:2262-2275)
+// then k_ic_bits (the CU's chroma bits from the CI_CURR_BEST state, the cost, the comparison) and k_ic_keep (xSetIntraResultChromaQT: levels, reconstruction, arrays).
+// =====================================================================================================================
+struct IcWork { double best_cost; uint32_t best_dist, dist; int32_t best_mode, mode, keep, dir; uint8_t cbf[2][256], ts[2][256]; };
+
+__device__ static inline bool ic_leaf_here(const RqtClass& k, const hop_rqt_result* r, int part, int d) {   // does the CU's luma tree have the chroma block of this node?
+  if (r->tr_idx[part] != d) return false;
+  if (k.log2_cu - d == 2) { const int parts = 1 << (2 * (k.log2_cu - 2)); return (part % (parts >> (2 * (d - 1)))) == 0; }
+  return true;
+}
+__device__ static inline bool ic_ts_here(const RqtClass& k, const hop_rqt_result* r, int part, int d, int ts_fast) {   // checkTransformSkip, :2158-2174
+  const int log2 = k.log2_cu - d;
+  if (!k.use_ts || log2 > 3) return false;
+  if (!ts_fast) return true;
+  if (log2 >= 3) return false;
+  int nb = 0; for (int p = part; p < part + 4; p++) nb += r->tskip[0][p];
+  return nb > 0;
+}
+
+__global__ void k_ic_mode(int m, const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, hop_cabac_ctx* __restrict__ cur,
+                          hop_intra_cu_syntax* __restrict__ syn, IcWork* __restrict__ work) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int list[5] = { 0, 26, 10, 1, 36 };                                   // getAllowedChromaDir, TComDataCU.cpp:1746-1764
+  for (int q = 0; q < 4; q++) if (syn[i].luma_dir[0] == list[q]) { list[q] = 34; break; }
+  const int mode = list[m];
+  syn[i].chroma_is_dm = mode == 36; syn[i].chroma_dir = mode;
+  cur[i] = ctx_in[jobs[i].ctx_index];
+  IcWork* w = work + i;
+  if (m == 0) { w->best_cost = 1.7e+308; w->best_dist = 0; w->best_mode = 0; }
+  w->dist = 0; w->mode = mode; w->keep = 0; w->dir = mode == 36 ? syn[i].luma_dir[0] : mode;
+}
+
+__global__ void k_ic_begin(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, const hop_intra_rqt_opt* __restrict__ opt,
+                           int n, int bd_c, const hop_cabac_ctx* __restrict__ cur, hop_cabac_ctx* __restrict__ root, const hop_rqt_result* __restrict__ res,
+                           const IcWork* __restrict__ work, hop_intra_job* __restrict__ pj, int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off,
+                           hop_tu_rd_job* __restrict__ tuj2, int64_t* __restrict__ off2, size_t ts_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  hop_intra_job q0; memset(&q0, 0, sizeof(q0));
+  hop_tu_rd_job j0; memset(&j0, 0, sizeof(j0));
+  const hop_rqt_result* r = res + i;
+  if (!ic_leaf_here(k, r, nd.part, nd.d)) { if (comp == 1) { pj[i] = q0; modes[i] = 0; } tuj[i] = j0; off[i] = 0; tuj2[i] = j0; off2[i] = 0; return; }
+  root[i] = cur[i];
+  const hop_rqt_job jb = jobs[i];
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  const int da = nd.log2 == 2 ? nd.d - 1 : nd.d, lgc = k.log2_cu - da - 1, N = 1 << lgc;
+  if (comp == 1) {
+    hop_intra_job q = q0;
+    q.x = jb.x + rqt_zx(nd.part); q.y = jb.y + rqt_zy(nd.part); q.size = N; q.strong = 0;
+    const unsigned long long av = opt[i].avail[irq_node_index(da, k.log2_cu - da, nd.part)];
+    for (int u = 0; u < 4 * (N / 2) + 1 && u < 68; u++) q.flags[u] = (uint8_t)((av >> u) & 1ull);
+    pj[i] = q; modes[i] = work[i].dir;
+  }
+  hop_tu_rd_job j = j0;
+  j.x = jb.x + rqt_zx(nd.part); j.y = jb.y + rqt_zy(nd.part); j.comp = comp; j.log2_size = lgc; j.qp_scaled = jb.qp_scaled[comp]; j.tr_depth = nd.d; j.ctx_index = i;
+  j.sign_hide = k.sign_hide; j.use_ts = k.use_ts; j.bit_depth = bd_c; j.is_intra = 1; j.scan_idx = icu_scan(syn[i], parts, nd.part, lgc, comp); j.use_dst = 0; j.flags = 0;
+  j.lambda_rdoq = jb.lambda_rdoq[comp]; j.lambda_rd = jb.lambda_rd; j.dist_weight = jb.dist_weight[comp - 1];
+  tuj[i] = j; off[i] = (int64_t)rqt_coef_at(k, i, k.log2_max_tu - nd.log2, comp, nd.part);
+  if (ic_ts_here(k, r, nd.part, nd.d, opt[i].ts_fast)) { j.flags = HOP_TU_RD_TS; tuj2[i] = j; off2[i] = (int64_t)(ts_base + (size_t)i * 16); }
+  else { tuj2[i] = j0; off2[i] = 0; }
+}
+
+// the 4x4 block of the transform-skip variant, picture -> park
+__global__ __launch_bounds__(64) void k_ic_park(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_rqt_opt* __restrict__ opt, int n,
+                                                const hop_rqt_result* __restrict__ res, const int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ park) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 4), e = threadIdx.x & 15;
+  if (i >= n) return;
+  if (!ic_leaf_here(k, res + i, nd.part, nd.d) || !ic_ts_here(k, res + i, nd.part, nd.d, opt[i].ts_fast)) return;
+  park[(size_t)i * 16 + e] = rec[(size_t)(((jobs[i].y + rqt_zy(nd.part)) >> 1) + (e >> 2)) * pitch + ((jobs[i].x + rqt_zx(nd.part)) >> 1) + (e & 3)];
+}
+
+__global__ __launch_bounds__(64) void k_ic_single(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                  const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, const hop_cabac_ctx* __restrict__ root,
+                                                  hop_rqt_result* __restrict__ res, IcWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr,
+                                                  const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base, int16_t* __restrict__ rec, int pitch,
+                                                  const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  hop_rqt_result* r = res + i;
+  if (!ic_leaf_here(k, r, nd.part, nd.d)) return;
+  IcWork* w = work + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), da = nd.log2 == 2 ? nd.d - 1 : nd.d, nparts = parts >> (2 * da), lgc = k.log2_cu - da - 1, part = nd.part;
+  const uint32_t cbf0 = tr[i].abs_sum ? 1u : 0u;
+  for (int p = 0; p < nparts; p++) { r->cbf[comp][part + p] = (uint8_t)(cbf0 << nd.d); r->tskip[comp][part + p] = 0; }
+  if (!ic_ts_here(k, r, nd.part, nd.d, opt[i].ts_fast)) { w->dist += tr[i].dist; return; }
+  const double lambda = jobs[i].lambda_rd;
+  const int scan = icu_scan(syn[i], parts, part, lgc, comp);
+  int32_t* lv = coef + rqt_coef_at(k, i, k.log2_max_tu - nd.log2, comp, part); int32_t* tv = coef + ts_base + (size_t)i * 16;
+  RQ_LOAD(root[i]);
+  unsigned long long frac = RQ_LEFT();
+  frac += cb_code_tu(sh, lane, lv, lgc, 1, scan, k.sign_hide, k.use_ts, 0, 0, scans);
+  double cost = rqt_cost((uint32_t)(frac >> 15), tr[i].dist, lambda);
+  uint32_t dist = tr[i].dist;
+  if (tr2[i].abs_sum) {
+    rqt_store(sh, lane, frac, cur + i);                                 // CI_TEMP_BEST
+    RQ_LOAD(root[i]);
+    unsigned long long f1 = RQ_LEFT();
+    f1 += cb_code_tu(sh, lane, tv, lgc, 1, scan, k.sign_hide, k.use_ts, 1, 0, scans);
+    const double cost1 = rqt_cost((uint32_t)(f1 >> 15), tr2[i].dist, lambda);
+    if (cost1 < cost) {
+      dist = tr2[i].dist;
+      for (int e = 0; e < 16; e++) lv[e] = tv[e];
+      for (int p = 0; p < nparts; p++) { r->cbf[comp][part + p] = (uint8_t)(1u << nd.d); r->tskip[comp][part + p] = 1; }
+      int16_t* pic = rec + (size_t)((jobs[i].y + rqt_zy(part)) >> 1) * pitch + ((jobs[i].x + rqt_zx(part)) >> 1);
+      for (int e = 0; e < 16; e++) pic[(size_t)(e >> 2) * pitch + (e & 3)] = park[(size_t)i * 16 + e];
+      rqt_store(sh, lane, f1, cur + i);
+    }
+  } else rqt_store(sh, lane, frac, cur + i);
+  w->dist += dist;
+}
+
+__global__ void k_ic_fold(RqtClass k, RqtNode nd, int n, hop_rqt_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  hop_rqt_result* r = res + i;
+  if (r->tr_idx[nd.part] <= nd.d) return;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), q = nparts >> 2;
+  unsigned su = 0, sv = 0;
+  for (int kk = 0; kk < 4; kk++) { su |= (r->cbf[1][nd.part + kk * q] >> (nd.d + 1)) & 1u; sv |= (r->cbf[2][nd.part + kk * q] >> (nd.d + 1)) & 1u; }
+  for (int p = 0; p < nparts; p++) { r->cbf[1][nd.part + p] |= (uint8_t)(su << nd.d); r->cbf[2][nd.part + p] |= (uint8_t)(sv << nd.d); }
+}
+
+__global__ __launch_bounds__(64) void k_ic_bits(RqtClass k, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
+                                                const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_rqt_result* __restrict__ res,
+                                                IcWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const int ci = jobs[i].ctx_index;
+  RQ_LOAD(ctx_in[ci]); IRQ_CU_LOAD(cu_in[ci]);
+  unsigned long long frac = RQ_LEFT();
+  frac += icu_count(sh, lane, k, syn[i], 0, 0, 0, 1, res + i, nullptr, coef, i, scans);
+  IcWork* w = work + i;
+  const double cost = rqt_cost((uint32_t)(frac >> 15), w->dist, jobs[i].lambda_rd);
+  if (cost < w->best_cost) { w->best_cost = cost; w->best_dist = w->dist; w->best_mode = w->mode; w->keep = 1; }
+}
+
+// xSetIntraResultChromaQT (:2280-2345) for the CUs whose direction of this pass is the best so far
+__global__ __launch_bounds__(64) void k_ic_keep(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, const hop_rqt_result* __restrict__ res, IcWork* __restrict__ work,
+                                                const int32_t* __restrict__ coef, const int16_t* __restrict__ rec_cb, const int16_t* __restrict__ rec_cr, int pitch,
+                                                int32_t* __restrict__ coef_out, int16_t* __restrict__ reco_out) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  if (!work[i].keep) return;
+  const int cu = 1 << k.log2_cu, half = cu >> 1, parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)cu * cu, h2 = cu2 >> 2;
+  const hop_rqt_result* r = res + i;
+  for (int e = t; e < parts; e += 64) { work[i].cbf[0][e] = r->cbf[1][e]; work[i].cbf[1][e] = r->cbf[2][e]; work[i].ts[0][e] = r->tskip[1][e]; work[i].ts[1][e] = r->tskip[2][e]; }
+  for (int comp = 1; comp <= 2; comp++) {
+    for (int e = t; e < (int)h2; e += 64) {                            // chroma level e of the CU layout: partition e / 4; its block starts at the first partition of the chroma TU
+      const int p = e >> 2, d = r->tr_idx[p], log2 = k.log2_cu - d, dd = log2 == 2 ? d - 1 : d, np = parts >> (2 * dd), first = p - p % np;
+      coef_out[(size_t)i * (cu2 + 2 * h2) + cu2 + (size_t)(comp - 1) * h2 + e] = coef[rqt_coef_at(k, i, k.log2_max_tu - log2, comp, first) + (size_t)(e - 4 * first)];
+    }
+    const int16_t* pic = (comp == 1 ? rec_cb : rec_cr) + (size_t)(jobs[i].y >> 1) * pitch + (jobs[i].x >> 1);
+    for (int e = t; e < (int)h2; e += 64) { const int rr = e / half, cc = e % half; reco_out[(size_t)i * 2 * h2 + (size_t)(comp - 1) * h2 + e] = pic[(size_t)rr * pitch + cc]; }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_ic_commit(RqtClass k, int n, const IcWork* __restrict__ work, hop_rqt_result* __restrict__ res, hop_intra_chroma_result* __restrict__ cres) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  for (int e = t; e < parts; e += 64) { res[i].cbf[1][e] = work[i].cbf[0][e]; res[i].cbf[2][e] = work[i].cbf[1][e]; res[i].tskip[1][e] = work[i].ts[0][e]; res[i].tskip[2][e] = work[i].ts[1][e]; }
+  if (t == 0) { cres[i].best_mode = work[i].best_mode; cres[i].dist = work[i].best_dist; }
+}
+
+size_t hop_intra_chroma_work_bytes(int log2_cu, int n) {
+  const size_t cu2 = (size_t)1 << (2 * log2_cu);
+  return (size_t)n * (2 * sizeof(hop_cabac_ctx) + sizeof(hop_intra_cu_syntax) + sizeof(IcWork) + sizeof(hop_intra_job) + 4 + 2 * (sizeof(hop_tu_rd_job) + 8 + sizeof(hop_tu_rd_result)) +
+                     (6 * cu2 + 16) * 4 + 32) + 32 * 256;
+}
+
+// one class of CUs (size, transform-tree limits / flags); d_res: tr_idx and tskip[0] as the luma search left them (read), cbf[1..2] / tskip[1..2] (written)
+int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
+                                   const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
+                                   hop_rqt_result* d_res, hop_intra_chroma_result* d_cres, int32_t* d_coef_out, int16_t* d_reco_out, void* vbuf, size_t buf_bytes) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t cu2 = (size_t)1 << (2 * log2_cu), n_coeff = (size_t)n * (6 * cu2 + 16), ts_base = (size_t)n * 6 * cu2;
+  char* buf = (char*)vbuf; size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
+  struct Bufs { hop_cabac_ctx *cur, *root; hop_intra_cu_syntax* syn; IcWork* work; hop_intra_job* pj; int32_t* modes; hop_tu_rd_job *tuj, *tuj2; int64_t *off, *off2;
+                hop_tu_rd_result *tr, *tr2; int32_t* coef; int16_t* park; size_t n_coeff, ts_base; } B;
+  B.cur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); B.root = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx));
+  B.syn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax)); B.work = (IcWork*)take((size_t)n * sizeof(IcWork));
+  B.pj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job)); B.modes = (int32_t*)take((size_t)n * 4);
+  B.tuj = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job)); B.tuj2 = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job));
+  B.off = (int64_t*)take((size_t)n * 8); B.off2 = (int64_t*)take((size_t)n * 8);
+  B.tr = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result)); B.tr2 = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result));
+  B.coef = (int32_t*)take(n_coeff * 4); B.park = (int16_t*)take((size_t)n * 32);
+  B.n_coeff = n_coeff; B.ts_base = ts_base;
+  if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra chroma search: work buffer too small");
+  hipError_t e = hipMemcpyAsync(B.syn, d_syn_in, (size_t)n * sizeof(hop_intra_cu_syntax), hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search: %s", hipGetErrorString(e));
+  e = hipMemsetAsync(B.coef, 0, n_coeff * 4, c->stream);
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search: %s", hipGetErrorString(e));
+  const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, pitch = c->pic_w >> 1;
+  struct Rec { static int go(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job* d_jobs, const hop_intra_rqt_opt* d_opt, hop_rqt_result* d_res, Bufs& B, int part, int d, int log2) {
+    RqtNode nd; memset(&nd, 0, sizeof(nd));
+    nd.part = part; nd.d = d; nd.log2 = log2;
+    const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, pitch = c->pic_w >> 1;
+    const bool may_ts = k.use_ts && log2 <= 3;
+    if (log2 <= k.log2_max_tu && !(log2 == 2 && (part & 3))) {          // a transform unit can sit here (4x4 luma: the chroma block belongs to the first of four)
+      for (int comp = 1; comp <= 2; comp++) {
+        hipLaunchKernelGGL(k_ic_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, comp, d_jobs, B.syn, d_opt, n, c->bd_c, B.cur, B.root, d_res, B.work, B.pj, B.modes, B.tuj, B.off,
+                           B.tuj2, B.off2, B.ts_base);
+        int r;
+        if (comp == 1) { r = hop_launch_intra_pred_chroma(c, n, B.pj, B.modes); if (r) return r; }
+        if (may_ts) {
+          r = hop_launch_tu_rd(c, n, B.tuj2, B.cur, B.off2, B.n_coeff, B.coef, B.tr2, 1); if (r) return r;
+          hipLaunchKernelGGL(k_ic_park, dim3((n + 3) / 4), dim3(64), 0, c->stream, k, nd, d_jobs, d_opt, n, d_res, c->rec[comp], pitch, B.park);
+        }
+        const int lgc = log2 == 2 ? 2 : log2 - 1;
+        r = hop_launch_tu_rd(c, n, B.tuj, B.cur, B.off, B.n_coeff, B.coef, B.tr, lgc <= 3 ? 1 : 0); if (r) return r;
+        hipLaunchKernelGGL(k_ic_single, dim3(g64), dim3(64), 0, c->stream, k, nd, comp, d_jobs, B.syn, d_opt, n, B.cur, B.root, d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base,
+                           c->rec[comp], pitch, B.park, c->rdoq_scans);
+      }
+    }
+    if (log2 > k.log2_min_tu) {
+      const int q = ((1 << (2 * (k.log2_cu - 2))) >> (2 * d)) >> 2;
+      for (int kk = 0; kk < 4; kk++) { const int r = go(c, k, n, d_jobs, d_opt, d_res, B, part + kk * q, d + 1, log2 - 1); if (r) return r; }
+      hipLaunchKernelGGL(k_ic_fold, dim3(g256), dim3(256), 0, c->stream, k, nd, n, d_res);
+    }
+    (void)g64;
+    return HOP_OK;
+  } };
+  for (int m = 0; m < 5; m++) {
+    hipLaunchKernelGGL(k_ic_mode, dim3(g256), dim3(256), 0, c->stream, m, d_jobs, n, d_ctx_in, B.cur, B.syn, B.work);
+    const int rc = Rec::go(c, k, n, d_jobs, d_opt, d_res, B, 0, 0, k.log2_cu);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ic_bits, dim3(g64), dim3(64), 0, c->stream, k, d_jobs, B.syn, n, d_ctx_in, d_cu_in, d_res, B.work, B.coef, c->rdoq_scans);
+    hipLaunchKernelGGL(k_ic_keep, dim3(n), dim3(64), 0, c->stream, k, d_jobs, n, d_res, B.work, B.coef, c->rec[1], c->rec[2], pitch, d_coef_out, d_reco_out);
+  }
+  hipLaunchKernelGGL(k_ic_commit, dim3(n), dim3(64), 0, c->stream, k, n, B.work, d_res, d_cres);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

@@ -366,6 +366,18 @@ class Context:
                                                cu_ctx_in.ctypes.data, sres.ctypes.data, res.ctypes.data, coef.ctypes.data, reco.ctypes.data), "hop_intra_luma_search")
         return sres, res, coef, reco
 
+    def intra_chroma_search(self, jobs, syntax, opts, res, ctx_in, cu_ctx_in):
+        """estIntraPredChromaQT: res holds tr_idx / tskip[0] of the luma search; returns (mode, dist) pairs, the arrays incl. cbf[1..2] / tskip[1..2], levels (1.5 size^2 per
+        job, the chroma parts filled) and the chroma reconstruction planes (size^2 / 2 per job: Cb, Cr)"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, INTRA_CU_SYNTAX_DTYPE); opts = np.ascontiguousarray(opts, INTRA_RQT_OPT_DTYPE)
+        res = np.ascontiguousarray(res, RQT_RESULT_DTYPE).copy(); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); cres = np.zeros(n, np.dtype([("best_mode", "<i4"), ("dist", "<u4")]))
+        coef = np.zeros(int(sum((3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs)), np.int32); reco = np.zeros(int(sum((1 << (2 * int(j["log2_cu"]))) // 2 for j in jobs)), np.int16)
+        self.L.hop_intra_chroma_search.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 6
+        self._chk(self.L.hop_intra_chroma_search(self.h, n, jobs.ctypes.data, syntax.ctypes.data, opts.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data,
+                                                 res.ctypes.data, cres.ctypes.data, coef.ctypes.data, reco.ctypes.data), "hop_intra_chroma_search")
+        return cres, res, coef, reco
+
     def intra_pred(self, jobs, modes):
         n = len(jobs)
         arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)

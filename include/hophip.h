@@ -478,6 +478,22 @@ int hop_intra_luma_search(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const ho
 int hop_intra_luma_search_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, int part_nxn, int num_full_rd, const hop_intra_cu_syntax* d_syntax,
                                  const hop_intra_rqt_opt* d_opts, const hop_intra_search_job* d_sjobs, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in,
                                  hop_intra_search_result* d_sresults, hop_rqt_result* d_results, int32_t* d_coef_out, int16_t* d_reco_out);
+/* ---- chroma intra search of a CU (row a8) ---- */
+/* replaces: TEncSearch::estIntraPredChromaQT (TLibEncoder/TEncSearch.cpp:2720-2785) with xRecurIntraChromaCodingQT (:2130-2277) for a batch of CUs: the five allowed
+ * chroma directions (TComDataCU::getAllowedChromaDir, TComDataCU.cpp:1746-1764), each coded along the luma transform tree -- xIntraCodingChromaBlk per block and plane
+ * (:1164-1330: hop_intra_pred_chroma + the intra leaf with the chroma quantiser, lambda and distortion weight), for 4x4 blocks also as transform-skip blocks, the better
+ * variant by its xGetIntraBitsQTChroma cost (:2176-2247) --, then the CU's chroma bits from the CI_CURR_BEST state (xGetIntraBitsQT, chroma only) and the cost; the best
+ * direction kept as xSetIntraResultChromaQT keeps it (:2280-2345).  jobs / syntax (luma directions decided, part_nxn, skip flag ...) / opts (ts_fast, avail) as for the luma
+ * search; results on entry: tr_idx and tskip[0] of the luma search; on return also cbf[1..2] and tskip[1..2].  The chroma reconstruction pictures are read and written as
+ * the search goes (afterwards they hold what the last direction tested left, as in the reference).  The CUs of one call must not lie in each other's neighbourhood. */
+typedef struct { int32_t best_mode; uint32_t dist; } hop_intra_chroma_result;   /* getChromaIntraDir (0 / 26 / 10 / 1 / 34, or 36 = DM_CHROMA_IDX), uiBestDist */
+/* coef_out: per job 1.5 * size^2 entries, the two chroma parts (getCoeffCb / getCoeffCr) written; reco_out: per job size^2 / 2 samples, Cb then Cr (pcRecoYuv) */
+int hop_intra_chroma_search(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, int n_ctx, const hop_cabac_ctx* ctx_in,
+                            const hop_cabac_cu_ctx* cu_ctx_in, hop_rqt_result* results, hop_intra_chroma_result* cresults, int32_t* coef_out, int16_t* reco_out);
+/* device-resident form: all n CUs of ONE class (size, transform-tree limits / flags of *cls); asynchronous, unchecked */
+int hop_intra_chroma_search_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_intra_cu_syntax* d_syntax, const hop_intra_rqt_opt* d_opts,
+                                   const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, hop_rqt_result* d_results, hop_intra_chroma_result* d_cresults,
+                                   int32_t* d_coef_out, int16_t* d_reco_out);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -880,3 +880,58 @@ def test_intra_luma_search_random_vs_oracle(hp):
         assert np.array_equal(R, R2), bd
         assert nxn_n >= 4, (bd, nxn_n, final_better)
         ctx.close()
+
+
+def test_intra_chroma_search_encoder_calls(hp):
+    """hop_intra_chroma_search (estIntraPredChromaQT: the five allowed directions along the luma tree, chroma leaf per plane, transform-skip retry per component, the CU's
+    chroma bits, the best kept) on the 44 calls recorded inside the encoder, each in its own tile: direction, distortion, cbf / transform-skip arrays, chroma levels,
+    reconstruction planes and the chroma pictures afterwards"""
+    from goldutil import encoder_csearch_calls
+    cases = list(encoder_csearch_calls())
+    n = len(cases); T = 192; G = 7; W = H = T * G
+    assert n <= G * G
+    C = [np.zeros((H // 2, W // 2), np.int16) for _ in range(2)]; R = [np.zeros((H // 2, W // 2), np.int16) for _ in range(2)]
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(n, hp.INTRA_RQT_OPT_DTYPE); res = np.zeros(n, hp.RQT_RESULT_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; j = jobs[i]; cu = 1 << int(cfg["log2_cu"]); half = cu // 2; Wn = cu + 1
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        for k in range(2):
+            C[k][y0 // 2:y0 // 2 + half, x0 // 2:x0 // 2 + half] = c["org"].reshape(2, half, half)[k]
+            R[k][y0 // 2 - 1:y0 // 2 - 1 + Wn, x0 // 2 - 1:x0 // 2 - 1 + Wn] = c["win"].reshape(2, Wn, Wn)[k]
+        j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x0, y0, int(cfg["log2_cu"]), cfg["qp"], i
+        j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"]
+        j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = cfg["lambda_rd"], cfg["lambda_rdoq"], cfg["dist_weight"][1:]
+        for k in ("part_nxn", "skip_flag", "skip_ctx", "is_min_cu", "luma_dir", "preds", "pred_num", "chroma_is_dm", "chroma_dir"): syn[i][k] = c["syn"][k]
+        opts[i]["ts_fast"] = c["nd"][0]
+        av = c["avail"].reshape(341, 36).astype(np.uint64)
+        opts[i]["avail"] = (av << np.arange(36, dtype=np.uint64)[None, :]).sum(axis=1)
+        a = c["ain"].reshape(7, 256); res[i]["tr_idx"] = a[0]; res[i]["cbf"] = a[1:4]; res[i]["tskip"] = a[4:7]
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i] = c["cuin"]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(np.zeros((H, W), np.int16), C[0], C[1])
+    for k in range(2): ctx.plane_upload("recon", 1 + k, R[k])
+    cres, res2, coef, reco = ctx.intra_chroma_search(jobs, syn, opts, res, snaps, cus)
+    R2 = [ctx.recon_download(1), ctx.recon_download(2)]
+    o = ro = 0; kinds = set()
+    for i, c in enumerate(cases):
+        cu = 1 << int(c["cfg"]["log2_cu"]); half = cu // 2; parts = (cu // 4) ** 2
+        tag = (i, cu, int(c["ain"][:parts].max()))
+        assert int(cres[i]["best_mode"]) == c["mode"] and int(cres[i]["dist"]) == c["dist"], (tag, cres[i], c["mode"], c["dist"])
+        a = c["aout"].reshape(7, 256)
+        assert np.array_equal(res2[i]["cbf"][1:, :parts], a[2:4, :parts]) and np.array_equal(res2[i]["tskip"][1:, :parts], a[5:7, :parts]), tag
+        assert np.array_equal(coef[o + cu * cu:o + cu * cu * 3 // 2], c["coef"]) and np.array_equal(reco[ro:ro + cu * cu // 2], c["reco"]), tag
+        x0, y0 = (i % G) * T + 64, (i // G) * T + 64
+        for k in range(2):
+            blk = c["rec"].reshape(2, half, half)[k]
+            assert np.array_equal(R2[k][y0 // 2:y0 // 2 + half, x0 // 2:x0 // 2 + half], blk), (tag, k)
+            R[k][y0 // 2:y0 // 2 + half, x0 // 2:x0 // 2 + half] = blk
+        kinds.add((cu, c["mode"], int(a[5:7, :parts].any()), int(a[0, :parts].max())))
+        o += cu * cu * 3 // 2; ro += cu * cu // 2
+    assert np.array_equal(R[0], R2[0]) and np.array_equal(R[1], R2[1])
+    assert len(kinds) >= 15 and any(k[2] for k in kinds)
+    bad = res.copy(); bad[0]["tr_idx"][0] = 7
+    with pytest.raises(hp.HopError):
+        ctx.intra_chroma_search(jobs, syn, opts, bad, snaps, cus)
+    ctx.close()

@@ -935,3 +935,61 @@ def test_intra_chroma_search_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.intra_chroma_search(jobs, syn, opts, bad, snaps, cus)
     ctx.close()
+
+
+def test_intra_chroma_search_random_vs_oracle(hp):
+    """hop_intra_luma_search followed by hop_intra_chroma_search on the random CUs of the luma tests (8 and 10 bit, every CU size, NxN, deeper trees, random availability),
+    with chroma planes of their own, chroma quantisers / lambdas / distortion weights that differ per plane, TransformSkipFast on and off: the chroma search against the
+    restatement fed with the same luma arrays"""
+    from goldutil import oracle_intra_chroma_search, INTRA_SYN
+    for bd in (8, 10):
+        W, H, Y, R, jobs, syn, opts, cfgs, snaps, cus, avs = _irqt_random_cases(hp, hp.load(), bd)
+        n = len(jobs); mid = 1 << (bd - 1); top = (1 << bd) - 1
+        rng = np.random.default_rng(110 + bd)
+        sj = np.zeros(n, hp.INTRA_SEARCH_JOB_DTYPE)
+        sj["left_dir"] = rng.integers(0, 35, (n, 4)); sj["above_dir"] = rng.integers(0, 35, (n, 4)); sj["rough_flags"] = 1
+        C = [np.full((H // 2, W // 2), mid, np.int16) for _ in range(2)]; RC = [rng.integers(0, top + 1, (H // 2, W // 2)).astype(np.int16) for _ in range(2)]
+        for i in range(n):
+            cu = 1 << int(jobs[i]["log2_cu"]); half = cu // 2; Wn = cu + 1; x0, y0 = int(jobs[i]["x"]) // 2, int(jobs[i]["y"]) // 2
+            sj[i]["sqrt_lambda"] = float(np.sqrt(jobs[i]["lambda_rd"])); sj[i]["num_full_rd"] = 8 if (cu >> int(syn[i]["part_nxn"])) <= 8 else 3
+            for k in range(2):
+                amp = float(rng.choice([15, 40, 80])) * (1 << (bd - 8))
+                f = gaussian_filter(rng.normal(0, 1, (Wn + 16, Wn + 16)), float(rng.choice([1.0, 2.5, 5])))[8:-8, 8:-8]
+                f = mid + amp * f / max(1e-9, float(np.abs(f).max()))
+                if rng.random() < 0.5:
+                    m = rng.random(f.shape) < 0.06; f[m] += rng.choice([-1, 1], int(m.sum())) * 2.5 * amp
+                f = np.clip(np.rint(f), 0, top).astype(np.int16)
+                C[k][y0:y0 + half, x0:x0 + half] = f[1:1 + half, 1:1 + half]
+                RC[k][y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn] = np.clip(f + rng.integers(-2, 3, f.shape), 0, top)
+            qp = int(jobs[i]["qp_scaled"][0]); w = (float(rng.choice([1.0, 1.26, 1.59])), float(rng.choice([1.0, 1.26])))
+            jobs[i]["qp_scaled"] = (qp, max(6 * (bd - 8), qp - int(rng.integers(0, 4))), max(6 * (bd - 8), qp - int(rng.integers(0, 6))))
+            lam = float(jobs[i]["lambda_rd"]); jobs[i]["lambda_rdoq"] = (lam, lam / w[0], lam / w[1]); jobs[i]["dist_weight"] = w
+            cfgs[i]["qp"] = jobs[i]["qp_scaled"]; cfgs[i]["lambda_rdoq"] = jobs[i]["lambda_rdoq"]; cfgs[i]["dist_weight"] = (1.0, w[0], w[1])
+        ctx = hp.Context(W, H, bd)
+        ctx.upload_orig(Y, C[0], C[1])
+        ctx.plane_upload("recon", 0, R)
+        for k in range(2): ctx.plane_upload("recon", 1 + k, RC[k])
+        sres, res, coef_y, reco_y = ctx.intra_luma_search(jobs, syn, opts, sj, snaps, cus)
+        syn2 = syn.copy(); syn2["luma_dir"] = sres["best_dir"]
+        cres, res2, coef, reco = ctx.intra_chroma_search(jobs, syn2, opts, res, snaps, cus)
+        R2 = [ctx.recon_download(1), ctx.recon_download(2)]
+        o = ro = 0; ts = 0; modes = set()
+        for i in range(n):
+            c = cfgs[i]; cu = 1 << int(c["log2_cu"]); half = cu // 2; Wn = cu + 1; parts = (cu // 4) ** 2
+            x0, y0 = int(jobs[i]["x"]) // 2, int(jobs[i]["y"]) // 2
+            osyn = np.zeros(1, INTRA_SYN)
+            for k in INTRA_SYN.names: osyn[0][k] = syn2[i][k]
+            coder = snaps[i, :150].tobytes() + b"\0\0" + (int(snaps[i, 150]) | (int(snaps[i, 151]) << 8)).to_bytes(8, "little")
+            arr_in = np.concatenate([res[i]["tr_idx"][None, :], res[i]["cbf"], res[i]["tskip"]]).reshape(-1)
+            org = np.concatenate([C[k][y0:y0 + half, x0:x0 + half].reshape(-1) for k in range(2)]); win = np.concatenate([RC[k][y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn].reshape(-1) for k in range(2)])
+            mode, dist, arr, ocoef, oreco, owin = oracle_intra_chroma_search(c, osyn[0], int(opts[i]["ts_fast"]), avs[i], org, win, arr_in, np.frombuffer(coder, np.uint8), cus[i])
+            tag = (bd, i, cu, int(res[i]["tr_idx"][:parts].max()))
+            assert int(cres[i]["best_mode"]) == mode and int(cres[i]["dist"]) == dist, (tag, cres[i], mode, dist)
+            assert np.array_equal(res2[i]["cbf"][1:, :parts], arr[2:4, :parts]) and np.array_equal(res2[i]["tskip"][1:, :parts], arr[5:7, :parts]), tag
+            assert np.array_equal(coef[o + cu * cu:o + cu * cu * 3 // 2], ocoef) and np.array_equal(reco[ro:ro + cu * cu // 2], oreco), tag
+            for k in range(2): RC[k][y0 - 1:y0 - 1 + Wn, x0 - 1:x0 - 1 + Wn] = owin.reshape(2, Wn, Wn)[k]
+            ts += int(arr[5:7, :parts].any()); modes.add(mode)
+            o += cu * cu * 3 // 2; ro += cu * cu // 2
+        assert np.array_equal(RC[0], R2[0]) and np.array_equal(RC[1], R2[1]), bd
+        assert ts >= 3 and len(modes) >= 4, (bd, ts, modes)
+        ctx.close()

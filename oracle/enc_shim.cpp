@@ -960,6 +960,62 @@ Void TEncSearch::estIntraPredChromaQT(TComDataCU* pcCU, TComYuv* pcOrgYuv, TComY
   m_pcRDGoOnSbacCoder->load(best);
 }
 
+// ---- an intra CU candidate: TEncCu::xCheckRDCostIntra (TLibEncoder/TEncCu.cpp:1455-1507) - the searches as the reference calls them, the CU's bits -> hop_o_intra_cu_total_bits ----
+extern "C" void hop_ref_orig_check_intra(TEncCu*, TComDataCU*&, TComDataCU*&, PartSize);
+namespace { unsigned long g_calls14[1] = { 0 };
+struct Report14 { ~Report14() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: intraCu %lu\n", g_calls14[0]); } } g_report14; }
+
+Void TEncCu::xCheckRDCostIntra(TComDataCU*& rpcBestCU, TComDataCU*& rpcTempCU, PartSize eSize)
+{
+  static const bool orig = hand_back("xCheckRDCostIntra");
+  if (orig) { hop_ref_orig_check_intra(this, rpcBestCU, rpcTempCU, eSize); return; }
+  TComSlice* sl = rpcTempCU->getSlice();
+  if (sl->getPPS()->getTransquantBypassEnableFlag() || sl->getSPS()->getUsePCM() || getdQPFlag() || sl->isIntra()) {
+    fprintf(stderr, "hop shim: xCheckRDCostIntra is replaced without transquant bypass, PCM, cu_qp_delta, for ISS slices\n"); abort();
+  }
+  g_calls14[0]++;
+  const UInt uiDepth = rpcTempCU->getDepth(0);
+  rpcTempCU->setSkipFlagSubParts(false, 0, uiDepth);
+  rpcTempCU->setPartSizeSubParts(eSize, 0, uiDepth);
+  rpcTempCU->setPredModeSubParts(MODE_INTRA, 0, uiDepth);
+  UInt uiPreCalcDistC = 0;
+  m_pcPredSearch->estIntraPredQT(rpcTempCU, m_ppcOrigYuv[uiDepth], m_ppcPredYuvTemp[uiDepth], m_ppcResiYuvTemp[uiDepth], m_ppcRecoYuvTemp[uiDepth], uiPreCalcDistC, true);
+  m_ppcRecoYuvTemp[uiDepth]->copyToPicLuma(rpcTempCU->getPic()->getPicYuvRec(), rpcTempCU->getAddr(), rpcTempCU->getZorderIdxInCU());
+  m_pcPredSearch->estIntraPredChromaQT(rpcTempCU, m_ppcOrigYuv[uiDepth], m_ppcPredYuvTemp[uiDepth], m_ppcResiYuvTemp[uiDepth], m_ppcRecoYuvTemp[uiDepth], uiPreCalcDistC);
+  // the bits of the finished CU
+  hop_o_rqt_cfg cfg; hop_o_intra_syntax y; std::vector<uint8_t> avail;
+  intra_env(m_pcPredSearch, rpcTempCU, 0, 0, cfg, y, avail);
+  const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
+  hop_o_rqt_state st; memset(&st, 0, sizeof(st));
+  memcpy(st.tr_idx, rpcTempCU->m_puhTrIdx, parts);
+  for (int c = 0; c < 3; c++) { memcpy(st.cbf[c], rpcTempCU->m_puhCbf[c], parts); memcpy(st.tskip[c], rpcTempCU->m_puhTransformSkip[c], parts); }
+  std::vector<int32_t> coef((size_t)cu * cu * 3 / 2);
+  memcpy(&coef[0], rpcTempCU->getCoeffY(), (size_t)cu * cu * 4);
+  memcpy(&coef[(size_t)cu * cu], rpcTempCU->getCoeffCb(), (size_t)cu * cu); memcpy(&coef[(size_t)cu * cu * 5 / 4], rpcTempCU->getCoeffCr(), (size_t)cu * cu);
+  TEncSbac* sb = m_pcRDGoOnSbacCoder;
+  hop_o_coder coder; coder_get(sb, &coder);
+  uint8_t cuctx[20] = { 0 }; { CuSets2 r = cu_sets2(sb); uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  const hop_o_coder coder_in = coder; uint8_t cu_in[20]; memcpy(cu_in, cuctx, 20);
+  const uint32_t bits = hop_o_intra_cu_total_bits(&cfg, &y, &st, &coef[0], &coder, cuctx);
+  {                                                                 // HOP_SHIM_TRACE_INTRACU=<file>
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_INTRACU"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) {
+      fwrite(&cfg, sizeof(cfg), 1, f); fwrite(&y, sizeof(y), 1, f); fwrite(st.tr_idx, 1, 256, f); fwrite(st.cbf, 1, 768, f); fwrite(st.tskip, 1, 768, f);
+      fwrite(&coef[0], 4, coef.size(), f); fwrite(&coder_in, sizeof(coder_in), 1, f); fwrite(cu_in, 1, 20, f); fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 20, f);
+      const uint32_t o2[2] = { bits, (uint32_t)rpcTempCU->getTotalDistortion() }; fwrite(o2, 4, 2, f);
+    }
+  }
+  coder_put(sb, &coder);
+  { CuSets2 r = cu_sets2(sb); const uint8_t* d = cuctx; for (int i = 0; i < 11; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
+  m_pcRDGoOnSbacCoder->store(m_pppcRDSbacCoder[uiDepth][CI_TEMP_BEST]);
+  rpcTempCU->getTotalBits() = bits;
+  rpcTempCU->getTotalBins() = ((TEncBinCABAC*)((TEncSbac*)m_pcEntropyCoder->m_pcEntropyCoderIf)->getEncBinIf())->getBinsCoded();
+  rpcTempCU->getTotalCost() = hop_o_calc_rd_cost(bits, rpcTempCU->getTotalDistortion(), m_pcRdCost->m_dLambda);
+  xCheckDQP(rpcTempCU);
+  xCheckBestMode(rpcBestCU, rpcTempCU, uiDepth);
+}
+
 // ---- chroma intra prediction: TComPrediction::predIntraChromaAng (TLibCommon/TComPrediction.cpp:375-390) -> hop_o_intra_pred_chroma ----
 namespace { unsigned long g_calls10[1] = { 0 };
 struct Report10 { ~Report10() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: chromaPred %lu\n", g_calls10[0]); } } g_report10; }

@@ -373,8 +373,9 @@ static void part_size(Syn* s, const hop_o_cu_syntax* y, int log2_cu)
   if (y->is_min_cu && log2_cu != 3) { bin(s, CU_PART, 0); bin(s, CU_PART + 1, 0); bin(s, CU_PART + 2, 0); }      /* NxN */
 }
 /* xEncodeTransform */
-static void transform_tree(const hop_o_rqt_cfg* g, const hop_o_cu_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* c, int part, int trIdx, int log2,
-                           int* bakPart)
+static int tu_scan(const hop_o_intra_syntax* y, int parts, int part, int width, int comp);
+static void transform_tree(const hop_o_rqt_cfg* g, const hop_o_intra_syntax* iy /* NULL: an SS/GT ("inter") CU */, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* c,
+                           int part, int trIdx, int log2, int* bakPart)
 {
   const int parts = 1 << (2 * (g->log2_cu - 2)), cu2 = 1 << (2 * g->log2_cu);
   const int subdiv = st->tr_idx[part] > trIdx;
@@ -384,7 +385,8 @@ static void transform_tree(const hop_o_rqt_cfg* g, const hop_o_cu_syntax* y, con
     if (part % pn == 0) *bakPart = part;
     else if (part % pn == pn - 1) { cbfU = (st->cbf[1][*bakPart] >> trIdx) & 1; cbfV = (st->cbf[2][*bakPart] >> trIdx) & 1; }
   }
-  if (g->inter_split_flag && trIdx == 0) { /* QuadtreeTUMaxDepthInter == 1, partition != 2Nx2N: the split is inferred */ }
+  if (iy && iy->part_nxn && trIdx == 0) { /* intra NxN: the split is inferred (TEncEntropy.cpp:246-249) */ }
+  else if (!iy && g->inter_split_flag && trIdx == 0) { /* QuadtreeTUMaxDepthInter == 1, partition != 2Nx2N: the split is inferred */ }
   else if (log2 > g->log2_max_tu) { }
   else if (log2 == 2) { }
   else if (log2 == g->log2_min_tu_in_cu) { }
@@ -396,20 +398,20 @@ static void transform_tree(const hop_o_rqt_cfg* g, const hop_o_cu_syntax* y, con
   }
   if (subdiv) {
     const int q = (parts >> (2 * trIdx)) >> 2;
-    for (int k = 0; k < 4; k++) transform_tree(g, y, st, coef, c, part + k * q, trIdx + 1, log2 - 1, bakPart);
+    for (int k = 0; k < 4; k++) transform_tree(g, iy, st, coef, c, part + k * q, trIdx + 1, log2 - 1, bakPart);
     return;
   }
-  if (!(trIdx == 0 && !((st->cbf[1][part]) & 1) && !((st->cbf[2][part]) & 1)))
+  if (iy || !(trIdx == 0 && !((st->cbf[1][part]) & 1) && !((st->cbf[2][part]) & 1)))                  /* inferred for a non-intra CU without chroma cbf (:334-338) */
     c->frac += hop_o_cabac_cbf_bits(&c->ctx, 0, st->tr_idx[part], (st->cbf[0][part] >> st->tr_idx[part]) & 1);
-  if (cbfY) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + 16 * part, log2, 0, 0, g->sign_hide, g->use_ts, st->tskip[0][part]);
+  if (cbfY) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + 16 * part, log2, 0, iy ? tu_scan(iy, parts, part, 1 << log2, 0) : 0, g->sign_hide, g->use_ts, st->tskip[0][part]);
   if (log2 > 2) {
-    if (cbfU) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + 4 * part, log2 - 1, 1, 0, g->sign_hide, g->use_ts, st->tskip[1][part]);
-    if (cbfV) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + (cu2 >> 2) + 4 * part, log2 - 1, 2, 0, g->sign_hide, g->use_ts, st->tskip[2][part]);
+    if (cbfU) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + 4 * part, log2 - 1, 1, iy ? tu_scan(iy, parts, part, 1 << (log2 - 1), 1) : 0, g->sign_hide, g->use_ts, st->tskip[1][part]);
+    if (cbfV) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + (cu2 >> 2) + 4 * part, log2 - 1, 2, iy ? tu_scan(iy, parts, part, 1 << (log2 - 1), 2) : 0, g->sign_hide, g->use_ts, st->tskip[2][part]);
   } else {
     const int pn = parts >> (2 * (trIdx - 1));
     if (part % pn == pn - 1) {
-      if (cbfU) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + 4 * *bakPart, 2, 1, 0, g->sign_hide, g->use_ts, st->tskip[1][*bakPart]);
-      if (cbfV) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + (cu2 >> 2) + 4 * *bakPart, 2, 2, 0, g->sign_hide, g->use_ts, st->tskip[2][*bakPart]);
+      if (cbfU) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + 4 * *bakPart, 2, 1, iy ? tu_scan(iy, parts, *bakPart, 4, 1) : 0, g->sign_hide, g->use_ts, st->tskip[1][*bakPart]);
+      if (cbfV) c->frac += hop_o_cabac_coeff_bits(&c->ctx, coef + cu2 + (cu2 >> 2) + 4 * *bakPart, 2, 2, iy ? tu_scan(iy, parts, *bakPart, 4, 2) : 0, g->sign_hide, g->use_ts, st->tskip[2][*bakPart]);
     }
   }
 }
@@ -439,7 +441,7 @@ uint32_t hop_o_inter_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_cu_syntax* y,
     if (y->pu[p].gt_flag) vec_like_mvd(&s, CU_GT, y->pu[p].gt, 6);      /* corners 0..2 (IT_GT_AFFINE) */
   }
   if (!(y->pu[0].merge_flag && y->part_size == 0)) coder->frac += hop_o_cabac_root_cbf_bits(&coder->ctx, root);
-  if (root) { int bak = 0; transform_tree(cfg, y, st, coef, coder, 0, 0, cfg->log2_cu, &bak); }
+  if (root) { int bak = 0; transform_tree(cfg, NULL, st, coef, coder, 0, 0, cfg->log2_cu, &bak); }
   return (uint32_t)(coder->frac >> 15);
 }
 
@@ -880,4 +882,25 @@ void hop_o_intra_chroma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_synta
     }
   }
   memcpy(st->cbf[1], keep[0], (size_t)parts); memcpy(st->cbf[2], keep[1], (size_t)parts); memcpy(st->tskip[1], keep[2], (size_t)parts); memcpy(st->tskip[2], keep[3], (size_t)parts);
+}
+
+
+/* ---- rows a0 / a8: the bits of a finished intra CU as TEncCu::xCheckRDCostIntra counts them (TLibEncoder/TEncCu.cpp:1483-1503) ----
+ * resetBits, skip flag, prediction mode, partition size (encodeSkipFlag / encodePredMode / encodePartSize), the luma directions of all PUs and the chroma direction
+ * (encodePredInfo: TEncEntropy::encodeIntraDirModeLuma with the grouped flags of codeIntraDirLumaAng - the context-coded bins come in the same order as one PU
+ * after the other, so the sum is the same -, encodeIntraDirModeChroma), then encodeCoeff = xEncodeTransform (TEncEntropy.cpp:219-420) on the CU's final levels:
+ * split flags, chroma cbfs, luma cbf and the levels of a transform unit interleaved, scans by direction.  No PCM, no transquant bypass, no cu_qp_delta, not an I slice.
+ * coef: Y | Cb | Cr in the CU layout.  Returns the bits; the coder afterwards is what the caller stores as CI_TEMP_BEST. */
+uint32_t hop_o_intra_cu_total_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* coder, uint8_t cu_ctx[20])
+{
+  Syn s = { coder, cu_ctx };
+  coder->frac &= 32767;
+  bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);
+  bin(&s, CU_PRED, 1);
+  if (y->is_min_cu) bin(&s, CU_PART, y->part_nxn ? 0 : 1);
+  for (int p = 0; p < (y->part_nxn ? 4 : 1); p++) intra_dir(&s, y->luma_dir[p], y->preds[p], y->pred_num[p]);
+  if (y->chroma_is_dm) bin(&s, CU_CPRED, 0); else { bin(&s, CU_CPRED, 1); ep(&s, 2); }
+  int bak = 0;
+  transform_tree(cfg, y, st, coef, coder, 0, 0, cfg->log2_cu, &bak);
+  return (uint32_t)(coder->frac >> 15);
 }

@@ -331,3 +331,15 @@ def oracle_intra_chroma_search(cfg, syn, ts_fast, avail, org, win, arr_in, coder
                                 ctypes.addressof(dist), coef.ctypes.data, coef.ctypes.data + 4 * h2, reco.ctypes.data, reco.ctypes.data + 2 * h2)
     arr = np.concatenate([np.frombuffer(bytes(st.tr_idx), np.uint8), np.frombuffer(bytes(st.cbf), np.uint8), np.frombuffer(bytes(st.tskip), np.uint8)]).reshape(7, 256).copy()
     return mode.value, dist.value, arr, coef, reco, win
+
+
+def encoder_intracu_calls():
+    """tests/golden/encoder_intracu_calls.npz (oracle/make_golden17.py): the bit counts of finished intra CUs (xCheckRDCostIntra) of two real encodes: cfg, syntax, tr_idx |
+    cbf[3] | tskip[3], the CU's levels Y | Cb | Cr, coder (160 B) / CU contexts in and out, bits, distortion"""
+    g = load("encoder_intracu_calls.npz")
+    o = 0
+    for i in range(len(g["bits"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu * 3 // 2
+        yield dict(cfg=g["cfg"][i], syn=g["syn"][i], arr=g["arr"][i], coef=np.ascontiguousarray(g["coef"][o:o + n]), cin=g["cin"][i], cuin=g["cuin"][i], cout=g["cout"][i],
+                   cuout=g["cuout"][i], bits=int(g["bits"][i]), dist=int(g["dist"][i]))
+        o += n

@@ -187,3 +187,23 @@ def test_intra_chroma_search_on_encoder_calls():
         assert np.array_equal(w2.reshape(-1), c["rec"]), n
         kinds.add((cu, mode, int(arr[5:7, :parts].any()), int(arr[0, :parts].max()))); n += 1
     assert n == 44 and len(kinds) >= 15 and any(k[2] for k in kinds) and len(set(k[1] for k in kinds)) >= 4, kinds
+
+
+def test_intra_cu_total_bits_on_encoder_calls():
+    """the counting part of xCheckRDCostIntra (header, luma and chroma directions, xEncodeTransform with the intra rules on the CU's final levels): the restatement on 40
+    calls recorded inside the encoder - bits and every context state afterwards (what the encoder stores as CI_TEMP_BEST)"""
+    from goldutil import encoder_intracu_calls, RQT_CFG, INTRA_SYN, _OCoder, _OState
+    O = oracle()
+    O.hop_o_intra_cu_total_bits.restype = ctypes.c_uint32
+    O.hop_o_intra_cu_total_bits.argtypes = [ctypes.c_void_p] * 6
+    n = 0; kinds = set()
+    for c in encoder_intracu_calls():
+        cfg = np.zeros(1, RQT_CFG); cfg[0] = c["cfg"]; syn = np.zeros(1, INTRA_SYN); syn[0] = c["syn"]
+        st = _OState(); ctypes.memmove(ctypes.byref(st), c["arr"].tobytes(), 1792)
+        coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), c["cin"].tobytes(), 160)
+        cu = c["cuin"].copy()
+        bits = O.hop_o_intra_cu_total_bits(cfg.ctypes.data, syn.ctypes.data, ctypes.addressof(st), c["coef"].ctypes.data, ctypes.addressof(coder), cu.ctypes.data)
+        assert bits == c["bits"], (n, bits, c["bits"])
+        assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
+        kinds.add((int(cfg[0]["log2_cu"]), int(syn[0]["part_nxn"]), int(syn[0]["chroma_is_dm"]))); n += 1
+    assert n == 40 and len(kinds) >= 6

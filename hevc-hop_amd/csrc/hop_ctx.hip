@@ -1107,6 +1107,83 @@ int hop_intra_chroma_search(hop_ctx* c, int n, const hop_rqt_job* jobs, const ho
   return HOP_OK;
 }
 
+int hop_intra_cu_total_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_intra_cu_syntax* d_syntax, const hop_rqt_result* d_results,
+                                   const int32_t* d_coef, const uint32_t* d_dist, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, double* d_cost,
+                                   hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out) {
+  if (!c || n < 0 || !cls || (n && (!d_jobs || !d_syntax || !d_results || !d_coef || !d_ctx_in || !d_cu_ctx_in || !d_bits))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_total_bits_device: bad argument");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_total_bits_device: illegal CU class");
+  if (n == 0) return HOP_OK;
+  return hop_launch_intra_cu_total(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, n, d_jobs, d_syntax, d_results, d_coef, d_ctx_in,
+                                   d_cu_ctx_in, d_dist, d_bits, d_cost, d_ctx_out, d_cu_ctx_out);
+}
+
+int hop_intra_cu_total_bits(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, const uint32_t* dist,
+                            int n_ctx, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, double* cost, hop_cabac_ctx* ctx_out,
+                            hop_cabac_cu_ctx* cu_ctx_out) {
+  if (!c || n < 0 || (n && (!jobs || !syntax || !results || !coef || !dist || !ctx_in || !cu_ctx_in || !bits || !cost || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_total_bits: bad argument");
+  if (n == 0) return HOP_OK;
+  std::vector<size_t> coff(n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const hop_rqt_job& j = jobs[i]; const hop_intra_cu_syntax& y = syntax[i];
+    const int parts = 1 << (2 * (j.log2_cu - 2));
+    bool ok = j.log2_cu >= 3 && j.log2_cu <= 6 && j.ctx_index >= 0 && j.ctx_index < n_ctx && j.log2_max_tu >= 2 && j.log2_max_tu <= 5 && j.log2_min_tu_in_cu >= 2 &&
+              j.log2_min_tu_in_cu <= j.log2_max_tu && j.log2_cu - j.log2_min_tu_in_cu <= 3 && j.log2_cu - j.log2_max_tu <= 1 && j.lambda_rd > 0.0 && y.skip_ctx >= 0 && y.skip_ctx <= 2;
+    for (int p = 0; p < (y.part_nxn ? 4 : 1) && ok; p++) ok = y.luma_dir[p] >= 0 && y.luma_dir[p] < 35 && y.pred_num[p] >= 0 && y.pred_num[p] <= 3;
+    for (int p = 0; p < parts && ok; p++) {
+      const int d = results[i].tr_idx[p], lg = j.log2_cu - d;
+      ok = d >= (y.part_nxn ? 1 : 0) && d <= 3 && lg >= j.log2_min_tu_in_cu && lg <= j.log2_max_tu && results[i].tr_idx[p - p % (parts >> (2 * d))] == d;
+    }
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "intra CU bits job %d: illegal CU class / syntax elements / transform tree / snapshot", i);
+    coff[i + 1] = coff[i] + (((size_t)3 << (2 * j.log2_cu)) >> 1);
+  }
+  for (int k = 0; k < n_ctx; k++) {
+    for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+    for (int i = 0; i < 19; i++) if (cu_ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "CU context snapshot %d: state %d out of range", k, i);
+  }
+  std::vector<char> done(n, 0);
+  for (int first = 0; first < n; first++) {
+    if (done[first]) continue;
+    const hop_rqt_job& f = jobs[first];
+    std::vector<int> idx; std::vector<hop_rqt_job> cls; std::vector<hop_intra_cu_syntax> sy; std::vector<hop_rqt_result> rr; std::vector<uint32_t> dd;
+    for (int i = first; i < n; i++) {
+      const hop_rqt_job& j = jobs[i];
+      if (!done[i] && j.log2_cu == f.log2_cu && j.log2_max_tu == f.log2_max_tu && j.log2_min_tu_in_cu == f.log2_min_tu_in_cu && !j.sign_hide == !f.sign_hide && !j.use_ts == !f.use_ts) {
+        done[i] = 1; idx.push_back(i); cls.push_back(j); sy.push_back(syntax[i]); rr.push_back(results[i]); dd.push_back(dist[i]);
+      }
+    }
+    const int m = (int)idx.size();
+    const size_t cu3 = ((size_t)3 << (2 * f.log2_cu)) / 2;
+    std::vector<int32_t> co((size_t)m * cu3);
+    for (int t = 0; t < m; t++) memcpy(co.data() + (size_t)t * cu3, coef + coff[idx[t]], cu3 * 4);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_j = 0, o_y = al((size_t)m * sizeof(hop_rqt_job)), o_r = al(o_y + (size_t)m * sizeof(hop_intra_cu_syntax)), o_o = al(o_r + (size_t)m * sizeof(hop_rqt_result));
+    const size_t o_d = al(o_o + (size_t)m * cu3 * 4), o_c = al(o_d + (size_t)m * 4), o_u = al(o_c + (size_t)n_ctx * sizeof(hop_cabac_ctx)), o_b = al(o_u + (size_t)n_ctx * sizeof(hop_cabac_cu_ctx));
+    const size_t o_k = al(o_b + (size_t)m * 4), o_x = al(o_k + (size_t)m * 8), o_v = al(o_x + (size_t)m * sizeof(hop_cabac_ctx)), o_e = al(o_v + (size_t)m * sizeof(hop_cabac_cu_ctx));
+    void* st; int r = hop_stage(c, o_e + 256, &st); if (r) return r;
+    char* b = (char*)st;
+    HIPCHK(c, hipMemcpyAsync(b + o_j, cls.data(), (size_t)m * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_y, sy.data(), (size_t)m * sizeof(hop_intra_cu_syntax), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_r, rr.data(), (size_t)m * sizeof(hop_rqt_result), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_o, co.data(), (size_t)m * cu3 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_d, dd.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, (size_t)n_ctx * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_u, cu_ctx_in, (size_t)n_ctx * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, c->stream));
+    r = hop_intra_cu_total_bits_device(c, m, (const hop_rqt_job*)(b + o_j), &f, (const hop_intra_cu_syntax*)(b + o_y), (const hop_rqt_result*)(b + o_r), (const int32_t*)(b + o_o),
+                                       (const uint32_t*)(b + o_d), (const hop_cabac_ctx*)(b + o_c), (const hop_cabac_cu_ctx*)(b + o_u), (uint32_t*)(b + o_b), (double*)(b + o_k),
+                                       (hop_cabac_ctx*)(b + o_x), (hop_cabac_cu_ctx*)(b + o_v));
+    if (r) return r;
+    std::vector<uint32_t> bb(m); std::vector<double> kk(m); std::vector<hop_cabac_ctx> cx(m); std::vector<hop_cabac_cu_ctx> cv(m);
+    HIPCHK(c, hipMemcpyAsync(bb.data(), b + o_b, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(kk.data(), b + o_k, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cx.data(), b + o_x, (size_t)m * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cv.data(), b + o_v, (size_t)m * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < m; t++) { bits[idx[t]] = bb[t]; cost[idx[t]] = kk[t]; if (ctx_out) ctx_out[idx[t]] = cx[t]; if (cu_ctx_out) cu_ctx_out[idx[t]] = cv[t]; }
+  }
+  return HOP_OK;
+}
+
 int hop_inter_cu_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results, const int32_t* d_coef,
                              const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out,
                              hop_cabac_cu_ctx* d_cu_ctx_out) {

@@ -1324,3 +1324,87 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+// =====================================================================================================================
+// The bits of a finished intra CU as TEncCu::xCheckRDCostIntra counts them (TLibEncoder/TEncCu.cpp:1483-1503): skip flag, prediction mode, partition size, the luma
+// directions of all PUs and the chroma direction (encodePredInfo), then encodeCoeff = xEncodeTransform (TEncEntropy.cpp:219-420) on the CU's final levels with the
+// intra rules (the split of an NxN CU inferred, the luma cbf always coded, scans by direction).  One lane per CU; cost = calcRdCost(bits, distortion).
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                       const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                       const hop_cabac_cu_ctx* __restrict__ cu_in, const uint32_t* __restrict__ dist, uint32_t* __restrict__ bits_out,
+                                                       double* __restrict__ cost_out, hop_cabac_ctx* __restrict__ ctx_out, hop_cabac_cu_ctx* __restrict__ cu_out,
+                                                       const uint16_t* __restrict__ scans) {
+  __shared__ CabacLds sh;
+  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const int ci = jobs[i].ctx_index;
+  RQ_LOAD(ctx_in[ci]); IRQ_CU_LOAD(cu_in[ci]);
+  const hop_intra_cu_syntax y = syn[i];
+  const hop_rqt_result* r = res + i;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  const int32_t* cf = coef + (size_t)i * (cu2 + (cu2 >> 1));
+  unsigned long long frac = RQ_LEFT();
+  CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
+  CBIN(CU_PRED, 1);
+  if (y.is_min_cu) CBIN(CU_PART, y.part_nxn ? 0 : 1);
+  for (int p = 0; p < (y.part_nxn ? 4 : 1); p++) frac += icu_dir(sh, lane, y.luma_dir[p], y.preds[p], y.pred_num[p]);
+  if (y.chroma_is_dm) CBIN(CU_CPRED, 0); else { CBIN(CU_CPRED, 1); CEP(2); }
+  int sp_part[4], sp_k[4]; int sp = 0, bak = 0;
+  sp_part[0] = 0; sp_k[0] = -1;
+  while (sp >= 0) {
+    const int part = sp_part[sp], trIdx = sp, log2 = k.log2_cu - sp;
+    if (sp_k[sp] < 0) {
+      const int subdiv = r->tr_idx[part] > trIdx;
+      const int cbfY = (r->cbf[0][part] >> trIdx) & 1; int cbfU = (r->cbf[1][part] >> trIdx) & 1, cbfV = (r->cbf[2][part] >> trIdx) & 1;
+      if (log2 == 2) {
+        const int pn = parts >> (2 * (trIdx - 1));
+        if (part % pn == 0) bak = part;
+        else if (part % pn == pn - 1) { cbfU = (r->cbf[1][bak] >> trIdx) & 1; cbfV = (r->cbf[2][bak] >> trIdx) & 1; }
+      }
+      if (!((y.part_nxn && trIdx == 0) || log2 > k.log2_max_tu || log2 == 2 || log2 == k.log2_min_tu)) CBIN(CX_TRANS_SUBDIV + 5 - log2, subdiv);
+      const int first = trIdx == 0;
+      if (first || log2 > 2) {
+        if (first || ((r->cbf[1][part] >> (trIdx - 1)) & 1)) CBIN(rqt_cbf_ctx(1, trIdx), (r->cbf[1][part] >> trIdx) & 1);
+        if (first || ((r->cbf[2][part] >> (trIdx - 1)) & 1)) CBIN(rqt_cbf_ctx(2, trIdx), (r->cbf[2][part] >> trIdx) & 1);
+      }
+      if (!subdiv) {
+        CBIN(rqt_cbf_ctx(0, r->tr_idx[part]), (r->cbf[0][part] >> r->tr_idx[part]) & 1);
+        if (cbfY) frac += cb_code_tu(sh, lane, cf + 16 * part, log2, 0, icu_scan(y, parts, part, log2, 0), k.sign_hide, k.use_ts, r->tskip[0][part], 0, scans);
+        if (log2 > 2) {
+          if (cbfU) frac += cb_code_tu(sh, lane, cf + cu2 + 4 * part, log2 - 1, 1, icu_scan(y, parts, part, log2 - 1, 1), k.sign_hide, k.use_ts, r->tskip[1][part], 0, scans);
+          if (cbfV) frac += cb_code_tu(sh, lane, cf + cu2 + (cu2 >> 2) + 4 * part, log2 - 1, 1, icu_scan(y, parts, part, log2 - 1, 2), k.sign_hide, k.use_ts, r->tskip[2][part], 0, scans);
+        } else {
+          const int pn = parts >> (2 * (trIdx - 1));
+          if (part % pn == pn - 1) {
+            if (cbfU) frac += cb_code_tu(sh, lane, cf + cu2 + 4 * bak, 2, 1, icu_scan(y, parts, bak, 2, 1), k.sign_hide, k.use_ts, r->tskip[1][bak], 0, scans);
+            if (cbfV) frac += cb_code_tu(sh, lane, cf + cu2 + (cu2 >> 2) + 4 * bak, 2, 1, icu_scan(y, parts, bak, 2, 2), k.sign_hide, k.use_ts, r->tskip[2][bak], 0, scans);
+          }
+        }
+        sp--; continue;
+      }
+      sp_k[sp] = 0;
+    }
+    if (sp_k[sp] < 4) { const int q = (parts >> (2 * trIdx)) >> 2, kk = sp_k[sp]++; sp_part[sp + 1] = part + kk * q; sp_k[sp + 1] = -1; sp++; }
+    else sp--;
+  }
+  const uint32_t bits = (uint32_t)(frac >> 15);
+  bits_out[i] = bits;
+  if (cost_out) cost_out[i] = rqt_cost(bits, dist ? dist[i] : 0u, jobs[i].lambda_rd);
+  if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
+  if (cu_out) IRQ_CU_STORE(cu_out[i]);
+}
+
+int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn,
+                              const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, const uint32_t* d_dist,
+                              uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
+  RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
+  const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
+  hipLaunchKernelGGL(k_intra_cu_total, dim3((n + 63) / 64), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_dist, d_bits, d_cost, d_ctx_out, d_cu_out,
+                     c->rdoq_scans);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_cu_total launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

@@ -378,6 +378,16 @@ class Context:
                                                  res.ctypes.data, cres.ctypes.data, coef.ctypes.data, reco.ctypes.data), "hop_intra_chroma_search")
         return cres, res, coef, reco
 
+    def intra_cu_total_bits(self, jobs, syntax, res, coef, dist, ctx_in, cu_ctx_in):
+        """the counting part of xCheckRDCostIntra: returns bits, costs, coder states (n, 152) and CU-level states (n, 20) afterwards"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, INTRA_CU_SYNTAX_DTYPE); res = np.ascontiguousarray(res, RQT_RESULT_DTYPE)
+        coef = np.ascontiguousarray(coef, np.int32); dist = np.ascontiguousarray(dist, np.uint32); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); bits = np.zeros(n, np.uint32); cost = np.zeros(n, np.float64); cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, CABAC_CU_CTX_BYTES), np.uint8)
+        self.L.hop_intra_cu_total_bits.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 6
+        self._chk(self.L.hop_intra_cu_total_bits(self.h, n, jobs.ctypes.data, syntax.ctypes.data, res.ctypes.data, coef.ctypes.data, dist.ctypes.data, len(ctx_in), ctx_in.ctypes.data,
+                                                 cu_ctx_in.ctypes.data, bits.ctypes.data, cost.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_intra_cu_total_bits")
+        return bits, cost, cx, cu
+
     def intra_pred(self, jobs, modes):
         n = len(jobs)
         arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)

@@ -494,6 +494,20 @@ int hop_intra_chroma_search(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const 
 int hop_intra_chroma_search_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_intra_cu_syntax* d_syntax, const hop_intra_rqt_opt* d_opts,
                                    const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, hop_rqt_result* d_results, hop_intra_chroma_result* d_cresults,
                                    int32_t* d_coef_out, int16_t* d_reco_out);
+/* ---- the bits and cost of a finished intra CU (rows a0 / a8) ---- */
+/* replaces: the counting part of TEncCu::xCheckRDCostIntra (TLibEncoder/TEncCu.cpp:1483-1503) for a batch of CUs: resetBits, encodeSkipFlag / encodePredMode /
+ * encodePartSize, encodePredInfo (the luma directions of all PUs against their most probable modes, the chroma direction), encodeCoeff = xEncodeTransform
+ * (TEncEntropy.cpp:219-420) on the CU's final levels with the intra rules, getTotalCost = calcRdCost(bits, getTotalDistortion).  syntax: all elements of the CU (tr_depth /
+ * part / b_* not read); results: the arrays after the luma and chroma searches; coef: 1.5 * size^2 levels per CU (Y | Cb | Cr, CU layout); dist: getTotalDistortion per CU.
+ * ctx_in / cu_ctx_in[jobs[i].ctx_index]: the coder the searches left (CI_CURR_BEST); ctx_out / cu_ctx_out (may be NULL): what the caller stores as CI_TEMP_BEST.
+ * No PCM, no transquant bypass, no cu_qp_delta, not an I slice. */
+int hop_intra_cu_total_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_rqt_result* results, const int32_t* coef, const uint32_t* dist,
+                            int n_ctx, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in, uint32_t* bits, double* cost, hop_cabac_ctx* ctx_out,
+                            hop_cabac_cu_ctx* cu_ctx_out);
+/* device-resident form, one class of CUs; asynchronous, unchecked */
+int hop_intra_cu_total_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_intra_cu_syntax* d_syntax, const hop_rqt_result* d_results,
+                                   const int32_t* d_coef, const uint32_t* d_dist, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, double* d_cost,
+                                   hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -993,3 +993,34 @@ def test_intra_chroma_search_random_vs_oracle(hp):
         assert np.array_equal(RC[0], R2[0]) and np.array_equal(RC[1], R2[1]), bd
         assert ts >= 3 and len(modes) >= 4, (bd, ts, modes)
         ctx.close()
+
+
+def test_intra_cu_total_bits_encoder_calls(hp):
+    """hop_intra_cu_total_bits (the counting part of xCheckRDCostIntra: header, luma and chroma directions, xEncodeTransform with the intra rules on the final levels, the RD
+    cost) on the 40 calls recorded inside the encoder: bits, cost (the restatement's calcRdCost on the recorded distortion), all context states afterwards"""
+    from goldutil import encoder_intracu_calls
+    O = oracle(); O.hop_o_calc_rd_cost.restype = ctypes.c_double; O.hop_o_calc_rd_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double]
+    cases = list(encoder_intracu_calls())
+    n = len(cases)
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.INTRA_CU_SYNTAX_DTYPE); res = np.zeros(n, hp.RQT_RESULT_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; j = jobs[i]
+        j["log2_cu"], j["ctx_index"], j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = int(cfg["log2_cu"]), i, cfg["sign_hide"], cfg["use_ts"], cfg["log2_max_tu"], cfg["log2_min_tu_in_cu"]
+        j["lambda_rd"] = cfg["lambda_rd"]; j["lambda_rdoq"] = 1.0
+        for k in ("part_nxn", "skip_flag", "skip_ctx", "is_min_cu", "luma_dir", "preds", "pred_num", "chroma_is_dm", "chroma_dir"): syn[i][k] = c["syn"][k]
+        a = c["arr"].reshape(7, 256); res[i]["tr_idx"] = a[0]; res[i]["cbf"] = a[1:4]; res[i]["tskip"] = a[4:7]
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i] = c["cuin"]
+    ctx = hp.Context(64, 64)
+    dist = np.array([c["dist"] for c in cases], np.uint32)
+    bits, cost, cx, cu = ctx.intra_cu_total_bits(jobs, syn, res, np.concatenate([c["coef"] for c in cases]), dist, snaps, cus)
+    for i, c in enumerate(cases):
+        assert int(bits[i]) == c["bits"], (i, int(c["cfg"]["log2_cu"]), int(bits[i]), c["bits"])
+        assert float(cost[i]) == O.hop_o_calc_rd_cost(c["bits"], c["dist"], float(c["cfg"]["lambda_rd"])), i
+        assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), i
+        assert np.array_equal(cu[i], c["cuout"]), i
+    bad = res.copy(); bad[0]["tr_idx"][0] = 7
+    with pytest.raises(hp.HopError):
+        ctx.intra_cu_total_bits(jobs, syn, bad, np.concatenate([c["coef"] for c in cases]), dist, snaps, cus)
+    ctx.close()

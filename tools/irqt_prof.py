@@ -16,7 +16,8 @@ f = gaussian_filter(rng.normal(0, 1, (H // 4, W // 4)).astype(np.float32), 2.0)
 f = np.kron(f / np.abs(f).max(), np.ones((4, 4), np.float32))
 Y = np.clip(128 + 90 * gaussian_filter(f, 1.5) + rng.normal(0, 2, (H, W)), 0, 255).astype(np.int16)
 ctx = hp.Context(W, H)
-ctx.upload_orig(Y, np.full((H // 2, W // 2), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16))
+C = np.ascontiguousarray(Y[::2, ::2] // 2 + 64)
+ctx.upload_orig(Y, C, C)
 snap = np.zeros((1, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((1, hp.CABAC_CU_CTX_BYTES), np.uint8)
 ctx.L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; ctx.L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 ctx.L.hop_cabac_init(snap.ctypes.data, 3, 32); ctx.L.hop_cabac_cu_init(cus.ctypes.data, 3, 32)
@@ -76,5 +77,24 @@ for lg, nxn in ((3, 1), (3, 0), (4, 0), (5, 0), (6, 0)):
                                                     dq.data_ptr(), dr.data_ptr(), dc.data_ptr(), dk.data_ptr()), "intra_luma_search_device")
         ctx.sync(); dt = time.perf_counter() - t0
     sr = np.frombuffer(dq.cpu().numpy().tobytes(), hp.INTRA_SEARCH_RESULT_DTYPE)
-    print("%2dx%-2d %5s %8d %8.4f %8.1f %10.1f %10.2f" % (S, S, "NxN" if nxn else "2Nx2N", n, dt, n / dt / 1e3, n * S * S / dt / 1e6, float(sr["n_cand"][:, 0].mean())))
+    print("%2dx%-2d %5s %8d %8.4f %8.1f %10.1f %10.2f" % (S, S, "NxN" if nxn else "2Nx2N", n, dt, n / dt / 1e3, n * S * S / dt / 1e6, float(sr["n_cand"][:, 0].mean())), end="")
+    # the chroma search on the luma result (hop_intra_chroma_search_device = estIntraPredChromaQT), then the CU's bits and cost (hop_intra_cu_total_bits_device)
+    syn2 = syn.copy(); syn2["luma_dir"] = sr["best_dir"]; syn2["preds"] = (0, 1, 26); syn2["pred_num"] = 3
+    dy2 = torch.from_numpy(syn2.view(np.uint8)).to(dev)
+    dcr = torch.zeros(n * 8, dtype=torch.uint8, device=dev); dk2 = torch.zeros(n * S * S // 2, dtype=torch.int16, device=dev)
+    ctx.L.hop_intra_chroma_search_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
+    for it in range(2):
+        ctx.plane_upload("recon", 1, C); ctx.plane_upload("recon", 2, C)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx._chk(ctx.L.hop_intra_chroma_search_device(ctx.h, n, dj.data_ptr(), jobs[:1].ctypes.data, dy2.data_ptr(), do.data_ptr(), ds.data_ptr(), du.data_ptr(), dr.data_ptr(),
+                                                      dcr.data_ptr(), dc.data_ptr(), dk2.data_ptr()), "intra_chroma_search_device")
+        ctx.sync(); dtc = time.perf_counter() - t0
+    ctx.L.hop_intra_cu_total_bits_device.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 12
+    db = torch.zeros(n, dtype=torch.int32, device=dev); dco = torch.zeros(n, dtype=torch.float64, device=dev); dd = torch.zeros(n, dtype=torch.int32, device=dev)
+    for it in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx._chk(ctx.L.hop_intra_cu_total_bits_device(ctx.h, n, dj.data_ptr(), jobs[:1].ctypes.data, dy2.data_ptr(), dr.data_ptr(), dc.data_ptr(), dd.data_ptr(), ds.data_ptr(),
+                                                      du.data_ptr(), db.data_ptr(), dco.data_ptr(), None, None), "intra_cu_total_bits_device")
+        ctx.sync(); dtb = time.perf_counter() - t0
+    print("   chroma %.4f s (%.1f kCU/s)   bits %.4f s   whole candidate %.1f kCU/s" % (dtc, n / dtc / 1e3, dtb, n / (dt + dtc + dtb) / 1e3))
 ctx.close()

@@ -1024,3 +1024,38 @@ def test_intra_cu_total_bits_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.intra_cu_total_bits(jobs, syn, bad, np.concatenate([c["coef"] for c in cases]), dist, snaps, cus)
     ctx.close()
+
+
+def test_intra_entries_empty_and_error_paths(hp):
+    """the quadtree / search entries with nothing to do (n = 0 is not an error) and used wrongly (before the original was uploaded; a CU outside the picture; a snapshot
+    index out of range): every failure is reported through the error code and hop_last_error, nothing is computed"""
+    ctx = hp.Context(128, 128)
+    jobs = np.zeros(1, hp.RQT_JOB_DTYPE); syn = np.zeros(1, hp.INTRA_CU_SYNTAX_DTYPE); opts = np.zeros(1, hp.INTRA_RQT_OPT_DTYPE); sj = np.zeros(1, hp.INTRA_SEARCH_JOB_DTYPE)
+    res = np.zeros(1, hp.RQT_RESULT_DTYPE); snap = np.zeros((1, hp.CABAC_CTX_BYTES), np.uint8); cu = np.zeros((1, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    jobs["log2_cu"] = 4; jobs["qp_scaled"] = 30; jobs["log2_max_tu"] = 5; jobs["log2_min_tu_in_cu"] = 2; jobs["lambda_rd"] = 50.0; jobs["lambda_rdoq"] = 50.0; jobs["dist_weight"] = 1.0
+    syn["pred_num"] = 3; syn["preds"] = (0, 1, 26); sj["sqrt_lambda"] = 7.0; sj["num_full_rd"] = 3; sj["left_dir"] = 1; sj["above_dir"] = 1
+    with pytest.raises(hp.HopError):                                    # no original yet
+        ctx.intra_rqt(jobs, syn, opts, snap, cu)
+    with pytest.raises(hp.HopError):
+        ctx.intra_luma_search(jobs, syn, opts, sj, snap, cu)
+    with pytest.raises(hp.HopError):
+        ctx.intra_chroma_search(jobs, syn, opts, res, snap, cu)
+    ctx.upload_orig(np.full((128, 128), 128, np.int16), np.full((64, 64), 128, np.int16), np.full((64, 64), 128, np.int16))
+    e = lambda a: a[:0]
+    r0 = ctx.intra_rqt(e(jobs), e(syn), e(opts), snap, cu); assert len(r0[0]) == 0
+    s0 = ctx.intra_luma_search(e(jobs), e(syn), e(opts), e(sj), snap, cu); assert len(s0[0]) == 0
+    c0 = ctx.intra_chroma_search(e(jobs), e(syn), e(opts), e(res), snap, cu); assert len(c0[0]) == 0
+    b0 = ctx.intra_cu_total_bits(e(jobs), e(syn), e(res), np.zeros(0, np.int32), np.zeros(0, np.uint32), snap, cu); assert len(b0[0]) == 0
+    for field, value in (("x", 120), ("ctx_index", 1), ("log2_cu", 7), ("log2_min_tu_in_cu", 6)):
+        bad = jobs.copy(); bad[field] = value
+        with pytest.raises(hp.HopError):
+            ctx.intra_rqt(bad, syn, opts, snap, cu)
+        with pytest.raises(hp.HopError):
+            ctx.intra_luma_search(bad, syn, opts, sj, snap, cu)
+        with pytest.raises(hp.HopError):
+            ctx.intra_chroma_search(bad, syn, opts, res, snap, cu)
+    # and a legal call still works afterwards: a flat CU costs a few bits and reconstructs exactly
+    opts["avail"] = 0; sj["rough_flags"] = 0
+    sres, r, coef, reco = ctx.intra_luma_search(jobs, syn, opts, sj, snap, cu)
+    assert int(sres[0]["dist"]) == 0 and not coef.any() and (reco == 128).all()
+    ctx.close()

@@ -1016,6 +1016,64 @@ Void TEncCu::xCheckRDCostIntra(TComDataCU*& rpcBestCU, TComDataCU*& rpcTempCU, P
   xCheckBestMode(rpcBestCU, rpcTempCU, uiDepth);
 }
 
+// ---- an SS/GT CU without residual: the bSkipRes branch of TEncSearch::encodeResAndCalcRdInterCU (TLibEncoder/TEncSearch.cpp:6635-6668) -> hop_o_inter_cu_skip ----
+// (every other call goes back to the reference's definition, whose quadtree and syntax-bit members are replaced above)
+extern "C" void hop_ref_orig_encode_res(TEncSearch*, TComDataCU*, TComYuv*, TComYuv*, TComYuv*&, TComYuv*&, TComYuv*&, Bool);
+namespace { unsigned long g_calls15[1] = { 0 };
+struct Report15 { ~Report15() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: cuSkip %lu\n", g_calls15[0]); } } g_report15; }
+
+Void TEncSearch::encodeResAndCalcRdInterCU(TComDataCU* pcCU, TComYuv* pcYuvOrg, TComYuv* pcYuvPred, TComYuv*& rpcYuvResi, TComYuv*& rpcYuvResiBest, TComYuv*& rpcYuvRec, Bool bSkipRes)
+{
+  if (!bSkipRes || pcCU->isIntra(0)) { hop_ref_orig_encode_res(this, pcCU, pcYuvOrg, pcYuvPred, rpcYuvResi, rpcYuvResiBest, rpcYuvRec, bSkipRes); return; }
+  TComSlice* sl = pcCU->getSlice();
+  if (sl->getPPS()->getTransquantBypassEnableFlag()) { fprintf(stderr, "hop shim: the skip variant is replaced without transquant bypass\n"); abort(); }
+  g_calls15[0]++;
+  const UInt depth = pcCU->getDepth(0);
+  pcCU->setSkipFlagSubParts(true, 0, depth);
+  rpcYuvResi->clear();
+  pcYuvPred->copyToPartYuv(rpcYuvRec, 0);
+  hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
+  cfg.log2_cu = g_aucConvertToBit[sl->getSPS()->getMaxCUWidth() >> depth] + 2; cfg.bit_depth_y = g_bitDepthY; cfg.bit_depth_c = g_bitDepthC;
+  cfg.lambda_rd = m_pcRdCost->m_dLambda; cfg.dist_weight[0] = 1.0; cfg.dist_weight[1] = m_pcRdCost->m_cbDistortionWeight; cfg.dist_weight[2] = m_pcRdCost->m_crDistortionWeight;
+  const int cu = 1 << cfg.log2_cu;
+  std::vector<int16_t> pr[3], og[3];
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? cu / 2 : cu; pr[c].resize((size_t)w * w); og[c].resize((size_t)w * w);
+    const Pel* p = c == 0 ? rpcYuvRec->getLumaAddr() : c == 1 ? rpcYuvRec->getCbAddr() : rpcYuvRec->getCrAddr(); const int ps = c ? rpcYuvRec->getCStride() : rpcYuvRec->getStride();
+    const Pel* o = c == 0 ? pcYuvOrg->getLumaAddr() : c == 1 ? pcYuvOrg->getCbAddr() : pcYuvOrg->getCrAddr(); const int os = c ? pcYuvOrg->getCStride() : pcYuvOrg->getStride();
+    for (int r = 0; r < w; r++) { memcpy(&pr[c][(size_t)r * w], p + r * ps, w * sizeof(Pel)); memcpy(&og[c][(size_t)r * w], o + r * os, w * sizeof(Pel)); }
+  }
+  m_pcRDGoOnSbacCoder->load(m_pppcRDSbacCoder[depth][CI_CURR_BEST]);
+  TEncSbac* sb = m_pcRDGoOnSbacCoder;
+  hop_o_coder coder; coder_get(sb, &coder);
+  uint8_t cuctx[16] = { 0 }; { CuSets r = cu_sets(sb); uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) *d++ = r.p[i][j].m_ucState; }
+  const hop_o_coder coder_in = coder; uint8_t cu_in[16]; memcpy(cu_in, cuctx, 16);
+  const int16_t* pp[3] = { &pr[0][0], &pr[1][0], &pr[2][0] }; const int16_t* oo[3] = { &og[0][0], &og[1][0], &og[2][0] };
+  uint32_t d3[3]; double cost = 0;
+  const int skipCtx = (int)pcCU->getCtxSkipFlag(0), mergeIdx = (int)pcCU->getMergeIndex(0), maxCand = (int)sl->getMaxNumMergeCand();
+  const uint32_t bits = hop_o_inter_cu_skip(&cfg, skipCtx, mergeIdx, maxCand, pp, oo, &coder, cuctx, d3, &cost);
+  {                                                                 // HOP_SHIM_TRACE_CUSKIP=<file>
+    static FILE* f = NULL; static bool tried = false;
+    if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_CUSKIP"); if (pth && *pth) f = fopen(pth, "wb"); }
+    if (f) {
+      const int32_t nd[4] = { skipCtx, mergeIdx, maxCand, 0 };
+      fwrite(&cfg, sizeof(cfg), 1, f); fwrite(nd, 4, 4, f);
+      for (int c = 0; c < 3; c++) fwrite(&pr[c][0], 2, pr[c].size(), f);
+      for (int c = 0; c < 3; c++) fwrite(&og[c][0], 2, og[c].size(), f);
+      fwrite(&coder_in, sizeof(coder_in), 1, f); fwrite(cu_in, 1, 16, f); fwrite(&coder, sizeof(coder), 1, f); fwrite(cuctx, 1, 16, f);
+      const uint32_t o4[4] = { bits, d3[0], d3[1], d3[2] }; fwrite(o4, 4, 4, f); fwrite(&cost, 8, 1, f);
+    }
+  }
+  coder_put(sb, &coder);
+  { CuSets r = cu_sets(sb); const uint8_t* d = cuctx; for (int i = 0; i < 9; i++) for (int j = 0; j < r.n[i]; j++) r.p[i][j].m_ucState = *d++; }
+  pcCU->getTotalBits() = bits;
+  pcCU->getTotalDistortion() = d3[0] + d3[1] + d3[2];
+  pcCU->getTotalCost() = cost;
+  m_pcRDGoOnSbacCoder->store(m_pppcRDSbacCoder[depth][CI_TEMP_BEST]);
+  pcCU->setCbfSubParts(0, 0, 0, 0, depth);
+  pcCU->setTrIdxSubParts(0, 0, depth);
+}
+
 // ---- chroma intra prediction: TComPrediction::predIntraChromaAng (TLibCommon/TComPrediction.cpp:375-390) -> hop_o_intra_pred_chroma ----
 namespace { unsigned long g_calls10[1] = { 0 };
 struct Report10 { ~Report10() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop shim calls: chromaPred %lu\n", g_calls10[0]); } } g_report10; }

@@ -167,6 +167,9 @@ void hop_o_intra_chroma_search(const hop_o_rqt_cfg* cfg, const hop_o_intra_synta
                                hop_o_rqt_state* st, int* best_mode, uint32_t* best_dist, int32_t* coef_cb, int32_t* coef_cr, int16_t* reco_cb, int16_t* reco_cr);
 /* rows a0 / a8: the bits of a finished intra CU (the counting part of TEncCu::xCheckRDCostIntra): header, directions, xEncodeTransform on the final levels (Y | Cb | Cr) */
 uint32_t hop_o_intra_cu_total_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax* y, const hop_o_rqt_state* st, const int32_t* coef, hop_o_coder* coder, uint8_t cu_ctx[20]);
+/* row a8b without residual (encodeResAndCalcRdInterCU, bSkipRes): distortion of the prediction per plane, bits of skip flag + merge index, cost */
+uint32_t hop_o_inter_cu_skip(const hop_o_rqt_cfg* cfg, int skip_ctx, int merge_idx, int max_merge_cand, const int16_t* const pred[3], const int16_t* const org[3],
+                             hop_o_coder* coder, uint8_t cu_ctx[16], uint32_t dist3[3], double* cost);
 int hop_o_inter_cu_finish(const hop_o_rqt_cfg* cfg, hop_o_rqt_state* st, const hop_o_coder* coder, double cost, uint32_t zero_dist,
                           const int16_t* const pred[3], const int16_t* const org[3], int16_t* const rec[3], uint32_t dist3[3], int32_t* final_coef);
 int hop_o_tu_rd(const int16_t* resi, int log2_size, int comp, int qp_scaled, int bit_depth, int tr_depth, int sign_hide, int use_ts,

@@ -904,3 +904,25 @@ uint32_t hop_o_intra_cu_total_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_s
   transform_tree(cfg, y, st, coef, coder, 0, 0, cfg->log2_cu, &bak);
   return (uint32_t)(coder->frac >> 15);
 }
+
+
+/* ---- row a8b, the variant without residual: TEncSearch::encodeResAndCalcRdInterCU with bSkipRes (TLibEncoder/TEncSearch.cpp:6635-6668) ----
+ * The reconstruction is the prediction; its distortion against the original per plane (getDistPart: the chroma planes weighted), the bits of a set skip flag and
+ * the merge index from the CI_CURR_BEST state, calcRdCost.  pred / org: the CU's planes (pitch = CU size, chroma half).  The coder afterwards is CI_TEMP_BEST. */
+uint32_t hop_o_inter_cu_skip(const hop_o_rqt_cfg* cfg, int skip_ctx, int merge_idx, int max_merge_cand, const int16_t* const pred[3], const int16_t* const org[3],
+                             hop_o_coder* coder, uint8_t cu_ctx[16], uint32_t dist3[3], double* cost)
+{
+  const int cu = 1 << cfg->log2_cu;
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? cu >> 1 : cu;
+    const uint32_t sse = hop_o_sse(org[c], w, pred[c], w, w, w, c ? cfg->bit_depth_c : cfg->bit_depth_y);
+    dist3[c] = c ? (uint32_t)(int)(cfg->dist_weight[c] * sse) : sse;
+  }
+  Syn s = { coder, cu_ctx };
+  coder->frac &= 32767;
+  bin(&s, CU_SKIP + skip_ctx, 1);
+  merge_index(&s, merge_idx, max_merge_cand);
+  const uint32_t bits = (uint32_t)(coder->frac >> 15);
+  *cost = hop_o_calc_rd_cost(bits, dist3[0] + dist3[1] + dist3[2], cfg->lambda_rd);
+  return bits;
+}

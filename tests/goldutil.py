@@ -343,3 +343,16 @@ def encoder_intracu_calls():
         yield dict(cfg=g["cfg"][i], syn=g["syn"][i], arr=g["arr"][i], coef=np.ascontiguousarray(g["coef"][o:o + n]), cin=g["cin"][i], cuin=g["cuin"][i], cout=g["cout"][i],
                    cuout=g["cuout"][i], bits=int(g["bits"][i]), dist=int(g["dist"][i]))
         o += n
+
+
+def encoder_cuskip_calls():
+    """tests/golden/encoder_cuskip_calls.npz (oracle/make_golden18.py): residual-free candidates (encodeResAndCalcRdInterCU, bSkipRes) of two real encodes: cfg, nd = (skip
+    context, merge index, MaxNumMergeCand, -), prediction and original planes Y | Cb | Cr of the CU, coder (160 B) and the 16 CU-level context states in and out, o4 =
+    (bits, distortion Y, Cb, Cr), cost"""
+    g = load("encoder_cuskip_calls.npz")
+    o = 0
+    for i in range(len(g["cost"])):
+        cu = 1 << int(g["cfg"][i]["log2_cu"]); n = cu * cu * 3 // 2
+        yield dict(cfg=g["cfg"][i], nd=[int(v) for v in g["nd"][i]], pred=np.ascontiguousarray(g["pred"][o:o + n]), org=np.ascontiguousarray(g["org"][o:o + n]), cin=g["cin"][i],
+                   cuin=g["cuin"][i], cout=g["cout"][i], cuout=g["cuout"][i], o4=[int(v) for v in g["o4"][i]], cost=float(g["cost"][i]))
+        o += n

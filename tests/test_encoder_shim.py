@@ -44,7 +44,7 @@ def encode(exe, W, H, seed, td, extra_env=None, sharp=False):
 LOW = ("ss", "frac", "gt", "predY", "predC", "xT", "xIT", "dequant", "rdoq", "estBit", "fillRefs", "distPart", "commit", "rqt", "cuBits", "intraBits")
 # the composite restatements stand in for members that call other replaced members; HOP_SHIM_ORIG hands the named composites back to the reference's own
 # definitions, so every level of the stack is reached (and counted) by some run
-LEVELS = {"": ("ss", "frac", "gt", "predY", "predC", "distPart", "commit", "rqt", "cuBits", "intraSearch", "chromaSearch", "intraCu"),   # transforms, RDOQ, estBit, prediction: all inside the composites here
+LEVELS = {"": ("ss", "frac", "gt", "predY", "predC", "distPart", "commit", "rqt", "cuBits", "intraSearch", "chromaSearch", "intraCu", "cuSkip"),   # transforms, RDOQ, estBit, prediction: all inside the composites here
           "estIntraPredQT,estIntraPredChromaQT": LOW + ("intraRqt", "modeBits", "candList", "intraPred", "calcHAD", "chromaPred"),
           "estIntraPredQT,estIntraPredChromaQT,xRecurIntraCodingQT": LOW + ("modeBits", "candList", "intraPred", "calcHAD", "chromaPred", "tskip")}
 

@@ -207,3 +207,26 @@ def test_intra_cu_total_bits_on_encoder_calls():
         assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
         kinds.add((int(cfg[0]["log2_cu"]), int(syn[0]["part_nxn"]), int(syn[0]["chroma_is_dm"]))); n += 1
     assert n == 40 and len(kinds) >= 6
+
+
+def test_inter_cu_skip_on_encoder_calls():
+    """encodeResAndCalcRdInterCU without residual (bSkipRes): the restatement on the calls recorded inside the encoder - the three distortions of the prediction, bits of skip
+    flag + merge index, cost, context states afterwards"""
+    from goldutil import encoder_cuskip_calls, RQT_CFG, _OCoder
+    O = oracle()
+    O.hop_o_inter_cu_skip.restype = ctypes.c_uint32
+    O.hop_o_inter_cu_skip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+    P3 = ctypes.c_void_p * 3
+    n = 0; kinds = set()
+    for c in encoder_cuskip_calls():
+        cfg = np.zeros(1, RQT_CFG); cfg[0] = c["cfg"]; cu2 = 1 << (2 * int(cfg[0]["log2_cu"]))
+        pl = lambda a: [np.ascontiguousarray(a[:cu2]), np.ascontiguousarray(a[cu2:cu2 + cu2 // 4]), np.ascontiguousarray(a[cu2 + cu2 // 4:])]
+        pr, og = pl(c["pred"]), pl(c["org"])
+        coder = _OCoder(); ctypes.memmove(ctypes.byref(coder), c["cin"].tobytes(), 160)
+        cu = c["cuin"].copy(); d3 = (ctypes.c_uint32 * 3)(); cost = ctypes.c_double()
+        bits = O.hop_o_inter_cu_skip(cfg.ctypes.data, c["nd"][0], c["nd"][1], c["nd"][2], P3(*[a.ctypes.data for a in pr]), P3(*[a.ctypes.data for a in og]), ctypes.addressof(coder),
+                                     cu.ctypes.data, ctypes.addressof(d3), ctypes.addressof(cost))
+        assert [bits] + list(d3) == c["o4"] and cost.value == c["cost"], (n, bits, list(d3), c["o4"])
+        assert bytes(coder.ctx) == c["cout"]["ctx"].tobytes() and int(coder.frac) == int(c["cout"]["frac"]) and np.array_equal(cu, c["cuout"]), n
+        kinds.add((int(cfg[0]["log2_cu"]), c["nd"][1])); n += 1
+    assert n >= 10 and len(kinds) >= 4, (n, kinds)

@@ -1184,6 +1184,53 @@ int hop_intra_cu_total_bits(hop_ctx* c, int n, const hop_rqt_job* jobs, const ho
   return HOP_OK;
 }
 
+int hop_inter_cu_skip_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syntax, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in,
+                             hop_cu_final* d_finals, uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_syntax || !d_ctx_in || !d_cu_ctx_in || !d_finals || !d_bits || !d_cost))) return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_skip_device: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_inter_cu_skip: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  return hop_launch_cu_skip(c, n, d_jobs, d_syntax, d_ctx_in, d_cu_ctx_in, d_finals, d_bits, d_cost, d_ctx_out, d_cu_ctx_out);
+}
+
+int hop_inter_cu_skip(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, int n_ctx, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in,
+                      hop_cu_final* finals, uint32_t* bits, double* cost, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out) {
+  if (!c || n < 0 || (n && (!jobs || !syntax || !ctx_in || !cu_ctx_in || !finals || !bits || !cost || n_ctx <= 0))) return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_skip: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_inter_cu_skip: hop_upload_orig has not been called");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const hop_rqt_job& j = jobs[i]; const hop_cu_syntax& y = syntax[i];
+    const int S = 1 << j.log2_cu;
+    const bool ok = j.log2_cu >= 3 && j.log2_cu <= 6 && j.x >= 0 && j.y >= 0 && (j.x & (S - 1)) == 0 && (j.y & (S - 1)) == 0 && j.x + S <= c->pic_w && j.y + S <= c->pic_h &&
+                    j.ctx_index >= 0 && j.ctx_index < n_ctx && j.lambda_rd > 0.0 && y.skip_ctx >= 0 && y.skip_ctx <= 2 && y.max_merge_cand >= 1 && y.max_merge_cand <= 5 &&
+                    y.pu[0].merge_idx >= 0 && y.pu[0].merge_idx < y.max_merge_cand;
+    if (!ok) return hop_set_err(c, HOP_ERR_ARG, "skip candidate %d: illegal CU / snapshot / merge index / parameters", i);
+  }
+  for (int k = 0; k < n_ctx; k++) {
+    for (int i = 0; i < 150; i++) if (ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "context snapshot %d: state %d out of range", k, i);
+    for (int i = 0; i < 19; i++) if (cu_ctx_in[k].state[i] > 127) return hop_set_err(c, HOP_ERR_ARG, "CU context snapshot %d: state %d out of range", k, i);
+  }
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_j = 0, o_y = al((size_t)n * sizeof(hop_rqt_job)), o_c = al(o_y + (size_t)n * sizeof(hop_cu_syntax)), o_u = al(o_c + (size_t)n_ctx * sizeof(hop_cabac_ctx));
+  const size_t o_f = al(o_u + (size_t)n_ctx * sizeof(hop_cabac_cu_ctx)), o_b = al(o_f + (size_t)n * sizeof(hop_cu_final)), o_k = al(o_b + (size_t)n * 4), o_x = al(o_k + (size_t)n * 8);
+  const size_t o_v = al(o_x + (size_t)n * sizeof(hop_cabac_ctx)), o_e = al(o_v + (size_t)n * sizeof(hop_cabac_cu_ctx));
+  void* st; int r = hop_stage(c, o_e + 256, &st); if (r) return r;
+  char* b = (char*)st;
+  HIPCHK(c, hipMemcpyAsync(b + o_j, jobs, (size_t)n * sizeof(hop_rqt_job), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_y, syntax, (size_t)n * sizeof(hop_cu_syntax), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_c, ctx_in, (size_t)n_ctx * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_u, cu_ctx_in, (size_t)n_ctx * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, c->stream));
+  r = hop_inter_cu_skip_device(c, n, (const hop_rqt_job*)(b + o_j), (const hop_cu_syntax*)(b + o_y), (const hop_cabac_ctx*)(b + o_c), (const hop_cabac_cu_ctx*)(b + o_u),
+                               (hop_cu_final*)(b + o_f), (uint32_t*)(b + o_b), (double*)(b + o_k), (hop_cabac_ctx*)(b + o_x), (hop_cabac_cu_ctx*)(b + o_v));
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(finals, b + o_f, (size_t)n * sizeof(hop_cu_final), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(bits, b + o_b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cost, b + o_k, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (ctx_out) HIPCHK(c, hipMemcpyAsync(ctx_out, b + o_x, (size_t)n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, c->stream));
+  if (cu_ctx_out) HIPCHK(c, hipMemcpyAsync(cu_ctx_out, b + o_v, (size_t)n * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
 int hop_inter_cu_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results, const int32_t* d_coef,
                              const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out,
                              hop_cabac_cu_ctx* d_cu_ctx_out) {

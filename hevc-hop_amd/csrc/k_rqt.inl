@@ -1408,3 +1408,62 @@ int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_cu_total launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+// =====================================================================================================================
+// The residual-free candidate of an SS/GT CU: TEncSearch::encodeResAndCalcRdInterCU with bSkipRes (TLibEncoder/TEncSearch.cpp:6635-6668).  One workgroup per CU: the
+// three SSEs of the prediction picture against the original (getDistPart: chroma weighted), the prediction copied into the reconstruction picture, then lane 0 counts
+// the skip flag and the merge index from the CI_CURR_BEST state and forms calcRdCost.
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void k_cu_skip(int n, const hop_rqt_job* __restrict__ jobs, const hop_cu_syntax* __restrict__ syn, hop_pics pic, int16_t* __restrict__ rec_y,
+                                                int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                const hop_cabac_cu_ctx* __restrict__ cu_in, hop_cu_final* __restrict__ fin, uint32_t* __restrict__ bits_out, double* __restrict__ cost_out,
+                                                hop_cabac_ctx* __restrict__ ctx_out, hop_cabac_cu_ctx* __restrict__ cu_out) {
+  __shared__ CabacLds sh;
+  __shared__ unsigned long long s_sse[3];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const hop_rqt_job jb = jobs[i];
+  const int cu = 1 << jb.log2_cu;
+  if (lane < 3) s_sse[lane] = 0;
+  __syncthreads();
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? cu >> 1 : cu, pitch = c ? pic.pic_w >> 1 : pic.pic_w, x0 = c ? jb.x >> 1 : jb.x, y0 = c ? jb.y >> 1 : jb.y, bd = c ? pic.bd_c : pic.bd_y;
+    const int16_t* org = (c == 0 ? pic.org_y : c == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
+    const int16_t* prd = (c == 0 ? pic.pred_y : c == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+    int16_t* rec = (c == 0 ? rec_y : c == 1 ? rec_cb : rec_cr) + (size_t)y0 * pitch + x0;
+    const int shift = bd > 8 ? (bd - 8) << 1 : 0;                      // DISTORTION_PRECISION_ADJUSTMENT, as k_distortion
+    unsigned long long acc = 0;
+    for (int e = lane; e < w * w; e += 64) {
+      const int r = e / w, q = e % w; const int d = (int)org[(size_t)r * pitch + q] - (int)prd[(size_t)r * pitch + q];
+      acc += (unsigned long long)((unsigned)(d * d) >> shift);
+      rec[(size_t)r * pitch + q] = prd[(size_t)r * pitch + q];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) s_sse[c] = acc;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  const uint32_t dY = (uint32_t)s_sse[0], dU = (uint32_t)(int)(jb.dist_weight[0] * (uint32_t)s_sse[1]), dV = (uint32_t)(int)(jb.dist_weight[1] * (uint32_t)s_sse[2]);
+  const int ci = jb.ctx_index;
+  RQ_LOAD(ctx_in[ci]);
+  for (int q = 0; q < 20; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
+  unsigned long long frac = RQ_LEFT();
+  CBIN(CU_SKIP + syn[i].skip_ctx, 1);
+  frac += cu_merge_index(sh, lane, syn[i].pu[0].merge_idx, syn[i].max_merge_cand);
+  const uint32_t bits = (uint32_t)(frac >> 15);
+  bits_out[i] = bits;
+  cost_out[i] = rqt_cost(bits, dY + dU + dV, jb.lambda_rd);
+  fin[i].root_cbf = 0; fin[i].dist[0] = dY; fin[i].dist[1] = dU; fin[i].dist[2] = dV;
+  if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
+  if (cu_out) for (int q = 0; q < 20; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
+}
+
+int hop_launch_cu_skip(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syn, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, hop_cu_final* d_fin,
+                       uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
+  const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
+  hipLaunchKernelGGL(k_cu_skip, dim3(n), dim3(64), 0, c->stream, n, d_jobs, d_syn, hop_make_pics(c), c->rec[0], c->rec[1], c->rec[2], d_ctx_in, d_cu_in, d_fin, d_bits, d_cost, d_ctx_out,
+                     d_cu_out);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "cu_skip launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

@@ -388,6 +388,16 @@ class Context:
                                                  cu_ctx_in.ctypes.data, bits.ctypes.data, cost.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_intra_cu_total_bits")
         return bits, cost, cx, cu
 
+    def inter_cu_skip(self, jobs, syntax, ctx_in, cu_ctx_in):
+        """encodeResAndCalcRdInterCU without residual: returns (n, 4) root_cbf | dist Y, Cb, Cr, bits, costs, coder states (n, 152), CU-level states (n, 20)"""
+        jobs = np.ascontiguousarray(jobs, RQT_JOB_DTYPE); syntax = np.ascontiguousarray(syntax, CU_SYNTAX_DTYPE); ctx_in = np.ascontiguousarray(ctx_in, np.uint8); cu_ctx_in = np.ascontiguousarray(cu_ctx_in, np.uint8)
+        n = len(jobs); fin = np.zeros((n, 4), np.uint32); bits = np.zeros(n, np.uint32); cost = np.zeros(n, np.float64)
+        cx = np.zeros((n, CABAC_CTX_BYTES), np.uint8); cu = np.zeros((n, CABAC_CU_CTX_BYTES), np.uint8)
+        self.L.hop_inter_cu_skip.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7
+        self._chk(self.L.hop_inter_cu_skip(self.h, n, jobs.ctypes.data, syntax.ctypes.data, len(ctx_in), ctx_in.ctypes.data, cu_ctx_in.ctypes.data, fin.ctypes.data, bits.ctypes.data,
+                                           cost.ctypes.data, cx.ctypes.data, cu.ctypes.data), "hop_inter_cu_skip")
+        return fin, bits, cost, cx, cu
+
     def intra_pred(self, jobs, modes):
         n = len(jobs)
         arr = (IntraJob * n)(*jobs); m = np.ascontiguousarray(modes, np.int32)

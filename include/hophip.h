@@ -508,6 +508,15 @@ int hop_intra_cu_total_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const 
 int hop_intra_cu_total_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_intra_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                                    const int32_t* d_coef, const uint32_t* d_dist, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, double* d_cost,
                                    hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);
+/* ---- the residual-free candidate of an SS/GT CU (row a8b) ---- */
+/* replaces: TEncSearch::encodeResAndCalcRdInterCU with bSkipRes (TLibEncoder/TEncSearch.cpp:6635-6668) for a batch of CUs: the reconstruction is the prediction picture
+ * (copied into the reconstruction picture), finals[i].dist its distortion against the original per plane (chroma weighted, root_cbf 0), bits[i] the skip flag and the merge
+ * index (syntax[i].skip_ctx, pu[0].merge_idx, max_merge_cand) counted from the CI_CURR_BEST state, cost[i] = calcRdCost; ctx_out / cu_ctx_out (may be NULL): the coder to
+ * store as CI_TEMP_BEST.  jobs: position, size, ctx_index, lambda_rd, dist_weight are read. */
+int hop_inter_cu_skip(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu_syntax* syntax, int n_ctx, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_ctx_in,
+                      hop_cu_final* finals, uint32_t* bits, double* cost, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
+int hop_inter_cu_skip_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syntax, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in,
+                             hop_cu_final* d_finals, uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);   /* asynchronous, unchecked */
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

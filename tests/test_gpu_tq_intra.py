@@ -1059,3 +1059,42 @@ def test_intra_entries_empty_and_error_paths(hp):
     sres, r, coef, reco = ctx.intra_luma_search(jobs, syn, opts, sj, snap, cu)
     assert int(sres[0]["dist"]) == 0 and not coef.any() and (reco == 128).all()
     ctx.close()
+
+
+def test_inter_cu_skip_encoder_calls(hp):
+    """hop_inter_cu_skip (encodeResAndCalcRdInterCU without residual) on the calls recorded inside the encoder, each CU placed in one picture with its recorded prediction
+    and original: the three distortions, bits of skip flag + merge index, cost, context states, and the prediction copied into the reconstruction picture"""
+    from goldutil import encoder_cuskip_calls
+    cases = list(encoder_cuskip_calls())
+    n = len(cases); G = 5; W = H = 64 * G
+    assert n <= G * G
+    O = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]; P = [a.copy() for a in O]
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.CU_SYNTAX_DTYPE)
+    snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    for i, c in enumerate(cases):
+        cfg = c["cfg"]; cu = 1 << int(cfg["log2_cu"]); n2 = cu * cu; x0, y0 = (i % G) * 64, (i // G) * 64
+        for k, (a, b, w, xx, yy) in enumerate(((0, n2, cu, x0, y0), (n2, n2 + n2 // 4, cu // 2, x0 // 2, y0 // 2), (n2 + n2 // 4, n2 * 3 // 2, cu // 2, x0 // 2, y0 // 2))):
+            O[k][yy:yy + w, xx:xx + w] = c["org"][a:b].reshape(w, w); P[k][yy:yy + w, xx:xx + w] = c["pred"][a:b].reshape(w, w)
+        j = jobs[i]; j["x"], j["y"], j["log2_cu"], j["ctx_index"], j["lambda_rd"], j["dist_weight"] = x0, y0, int(cfg["log2_cu"]), i, cfg["lambda_rd"], cfg["dist_weight"][1:]
+        j["log2_max_tu"] = 5; j["log2_min_tu_in_cu"] = 2; j["lambda_rdoq"] = 1.0
+        syn[i]["skip_ctx"], syn[i]["max_merge_cand"], syn[i]["n_pu"] = c["nd"][0], c["nd"][2], 1; syn[i]["pu"][0]["merge_flag"] = 1; syn[i]["pu"][0]["merge_idx"] = c["nd"][1]
+        snaps[i, :150] = c["cin"]["ctx"]; left = int(c["cin"]["frac"]) & 32767; snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+        cus[i, :16] = c["cuin"]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(*O)
+    for k in range(3):
+        ctx.plane_upload("pred", k, P[k]); ctx.plane_upload("recon", k, np.full(P[k].shape, -7, np.int16))
+    fin, bits, cost, cx, cu_out = ctx.inter_cu_skip(jobs, syn, snaps, cus)
+    for i, c in enumerate(cases):
+        assert [int(bits[i])] + [int(v) for v in fin[i, 1:]] == c["o4"] and int(fin[i, 0]) == 0 and float(cost[i]) == c["cost"], (i, bits[i], fin[i], c["o4"])
+        assert np.array_equal(cx[i, :150], c["cout"]["ctx"]) and (int(cx[i, 150]) | (int(cx[i, 151]) << 8)) == (int(c["cout"]["frac"]) & 32767), i
+        assert np.array_equal(cu_out[i, :16], c["cuout"]), i
+    for k in range(3):
+        R = ctx.recon_download(k)
+        for i, c in enumerate(cases):
+            cu = (1 << int(c["cfg"]["log2_cu"])) >> (1 if k else 0); xx, yy = ((i % G) * 64) >> (1 if k else 0), ((i // G) * 64) >> (1 if k else 0)
+            assert np.array_equal(R[yy:yy + cu, xx:xx + cu], P[k][yy:yy + cu, xx:xx + cu]), (k, i)
+    bad = syn.copy(); bad[0]["pu"][0]["merge_idx"] = 9
+    with pytest.raises(hp.HopError):
+        ctx.inter_cu_skip(jobs, bad, snaps, cus)
+    ctx.close()

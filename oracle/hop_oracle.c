@@ -20,6 +20,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+static int trunc_x86(double v) { return (v >= -2147483648.0 && v < 2147483648.0) ? (int)v : (-2147483647 - 1); }   /* cvttsd2si */
 #include "hop_oracle.h"
 
 #define HOP_NOT_VALID (-1)           /* TLibCommon/CommonDef.h:126 */
@@ -148,7 +149,7 @@ uint32_t hop_o_bits_gt(const int v[8])
 /* TLibCommon/TComRdCost.h:185-202 with FIX203 (TComRdCost.h:52): (cost * bits) >> 16 in UInt */
 static inline uint32_t mv_bits(int x, int y, int scale, int predX, int predY)
 {
-  return hop_o_component_bits((x << scale) - predX) + hop_o_component_bits((y << scale) - predY);
+  return hop_o_component_bits((x * (1 << scale)) - predX) + hop_o_component_bits((y * (1 << scale)) - predY);
 }
 static inline uint32_t mv_cost(uint32_t lambdaCost, int x, int y, int scale, int predX, int predY)
 {
@@ -377,7 +378,7 @@ uint32_t hop_o_frac_search(const int16_t* org, int orgStride, const int16_t* ref
     int hx = kRefineH[i][0], hy = kRefineH[i][1];
     frac_block(ref, refStride, w, h, 2 * hx, 2 * hy, bitDepth, blk);
     uint32_t d = useHad ? hop_o_hads(org, orgStride, blk, w, w, h, bitDepth) : hop_o_sad(org, orgStride, blk, w, w, h, bitDepth, 0);
-    d += mv_cost(lambdaCost, hx + (mvX << 1), hy + (mvY << 1), 1, predX, predY);
+    d += mv_cost(lambdaCost, hx + (mvX * 2), hy + (mvY * 2), 1, predX, predY);
     if (d < best) { best = d; bi = i; }
   }
   half[0] = kRefineH[bi][0]; half[1] = kRefineH[bi][1];
@@ -386,7 +387,7 @@ uint32_t hop_o_frac_search(const int16_t* org, int orgStride, const int16_t* ref
     int qx = kRefineQ[i][0], qy = kRefineQ[i][1];
     frac_block(ref, refStride, w, h, 2 * half[0] + qx, 2 * half[1] + qy, bitDepth, blk);
     uint32_t d = useHad ? hop_o_hads(org, orgStride, blk, w, w, h, bitDepth) : hop_o_sad(org, orgStride, blk, w, w, h, bitDepth, 0);
-    d += mv_cost(lambdaCost, qx + (((mvX << 1) + half[0]) << 1), qy + (((mvY << 1) + half[1]) << 1), 0, predX, predY);
+    d += mv_cost(lambdaCost, qx + (((mvX * 2) + half[0]) * 2), qy + (((mvY * 2) + half[1]) * 2), 0, predX, predY);
     if (d < best) { best = d; bi = i; }
   }
   qter[0] = kRefineQ[bi][0]; qter[1] = kRefineQ[bi][1];
@@ -459,8 +460,9 @@ static void projective_transform(const int16_t* refCentre, int16_t* aux, const d
     for (int x = offsetX; x < offsetX + wv; x++) {
       double Fx = (h[0] * x + h[3] * y + h[6]) / (h[2] * x + h[5] * y + h[8]);
       double Fy = (h[1] * x + h[4] * y + h[7]) / (h[2] * x + h[5] * y + h[8]);
-      int Y = (int)Fy - offsetY;
-      int X = (int)Fx - offsetX;
+      /* (Int)Fy - offset as the reference's x86 build computes it: cvttsd2si gives INT_MIN for NaN / out-of-range quotients, the subtraction wraps */
+      int Y = (int)((unsigned)trunc_x86(Fy) - (unsigned)offsetY);
+      int X = (int)((unsigned)trunc_x86(Fx) - (unsigned)offsetX);
       double q = (Fy - offsetY - (double)Y);
       double p = (Fx - offsetX - (double)X);
       if (Y < -m) Y = -m;

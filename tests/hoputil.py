@@ -78,9 +78,12 @@ class Planes:
     def __init__(self, W, H):
         self.W, self.H = W, H
         self.sy, self.sc = W + 2 * MARGIN_Y, (W >> 1) + 2 * MARGIN_C
-        self.bufY = np.full((H + 2 * MARGIN_Y, self.sy), -1, np.int16)
-        self.bufCb = np.full(((H >> 1) + 2 * MARGIN_C, self.sc), -1, np.int16)
-        self.bufCr = np.full(((H >> 1) + 2 * MARGIN_C, self.sc), -1, np.int16)
+        # the planes are views into larger arrays with GUARD sentinel rows above and below, as the library keeps them (HOP_GUARD_ROWS): the GT search of a PU at the
+        # picture's top or bottom edge reads a row beyond the reference's own allocation (the reference reads whatever the heap holds there; its results do not depend on it)
+        G = 64
+        self._backY = np.full((H + 2 * MARGIN_Y + 2 * G, self.sy), -1, np.int16); self.bufY = self._backY[G:-G]
+        self._backCb = np.full(((H >> 1) + 2 * MARGIN_C + 2 * G, self.sc), -1, np.int16); self.bufCb = self._backCb[G:-G]
+        self._backCr = np.full(((H >> 1) + 2 * MARGIN_C + 2 * G, self.sc), -1, np.int16); self.bufCr = self._backCr[G:-G]
 
     def y00(self):
         return self.bufY[MARGIN_Y:, MARGIN_Y:]

@@ -945,7 +945,7 @@ int hop_intra_luma_search_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, c
     c->rqt_bytes = wb + wb / 8;
   }
   return hop_launch_intra_search(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, nxn, num_full_rd, n, d_jobs, d_syntax, d_opts,
-                                 d_sjobs, d_ctx_in, d_cu_ctx_in, d_sresults, d_results, d_coef_out, d_reco_out, c->rqt_buf, c->rqt_bytes);
+                                 d_sjobs, d_ctx_in, d_cu_ctx_in, d_sresults, d_results, d_coef_out, d_reco_out, c->rqt_buf, c->rqt_bytes, nullptr);
 }
 
 int hop_intra_luma_search(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, const hop_intra_search_job* sjobs,
@@ -1034,7 +1034,7 @@ int hop_intra_chroma_search_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs,
     c->rqt_bytes = wb + wb / 8;
   }
   return hop_launch_intra_chroma_search(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, cls->sign_hide ? 1 : 0, cls->use_ts ? 1 : 0, n, d_jobs, d_syntax, d_opts, d_ctx_in,
-                                        d_cu_ctx_in, d_results, d_cresults, d_coef_out, d_reco_out, c->rqt_buf, c->rqt_bytes);
+                                        d_cu_ctx_in, d_results, d_cresults, d_coef_out, d_reco_out, c->rqt_buf, c->rqt_bytes, nullptr);
 }
 
 int hop_intra_chroma_search(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syntax, const hop_intra_rqt_opt* opts, int n_ctx, const hop_cabac_ctx* ctx_in,
@@ -1229,6 +1229,68 @@ int hop_inter_cu_skip(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_cu_s
   if (cu_ctx_out) HIPCHK(c, hipMemcpyAsync(cu_ctx_out, b + o_v, (size_t)n * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
+}
+
+// one class of intra candidates, device-resident from the rough search to the cost: luma search -> chroma search -> bits and cost, no host step in between
+static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
+  const hop_rqt_job* cls = &k.cls;
+  const int nxn = k.part_nxn ? 1 : 0;
+  if (k.n < 0 || (k.n && (!k.d_jobs || !k.d_syntax || !k.d_opts || !k.d_sjobs || !k.d_sresults || !k.d_results || !k.d_cresults || !k.d_coef || !k.d_reco_y || !k.d_reco_c ||
+                          !k.d_syntax_out || !k.d_dist || !k.d_bits || !k.d_cost)))
+    return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: bad class descriptor");
+  if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+      cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1 || cls->log2_cu - nxn < cls->log2_min_tu_in_cu || k.num_full_rd < 1 || k.num_full_rd > 8)
+    return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: illegal CU class");
+  if (k.n == 0) return HOP_OK;
+  size_t wb = hop_intra_search_work_bytes(cls->log2_cu, k.n); const size_t wc = hop_intra_chroma_work_bytes(cls->log2_cu, k.n);
+  if (wc > wb) wb = wc;
+  if (wb > c->rqt_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
+    c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
+    c->rqt_bytes = wb + wb / 8;
+  }
+  const int sh = cls->sign_hide ? 1 : 0, ts = cls->use_ts ? 1 : 0;
+  int r = hop_launch_intra_search(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, sh, ts, nxn, k.num_full_rd, k.n, k.d_jobs, k.d_syntax, k.d_opts, k.d_sjobs, d_ctx_in, d_cu_ctx_in,
+                                  k.d_sresults, k.d_results, k.d_coef, k.d_reco_y, c->rqt_buf, c->rqt_bytes, k.d_syntax_out);
+  if (r) return r;
+  r = hop_launch_intra_chroma_search(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, sh, ts, k.n, k.d_jobs, k.d_syntax_out, k.d_opts, d_ctx_in, d_cu_ctx_in, k.d_results,
+                                     k.d_cresults, k.d_coef, k.d_reco_c, c->rqt_buf, c->rqt_bytes, k.d_syntax_out);
+  if (r) return r;
+  r = hop_launch_intra_dist_sum(c, k.n, k.d_sresults, k.d_cresults, k.d_dist);
+  if (r) return r;
+  // the chroma direction of the winner goes into the syntax elements before the bits are counted
+  return hop_launch_intra_cu_total(c, cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, sh, ts, k.n, k.d_jobs, k.d_syntax_out, k.d_results, k.d_coef, d_ctx_in, d_cu_ctx_in, k.d_dist,
+                                   k.d_bits, k.d_cost, k.d_ctx_out, k.d_cu_ctx_out);
+}
+
+int hop_intra_cu_device_classes(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
+  if (!c || n_classes < 0 || (n_classes && (!classes || !d_ctx_in || !d_cu_ctx_in))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_cu_device_classes: hop_upload_orig has not been called");
+  if (n_classes == 0) return HOP_OK;
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+  bool used[HOP_MAX_LANES - 1] = { false, false, false };
+  int rc = HOP_OK;
+  for (int i = 0; i < n_classes && rc == HOP_OK; i++) {
+    const int lane = i % HOP_MAX_LANES;
+    if (lane == 0) { rc = intra_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in); continue; }
+    const int k = lane - 1;
+    std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    rc = intra_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in);
+    std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    used[k] = true;
+  }
+  for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
+    if (!used[k]) continue;
+    hipError_t e = hipEventRecord(c->ev_join[k], c->xstream[k]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join[k], 0);
+    if (e != hipSuccess && rc == HOP_OK) rc = hop_set_err(c, HOP_ERR_DEVICE, "hop_intra_cu_device_classes: stream join: %s", hipGetErrorString(e));
+  }
+  return rc;
 }
 
 int hop_inter_cu_bits_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results, const int32_t* d_coef,

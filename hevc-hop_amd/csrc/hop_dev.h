@@ -149,11 +149,13 @@ size_t hop_intra_search_work_bytes(int log2_cu, int n);
 int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int nxn, int num_full_rd, int n, const hop_rqt_job* d_jobs,
                             const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_intra_search_job* d_sj, const hop_cabac_ctx* d_ctx_in,
                             const hop_cabac_cu_ctx* d_cu_in, hop_intra_search_result* d_sres, hop_rqt_result* d_res, int32_t* d_coef_out, int16_t* d_reco_out, void* buf,
-                            size_t buf_bytes);
+                            size_t buf_bytes, hop_intra_cu_syntax* d_syn_out);
+int hop_launch_intra_dist_sum(hop_ctx* c, int n, const hop_intra_search_result* d_sres, const hop_intra_chroma_result* d_cres, uint32_t* d_dist);
 size_t hop_intra_chroma_work_bytes(int log2_cu, int n);
 int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
                                    const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
-                                   hop_rqt_result* d_res, hop_intra_chroma_result* d_cres, int32_t* d_coef_out, int16_t* d_reco_out, void* buf, size_t buf_bytes);
+                                   hop_rqt_result* d_res, hop_intra_chroma_result* d_cres, int32_t* d_coef_out, int16_t* d_reco_out, void* buf, size_t buf_bytes,
+                                   hop_intra_cu_syntax* d_syn_update);
 int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn,
                               const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, const uint32_t* d_dist,
                               uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);

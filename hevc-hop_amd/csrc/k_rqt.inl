@@ -1037,7 +1037,7 @@ size_t hop_intra_search_work_bytes(int log2_cu, int n) {
 int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int nxn, int num_full_rd, int n, const hop_rqt_job* d_jobs,
                             const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_intra_search_job* d_sj, const hop_cabac_ctx* d_ctx_in,
                             const hop_cabac_cu_ctx* d_cu_in, hop_intra_search_result* d_sres, hop_rqt_result* d_res, int32_t* d_coef_out, int16_t* d_reco_out, void* vbuf,
-                            size_t buf_bytes) {
+                            size_t buf_bytes, hop_intra_cu_syntax* d_syn_out /* may be NULL: the syntax elements with the decided directions and their predictors */) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t cu2 = (size_t)1 << (2 * log2_cu), rq = al(hop_intra_rqt_work_bytes(log2_cu, n));
@@ -1071,6 +1071,10 @@ int hop_launch_intra_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_m
       hipLaunchKernelGGL(k_is_keep, dim3(n), dim3(64), 0, c->stream, k, pu, nxn, pass, n_max, d_jobs, n, mres, syn, tmp, coef_tmp, c->rec[0], pitch, work, d_coef_out, d_reco_out);
     }
     hipLaunchKernelGGL(k_is_commit, dim3(n), dim3(64), 0, c->stream, k, pu, nxn, d_jobs, n, work, mres, syn, d_res, d_sres, c->rec[0], pitch, d_reco_out);
+  }
+  if (d_syn_out) {
+    e = hipMemcpyAsync(d_syn_out, syn, (size_t)n * sizeof(hop_intra_cu_syntax), hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search: %s", hipGetErrorString(e));
   }
   e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra search launch: %s", hipGetErrorString(e));
@@ -1245,11 +1249,15 @@ __global__ __launch_bounds__(64) void k_ic_keep(RqtClass k, const hop_rqt_job* _
   }
 }
 
-__global__ __launch_bounds__(64) void k_ic_commit(RqtClass k, int n, const IcWork* __restrict__ work, hop_rqt_result* __restrict__ res, hop_intra_chroma_result* __restrict__ cres) {
+__global__ __launch_bounds__(64) void k_ic_commit(RqtClass k, int n, const IcWork* __restrict__ work, hop_rqt_result* __restrict__ res, hop_intra_chroma_result* __restrict__ cres,
+                                                  hop_intra_cu_syntax* __restrict__ syn_update) {
   const int i = blockIdx.x, t = threadIdx.x;
   const int parts = 1 << (2 * (k.log2_cu - 2));
   for (int e = t; e < parts; e += 64) { res[i].cbf[1][e] = work[i].cbf[0][e]; res[i].cbf[2][e] = work[i].cbf[1][e]; res[i].tskip[1][e] = work[i].ts[0][e]; res[i].tskip[2][e] = work[i].ts[1][e]; }
-  if (t == 0) { cres[i].best_mode = work[i].best_mode; cres[i].dist = work[i].best_dist; }
+  if (t == 0) {
+    cres[i].best_mode = work[i].best_mode; cres[i].dist = work[i].best_dist;
+    if (syn_update) { syn_update[i].chroma_is_dm = work[i].best_mode == 36; syn_update[i].chroma_dir = work[i].best_mode; }   // setChromIntraDirSubParts (:2779)
+  }
 }
 
 size_t hop_intra_chroma_work_bytes(int log2_cu, int n) {
@@ -1261,7 +1269,8 @@ size_t hop_intra_chroma_work_bytes(int log2_cu, int n) {
 // one class of CUs (size, transform-tree limits / flags); d_res: tr_idx and tskip[0] as the luma search left them (read), cbf[1..2] / tskip[1..2] (written)
 int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
                                    const hop_intra_cu_syntax* d_syn_in, const hop_intra_rqt_opt* d_opt, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
-                                   hop_rqt_result* d_res, hop_intra_chroma_result* d_cres, int32_t* d_coef_out, int16_t* d_reco_out, void* vbuf, size_t buf_bytes) {
+                                   hop_rqt_result* d_res, hop_intra_chroma_result* d_cres, int32_t* d_coef_out, int16_t* d_reco_out, void* vbuf, size_t buf_bytes,
+                                   hop_intra_cu_syntax* d_syn_update /* may be NULL: receives the decided chroma direction */) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t cu2 = (size_t)1 << (2 * log2_cu), n_coeff = (size_t)n * (6 * cu2 + 16), ts_base = (size_t)n * 6 * cu2;
@@ -1319,7 +1328,7 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
     hipLaunchKernelGGL(k_ic_bits, dim3(g64), dim3(64), 0, c->stream, k, d_jobs, B.syn, n, d_ctx_in, d_cu_in, d_res, B.work, B.coef, c->rdoq_scans);
     hipLaunchKernelGGL(k_ic_keep, dim3(n), dim3(64), 0, c->stream, k, d_jobs, n, d_res, B.work, B.coef, c->rec[1], c->rec[2], pitch, d_coef_out, d_reco_out);
   }
-  hipLaunchKernelGGL(k_ic_commit, dim3(n), dim3(64), 0, c->stream, k, n, B.work, d_res, d_cres);
+  hipLaunchKernelGGL(k_ic_commit, dim3(n), dim3(64), 0, c->stream, k, n, B.work, d_res, d_cres, d_syn_update);
   e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search launch: %s", hipGetErrorString(e));
   return HOP_OK;
@@ -1465,5 +1474,18 @@ int hop_launch_cu_skip(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_c
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "cu_skip launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+
+// getTotalDistortion of an intra candidate: luma search + chroma search
+__global__ void k_intra_dist_sum(int n, const hop_intra_search_result* __restrict__ sres, const hop_intra_chroma_result* __restrict__ cres, uint32_t* __restrict__ dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dist[i] = sres[i].dist + cres[i].dist;
+}
+int hop_launch_intra_dist_sum(hop_ctx* c, int n, const hop_intra_search_result* d_sres, const hop_intra_chroma_result* d_cres, uint32_t* d_dist) {
+  hipLaunchKernelGGL(k_intra_dist_sum, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_sres, d_cres, d_dist);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_dist_sum launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }

@@ -517,6 +517,22 @@ int hop_inter_cu_skip(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu
                       hop_cu_final* finals, uint32_t* bits, double* cost, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
 int hop_inter_cu_skip_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syntax, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in,
                              hop_cu_final* d_finals, uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);   /* asynchronous, unchecked */
+/* ---- whole intra candidates, device-resident (rows a0 / a8) ---- */
+/* The body of TEncCu::xCheckRDCostIntra (TLibEncoder/TEncCu.cpp:1455-1503) for several classes of CUs at once, with no host step between the stages: per class
+ * hop_intra_luma_search_device -> hop_intra_chroma_search_device -> getTotalDistortion -> hop_intra_cu_total_bits_device, the classes on separate streams (their chains of
+ * small batch steps fill each other's gaps).  All pointers are device memory except the descriptor array itself; d_syntax_out receives the syntax elements with the decided
+ * directions (what the bit count used).  The CUs of ALL classes of one call must not lie in each other's neighbourhood.  Asynchronous, unchecked beyond the class fields. */
+typedef struct {
+  int32_t n, part_nxn, num_full_rd, pad;
+  hop_rqt_job cls;                            /* size, transform-tree limits and flags of the class (a copy of any of its jobs) */
+  const hop_rqt_job* d_jobs; const hop_intra_cu_syntax* d_syntax; const hop_intra_rqt_opt* d_opts; const hop_intra_search_job* d_sjobs;
+  hop_intra_search_result* d_sresults; hop_rqt_result* d_results; hop_intra_chroma_result* d_cresults;
+  int32_t* d_coef;                            /* 1.5 * size^2 levels per CU: Y | Cb | Cr */
+  int16_t* d_reco_y; int16_t* d_reco_c;       /* size^2 and size^2 / 2 (Cb, Cr) samples per CU */
+  hop_intra_cu_syntax* d_syntax_out; uint32_t* d_dist; uint32_t* d_bits; double* d_cost;
+  hop_cabac_ctx* d_ctx_out; hop_cabac_cu_ctx* d_cu_ctx_out;   /* may be NULL */
+} hop_intra_class;
+int hop_intra_cu_device_classes(hop_ctx* ctx, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -1098,3 +1098,91 @@ def test_inter_cu_skip_encoder_calls(hp):
     with pytest.raises(hp.HopError):
         ctx.inter_cu_skip(jobs, bad, snaps, cus)
     ctx.close()
+
+
+def test_intra_cu_device_classes_vs_staged_entries(hp):
+    """hop_intra_cu_device_classes (whole intra candidates device-resident: luma search -> chroma search -> distortion -> bits and cost, classes on separate streams) on the
+    random CUs of the search tests: every output equals what the three host-array entries give stage by stage (those are checked against the restatement above), the
+    syntax elements it hands back carry the decided directions and their most probable modes"""
+    import torch
+    bd = 8
+    W, H, Y, R, jobs, syn, opts, cfgs, snaps, cus, avs = _irqt_random_cases(hp, hp.load(), bd)
+    n = len(jobs); mid = 1 << (bd - 1)
+    rng = np.random.default_rng(130)
+    sj = np.zeros(n, hp.INTRA_SEARCH_JOB_DTYPE)
+    sj["left_dir"] = rng.integers(0, 35, (n, 4)); sj["above_dir"] = rng.integers(0, 35, (n, 4)); sj["rough_flags"] = 1
+    for i in range(n):
+        sj[i]["sqrt_lambda"] = float(np.sqrt(jobs[i]["lambda_rd"])); sj[i]["num_full_rd"] = 8 if ((1 << int(jobs[i]["log2_cu"])) >> int(syn[i]["part_nxn"])) <= 8 else 3
+    C = [np.clip(Y[::2, ::2] // 2 + 60 + k * 9, 0, 255).astype(np.int16) for k in range(2)]
+    RC = [rng.integers(0, 256, (H // 2, W // 2)).astype(np.int16) for _ in range(2)]
+    def fresh():
+        ctx = hp.Context(W, H, bd)
+        ctx.upload_orig(Y, C[0], C[1]); ctx.plane_upload("recon", 0, R)
+        for k in range(2): ctx.plane_upload("recon", 1 + k, RC[k])
+        return ctx
+    # staged: the three host-array entries
+    ctx = fresh()
+    sres, res, coef_y, reco_y = ctx.intra_luma_search(jobs, syn, opts, sj, snaps, cus)
+    syn2 = syn.copy(); syn2["luma_dir"] = sres["best_dir"]
+    for i in range(n):                                                   # getIntraDirLumaPredictor per PU, as the search derived them
+        nxn = int(syn[i]["part_nxn"])
+        for pu in range(4 if nxn else 1):
+            l = int(sres[i]["best_dir"][pu - 1]) if (nxn and pu & 1) else int(sj[i]["left_dir"][pu]); a = int(sres[i]["best_dir"][pu - 2]) if (nxn and pu & 2) else int(sj[i]["above_dir"][pu])
+            syn2[i]["preds"][pu] = ((l, ((l + 29) % 32) + 2, ((l - 1) % 32) + 2) if l > 1 else (0, 1, 26)) if l == a else (l, a, 0 if (l and a) else (26 if l + a < 2 else 1))
+            syn2[i]["pred_num"][pu] = 3
+    cres, res2, coef_c, reco_c = ctx.intra_chroma_search(jobs, syn2, opts, res, snaps, cus)
+    syn3 = syn2.copy(); syn3["chroma_is_dm"] = cres["best_mode"] == 36; syn3["chroma_dir"] = cres["best_mode"]
+    coef = coef_y + coef_c
+    dist = (sres["dist"] + cres["dist"]).astype(np.uint32)
+    bits, cost, cx, cu_out = ctx.intra_cu_total_bits(jobs, syn3, res2, coef, dist, snaps, cus)
+    rec_staged = [ctx.recon_download(k) for k in range(3)]
+    ctx.close()
+    # device-resident, classes on streams
+    ctx = fresh()
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    CLS = np.dtype([("n", "<i4"), ("part_nxn", "<i4"), ("num_full_rd", "<i4"), ("pad", "<i4"), ("cls", hp.RQT_JOB_DTYPE)] + [(k, "<u8") for k in
+                   ("d_jobs", "d_syntax", "d_opts", "d_sjobs", "d_sresults", "d_results", "d_cresults", "d_coef", "d_reco_y", "d_reco_c", "d_syntax_out", "d_dist", "d_bits", "d_cost",
+                    "d_ctx_out", "d_cu_ctx_out")])
+    assert CLS.itemsize == 16 + hp.RQT_JOB_DTYPE.itemsize + 16 * 8
+    groups = {}
+    for i in range(n):
+        j = jobs[i]; groups.setdefault((int(j["log2_cu"]), int(j["log2_min_tu_in_cu"]), int(j["sign_hide"]), int(j["use_ts"]), int(syn[i]["part_nxn"])), []).append(i)
+    d_snap = up(snaps); d_cus = up(cus)
+    descs = np.zeros(len(groups), CLS); keep = []
+    for gi, (key, idx) in enumerate(sorted(groups.items())):
+        m = len(idx); S = 1 << key[0]
+        jj = jobs[idx].copy(); jj["ctx_index"] = idx
+        bufs = dict(d_jobs=up(jj), d_syntax=up(syn[idx]), d_opts=up(opts[idx]), d_sjobs=up(sj[idx]),
+                    d_sresults=torch.zeros(m * hp.INTRA_SEARCH_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev), d_results=torch.zeros(m * hp.RQT_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+                    d_cresults=torch.zeros(m * 8, dtype=torch.uint8, device=dev), d_coef=torch.zeros(m * S * S * 3 // 2, dtype=torch.int32, device=dev),
+                    d_reco_y=torch.zeros(m * S * S, dtype=torch.int16, device=dev), d_reco_c=torch.zeros(m * S * S // 2, dtype=torch.int16, device=dev),
+                    d_syntax_out=torch.zeros(m * hp.INTRA_CU_SYNTAX_DTYPE.itemsize, dtype=torch.uint8, device=dev), d_dist=torch.zeros(m, dtype=torch.int32, device=dev),
+                    d_bits=torch.zeros(m, dtype=torch.int32, device=dev), d_cost=torch.zeros(m, dtype=torch.float64, device=dev),
+                    d_ctx_out=torch.zeros(m * hp.CABAC_CTX_BYTES, dtype=torch.uint8, device=dev), d_cu_ctx_out=torch.zeros(m * hp.CABAC_CU_CTX_BYTES, dtype=torch.uint8, device=dev))
+        d = descs[gi]; d["n"], d["part_nxn"], d["num_full_rd"], d["cls"] = m, key[4], int(sj[idx[0]]["num_full_rd"]), jj[0]
+        for k2, t in bufs.items(): d[k2] = t.data_ptr()
+        keep.append((idx, S, bufs))
+    ctx.L.hop_intra_cu_device_classes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ctx._chk(ctx.L.hop_intra_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, d_snap.data_ptr(), d_cus.data_ptr()), "hop_intra_cu_device_classes")
+    ctx.sync()
+    coff = np.concatenate([[0], np.cumsum([(3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs])]); yoff = np.concatenate([[0], np.cumsum([1 << (2 * int(j["log2_cu"])) for j in jobs])])
+    for idx, S, b in keep:
+        dn = lambda t, dt: np.frombuffer(t.cpu().numpy().tobytes(), dt)
+        g_s = dn(b["d_sresults"], hp.INTRA_SEARCH_RESULT_DTYPE); g_r = dn(b["d_results"], hp.RQT_RESULT_DTYPE); g_c = dn(b["d_cresults"], np.dtype([("best_mode", "<i4"), ("dist", "<u4")]))
+        g_y = dn(b["d_syntax_out"], hp.INTRA_CU_SYNTAX_DTYPE); g_co = b["d_coef"].cpu().numpy(); g_ry = b["d_reco_y"].cpu().numpy(); g_rc = b["d_reco_c"].cpu().numpy()
+        g_b = b["d_bits"].cpu().numpy().view(np.uint32); g_k = b["d_cost"].cpu().numpy(); g_d = b["d_dist"].cpu().numpy().view(np.uint32)
+        g_cx = b["d_ctx_out"].cpu().numpy().reshape(-1, hp.CABAC_CTX_BYTES); g_cu = b["d_cu_ctx_out"].cpu().numpy().reshape(-1, hp.CABAC_CU_CTX_BYTES)
+        for t, i in enumerate(idx):
+            parts = (S // 4) ** 2; npu = 4 if syn[i]["part_nxn"] else 1; tag = (i, S, npu)
+            assert g_s[t].tobytes() == sres[i].tobytes() and int(g_c[t]["best_mode"]) == int(cres[i]["best_mode"]) and int(g_c[t]["dist"]) == int(cres[i]["dist"]), tag
+            for name in ("tr_idx", "cbf", "tskip"): assert np.array_equal(g_r[t][name][..., :parts], res2[i][name][..., :parts]), (tag, name)
+            assert np.array_equal(g_co[t * S * S * 3 // 2:(t + 1) * S * S * 3 // 2], coef[coff[i]:coff[i + 1]]), tag
+            assert np.array_equal(g_ry[t * S * S:(t + 1) * S * S], reco_y[yoff[i]:yoff[i + 1]]) and np.array_equal(g_rc[t * S * S // 2:(t + 1) * S * S // 2], reco_c[yoff[i] // 2:yoff[i + 1] // 2]), tag
+            assert int(g_d[t]) == int(dist[i]) and int(g_b[t]) == int(bits[i]) and float(g_k[t]) == float(cost[i]), (tag, g_b[t], bits[i])
+            assert np.array_equal(g_cx[t], cx[i]) and np.array_equal(g_cu[t], cu_out[i]), tag
+            for name in ("luma_dir", "preds", "pred_num"): assert np.array_equal(g_y[t][name][:npu], syn3[i][name][:npu]), (tag, name)
+            assert int(g_y[t]["chroma_is_dm"]) == int(syn3[i]["chroma_is_dm"]) and int(g_y[t]["chroma_dir"]) == int(syn3[i]["chroma_dir"]), tag
+    for k in range(3): assert np.array_equal(ctx.recon_download(k), rec_staged[k]), k
+    assert len(groups) >= 8
+    ctx.close()

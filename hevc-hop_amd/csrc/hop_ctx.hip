@@ -116,6 +116,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
                    c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits };
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int k = 0; k < 8; k++) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
     if (c->xstream[k]) (void)hipStreamDestroy(c->xstream[k]);
@@ -1265,10 +1266,59 @@ static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop
                                    k.d_bits, k.d_cost, k.d_ctx_out, k.d_cu_ctx_out);
 }
 
+static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
+
+// The chains are thousands of small launches (the host, not the GPU, sets the pace): a call that repeats - same descriptors, same buffers - is captured into a graph the
+// second time it is seen and replayed from then on.  HOP_GRAPHS=0 turns this off; so does profiling (its events are recorded around the launches).
 int hop_intra_cu_device_classes(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
   if (!c || n_classes < 0 || (n_classes && (!classes || !d_ctx_in || !d_cu_ctx_in))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_cu_device_classes: hop_upload_orig has not been called");
   if (n_classes == 0) return HOP_OK;
+  static const bool graphs_on = !(getenv("HOP_GRAPHS") && getenv("HOP_GRAPHS")[0] == '0');
+  if (!graphs_on || c->prof_on) return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+  uint64_t key = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t nbytes) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < nbytes; i++) { key ^= b[i]; key *= 1099511628211ull; } };
+  mix(classes, (size_t)n_classes * sizeof(hop_intra_class)); mix(&d_ctx_in, sizeof(void*)); mix(&d_cu_ctx_in, sizeof(void*));
+  mix(&c->scratch, sizeof(void*)); mix(&c->scratch_bytes, sizeof(size_t)); mix(&c->rqt_buf, sizeof(void*)); mix(&c->rqt_bytes, sizeof(size_t));
+  mix(c->xscratch, sizeof(c->xscratch)); mix(c->xscratch_bytes, sizeof(c->xscratch_bytes)); mix(c->xrqt_buf, sizeof(c->xrqt_buf)); mix(c->xrqt_bytes, sizeof(c->xrqt_bytes));
+  int slot = -1;
+  for (int i = 0; i < 8; i++) if (c->graphs[i].seen && c->graphs[i].key == key) slot = i;
+  if (slot >= 0 && c->graphs[slot].exec) {
+    hipError_t e = hipGraphLaunch(c->graphs[slot].exec, c->stream);
+    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_intra_cu_device_classes: graph launch: %s", hipGetErrorString(e));
+    c->graph_replays++;
+    return HOP_OK;
+  }
+  if (slot < 0) {                                                     // first sighting: run it the ordinary way (buffers reach their sizes), remember the call
+    slot = c->graph_next; c->graph_next = (c->graph_next + 1) % 8;
+    if (c->graphs[slot].exec) { (void)hipGraphExecDestroy(c->graphs[slot].exec); c->graphs[slot].exec = nullptr; }
+    c->graphs[slot].key = key; c->graphs[slot].seen = 1;
+    return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+  }
+  if (c->graphs[slot].seen < 0) return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);   // capture failed before: stay on the ordinary path
+  hipGraph_t g = nullptr;
+  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in); }
+  const int rc = intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+  hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (rc != HOP_OK || e != hipSuccess || !g) {
+    (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g);
+    c->graphs[slot].seen = -1;
+    return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+  }
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess || !ex) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in); }
+  c->graphs[slot].exec = ex;
+  e = hipGraphLaunch(ex, c->stream);
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_intra_cu_device_classes: graph launch: %s", hipGetErrorString(e));
+  c->graph_replays++;
+  return HOP_OK;
+}
+
+long hop_graph_replays(hop_ctx* c) { return c ? c->graph_replays : 0; }
+
+static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
   bool used[HOP_MAX_LANES - 1] = { false, false, false };

@@ -38,6 +38,8 @@ struct hop_ctx {
   int32_t* entropy_bits;             // device: the 128 fractional-bit values of the CABAC states (ContextModel::m_entropyBits)
   uint16_t* rdoq_scans;              // device: the scan tables of the RDOQ kernel (hop_rdoq_build_scans)
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
+  // instantiated graphs of launch-bound chains (hop_intra_cu_device_classes): key = hash of the call's descriptors and of every buffer the chain touches
+  struct { uint64_t key; int seen; hipGraphExec_t exec; } graphs[8]; int graph_next; long graph_replays;
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
   bool   prof_on;

@@ -533,6 +533,9 @@ typedef struct {
   hop_cabac_ctx* d_ctx_out; hop_cabac_cu_ctx* d_cu_ctx_out;   /* may be NULL */
 } hop_intra_class;
 int hop_intra_cu_device_classes(hop_ctx* ctx, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
+/* A call that repeats (same descriptors, same buffers) is captured into a HIP graph the second time it is seen and replayed from then on (HOP_GRAPHS=0 turns that off).
+ * Diagnostics: how many calls of this context were served by a graph launch. */
+long hop_graph_replays(hop_ctx* ctx);
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,

@@ -1164,8 +1164,17 @@ def test_intra_cu_device_classes_vs_staged_entries(hp):
         for k2, t in bufs.items(): d[k2] = t.data_ptr()
         keep.append((idx, S, bufs))
     ctx.L.hop_intra_cu_device_classes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    ctx._chk(ctx.L.hop_intra_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, d_snap.data_ptr(), d_cus.data_ptr()), "hop_intra_cu_device_classes")
-    ctx.sync()
+    # four calls on the same buffers: the first two issue the launches one by one, the third is captured into a graph, the fourth replays it (HOP_GRAPHS=0: all four the
+    # ordinary way); every call starts from the same pictures and must leave the same results, so the comparison below checks the replayed graph
+    for rep in range(4):
+        ctx.plane_upload("recon", 0, R)
+        for k in range(2): ctx.plane_upload("recon", 1 + k, RC[k])
+        for idx, S, b in keep:
+            for name in ("d_sresults", "d_results", "d_cresults", "d_coef", "d_reco_y", "d_reco_c", "d_syntax_out", "d_dist", "d_bits", "d_cost", "d_ctx_out", "d_cu_ctx_out"): b[name].zero_()
+        ctx._chk(ctx.L.hop_intra_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, d_snap.data_ptr(), d_cus.data_ptr()), "hop_intra_cu_device_classes")
+        ctx.sync()
+    ctx.L.hop_graph_replays.restype = ctypes.c_long; ctx.L.hop_graph_replays.argtypes = [ctypes.c_void_p]
+    assert ctx.L.hop_graph_replays(ctx.h) == (0 if os.environ.get("HOP_GRAPHS", "1")[0] == "0" else 2)      # the capture and one replay
     coff = np.concatenate([[0], np.cumsum([(3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs])]); yoff = np.concatenate([[0], np.cumsum([1 << (2 * int(j["log2_cu"])) for j in jobs])])
     for idx, S, b in keep:
         dn = lambda t, dt: np.frombuffer(t.cpu().numpy().tobytes(), dt)

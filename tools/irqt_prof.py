@@ -51,6 +51,7 @@ for lg in (3, 4, 5, 6):
               float(np.mean([r["tr_idx"][:S * S // 16].mean() for r in res[:2000]])), 100.0 * float(np.mean(res["cbf"][:, 0, 0] != 0))))
 # the whole luma search of a CU (hop_intra_luma_search_device = estIntraPredQT): rough search, candidate list, 4..10 candidate trees, the final tree
 print("CU   part     CUs  device s   kCU/s  Msamples/s   candidates")
+keep_cls = []
 ctx.L.hop_intra_luma_search_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 9
 for lg, nxn in ((3, 1), (3, 0), (4, 0), (5, 0), (6, 0)):
     S = 1 << lg
@@ -97,4 +98,25 @@ for lg, nxn in ((3, 1), (3, 0), (4, 0), (5, 0), (6, 0)):
                                                       du.data_ptr(), db.data_ptr(), dco.data_ptr(), None, None), "intra_cu_total_bits_device")
         ctx.sync(); dtb = time.perf_counter() - t0
     print("   chroma %.4f s (%.1f kCU/s)   bits %.4f s   whole candidate %.1f kCU/s" % (dtc, n / dtc / 1e3, dtb, n / (dt + dtc + dtb) / 1e3))
+    keep_cls.append((n, nxn, nf, jobs[:1].copy(), dj, dy, do, dsj, dq, dr, dcr, dc, dk, dk2, torch.zeros(n * hp.INTRA_CU_SYNTAX_DTYPE.itemsize, dtype=torch.uint8, device=dev), dd, db, dco, dt + dtc + dtb))
+# all five classes of this phase of the frame at once (hop_intra_cu_device_classes: one chain per class, the classes on separate streams)
+CLS = np.dtype([("n", "<i4"), ("part_nxn", "<i4"), ("num_full_rd", "<i4"), ("pad", "<i4"), ("cls", hp.RQT_JOB_DTYPE)] + [(k, "<u8") for k in
+               ("d_jobs", "d_syntax", "d_opts", "d_sjobs", "d_sresults", "d_results", "d_cresults", "d_coef", "d_reco_y", "d_reco_c", "d_syntax_out", "d_dist", "d_bits", "d_cost",
+                "d_ctx_out", "d_cu_ctx_out")])
+descs = np.zeros(len(keep_cls), CLS)
+for d, t in zip(descs, keep_cls):
+    d["n"], d["part_nxn"], d["num_full_rd"], d["cls"] = t[0], t[1], t[2], t[3][0]
+    for name, buf in zip(("d_jobs", "d_syntax", "d_opts", "d_sjobs", "d_sresults", "d_results", "d_cresults", "d_coef", "d_reco_y", "d_reco_c", "d_syntax_out", "d_dist", "d_bits", "d_cost"), t[4:18]):
+        d[name] = buf.data_ptr()
+ctx.L.hop_intra_cu_device_classes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+# (the five sets overlap in the picture; the timing does not care, a caller would hand over sets that do not)
+# calls 1-2 issue the launches one by one, call 3 captures them into a graph, calls 4-6 replay it
+times = []
+for it in range(6):
+    ctx.plane_upload("recon", 0, Y); ctx.plane_upload("recon", 1, C); ctx.plane_upload("recon", 2, C)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctx._chk(ctx.L.hop_intra_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, ds.data_ptr(), du.data_ptr()), "hop_intra_cu_device_classes")
+    ctx.sync(); dta = time.perf_counter() - t0; times.append(dta)
+print("per call:", " ".join("%.4f" % t for t in times), "(launch by launch, launch by launch, capture, replay x3)")
+print("all five classes at once: %.4f s (one after the other: %.4f s); %d candidates, %.1f kCU/s" % (dta, sum(t[18] for t in keep_cls), sum(t[0] for t in keep_cls), sum(t[0] for t in keep_cls) / dta / 1e3))
 ctx.close()

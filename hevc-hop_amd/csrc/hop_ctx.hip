@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <functional>
 #include <utility>
 #include <algorithm>
 #include "hop_dev.h"
@@ -1268,24 +1269,21 @@ static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop
 
 static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
 
-// The chains are thousands of small launches (the host, not the GPU, sets the pace): a call that repeats - same descriptors, same buffers - is captured into a graph the
-// second time it is seen and replayed from then on.  HOP_GRAPHS=0 turns this off; so does profiling (its events are recorded around the launches).
-int hop_intra_cu_device_classes(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
-  if (!c || n_classes < 0 || (n_classes && (!classes || !d_ctx_in || !d_cu_ctx_in))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: bad argument");
-  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_cu_device_classes: hop_upload_orig has not been called");
-  if (n_classes == 0) return HOP_OK;
+// The candidate chains are thousands of small launches: a call that repeats - same descriptors, same buffers - is captured into a graph the second time it is seen and
+// replayed from then on.  HOP_GRAPHS=0 turns this off; so does profiling (its events are recorded around the launches).  desc / desc_bytes: what identifies the call.
+static int hop_graph_or_issue(hop_ctx* c, const char* what, const void* desc, size_t desc_bytes, const void* p0, const void* p1, const std::function<int()>& issue) {
   static const bool graphs_on = !(getenv("HOP_GRAPHS") && getenv("HOP_GRAPHS")[0] == '0');
-  if (!graphs_on || c->prof_on) return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+  if (!graphs_on || c->prof_on) return issue();
   uint64_t key = 1469598103934665603ull;
   auto mix = [&](const void* p, size_t nbytes) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < nbytes; i++) { key ^= b[i]; key *= 1099511628211ull; } };
-  mix(classes, (size_t)n_classes * sizeof(hop_intra_class)); mix(&d_ctx_in, sizeof(void*)); mix(&d_cu_ctx_in, sizeof(void*));
+  mix(what, strlen(what)); mix(desc, desc_bytes); mix(&p0, sizeof(void*)); mix(&p1, sizeof(void*));
   mix(&c->scratch, sizeof(void*)); mix(&c->scratch_bytes, sizeof(size_t)); mix(&c->rqt_buf, sizeof(void*)); mix(&c->rqt_bytes, sizeof(size_t));
   mix(c->xscratch, sizeof(c->xscratch)); mix(c->xscratch_bytes, sizeof(c->xscratch_bytes)); mix(c->xrqt_buf, sizeof(c->xrqt_buf)); mix(c->xrqt_bytes, sizeof(c->xrqt_bytes));
   int slot = -1;
   for (int i = 0; i < 8; i++) if (c->graphs[i].seen && c->graphs[i].key == key) slot = i;
   if (slot >= 0 && c->graphs[slot].exec) {
     hipError_t e = hipGraphLaunch(c->graphs[slot].exec, c->stream);
-    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_intra_cu_device_classes: graph launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "%s: graph launch: %s", what, hipGetErrorString(e));
     c->graph_replays++;
     return HOP_OK;
   }
@@ -1293,30 +1291,79 @@ int hop_intra_cu_device_classes(hop_ctx* c, int n_classes, const hop_intra_class
     slot = c->graph_next; c->graph_next = (c->graph_next + 1) % 8;
     if (c->graphs[slot].exec) { (void)hipGraphExecDestroy(c->graphs[slot].exec); c->graphs[slot].exec = nullptr; }
     c->graphs[slot].key = key; c->graphs[slot].seen = 1;
-    return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+    return issue();
   }
-  if (c->graphs[slot].seen < 0) return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);   // capture failed before: stay on the ordinary path
+  if (c->graphs[slot].seen < 0) return issue();                        // capture failed before: stay on the ordinary path
   hipGraph_t g = nullptr;
-  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in); }
-  const int rc = intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return issue(); }
+  const int rc = issue();
   hipError_t e = hipStreamEndCapture(c->stream, &g);
   if (rc != HOP_OK || e != hipSuccess || !g) {
     (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g);
     c->graphs[slot].seen = -1;
-    return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
+    return issue();
   }
   hipGraphExec_t ex = nullptr;
   e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
-  if (e != hipSuccess || !ex) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in); }
+  if (e != hipSuccess || !ex) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return issue(); }
   c->graphs[slot].exec = ex;
   e = hipGraphLaunch(ex, c->stream);
-  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_intra_cu_device_classes: graph launch: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "%s: graph launch: %s", what, hipGetErrorString(e));
   c->graph_replays++;
   return HOP_OK;
 }
 
+int hop_intra_cu_device_classes(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
+  if (!c || n_classes < 0 || (n_classes && (!classes || !d_ctx_in || !d_cu_ctx_in))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_cu_device_classes: hop_upload_orig has not been called");
+  if (n_classes == 0) return HOP_OK;
+  return hop_graph_or_issue(c, "hop_intra_cu_device_classes", classes, (size_t)n_classes * sizeof(hop_intra_class), d_ctx_in, d_cu_ctx_in,
+                            [&]() { return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in); });
+}
+
 long hop_graph_replays(hop_ctx* c) { return c ? c->graph_replays : 0; }
+
+static int inter_candidate_chain(hop_ctx* c, const hop_inter_class& k, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
+  if (k.n < 0 || (k.n && (!k.d_jobs || !k.d_syntax || !k.d_results || !k.d_coef || !k.d_ctx_after || !k.d_finals || !k.d_bits || !k.d_skipped || !k.d_cost)))
+    return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_device_classes: bad class descriptor");
+  if (k.n == 0) return HOP_OK;
+  int r = hop_rqt_device(c, k.n, k.d_jobs, &k.cls, d_ctx_in, k.d_results, k.d_coef, k.d_ctx_after); if (r) return r;
+  r = hop_rqt_finish_device(c, k.n, k.d_jobs, &k.cls, k.d_results, k.d_coef, k.d_ctx_after, k.d_finals); if (r) return r;
+  r = hop_inter_cu_bits_device(c, k.n, k.d_jobs, &k.cls, k.d_syntax, k.d_results, k.d_coef, d_ctx_in, d_cu_ctx_in, k.d_bits, k.d_skipped, k.d_ctx_out, k.d_cu_ctx_out); if (r) return r;
+  return hop_launch_inter_cost(c, k.n, k.d_jobs, k.d_finals, k.d_bits, k.d_cost);
+}
+
+int hop_inter_cu_device_classes(hop_ctx* c, int n_classes, const hop_inter_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
+  if (!c || n_classes < 0 || (n_classes && (!classes || !d_ctx_in || !d_cu_ctx_in))) return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_device_classes: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_inter_cu_device_classes: hop_upload_orig has not been called");
+  if (n_classes == 0) return HOP_OK;
+  auto issue = [&]() -> int {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+    bool used[HOP_MAX_LANES - 1] = { false, false, false };
+    int rc = HOP_OK;
+    for (int i = 0; i < n_classes && rc == HOP_OK; i++) {
+      const int lane = i % HOP_MAX_LANES;
+      if (lane == 0) { rc = inter_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in); continue; }
+      const int k = lane - 1;
+      std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+      std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+      rc = inter_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in);
+      std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
+      std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+      used[k] = true;
+    }
+    for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
+      if (!used[k]) continue;
+      hipError_t e = hipEventRecord(c->ev_join[k], c->xstream[k]);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join[k], 0);
+      if (e != hipSuccess && rc == HOP_OK) rc = hop_set_err(c, HOP_ERR_DEVICE, "hop_inter_cu_device_classes: stream join: %s", hipGetErrorString(e));
+    }
+    return rc;
+  };
+  return hop_graph_or_issue(c, "hop_inter_cu_device_classes", classes, (size_t)n_classes * sizeof(hop_inter_class), d_ctx_in, d_cu_ctx_in, issue);
+}
 
 static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));

@@ -163,6 +163,7 @@ int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2
                               uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);
 int hop_launch_cu_skip(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syn, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, hop_cu_final* d_fin,
                        uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);
+int hop_launch_inter_cost(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_cu_final* d_fin, const uint32_t* d_bits, double* d_cost);
 size_t hop_rqt_finish_work_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n);
 int hop_launch_rqt_finish(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int use_ts, int n, const hop_rqt_job* d_jobs, hop_rqt_result* d_res, int32_t* d_coef,
                           const hop_cabac_ctx* d_after, hop_cu_final* d_fin, void* buf);

@@ -1489,3 +1489,16 @@ int hop_launch_intra_dist_sum(hop_ctx* c, int n, const hop_intra_search_result* 
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_dist_sum launch: %s", hipGetErrorString(e));
   return HOP_OK;
 }
+
+
+// getTotalCost of an SS/GT candidate with residual: calcRdCost(bits of xAddSymbolBitsInter, the three final distortions) (TEncSearch.cpp:6804-6812)
+__global__ void k_inter_cost(int n, const hop_rqt_job* __restrict__ jobs, const hop_cu_final* __restrict__ fin, const uint32_t* __restrict__ bits, double* __restrict__ cost) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cost[i] = rqt_cost(bits[i], fin[i].dist[0] + fin[i].dist[1] + fin[i].dist[2], jobs[i].lambda_rd);
+}
+int hop_launch_inter_cost(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_cu_final* d_fin, const uint32_t* d_bits, double* d_cost) {
+  hipLaunchKernelGGL(k_inter_cost, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_jobs, d_fin, d_bits, d_cost);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "inter_cost launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

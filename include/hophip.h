@@ -517,6 +517,21 @@ int hop_inter_cu_skip(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu
                       hop_cu_final* finals, uint32_t* bits, double* cost, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_ctx_out);
 int hop_inter_cu_skip_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syntax, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in,
                              hop_cu_final* d_finals, uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);   /* asynchronous, unchecked */
+/* ---- whole SS/GT candidates with residual, device-resident (rows a0 / a8b) ---- */
+/* TEncSearch::encodeResAndCalcRdInterCU without bSkipRes (TLibEncoder/TEncSearch.cpp:6670-6822) for several classes of CUs at once, no host step between the stages: per
+ * class hop_rqt_device -> hop_rqt_finish_device -> hop_inter_cu_bits_device -> getTotalCost = calcRdCost(bits, final distortions); the classes on separate streams; a call
+ * that repeats is replayed as a HIP graph (see hop_intra_cu_device_classes).  The prediction picture holds the candidates' predictions.  All pointers device memory except
+ * the descriptor array; d_ctx_after: scratch for the coder after the quadtree (n states).  Asynchronous, unchecked beyond the class fields. */
+typedef struct {
+  int32_t n, pad;
+  hop_rqt_job cls;
+  const hop_rqt_job* d_jobs; const hop_cu_syntax* d_syntax;
+  hop_rqt_result* d_results; int32_t* d_coef; hop_cabac_ctx* d_ctx_after; hop_cu_final* d_finals;
+  uint32_t* d_bits; uint32_t* d_skipped; double* d_cost;
+  hop_cabac_ctx* d_ctx_out; hop_cabac_cu_ctx* d_cu_ctx_out;   /* may be NULL */
+} hop_inter_class;
+int hop_inter_cu_device_classes(hop_ctx* ctx, int n_classes, const hop_inter_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
+
 /* ---- whole intra candidates, device-resident (rows a0 / a8) ---- */
 /* The body of TEncCu::xCheckRDCostIntra (TLibEncoder/TEncCu.cpp:1455-1503) for several classes of CUs at once, with no host step between the stages: per class
  * hop_intra_luma_search_device -> hop_intra_chroma_search_device -> getTotalDistortion -> hop_intra_cu_total_bits_device, the classes on separate streams (their chains of

@@ -1195,3 +1195,85 @@ def test_intra_cu_device_classes_vs_staged_entries(hp):
     for k in range(3): assert np.array_equal(ctx.recon_download(k), rec_staged[k]), k
     assert len(groups) >= 8
     ctx.close()
+
+
+def test_inter_cu_device_classes_vs_staged_entries(hp):
+    """hop_inter_cu_device_classes (SS/GT candidates with residual, device-resident: quadtree -> root-cbf decision and reconstruction -> CU syntax bits -> cost, classes on
+    separate streams, repeated calls replayed as a graph) against the three host-array entries stage by stage (those are checked against the restatement and the recorded
+    encoder calls above): 40 random CUs of all sizes, four calls (launch by launch twice, captured, replayed)"""
+    import torch
+    O = oracle(); O.hop_o_calc_rd_cost.restype = ctypes.c_double; O.hop_o_calc_rd_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double]
+    rng = np.random.default_rng(150)
+    W, H, n = 512, 320, 40
+    org = [np.full((H, W), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16), np.full((H // 2, W // 2), 128, np.int16)]
+    jobs = np.zeros(n, hp.RQT_JOB_DTYPE); syn = np.zeros(n, hp.CU_SYNTAX_DTYPE); snaps = np.zeros((n, hp.CABAC_CTX_BYTES), np.uint8); cus = np.zeros((n, hp.CABAC_CU_CTX_BYTES), np.uint8)
+    L = hp.load(); L.hop_cabac_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; L.hop_cabac_cu_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    for i in range(n):
+        lg = 3 + (i % 4); cu = 1 << lg; x, y = 64 * (i % 8), 64 * (i // 8)
+        yy, xx = np.mgrid[0:cu, 0:cu]; amp = float(rng.choice([4, 12, 40]))
+        ry = amp * np.sin(xx * rng.uniform(0.1, 0.9) + rng.uniform(0, 3)) * np.cos(yy * rng.uniform(0.1, 0.9)) + rng.normal(0, amp / 4, (cu, cu))
+        if rng.random() < 0.5:
+            m = rng.random((cu, cu)) < 0.06; ry[m] += rng.choice([-1, 1], int(m.sum())) * 6 * amp
+        org[0][y:y + cu, x:x + cu] += np.rint(ry).astype(np.int16)
+        for k in (1, 2): org[k][y // 2:(y + cu) // 2, x // 2:(x + cu) // 2] += np.rint(ry[::2, ::2] * (0.5 if k == 1 else -0.4)).astype(np.int16)
+        qp = int(rng.integers(22, 40)); lam = 0.57 * 2.0 ** ((qp - 12) / 3.0); w = float(rng.choice([1.0, 1.26]))
+        j = jobs[i]; j["x"], j["y"], j["log2_cu"], j["qp_scaled"], j["ctx_index"] = x, y, lg, (qp, qp - 1, qp - 2), i
+        j["sign_hide"], j["use_ts"], j["log2_max_tu"], j["log2_min_tu_in_cu"] = 1, 1, 5, max(2, lg - 2)
+        j["lambda_rd"], j["lambda_rdoq"], j["dist_weight"] = lam, (lam, lam / w, lam / w), (w, w)
+        s = syn[i]; s["n_pu"], s["max_merge_cand"], s["amp_acc"], s["is_min_cu"], s["skip_ctx"] = 1, 5, int(cu >= 16), int(cu == 8), int(rng.integers(0, 3))
+        s["pu"][0]["mvd"] = rng.integers(-40, 41, 2); s["pu"][0]["gt_flag"] = int(rng.integers(0, 2)); s["pu"][0]["gt"] = rng.integers(-3, 4, 8)
+        assert L.hop_cabac_init(snaps[i].ctypes.data, int(rng.integers(0, 5)), qp) == 0 and L.hop_cabac_cu_init(cus[i].ctypes.data, int(rng.integers(0, 5)), qp) == 0
+        left = int(rng.integers(0, 32768)); snaps[i, 150], snaps[i, 151] = left & 255, left >> 8
+    org = [np.clip(a, 0, 255) for a in org]
+    def fresh():
+        ctx = hp.Context(W, H)
+        ctx.upload_orig(*org)
+        for k in range(3):
+            ctx.plane_upload("pred", k, np.full(org[k].shape, 128, np.int16)); ctx.plane_upload("recon", k, np.zeros(org[k].shape, np.int16))
+        return ctx
+    ctx = fresh()
+    res, co, cx = ctx.rqt(jobs, snaps)
+    res3, co3, fin3 = ctx.rqt_finish(jobs, res, co, cx)
+    bits, skipped, bx, bu = ctx.inter_cu_bits(jobs, syn, res3, co3, snaps, cus)
+    rec_staged = [ctx.recon_download(k) for k in range(3)]
+    ctx.close()
+    ctx = fresh()
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    CLS = np.dtype([("n", "<i4"), ("pad", "<i4"), ("cls", hp.RQT_JOB_DTYPE)] + [(k, "<u8") for k in
+                   ("d_jobs", "d_syntax", "d_results", "d_coef", "d_ctx_after", "d_finals", "d_bits", "d_skipped", "d_cost", "d_ctx_out", "d_cu_ctx_out")])
+    groups = {}
+    for i in range(n): groups.setdefault(int(jobs[i]["log2_cu"]), []).append(i)
+    d_snap = up(snaps); d_cus = up(cus)
+    descs = np.zeros(len(groups), CLS); keep = []
+    for gi, (lg, idx) in enumerate(sorted(groups.items())):
+        m = len(idx); S = 1 << lg; jj = jobs[idx].copy()
+        b = dict(d_jobs=up(jj), d_syntax=up(syn[idx]), d_results=torch.zeros(m * hp.RQT_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev), d_coef=torch.zeros(m * S * S * 3 // 2, dtype=torch.int32, device=dev),
+                 d_ctx_after=torch.zeros(m * hp.CABAC_CTX_BYTES, dtype=torch.uint8, device=dev), d_finals=torch.zeros(m * 4, dtype=torch.int32, device=dev), d_bits=torch.zeros(m, dtype=torch.int32, device=dev),
+                 d_skipped=torch.zeros(m, dtype=torch.int32, device=dev), d_cost=torch.zeros(m, dtype=torch.float64, device=dev),
+                 d_ctx_out=torch.zeros(m * hp.CABAC_CTX_BYTES, dtype=torch.uint8, device=dev), d_cu_ctx_out=torch.zeros(m * hp.CABAC_CU_CTX_BYTES, dtype=torch.uint8, device=dev))
+        d = descs[gi]; d["n"], d["cls"] = m, jj[0]
+        for k2, t in b.items(): d[k2] = t.data_ptr()
+        keep.append((idx, S, b))
+    ctx.L.hop_inter_cu_device_classes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ctx.L.hop_graph_replays.restype = ctypes.c_long; ctx.L.hop_graph_replays.argtypes = [ctypes.c_void_p]
+    for rep in range(4):
+        for k in range(3): ctx.plane_upload("recon", k, np.zeros(org[k].shape, np.int16))
+        for idx, S, b in keep:
+            for name in ("d_results", "d_coef", "d_ctx_after", "d_finals", "d_bits", "d_skipped", "d_cost", "d_ctx_out", "d_cu_ctx_out"): b[name].zero_()
+        ctx._chk(ctx.L.hop_inter_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, d_snap.data_ptr(), d_cus.data_ptr()), "hop_inter_cu_device_classes")
+        ctx.sync()
+    assert ctx.L.hop_graph_replays(ctx.h) == (0 if os.environ.get("HOP_GRAPHS", "1")[0] == "0" else 2)
+    coff = np.concatenate([[0], np.cumsum([(3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs])])
+    for idx, S, b in keep:
+        g_r = np.frombuffer(b["d_results"].cpu().numpy().tobytes(), hp.RQT_RESULT_DTYPE); g_co = b["d_coef"].cpu().numpy(); g_f = b["d_finals"].cpu().numpy().view(np.uint32).reshape(-1, 4)
+        g_b = b["d_bits"].cpu().numpy().view(np.uint32); g_s = b["d_skipped"].cpu().numpy().view(np.uint32); g_k = b["d_cost"].cpu().numpy()
+        g_cx = b["d_ctx_out"].cpu().numpy().reshape(-1, hp.CABAC_CTX_BYTES); g_cu = b["d_cu_ctx_out"].cpu().numpy().reshape(-1, hp.CABAC_CU_CTX_BYTES)
+        for t, i in enumerate(idx):
+            parts = (S // 4) ** 2
+            for name in ("tr_idx", "cbf", "tskip"): assert np.array_equal(g_r[t][name][..., :parts], res3[i][name][..., :parts]), (i, name)
+            assert np.array_equal(g_co[t * S * S * 3 // 2:(t + 1) * S * S * 3 // 2], co3[coff[i]:coff[i + 1]]) and np.array_equal(g_f[t], fin3[i]), i
+            assert int(g_b[t]) == int(bits[i]) and int(g_s[t]) == int(skipped[i]) and np.array_equal(g_cx[t], bx[i]) and np.array_equal(g_cu[t], bu[i]), i
+            assert float(g_k[t]) == O.hop_o_calc_rd_cost(int(bits[i]), int(fin3[i][1]) + int(fin3[i][2]) + int(fin3[i][3]), float(jobs[i]["lambda_rd"])), i
+    for k in range(3): assert np.array_equal(ctx.recon_download(k), rec_staged[k]), k
+    ctx.close()

@@ -124,6 +124,9 @@ def main():
     args = ap.parse_args()
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: for N > 1 launch it as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (one process per GPU)" % (args.gpus, world))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libhophip has no CPU path")
@@ -312,9 +315,8 @@ def main():
     L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.hop_profile_reset.argtypes = [ctypes.c_void_p]
     L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    barrier()
-    chk(L.hop_profile_reset(ctx.h), "profile_reset")
-    chk(L.hop_profile_enable(ctx.h, 1), "profile_enable")
+    L.hop_set_lanes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    # ---- the timed region: exactly `steps` steps, profiling OFF (no event pairs around the launches) ----
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -325,12 +327,25 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- a separate, untimed profiling pass for the roofline: ONE stream lane, so that no two kernels share the device and the
+    #      HIP-event durations (recorded on the library's stream) are exclusive.  profiles/r02_bench_excl_kernel_stats.csv is the
+    #      rocprofv3 --kernel-trace --stats view of the same pass (HOP_LANES=1). ----
+    prof_steps = max(1, min(2, args.steps))
+    chk(L.hop_set_lanes(ctx.h, 1), "set_lanes")
+    chk(L.hop_profile_reset(ctx.h), "profile_reset")
+    chk(L.hop_profile_enable(ctx.h, 1), "profile_enable")
+    barrier()
+    tp0 = time.perf_counter()
+    for _ in range(prof_steps):
+        step()
+    barrier()
+    prof_ms_per_step = (time.perf_counter() - tp0) / prof_steps * 1e3
     prof = {}
     names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 6: "k_tu_rd (transform + setup + inverse + decide)", 7: "k_intra_rough", 8: "k_rdoq", 9: "k_coeff_bits"}
     for kid, name in names.items():
         la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
         chk(L.hop_profile_read(ctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
-        prof[name] = {"launches": la.value, "total_ms": ms.value, "units": un.value}
+        prof[name] = {"launches": la.value, "total_ms": ms.value, "units": un.value, "ms_per_step": ms.value / prof_steps}
     chk(L.hop_profile_enable(ctx.h, 0), "profile_disable")
     # a result checksum so that a run can be compared with another build
     res_host = np.frombuffer(d_res.cpu().numpy().tobytes(), hp.PU_RESULT_DTYPE)
@@ -352,7 +367,7 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["total_ms"])
         p = prof[dom]
         avg_ms = p["total_ms"] / max(1, p["launches"])
-        ctus_per_launch = my_ctus * args.steps / max(1, p["launches"])
+        ctus_per_launch = my_ctus * prof_steps / max(1, p["launches"])
         achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (profiles/r01_traffic.json; PMC counters cannot be read from inside the process)
@@ -366,10 +381,10 @@ def main():
         # honest VALU-side figures (neither HBM nor MFMA binds this path)
         st = 1 + 2
         samples = float(np.sum(st * np.array([gt_iters(int(w), int(h)) for w, h in zip(jobs["w"], jobs["h"])]) * 56.0 * jobs["w"] * jobs["h"]))
-        gt_tflops = samples * WARP_FLOP_PER_SAMPLE * args.steps / (prof["k_gt_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_gt_search"]["total_ms"] else 0.0
+        gt_tflops = samples * WARP_FLOP_PER_SAMPLE * prof_steps / (prof["k_gt_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_gt_search"]["total_ms"] else 0.0
         win = (jobs["rng_right"] - jobs["rng_left"] + 1).clip(0) * (jobs["rng_bottom"] - jobs["rng_top"] + 1).clip(0)
         sad_ops = float(np.sum(win.astype(np.float64) * jobs["w"] * jobs["h"] / np.where(jobs["h"] > 8, 2, 1) / 2.0))   # v_sad_u16 lane-ops
-        ss_tops = sad_ops * args.steps / (prof["k_ss_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_ss_search"]["total_ms"] else 0.0
+        ss_tops = sad_ops * prof_steps / (prof["k_ss_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_ss_search"]["total_ms"] else 0.0
         out = {
             "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (hot-path kernels, frozen SS reference)",
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -392,8 +407,8 @@ def main():
                          "note": "reference-equivalent work (one full search per PU); CU families derive the five symmetric PUs of a CU from one set of "
                                  "quadrant SADs, so about a third of these v_sad_u16 are executed"},
             "kernels": prof,
-            "kernels_note": "HIP-event time per launch; hop_me_search_device runs the two halves of a batch on two streams, so launches of "
-                            "different kernels overlap and the totals add up to more than the step time",
+            "kernels_note": "HIP-event time per launch from a separate untimed pass of %d step(s) on ONE stream lane (hop_set_lanes 1): exclusive durations; "
+                            "that pass ran at %.1f ms per step, the timed region (2 lanes, profiling off) at ms_per_step" % (prof_steps, prof_ms_per_step),
             "tu_rd_crc": tu_crc,
             "result_crc": int(np.bitwise_xor.reduce(res_host["cost"].astype(np.uint64) * np.arange(1, len(res_host) + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)),
         }

@@ -315,6 +315,12 @@ static int me_pipeline(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_resul
   return HOP_OK;
 }
 
+int hop_set_lanes(hop_ctx* c, int lanes) {
+  if (!c || lanes < 1 || lanes > HOP_MAX_LANES) return hop_set_err(c, HOP_ERR_ARG, "hop_set_lanes: 1..%d", HOP_MAX_LANES);
+  c->lanes = lanes;
+  return HOP_OK;
+}
+
 int hop_me_search_device(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_results, int stage) {
   if (!c || n < 0 || stage < HOP_STAGE_INT || stage > HOP_STAGE_GT || (n && (!d_jobs || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_me_search_device: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_me_search: hop_upload_orig has not been called");

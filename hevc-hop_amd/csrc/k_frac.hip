@@ -43,13 +43,15 @@ __global__ __launch_bounds__(NW * 64) void k_frac(const hop_pu_job* __restrict__
   if (blockIdx.x >= *count) return;
   const int pu = index[blockIdx.x];
   const hop_pu_job jb = jobs[pu];
-  hop_pu_result rr = res[pu];
-  if (rr.not_valid) return;
+  // only the fields the stage reads are loaded and only the ones it changes are stored: a local copy of the 100-byte result
+  // lived on the scratch stack (40 B private segment per lane, 2.2 KB of HBM writes per PU, profiles/r01_traffic.json)
+  hop_pu_result* __restrict__ rp = res + pu;
+  if (rp->not_valid) return;
   const int W = jb.w, H = jb.h, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int bd = pic.bd_y, headRoom = 14 - bd, maxVal = (1 << bd) - 1;
   const bool use_had = (jb.flags & HOP_FLAG_HADME) != 0;
   const bool had8 = ((W & 7) == 0) && ((H & 7) == 0);
-  const int mvx = rr.mv_int[0], mvy = rr.mv_int[1];
+  const int mvx = rp->mv_int[0], mvy = rp->mv_int[1];
   {
     const int16_t* src = pic.ss_y + (ptrdiff_t)(jb.pu_y + mvy - 4) * pic.stride_y + (jb.pu_x + mvx - 4);
     for (int i = tid; i < (H + 8) * (W + 8); i += NT) {
@@ -61,12 +63,12 @@ __global__ __launch_bounds__(NW * 64) void k_frac(const hop_pu_job* __restrict__
       sh.org[i] = pic.org_y[(size_t)(jb.pu_y + r) * pic.pic_w + jb.pu_x + c];
     }
   }
-  int half[2] = {0, 0}, qter[2] = {0, 0};
+  int half0 = 0, half1 = 0, qter0 = 0, qter1 = 0;
   uint32_t cost_best = 0xFFFFFFFFu;
   for (int stage = 0; stage < 2; stage++) {
     // stage 0: half-pel, candidates (2*hx, 2*hy); stage 1: quarter-pel around the half-pel winner
     const int step = stage == 0 ? 2 : 1;
-    const int fxc = stage == 0 ? 0 : 2 * half[0], fyc = stage == 0 ? 0 : 2 * half[1];
+    const int fxc = stage == 0 ? 0 : 2 * half0, fyc = stage == 0 ? 0 : 2 * half1;
     fr_sync<NW>();
     if (tid < 9) sh.cand[tid] = 0;
     // ---- three horizontal phase planes: fx = fxc + (p-1)*step ----
@@ -154,19 +156,18 @@ __global__ __launch_bounds__(NW * 64) void k_frac(const hop_pu_job* __restrict__
       const int8_t* rf = stage == 0 ? c_refine_h[ci] : c_refine_q[ci];
       uint32_t d = (uint32_t)sh.cand[ci] >> (bd - 8);
       if (stage == 0) d += hopd_mv_cost(jb.lambda_cost, rf[0] + (mvx << 1), rf[1] + (mvy << 1), 1, jb.pred_x, jb.pred_y);        // cost scale 1, :4615
-      else d += hopd_mv_cost(jb.lambda_cost, rf[0] + (((mvx << 1) + half[0]) << 1), rf[1] + (((mvy << 1) + half[1]) << 1), 0, jb.pred_x, jb.pred_y);   // :6599-6608
+      else d += hopd_mv_cost(jb.lambda_cost, rf[0] + (((mvx << 1) + half0) << 1), rf[1] + (((mvy << 1) + half1) << 1), 0, jb.pred_x, jb.pred_y);   // :6599-6608
       if (d < best) { best = d; bi = ci; }
     }
-    if (stage == 0) { half[0] = c_refine_h[bi][0]; half[1] = c_refine_h[bi][1]; }
-    else { qter[0] = c_refine_q[bi][0]; qter[1] = c_refine_q[bi][1]; }
+    if (stage == 0) { half0 = c_refine_h[bi][0]; half1 = c_refine_h[bi][1]; }
+    else { qter0 = c_refine_q[bi][0]; qter1 = c_refine_q[bi][1]; }
     cost_best = best;
   }
   if (tid == 0) {
-    rr.half[0] = half[0]; rr.half[1] = half[1]; rr.qter[0] = qter[0]; rr.qter[1] = qter[1];
-    rr.frac_cost = cost_best; rr.cost = cost_best;
-    rr.mv_final[0] = mvx; rr.mv_final[1] = mvy;
-    rr.half_final[0] = half[0]; rr.half_final[1] = half[1]; rr.qter_final[0] = qter[0]; rr.qter_final[1] = qter[1];
-    res[pu] = rr;
+    rp->half[0] = half0; rp->half[1] = half1; rp->qter[0] = qter0; rp->qter[1] = qter1;
+    rp->frac_cost = cost_best; rp->cost = cost_best;
+    rp->mv_final[0] = mvx; rp->mv_final[1] = mvy;
+    rp->half_final[0] = half0; rp->half_final[1] = half1; rp->qter_final[0] = qter0; rp->qter_final[1] = qter1;
   }
 }
 

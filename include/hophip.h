@@ -570,6 +570,11 @@ int hop_enumerate_ctu_jobs(int pic_w, int pic_h, int ctu_addr, int search_range,
                            int n_amvp, const int amvp_qpel[4], uint32_t lambda_cost, int flags, int with_amp,
                            hop_pu_job* out, int32_t* cu_index_out, int max_out);
 
+/* How many stream lanes hop_me_search_device cuts a large batch into (1..4; default 2 or HOP_LANES).  The results do not
+ * depend on it.  With 1 lane every kernel runs alone on the device: the setting bench.py uses for its profiling pass, so that
+ * HIP-event durations are exclusive. */
+int hop_set_lanes(hop_ctx* ctx, int lanes);
+
 /* ---- profiling (bench.py roofline): HIP events around every kernel launch on the context stream ---- */
 #define HOP_K_SS_SEARCH 0
 #define HOP_K_FRAC      1

@@ -6,9 +6,10 @@
  *
  * Reference: zinsayon/HEVC-HOP (HM-15.0 fork).  Every function cites the reference file:line
  * it restates (paths relative to /root/reference/source/Lib).  Parity is PINNED: each function is
- * checked against the reference's own code compiled into oracle/_ref/libref_harness.so
- * (tests/test_oracle_vs_ref.py, runs where /root/reference exists) and against the golden
- * vectors in tests/golden/ generated from that harness (oracle/make_golden.py).
+ * checked against golden vectors (tests/golden/*.npz, replayed by tests/test_oracle_golden*.py) that
+ * oracle/make_golden*.py generated from the reference's own code compiled into
+ * oracle/_ref/libref_harness.so, and it runs inside the reference encoder in place of the reference's
+ * members with an unchanged bitstream (tests/test_encoder_shim.py, where /root/reference exists).
  *
  * Plain C99, integer arithmetic except the GT warp which is IEEE double evaluated in the
  * reference's operation order; build with -ffp-contract=off (oracle/Makefile).

@@ -204,77 +204,7 @@ int hop_ssref_commit_cus_device(hop_ctx* c, int n, const int32_t* d_rect4, const
   return hop_launch_ssref_commit(c, n, d_rect4, d_rec_y, d_rec_cb, d_rec_cr, 0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// host logic
-// ---------------------------------------------------------------------------------------------
-static inline int imin(int a, int b) { return a < b ? a : b; }
-static inline int imax(int a, int b) { return a > b ? a : b; }
-// TComDataCU::clipMv, TLibCommon/TComDataCU.cpp:3492-3504 (g_uiMaxCUWidth/Height = 64)
-static void clip_mv(int pic_w, int pic_h, int cu_x, int cu_y, int& hor, int& ver) {
-  const int sh = 2, off = 8;
-  int hmax = (pic_w + off - cu_x - 1) * 4, hmin = (-64 - off - cu_x + 1) * 4;
-  int vmax = (pic_h + off - cu_y - 1) * 4, vmin = (-64 - off - cu_y + 1) * 4;
-  (void)sh;
-  hor = imin(hmax, imax(hmin, hor));
-  ver = imin(vmax, imax(vmin, ver));
-}
-
-void hop_set_search_range(int pic_w, int pic_h, int cu_x, int cu_y, int cu_size, int ctu_addr, int frame_width_in_ctu,
-                          int pred_x, int pred_y, int search_range, int off_x, int off_y, int first_row, int first_col, int out[6]) {
-  // TEncSearch::xSetSearchRange(pcCU, cMvPred, iSrchRng, LT, RB), TEncSearch.cpp:6204-6220; TComMv stores Short
-  int ph = pred_x, pv = pred_y;
-  clip_mv(pic_w, pic_h, cu_x, cu_y, ph, pv);
-  int lh = (int16_t)(ph - search_range * 4), lv = (int16_t)(pv - search_range * 4);
-  int rh = (int16_t)(ph + search_range * 4), rv = (int16_t)(pv + search_range * 4);
-  clip_mv(pic_w, pic_h, cu_x, cu_y, lh, lv);
-  clip_mv(pic_w, pic_h, cu_x, cu_y, rh, rv);
-  int left = lh >> 2, top = lv >> 2, right = rh >> 2, bottom = rv >> 2;
-  // SS overload, TEncSearch.cpp:6224-6259
-  if (first_col && first_row) {
-    right = left + 1;
-    top = bottom + 1;
-  } else {
-    bottom = (bottom > (-off_y - 4)) ? (-off_y - 4) : bottom;
-    off_x = -off_x - cu_size - 4;
-    off_y = -off_y - cu_size - 4;
-    bottom = (first_col && (bottom > off_y)) ? off_y : bottom;
-    right = (first_row && (right > off_x)) ? off_x : right;
-    right = (!first_row && (ctu_addr < frame_width_in_ctu) && (right > (off_x + (cu_size << 1)))) ? (off_x + (cu_size << 1)) : right;
-  }
-  lh = (int16_t)(left * 4); lv = (int16_t)(top * 4); rh = (int16_t)(right * 4); rv = (int16_t)(bottom * 4);
-  clip_mv(pic_w, pic_h, cu_x, cu_y, lh, lv);
-  clip_mv(pic_w, pic_h, cu_x, cu_y, rh, rv);
-  out[0] = lh >> 2; out[1] = rh >> 2; out[2] = lv >> 2; out[3] = rv >> 2; out[4] = off_x; out[5] = off_y;
-}
-
-uint32_t hop_component_bits(int v) { return hopd_component_bits(v); }
-uint32_t hop_bits_gt(const int v[8]) {   // IT_GT_AFFINE: corners 0..2 only, TComRdCost.h:205-215
-  uint32_t b = 0; for (int i = 0; i < 6; i++) b += hopd_component_bits(v[i]); return b;
-}
-
-void hop_me_finish(const hop_pu_job* job, const hop_pu_result* res, int stage, uint32_t bits_in,
-                   int mv_qpel[2], uint32_t* bits_out, uint32_t* cost_out) {
-  // TEncSearch.cpp:4654-4682 (fWeight = 1: uni-prediction; cost scale is 0 at this point)
-  int mvx, mvy;
-  if (stage >= HOP_STAGE_GT) { mvx = (res->mv_final[0] << 2) + (res->half_final[0] << 1) + res->qter_final[0]; mvy = (res->mv_final[1] << 2) + (res->half_final[1] << 1) + res->qter_final[1]; }
-  else if (stage == HOP_STAGE_FRAC) { mvx = (res->mv_int[0] << 2) + (res->half[0] << 1) + res->qter[0]; mvy = (res->mv_int[1] << 2) + (res->half[1] << 1) + res->qter[1]; }
-  else { mvx = res->mv_int[0] << 2; mvy = res->mv_int[1] << 2; }
-  mv_qpel[0] = mvx; mv_qpel[1] = mvy;
-  uint32_t mv_bits = hopd_component_bits(mvx - job->pred_x) + hopd_component_bits(mvy - job->pred_y);
-  uint32_t bits = bits_in + mv_bits + 1;                       // + GT flag (:4669)
-  if (stage >= HOP_STAGE_GT) {
-    // :4673-4678 -- the chained '==' evaluates left to right on ints/bools; restated literally
-    const int32_t* g = res->gt;
-    int chain = (g[0] == g[1]);
-    chain = (chain == g[2]); chain = (chain == g[3]); chain = (chain == g[4]);
-    chain = (chain == g[5]); chain = (chain == g[6]); chain = (chain == g[7]);
-    if (!chain) { int v[8]; for (int i = 0; i < 8; i++) v[i] = g[i]; bits += hop_bits_gt(v); }
-  }
-  uint32_t cost_mv = (job->lambda_cost * mv_bits) >> 16, cost_bits = (job->lambda_cost * bits) >> 16;
-  uint32_t cost = (stage == HOP_STAGE_INT) ? res->sad + ((job->lambda_cost * mv_bits) >> 16) : res->cost;
-  *bits_out = bits;
-  *cost_out = (uint32_t)((double)cost - (double)cost_mv) + cost_bits;   // floor(fWeight*(cost - mvcost)) + cost(bits)
-}
+// host logic (hop_set_search_range, hop_component_bits, hop_bits_gt, hop_me_finish, the CABAC bin helpers): host/hop_hostlogic.cpp
 
 // ---------------------------------------------------------------------------------------------
 // hot path entry points

@@ -50,105 +50,7 @@ __constant__ uint8_t c_cb_ctx_ind_map[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8
 #define CX_TS 148
 #define CX_COUNT 150
 
-// ---- host: initialisation values, rows = slice types B, P, I, ISS, PSS (TypeDef.h:418-427) ----
-#define CNU 154
-static const uint8_t h_init[5][CX_COUNT] = {
-  /* B   */ { 153, 111, CNU, CNU, 149, 92, 167, 154,   224, 167, 122,   79,   121, 140, 61, 154,
-              170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140,
-              125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
-              107, 167, 91, 107, 107, 167,   139, 139 },
-  /* P   */ { 153, 111, CNU, CNU, 149, 107, 167, 154,   124, 138, 94,   79,   121, 140, 61, 154,
-              155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
-              125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-              107, 167, 91, 122, 107, 167,   139, 139 },
-  /* I   */ { 111, 141, CNU, CNU, 94, 138, 182, 154,   153, 138, 138,   CNU,   91, 171, 134, 141,
-              111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111,
-              110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-              138, 153, 136, 167, 152, 152,   139, 139 },
-  /* ISS */ { 153, 111, CNU, CNU, 149, 107, 167, 154,   124, 138, 94,   79,   121, 140, 61, 154,
-              155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
-              125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-              107, 167, 91, 122, 107, 167,   139, 139 },
-  /* PSS */ { 153, 111, CNU, CNU, 149, 107, 167, 154,   124, 138, 94,   79,   121, 140, 61, 154,
-              155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
-              125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU,
-              154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-              107, 167, 91, 122, 107, 167,   139, 139 },
-};
-
-static uint8_t h_ctx_init(int qp, int initValue) {          // ContextModel::init, ContextModel.cpp:56-65
-  qp = qp < 0 ? 0 : qp > 51 ? 51 : qp;
-  const int slope = (initValue >> 4) * 5 - 45, offset = ((initValue & 15) << 3) - 16;
-  int initState = ((slope * qp) >> 4) + offset;
-  initState = initState < 1 ? 1 : initState > 126 ? 126 : initState;
-  const unsigned mp = (initState >= 64);
-  return (uint8_t)(((mp ? (initState - 64) : (63 - initState)) << 1) + mp);
-}
-static int h_conv_to_bit(int w) { return w == 4 ? 0 : w == 8 ? 1 : w == 16 ? 2 : 3; }
-
-extern "C" {
-
-int hop_cabac_init(hop_cabac_ctx* ctx, int slice_type, int qp) {
-  if (!ctx || slice_type < 0 || slice_type > 4) return HOP_ERR_ARG;
-  for (int i = 0; i < CX_COUNT; i++) ctx->state[i] = h_ctx_init(qp, h_init[slice_type][i]);
-  ctx->state[150] = ctx->state[151] = 0;
-  return HOP_OK;
-}
-
-// CU-level sets of hop_cabac_cu_ctx: skip[3], merge_flag, merge_idx, part_size[4], pred_mode, mvd[2], mvp_idx, gt_flag, gt[2], intra_pred, chroma_pred[2];
-// rows B, P, I, ISS, PSS (TLibCommon/ContextTables.h:140-310, 472-482)
-static const uint8_t h_cu_init[5][20] = {
-  { 197, 185, 201, 154, 137, 154, 139, 154, 154, 134, 169, 198, 168, 154, 169, 198, 183, 152, 139, CNU },
-  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198, 154, 152, 139, CNU },
-  { CNU, CNU, CNU, CNU, CNU, 184, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, CNU, 184,  63, 139, CNU },
-  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198, 154, 152, 139, CNU },
-  { 197, 185, 201, 110, 122, 154, 139, 154, 154, 149, 140, 198, 168, 110, 140, 198, 154, 152, 139, CNU } };
-int hop_cabac_cu_init(hop_cabac_cu_ctx* ctx, int slice_type, int qp) {
-  if (!ctx || slice_type < 0 || slice_type > 4) return HOP_ERR_ARG;
-  for (int i = 0; i < 19; i++) ctx->state[i] = h_ctx_init(qp, h_cu_init[slice_type][i]);
-  ctx->state[19] = 0;
-  return HOP_OK;
-}
-
-int hop_cabac_est_bits(const hop_cabac_ctx* ctx, int width, int comp, hop_estbits* eb) {
-  if (!ctx || !eb || (width != 4 && width != 8 && width != 16 && width != 32) || comp < 0 || comp > 2 || (comp && width == 32)) return HOP_ERR_ARG;
-  static const uint8_t grp[32] = { 0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8,8,8,8,8,8,8,8,9,9,9,9,9,9,9,9 };
-  const uint8_t* s = ctx->state;
-  const int chroma = comp != 0;
-  // estCBFBit reads 12 models from a set of 8 and 4 from the root set of 1: the sets behind them are read too (reproduced)
-  for (int i = 0; i < 12; i++) { eb->blockCbpBits[i][0] = h_entropy_bits[s[CX_QT_CBF + i] ^ 0]; eb->blockCbpBits[i][1] = h_entropy_bits[s[CX_QT_CBF + i] ^ 1]; }
-  for (int i = 0; i < 4; i++) { eb->blockRootCbpBits[i][0] = h_entropy_bits[s[CX_ROOT_CBF + i] ^ 0]; eb->blockRootCbpBits[i][1] = h_entropy_bits[s[CX_ROOT_CBF + i] ^ 1]; }
-  for (int i = 0; i < 2; i++) for (int b = 0; b < 2; b++) eb->significantCoeffGroupBits[i][b] = h_entropy_bits[s[CX_SIG_CG + 2 * chroma + i] ^ b];
-  int firstCtx = 1, numCtx = 8;
-  if (width >= 16) { firstCtx = chroma ? 12 : 21; numCtx = chroma ? 3 : 6; }
-  else if (width == 8) { firstCtx = 9; numCtx = chroma ? 3 : 12; }
-  const int base = CX_SIG + (chroma ? 27 : 0);
-  for (int b = 0; b < 2; b++) eb->significantBits[0][b] = h_entropy_bits[s[base] ^ b];
-  for (int i = firstCtx; i < firstCtx + numCtx; i++) for (int b = 0; b < 2; b++) eb->significantBits[i][b] = h_entropy_bits[s[base + i] ^ b];
-  const int cb = h_conv_to_bit(width);
-  const int off = chroma ? 0 : (cb * 3 + ((cb + 1) >> 2)), sh = chroma ? cb : ((cb + 3) >> 2);
-  const uint8_t* px = s + CX_LAST_X + 15 * chroma; const uint8_t* py = s + CX_LAST_Y + 15 * chroma;
-  int bitsX = 0, bitsY = 0, c;
-  for (c = 0; c < grp[width - 1]; c++) { const int o = off + (c >> sh); eb->lastXBits[c] = bitsX + h_entropy_bits[px[o] ^ 0]; bitsX += h_entropy_bits[px[o] ^ 1]; }
-  eb->lastXBits[c] = bitsX;
-  for (c = 0; c < grp[width - 1]; c++) { const int o = off + (c >> sh); eb->lastYBits[c] = bitsY + h_entropy_bits[py[o] ^ 0]; bitsY += h_entropy_bits[py[o] ^ 1]; }
-  eb->lastYBits[c] = bitsY;
-  const int no = chroma ? 8 : 16, na = chroma ? 2 : 4, oo = CX_ONE + (chroma ? 16 : 0), oa = CX_ABS + (chroma ? 4 : 0);
-  for (int i = 0; i < no; i++) { eb->greaterOneBits[i][0] = h_entropy_bits[s[oo + i] ^ 0]; eb->greaterOneBits[i][1] = h_entropy_bits[s[oo + i] ^ 1]; }
-  for (int i = 0; i < na; i++) { eb->levelAbsBits[i][0] = h_entropy_bits[s[oa + i] ^ 0]; eb->levelAbsBits[i][1] = h_entropy_bits[s[oa + i] ^ 1]; }
-  return HOP_OK;
-}
-
-} // extern "C"
+// (context initialisation and TEncSbac::estBit are host logic: host/hop_hostlogic.cpp)
 
 // ---- device: counted bits of codeCoeffNxN, one lane per TU ----
 struct CabacLds { uint8_t st[172][64]; uint16_t absCoeff[16][64]; };      // rows 0..151: hop_cabac_ctx; 152..171: the CU-level sets of hop_cabac_cu_ctx (k_rqt.inl)

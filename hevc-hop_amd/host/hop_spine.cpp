@@ -1,0 +1,837 @@
+// hop_spine.cpp -- the host RD spine.  Citations: paths under /root/reference/source/Lib.
+//   TEncCu::xCompressCU TLibEncoder/TEncCu.cpp:371-892, deriveTestModeAMP :292-356, xCheckRDCostMerge2Nx2N :1243-1395, xCheckRDCostInter :1399-1453,
+//   xCheckRDCostIntra :1455-1507, xCheckBestMode :1557-1590; TEncSearch::predInterSearch TLibEncoder/TEncSearch.cpp:3141-4169 (one reference list with
+//   the SS picture: the bi-predictive half is unreachable), xEstimateMvPredAMVP :4173-4262, xGetTemplateCost :4411-4477, xCheckBestMVP :4364-4409,
+//   xMergeEstimation :2992-3106, xGetInterPredictionError :2951-2977, xGetBlkBits :4294-4353; TComDataCU::fillMvpCand TLibCommon/TComDataCU.cpp:3297-3478,
+//   getInterMergeCandidates :2761-3204 with the micro-image candidates :2620-2748, the neighbour access :1270-1635, getPartOffset :2251-2296,
+//   getIntraDirLumaPredictor :1772-1830, getCtxSplitFlag :1832, getCtxSkipFlag :1888; TEncSlice::compressSlice TLibEncoder/TEncSlice.cpp:1000-1196
+//   (compressCU, then encodeCU on the CTU's entry coder: that pass is what the next CTU starts from).
+// The spine keeps the reference's bookkeeping literally where results depend on it: which coder the split flag is counted on (the go-on coder as
+// the last candidate left it), the fields a PU carries while its merge candidates are rated (the GT vectors of its motion search), the partition
+// index handed to the micro-image candidates.
+#include "hop_spine.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+
+namespace hopspine {
+
+static const double MAX_DOUBLE = 1.7e+308;           // TLibCommon/CommonDef.h
+static const uint32_t MAX_UINT = 0xFFFFFFFFu;
+static const int CTU = 64;
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// configuration
+// ---------------------------------------------------------------------------------------------------------------------------------
+void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size) {
+  memset(&c, 0, sizeof(c));
+  c.pic_w = pic_w; c.pic_h = pic_h; c.bit_depth = 8; c.qp = qp; c.slice_type = 3;
+  c.search_range = 128; c.mi_size = mi_size; c.mi_merge = 1; c.max_merge_cand = 5;
+  c.amp = 1; c.fen = 1; c.hadme = 1; c.fdm = 1; c.esd = 0; c.cfm = 0; c.ecu = 0;
+  c.log2_max_tu = 5; c.log2_min_tu = 2; c.tu_max_depth_inter = 3; c.tu_max_depth_intra = 3;
+  c.sign_hide = 1; c.use_ts = 1; c.ts_fast = 1; c.strong_intra = 1; c.wpp = 0;
+  finish_config(c);
+}
+
+void finish_config(EncConfig& c) {
+  // TEncSlice::initEncSlice, TLibEncoder/TEncSlice.cpp:358-462: I / ISS slice at depth 0, GOP size 1, no QP offsets
+  static const uint8_t chroma_scale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+                                            29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };   // g_aucChromaScale, TComRom.cpp
+  double lambda = 0.57 * pow(2.0, (c.qp - 12) / 3.0);
+  if (!c.hadme && c.slice_type != 2) lambda *= 0.95;
+  c.lambda = lambda; c.sqrt_lambda = sqrt(lambda); c.lambda_sad = (uint32_t)floor(65536.0 * c.sqrt_lambda);
+  const int qpc = c.qp < 0 ? 0 : c.qp > 57 ? 57 : c.qp;
+  const double w = pow(2.0, (c.qp - chroma_scale[qpc]) / 3.0);
+  c.dist_weight[0] = c.dist_weight[1] = w;
+  c.lambda_rdoq[0] = lambda; c.lambda_rdoq[1] = c.lambda_rdoq[2] = lambda / w;
+  // TComTrQuant::setQPforQuant, TLibCommon/TComTrQuant.cpp:192-214 (qpBdOffset = 6 * (bit depth - 8))
+  const int off = 6 * (c.bit_depth - 8);
+  c.qp_scaled[0] = c.qp + off;
+  int q = c.qp < -off ? -off : c.qp > 57 ? 57 : c.qp;
+  c.qp_scaled[1] = c.qp_scaled[2] = q < 0 ? q + off : chroma_scale[q] + off;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// z-order
+// ---------------------------------------------------------------------------------------------------------------------------------
+static inline int zidx(int x4, int y4) {            // g_auiRasterToZscan for a 16x16 grid of 4x4 units: x in the even bits
+  int z = 0;
+  for (int b = 0; b < 4; b++) z |= (((x4 >> b) & 1) << (2 * b)) | (((y4 >> b) & 1) << (2 * b + 1));
+  return z;
+}
+static inline void zpos(int z, int& x4, int& y4) {
+  x4 = y4 = 0;
+  for (int b = 0; b < 4; b++) { x4 |= ((z >> (2 * b)) & 1) << b; y4 |= ((z >> (2 * b + 1)) & 1) << b; }
+}
+static inline int zpix(int px, int py) { return zidx((px & 63) >> 2, (py & 63) >> 2); }
+
+static double calc_rd_cost(uint32_t bits, uint32_t dist, double lambda) {     // TComRdCost::calcRdCost, DF_DEFAULT (TComRdCost.cpp:59-111)
+  double d = (double)dist + (double)((int)(bits * lambda + .5));
+  return (double)(uint32_t)floor(d);
+}
+static inline uint32_t component_bits(int v) { return hop_component_bits(v); }
+
+static void part_init(Part& p, int depth) {          // TComDataCU::initEstData, TComDataCU.cpp:586-665
+  memset(&p, 0, sizeof(p));
+  p.depth = (uint8_t)depth; p.pred_mode = MODE_NONE; p.part_size = SIZE_NONE; p.luma_dir = DC_IDX;
+  p.ref_idx = -1; p.mvp_idx = -1; p.mvp_num = -1;
+}
+
+// PU geometry ------------------------------------------------------------------------------------------------------------------------
+static int num_pus(int ps) { return ps == SIZE_2Nx2N ? 1 : ps == SIZE_NxN ? 4 : 2; }
+// TComDataCU::getPartIndexAndSize (TComDataCU.cpp:2210-2249) in samples: offset of the PU inside the CU and its size
+static void pu_rect(int ps, int S, int pu, int& ox, int& oy, int& w, int& h) {
+  ox = oy = 0; w = h = S;
+  switch (ps) {
+    case SIZE_2NxN:  h = S >> 1; oy = pu ? S >> 1 : 0; break;
+    case SIZE_Nx2N:  w = S >> 1; ox = pu ? S >> 1 : 0; break;
+    case SIZE_NxN:   w = h = S >> 1; ox = (pu & 1) ? S >> 1 : 0; oy = (pu >> 1) ? S >> 1 : 0; break;
+    case SIZE_2NxnU: h = pu ? (S >> 2) + (S >> 1) : S >> 2; oy = pu ? S >> 2 : 0; break;
+    case SIZE_2NxnD: h = pu ? S >> 2 : (S >> 2) + (S >> 1); oy = pu ? (S >> 2) + (S >> 1) : 0; break;
+    case SIZE_nLx2N: w = pu ? (S >> 2) + (S >> 1) : S >> 2; ox = pu ? S >> 2 : 0; break;
+    case SIZE_nRx2N: w = pu ? S >> 2 : (S >> 2) + (S >> 1); ox = pu ? (S >> 2) + (S >> 1) : 0; break;
+    default: break;
+  }
+}
+// TComDataCU::getPartPosition (TComDataCU.cpp:3229-3288): only the size is used by its callers here; partIdx is whatever the caller hands over
+static void part_position_size(int ps, int S, unsigned partIdx, int& w, int& h) {
+  w = h = S;
+  switch (ps) {
+    case SIZE_2NxN:  h = S >> 1; break;
+    case SIZE_Nx2N:  w = S >> 1; break;
+    case SIZE_NxN:   w = h = S >> 1; break;
+    case SIZE_2NxnU: h = partIdx == 0 ? S >> 2 : (S >> 2) + (S >> 1); break;
+    case SIZE_2NxnD: h = partIdx == 0 ? (S >> 2) + (S >> 1) : S >> 2; break;
+    case SIZE_nLx2N: w = partIdx == 0 ? S >> 2 : (S >> 2) + (S >> 1); break;
+    case SIZE_nRx2N: w = partIdx == 0 ? (S >> 2) + (S >> 1) : S >> 2; break;
+    default: break;
+  }
+}
+// TComDataCU::getPartOffset (TComDataCU.cpp:2251-2296), incl. SIZE_nLx2N's offY = height
+static void part_offset(int ps, int S, int pu, int& offx, int& offy) {
+  offx = offy = 0;
+  switch (ps) {
+    case SIZE_2NxN:  offy = pu ? S >> 1 : 0; break;
+    case SIZE_Nx2N:  offx = pu ? S >> 1 : 0; break;
+    case SIZE_NxN:   offx = (pu & 1) ? S >> 1 : 0; offy = (pu & 2) ? S >> 1 : 0; break;
+    case SIZE_2NxnU: offy = pu ? S >> 2 : 0; break;
+    case SIZE_2NxnD: offy = pu ? (S >> 2) + (S >> 1) : 0; break;
+    case SIZE_nLx2N: offx = pu ? S >> 2 : 0; offy = S; break;
+    case SIZE_nRx2N: offx = pu ? (S >> 2) + (S >> 1) : 0; break;
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// one CTU
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct MvField { int16_t mv[2]; int8_t ref; };
+struct MergeCands { MvField f[5]; uint8_t dir[5]; int n; };
+struct AmvpInfo { int n; int16_t cand[3][2]; };
+
+class CtuWorker {
+ public:
+  CtuWorker(Encoder& e, int lane) : E(e), cfg(e.cfg_), be(e.be_), lane_(lane) { for (int d = 0; d < 4; d++) { best_[d] = &store_[d][0]; temp_[d] = &store_[d][1]; } }
+  void compress_ctu(int addr, const Coder& entry, Coder& exit);
+ private:
+  Encoder& E; const EncConfig& cfg; Backend* be; int lane_;
+  CuData store_[4][2]; CuData* best_[4]; CuData* temp_[4];
+  enum { CI_CURR = 0, CI_NEXT = 1, CI_TEMP = 2 };
+  Coder sb_[4][3]; Coder goon_;
+  int ctu_addr_, ctu_x_, ctu_y_;
+
+  // data model
+  void init_cu(CuData& c, int abs_idx, int depth, int x, int y);
+  void init_est(CuData& c) { for (int i = 0; i < c.num_part; i++) part_init(c.p[i], c.depth); c.cost = MAX_DOUBLE; c.bits = 0; c.dist = 0; }
+  Part& pic_part(int px, int py) { return E.pic[(size_t)((py >> 6) * E.wctu_ + (px >> 6)) * 256 + zpix(px, py)]; }
+  const Part* part_at(const CuData& c, int px, int py) {
+    if (px >= c.x && px < c.x + c.size && py >= c.y && py < c.y + c.size) return &c.p[zpix(px, py) - c.abs_idx];
+    return &pic_part(px, py);
+  }
+  void copy_to_pic(const CuData& c) { memcpy(&E.pic[(size_t)c.ctu_addr * 256 + c.abs_idx], c.p, sizeof(Part) * c.num_part); }
+  void set_parts(CuData& c, int ox, int oy, int w, int h, void (*fn)(Part&, const void*), const void* arg) {
+    for (int yy = oy; yy < oy + h; yy += 4) for (int xx = ox; xx < ox + w; xx += 4) fn(c.p[zpix(c.x + xx, c.y + yy) - c.abs_idx], arg);
+  }
+  // neighbours (TComDataCU::getPULeft ... getPUBelowLeftAdi): the unit the reference would return, or NULL
+  const Part* nb_left(const CuData& c, int x, int y) { return ((x & 63) || x > 0) ? part_at(c, x - 4, y) : NULL; }
+  const Part* nb_above(const CuData& c, int x, int y, bool planar_at_ctu_boundary = false) {
+    if (y & 63) return part_at(c, x, y - 4);
+    if (planar_at_ctu_boundary || y == 0) return NULL;
+    return part_at(c, x, y - 4);
+  }
+  const Part* nb_above_left(const CuData& c, int x, int y) {
+    const bool ok = (x & 63) ? ((y & 63) ? true : y > 0) : ((y & 63) ? x > 0 : (x > 0 && y > 0));
+    return ok ? part_at(c, x - 4, y - 4) : NULL;
+  }
+  bool ar_avail(int x, int y, int k) {              // unit k to the right of (x, y), one row up (k = 1: getPUAboveRight)
+    if (x + 4 * k >= cfg.pic_w) return false;
+    if (((x & 63) >> 2) + k < 16) return (y & 63) ? zpix(x, y) > zpix(x + 4 * k, y - 4) : y > 0;
+    return (y & 63) ? false : y > 0;
+  }
+  bool bl_avail(int x, int y, int k) {              // unit k below (x, y), one column to the left
+    if (y + 4 * k >= cfg.pic_h) return false;
+    if (((y & 63) >> 2) + k < 16) return (x & 63) ? zpix(x, y) > zpix(x - 4, y + 4 * k) : x > 0;
+    return false;
+  }
+  const Part* nb_above_right(const CuData& c, int x, int y) { return ar_avail(x, y, 1) ? part_at(c, x + 4, y - 4) : NULL; }
+  const Part* nb_below_left(const CuData& c, int x, int y) { return bl_avail(x, y, 1) ? part_at(c, x - 4, y + 4) : NULL; }
+
+  // the spine
+  void compress_cu(int d, int parent_part_size);
+  void check_best_mode(int d, bool save_recon);
+  void check_merge_2Nx2N(int d, bool* early_skip);
+  void check_inter(int d, int part_size, bool use_mrg);
+  void check_intra(int d, int part_size);
+  bool pred_inter_search(CuData& c, int part_size, bool use_mrg);
+  void fill_mvp_cand(const CuData& c, int pu, AmvpInfo& info);
+  void merge_candidates(const CuData& c, int pu, MergeCands& mc);
+  bool mi_cand(const CuData& c, int which, int ux, int uy, int16_t mv[2]);
+  uint32_t inter_pred_error(CuData& c, int pu);
+  void motion_comp_pu(CuData& c, int pu);
+  void clip_mv(const CuData& c, int& h, int& v) const;
+  bool valid_pattern(int px, int py, int w, int h, int mvx, int mvy);
+  uint32_t split_flag_bits(const CuData& c, int d, Coder& k);
+  void eval_inter(int d, bool skip_res);
+  void fill_intra_eval(const CuData& c, int part_size, IntraEval& e);
+  void set_cu_field_u8(CuData& c, size_t off, uint8_t v) { for (int i = 0; i < c.num_part; i++) ((uint8_t*)&c.p[i])[off] = v; }
+  void trace_candidate(const CuData& c);
+  uint64_t final_walk(int x, int y, int size, int d, Coder& k);
+};
+
+void CtuWorker::init_cu(CuData& c, int abs_idx, int depth, int x, int y) {
+  c.ctu_addr = ctu_addr_; c.ctu_x = ctu_x_; c.ctu_y = ctu_y_; c.abs_idx = abs_idx; c.depth = depth; c.x = x; c.y = y; c.size = CTU >> depth; c.num_part = 256 >> (2 * depth);
+  for (int i = 0; i < c.num_part; i++) { part_init(c.p[i], depth); c.fbits[i] = 0; }
+  c.cost = MAX_DOUBLE; c.bits = 0; c.dist = 0;
+}
+
+void CtuWorker::clip_mv(const CuData& c, int& h, int& v) const {          // TComDataCU::clipMv, TComDataCU.cpp:3492-3504 (the CU's position)
+  const int hmax = (cfg.pic_w + 8 - c.x - 1) * 4, hmin = (-CTU - 8 - c.x + 1) * 4;
+  const int vmax = (cfg.pic_h + 8 - c.y - 1) * 4, vmin = (-CTU - 8 - c.y + 1) * 4;
+  h = std::min(hmax, std::max(hmin, h)); v = std::min(vmax, std::max(vmin, v));
+}
+
+bool CtuWorker::valid_pattern(int px, int py, int w, int h, int mvx, int mvy) {
+  int32_t q[6] = { px, py, w, h, mvx, mvy }; uint8_t ok = 0;
+  be->valid_pattern(lane_, 1, q, &ok);
+  return ok != 0;
+}
+
+void CtuWorker::trace_candidate(const CuData& c) {
+  E.n_candidates++;
+  if (!E.trace) return;
+  fprintf(E.trace, "%d %d %d %d %d %d %d %d %u %u %.17g\n", c.depth, c.x, c.y, CTU >> c.p[0].depth, c.p[0].pred_mode, c.p[0].part_size, c.p[0].skip, c.p[0].merge_flag, c.bits, c.dist, c.cost);
+}
+
+// TEncCu::xCheckBestMode (:1557-1590): strict '<'; the winner's reconstruction is put aside, its coder becomes CI_NEXT_BEST
+void CtuWorker::check_best_mode(int d, bool save_recon) {
+  trace_candidate(*temp_[d]);
+  if (temp_[d]->cost < best_[d]->cost) {
+    std::swap(best_[d], temp_[d]);
+    if (save_recon) be->recon_save(lane_, d, best_[d]->x, best_[d]->y, best_[d]->size);
+    sb_[d][CI_NEXT] = sb_[d][CI_TEMP];
+  }
+}
+
+// split_cu_flag counted on coder k as the reference's resetBits / encodeSplitFlag / getNumberOfWrittenBits does (TEncCu.cpp:686-688, :803-806; TEncSbac.cpp:731-754)
+uint32_t CtuWorker::split_flag_bits(const CuData& c, int d, Coder& k) {
+  uint32_t frac = coder_frac(k);
+  if (d < 3) {
+    const Part* l = nb_left(c, c.x, c.y); const Part* a = nb_above(c, c.x, c.y);
+    const int ctx = (l ? (l->depth > d) : 0) + (a ? (a->depth > d) : 0);
+    frac += hop_cabac_bin_bits(&k.split[ctx], c.p[0].depth > d ? 1 : 0);
+  }
+  coder_set_frac(k, frac & 32767);
+  return frac >> 15;
+}
+
+// ---- AMVP: TComDataCU::fillMvpCand (TComDataCU.cpp:3297-3478), one list with the SS picture ----
+bool CtuWorker::mi_cand(const CuData& c, int which, int ux, int uy, int16_t mv[2]) {
+  // getMILeftCand / getMIAboveCand / getMIAboveLeftCand (:2620-2748): which = 0 left, 1 above, 2 above-left; (ux, uy) = the unit whose z-index the
+  // reference hands over -- also as the "partition index" of getPartPosition, so every PU but one at the CTU's origin reads the second PU's size
+  if (which != 1 && (ux & 63) == 0) return false;
+  if (which == 1 && (uy & 63) == 0) return false;
+  int w, h; part_position_size(c.p[0].part_size, c.size, (unsigned)zpix(ux, uy), w, h);
+  const int mi = cfg.mi_size;
+  const double xs = which == 1 ? 0.0 : -ceil((double)w / (double)mi), ys = which == 0 ? 0.0 : -ceil((double)h / (double)mi);
+  const int16_t mh = (int16_t)((int16_t)(xs * mi) << 2), mvv = (int16_t)((int16_t)(ys * mi) << 2);
+  // isMvInsidePic (:2598-2610)
+  const int hmax = (cfg.pic_w + 8 - c.x - 1) << 2, hmin = (-CTU - 8 - c.x + 1) * 4, vmax = (cfg.pic_h + 8 - c.y - 1) << 2, vmin = (-CTU - 8 - c.y + 1) * 4;
+  if (!(mh >= hmin && mh <= hmax && mvv >= vmin && mvv <= vmax)) return false;
+  mv[0] = mh; mv[1] = mvv;
+  return true;
+}
+
+void CtuWorker::fill_mvp_cand(const CuData& c, int pu, AmvpInfo& info) {
+  int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
+  const int ltx = c.x + ox, lty = c.y + oy, rtx = ltx + w - 4, rty = lty, lbx = ltx, lby = lty + h - 4;
+  info.n = 0;
+  auto add = [&](const Part* nb) -> bool {           // xAddMVPCand / xAddMVPCandOrder (:3552-3782) with one SS reference: an inter neighbour's vector as it is
+    if (!nb || nb->ref_idx < 0) return false;
+    if (info.n < 3) { info.cand[info.n][0] = nb->mv[0]; info.cand[info.n][1] = nb->mv[1]; }
+    info.n++;
+    return true;
+  };
+  const Part* bl = nb_below_left(c, lbx, lby); const Part* l = nb_left(c, lbx, lby);
+  bool added_smvp = bl && bl->pred_mode != MODE_INTRA;
+  if (!added_smvp) added_smvp = l && l->pred_mode != MODE_INTRA;
+  bool added = add(bl);
+  if (!added) added = add(l);
+  if (!added) { added = add(bl); if (!added) add(l); }
+  const Part* ar = nb_above_right(c, rtx, rty); const Part* a = nb_above(c, rtx, rty); const Part* al = nb_above_left(c, ltx, lty);
+  added = add(ar);
+  if (!added) added = add(a);
+  if (!added) add(al);
+  if (!added_smvp) {
+    added = add(ar);
+    if (!added) added = add(a);
+    if (!added) add(al);
+  }
+  if (info.n == 2 && info.cand[0][0] == info.cand[1][0] && info.cand[0][1] == info.cand[1][1]) info.n = 1;
+  if (info.n > 2) info.n = 2;                        // AMVP_MAX_NUM_CANDS
+  if (cfg.mi_merge) {
+    if (info.n < 2) {
+      int16_t mv[2];
+      bool ok = mi_cand(c, 0, lbx, lby, mv);
+      if (!ok) ok = mi_cand(c, 1, rtx, rty, mv);
+      if (!ok) ok = mi_cand(c, 2, ltx, lty, mv);
+      if (ok) { info.cand[info.n][0] = mv[0]; info.cand[info.n][1] = mv[1]; info.n++; }
+    }
+    if (info.n == 2 && info.cand[0][0] == info.cand[1][0] && info.cand[0][1] == info.cand[1][1]) info.n = 1;
+  }
+  while (info.n < 2) { info.cand[info.n][0] = 0; info.cand[info.n][1] = 0; info.n++; }
+}
+
+// ---- merge candidates: TComDataCU::getInterMergeCandidates (TComDataCU.cpp:2761-3204), P-like slice, no temporal candidate ----
+void CtuWorker::merge_candidates(const CuData& c, int pu, MergeCands& mc) {
+  const int ps = c.p[0].part_size, maxc = cfg.max_merge_cand;
+  int ox, oy, w, h; pu_rect(ps, c.size, pu, ox, oy, w, h);
+  const int ltx = c.x + ox, lty = c.y + oy, rtx = ltx + w - 4, rty = lty, lbx = ltx, lby = lty + h - 4;
+  for (int i = 0; i < 5; i++) { mc.f[i].mv[0] = mc.f[i].mv[1] = 0; mc.f[i].ref = -1; mc.dir[i] = 0; }
+  mc.n = maxc;
+  int cnt = 0;
+  auto same = [](const Part* a, const Part* b) { return a->inter_dir == b->inter_dir && (!(a->inter_dir & 1) || (a->mv[0] == b->mv[0] && a->mv[1] == b->mv[1] && a->ref_idx == b->ref_idx)); };
+  auto take = [&](const Part* nb) { mc.dir[cnt] = nb->inter_dir; mc.f[cnt].mv[0] = nb->mv[0]; mc.f[cnt].mv[1] = nb->mv[1]; mc.f[cnt].ref = nb->ref_idx; cnt++; };
+  // (isDiffMER is always true at parallel merge level 2: a neighbouring unit is another 4x4 block)
+  const Part* A1 = nb_left(c, lbx, lby);
+  const bool okA1 = A1 && !(pu == 1 && (ps == SIZE_Nx2N || ps == SIZE_nLx2N || ps == SIZE_nRx2N)) && A1->pred_mode != MODE_INTRA;
+  if (okA1) take(A1);
+  if (cnt == maxc) return;
+  const Part* B1 = nb_above(c, rtx, rty);
+  const bool okB1 = B1 && !(pu == 1 && (ps == SIZE_2NxN || ps == SIZE_2NxnU || ps == SIZE_2NxnD)) && B1->pred_mode != MODE_INTRA;
+  if (okB1 && (!okA1 || !same(A1, B1))) take(B1);
+  if (cnt == maxc) return;
+  const Part* B0 = nb_above_right(c, rtx, rty);
+  const bool okB0 = B0 && B0->pred_mode != MODE_INTRA;
+  if (okB0 && (!okB1 || !same(B1, B0))) take(B0);
+  if (cnt == maxc) return;
+  const Part* A0 = nb_below_left(c, lbx, lby);
+  const bool okA0 = A0 && A0->pred_mode != MODE_INTRA;
+  if (okA0 && (!okA1 || !same(A1, A0))) take(A0);
+  if (cnt == maxc) return;
+  if (cnt < 4) {
+    const Part* B2 = nb_above_left(c, ltx, lty);
+    const bool okB2 = B2 && B2->pred_mode != MODE_INTRA;
+    if (okB2 && (!okA1 || !same(A1, B2)) && (!okB1 || !same(B1, B2))) take(B2);
+  }
+  if (cnt == maxc) return;
+  if (cfg.mi_merge) {                                // :2942-3035, all three from the PU's first unit
+    int16_t mv[2];
+    if (cnt < 4 && mi_cand(c, 0, ltx, lty, mv)) { mc.dir[cnt] = 1; mc.f[cnt].mv[0] = mv[0]; mc.f[cnt].mv[1] = mv[1]; mc.f[cnt].ref = 0; cnt++; }
+    if (cnt == maxc) return;
+    if (mi_cand(c, 1, ltx, lty, mv) && cnt < 4) { mc.dir[cnt] = 1; mc.f[cnt].mv[0] = mv[0]; mc.f[cnt].mv[1] = mv[1]; mc.f[cnt].ref = 0; cnt++; }
+    if (cnt == maxc) return;
+    if (mi_cand(c, 2, ltx, lty, mv) && cnt < 4) { mc.dir[cnt] = 1; mc.f[cnt].mv[0] = mv[0]; mc.f[cnt].mv[1] = mv[1]; mc.f[cnt].ref = 0; cnt++; }
+    if (cnt == maxc) return;
+  }
+  while (cnt < maxc) { mc.dir[cnt] = 1; mc.f[cnt].mv[0] = mc.f[cnt].mv[1] = 0; mc.f[cnt].ref = 0; cnt++; }   // zero candidates (:3177-3201)
+  mc.n = cnt;
+}
+
+// TComPrediction::motionCompensation for one PU (TComPrediction.cpp:419-470 -> xPredInterUni :528-552): the vector clipped, GT iff the PU is not merged and has its flag
+void CtuWorker::motion_comp_pu(CuData& c, int pu) {
+  int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
+  const Part& p = *part_at(c, c.x + ox, c.y + oy);
+  hop_pred_job j; memset(&j, 0, sizeof(j));
+  j.pu_x = c.x + ox; j.pu_y = c.y + oy; j.w = w; j.h = h;
+  int mh = p.mv[0], mvv = p.mv[1]; clip_mv(c, mh, mvv);
+  j.mv_x = mh; j.mv_y = mvv; j.use_gt = (!p.merge_flag && p.gt_flag) ? 1 : 0;
+  for (int k = 0; k < 8; k++) j.gt[k] = p.gt[k];
+  be->pred_inter(lane_, 1, &j);
+}
+uint32_t CtuWorker::inter_pred_error(CuData& c, int pu) {                  // TEncSearch::xGetInterPredictionError (:2951-2977)
+  motion_comp_pu(c, pu);
+  int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
+  hop_dist_job d; d.x = c.x + ox; d.y = c.y + oy; d.w = w; d.h = h; d.comp = 0; d.kind = cfg.hadme ? HOP_DIST_HADS : HOP_DIST_SAD;
+  uint32_t e = 0; be->distortion(lane_, 1, &d, &e);
+  return e;
+}
+
+struct PuFields { int16_t mv[2], mvd[2], gt[8]; int8_t ref, mvp_idx, mvp_num; uint8_t gt_flag, merge_flag, merge_idx, inter_dir; };
+static void apply_pu_fields(Part& p, const void* a) {
+  const PuFields& f = *(const PuFields*)a;
+  p.mv[0] = f.mv[0]; p.mv[1] = f.mv[1]; p.mvd[0] = f.mvd[0]; p.mvd[1] = f.mvd[1]; memcpy(p.gt, f.gt, sizeof(p.gt));
+  p.ref_idx = f.ref; p.mvp_idx = f.mvp_idx; p.mvp_num = f.mvp_num; p.gt_flag = f.gt_flag; p.merge_flag = f.merge_flag; p.merge_idx = f.merge_idx; p.inter_dir = f.inter_dir;
+}
+
+// TEncSearch::predInterSearch (:3141-4169) for an ISS slice: list 0 with the SS picture only
+bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
+  const int npu = num_pus(ps);
+  const uint32_t lam = cfg.lambda_sad;
+  for (int pu = 0; pu < npu; pu++) {
+    int ox, oy, w, h; pu_rect(ps, c.size, pu, ox, oy, w, h);
+    const int px = c.x + ox, py = c.y + oy;
+    const bool test_normal = !(use_mrg && c.size > 8 && npu == 2);
+    PuFields me; memset(&me, 0, sizeof(me)); me.ref = -1; me.mvp_idx = -1; me.mvp_num = -1;
+    uint32_t me_bits = 0;
+    bool not_valid = false;
+    if (test_normal) {
+      uint32_t bits = (ps == SIZE_2Nx2N || ps == SIZE_NxN) ? 1 : 3;      // xGetBlkBits with bPSlice (:4294-4353)
+      // xEstimateMvPredAMVP (:4173-4262): the candidate with the smallest template cost
+      AmvpInfo info; fill_mvp_cand(c, pu, info);
+      int best_idx = 0; uint32_t best_cost = 0x7FFFFFFFu;
+      for (int i = 0; i < info.n; i++) {
+        uint32_t cost = 0x7FFFFFFFu;                                      // xGetTemplateCost (:4411-4477)
+        if (valid_pattern(px, py, w, h, info.cand[i][0], info.cand[i][1])) {
+          hop_pred_job j; memset(&j, 0, sizeof(j));
+          j.pu_x = px; j.pu_y = py; j.w = w; j.h = h;
+          int mh = info.cand[i][0], mvv = info.cand[i][1]; clip_mv(c, mh, mvv);
+          j.mv_x = mh; j.mv_y = mvv; j.use_gt = 0;
+          be->pred_inter(lane_, 1, &j);
+          hop_dist_job d; d.x = px; d.y = py; d.w = w; d.h = h; d.comp = 0; d.kind = HOP_DIST_SAD;
+          uint32_t sad = 0; be->distortion(lane_, 1, &d, &sad);
+          const double rd = (double)sad + (double)((int)(1 * (double)lam + .5) >> 16);   // calcRdCost(m_auiMVPIdxCost = 1 bit, SAD, false, DF_SAD)
+          cost = (uint32_t)(double)(uint32_t)floor(rd);
+        }
+        if (best_cost > cost) { best_cost = cost; best_idx = i; }
+      }
+      int pred[2] = { info.cand[best_idx][0], info.cand[best_idx][1] };
+      int mvp_idx = best_idx; const int mvp_num = info.n;
+      bits += 1;                                                          // m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS]
+      // xMotionEstimation (:4479-4683)
+      hop_pu_job j; memset(&j, 0, sizeof(j));
+      j.pu_x = px; j.pu_y = py; j.w = w; j.h = h;
+      int offx, offy; part_offset(ps, c.size, pu, offx, offy);
+      int r6[6];
+      hop_set_search_range(cfg.pic_w, cfg.pic_h, c.x, c.y, c.size, c.ctu_addr, E.wctu_, pred[0], pred[1], cfg.search_range, offx, offy, c.y == 0, c.x == 0, r6);
+      j.rng_left = r6[0]; j.rng_right = r6[1]; j.rng_top = r6[2]; j.rng_bottom = r6[3]; j.off_x = r6[4]; j.off_y = r6[5];
+      j.pred_x = pred[0]; j.pred_y = pred[1]; j.lambda_cost = lam; j.n_amvp = info.n;
+      for (int i = 0; i < info.n; i++) { j.amvp[2 * i] = info.cand[i][0]; j.amvp[2 * i + 1] = info.cand[i][1]; }
+      j.flags = (cfg.fen ? HOP_FLAG_FEN : 0) | (cfg.hadme ? HOP_FLAG_HADME : 0);
+      hop_pu_result r; memset(&r, 0, sizeof(r));
+      be->me_search(lane_, 1, &j, &r);
+      not_valid = r.not_valid != 0;
+      if (!not_valid) {
+        int mvq[2]; uint32_t cost = 0;
+        hop_me_finish(&j, &r, HOP_STAGE_GT, bits, mvq, &bits, &cost);
+        // xCheckBestMVP (:4364-4409): the predictor that makes the vector cheapest
+        {
+          int best = mvp_idx;
+          const int org_bits = (int)(component_bits(mvq[0] - pred[0]) + component_bits(mvq[1] - pred[1])) + 1;
+          int best_bits = org_bits;
+          for (int i = 0; i < info.n; i++) {
+            if (i == mvp_idx) continue;
+            const int b = (int)(component_bits(mvq[0] - info.cand[i][0]) + component_bits(mvq[1] - info.cand[i][1])) + 1;
+            if (b < best_bits) { best_bits = b; best = i; }
+          }
+          if (best != mvp_idx) {
+            pred[0] = info.cand[best][0]; pred[1] = info.cand[best][1]; mvp_idx = best;
+            const uint32_t ob = bits;
+            bits = ob - org_bits + best_bits;
+            cost = (cost - ((lam * ob) >> 16)) + ((lam * bits) >> 16);
+          }
+        }
+        me.mv[0] = (int16_t)mvq[0]; me.mv[1] = (int16_t)mvq[1]; me.ref = 0;
+        me.mvd[0] = (int16_t)(mvq[0] - pred[0]); me.mvd[1] = (int16_t)(mvq[1] - pred[1]);
+        for (int k = 0; k < 8; k++) me.gt[k] = (int16_t)r.gt[k];
+        me.gt_flag = r.gt_flag ? 1 : 0; me.inter_dir = 1; me.mvp_idx = (int8_t)mvp_idx; me.mvp_num = (int8_t)mvp_num;
+        me_bits = bits;
+      }
+    }
+    // the PU's fields cleared (:3699-3727), then the search result (:3885-3922)
+    { PuFields z; memset(&z, 0, sizeof(z)); z.ref = -1; z.mvp_idx = -1; z.mvp_num = -1; z.inter_dir = part_at(c, px, py)->inter_dir; z.merge_flag = part_at(c, px, py)->merge_flag; z.merge_idx = part_at(c, px, py)->merge_idx;
+      set_parts(c, ox, oy, w, h, apply_pu_fields, &z);
+      c.p[pu].gt_flag = 0; }                                                 // setGTFlag(iPartIdx, false) (:3721): the partition with the PU's NUMBER, not its address
+    if (test_normal) {
+      if (not_valid) return false;                                         // :3964-3967
+      set_parts(c, ox, oy, w, h, apply_pu_fields, &me);
+    }
+    if (ps != SIZE_2Nx2N) {
+      // ME against merge (:3977-4146)
+      uint32_t me_cost = MAX_UINT;
+      if (test_normal) { const uint32_t err = inter_pred_error(c, pu); me_cost = err + ((lam * me_bits) >> 16); }
+      PuFields saved = me;
+      if (!test_normal) { memset(&saved, 0, sizeof(saved)); saved.ref = -1; saved.mvp_idx = -1; saved.mvp_num = -1; }
+      // xMergeEstimation (:2992-3106)
+      MergeCands mc; merge_candidates(c, pu, mc);
+      uint32_t mrg_cost = MAX_UINT; int mrg_idx = 0; bool val_merge = false;
+      for (int k = 0; k < mc.n; k++) {
+        PuFields f = test_normal ? me : saved;                             // the GT fields and flag stay what the motion search left in the CU
+        f.mv[0] = mc.f[k].mv[0]; f.mv[1] = mc.f[k].mv[1]; f.ref = mc.f[k].ref;
+        set_parts(c, ox, oy, w, h, apply_pu_fields, &f);
+        if (f.ref == 0) {
+          int mh = f.mv[0], mvv = f.mv[1]; clip_mv(c, mh, mvv);
+          if (!valid_pattern(px, py, w, h, mh, mvv)) continue;
+        }
+        val_merge = true;
+        uint32_t cand = inter_pred_error(c, pu);
+        uint32_t cb = (uint32_t)k + 1; if (k == cfg.max_merge_cand - 1) cb--;
+        cand += (lam * cb) >> 16;
+        if (cand < mrg_cost) { mrg_cost = cand; mrg_idx = k; }
+      }
+      if (!val_merge) { mrg_cost = MAX_UINT; if (!test_normal) return false; }
+      if (mrg_cost < me_cost) {
+        PuFields f; memset(&f, 0, sizeof(f));
+        f.merge_flag = 1; f.merge_idx = (uint8_t)mrg_idx; f.inter_dir = mc.dir[mrg_idx]; f.mv[0] = mc.f[mrg_idx].mv[0]; f.mv[1] = mc.f[mrg_idx].mv[1]; f.ref = mc.f[mrg_idx].ref;
+        f.mvp_idx = -1; f.mvp_num = -1;
+        set_parts(c, ox, oy, w, h, apply_pu_fields, &f);
+      } else {
+        PuFields f = saved; f.merge_flag = 0;
+        bool any = false; for (int k = 0; k < 8; k++) any |= f.gt[k] != 0;
+        f.gt_flag = any ? 1 : 0;
+        set_parts(c, ox, oy, w, h, apply_pu_fields, &f);
+      }
+    }
+    motion_comp_pu(c, pu);                                                 // :4158
+  }
+  return true;
+}
+
+// ---- candidate evaluation through the backend ----
+static void fill_rqt_job(const EncConfig& cfg, const CuData& c, bool intra, int part_size, hop_rqt_job& j) {
+  memset(&j, 0, sizeof(j));
+  j.x = c.x; j.y = c.y; j.log2_cu = 6 - c.depth;
+  for (int k = 0; k < 3; k++) { j.qp_scaled[k] = cfg.qp_scaled[k]; j.lambda_rdoq[k] = cfg.lambda_rdoq[k]; }
+  j.ctx_index = 0; j.sign_hide = cfg.sign_hide; j.use_ts = cfg.use_ts; j.log2_max_tu = cfg.log2_max_tu;
+  // TComDataCU::getQuadtreeTULog2MinSizeInCU (TComDataCU.cpp:1860-1886)
+  const int max_depth = intra ? cfg.tu_max_depth_intra : cfg.tu_max_depth_inter;
+  const int isf = (intra && part_size == SIZE_NxN) ? 1 : 0, esf = (!intra && max_depth == 1 && part_size != SIZE_2Nx2N) ? 1 : 0;
+  int m;
+  if (j.log2_cu < cfg.log2_min_tu + max_depth - 1 + esf + isf) m = cfg.log2_min_tu;
+  else { m = j.log2_cu - (max_depth - 1 + esf + isf); if (m > cfg.log2_max_tu) m = cfg.log2_max_tu; }
+  j.log2_min_tu_in_cu = m; j.inter_split_flag = esf;
+  j.lambda_rd = cfg.lambda; j.dist_weight[0] = cfg.dist_weight[0]; j.dist_weight[1] = cfg.dist_weight[1];
+}
+
+void CtuWorker::eval_inter(int d, bool skip_res) {
+  CuData& c = *temp_[d];
+  InterEval e; memset(&e, 0, sizeof(e));
+  const int ps = c.p[0].part_size;
+  fill_rqt_job(cfg, c, false, ps, e.job);
+  e.skip_res = skip_res ? 1 : 0;
+  hop_cu_syntax& y = e.syn;
+  y.part_size = ps; y.n_pu = num_pus(ps); y.skip_flag = c.p[0].skip;
+  { const Part* l = nb_left(c, c.x, c.y); const Part* a = nb_above(c, c.x, c.y); y.skip_ctx = (l ? l->skip : 0) + (a ? a->skip : 0); }   // getCtxSkipFlag (:1888)
+  y.amp_acc = (cfg.amp && d < 3) ? 1 : 0; y.is_min_cu = d == 3; y.max_merge_cand = cfg.max_merge_cand;
+  for (int pu = 0; pu < y.n_pu; pu++) {
+    int ox, oy, w, h; pu_rect(ps, c.size, pu, ox, oy, w, h);
+    const Part& p = *part_at(c, c.x + ox, c.y + oy);
+    y.pu[pu].merge_flag = p.merge_flag; y.pu[pu].merge_idx = p.merge_idx; y.pu[pu].mvd[0] = p.mvd[0]; y.pu[pu].mvd[1] = p.mvd[1]; y.pu[pu].mvp_idx = p.mvp_idx;
+    y.pu[pu].gt_flag = p.gt_flag; for (int k = 0; k < 8; k++) y.pu[pu].gt[k] = p.gt[k];
+  }
+  EvalResult r; memset(&r, 0, sizeof(r));
+  const Coder& in = sb_[d][CI_CURR];
+  be->inter_cu(lane_, e, in, r);
+  for (int i = 0; i < c.num_part; i++) {
+    Part& p = c.p[i];
+    p.tr_idx = r.tr_idx[i]; for (int k = 0; k < 3; k++) { p.cbf[k] = r.cbf[k][i]; p.tskip[k] = r.tskip[k][i]; }
+    if (skip_res || r.skipped) p.skip = 1;
+  }
+  c.bits = r.bits; c.dist = r.dist; c.cost = calc_rd_cost(r.bits, r.dist, cfg.lambda);
+  r.after.split[0] = in.split[0]; r.after.split[1] = in.split[1]; r.after.split[2] = in.split[2];
+  goon_ = r.after; sb_[d][CI_TEMP] = r.after;
+  c.fbits[0] = ((uint64_t)r.bits << 15) + coder_frac(r.after) - coder_frac(in);
+}
+
+void CtuWorker::check_inter(int d, int ps, bool use_mrg) {                 // TEncCu::xCheckRDCostInter (:1399-1453)
+  CuData& c = *temp_[d];
+  for (int i = 0; i < c.num_part; i++) { c.p[i].depth = (uint8_t)d; c.p[i].skip = 0; c.p[i].part_size = (uint8_t)ps; c.p[i].pred_mode = MODE_INTER; }
+  if (!pred_inter_search(c, ps, use_mrg)) { c.cost = MAX_DOUBLE; return; }
+  eval_inter(d, false);
+  check_best_mode(d, true);
+}
+
+void CtuWorker::check_merge_2Nx2N(int d, bool* early_skip) {               // TEncCu::xCheckRDCostMerge2Nx2N (:1243-1395)
+  CuData* c = temp_[d];
+  for (int i = 0; i < c->num_part; i++) c->p[i].part_size = SIZE_2Nx2N;
+  MergeCands mc; merge_candidates(*c, 0, mc);
+  int buf[5] = { 0, 0, 0, 0, 0 };
+  bool best_is_skip = false;
+  for (int nores = 0; nores < 2; nores++) {
+    for (int k = 0; k < mc.n; k++) {
+      if (nores == 1 && buf[k] == 1) continue;
+      if (best_is_skip && nores == 0) continue;
+      c = temp_[d];
+      for (int i = 0; i < c->num_part; i++) {
+        Part& p = c->p[i];
+        p.pred_mode = MODE_INTER; p.part_size = SIZE_2Nx2N; p.merge_flag = 1; p.merge_idx = (uint8_t)k; p.inter_dir = mc.dir[k];
+        p.mv[0] = mc.f[k].mv[0]; p.mv[1] = mc.f[k].mv[1]; p.ref_idx = mc.f[k].ref;
+      }
+      if (mc.f[k].ref == 0) {
+        int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(*c, mh, mvv);
+        if (!valid_pattern(c->x, c->y, c->size, c->size, mh, mvv)) { init_est(*c); continue; }
+      }
+      motion_comp_pu(*c, 0);
+      eval_inter(d, nores != 0);
+      const int root = (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1);
+      if (nores == 0 && root == 0) buf[k] = 1;
+      for (int i = 0; i < c->num_part; i++) c->p[i].skip = root == 0;
+      check_best_mode(d, true);
+      init_est(*temp_[d]);
+      if (cfg.fdm && !best_is_skip) {
+        const Part& b = best_[d]->p[0];
+        best_is_skip = ((b.cbf[0] & 1) | (b.cbf[1] & 1) | (b.cbf[2] & 1)) == 0;
+      }
+    }
+    if (nores == 0 && cfg.esd) {
+      const Part& b = best_[d]->p[0];
+      if (((b.cbf[0] & 1) | (b.cbf[1] & 1) | (b.cbf[2] & 1)) == 0) {
+        if (b.merge_flag) *early_skip = true;
+        else if (abs(b.mvd[0]) + abs(b.mvd[1]) == 0) *early_skip = true;
+      }
+    }
+  }
+}
+
+void CtuWorker::fill_intra_eval(const CuData& c, int ps, IntraEval& e) {
+  memset(&e, 0, sizeof(e));
+  fill_rqt_job(cfg, c, true, ps, e.job);
+  e.part_nxn = ps == SIZE_NxN ? 1 : 0;
+  hop_intra_cu_syntax& y = e.syn;
+  y.part_nxn = e.part_nxn; y.skip_flag = 0; y.is_min_cu = c.depth == 3;
+  { const Part* l = nb_left(c, c.x, c.y); const Part* a = nb_above(c, c.x, c.y); y.skip_ctx = (l ? l->skip : 0) + (a ? a->skip : 0); }
+  e.opt.ts_fast = cfg.ts_fast; e.opt.strong = cfg.strong_intra;
+  auto flags_of = [&](int x, int yy, int size, uint8_t* fl) {
+    const int u = size / 4;
+    memset(fl, 0, 4 * u + 1);
+    fl[2 * u] = nb_above_left(c, x, yy) ? 1 : 0;                           // position only: part_at is never dereferenced here
+    for (int i = 0; i < u; i++) {
+      fl[2 * u + 1 + i] = ((yy & 63) || yy > 0) ? 1 : 0;                   // above (isAboveAvailable)
+      fl[2 * u - 1 - i] = ((x & 63) || x > 0) ? 1 : 0;                     // left, upwards from the corner
+      fl[3 * u + 1 + i] = ar_avail(x + size - 4, yy, i + 1) ? 1 : 0;       // above right, from the block's top-right unit
+      fl[u - 1 - i] = bl_avail(x, yy + size - 4, i + 1) ? 1 : 0;           // below left, from the bottom-left unit
+    }
+  };
+  // every node of the CU's transform tree that can be predicted (size 4..32)
+  static const int base[5] = { 0, 1, 5, 21, 85 };
+  const int log2_cu = 6 - c.depth;
+  for (int dd = 0; dd <= 4 && log2_cu - dd >= 2; dd++) {
+    const int l2 = log2_cu - dd; if (l2 > 5) continue;
+    const int size = 1 << l2, np = 1 << (2 * (l2 - 2));
+    for (int p = 0; p < c.num_part; p += np) {
+      int x4, y4; zpos(p, x4, y4);
+      uint8_t fl[68];
+      flags_of(c.x + 4 * x4, c.y + 4 * y4, size, fl);
+      uint64_t m = 0; for (int i = 0; i < 4 * (size / 4) + 1; i++) if (fl[i]) m |= 1ull << i;
+      e.opt.avail[base[dd] + (p >> (2 * (l2 - 2)))] = m;
+    }
+  }
+  const int npu = e.part_nxn ? 4 : 1, N = c.size >> e.part_nxn;
+  for (int pu = 0; pu < npu; pu++) {
+    const int x = c.x + (pu & 1) * N, yy = c.y + (pu >> 1) * N;
+    const Part* l = nb_left(c, x, yy); const Part* a = nb_above(c, x, yy, true);
+    e.sjob.left_dir[pu] = l ? (l->pred_mode == MODE_INTRA ? l->luma_dir : DC_IDX) : DC_IDX;
+    e.sjob.above_dir[pu] = a ? (a->pred_mode == MODE_INTRA ? a->luma_dir : DC_IDX) : DC_IDX;
+    flags_of(x, yy, N, e.sjob.rough_flags[pu]);
+  }
+  e.sjob.sqrt_lambda = cfg.sqrt_lambda;
+  e.sjob.num_full_rd = N <= 8 ? 8 : 3;                                     // g_aucIntraModeNumFast (TComRom.cpp:274-282)
+}
+
+void CtuWorker::check_intra(int d, int ps) {                               // TEncCu::xCheckRDCostIntra (:1455-1507)
+  CuData& c = *temp_[d];
+  for (int i = 0; i < c.num_part; i++) { c.p[i].skip = 0; c.p[i].part_size = (uint8_t)ps; c.p[i].pred_mode = MODE_INTRA; }
+  IntraEval e; fill_intra_eval(c, ps, e);
+  EvalResult r; memset(&r, 0, sizeof(r));
+  const Coder& in = sb_[d][CI_CURR];
+  be->intra_cu(lane_, e, in, r);
+  const int npu = e.part_nxn ? 4 : 1, q = c.num_part >> 2;
+  for (int i = 0; i < c.num_part; i++) {
+    Part& p = c.p[i];
+    p.tr_idx = r.tr_idx[i]; for (int k = 0; k < 3; k++) { p.cbf[k] = r.cbf[k][i]; p.tskip[k] = r.tskip[k][i]; }
+    p.luma_dir = (uint8_t)r.luma_dir[npu == 4 ? i / q : 0]; p.chroma_dir = (uint8_t)r.chroma_dir;
+  }
+  c.bits = r.bits; c.dist = r.dist; c.cost = calc_rd_cost(r.bits, r.dist, cfg.lambda);
+  r.after.split[0] = in.split[0]; r.after.split[1] = in.split[1]; r.after.split[2] = in.split[2];
+  goon_ = r.after; sb_[d][CI_TEMP] = r.after;
+  c.fbits[0] = ((uint64_t)r.bits << 15) + coder_frac(r.after) - coder_frac(in);
+  check_best_mode(d, true);
+}
+
+// TEncCu::xCompressCU (:371-892)
+void CtuWorker::compress_cu(int d, int parent_ps) {
+  const int x = best_[d]->x, y = best_[d]->y, size = best_[d]->size;
+  bool sub_branch = true, do_not_block_pu = true, early_skip = false, boundary = false;
+  const bool inside = (x + size <= cfg.pic_w) && (y + size <= cfg.pic_h);
+  const bool not_i = cfg.slice_type != 2;
+  auto root_cbf = [](const CuData* c) { return (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1); };
+  if (inside) {
+    init_est(*temp_[d]);
+    if (not_i) {
+      if (cfg.esd) { check_inter(d, SIZE_2Nx2N, false); init_est(*temp_[d]); }
+      check_merge_2Nx2N(d, &early_skip); init_est(*temp_[d]);
+      if (!cfg.esd) {
+        check_inter(d, SIZE_2Nx2N, false); init_est(*temp_[d]);
+        if (cfg.cfm) do_not_block_pu = root_cbf(best_[d]) != 0;
+      }
+    }
+    if (!early_skip) {
+      init_est(*temp_[d]);
+      if (not_i) {
+        if (size != 8 && d == 3 && do_not_block_pu) { check_inter(d, SIZE_NxN, false); init_est(*temp_[d]); }
+        if (do_not_block_pu) {
+          check_inter(d, SIZE_Nx2N, false); init_est(*temp_[d]);
+          if (cfg.cfm && best_[d]->p[0].part_size == SIZE_Nx2N) do_not_block_pu = root_cbf(best_[d]) != 0;
+        }
+        if (do_not_block_pu) {
+          check_inter(d, SIZE_2NxN, false); init_est(*temp_[d]);
+          if (cfg.cfm && best_[d]->p[0].part_size == SIZE_2NxN) do_not_block_pu = root_cbf(best_[d]) != 0;
+        }
+        if (cfg.amp && d < 3) {                                            // getAMPAcc(depth)
+          // deriveTestModeAMP (:292-356)
+          bool hor = false, ver = false, mhor = false, mver = false;
+          const Part& b = best_[d]->p[0];
+          if (b.part_size == SIZE_2NxN) hor = true;
+          else if (b.part_size == SIZE_Nx2N) ver = true;
+          else if (b.part_size == SIZE_2Nx2N && !b.merge_flag && !b.skip) { hor = true; ver = true; }
+          if (parent_ps >= SIZE_2NxnU && parent_ps <= SIZE_nRx2N) { mhor = true; mver = true; }
+          if (parent_ps == SIZE_NONE) {
+            if (b.part_size == SIZE_2NxN) mhor = true;
+            else if (b.part_size == SIZE_Nx2N) mver = true;
+          }
+          if (b.part_size == SIZE_2Nx2N && !b.skip) { mhor = true; mver = true; }
+          if (size == 64) { hor = false; ver = false; }
+          auto amp = [&](int ps, bool mrg, bool cfm_check) {
+            if (!do_not_block_pu) return;
+            check_inter(d, ps, mrg); init_est(*temp_[d]);
+            if (cfm_check && cfg.cfm && best_[d]->p[0].part_size == ps) do_not_block_pu = root_cbf(best_[d]) != 0;
+          };
+          if (hor) { amp(SIZE_2NxnU, false, true); amp(SIZE_2NxnD, false, true); }
+          else if (mhor) { amp(SIZE_2NxnU, true, true); amp(SIZE_2NxnD, true, true); }
+          if (ver) { amp(SIZE_nLx2N, false, true); amp(SIZE_nRx2N, false, false); }
+          else if (mver) { amp(SIZE_nLx2N, true, true); amp(SIZE_nRx2N, true, false); }
+        }
+      }
+      const Part& b = best_[d]->p[0];
+      if (!not_i || b.cbf[0] != 0 || b.cbf[1] != 0 || b.cbf[2] != 0 || cfg.slice_type == 3 || b.part_size == SIZE_NONE) {
+        check_intra(d, SIZE_2Nx2N); init_est(*temp_[d]);
+        if (d == 3 && size > (1 << cfg.log2_min_tu)) { check_intra(d, SIZE_NxN); init_est(*temp_[d]); }
+      }
+    }
+    // the split flag of "not split", counted on the go-on coder as the last candidate left it (:686-690)
+    best_[d]->bits += split_flag_bits(*best_[d], d, goon_);
+    best_[d]->cost = calc_rd_cost(best_[d]->bits, best_[d]->dist, cfg.lambda);
+    sub_branch = !(cfg.ecu && best_[d]->p[0].skip);
+  } else boundary = true;
+
+  bool split_is_best = false;
+  if (sub_branch && d < 3) {
+    init_est(*temp_[d]);
+    CuData* t = temp_[d];
+    const int nd = d + 1, q = t->num_part >> 2, h = size >> 1;
+    for (int i = 0; i < 4; i++) {
+      const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
+      init_cu(*best_[nd], t->abs_idx + i * q, nd, sx, sy); init_cu(*temp_[nd], t->abs_idx + i * q, nd, sx, sy);
+      if (sx < cfg.pic_w && sy < cfg.pic_h) {
+        sb_[nd][CI_CURR] = i == 0 ? sb_[d][CI_CURR] : sb_[nd][CI_NEXT];
+        compress_cu(nd, best_[d]->p[0].pred_mode == MODE_INTRA ? (int)SIZE_NONE : (int)best_[d]->p[0].part_size);
+      } else copy_to_pic(*best_[nd]);
+      // copyPartFrom (TComDataCU.cpp:1005-1096)
+      t = temp_[d];
+      memcpy(&t->p[i * q], best_[nd]->p, sizeof(Part) * q); memcpy(&t->fbits[i * q], best_[nd]->fbits, sizeof(uint64_t) * q);
+      if (sx < cfg.pic_w && sy < cfg.pic_h) { t->bits += best_[nd]->bits; t->dist += best_[nd]->dist; }
+    }
+    if (!boundary) t->bits += split_flag_bits(*t, d, goon_);
+    t->cost = calc_rd_cost(t->bits, t->dist, cfg.lambda);
+    sb_[d][CI_TEMP] = sb_[nd][CI_NEXT];
+    CuData* before = best_[d];
+    check_best_mode(d, false);
+    split_is_best = best_[d] != before;
+  }
+  copy_to_pic(*best_[d]);
+  if (!boundary) {
+    if (!split_is_best) be->recon_restore(lane_, d, x, y, size);           // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture
+    be->commit(lane_, x, y, size);                                         // xCopyYuv2SSRef (:872-880)
+  }
+}
+
+// the pass of TEncCu::encodeCU over the finished CTU (TEncSlice.cpp:1142 on the CTU's entry coder): split flags in coding order on the evolving
+// split contexts; the CUs' own syntax was counted when they were chosen (its context updates are in CI_NEXT_BEST, its fractional bits in fbits)
+uint64_t CtuWorker::final_walk(int x, int y, int size, int d, Coder& k) {
+  const CuData& c = *best_[0];
+  const bool inside = (x + size <= cfg.pic_w) && (y + size <= cfg.pic_h);
+  const Part& p = c.p[zpix(x, y)];
+  uint64_t total = 0;
+  if (inside && d < 3) {
+    const Part* l = nb_left(c, x, y); const Part* a = nb_above(c, x, y);
+    const int ctx = (l ? (l->depth > d) : 0) + (a ? (a->depth > d) : 0);
+    total += hop_cabac_bin_bits(&k.split[ctx], p.depth > d ? 1 : 0);
+  }
+  if ((d < p.depth && d < 3) || !inside) {
+    const int h = size >> 1;
+    for (int i = 0; i < 4; i++) {
+      const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
+      if (sx < cfg.pic_w && sy < cfg.pic_h) total += final_walk(sx, sy, h, d + 1, k);
+    }
+    return total;
+  }
+  return total + c.fbits[zpix(x, y)];
+}
+
+void CtuWorker::compress_ctu(int addr, const Coder& entry, Coder& exit) {
+  ctu_addr_ = addr; ctu_x_ = (addr % E.wctu_) * CTU; ctu_y_ = (addr / E.wctu_) * CTU;
+  init_cu(*best_[0], 0, 0, ctu_x_, ctu_y_); init_cu(*temp_[0], 0, 0, ctu_x_, ctu_y_);
+  sb_[0][CI_CURR] = entry; sb_[0][CI_NEXT] = entry; sb_[0][CI_TEMP] = entry; goon_ = entry;
+  compress_cu(0, SIZE_NONE);
+  E.ctu_cost[addr] = best_[0]->cost; E.ctu_bits[addr] = best_[0]->bits; E.ctu_dist[addr] = best_[0]->dist;
+  // the coder the next CTU starts from
+  exit = sb_[0][CI_NEXT];
+  memcpy(exit.split, entry.split, 3);
+  uint64_t total = coder_frac(entry);
+  total += final_walk(ctu_x_, ctu_y_, CTU, 0, exit);
+  if (addr != E.n_ctu() - 1) total += hop_cabac_trm_bits(0);              // TEncCu::finishCU (:940-945): no terminating bin after the slice's last CTU
+  coder_set_frac(exit, (uint32_t)(total & 32767));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// the picture
+// ---------------------------------------------------------------------------------------------------------------------------------
+Encoder::Encoder(const EncConfig& cfg, Backend* be) : trace(NULL), n_candidates(0), cfg_(cfg), be_(be) {
+  wctu_ = (cfg.pic_w + 63) / 64; hctu_ = (cfg.pic_h + 63) / 64;
+  ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0);
+  pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu());
+  for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
+}
+
+void intra_syntax_dirs(hop_intra_cu_syntax& syn, const hop_intra_search_job& sj, const int dirs[4]) {
+  const int npu = syn.part_nxn ? 4 : 1;
+  for (int pu = 0; pu < npu; pu++) {
+    const int l = (pu & 1) ? dirs[pu - 1] : sj.left_dir[pu], a = (pu >> 1) ? dirs[pu - 2] : sj.above_dir[pu];
+    int* pr = syn.preds[pu];
+    if (l == a) {
+      if (l > 1) { pr[0] = l; pr[1] = ((l + 29) % 32) + 2; pr[2] = ((l - 1) % 32) + 2; }
+      else { pr[0] = PLANAR_IDX; pr[1] = DC_IDX; pr[2] = VER_IDX; }
+    } else {
+      pr[0] = l; pr[1] = a;
+      pr[2] = (l && a) ? (int)PLANAR_IDX : ((l + a) < 2 ? (int)VER_IDX : (int)DC_IDX);
+    }
+    syn.pred_num[pu] = 3; syn.luma_dir[pu] = dirs[pu];
+  }
+}
+
+void Encoder::encode_frame(int first_ctus) {
+  be_->begin_frame();
+  for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
+  Coder k; memset(&k, 0, sizeof(k));
+  hop_cabac_init(&k.r, cfg_.slice_type, cfg_.qp); hop_cabac_cu_init(&k.c, cfg_.slice_type, cfg_.qp); hop_cabac_split_init(k.split, cfg_.slice_type, cfg_.qp);
+  CtuWorker* w = new CtuWorker(*this, 0);
+  const int n = (first_ctus > 0 && first_ctus < n_ctu()) ? first_ctus : n_ctu();
+  for (int a = 0; a < n; a++) {
+    ctu_entry[a] = k;
+    Coder next; w->compress_ctu(a, k, next);
+    k = next;
+  }
+  delete w;
+}
+
+}  // namespace hopspine

@@ -1,0 +1,109 @@
+// hop_spine.h -- the host RD spine of the HOP encoder: TEncCu::xCompressCU with its mode order,
+// xCheckRDCost{Merge2Nx2N,Inter,Intra}, xCheckBestMode, the snapshot discipline of the RD coders, TEncSearch::predInterSearch
+// (AMVP / merge candidate derivation, ME-vs-merge) and the CTU loop of TEncSlice::compressSlice -- control over candidate
+// evaluations that all run behind a Backend.  The product backend (hop_spine_hip.cpp) drives libhophip's kernels; the tests
+// instantiate the same spine over the CPU restatement (oracle/spine_backend_cpu.cpp) to pin it against the reference encoder.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include "../../include/hophip.h"
+
+namespace hopspine {
+
+enum { MODE_INTER = 0, MODE_INTRA = 1, MODE_NONE = 15 };                       // TLibCommon/TypeDef.h PredMode
+enum { SIZE_2Nx2N = 0, SIZE_2NxN, SIZE_Nx2N, SIZE_NxN, SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N, SIZE_NONE = 15 };
+enum { DC_IDX = 1, PLANAR_IDX = 0, VER_IDX = 26, DM_CHROMA_IDX = 36 };
+
+// the state of one RD coder (TEncSbac + its counting bin coder): residual sets + carried fraction, CU-level sets, split_cu_flag
+struct Coder { hop_cabac_ctx r; hop_cabac_cu_ctx c; uint8_t split[3]; uint8_t pad; };
+static inline uint32_t coder_frac(const Coder& k) { return (uint32_t)k.r.state[150] | ((uint32_t)k.r.state[151] << 8); }
+static inline void coder_set_frac(Coder& k, uint32_t f) { k.r.state[150] = (uint8_t)(f & 255); k.r.state[151] = (uint8_t)((f >> 8) & 127); }
+
+struct EncConfig {
+  int pic_w, pic_h, bit_depth;
+  int qp, slice_type;              // slice_type as hop_cabac_init: 3 = ISS
+  int search_range, mi_size, mi_merge, max_merge_cand;
+  int amp, fen, hadme, fdm, esd, cfm, ecu;
+  int log2_max_tu, log2_min_tu, tu_max_depth_inter, tu_max_depth_intra;
+  int sign_hide, use_ts, ts_fast, strong_intra;
+  int wpp;                         // 0: contexts run on from CTU to CTU in raster order (shipped configurations); 1: WaveFrontSynchro rows
+  // derived by finish_config()
+  double lambda, sqrt_lambda, lambda_rdoq[3], dist_weight[2];
+  uint32_t lambda_sad;
+  int qp_scaled[3];
+};
+void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size);   // cfg/3DHencoder_intra_main.cfg
+void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
+
+// one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
+struct Part {
+  uint8_t depth, pred_mode, part_size, skip, merge_flag, merge_idx, gt_flag, inter_dir;
+  int8_t  ref_idx, mvp_idx, mvp_num; uint8_t luma_dir, chroma_dir, tr_idx;
+  uint8_t cbf[3], tskip[3];
+  int16_t mv[2], mvd[2], gt[8];
+};
+
+struct CuData {                    // TComDataCU as the RD search uses it (one CU of the quadtree, or the whole CTU)
+  int ctu_addr, ctu_x, ctu_y, abs_idx, depth, x, y, size, num_part;
+  Part p[256];
+  uint64_t fbits[256];             // at a coded CU's first partition: the fractional bits of its syntax (what the final pass of the CTU adds to the coder's fraction)
+  double cost; uint32_t bits, dist;
+};
+
+// ---- candidate evaluation requests (the boundary between the spine and the kernels) ----
+struct InterEval {                 // encodeResAndCalcRdInterCU of a CU whose prediction is in the prediction picture
+  hop_rqt_job job; hop_cu_syntax syn; int skip_res;
+};
+struct IntraEval {                 // the body of xCheckRDCostIntra
+  hop_rqt_job job; hop_intra_cu_syntax syn; hop_intra_rqt_opt opt; hop_intra_search_job sjob; int part_nxn;
+};
+struct EvalResult {
+  double cost; uint32_t bits, dist; int skipped, root_cbf;
+  Coder after;                     // the coder the candidate leaves (CI_TEMP_BEST)
+  uint8_t tr_idx[256], cbf[3][256], tskip[3][256];
+  int luma_dir[4], chroma_dir;     // intra
+};
+
+// A backend owns the pictures (original, SS reference, prediction picture, reconstruction picture) and evaluates requests.
+// Every call is synchronous for the calling lane; `lane` names the CTU worker (stash slots are per lane).
+class Backend {
+ public:
+  virtual ~Backend() {}
+  virtual void begin_frame() = 0;                                                        // SS reference to the sentinel
+  virtual void me_search(int lane, int n, const hop_pu_job* jobs, hop_pu_result* res) = 0;   // SS + fractional + GT search
+  virtual void pred_inter(int lane, int n, const hop_pred_job* jobs) = 0;                // into the prediction picture
+  virtual void distortion(int lane, int n, const hop_dist_job* jobs, uint32_t* out) = 0; // original vs prediction picture
+  virtual void valid_pattern(int lane, int n, const int32_t* xywh_mv /* 6 per item: x, y, w, h, mvx, mvy (quarter-pel) */, uint8_t* out) = 0;
+  // candidate evaluation; afterwards the reconstruction picture holds the candidate's reconstruction in the CU's area
+  virtual void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) = 0;
+  virtual void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& out) = 0;
+  // reconstruction picture <-> stash slot (lane, slot): rect = x, y, size
+  virtual void recon_save(int lane, int slot, int x, int y, int size) = 0;
+  virtual void recon_restore(int lane, int slot, int x, int y, int size) = 0;
+  virtual void commit(int lane, int x, int y, int size) = 0;                             // reconstruction picture -> SS reference (xCopyYuv2SSRef)
+};
+
+// the luma directions of a finished intra search and their most probable modes (TComDataCU::getIntraDirLumaPredictor, TComDataCU.cpp:1772-1830) into the CU's
+// syntax elements: neighbours outside the CU from sj.left_dir / above_dir, inside it the PUs decided before
+void intra_syntax_dirs(hop_intra_cu_syntax& syn, const hop_intra_search_job& sj, const int dirs[4]);
+
+class Encoder {
+ public:
+  Encoder(const EncConfig& cfg, Backend* be);
+  void encode_frame(int first_ctus = 0);             // the CTUs in raster order (all, or the first `first_ctus`)
+  const EncConfig& config() const { return cfg_; }
+  int n_ctu() const { return wctu_ * hctu_; }
+  // results
+  std::vector<double>   ctu_cost;                    // per CTU: getTotalCost of compressCU (what cost.csv records)
+  std::vector<uint32_t> ctu_bits, ctu_dist;
+  std::vector<Part>     pic;                         // 256 parts per CTU, z-order
+  std::vector<Coder>    ctu_entry;                   // coder at the start of every CTU
+  FILE* trace;                                       // optional: one line per candidate that reaches xCheckBestMode
+  uint64_t n_candidates;
+ private:
+  friend class CtuWorker;
+  EncConfig cfg_; Backend* be_; int wctu_, hctu_;
+};
+
+}  // namespace hopspine

@@ -133,6 +133,14 @@ uint32_t hop_bits_gt(const int v[8]);
 void hop_me_finish(const hop_pu_job* job, const hop_pu_result* res, int stage, uint32_t bits_in,
                    int mv_qpel[2], uint32_t* bits_out, uint32_t* cost_out);
 
+/* single bins of the counting coder, for the split_cu_flag the RD spine counts itself (host only):
+ * replaces: TEncBinCABACCounter::encodeBin (TLibEncoder/TEncBinCoderCABACCounter.cpp:72-78) = ContextModel::getEntropyBits + update (TLibCommon/ContextModel.h:78,
+ * ContextModel.cpp:67-128): returns the fractional bits (15 binary places) of coding `bin` in *state and moves the state on; encodeBinTrm (:104-108) for the
+ * end_of_slice_segment_flag; ContextModel3DBuffer::initBuffer with INIT_SPLIT_FLAG (TLibCommon/ContextTables.h:126-136), slice_type as hop_cabac_init. */
+uint32_t hop_cabac_bin_bits(uint8_t* state, int bin);
+uint32_t hop_cabac_trm_bits(int bin);
+int hop_cabac_split_init(uint8_t split_ctx[3], int slice_type, int qp);
+
 /* ---- the hot path ---- */
 /* replaces: TEncSearch::xPatternSearch (:6262-6371) + xPatternSearchFracDIF (:6564-6610) +
  * xPatternSearchGT (:4686-5467) for a batch of PUs; the original block is read from the resident

@@ -1089,3 +1089,46 @@ Void TComPrediction::predIntraChromaAng(Int* piSrc, UInt uiDirMode, Pel* piPred,
   hop_o_intra_pred_chroma(L, N, (int)uiDirMode, g_bitDepthC, pred);
   for (int r = 0; r < N; r++) memcpy(piPred + r * uiStride, pred + r * N, N * sizeof(Pel));
 }
+
+// ---- observers for the RD spine (row a0): nothing is replaced here, the calls are logged and handed to the reference's own definitions ----
+// HOP_SHIM_TRACE_BEST=<file>: one text line per candidate that reaches TEncCu::xCheckBestMode (TLibEncoder/TEncCu.cpp:1557-1590), in the format of
+// hopspine::CtuWorker::trace_candidate: depth x y size pred_mode part_size skip merge bits dist cost.
+// HOP_SHIM_TRACE_CTU=<file>: after every TEncCu::compressCU (:246-264) the CTU's finished per-partition data, binary: address, cost, bits, distortion, then 256 records of
+// depth, pred_mode, part_size, skip, merge_flag, merge_idx, gt_flag, luma_dir, chroma_dir, tr_idx, cbf[3], mv[2], gt[8] (int16 each).
+extern "C" void hop_ref_orig_check_best(TEncCu*, TComDataCU*&, TComDataCU*&, UInt);
+extern "C" void hop_ref_orig_compress_cu(TEncCu*, TComDataCU*&);
+Void TEncCu::xCheckBestMode(TComDataCU*& rpcBestCU, TComDataCU*& rpcTempCU, UInt uiDepth)
+{
+  static FILE* f = NULL; static bool tried = false;
+  if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_BEST"); if (pth && *pth) f = fopen(pth, "w"); }
+  if (f) {
+    TComDataCU* c = rpcTempCU;
+    fprintf(f, "%d %d %d %d %d %d %d %d %u %u %.17g\n", (int)uiDepth, (int)c->getCUPelX(), (int)c->getCUPelY(), (int)c->getWidth(0), (int)c->getPredictionMode(0), (int)c->getPartitionSize(0),
+            (int)c->getSkipFlag(0), (int)c->getMergeFlag(0), c->getTotalBits(), c->getTotalDistortion(), c->getTotalCost());
+    fflush(f);
+  }
+  hop_ref_orig_check_best(this, rpcBestCU, rpcTempCU, uiDepth);
+}
+Void TEncCu::compressCU(TComDataCU*& rpcCU)
+{
+  hop_ref_orig_compress_cu(this, rpcCU);
+  static FILE* f = NULL; static bool tried = false;
+  if (!tried) { tried = true; const char* pth = getenv("HOP_SHIM_TRACE_CTU"); if (pth && *pth) f = fopen(pth, "wb"); }
+  if (f) {
+    TComDataCU* c = rpcCU;
+    const int32_t addr = (int32_t)c->getAddr(); const double cost = c->getTotalCost(); const uint32_t bd[2] = { c->getTotalBits(), c->getTotalDistortion() };
+    fwrite(&addr, 4, 1, f); fwrite(&cost, 8, 1, f); fwrite(bd, 4, 2, f);
+    for (UInt i = 0; i < c->getTotalNumPart(); i++) {
+      int16_t r[23];
+      r[0] = c->getDepth(i); r[1] = c->getPredictionMode(i); r[2] = c->getPartitionSize(i); r[3] = c->getSkipFlag(i); r[4] = c->getMergeFlag(i); r[5] = c->getMergeIndex(i);
+      r[6] = c->getGTFlag(i); r[7] = c->getLumaIntraDir(i); r[8] = c->getChromaIntraDir(i); r[9] = c->getTransformIdx(i);
+      r[10] = c->getCbf(i, TEXT_LUMA); r[11] = c->getCbf(i, TEXT_CHROMA_U); r[12] = c->getCbf(i, TEXT_CHROMA_V);
+      const TComMv m = c->getCUMvField(REF_PIC_LIST_0)->getMv(i); r[13] = m.getHor(); r[14] = m.getVer();
+      const TComMv g0 = c->getCUGT0Field(REF_PIC_LIST_0)->getMv(i), g1 = c->getCUGT1Field(REF_PIC_LIST_0)->getMv(i), g2 = c->getCUGT2Field(REF_PIC_LIST_0)->getMv(i),
+                   g3 = c->getCUGT3Field(REF_PIC_LIST_0)->getMv(i);
+      r[15] = g0.getHor(); r[16] = g0.getVer(); r[17] = g1.getHor(); r[18] = g1.getVer(); r[19] = g2.getHor(); r[20] = g2.getVer(); r[21] = g3.getHor(); r[22] = g3.getVer();
+      fwrite(r, 2, 23, f);
+    }
+    fflush(f);
+  }
+}

@@ -6,7 +6,7 @@
  *
  * Reference: zinsayon/HEVC-HOP (HM-15.0 fork).  Every function cites the reference file:line
  * it restates (paths relative to /root/reference/source/Lib).  Parity is PINNED: each function is
- * checked against golden vectors (tests/golden/*.npz, replayed by tests/test_oracle_golden*.py) that
+ * checked against golden vectors (the npz files of tests/golden, replayed by tests/test_oracle_golden*.py) that
  * oracle/make_golden*.py generated from the reference's own code compiled into
  * oracle/_ref/libref_harness.so, and it runs inside the reference encoder in place of the reference's
  * members with an unchanged bitstream (tests/test_encoder_shim.py, where /root/reference exists).

@@ -1,0 +1,226 @@
+// spine_backend_cpu.cpp -- TEST INFRASTRUCTURE ONLY: the RD spine of the product (hevc-hop_amd/host/hop_spine.cpp, compiled here unchanged) instantiated over
+// the CPU restatement (oracle/hop_oracle*.c) instead of the HIP kernels.  It exists so that the spine -- host logic -- can be pinned against the reference encoder
+// in the build container (tests/test_spine_cpu.py: per-CTU costs of cost.csv, every candidate of the reference's RD search, the reconstruction), and it is the
+// "same work" CPU port bench.py times as cpu_baseline.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load libhop_spine_cpu.so.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <vector>
+#include "../hevc-hop_amd/host/hop_spine.h"
+extern "C" {
+#include "hop_oracle.h"
+}
+
+using namespace hopspine;
+
+namespace {
+
+struct Plane { int w, h, stride, margin; std::vector<int16_t> buf; int16_t* p00; };
+
+class CpuBackend : public Backend {
+ public:
+  CpuBackend(int W, int H, int bd, const int16_t* y, const int16_t* cb, const int16_t* cr) : W(W), H(H), bd(bd) {
+    for (int c = 0; c < 3; c++) {
+      const int w = c ? W / 2 : W, h = c ? H / 2 : H;
+      org[c].assign((size_t)w * h, 0); pred[c].assign((size_t)w * h, 0); rec[c].assign((size_t)w * h, 0);
+      memcpy(&org[c][0], c == 0 ? y : c == 1 ? cb : cr, (size_t)w * h * 2);
+      const int m = c ? 40 : 80, G = 64;                                   // the reference's margins + guard rows (see tests/hoputil.py:Planes)
+      ss[c].w = w; ss[c].h = h; ss[c].margin = m; ss[c].stride = w + 2 * m;
+      ss[c].buf.assign((size_t)ss[c].stride * (h + 2 * m + 2 * G), -1);
+      ss[c].p00 = &ss[c].buf[0] + (size_t)(G + m) * ss[c].stride + m;
+    }
+  }
+  void begin_frame() {
+    for (int c = 0; c < 3; c++) { std::fill(ss[c].buf.begin(), ss[c].buf.end(), (int16_t)-1); std::fill(rec[c].begin(), rec[c].end(), (int16_t)0); }
+  }
+  void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) {
+    for (int i = 0; i < n; i++) {
+      const hop_pu_job& j = jobs[i]; hop_pu_result& r = res[i];
+      int64_t out[32]; memset(out, 0, sizeof(out));
+      int amvp[4] = { j.amvp[0], j.amvp[1], j.amvp[2], j.amvp[3] };
+      hop_o_me_pu(&org[0][(size_t)j.pu_y * W + j.pu_x], W, ss[0].p00, ss[0].stride, j.pu_x, j.pu_y, j.w, j.h, j.rng_left, j.rng_right, j.rng_top, j.rng_bottom, j.off_x, j.off_y,
+                  j.pred_x, j.pred_y, j.n_amvp, amvp, j.lambda_cost, (j.flags & HOP_FLAG_FEN) ? 1 : 0, (j.flags & HOP_FLAG_HADME) ? 1 : 0, bd, 3, out);
+      memset(&r, 0, sizeof(r));
+      r.mv_int[0] = (int32_t)out[0]; r.mv_int[1] = (int32_t)out[1]; r.sad = (uint32_t)out[2]; r.not_valid = (int32_t)out[3];
+      r.half[0] = (int32_t)out[4]; r.half[1] = (int32_t)out[5]; r.qter[0] = (int32_t)out[6]; r.qter[1] = (int32_t)out[7]; r.frac_cost = (uint32_t)out[8];
+      r.gt_flag = (int32_t)out[9]; for (int k = 0; k < 8; k++) r.gt[k] = (int32_t)out[10 + k];
+      r.cost = (uint32_t)out[18]; r.mv_final[0] = (int32_t)out[19]; r.mv_final[1] = (int32_t)out[20];
+      r.half_final[0] = (int32_t)out[21]; r.half_final[1] = (int32_t)out[22]; r.qter_final[0] = (int32_t)out[23]; r.qter_final[1] = (int32_t)out[24];
+    }
+  }
+  void pred_inter(int, int n, const hop_pred_job* jobs) {
+    for (int i = 0; i < n; i++) {
+      const hop_pred_job& j = jobs[i];
+      std::vector<int16_t> py((size_t)j.w * j.h), pb((size_t)j.w * j.h / 4), pr((size_t)j.w * j.h / 4);
+      int gt[8]; for (int k = 0; k < 8; k++) gt[k] = j.gt[k];
+      hop_o_pred_inter(ss[0].p00, ss[0].stride, ss[1].p00, ss[2].p00, ss[1].stride, j.pu_x, j.pu_y, j.w, j.h, j.mv_x, j.mv_y, j.use_gt, gt, bd, bd, &py[0], &pb[0], &pr[0]);
+      for (int r = 0; r < j.h; r++) memcpy(&pred[0][(size_t)(j.pu_y + r) * W + j.pu_x], &py[(size_t)r * j.w], j.w * 2);
+      for (int r = 0; r < j.h / 2; r++) {
+        memcpy(&pred[1][(size_t)(j.pu_y / 2 + r) * (W / 2) + j.pu_x / 2], &pb[(size_t)r * (j.w / 2)], j.w);
+        memcpy(&pred[2][(size_t)(j.pu_y / 2 + r) * (W / 2) + j.pu_x / 2], &pr[(size_t)r * (j.w / 2)], j.w);
+      }
+    }
+  }
+  void distortion(int, int n, const hop_dist_job* jobs, uint32_t* out) {
+    for (int i = 0; i < n; i++) {
+      const hop_dist_job& j = jobs[i];
+      const int s = j.comp ? 1 : 0, st = j.comp ? W / 2 : W;
+      const int16_t* o = &org[j.comp][(size_t)(j.y >> s) * st + (j.x >> s)]; const int16_t* p = &pred[j.comp][(size_t)(j.y >> s) * st + (j.x >> s)];
+      const int w = j.w >> s, h = j.h >> s;
+      out[i] = j.kind == HOP_DIST_SAD ? hop_o_sad(o, st, p, st, w, h, bd, 0) : j.kind == HOP_DIST_SSE ? hop_o_sse(o, st, p, st, w, h, bd) : hop_o_hads(o, st, p, st, w, h, bd);
+    }
+  }
+  void valid_pattern(int, int n, const int32_t* q, uint8_t* out) {          // TComRdCost::isValidPattern (TLibCommon/TComRdCost.cpp:430-443)
+    for (int i = 0; i < n; i++, q += 6) {
+      const int16_t* lb = ss[0].p00 + (ptrdiff_t)(q[1] + (q[5] >> 2) + q[3] + 4) * ss[0].stride + (q[0] + (q[4] >> 2));
+      out[i] = (lb[0] != -1 && lb[q[2] + 4] != -1) ? 1 : 0;
+    }
+  }
+  static void cfg_of(const hop_rqt_job& j, int bd, hop_o_rqt_cfg& c) {
+    memset(&c, 0, sizeof(c));
+    c.log2_cu = j.log2_cu; for (int k = 0; k < 3; k++) { c.qp[k] = j.qp_scaled[k]; c.lambda_rdoq[k] = j.lambda_rdoq[k]; }
+    c.bit_depth_y = c.bit_depth_c = bd; c.sign_hide = j.sign_hide; c.use_ts = j.use_ts; c.log2_max_tu = j.log2_max_tu; c.log2_min_tu_in_cu = j.log2_min_tu_in_cu;
+    c.inter_split_flag = j.inter_split_flag; c.lambda_rd = j.lambda_rd; c.dist_weight[0] = 1.0; c.dist_weight[1] = j.dist_weight[0]; c.dist_weight[2] = j.dist_weight[1];
+  }
+  static void coder_in(const Coder& k, hop_o_coder& c, uint8_t cu[20]) { memcpy(&c.ctx, k.r.state, 150); c.frac = coder_frac(k); memcpy(cu, k.c.state, 20); }
+  static void coder_out(const hop_o_coder& c, const uint8_t cu[20], Coder& k) { memcpy(k.r.state, &c.ctx, 150); coder_set_frac(k, (uint32_t)(c.frac & 32767)); memcpy(k.c.state, cu, 20); }
+  struct Layers {                                                            // the m_ppcQTTempCoeff / m_pcQTTempTComYuv layer buffers of one CU
+    std::vector<int32_t> coef[4][3]; std::vector<int16_t> resi[4][3];
+    Layers(int cu, hop_o_rqt_state& st) {
+      memset(&st, 0, sizeof(st));
+      for (int l = 0; l < 4; l++) for (int c = 0; c < 3; c++) {
+        const size_t n = c ? (size_t)cu * cu / 4 : (size_t)cu * cu;
+        coef[l][c].assign(n, 0); resi[l][c].assign(n, 0); st.coef[l][c] = &coef[l][c][0]; st.resi[l][c] = &resi[l][c][0];
+      }
+    }
+  };
+  void cu_planes(const std::vector<int16_t>* src, int x, int y, int cu, std::vector<int16_t> out[3]) {
+    for (int c = 0; c < 3; c++) {
+      const int s = c ? 1 : 0, w = cu >> s, st = c ? W / 2 : W;
+      out[c].resize((size_t)w * w);
+      for (int r = 0; r < w; r++) memcpy(&out[c][(size_t)r * w], &src[c][(size_t)((y >> s) + r) * st + (x >> s)], w * 2);
+    }
+  }
+  void put_rec(const std::vector<int16_t> in[3], int x, int y, int cu) {
+    for (int c = 0; c < 3; c++) {
+      const int s = c ? 1 : 0, w = cu >> s, st = c ? W / 2 : W;
+      for (int r = 0; r < w; r++) memcpy(&rec[c][(size_t)((y >> s) + r) * st + (x >> s)], &in[c][(size_t)r * w], w * 2);
+    }
+  }
+  void inter_cu(int, const InterEval& e, const Coder& in, EvalResult& out) {
+    hop_o_rqt_cfg cfg; cfg_of(e.job, bd, cfg);
+    const int cu = 1 << cfg.log2_cu, x = e.job.x, y = e.job.y, parts = (cu / 4) * (cu / 4);
+    std::vector<int16_t> pr[3], og[3], rc[3];
+    cu_planes(pred, x, y, cu, pr); cu_planes(org, x, y, cu, og);
+    for (int c = 0; c < 3; c++) rc[c].assign(pr[c].size(), 0);
+    const int16_t* pp[3] = { &pr[0][0], &pr[1][0], &pr[2][0] }; const int16_t* oo[3] = { &og[0][0], &og[1][0], &og[2][0] }; int16_t* rr[3] = { &rc[0][0], &rc[1][0], &rc[2][0] };
+    hop_o_coder coder; uint8_t cuctx[20]; coder_in(in, coder, cuctx);
+    memset(out.tr_idx, 0, sizeof(out.tr_idx)); memset(out.cbf, 0, sizeof(out.cbf)); memset(out.tskip, 0, sizeof(out.tskip));
+    if (e.skip_res) {
+      uint32_t d3[3]; double cost = 0;
+      const uint32_t bits = hop_o_inter_cu_skip(&cfg, e.syn.skip_ctx, e.syn.pu[0].merge_idx, e.syn.max_merge_cand, pp, oo, &coder, cuctx, d3, &cost);
+      out.bits = bits; out.dist = d3[0] + d3[1] + d3[2]; out.cost = cost; out.skipped = 1; out.root_cbf = 0;
+      put_rec(pr, x, y, cu);
+      coder_out(coder, cuctx, out.after);
+      return;
+    }
+    std::vector<int16_t> rs[3];
+    for (int c = 0; c < 3; c++) { rs[c].resize(pr[c].size()); for (size_t i = 0; i < pr[c].size(); i++) rs[c][i] = (int16_t)(og[c][i] - pr[c][i]); }
+    hop_o_rqt_state st; Layers L(cu, st);
+    double cost = 0; uint32_t bits = 0, dist = 0, zd = 0;
+    hop_o_coder q = coder;
+    hop_o_rqt(&cfg, &rs[0][0], cu, &rs[1][0], &rs[2][0], cu / 2, &q, &st, &cost, &bits, &dist, &zd);
+    std::vector<int32_t> coef((size_t)cu * cu * 3 / 2, 0);
+    uint32_t d3[3];
+    const int root = hop_o_inter_cu_finish(&cfg, &st, &q, cost, zd, pp, oo, rr, d3, &coef[0]);
+    hop_o_cu_syntax syn; memcpy(&syn, &e.syn, sizeof(syn));
+    int skipped = 0;
+    const uint32_t cbits = hop_o_inter_cu_bits(&cfg, &syn, &st, &coef[0], &coder, cuctx, &skipped);
+    out.bits = cbits; out.dist = d3[0] + d3[1] + d3[2]; out.cost = hop_o_calc_rd_cost(cbits, out.dist, cfg.lambda_rd); out.skipped = skipped; out.root_cbf = root;
+    memcpy(out.tr_idx, st.tr_idx, parts); for (int c = 0; c < 3; c++) { memcpy(out.cbf[c], st.cbf[c], parts); memcpy(out.tskip[c], st.tskip[c], parts); }
+    put_rec(rc, x, y, cu);
+    coder_out(coder, cuctx, out.after);
+  }
+  void intra_cu(int, const IntraEval& e, const Coder& in, EvalResult& out) {
+    hop_o_rqt_cfg cfg; cfg_of(e.job, bd, cfg);
+    const int cu = 1 << cfg.log2_cu, x = e.job.x, y = e.job.y, parts = (cu / 4) * (cu / 4), half = cu / 2;
+    hop_o_intra_syntax syn; memset(&syn, 0, sizeof(syn));
+    syn.part_nxn = e.syn.part_nxn; syn.skip_flag = e.syn.skip_flag; syn.skip_ctx = e.syn.skip_ctx; syn.is_min_cu = e.syn.is_min_cu;
+    std::vector<uint8_t> avail((size_t)341 * HOP_O_AVAIL_PITCH, 0);
+    for (int nidx = 0; nidx < 341; nidx++) for (int u = 0; u < 33; u++) avail[(size_t)nidx * HOP_O_AVAIL_PITCH + u] = (uint8_t)((e.opt.avail[nidx] >> u) & 1);
+    hop_o_rqt_state st; Layers L(cu, st);
+    hop_o_intra_rqt_in rin; memset(&rin, 0, sizeof(rin));
+    rin.org = &org[0][(size_t)y * W + x]; rin.org_stride = W; rin.rec = &rec[0][(size_t)y * W + x]; rin.rec_stride = W;
+    rin.avail = &avail[0]; rin.strong = e.opt.strong; rin.ts_fast = e.opt.ts_fast;
+    hop_o_intra_search_in sin; memset(&sin, 0, sizeof(sin));
+    uint8_t rough[4 * 68];
+    for (int p = 0; p < 4; p++) { sin.left_dir[p] = e.sjob.left_dir[p]; sin.above_dir[p] = e.sjob.above_dir[p]; memcpy(rough + 68 * p, e.sjob.rough_flags[p], 68); }
+    sin.rough_flags = rough; sin.sqrt_lambda = e.sjob.sqrt_lambda; sin.num_full_rd = e.sjob.num_full_rd;
+    hop_o_coder coder; uint8_t cuctx[20]; coder_in(in, coder, cuctx);
+    std::vector<int32_t> coef((size_t)cu * cu * 3 / 2, 0);
+    std::vector<int16_t> rc[3]; rc[0].assign((size_t)cu * cu, 0); rc[1].assign((size_t)half * half, 0); rc[2].assign((size_t)half * half, 0);
+    int best_dir[4] = { 0, 0, 0, 0 }, ncand[4]; uint32_t dist_y = 0;
+    hop_o_intra_luma_search(&cfg, &syn, &rin, &sin, &coder, cuctx, &st, best_dir, &coef[0], &rc[0][0], &dist_y, ncand);
+    // TEncCu.cpp:1476: the CU's luma reconstruction into the picture before the chroma search
+    for (int r = 0; r < cu; r++) memcpy(&rec[0][(size_t)(y + r) * W + x], &rc[0][(size_t)r * cu], cu * 2);
+    hop_intra_cu_syntax tmp = e.syn; intra_syntax_dirs(tmp, e.sjob, best_dir);
+    for (int p = 0; p < 4; p++) { syn.luma_dir[p] = tmp.luma_dir[p]; syn.pred_num[p] = tmp.pred_num[p]; for (int k = 0; k < 3; k++) syn.preds[p][k] = tmp.preds[p][k]; }
+    hop_o_intra_chroma_in cin; memset(&cin, 0, sizeof(cin));
+    const size_t co = (size_t)(y / 2) * (W / 2) + x / 2;
+    cin.org_cb = &org[1][co]; cin.org_cr = &org[2][co]; cin.org_stride = W / 2; cin.rec_cb = &rec[1][co]; cin.rec_cr = &rec[2][co]; cin.rec_stride = W / 2;
+    cin.avail = &avail[0]; cin.ts_fast = e.opt.ts_fast;
+    int best_mode = 0; uint32_t best_dist = 0;
+    hop_o_intra_chroma_search(&cfg, &syn, &cin, &coder, cuctx, &st, &best_mode, &best_dist, &coef[(size_t)cu * cu], &coef[(size_t)cu * cu * 5 / 4], &rc[1][0], &rc[2][0]);
+    syn.chroma_is_dm = best_mode == 36; syn.chroma_dir = best_mode;
+    const uint32_t bits = hop_o_intra_cu_total_bits(&cfg, &syn, &st, &coef[0], &coder, cuctx);
+    out.bits = bits; out.dist = dist_y + best_dist; out.cost = hop_o_calc_rd_cost(bits, out.dist, cfg.lambda_rd); out.skipped = 0; out.root_cbf = 1;
+    memset(out.tr_idx, 0, sizeof(out.tr_idx)); memset(out.cbf, 0, sizeof(out.cbf)); memset(out.tskip, 0, sizeof(out.tskip));
+    memcpy(out.tr_idx, st.tr_idx, parts); for (int c = 0; c < 3; c++) { memcpy(out.cbf[c], st.cbf[c], parts); memcpy(out.tskip[c], st.tskip[c], parts); }
+    for (int p = 0; p < 4; p++) out.luma_dir[p] = best_dir[p];
+    out.chroma_dir = best_mode;
+    put_rec(rc, x, y, cu);
+    coder_out(coder, cuctx, out.after);
+  }
+  void recon_save(int lane, int slot, int x, int y, int size) { std::vector<int16_t>* s = stash[lane * 16 + slot]; cu_planes(rec, x, y, size, s); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { put_rec(stash[lane * 16 + slot], x, y, size); }
+  void commit(int, int x, int y, int size) {
+    std::vector<int16_t> b[3]; cu_planes(rec, x, y, size, b);
+    hop_o_ssref_commit_cu(ss[0].p00, ss[1].p00, ss[2].p00, W, H, x, y, size, &b[0][0], &b[1][0], &b[2][0]);
+  }
+  int W, H, bd;
+  std::vector<int16_t> org[3], pred[3], rec[3];
+  Plane ss[3];
+  std::map<int, std::vector<int16_t>[3]> stash;
+};
+
+}  // namespace
+
+extern "C" {
+
+// One frame through the spine on the CPU restatement.  y / cb / cr: the original (pitch w, w/2).  Outputs (any may be NULL): ctu_cost / ctu_bits / ctu_dist per CTU,
+// parts = the finished picture's per-4x4 data (sizeof(hopspine::Part) per unit, 256 per CTU, z-order), rec_* the reconstruction before the loop filters, entry = the coder
+// every CTU started from (sizeof(hopspine::Coder) each).  trace_path: one line per candidate that reaches xCheckBestMode.  Returns the number of such candidates.
+long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
+                          double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, void* entry) {
+  EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size);
+  CpuBackend be(w, h, 8, y, cb, cr);
+  Encoder enc(cfg, &be);
+  if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
+  enc.encode_frame(first_ctus);
+  if (enc.trace) fclose(enc.trace);
+  const int n = enc.n_ctu();
+  if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
+  if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
+  if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
+  if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
+  if (entry) memcpy(entry, &enc.ctu_entry[0], n * sizeof(Coder));
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
+  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
+  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
+  return (long)enc.n_candidates;
+}
+int hop_spine_sizeof_part(void) { return (int)sizeof(Part); }
+int hop_spine_sizeof_coder(void) { return (int)sizeof(Coder); }
+
+}

@@ -117,7 +117,7 @@ void hop_ctx_destroy(hop_ctx* c) {
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
                    c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits };
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (int k = 0; k < 8; k++) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
+  for (int k = 0; k < HOP_GRAPH_SLOTS; k++) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
     if (c->xstream[k]) (void)hipStreamDestroy(c->xstream[k]);
@@ -572,8 +572,9 @@ int hop_rqt_device_classes(hop_ctx* c, int n_classes, const int* n, const hop_rq
   if (!c || n_classes < 0 || (n_classes && (!n || !d_jobs || !cls || !d_results))) return hop_set_err(c, HOP_ERR_ARG, "hop_rqt_device_classes: bad argument");
   if (n_classes == 0) return HOP_OK;
   // classes are independent chains of small kernels: each runs on its own stream (with its own scratch and state buffers)
-  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-  for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+  const int n_fork = std::min(n_classes, HOP_MAX_LANES) - 1;            // only the lanes this call uses (see hop_inter_cu_device_classes)
+  if (n_fork > 0) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int k = 0; k < n_fork; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
   bool used[HOP_MAX_LANES - 1] = { false, false, false };
   int rc = HOP_OK;
   for (int i = 0; i < n_classes && rc == HOP_OK; i++) {
@@ -1216,7 +1217,7 @@ static int hop_graph_or_issue(hop_ctx* c, const char* what, const void* desc, si
   mix(&c->scratch, sizeof(void*)); mix(&c->scratch_bytes, sizeof(size_t)); mix(&c->rqt_buf, sizeof(void*)); mix(&c->rqt_bytes, sizeof(size_t));
   mix(c->xscratch, sizeof(c->xscratch)); mix(c->xscratch_bytes, sizeof(c->xscratch_bytes)); mix(c->xrqt_buf, sizeof(c->xrqt_buf)); mix(c->xrqt_bytes, sizeof(c->xrqt_bytes));
   int slot = -1;
-  for (int i = 0; i < 8; i++) if (c->graphs[i].seen && c->graphs[i].key == key) slot = i;
+  for (int i = 0; i < HOP_GRAPH_SLOTS; i++) if (c->graphs[i].seen && c->graphs[i].key == key) slot = i;
   if (slot >= 0 && c->graphs[slot].exec) {
     hipError_t e = hipGraphLaunch(c->graphs[slot].exec, c->stream);
     if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "%s: graph launch: %s", what, hipGetErrorString(e));
@@ -1224,8 +1225,11 @@ static int hop_graph_or_issue(hop_ctx* c, const char* what, const void* desc, si
     return HOP_OK;
   }
   if (slot < 0) {                                                     // first sighting: run it the ordinary way (buffers reach their sizes), remember the call
-    slot = c->graph_next; c->graph_next = (c->graph_next + 1) % 8;
-    if (c->graphs[slot].exec) { (void)hipGraphExecDestroy(c->graphs[slot].exec); c->graphs[slot].exec = nullptr; }
+    slot = c->graph_next; c->graph_next = (c->graph_next + 1) % HOP_GRAPH_SLOTS;
+    if (c->graphs[slot].exec) {                                         // the evicted graph may still be running: wait before it is destroyed
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipGraphExecDestroy(c->graphs[slot].exec); c->graphs[slot].exec = nullptr;
+    }
     c->graphs[slot].key = key; c->graphs[slot].seen = 1;
     return issue();
   }
@@ -1237,6 +1241,11 @@ static int hop_graph_or_issue(hop_ctx* c, const char* what, const void* desc, si
   if (rc != HOP_OK || e != hipSuccess || !g) {
     (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g);
     c->graphs[slot].seen = -1;
+    // the ordinary path may only be taken once no stream is capturing any more
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    bool capturing = hipStreamIsCapturing(c->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+    for (int k = 0; k < HOP_MAX_LANES - 1 && !capturing; k++) capturing = hipStreamIsCapturing(c->xstream[k], &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+    if (capturing) return hop_set_err(c, HOP_ERR_DEVICE, "%s: stream capture did not end", what);
     return issue();
   }
   hipGraphExec_t ex = nullptr;
@@ -1275,8 +1284,10 @@ int hop_inter_cu_device_classes(hop_ctx* c, int n_classes, const hop_inter_class
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_inter_cu_device_classes: hop_upload_orig has not been called");
   if (n_classes == 0) return HOP_OK;
   auto issue = [&]() -> int {
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+    // only the lanes this call uses take part (a forked lane that is never joined would leave a stream capture with an unjoined participant)
+    const int n_fork = std::min(n_classes, HOP_MAX_LANES) - 1;
+    if (n_fork > 0) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int k = 0; k < n_fork; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
     bool used[HOP_MAX_LANES - 1] = { false, false, false };
     int rc = HOP_OK;
     for (int i = 0; i < n_classes && rc == HOP_OK; i++) {
@@ -1302,8 +1313,9 @@ int hop_inter_cu_device_classes(hop_ctx* c, int n_classes, const hop_inter_class
 }
 
 static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
-  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-  for (int k = 0; k < HOP_MAX_LANES - 1; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
+  const int n_fork = std::min(n_classes, HOP_MAX_LANES) - 1;            // only the lanes this call uses (see hop_inter_cu_device_classes)
+  if (n_fork > 0) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int k = 0; k < n_fork; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
   bool used[HOP_MAX_LANES - 1] = { false, false, false };
   int rc = HOP_OK;
   for (int i = 0; i < n_classes && rc == HOP_OK; i++) {

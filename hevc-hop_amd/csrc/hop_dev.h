@@ -13,6 +13,7 @@
 // they hold the sentinel and are not part of the reference layout.
 #define HOP_GUARD_ROWS 64
 #define HOP_MAX_LANES 4
+#define HOP_GRAPH_SLOTS 256  // instantiated graphs of launch-bound chains kept per context
 
 struct hop_ctx {
   int pic_w, pic_h, bd_y, bd_c, device;
@@ -39,7 +40,9 @@ struct hop_ctx {
   uint16_t* rdoq_scans;              // device: the scan tables of the RDOQ kernel (hop_rdoq_build_scans)
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
   // instantiated graphs of launch-bound chains (hop_intra_cu_device_classes): key = hash of the call's descriptors and of every buffer the chain touches
-  struct { uint64_t key; int seen; hipGraphExec_t exec; } graphs[8]; int graph_next; long graph_replays;
+  struct { uint64_t key; int seen; hipGraphExec_t exec; } graphs[HOP_GRAPH_SLOTS]; int graph_next; long graph_replays;
+  // RD spine support (k_spine.hip): stash slots for reconstruction blocks (64 x 64 x 1.5 samples each), allocated on first use
+  int16_t* stash; int stash_slots;
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
   bool   prof_on;

@@ -1,0 +1,285 @@
+// k_spine.hip -- what the RD spine (host/hop_spine.cpp) needs on the device besides the candidate kernels, and the spine's product backend.
+//   hop_valid_pattern      TComRdCost::isValidPattern (TLibCommon/TComRdCost.cpp:430-443) on the resident SS reference, as TEncCu::xCheckRDCostMerge2Nx2N (:1319),
+//                          TEncSearch::xMergeEstimation (TEncSearch.cpp:3076) and xGetTemplateCost (:4447) call it
+//   hop_recon_stash        the swap of m_ppcRecoYuvBest / m_ppcRecoYuvTemp in TEncCu::xCheckBestMode (TEncCu.cpp:1572-1575) and xCopyYuv2Pic (:1623-1662): a candidate's
+//                          reconstruction put aside / brought back, block copies inside HBM
+//   hop_recon_put_device   TComYuv::copyToPicYuv of an intra candidate's pcRecoYuv (TEncCu.cpp:1476 and the picture copy of xCopyYuv2Pic)
+//   hop_ssref_commit_recon TEncCu::xCopyYuv2SSRef (:1677-1715) from the resident reconstruction picture
+//   hop_encode_frame       TEncSlice::compressSlice's CTU loop (TEncSlice.cpp:1000-1196) = the spine over these kernels
+// All byte moving: one 2-byte element per thread-iteration, rows contiguous.
+#include <string.h>
+#include <chrono>
+#include <vector>
+#include "hop_dev.h"
+#include "../host/hop_spine.h"
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hop_set_err((c), HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define STASH_SAMPLES 6144          // 64 x 64 luma + 2 x 32 x 32 chroma
+#define STASH_SLOTS 1024
+
+__global__ void k_valid_pattern(const int32_t* __restrict__ q, int n, const int16_t* __restrict__ y00, int stride, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* p = q + 6 * i;
+  const int16_t* lb = y00 + (ptrdiff_t)(p[1] + (p[5] >> 2) + p[3] + 4) * stride + (p[0] + (p[4] >> 2));
+  out[i] = (lb[0] != HOP_NOT_VALID && lb[p[2] + 4] != HOP_NOT_VALID) ? 1 : 0;
+}
+
+// grid (n, 3): block i of plane blockIdx.y between the reconstruction picture and its stash slot; rect4 = x, y, size, slot
+template <bool RESTORE>
+__global__ __launch_bounds__(256) void k_recon_stash(const int32_t* __restrict__ rect4, int16_t* __restrict__ ry, int16_t* __restrict__ rcb, int16_t* __restrict__ rcr, int pic_w,
+                                                     int16_t* __restrict__ stash) {
+  const int i = blockIdx.x, comp = blockIdx.y;
+  const int sh = comp ? 1 : 0, x = rect4[4 * i] >> sh, y = rect4[4 * i + 1] >> sh, s = rect4[4 * i + 2] >> sh, pitch = pic_w >> sh;
+  int16_t* pic = comp == 0 ? ry : comp == 1 ? rcb : rcr;
+  int16_t* st = stash + (size_t)rect4[4 * i + 3] * STASH_SAMPLES + (comp == 0 ? 0 : comp == 1 ? 4096 : 5120);
+  for (int k = threadIdx.x; k < s * s; k += blockDim.x) {
+    const int r = k / s, c = k - r * s;
+    if (RESTORE) pic[(size_t)(y + r) * pitch + x + c] = st[k]; else st[k] = pic[(size_t)(y + r) * pitch + x + c];
+  }
+}
+
+// grid (n, 3): the packed reconstruction of CU i (size^2 luma samples at i * size^2; size^2 / 2 chroma samples, Cb then Cr, at i * size^2 / 2) into the picture
+__global__ __launch_bounds__(256) void k_recon_put(const hop_rqt_job* __restrict__ jobs, const int16_t* __restrict__ reco_y, const int16_t* __restrict__ reco_c,
+                                                   int16_t* __restrict__ ry, int16_t* __restrict__ rcb, int16_t* __restrict__ rcr, int pic_w) {
+  const int i = blockIdx.x, comp = blockIdx.y;
+  const int S = 1 << jobs[i].log2_cu, sh = comp ? 1 : 0, x = jobs[i].x >> sh, y = jobs[i].y >> sh, s = S >> sh, pitch = pic_w >> sh;
+  const int16_t* src = comp == 0 ? reco_y + (size_t)i * S * S : reco_c + (size_t)i * (S * S / 2) + (comp == 2 ? s * s : 0);
+  int16_t* pic = comp == 0 ? ry : comp == 1 ? rcb : rcr;
+  for (int k = threadIdx.x; k < s * s; k += blockDim.x) { const int r = k / s, c = k - r * s; pic[(size_t)(y + r) * pitch + x + c] = src[k]; }
+}
+
+static int spine_stage(hop_ctx* c, size_t bytes, void** out) {      // a small staging area of its own (the host-array entries keep theirs)
+  return hop_scratch(c, bytes, out);
+}
+
+extern "C" {
+
+int hop_valid_pattern(hop_ctx* c, int n, const int32_t* xywh_mv, uint8_t* out) {
+  if (!c || n < 0 || (n && (!xywh_mv || !out))) return hop_set_err(c, HOP_ERR_ARG, "hop_valid_pattern: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {                                      // the two probes must stay inside the padded plane (+ guard rows)
+    const int32_t* p = xywh_mv + 6 * i;
+    const int px = p[0] + (p[4] >> 2), py = p[1] + (p[5] >> 2) + p[3] + 4;
+    if (px < -HOP_MARGIN_Y || px + p[2] + 4 >= c->pic_w + HOP_MARGIN_Y || py < -HOP_MARGIN_Y - HOP_GUARD_ROWS || py >= c->pic_h + HOP_MARGIN_Y + HOP_GUARD_ROWS)
+      return hop_set_err(c, HOP_ERR_ARG, "hop_valid_pattern: query %d leaves the padded picture", i);
+  }
+  void* st; int r = spine_stage(c, (size_t)n * 24 + 256 + n, &st); if (r) return r;
+  char* b = (char*)st; const size_t o = ((size_t)n * 24 + 255) & ~(size_t)255;
+  HIPCHK(c, hipMemcpyAsync(b, xywh_mv, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_valid_pattern, dim3((n + 63) / 64), dim3(64), 0, c->stream, (const int32_t*)b, n, c->ss00[0], c->stride_y, (uint8_t*)(b + o));
+  HIPCHK(c, hipMemcpyAsync(out, b + o, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+int hop_recon_stash(hop_ctx* c, int n, const int32_t* rect4, int restore) {
+  if (!c || n < 0 || (n && !rect4)) return hop_set_err(c, HOP_ERR_ARG, "hop_recon_stash: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const int x = rect4[4 * i], y = rect4[4 * i + 1], s = rect4[4 * i + 2], slot = rect4[4 * i + 3];
+    if ((s != 8 && s != 16 && s != 32 && s != 64) || x < 0 || y < 0 || (x % s) || (y % s) || x + s > c->pic_w || y + s > c->pic_h || slot < 0 || slot >= STASH_SLOTS)
+      return hop_set_err(c, HOP_ERR_ARG, "hop_recon_stash: block %d", i);
+  }
+  if (!c->stash) { HIPCHK(c, hipMalloc((void**)&c->stash, (size_t)STASH_SLOTS * STASH_SAMPLES * 2)); c->stash_slots = STASH_SLOTS; }
+  void* st; int r = spine_stage(c, (size_t)n * 16, &st); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(st, rect4, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  if (restore) hipLaunchKernelGGL(k_recon_stash<true>, dim3(n, 3), dim3(256), 0, c->stream, (const int32_t*)st, c->rec[0], c->rec[1], c->rec[2], c->pic_w, c->stash);
+  else hipLaunchKernelGGL(k_recon_stash<false>, dim3(n, 3), dim3(256), 0, c->stream, (const int32_t*)st, c->rec[0], c->rec[1], c->rec[2], c->pic_w, c->stash);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));                        // the staging area is the context's scratch: the next call may reuse it
+  return HOP_OK;
+}
+
+int hop_recon_put_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const int16_t* d_reco_y, const int16_t* d_reco_c) {
+  if (!c || n < 0 || (n && (!d_jobs || !d_reco_y || !d_reco_c))) return hop_set_err(c, HOP_ERR_ARG, "hop_recon_put_device: bad argument");
+  if (n == 0) return HOP_OK;
+  hipLaunchKernelGGL(k_recon_put, dim3(n, 3), dim3(256), 0, c->stream, d_jobs, d_reco_y, d_reco_c, c->rec[0], c->rec[1], c->rec[2], c->pic_w);
+  HIPCHK(c, hipGetLastError());
+  return HOP_OK;
+}
+
+int hop_ssref_commit_recon(hop_ctx* c, int n, const int32_t* rect4) {
+  if (!c || n < 0 || (n && !rect4)) return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_commit_recon: bad argument");
+  if (n == 0) return HOP_OK;
+  for (int i = 0; i < n; i++) {
+    const int x = rect4[4 * i], y = rect4[4 * i + 1], s = rect4[4 * i + 2];
+    if ((s != 8 && s != 16 && s != 32 && s != 64) || x < 0 || y < 0 || (x % s) || (y % s) || x + s > c->pic_w || y + s > c->pic_h) return hop_set_err(c, HOP_ERR_ARG, "hop_ssref_commit_recon: block %d", i);
+  }
+  void* st; int r = spine_stage(c, (size_t)n * 16, &st); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(st, rect4, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  r = hop_launch_ssref_commit(c, n, (const int32_t*)st, c->rec[0], c->rec[1], c->rec[2], 0); if (r) return r;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HOP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// the spine's product backend: every request goes to the kernels of this library; device-resident arenas, small transfers only
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+using namespace hopspine;
+
+struct Bail { int code; };
+// wall time and calls per kind of request of the last hop_encode_frame (hop_encode_stats): 0 me_search, 1 pred_inter, 2 distortion, 3 valid_pattern, 4 inter_cu with
+// residual, 5 inter_cu without, 6 intra_cu, 7 recon stash, 8 commit
+double g_stat_ms[16]; double g_stat_calls[16];
+struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int k) : k(k), t0(std::chrono::steady_clock::now()) {}
+              ~Tick() { g_stat_ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_stat_calls[k] += 1; } };
+#define BK(call) do { int r_ = (call); if (r_ != HOP_OK) throw Bail{ r_ }; } while (0)
+#define BH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hop_set_err(c, HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); throw Bail{ HOP_ERR_DEVICE }; } } while (0)
+
+class HipBackend : public Backend {
+ public:
+  enum { MAXN = 64 };
+  explicit HipBackend(hop_ctx* ctx) : c(ctx), arena(nullptr) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    o_jobs = take(MAXN * sizeof(hop_rqt_job)); o_syn = take(MAXN * sizeof(hop_cu_syntax)); o_isyn = take(MAXN * sizeof(hop_intra_cu_syntax)); o_isyn_out = take(MAXN * sizeof(hop_intra_cu_syntax));
+    o_opts = take(MAXN * sizeof(hop_intra_rqt_opt)); o_sjobs = take(MAXN * sizeof(hop_intra_search_job)); o_sres = take(MAXN * sizeof(hop_intra_search_result));
+    o_res = take(MAXN * sizeof(hop_rqt_result)); o_cres = take(MAXN * sizeof(hop_intra_chroma_result)); o_coef = take((size_t)MAXN * 6144 * 4);
+    o_reco_y = take((size_t)MAXN * 4096 * 2); o_reco_c = take((size_t)MAXN * 2048 * 2);
+    o_ctx_in = take(MAXN * sizeof(hop_cabac_ctx)); o_cu_in = take(MAXN * sizeof(hop_cabac_cu_ctx)); o_ctx_after = take(MAXN * sizeof(hop_cabac_ctx));
+    o_ctx_out = take(MAXN * sizeof(hop_cabac_ctx)); o_cu_out = take(MAXN * sizeof(hop_cabac_cu_ctx)); o_fin = take(MAXN * sizeof(hop_cu_final));
+    o_bits = take(MAXN * 4); o_skipped = take(MAXN * 4); o_cost = take(MAXN * 8); o_dist = take(MAXN * 4);
+    bytes = o;
+    if (hipMalloc((void**)&arena, bytes) != hipSuccess) { arena = nullptr; hop_set_err(c, HOP_ERR_DEVICE, "spine arena allocation failed"); }
+  }
+  ~HipBackend() { if (arena) (void)hipFree(arena); }
+  bool ok() const { return arena != nullptr; }
+
+  void begin_frame() { BK(hop_ssref_reset(c)); BK(hop_sync(c)); }
+  void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) { Tick t(0); BK(hop_me_search(c, n, jobs, res, HOP_STAGE_GT)); }
+  void pred_inter(int, int n, const hop_pred_job* jobs) { Tick t(1); BK(hop_pred_inter(c, n, jobs, nullptr, nullptr, nullptr)); }
+  void distortion(int, int n, const hop_dist_job* jobs, uint32_t* out) { Tick t(2); BK(hop_distortion(c, n, jobs, out)); }
+  void valid_pattern(int, int n, const int32_t* q, uint8_t* out) { Tick t(3); BK(hop_valid_pattern(c, n, q, out)); }
+  void recon_save(int lane, int slot, int x, int y, int size) { Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 0)); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 1)); }
+  void commit(int, int x, int y, int size) { Tick t(8); const int32_t r[4] = { x, y, size, 0 }; BK(hop_ssref_commit_recon(c, 1, r)); }
+
+  void inter_cu(int, const InterEval& e, const Coder& in, EvalResult& out) { const InterEval* pe = &e; const Coder* pi = &in; EvalResult* po = &out; inter_n(1, &pe, &pi, &po); }
+  void intra_cu(int, const IntraEval& e, const Coder& in, EvalResult& out) { const IntraEval* pe = &e; const Coder* pi = &in; EvalResult* po = &out; intra_n(1, &pe, &pi, &po); }
+
+  // n candidates of ONE class (CU size; with or without residual)
+  void inter_n(int n, const InterEval* const* e, const Coder* const* in, EvalResult* const* out) {
+    if (n > MAXN) throw Bail{ HOP_ERR_ARG };
+    Tick t(e[0]->skip_res ? 5 : 4);
+    hipStream_t s = c->stream;
+    std::vector<hop_rqt_job> jobs(n); std::vector<hop_cu_syntax> syn(n); std::vector<hop_cabac_ctx> cx(n); std::vector<hop_cabac_cu_ctx> cu(n);
+    for (int i = 0; i < n; i++) { jobs[i] = e[i]->job; jobs[i].ctx_index = i; syn[i] = e[i]->syn; cx[i] = in[i]->r; cu[i] = in[i]->c; }
+    BH(hipMemcpyAsync(arena + o_jobs, jobs.data(), n * sizeof(hop_rqt_job), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_syn, syn.data(), n * sizeof(hop_cu_syntax), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_ctx_in, cx.data(), n * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_cu_in, cu.data(), n * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, s));
+    std::vector<hop_cu_final> fin(n); std::vector<uint32_t> bits(n), skipped(n, 1); std::vector<hop_rqt_result> res;
+    if (e[0]->skip_res) {
+      BK(hop_inter_cu_skip_device(c, n, (const hop_rqt_job*)(arena + o_jobs), (const hop_cu_syntax*)(arena + o_syn), (const hop_cabac_ctx*)(arena + o_ctx_in),
+                                  (const hop_cabac_cu_ctx*)(arena + o_cu_in), (hop_cu_final*)(arena + o_fin), (uint32_t*)(arena + o_bits), (double*)(arena + o_cost),
+                                  (hop_cabac_ctx*)(arena + o_ctx_out), (hop_cabac_cu_ctx*)(arena + o_cu_out)));
+    } else {
+      hop_inter_class k; memset(&k, 0, sizeof(k));
+      k.n = n; k.cls = jobs[0]; k.cls.x = 0; k.cls.y = 0; k.cls.ctx_index = 0;
+      k.d_jobs = (const hop_rqt_job*)(arena + o_jobs); k.d_syntax = (const hop_cu_syntax*)(arena + o_syn); k.d_results = (hop_rqt_result*)(arena + o_res);
+      k.d_coef = (int32_t*)(arena + o_coef); k.d_ctx_after = (hop_cabac_ctx*)(arena + o_ctx_after); k.d_finals = (hop_cu_final*)(arena + o_fin);
+      k.d_bits = (uint32_t*)(arena + o_bits); k.d_skipped = (uint32_t*)(arena + o_skipped); k.d_cost = (double*)(arena + o_cost);
+      k.d_ctx_out = (hop_cabac_ctx*)(arena + o_ctx_out); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(arena + o_cu_out);
+      BK(hop_inter_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(arena + o_ctx_in), (const hop_cabac_cu_ctx*)(arena + o_cu_in)));
+      res.resize(n);
+      BH(hipMemcpyAsync(res.data(), arena + o_res, n * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, s));
+      BH(hipMemcpyAsync(skipped.data(), arena + o_skipped, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    BH(hipMemcpyAsync(fin.data(), arena + o_fin, n * sizeof(hop_cu_final), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(bits.data(), arena + o_bits, n * 4, hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(cx.data(), arena + o_ctx_out, n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(cu.data(), arena + o_cu_out, n * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, s));
+    BH(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++) {
+      EvalResult& o = *out[i];
+      o.bits = bits[i]; o.dist = fin[i].dist[0] + fin[i].dist[1] + fin[i].dist[2]; o.cost = 0; o.skipped = (int)skipped[i]; o.root_cbf = (int)fin[i].root_cbf;
+      if (e[0]->skip_res) { memset(o.tr_idx, 0, sizeof(o.tr_idx)); memset(o.cbf, 0, sizeof(o.cbf)); memset(o.tskip, 0, sizeof(o.tskip)); }
+      else { memcpy(o.tr_idx, res[i].tr_idx, 256); memcpy(o.cbf, res[i].cbf, 768); memcpy(o.tskip, res[i].tskip, 768); }
+      o.after = *in[i]; o.after.r = cx[i]; o.after.c = cu[i];
+    }
+  }
+  void intra_n(int n, const IntraEval* const* e, const Coder* const* in, EvalResult* const* out) {
+    if (n > MAXN) throw Bail{ HOP_ERR_ARG };
+    Tick t(6);
+    hipStream_t s = c->stream;
+    std::vector<hop_rqt_job> jobs(n); std::vector<hop_intra_cu_syntax> syn(n); std::vector<hop_intra_rqt_opt> opt(n); std::vector<hop_intra_search_job> sj(n);
+    std::vector<hop_cabac_ctx> cx(n); std::vector<hop_cabac_cu_ctx> cu(n);
+    for (int i = 0; i < n; i++) { jobs[i] = e[i]->job; jobs[i].ctx_index = i; syn[i] = e[i]->syn; opt[i] = e[i]->opt; sj[i] = e[i]->sjob; cx[i] = in[i]->r; cu[i] = in[i]->c; }
+    BH(hipMemcpyAsync(arena + o_jobs, jobs.data(), n * sizeof(hop_rqt_job), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_isyn, syn.data(), n * sizeof(hop_intra_cu_syntax), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_opts, opt.data(), n * sizeof(hop_intra_rqt_opt), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_sjobs, sj.data(), n * sizeof(hop_intra_search_job), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_ctx_in, cx.data(), n * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, s));
+    BH(hipMemcpyAsync(arena + o_cu_in, cu.data(), n * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, s));
+    hop_intra_class k; memset(&k, 0, sizeof(k));
+    k.n = n; k.part_nxn = e[0]->part_nxn; k.num_full_rd = e[0]->sjob.num_full_rd; k.cls = jobs[0]; k.cls.x = 0; k.cls.y = 0; k.cls.ctx_index = 0;
+    k.d_jobs = (const hop_rqt_job*)(arena + o_jobs); k.d_syntax = (const hop_intra_cu_syntax*)(arena + o_isyn); k.d_opts = (const hop_intra_rqt_opt*)(arena + o_opts);
+    k.d_sjobs = (const hop_intra_search_job*)(arena + o_sjobs); k.d_sresults = (hop_intra_search_result*)(arena + o_sres); k.d_results = (hop_rqt_result*)(arena + o_res);
+    k.d_cresults = (hop_intra_chroma_result*)(arena + o_cres); k.d_coef = (int32_t*)(arena + o_coef); k.d_reco_y = (int16_t*)(arena + o_reco_y); k.d_reco_c = (int16_t*)(arena + o_reco_c);
+    k.d_syntax_out = (hop_intra_cu_syntax*)(arena + o_isyn_out); k.d_dist = (uint32_t*)(arena + o_dist); k.d_bits = (uint32_t*)(arena + o_bits); k.d_cost = (double*)(arena + o_cost);
+    k.d_ctx_out = (hop_cabac_ctx*)(arena + o_ctx_out); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(arena + o_cu_out);
+    BK(hop_intra_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(arena + o_ctx_in), (const hop_cabac_cu_ctx*)(arena + o_cu_in)));
+    BK(hop_recon_put_device(c, n, k.d_jobs, k.d_reco_y, k.d_reco_c));
+    std::vector<hop_rqt_result> res(n); std::vector<hop_intra_search_result> sres(n); std::vector<hop_intra_chroma_result> cres(n); std::vector<uint32_t> bits(n), dist(n);
+    BH(hipMemcpyAsync(res.data(), arena + o_res, n * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(sres.data(), arena + o_sres, n * sizeof(hop_intra_search_result), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(cres.data(), arena + o_cres, n * sizeof(hop_intra_chroma_result), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(bits.data(), arena + o_bits, n * 4, hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(dist.data(), arena + o_dist, n * 4, hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(cx.data(), arena + o_ctx_out, n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(cu.data(), arena + o_cu_out, n * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, s));
+    BH(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++) {
+      EvalResult& o = *out[i];
+      o.bits = bits[i]; o.dist = dist[i]; o.cost = 0; o.skipped = 0; o.root_cbf = 1;
+      memcpy(o.tr_idx, res[i].tr_idx, 256); memcpy(o.cbf, res[i].cbf, 768); memcpy(o.tskip, res[i].tskip, 768);
+      for (int p = 0; p < 4; p++) o.luma_dir[p] = sres[i].best_dir[p];
+      o.chroma_dir = cres[i].best_mode;
+      o.after = *in[i]; o.after.r = cx[i]; o.after.c = cu[i];
+    }
+  }
+ private:
+  hop_ctx* c; char* arena; size_t bytes;
+  size_t o_jobs, o_syn, o_isyn, o_isyn_out, o_opts, o_sjobs, o_sres, o_res, o_cres, o_coef, o_reco_y, o_reco_c, o_ctx_in, o_cu_in, o_ctx_after, o_ctx_out, o_cu_out, o_fin, o_bits, o_skipped,
+         o_cost, o_dist;
+};
+
+}  // namespace
+
+extern "C" {
+
+int hop_sizeof_cu_part(void) { return (int)sizeof(hopspine::Part); }
+void hop_encode_stats(double ms[16], double calls[16]) { memcpy(ms, g_stat_ms, sizeof(g_stat_ms)); memcpy(calls, g_stat_calls, sizeof(g_stat_calls)); }
+
+// One picture through the RD spine on the device: the original must be resident (hop_upload_orig).  Afterwards the reconstruction picture (hop_recon_download) holds the
+// reconstruction before the loop filters and the SS reference equals it.  Outputs may be NULL.
+int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates) {
+  if (!c || !p) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_encode_frame: hop_upload_orig has not been called");
+  if (c->bd_y != 8 || c->bd_c != 8) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: the HOP configuration is 8-bit (the GT warp clips to 255)");
+  if (p->qp < 0 || p->qp > 51 || p->mi_size <= 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: qp / micro-image size");
+  hopspine::EncConfig cfg; hopspine::default_hop_config(cfg, c->pic_w, c->pic_h, p->qp, p->mi_size);
+  HipBackend be(c);
+  if (!be.ok()) return HOP_ERR_DEVICE;
+  memset(g_stat_ms, 0, sizeof(g_stat_ms)); memset(g_stat_calls, 0, sizeof(g_stat_calls));
+  hopspine::Encoder enc(cfg, &be);
+  FILE* tf = nullptr;
+  if (p->trace_path && p->trace_path[0]) { tf = fopen(p->trace_path, "w"); enc.trace = tf; }
+  int rc = HOP_OK;
+  try { enc.encode_frame(p->first_ctus); } catch (const Bail& b) { rc = b.code; }
+  if (tf) fclose(tf);
+  if (rc != HOP_OK) return rc;
+  const int n = enc.n_ctu();
+  if (ctu_cost) memcpy(ctu_cost, enc.ctu_cost.data(), n * sizeof(double));
+  if (ctu_bits) memcpy(ctu_bits, enc.ctu_bits.data(), n * 4);
+  if (ctu_dist) memcpy(ctu_dist, enc.ctu_dist.data(), n * 4);
+  if (parts) memcpy(parts, enc.pic.data(), enc.pic.size() * sizeof(hopspine::Part));
+  if (n_candidates) *n_candidates = enc.n_candidates;
+  return HOP_OK;
+}
+
+}  // extern "C"

@@ -94,6 +94,15 @@ PU_RESULT_DTYPE = np.dtype([("mv_int", "<i4", (2,)), ("sad", "<u4"), ("not_valid
                             ("half_final", "<i4", (2,)), ("qter_final", "<i4", (2,))])
 assert PU_JOB_DTYPE.itemsize == ctypes.sizeof(PuJob) and PU_RESULT_DTYPE.itemsize == ctypes.sizeof(PuResult)
 
+CU_PART_DTYPE = np.dtype([("depth", "u1"), ("pred_mode", "u1"), ("part_size", "u1"), ("skip", "u1"), ("merge_flag", "u1"), ("merge_idx", "u1"), ("gt_flag", "u1"), ("inter_dir", "u1"),
+                          ("ref_idx", "i1"), ("mvp_idx", "i1"), ("mvp_num", "i1"), ("luma_dir", "u1"), ("chroma_dir", "u1"), ("tr_idx", "u1"), ("cbf", "u1", 3), ("tskip", "u1", 3),
+                          ("mv", "<i2", 2), ("mvd", "<i2", 2), ("gt", "<i2", 8)])                           # hop_cu_part
+
+
+class EncParams(ctypes.Structure):       # hop_enc_params
+    _fields_ = [("qp", ctypes.c_int32), ("mi_size", ctypes.c_int32), ("first_ctus", ctypes.c_int32), ("reserved", ctypes.c_int32), ("trace_path", ctypes.c_char_p)]
+
+
 _I16P = ctypes.POINTER(ctypes.c_int16)
 
 
@@ -256,6 +265,24 @@ class Context:
         a = np.empty(shape, np.int16)
         self._chk(self.L.hop_recon_download(self.h, comp, a.ctypes.data), "hop_recon_download")
         return a
+
+    def encode_frame(self, qp=32, mi_size=16, first_ctus=0, trace_path=None):
+        """hop_encode_frame: the RD spine over the kernels for the resident original.  Returns per-CTU (cost, bits, dist), parts (n_ctu, 256) CU_PART_DTYPE, candidates."""
+        L = self.L
+        L.hop_encode_frame.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_void_p]
+        assert L.hop_sizeof_cu_part() == CU_PART_DTYPE.itemsize
+        n = ((self.W + 63) // 64) * ((self.H + 63) // 64)
+        cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32); parts = np.zeros((n, 256), CU_PART_DTYPE)
+        nc = ctypes.c_uint64(0)
+        p = EncParams(qp, mi_size, first_ctus, 0, trace_path.encode() if trace_path else None)
+        self._chk(L.hop_encode_frame(self.h, ctypes.byref(p), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data, parts.ctypes.data, ctypes.byref(nc)), "hop_encode_frame")
+        return cost, bits, dist, parts, int(nc.value)
+
+    def encode_stats(self):
+        ms, calls = (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        self.L.hop_encode_stats(ms, calls)
+        names = ("me_search", "pred_inter", "distortion", "valid_pattern", "inter_cu", "inter_cu_skip", "intra_cu", "recon_stash", "commit")
+        return {k: {"ms": ms[i], "calls": int(calls[i])} for i, k in enumerate(names)}
 
     def tu_roundtrip(self, jobs, want_levels=True):
         n = len(jobs)

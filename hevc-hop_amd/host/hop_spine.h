@@ -36,13 +36,7 @@ struct EncConfig {
 void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size);   // cfg/3DHencoder_intra_main.cfg
 void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
 
-// one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
-struct Part {
-  uint8_t depth, pred_mode, part_size, skip, merge_flag, merge_idx, gt_flag, inter_dir;
-  int8_t  ref_idx, mvp_idx, mvp_num; uint8_t luma_dir, chroma_dir, tr_idx;
-  uint8_t cbf[3], tskip[3];
-  int16_t mv[2], mvd[2], gt[8];
-};
+typedef hop_cu_part Part;          // one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
 
 struct CuData {                    // TComDataCU as the RD search uses it (one CU of the quadtree, or the whole CTU)
   int ctu_addr, ctu_x, ctu_y, abs_idx, depth, x, y, size, num_part;

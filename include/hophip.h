@@ -583,6 +583,39 @@ int hop_enumerate_ctu_jobs(int pic_w, int pic_h, int ctu_addr, int search_range,
  * HIP-event durations are exclusive. */
 int hop_set_lanes(hop_ctx* ctx, int lanes);
 
+/* ---- the RD spine: a whole picture through TEncCu::compressCU (row a0) ---- */
+/* One 4x4 unit of the finished picture: TComDataCU's per-partition arrays (TLibCommon/TComDataCU.h:96-170) as the spine keeps them.  pred_mode: 0 inter (SS / GT),
+ * 1 intra, 15 none (outside the picture); part_size: PartSize, 15 none; ref_idx: 0 or -1; cbf: one bit per transform depth. */
+typedef struct {
+  uint8_t depth, pred_mode, part_size, skip, merge_flag, merge_idx, gt_flag, inter_dir;
+  int8_t  ref_idx, mvp_idx, mvp_num; uint8_t luma_dir, chroma_dir, tr_idx;
+  uint8_t cbf[3], tskip[3];
+  int16_t mv[2], mvd[2], gt[8];
+} hop_cu_part;
+int hop_sizeof_cu_part(void);
+/* replaces: TComRdCost::isValidPattern (TLibCommon/TComRdCost.cpp:430-443) on the resident SS reference for n queries of 6 values: PU x, y, w, h, vector (quarter-pel, as
+ * the caller clipped it): out[i] = 1 if the two probe samples below the displaced block are not the sentinel. */
+int hop_valid_pattern(hop_ctx* ctx, int n, const int32_t* xywh_mv, uint8_t* out);
+/* replaces: the bookkeeping of m_ppcRecoYuvBest / Temp in TEncCu::xCheckBestMode (TLibEncoder/TEncCu.cpp:1572-1575) and xCopyYuv2Pic (:1623-1662): n blocks
+ * rect4 = {x, y, size, slot} of the reconstruction picture put aside into stash slots (restore = 0) or brought back (restore = 1); 1024 slots. */
+int hop_recon_stash(hop_ctx* ctx, int n, const int32_t* rect4, int restore);
+/* replaces: TComYuv::copyToPicYuv of an intra candidate's reconstruction (TEncCu.cpp:1476, :1640): the packed blocks hop_intra_cu_device_classes leaves in d_reco_y /
+ * d_reco_c into the reconstruction picture at the jobs' positions; asynchronous on the context stream. */
+int hop_recon_put_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const int16_t* d_reco_y, const int16_t* d_reco_c);
+/* replaces: TEncCu::xCopyYuv2SSRef (TEncCu.cpp:1677-1715) from the context's reconstruction picture: n blocks rect4 = {x, y, size, -}. */
+int hop_ssref_commit_recon(hop_ctx* ctx, int n, const int32_t* rect4);
+/* replaces: the CTU loop of TEncSlice::compressSlice (TLibEncoder/TEncSlice.cpp:1000-1196) with TEncCu::compressCU (TEncCu.cpp:246-264, xCompressCU :371-892) for one
+ * picture of the HOP configuration (cfg/3DHencoder_intra_main.cfg: ISS slice, SS +-128 full search with FEN, GT search, AMP, RDOQ, transform skip, contexts running on
+ * from CTU to CTU): every candidate is evaluated by this library's kernels, the decisions are taken by the host spine (host/hop_spine.cpp).  The original must be resident
+ * (hop_upload_orig).  ctu_cost / ctu_bits / ctu_dist: getTotalCost / Bits / Distortion of every CTU (what the reference appends to cost.csv, TEncSlice.cpp:183-191);
+ * parts: 256 hop_cu_part per CTU in z-order; afterwards hop_recon_download gives the reconstruction before the loop filters.  first_ctus > 0: stop after that many CTUs.
+ * trace_path (may be NULL): one text line per candidate that reaches xCheckBestMode. */
+typedef struct { int32_t qp, mi_size, first_ctus, reserved; const char* trace_path; } hop_enc_params;
+int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates);
+/* diagnostics of the last hop_encode_frame of this process: host wall time (ms) and number of requests per kind -- 0 ME chain, 1 predictor, 2 distortion, 3 validity
+ * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */
+void hop_encode_stats(double ms[16], double calls[16]);
+
 /* ---- profiling (bench.py roofline): HIP events around every kernel launch on the context stream ---- */
 #define HOP_K_SS_SEARCH 0
 #define HOP_K_FRAC      1

@@ -1,0 +1,42 @@
+"""GPU: hop_encode_frame -- the RD spine (row a0) over the HIP kernels, through the C ABI -- against the reference encoder's own decisions (tests/golden/encoder_spine.npz):
+every candidate that reaches xCheckBestMode, the per-CTU costs of cost.csv, the finished per-partition data, and the reconstruction against the spine over the CPU
+restatement (which the CPU suite pins to the same goldens)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from hoputil import ROOT
+from test_spine_cpu import FRAMES, check_against_golden, frame, key_of, run_cpu, spine_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _hp():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hophip", os.path.join(ROOT, "hevc-hop_amd", "hophip.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("W,H,seed,sharp", FRAMES)
+def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp):
+    hp = _hp()
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    Y, Cb, Cr = frame(W, H, seed, sharp)
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, Cb, Cr)
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        cost, bits, dist, parts, nc = ctx.encode_frame(32, 16, 0, tp)
+        text = open(tp, "rb").read()
+    check_against_golden(G, key_of(W, H, seed, sharp), cost, bits, dist, parts.view(np.dtype(parts.dtype.descr)), text)
+    # the reconstruction (before the loop filters) and the SS reference it was committed to
+    _, _, _, _, rec, _ = run_cpu(spine_cpu(), W, H, Y, Cb, Cr)
+    for c in range(3):
+        assert np.array_equal(ctx.recon_download(c), rec[c]), c
+    m = 80
+    assert np.array_equal(ctx.ssref_download(0)[m:m + H, m:m + W], rec[0])
+    print(key_of(W, H, seed, sharp), nc, "candidates", {k: (round(v["ms"], 1), v["calls"]) for k, v in ctx.encode_stats().items()})
+    ctx.close()

@@ -1,0 +1,82 @@
+"""CPU: the RD spine (hevc-hop_amd/host/hop_spine.cpp) -- host logic of the product -- instantiated over the CPU restatement (oracle/spine_backend_cpu.cpp)
+against the reference encoder's own decisions (tests/golden/encoder_spine.npz, made by oracle/make_golden19.py from the shim encoder whose bitstream equals the unmodified
+reference's; the per-CTU costs there are cost.csv of the unmodified encoder).  Compared: EVERY candidate that reaches TEncCu::xCheckBestMode in coding order (mode,
+partition, flags, bits, distortion, cost), the per-CTU totals, and the finished per-partition data (depth, mode, partition, skip / merge / GT flags, intra directions,
+transform depth, cbf, vectors).  Frames: lenslets of 1, 4, 6 CTUs, a 200x136 frame whose right and bottom CTUs cross the picture edge, and the sharp frame on which
+transform skip wins."""
+import ctypes
+import os
+import subprocess
+import tempfile
+import zlib
+
+import numpy as np
+import pytest
+
+from hoputil import ROOT, lenslet, sharp_frame
+
+PART_DT = np.dtype([("depth", "u1"), ("pred_mode", "u1"), ("part_size", "u1"), ("skip", "u1"), ("merge_flag", "u1"), ("merge_idx", "u1"), ("gt_flag", "u1"), ("inter_dir", "u1"),
+                    ("ref_idx", "i1"), ("mvp_idx", "i1"), ("mvp_num", "i1"), ("luma_dir", "u1"), ("chroma_dir", "u1"), ("tr_idx", "u1"), ("cbf", "u1", 3), ("tskip", "u1", 3),
+                    ("mv", "i2", 2), ("mvd", "i2", 2), ("gt", "i2", 8)])
+FRAMES = [(64, 64, 1234, False), (128, 128, 1234, False), (192, 128, 7, False), (200, 136, 5, False), (64, 64, 77, True)]
+
+
+def key_of(W, H, seed, sharp):
+    return "%dx%d_seed%d%s" % (W, H, seed, "_sharp" if sharp else "")
+
+
+def frame(W, H, seed, sharp):
+    return sharp_frame(W, H, seed) if sharp else lenslet(W, H, 16, seed)
+
+
+def check_against_golden(G, key, cost, bits, dist, parts, trace_text):
+    """cost / bits / dist per CTU, parts = (n_ctu, 256) PART_DT, trace_text = the candidate trace (bytes)"""
+    want = zlib.decompress(G[key + "/trace"].tobytes()).split(b"\n")
+    got = trace_text.split(b"\n")
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert a == b, "%s: candidate %d differs\n  reference: %s\n  here     : %s" % (key, i, a.decode(), b.decode())
+    assert len(want) == len(got), (key, len(want), len(got))
+    assert np.array_equal(G[key + "/cost"], cost) and np.array_equal(G[key + "/bits"], bits) and np.array_equal(G[key + "/dist"], dist), key
+    R = G[key + "/parts"]
+    for a in range(R.shape[0]):
+        r, q = R[a], parts[a]
+        used = r[:, 1] != 15                                        # partitions outside the picture stay MODE_NONE
+        for name, col in (("depth", 0), ("pred_mode", 1), ("part_size", 2), ("skip", 3), ("merge_flag", 4), ("merge_idx", 5), ("gt_flag", 6), ("tr_idx", 9)):
+            assert np.array_equal(q[name][used].astype(np.int16), r[used, col]), (key, a, name)
+        intra, inter = used & (r[:, 1] == 1), used & (r[:, 1] == 0)
+        assert np.array_equal(q["luma_dir"][intra].astype(np.int16), r[intra, 7]) and np.array_equal(q["chroma_dir"][intra].astype(np.int16), r[intra, 8]), (key, a)
+        assert np.array_equal(q["cbf"][used].astype(np.int16), r[used, 10:13]), (key, a)
+        assert np.array_equal(q["mv"][inter], r[inter, 13:15]) and np.array_equal(q["gt"][inter], r[inter, 15:23]), (key, a)
+
+
+def spine_cpu():
+    so = os.path.join(ROOT, "oracle", "libhop_spine_cpu.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhop_spine_cpu.so"], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(so)
+    L.hop_spine_cpu_encode.restype = ctypes.c_long
+    L.hop_spine_cpu_encode.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
+    assert L.hop_spine_sizeof_part() == PART_DT.itemsize
+    return L
+
+
+def run_cpu(L, W, H, Y, Cb, Cr, qp=32, mi=16, first=0):
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32)
+    parts = np.zeros((n, 256), PART_DT)
+    rec = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+    a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        L.hop_spine_cpu_encode(W, H, qp, mi, first, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, tp.encode(), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data,
+                               parts.ctypes.data, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, None)
+        text = open(tp, "rb").read()
+    return cost, bits, dist, parts, rec, text
+
+
+@pytest.mark.parametrize("W,H,seed,sharp", FRAMES)
+def test_spine_over_the_restatement_equals_the_reference_encoder(W, H, seed, sharp):
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    L = spine_cpu()
+    Y, Cb, Cr = frame(W, H, seed, sharp)
+    cost, bits, dist, parts, rec, text = run_cpu(L, W, H, Y, Cb, Cr)
+    check_against_golden(G, key_of(W, H, seed, sharp), cost, bits, dist, parts, text)

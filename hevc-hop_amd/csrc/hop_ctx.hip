@@ -229,7 +229,8 @@ static int check_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
                  j.pu_x + j.rng_left - j.w / 2 - 4 < -(c->stride_y - 8) || j.pu_x + j.rng_right + 2 * j.w + 8 > c->stride_y + c->pic_w - 8;
       for (int k = 0; k < j.n_amvp; k++) {   // AMVP start vectors of the GT search (TEncSearch.cpp:5144-5150)
         const int sx = (int)(int16_t)j.amvp[2 * k] >> 2, sy = (int)(int16_t)j.amvp[2 * k + 1] >> 2;
-        bad = bad || j.pu_y + sy - j.h / 2 < -lim || j.pu_y + sy + j.h + j.h / 2 > c->pic_h + lim || sx < -(c->stride_y - 160) || sx > c->stride_y - 160;
+        bad = bad || j.pu_y + sy - j.h / 2 < -lim || j.pu_y + sy + j.h + j.h / 2 > c->pic_h + lim ||
+              j.pu_x + sx - j.w / 2 - 4 < -(c->stride_y - 8) || j.pu_x + sx + 2 * j.w + 8 > c->stride_y + c->pic_w - 8;   // columns: within one pitch, as for the window (a neighbour's unclipped vector may point past the margin)
       }
       if (bad)
         return hop_set_err(c, HOP_ERR_ARG, "PU job %d: search range leaves the padded reference", i);

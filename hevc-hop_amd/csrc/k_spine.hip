@@ -15,7 +15,7 @@
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hop_set_err((c), HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 #define STASH_SAMPLES 6144          // 64 x 64 luma + 2 x 32 x 32 chroma
-#define STASH_SLOTS 1024
+#define STASH_SLOTS 2048
 
 __global__ void k_valid_pattern(const int32_t* __restrict__ q, int n, const int16_t* __restrict__ y00, int stride, uint8_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,9 +130,9 @@ struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int
 #define BK(call) do { int r_ = (call); if (r_ != HOP_OK) throw Bail{ r_ }; } while (0)
 #define BH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hop_set_err(c, HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); throw Bail{ HOP_ERR_DEVICE }; } } while (0)
 
-class HipBackend : public Backend {
+class HipBackend : public BatchInner {
  public:
-  enum { MAXN = 64 };
+  enum { MAXN = 64, MAXP = 1024 };
   explicit HipBackend(hop_ctx* ctx) : c(ctx), arena(nullptr) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
@@ -143,6 +143,7 @@ class HipBackend : public Backend {
     o_ctx_in = take(MAXN * sizeof(hop_cabac_ctx)); o_cu_in = take(MAXN * sizeof(hop_cabac_cu_ctx)); o_ctx_after = take(MAXN * sizeof(hop_cabac_ctx));
     o_ctx_out = take(MAXN * sizeof(hop_cabac_ctx)); o_cu_out = take(MAXN * sizeof(hop_cabac_cu_ctx)); o_fin = take(MAXN * sizeof(hop_cu_final));
     o_bits = take(MAXN * 4); o_skipped = take(MAXN * 4); o_cost = take(MAXN * 8); o_dist = take(MAXN * 4);
+    o_pjobs = take(MAXP * sizeof(hop_pred_job)); o_djobs = take(MAXP * sizeof(hop_dist_job)); o_pout = take(MAXP * 4);
     bytes = o;
     if (hipMalloc((void**)&arena, bytes) != hipSuccess) { arena = nullptr; hop_set_err(c, HOP_ERR_DEVICE, "spine arena allocation failed"); }
   }
@@ -158,6 +159,39 @@ class HipBackend : public Backend {
   void recon_restore(int lane, int slot, int x, int y, int size) { Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 1)); }
   void commit(int, int x, int y, int size) { Tick t(8); const int32_t r[4] = { x, y, size, 0 }; BK(hop_ssref_commit_recon(c, 1, r)); }
 
+  void pred_cost(int, int n, const hop_pred_job* jobs, int kind, uint32_t* out) { pred_cost_n(1, &n, jobs, &kind, out); }
+  // step k of every sequence in one predictor launch + one distortion launch; the steps in order; one synchronisation at the end
+  void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {
+    Tick t(1);
+    int total = 0, maxlen = 0; for (int s = 0; s < m; s++) { total += len[s]; if (len[s] > maxlen) maxlen = len[s]; }
+    if (total == 0) return;
+    if (total > MAXP) throw Bail{ HOP_ERR_ARG };
+    std::vector<hop_pred_job> pj(total); std::vector<hop_dist_job> dj(total); std::vector<int> src(total), first(maxlen + 1, 0);
+    int at = 0;
+    for (int k = 0; k < maxlen; k++) {
+      first[k] = at;
+      for (int s = 0, base = 0; s < m; base += len[s], s++) {
+        if (len[s] <= k) continue;
+        const hop_pred_job& j = jobs[base + k];
+        pj[at] = j; dj[at].x = j.pu_x; dj[at].y = j.pu_y; dj[at].w = j.w; dj[at].h = j.h; dj[at].comp = 0; dj[at].kind = kinds[s]; src[at] = base + k; at++;
+      }
+    }
+    first[maxlen] = at;
+    hipStream_t st = c->stream;
+    BH(hipMemcpyAsync(arena + o_pjobs, pj.data(), total * sizeof(hop_pred_job), hipMemcpyHostToDevice, st));
+    BH(hipMemcpyAsync(arena + o_djobs, dj.data(), total * sizeof(hop_dist_job), hipMemcpyHostToDevice, st));
+    for (int k = 0; k < maxlen; k++) {
+      const int nk = first[k + 1] - first[k];
+      BK(hop_pred_inter_device(c, nk, (const hop_pred_job*)(arena + o_pjobs) + first[k]));
+      BK(hop_distortion_device(c, nk, (const hop_dist_job*)(arena + o_djobs) + first[k], (uint32_t*)(arena + o_pout) + first[k]));
+    }
+    std::vector<uint32_t> o(total);
+    BH(hipMemcpyAsync(o.data(), arena + o_pout, total * 4, hipMemcpyDeviceToHost, st));
+    BH(hipStreamSynchronize(st));
+    for (int i = 0; i < total; i++) out[src[i]] = o[i];
+  }
+  void stash_n(int n, const int32_t* rect4, int restore) { Tick t(7); BK(hop_recon_stash(c, n, rect4, restore)); }
+  void commit_n(int n, const int32_t* rect4) { Tick t(8); BK(hop_ssref_commit_recon(c, n, rect4)); }
   void inter_cu(int, const InterEval& e, const Coder& in, EvalResult& out) { const InterEval* pe = &e; const Coder* pi = &in; EvalResult* po = &out; inter_n(1, &pe, &pi, &po); }
   void intra_cu(int, const IntraEval& e, const Coder& in, EvalResult& out) { const IntraEval* pe = &e; const Coder* pi = &in; EvalResult* po = &out; intra_n(1, &pe, &pi, &po); }
 
@@ -245,7 +279,7 @@ class HipBackend : public Backend {
  private:
   hop_ctx* c; char* arena; size_t bytes;
   size_t o_jobs, o_syn, o_isyn, o_isyn_out, o_opts, o_sjobs, o_sres, o_res, o_cres, o_coef, o_reco_y, o_reco_c, o_ctx_in, o_cu_in, o_ctx_after, o_ctx_out, o_cu_out, o_fin, o_bits, o_skipped,
-         o_cost, o_dist;
+         o_cost, o_dist, o_pjobs, o_djobs, o_pout;
 };
 
 }  // namespace
@@ -263,6 +297,8 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   if (c->bd_y != 8 || c->bd_c != 8) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: the HOP configuration is 8-bit (the GT warp clips to 255)");
   if (p->qp < 0 || p->qp > 51 || p->mi_size <= 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: qp / micro-image size");
   hopspine::EncConfig cfg; hopspine::default_hop_config(cfg, c->pic_w, c->pic_h, p->qp, p->mi_size);
+  cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
+  if (cfg.wpp && p->wavefront_lag <= 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
   memset(g_stat_ms, 0, sizeof(g_stat_ms)); memset(g_stat_calls, 0, sizeof(g_stat_calls));
@@ -270,7 +306,10 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   FILE* tf = nullptr;
   if (p->trace_path && p->trace_path[0]) { tf = fopen(p->trace_path, "w"); enc.trace = tf; }
   int rc = HOP_OK;
-  try { enc.encode_frame(p->first_ctus); } catch (const Bail& b) { rc = b.code; }
+  try {
+    if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(&be, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
+    else enc.encode_frame(p->first_ctus);
+  } catch (const Bail& b) { rc = b.code; } catch (...) { rc = c->err[0] ? HOP_ERR_DEVICE : HOP_ERR_STATE; }
   if (tf) fclose(tf);
   if (rc != HOP_OK) return rc;
   const int n = enc.n_ctu();

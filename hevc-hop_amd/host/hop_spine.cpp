@@ -14,6 +14,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace hopspine {
 
@@ -132,7 +135,8 @@ struct AmvpInfo { int n; int16_t cand[3][2]; };
 
 class CtuWorker {
  public:
-  CtuWorker(Encoder& e, int lane) : E(e), cfg(e.cfg_), be(e.be_), lane_(lane) { for (int d = 0; d < 4; d++) { best_[d] = &store_[d][0]; temp_[d] = &store_[d][1]; } }
+  uint64_t n_cand_ = 0;
+  CtuWorker(Encoder& e, int lane, Backend* backend = NULL) : E(e), cfg(e.cfg_), be(backend ? backend : e.be_), lane_(lane) { for (int d = 0; d < 4; d++) { best_[d] = &store_[d][0]; temp_[d] = &store_[d][1]; } }
   void compress_ctu(int addr, const Coder& entry, Coder& exit);
  private:
   Encoder& E; const EncConfig& cfg; Backend* be; int lane_;
@@ -188,6 +192,7 @@ class CtuWorker {
   void merge_candidates(const CuData& c, int pu, MergeCands& mc);
   bool mi_cand(const CuData& c, int which, int ux, int uy, int16_t mv[2]);
   uint32_t inter_pred_error(CuData& c, int pu);
+  void pu_pred_job(const CuData& c, int pu, hop_pred_job& j);
   void motion_comp_pu(CuData& c, int pu);
   void clip_mv(const CuData& c, int& h, int& v) const;
   bool valid_pattern(int px, int py, int w, int h, int mvx, int mvy);
@@ -211,16 +216,30 @@ void CtuWorker::clip_mv(const CuData& c, int& h, int& v) const {          // TCo
   h = std::min(hmax, std::max(hmin, h)); v = std::min(vmax, std::max(vmin, v));
 }
 
+// TComRdCost::isValidPattern (TLibCommon/TComRdCost.cpp:430-443) without touching the device: the two probes read the SS reference at linear addresses of the padded
+// plane; a sample there is the sentinel unless the picture sample it copies (itself, or for a margin sample the nearest picture sample, TComPicYuv::extendPicBorder)
+// belongs to a CU that has been committed -- reconstructed samples are clipped to >= 0 and never equal the sentinel.
 bool CtuWorker::valid_pattern(int px, int py, int w, int h, int mvx, int mvy) {
-  int32_t q[6] = { px, py, w, h, mvx, mvy }; uint8_t ok = 0;
-  be->valid_pattern(lane_, 1, q, &ok);
-  return ok != 0;
+  const int stride = cfg.pic_w + 160, W8 = cfg.pic_w >> 3;
+  auto probe = [&](long off) -> bool {                // off: linear offset from picture sample (0, 0)
+    long o = off + 80L * stride + 80;                 // from the first sample of the padded plane
+    if (o < 0) return false;                          // guard rows hold the sentinel
+    const long by = o / stride, bx = o % stride;
+    if (by >= cfg.pic_h + 160) return false;
+    int x = (int)bx - 80, y = (int)by - 80;
+    x = x < 0 ? 0 : x >= cfg.pic_w ? cfg.pic_w - 1 : x; y = y < 0 ? 0 : y >= cfg.pic_h ? cfg.pic_h - 1 : y;
+    return E.committed[(size_t)(y >> 3) * W8 + (x >> 3)] != 0;
+  };
+  const long lb = (long)(py + (mvy >> 2) + h + 4) * stride + (px + (mvx >> 2));
+  return probe(lb) && probe(lb + w + 4);
 }
 
 void CtuWorker::trace_candidate(const CuData& c) {
-  E.n_candidates++;
+  n_cand_++;
   if (!E.trace) return;
-  fprintf(E.trace, "%d %d %d %d %d %d %d %d %u %u %.17g\n", c.depth, c.x, c.y, CTU >> c.p[0].depth, c.p[0].pred_mode, c.p[0].part_size, c.p[0].skip, c.p[0].merge_flag, c.bits, c.dist, c.cost);
+  char ln[160];
+  snprintf(ln, sizeof(ln), "%d %d %d %d %d %d %d %d %u %u %.17g\n", c.depth, c.x, c.y, CTU >> c.p[0].depth, c.p[0].pred_mode, c.p[0].part_size, c.p[0].skip, c.p[0].merge_flag, c.bits, c.dist, c.cost);
+  E.ctu_trace[ctu_addr_] += ln;
 }
 
 // TEncCu::xCheckBestMode (:1557-1590): strict '<'; the winner's reconstruction is put aside, its coder becomes CI_NEXT_BEST
@@ -350,20 +369,21 @@ void CtuWorker::merge_candidates(const CuData& c, int pu, MergeCands& mc) {
 
 // TComPrediction::motionCompensation for one PU (TComPrediction.cpp:419-470 -> xPredInterUni :528-552): the vector clipped, GT iff the PU is not merged and has its flag
 void CtuWorker::motion_comp_pu(CuData& c, int pu) {
+  hop_pred_job j; pu_pred_job(c, pu, j);
+  be->pred_inter(lane_, 1, &j);
+}
+void CtuWorker::pu_pred_job(const CuData& c, int pu, hop_pred_job& j) {
   int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
   const Part& p = *part_at(c, c.x + ox, c.y + oy);
-  hop_pred_job j; memset(&j, 0, sizeof(j));
+  memset(&j, 0, sizeof(j));
   j.pu_x = c.x + ox; j.pu_y = c.y + oy; j.w = w; j.h = h;
   int mh = p.mv[0], mvv = p.mv[1]; clip_mv(c, mh, mvv);
   j.mv_x = mh; j.mv_y = mvv; j.use_gt = (!p.merge_flag && p.gt_flag) ? 1 : 0;
   for (int k = 0; k < 8; k++) j.gt[k] = p.gt[k];
-  be->pred_inter(lane_, 1, &j);
 }
 uint32_t CtuWorker::inter_pred_error(CuData& c, int pu) {                  // TEncSearch::xGetInterPredictionError (:2951-2977)
-  motion_comp_pu(c, pu);
-  int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
-  hop_dist_job d; d.x = c.x + ox; d.y = c.y + oy; d.w = w; d.h = h; d.comp = 0; d.kind = cfg.hadme ? HOP_DIST_HADS : HOP_DIST_SAD;
-  uint32_t e = 0; be->distortion(lane_, 1, &d, &e);
+  hop_pred_job j; pu_pred_job(c, pu, j);
+  uint32_t e = 0; be->pred_cost(lane_, 1, &j, cfg.hadme ? HOP_DIST_HADS : HOP_DIST_SAD, &e);
   return e;
 }
 
@@ -390,20 +410,24 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       // xEstimateMvPredAMVP (:4173-4262): the candidate with the smallest template cost
       AmvpInfo info; fill_mvp_cand(c, pu, info);
       int best_idx = 0; uint32_t best_cost = 0x7FFFFFFFu;
-      for (int i = 0; i < info.n; i++) {
-        uint32_t cost = 0x7FFFFFFFu;                                      // xGetTemplateCost (:4411-4477)
-        if (valid_pattern(px, py, w, h, info.cand[i][0], info.cand[i][1])) {
-          hop_pred_job j; memset(&j, 0, sizeof(j));
+      {
+        // xGetTemplateCost (:4411-4477) of every candidate: not valid -> MAX_INT; else luma prediction with the clipped vector (no GT), SAD, + the index bit
+        hop_pred_job tj[3]; int ti[3], nt = 0; uint32_t sad[3];
+        for (int i = 0; i < info.n; i++) {
+          if (!valid_pattern(px, py, w, h, info.cand[i][0], info.cand[i][1])) continue;
+          hop_pred_job& j = tj[nt]; memset(&j, 0, sizeof(j));
           j.pu_x = px; j.pu_y = py; j.w = w; j.h = h;
           int mh = info.cand[i][0], mvv = info.cand[i][1]; clip_mv(c, mh, mvv);
           j.mv_x = mh; j.mv_y = mvv; j.use_gt = 0;
-          be->pred_inter(lane_, 1, &j);
-          hop_dist_job d; d.x = px; d.y = py; d.w = w; d.h = h; d.comp = 0; d.kind = HOP_DIST_SAD;
-          uint32_t sad = 0; be->distortion(lane_, 1, &d, &sad);
-          const double rd = (double)sad + (double)((int)(1 * (double)lam + .5) >> 16);   // calcRdCost(m_auiMVPIdxCost = 1 bit, SAD, false, DF_SAD)
-          cost = (uint32_t)(double)(uint32_t)floor(rd);
+          ti[nt++] = i;
         }
-        if (best_cost > cost) { best_cost = cost; best_idx = i; }
+        if (nt) be->pred_cost(lane_, nt, tj, HOP_DIST_SAD, sad);
+        uint32_t cost[3] = { 0x7FFFFFFFu, 0x7FFFFFFFu, 0x7FFFFFFFu };
+        for (int k = 0; k < nt; k++) {
+          const double rd = (double)sad[k] + (double)((int)(1 * (double)lam + .5) >> 16);   // calcRdCost(m_auiMVPIdxCost = 1 bit, SAD, false, DF_SAD)
+          cost[ti[k]] = (uint32_t)(double)(uint32_t)floor(rd);
+        }
+        for (int i = 0; i < info.n; i++) if (best_cost > cost[i]) { best_cost = cost[i]; best_idx = i; }
       }
       int pred[2] = { info.cand[best_idx][0], info.cand[best_idx][1] };
       int mvp_idx = best_idx; const int mvp_num = info.n;
@@ -465,19 +489,26 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       // xMergeEstimation (:2992-3106)
       MergeCands mc; merge_candidates(c, pu, mc);
       uint32_t mrg_cost = MAX_UINT; int mrg_idx = 0; bool val_merge = false;
-      for (int k = 0; k < mc.n; k++) {
-        PuFields f = test_normal ? me : saved;                             // the GT fields and flag stay what the motion search left in the CU
-        f.mv[0] = mc.f[k].mv[0]; f.mv[1] = mc.f[k].mv[1]; f.ref = mc.f[k].ref;
-        set_parts(c, ox, oy, w, h, apply_pu_fields, &f);
-        if (f.ref == 0) {
-          int mh = f.mv[0], mvv = f.mv[1]; clip_mv(c, mh, mvv);
-          if (!valid_pattern(px, py, w, h, mh, mvv)) continue;
+      {
+        // every valid candidate's prediction error: the PU keeps the GT fields and flag the motion search left in the CU while its vector is replaced (:3057-3058)
+        const PuFields base = test_normal ? me : saved;
+        hop_pred_job mj[5]; int mi[5], nm = 0; uint32_t err[5];
+        for (int k = 0; k < mc.n; k++) {
+          int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(c, mh, mvv);
+          if (mc.f[k].ref == 0 && !valid_pattern(px, py, w, h, mh, mvv)) continue;
+          hop_pred_job& j = mj[nm]; memset(&j, 0, sizeof(j));
+          j.pu_x = px; j.pu_y = py; j.w = w; j.h = h; j.mv_x = mh; j.mv_y = mvv;
+          j.use_gt = (!base.merge_flag && base.gt_flag) ? 1 : 0; for (int q = 0; q < 8; q++) j.gt[q] = base.gt[q];
+          mi[nm++] = k;
         }
-        val_merge = true;
-        uint32_t cand = inter_pred_error(c, pu);
-        uint32_t cb = (uint32_t)k + 1; if (k == cfg.max_merge_cand - 1) cb--;
-        cand += (lam * cb) >> 16;
-        if (cand < mrg_cost) { mrg_cost = cand; mrg_idx = k; }
+        if (nm) be->pred_cost(lane_, nm, mj, cfg.hadme ? HOP_DIST_HADS : HOP_DIST_SAD, err);
+        for (int t = 0; t < nm; t++) {
+          const int k = mi[t];
+          val_merge = true;
+          uint32_t cb = (uint32_t)k + 1; if (k == cfg.max_merge_cand - 1) cb--;
+          const uint32_t cand = err[t] + ((lam * cb) >> 16);
+          if (cand < mrg_cost) { mrg_cost = cand; mrg_idx = k; }
+        }
       }
       if (!val_merge) { mrg_cost = MAX_UINT; if (!test_normal) return false; }
       if (mrg_cost < me_cost) {
@@ -752,6 +783,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   if (!boundary) {
     if (!split_is_best) be->recon_restore(lane_, d, x, y, size);           // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture
     be->commit(lane_, x, y, size);                                         // xCopyYuv2SSRef (:872-880)
+    for (int yy = y >> 3; yy < (y + size) >> 3; yy++) memset(&E.committed[(size_t)yy * (cfg.pic_w >> 3) + (x >> 3)], 1, size >> 3);
   }
 }
 
@@ -798,8 +830,8 @@ void CtuWorker::compress_ctu(int addr, const Coder& entry, Coder& exit) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 Encoder::Encoder(const EncConfig& cfg, Backend* be) : trace(NULL), n_candidates(0), cfg_(cfg), be_(be) {
   wctu_ = (cfg.pic_w + 63) / 64; hctu_ = (cfg.pic_h + 63) / 64;
-  ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0);
-  pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu());
+  ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0); ctu_trace.resize(n_ctu()); batch_rounds = batch_requests = 0;
+  pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu()); committed.assign((size_t)(cfg.pic_w >> 3) * (cfg.pic_h >> 3), 0);
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
 }
 
@@ -822,6 +854,7 @@ void intra_syntax_dirs(hop_intra_cu_syntax& syn, const hop_intra_search_job& sj,
 void Encoder::encode_frame(int first_ctus) {
   be_->begin_frame();
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
+  std::fill(committed.begin(), committed.end(), (uint8_t)0);
   Coder k; memset(&k, 0, sizeof(k));
   hop_cabac_init(&k.r, cfg_.slice_type, cfg_.qp); hop_cabac_cu_init(&k.c, cfg_.slice_type, cfg_.qp); hop_cabac_split_init(k.split, cfg_.slice_type, cfg_.qp);
   CtuWorker* w = new CtuWorker(*this, 0);
@@ -830,8 +863,172 @@ void Encoder::encode_frame(int first_ctus) {
     ctu_entry[a] = k;
     Coder next; w->compress_ctu(a, k, next);
     k = next;
+    if (trace) { fputs(ctu_trace[a].c_str(), trace); ctu_trace[a].clear(); }
   }
+  n_candidates += w->n_cand_;
   delete w;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wavefront: one thread per CTU row, requests of the rows in flight rendezvous and are served in batches
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; };
+enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTORE, RQ_COMMIT, RQ_PCOST };
+
+class Rendezvous : public Backend {
+ public:
+  Rendezvous(BatchInner* inner, int n_threads) : rounds(0), requests(0), inner_(inner), active_(n_threads), failed_(false) {}
+  // a row thread is about to block on another row's progress / has been released / has finished
+  std::mutex m; std::condition_variable cv;
+  void begin_frame() {}
+  void me_search(int lane, int n, const hop_pu_job* j, hop_pu_result* r) { Req q = { RQ_ME, lane, n, j, NULL, r, 0, 0, 0, 0, false }; submit(q); }
+  void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false }; submit(q); }
+  void distortion(int lane, int n, const hop_dist_job* j, uint32_t* o) { Req q = { RQ_DIST, lane, n, j, NULL, o, 0, 0, 0, 0, false }; submit(q); }
+  void valid_pattern(int lane, int n, const int32_t* v, uint8_t* o) { Req q = { RQ_VALID, lane, n, v, NULL, o, 0, 0, 0, 0, false }; submit(q); }
+  void pred_cost(int lane, int n, const hop_pred_job* j, int kind, uint32_t* o) { Req q = { RQ_PCOST, lane, n, j, NULL, o, kind, 0, 0, 0, false }; submit(q); }
+  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTER, lane, 1, &e, &in, &o, e.job.log2_cu, e.skip_res, 0, 0, false }; submit(q); }
+  void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTRA, lane, 1, &e, &in, &o, e.job.log2_cu, e.part_nxn, 0, 0, false }; submit(q); }
+  void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false }; submit(q); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false }; submit(q); }
+  void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false }; submit(q); }
+  // progress waits of the row threads go through the same lock so that "nobody can run" is detected exactly
+  template <class Pred> void wait_until(std::unique_lock<std::mutex>& lk, Pred p) {
+    if (p()) return;
+    idle(lk);
+    cv.wait(lk, [&] { return p() || failed_; });
+    active_++;
+  }
+  void thread_done(std::unique_lock<std::mutex>& lk) { idle(lk); }
+  bool failed() const { return failed_; }
+  uint64_t rounds, requests;
+ private:
+  BatchInner* inner_; int active_; bool failed_; std::vector<Req*> pending_;
+  void idle(std::unique_lock<std::mutex>& lk) {       // the caller stops running; if it was the last one, it serves what is pending first
+    active_--;
+    while (active_ == 0 && !pending_.empty()) serve(lk);
+  }
+  void submit(Req& q) {
+    std::unique_lock<std::mutex> lk(m);
+    if (failed_) throw 1;
+    pending_.push_back(&q);
+    active_--;
+    while (active_ == 0 && !pending_.empty() && !q.done) serve(lk);
+    cv.wait(lk, [&] { return q.done || failed_; });
+    if (failed_ && !q.done) throw 1;
+  }
+  void serve(std::unique_lock<std::mutex>&) {         // called with the lock held and every thread parked: one batch per kind / class
+    std::vector<Req*> v; v.swap(pending_);
+    rounds++; requests += v.size();
+    try {
+      std::vector<char> used(v.size(), 0);
+      for (size_t i = 0; i < v.size(); i++) {
+        if (used[i]) continue;
+        std::vector<Req*> g;
+        for (size_t k = i; k < v.size(); k++) {
+          if (used[k] || v[k]->kind != v[i]->kind) continue;
+          if ((v[i]->kind == RQ_INTER || v[i]->kind == RQ_INTRA) && (v[k]->i0 != v[i]->i0 || v[k]->i1 != v[i]->i1)) continue;
+          used[k] = 1; g.push_back(v[k]);
+        }
+        run_group(g);
+      }
+    } catch (...) { failed_ = true; }
+    for (size_t i = 0; i < v.size(); i++) v[i]->done = true;
+    active_ += (int)v.size();
+    cv.notify_all();
+  }
+  void run_group(std::vector<Req*>& g) {
+    const int kind = g[0]->kind;
+    if (kind == RQ_ME) {
+      std::vector<hop_pu_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pu_job*)r->a, (const hop_pu_job*)r->a + r->n);
+      std::vector<hop_pu_result> o(j.size());
+      inner_->me_search(0, (int)j.size(), j.data(), o.data());
+      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], sizeof(hop_pu_result) * r->n); at += r->n; }
+    } else if (kind == RQ_PRED) {
+      std::vector<hop_pred_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pred_job*)r->a, (const hop_pred_job*)r->a + r->n);
+      inner_->pred_inter(0, (int)j.size(), j.data());
+    } else if (kind == RQ_DIST) {
+      std::vector<hop_dist_job> j; for (Req* r : g) j.insert(j.end(), (const hop_dist_job*)r->a, (const hop_dist_job*)r->a + r->n);
+      std::vector<uint32_t> o(j.size());
+      inner_->distortion(0, (int)j.size(), j.data(), o.data());
+      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], 4 * r->n); at += r->n; }
+    } else if (kind == RQ_VALID) {
+      std::vector<int32_t> j; for (Req* r : g) j.insert(j.end(), (const int32_t*)r->a, (const int32_t*)r->a + 6 * r->n);
+      std::vector<uint8_t> o(j.size() / 6);
+      inner_->valid_pattern(0, (int)o.size(), j.data(), o.data());
+      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], r->n); at += r->n; }
+    } else if (kind == RQ_PCOST) {
+      std::vector<int> len, kinds; std::vector<hop_pred_job> j;
+      for (Req* r : g) { len.push_back(r->n); kinds.push_back(r->i0); j.insert(j.end(), (const hop_pred_job*)r->a, (const hop_pred_job*)r->a + r->n); }
+      std::vector<uint32_t> o(j.size());
+      inner_->pred_cost_n((int)g.size(), len.data(), j.data(), kinds.data(), o.data());
+      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], 4 * r->n); at += r->n; }
+    } else if (kind == RQ_INTER) {
+      std::vector<const InterEval*> e; std::vector<const Coder*> in; std::vector<EvalResult*> o;
+      for (Req* r : g) { e.push_back((const InterEval*)r->a); in.push_back((const Coder*)r->b); o.push_back((EvalResult*)r->out); }
+      inner_->inter_n((int)g.size(), e.data(), in.data(), o.data());
+    } else if (kind == RQ_INTRA) {
+      std::vector<const IntraEval*> e; std::vector<const Coder*> in; std::vector<EvalResult*> o;
+      for (Req* r : g) { e.push_back((const IntraEval*)r->a); in.push_back((const Coder*)r->b); o.push_back((EvalResult*)r->out); }
+      inner_->intra_n((int)g.size(), e.data(), in.data(), o.data());
+    } else {
+      std::vector<int32_t> rc; for (Req* r : g) { rc.push_back(r->i0); rc.push_back(r->i1); rc.push_back(r->i2); rc.push_back(r->i3); }
+      if (kind == RQ_COMMIT) inner_->commit_n((int)g.size(), rc.data()); else inner_->stash_n((int)g.size(), rc.data(), kind == RQ_RESTORE);
+    }
+  }
+};
+}  // namespace
+
+void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int max_rows) {
+  if (!cfg_.wpp) throw 1;
+  inner->begin_frame();
+  for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
+  std::fill(committed.begin(), committed.end(), (uint8_t)0);
+  Coder init; memset(&init, 0, sizeof(init));
+  hop_cabac_init(&init.r, cfg_.slice_type, cfg_.qp); hop_cabac_cu_init(&init.c, cfg_.slice_type, cfg_.qp); hop_cabac_split_init(init.split, cfg_.slice_type, cfg_.qp);
+  const int rows = hctu_, cols = wctu_;
+  if (max_rows <= 0 || max_rows > 120) max_rows = 120;                  // stash slots: 128 lanes x 16
+  Rendezvous rv(inner, rows);
+  std::vector<int> done(rows, 0);                                      // CTUs finished per row
+  std::vector<Coder> sync(rows);                                       // the coder after the second CTU of each row (WaveFrontSynchro)
+  std::vector<uint64_t> cand(rows, 0);
+  std::vector<std::thread> th;
+  for (int r = 0; r < rows; r++) {
+    th.emplace_back([&, r]() {
+      CtuWorker* w = new CtuWorker(*this, r % 128, &rv);
+      try {
+        Coder k = init;
+        for (int c = 0; c < cols; c++) {
+          {
+            std::unique_lock<std::mutex> lk(rv.m);
+            // row r - 1 far enough ahead (and not more rows in flight than lanes: row r - max_rows finished)
+            rv.wait_until(lk, [&] { return (r == 0 || done[r - 1] >= std::min(cols, c + lag)) && (r < max_rows || done[r - max_rows] >= cols); });
+            if (rv.failed()) break;
+            if (c == 0 && r > 0 && cols >= 2) { k = sync[r - 1]; coder_set_frac(k, 0); }   // loadContexts: the contexts of the row above after its second CTU, the row's own (fresh) bin coder
+          }
+          const int a = r * cols + c;
+          ctu_entry[a] = k;
+          Coder next; w->compress_ctu(a, k, next);
+          k = next;
+          std::unique_lock<std::mutex> lk(rv.m);
+          if (c == 1) sync[r] = k;
+          done[r] = c + 1;
+          rv.cv.notify_all();
+        }
+      } catch (...) {}
+      cand[r] = w->n_cand_;
+      delete w;
+      std::unique_lock<std::mutex> lk(rv.m);
+      done[r] = cols;                                                  // (also after a failure, so that nobody waits for this row)
+      rv.thread_done(lk);
+      rv.cv.notify_all();
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int r = 0; r < rows; r++) n_candidates += cand[r];
+  batch_rounds = rv.rounds; batch_requests = rv.requests;
+  if (trace) for (int a = 0; a < n_ctu(); a++) { fputs(ctu_trace[a].c_str(), trace); ctu_trace[a].clear(); }
+  if (rv.failed()) throw 1;
 }
 
 }  // namespace hopspine

@@ -6,6 +6,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <string>
 #include <vector>
 #include "../../include/hophip.h"
 
@@ -69,6 +70,15 @@ class Backend {
   virtual void pred_inter(int lane, int n, const hop_pred_job* jobs) = 0;                // into the prediction picture
   virtual void distortion(int lane, int n, const hop_dist_job* jobs, uint32_t* out) = 0; // original vs prediction picture
   virtual void valid_pattern(int lane, int n, const int32_t* xywh_mv /* 6 per item: x, y, w, h, mvx, mvy (quarter-pel) */, uint8_t* out) = 0;
+  // the jobs ONE AFTER THE OTHER: predict job i into the prediction picture, then its luma distortion `kind` (HOP_DIST_*) against the original over the job's
+  // rectangle into out[i]; afterwards the picture holds the last job's prediction (the candidates of one PU overwrite each other, as in the reference's m_tmpYuvPred)
+  virtual void pred_cost(int lane, int n, const hop_pred_job* jobs, int kind, uint32_t* out) {
+    for (int i = 0; i < n; i++) {
+      pred_inter(lane, 1, jobs + i);
+      hop_dist_job d; d.x = jobs[i].pu_x; d.y = jobs[i].pu_y; d.w = jobs[i].w; d.h = jobs[i].h; d.comp = 0; d.kind = kind;
+      distortion(lane, 1, &d, out + i);
+    }
+  }
   // candidate evaluation; afterwards the reconstruction picture holds the candidate's reconstruction in the CU's area
   virtual void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) = 0;
   virtual void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& out) = 0;
@@ -76,6 +86,22 @@ class Backend {
   virtual void recon_save(int lane, int slot, int x, int y, int size) = 0;
   virtual void recon_restore(int lane, int slot, int x, int y, int size) = 0;
   virtual void commit(int lane, int x, int y, int size) = 0;                             // reconstruction picture -> SS reference (xCopyYuv2SSRef)
+};
+
+// The n-forms a backend may offer so that requests of several CTUs in flight are served by one launch chain.  The defaults loop over the single forms.
+class BatchInner : public Backend {
+ public:
+  virtual void inter_n(int n, const InterEval* const* e, const Coder* const* in, EvalResult* const* out) { for (int i = 0; i < n; i++) inter_cu(0, *e[i], *in[i], *out[i]); }
+  virtual void intra_n(int n, const IntraEval* const* e, const Coder* const* in, EvalResult* const* out) { for (int i = 0; i < n; i++) intra_cu(0, *e[i], *in[i], *out[i]); }
+  virtual void stash_n(int n, const int32_t* rect4 /* x, y, size, lane * 16 + slot */, int restore) {
+    for (int i = 0; i < n; i++) { const int32_t* r = rect4 + 4 * i; if (restore) recon_restore(r[3] >> 4, r[3] & 15, r[0], r[1], r[2]); else recon_save(r[3] >> 4, r[3] & 15, r[0], r[1], r[2]); }
+  }
+  virtual void commit_n(int n, const int32_t* rect4) { for (int i = 0; i < n; i++) commit(0, rect4[4 * i], rect4[4 * i + 1], rect4[4 * i + 2]); }
+  // m sequences of pred_cost requests (different CTUs, so their rectangles are disjoint): step k of all sequences may run together, the steps in order.
+  // jobs / kinds / out: concatenated sequence after sequence, len[s] jobs each
+  virtual void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {
+    for (int s = 0, at = 0; s < m; at += len[s], s++) pred_cost(0, len[s], jobs + at, kinds[s], out + at);
+  }
 };
 
 // the luma directions of a finished intra search and their most probable modes (TComDataCU::getIntraDirLumaPredictor, TComDataCU.cpp:1772-1830) into the CU's
@@ -86,6 +112,11 @@ class Encoder {
  public:
   Encoder(const EncConfig& cfg, Backend* be);
   void encode_frame(int first_ctus = 0);             // the CTUs in raster order (all, or the first `first_ctus`)
+  // CTU rows as a wavefront: row r starts CTU c once row r - 1 has finished CTU c + lag - 1 (lag 5 covers the reach of the SS / GT search); one thread per
+  // row, their requests rendezvous and go to `inner` in batches.  With cfg.wpp the rows' coders are synchronised as WaveFrontSynchro does (TEncSlice.cpp:1027-1051,
+  // :1158-1161) and the result equals the reference run with one substream per row; without it the rows would need the coder of the previous row's END (raster order),
+  // which serialises them: wavefront mode requires cfg.wpp.
+  void encode_frame_wavefront(BatchInner* inner, int lag = 5, int max_rows_in_flight = 0);
   const EncConfig& config() const { return cfg_; }
   int n_ctu() const { return wctu_ * hctu_; }
   // results
@@ -93,8 +124,11 @@ class Encoder {
   std::vector<uint32_t> ctu_bits, ctu_dist;
   std::vector<Part>     pic;                         // 256 parts per CTU, z-order
   std::vector<Coder>    ctu_entry;                   // coder at the start of every CTU
-  FILE* trace;                                       // optional: one line per candidate that reaches xCheckBestMode
+  FILE* trace;                                       // optional: one line per candidate that reaches xCheckBestMode (written CTU by CTU in raster order)
   uint64_t n_candidates;
+  std::vector<std::string> ctu_trace;                // the lines of each CTU while the picture is in flight
+  std::vector<uint8_t>  committed;                   // per 8x8 block: its reconstruction is in the SS reference (what TComRdCost::isValidPattern's sentinel test sees)
+  uint64_t batch_rounds, batch_requests;             // wavefront mode: rendezvous rounds and requests served
  private:
   friend class CtuWorker;
   EncConfig cfg_; Backend* be_; int wctu_, hctu_;

@@ -610,7 +610,15 @@ int hop_ssref_commit_recon(hop_ctx* ctx, int n, const int32_t* rect4);
  * (hop_upload_orig).  ctu_cost / ctu_bits / ctu_dist: getTotalCost / Bits / Distortion of every CTU (what the reference appends to cost.csv, TEncSlice.cpp:183-191);
  * parts: 256 hop_cu_part per CTU in z-order; afterwards hop_recon_download gives the reconstruction before the loop filters.  first_ctus > 0: stop after that many CTUs.
  * trace_path (may be NULL): one text line per candidate that reaches xCheckBestMode. */
-typedef struct { int32_t qp, mi_size, first_ctus, reserved; const char* trace_path; } hop_enc_params;
+typedef struct {
+  int32_t qp, mi_size, first_ctus;
+  int32_t wpp;            /* 1: the rows' coders are synchronised as WaveFrontSynchro does (TEncSlice.cpp:1027-1051, :1158-1161): the result equals the reference run with
+                             --WaveFrontSynchro=1 --WaveFrontSubstreams=<CTU rows>; 0: the shipped configuration (contexts run on in raster order, CTUs strictly serial) */
+  int32_t wavefront_lag;  /* > 0 (implies wpp): the CTU rows run as a wavefront -- row r codes CTU c once row r - 1 has finished CTU c + lag - 1 -- and the candidate
+                             evaluations of all rows in flight are batched into common launches; 5 covers the reach of the SS / GT search, so the result equals lag = infinity */
+  int32_t reserved;
+  const char* trace_path;
+} hop_enc_params;
 int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates);
 /* diagnostics of the last hop_encode_frame of this process: host wall time (ms) and number of requests per kind -- 0 ME chain, 1 predictor, 2 distortion, 3 validity
  * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */

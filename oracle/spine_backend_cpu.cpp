@@ -18,7 +18,7 @@ namespace {
 
 struct Plane { int w, h, stride, margin; std::vector<int16_t> buf; int16_t* p00; };
 
-class CpuBackend : public Backend {
+class CpuBackend : public BatchInner {
  public:
   CpuBackend(int W, int H, int bd, const int16_t* y, const int16_t* cb, const int16_t* cr) : W(W), H(H), bd(bd) {
     for (int c = 0; c < 3; c++) {
@@ -37,6 +37,13 @@ class CpuBackend : public Backend {
   void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) {
     for (int i = 0; i < n; i++) {
       const hop_pu_job& j = jobs[i]; hop_pu_result& r = res[i];
+      if (getenv("HOP_SPINE_CHECK") && j.rng_right >= j.rng_left && j.rng_bottom >= j.rng_top) {   // the argument check of libhophip's hop_me_search, to see which jobs it would refuse
+        const int lim = 80 + 64 - 4, stride = W + 160;
+        bool bad = j.pu_y + j.rng_top - j.h / 2 - 4 < -lim || j.pu_y + j.rng_bottom + j.h + j.h / 2 + 8 > H + lim || j.pu_x + j.rng_left - j.w / 2 - 4 < -(stride - 8) || j.pu_x + j.rng_right + 2 * j.w + 8 > stride + W - 8;
+        for (int k = 0; k < j.n_amvp; k++) { const int sx = (int)(int16_t)j.amvp[2 * k] >> 2, sy = (int)(int16_t)j.amvp[2 * k + 1] >> 2;
+          bad = bad || j.pu_y + sy - j.h / 2 < -lim || j.pu_y + sy + j.h + j.h / 2 > H + lim || j.pu_x + sx - j.w / 2 - 4 < -(stride - 8) || j.pu_x + sx + 2 * j.w + 8 > stride + W - 8; }
+        if (bad) fprintf(stderr, "refused: pu %d %d %dx%d rng %d..%d %d..%d amvp %d %d %d %d pred %d %d\n", j.pu_x, j.pu_y, j.w, j.h, j.rng_left, j.rng_right, j.rng_top, j.rng_bottom, j.amvp[0], j.amvp[1], j.amvp[2], j.amvp[3], j.pred_x, j.pred_y);
+      }
       int64_t out[32]; memset(out, 0, sizeof(out));
       int amvp[4] = { j.amvp[0], j.amvp[1], j.amvp[2], j.amvp[3] };
       hop_o_me_pu(&org[0][(size_t)j.pu_y * W + j.pu_x], W, ss[0].p00, ss[0].stride, j.pu_x, j.pu_y, j.w, j.h, j.rng_left, j.rng_right, j.rng_top, j.rng_bottom, j.off_x, j.off_y,
@@ -201,6 +208,8 @@ extern "C" {
 // One frame through the spine on the CPU restatement.  y / cb / cr: the original (pitch w, w/2).  Outputs (any may be NULL): ctu_cost / ctu_bits / ctu_dist per CTU,
 // parts = the finished picture's per-4x4 data (sizeof(hopspine::Part) per unit, 256 per CTU, z-order), rec_* the reconstruction before the loop filters, entry = the coder
 // every CTU started from (sizeof(hopspine::Coder) each).  trace_path: one line per candidate that reaches xCheckBestMode.  Returns the number of such candidates.
+long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
+                              double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, double* rounds_requests);
 long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
                           double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, void* entry) {
   EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size);
@@ -218,6 +227,27 @@ long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, con
   if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
   if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
   if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
+  return (long)enc.n_candidates;
+}
+// the same with WaveFrontSynchro semantics (one substream per CTU row): lag 0 = the CTUs in raster order on one thread, lag > 0 = the rows as a wavefront of threads whose
+// requests are served in batches (what the product does on the GPU)
+long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
+                              double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, double* rounds_requests) {
+  EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1;
+  CpuBackend be(w, h, 8, y, cb, cr);
+  Encoder enc(cfg, &be);
+  if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
+  try { enc.encode_frame_wavefront(&be, lag > 0 ? lag : 1 << 20); } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
+  if (enc.trace) fclose(enc.trace);
+  const int n = enc.n_ctu();
+  if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
+  if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
+  if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
+  if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
+  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
+  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
+  if (rounds_requests) { rounds_requests[0] = (double)enc.batch_rounds; rounds_requests[1] = (double)enc.batch_requests; }
   return (long)enc.n_candidates;
 }
 int hop_spine_sizeof_part(void) { return (int)sizeof(Part); }

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from hoputil import ROOT
-from test_spine_cpu import FRAMES, check_against_golden, frame, key_of, run_cpu, spine_cpu
+from test_spine_cpu import FRAMES, FRAMES_WPP, check_against_golden, frame, key_of, run_cpu, run_cpu_wpp, spine_cpu
 
 pytestmark = pytest.mark.gpu
 
@@ -39,4 +39,24 @@ def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp):
     m = 80
     assert np.array_equal(ctx.ssref_download(0)[m:m + H, m:m + W], rec[0])
     print(key_of(W, H, seed, sharp), nc, "candidates", {k: (round(v["ms"], 1), v["calls"]) for k, v in ctx.encode_stats().items()})
+    ctx.close()
+
+
+@pytest.mark.parametrize("W,H,seed,lag", FRAMES_WPP)
+def test_encode_frame_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed, lag):
+    """wpp without / with the wavefront of rows (their candidate evaluations batched into common launches) against the reference run with one substream per CTU row"""
+    hp = _hp()
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    Y, Cb, Cr = frame(W, H, seed, False)
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, Cb, Cr)
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        cost, bits, dist, parts, nc = ctx.encode_frame(32, 16, 0, tp, wpp=1, wavefront_lag=lag)
+        text = open(tp, "rb").read()
+    check_against_golden(G, key_of(W, H, seed, False) + "_wpp", cost, bits, dist, parts.view(np.dtype(parts.dtype.descr)), text)
+    _, _, _, _, rec, _, _ = run_cpu_wpp(spine_cpu(), W, H, Y, Cb, Cr, 0)
+    for c in range(3):
+        assert np.array_equal(ctx.recon_download(c), rec[c]), c
+    print(key_of(W, H, seed, False), "wpp lag", lag, nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
     ctx.close()

@@ -19,6 +19,7 @@ PART_DT = np.dtype([("depth", "u1"), ("pred_mode", "u1"), ("part_size", "u1"), (
                     ("ref_idx", "i1"), ("mvp_idx", "i1"), ("mvp_num", "i1"), ("luma_dir", "u1"), ("chroma_dir", "u1"), ("tr_idx", "u1"), ("cbf", "u1", 3), ("tskip", "u1", 3),
                     ("mv", "i2", 2), ("mvd", "i2", 2), ("gt", "i2", 8)])
 FRAMES = [(64, 64, 1234, False), (128, 128, 1234, False), (192, 128, 7, False), (200, 136, 5, False), (64, 64, 77, True)]
+FRAMES_WPP = [(192, 128, 7, 0), (448, 192, 3, 5)]     # W, H, seed, wavefront lag (0: the CTUs one after the other): against the reference run with WaveFrontSynchro
 
 
 def key_of(W, H, seed, sharp):
@@ -47,6 +48,24 @@ def check_against_golden(G, key, cost, bits, dist, parts, trace_text):
         assert np.array_equal(q["luma_dir"][intra].astype(np.int16), r[intra, 7]) and np.array_equal(q["chroma_dir"][intra].astype(np.int16), r[intra, 8]), (key, a)
         assert np.array_equal(q["cbf"][used].astype(np.int16), r[used, 10:13]), (key, a)
         assert np.array_equal(q["mv"][inter], r[inter, 13:15]) and np.array_equal(q["gt"][inter], r[inter, 15:23]), (key, a)
+
+
+def run_cpu_wpp(L, W, H, Y, Cb, Cr, lag, qp=32, mi=16):
+    L.hop_spine_cpu_encode_wpp.restype = ctypes.c_long
+    L.hop_spine_cpu_encode_wpp.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32)
+    parts = np.zeros((n, 256), PART_DT)
+    rec = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+    a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
+    rr = np.zeros(2, np.float64)
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        nc = L.hop_spine_cpu_encode_wpp(W, H, qp, mi, lag, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, tp.encode(), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data,
+                                        parts.ctypes.data, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, rr.ctypes.data)
+        assert nc > 0
+        text = open(tp, "rb").read()
+    return cost, bits, dist, parts, rec, text, rr
 
 
 def spine_cpu():
@@ -80,3 +99,15 @@ def test_spine_over_the_restatement_equals_the_reference_encoder(W, H, seed, sha
     Y, Cb, Cr = frame(W, H, seed, sharp)
     cost, bits, dist, parts, rec, text = run_cpu(L, W, H, Y, Cb, Cr)
     check_against_golden(G, key_of(W, H, seed, sharp), cost, bits, dist, parts, text)
+
+
+@pytest.mark.parametrize("W,H,seed,lag", FRAMES_WPP)
+def test_spine_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed, lag):
+    """cfg.wpp: every CTU row starts from the coder of the row above after its second CTU.  lag 5: one thread per row, the rows' requests served in batches (the product's
+    multi-CTU mode); a lag of 5 CTUs covers the reach of the SS / GT search, so the result is the serial one."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    L = spine_cpu()
+    Y, Cb, Cr = frame(W, H, seed, False)
+    cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+    check_against_golden(G, key_of(W, H, seed, False) + "_wpp", cost, bits, dist, parts, text)
+    if lag: assert rr[1] > rr[0]                                    # some rounds served more than one row

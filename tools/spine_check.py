@@ -8,19 +8,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from hoputil import lenslet, sharp_frame
 
-def run_reference(W, H, seed, sharp, td, qp=32, mi=16):
+def run_reference(W, H, seed, sharp, td, qp=32, mi=16, wpp=False):
     Y, Cb, Cr = sharp_frame(W, H, seed) if sharp else lenslet(W, H, 16, seed)
     with open(os.path.join(td, "in.yuv"), "wb") as f:
         f.write(Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes())
     env = dict(os.environ, HOP_SHIM_TRACE_BEST=os.path.join(td, "best.txt"), HOP_SHIM_TRACE_CTU=os.path.join(td, "ctu.bin"))
     t0 = time.time()
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "TAppEncoderShim"), "-c", "/root/reference/cfg/3DHencoder_intra_main.cfg", "-i", "in.yuv", "-wdt", str(W), "-hgt", str(H),
-                        "-fr", "30", "-f", "1", "-q", str(qp), "--MIsize=%d" % mi, "-b", "s.bin", "-o", "rec.yuv"], cwd=td, capture_output=True, text=True, env=env)
+                        "-fr", "30", "-f", "1", "-q", str(qp), "--MIsize=%d" % mi, "-b", "s.bin", "-o", "rec.yuv"] +
+                       (["--WaveFrontSynchro=1", "--WaveFrontSubstreams=%d" % ((H + 63) // 64)] if wpp else []), cwd=td, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return Y, Cb, Cr, time.time() - t0
 
-def run_spine(W, H, Y, Cb, Cr, trace, qp=32, mi=16, first=0):
+def run_spine(W, H, Y, Cb, Cr, trace, qp=32, mi=16, first=0, wpp_lag=None):
     L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libhop_spine_cpu.so"))
+    L.hop_spine_cpu_encode_wpp.restype = ctypes.c_long
+    L.hop_spine_cpu_encode_wpp.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
     L.hop_spine_cpu_encode.restype = ctypes.c_long
     L.hop_spine_cpu_encode.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
     n = ((W + 63) // 64) * ((H + 63) // 64)
@@ -30,6 +33,12 @@ def run_spine(W, H, Y, Cb, Cr, trace, qp=32, mi=16, first=0):
     rec = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
     a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
     t0 = time.time()
+    if wpp_lag is not None:
+        rr = np.zeros(2, np.float64)
+        nc = L.hop_spine_cpu_encode_wpp(W, H, qp, mi, wpp_lag, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, trace.encode(), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data,
+                                        parts.ctypes.data, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, rr.ctypes.data)
+        print("wavefront lag", wpp_lag, "rounds", int(rr[0]), "requests", int(rr[1]))
+        return nc, cost, bits, dist, parts, rec, time.time() - t0
     nc = L.hop_spine_cpu_encode(W, H, qp, mi, first, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, trace.encode(), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data,
                                 parts.ctypes.data, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, None)
     return nc, cost, bits, dist, parts, rec, time.time() - t0
@@ -45,13 +54,14 @@ def read_ctu_trace(path):
 def main():
     W, H, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     sharp = "--sharp" in sys.argv
+    wpp = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--wpp=")]      # --wpp=LAG: the reference with WaveFrontSynchro, the spine as a wavefront (0: serial)
     with tempfile.TemporaryDirectory() as td:
-        Y, Cb, Cr, tr = run_reference(W, H, seed, sharp, td)
+        Y, Cb, Cr, tr = run_reference(W, H, seed, sharp, td, wpp=bool(wpp))
         ref_lines = open(os.path.join(td, "best.txt")).read().split("\n")
         ctu = read_ctu_trace(os.path.join(td, "ctu.bin"))
         refrec = np.fromfile(os.path.join(td, "rec.yuv"), np.uint8)
         mine = os.path.join(td, "mine.txt")
-        nc, cost, bits, dist, parts, rec, ts = run_spine(W, H, Y, Cb, Cr, mine)
+        nc, cost, bits, dist, parts, rec, ts = run_spine(W, H, Y, Cb, Cr, mine, wpp_lag=wpp[0] if wpp else None)
         my_lines = open(mine).read().split("\n")
     print("reference %.1f s, %d candidates; spine %.1f s, %d candidates" % (tr, len(ref_lines) - 1, ts, nc))
     for i, (a, b) in enumerate(zip(ref_lines, my_lines)):

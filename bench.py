@@ -1,25 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- CTUs/sec of the HEVC-HOP hot path on MI355X (one JSON line, see the driver contract).
+"""bench.py -- CTUs/sec of the HEVC-HOP all-intra RD search on MI355X (one JSON line, see the driver contract).
 
-Workload (config.workload): one synthetic 7728x5368 8-bit lenslet frame (pitch 15), QP32 lambda, HOP on.
-One "step" = one pass of the hot path over every CTU of the frame (10 164 CTUs):
-  * the ME chain of TEncSearch::xMotionEstimation -- SS integer full search (+-128, FEN), half/quarter-pel
-    refinement (HAD), GT/HOP 4-corner diamond search (HAD) -- for the full RD-tree PU set of every CTU
-    (CU 64..8 x {2Nx2N, Nx2N, 2NxN} = 425 PUs per interior CTU, TEncCu::xCompressCU's symmetric test order),
-  * the final GT predictor (luma + chroma) of every 2Nx2N PU, depth by depth,
-  * the residual-quadtree leaf of that prediction's residual (TEncSearch::xEstimateResidualQT at the largest transform
-    size): DCT, estBit, RDOQ, CABAC-counted bits, dequantiser + inverse DCT, SSE and the cbf-zero decision of every
-    Y/Cb/Cr transform unit (2.6 M TUs per frame), from the slice's initial ISS context snapshot,
-  * the 35-mode intra rough search of every CU (+ the 4x4 blocks of NxN at maximum depth),
-  * the SS-reference commit (copy + border halo) of every CU of the frame.
-The SS reference is a resident, fully reconstructed picture ("frozen reference"): all CTUs are independent, so
-this measures the device-side hot path; the reference's host spine (the mode decision between the candidates
-and the context evolution it drives) is not part of it and is documented as not built yet in DESIGN.md.  Inputs (pictures, PU job lists) are
-resident in HBM before the timed region starts.
+DEFAULT (the metric of BASELINE.json, dependency-honest): one "step" = hop_encode_frame over the workload picture = the whole RD search of
+TEncSlice::compressSlice (TLibEncoder/TEncSlice.cpp:1000-1196): for every CTU every candidate TEncCu::xCompressCU tests -- merge / skip, SS + GT search
+for 2Nx2N, Nx2N, 2NxN and the AMP shapes with AMVP, merge and micro-image candidates, intra 2Nx2N / NxN with the 35-mode search and the transform tree,
+each with its residual quadtree, RDOQ and CABAC-counted bits -- the decision between them, the recursion over CU sizes, the SS reference growing from the
+sentinel CU by CU and the coder contexts carried from CU to CU.  The candidates are evaluated by the HIP kernels of libhophip, the decisions taken by the
+host spine (hevc-hop_amd/host/hop_spine.cpp); the CTU rows run as a lag-5 wavefront whose requests are served in batches.  Decisions, per-CTU RD costs
+(cost.csv) and reconstruction equal the reference encoder's (tests/test_gpu_spine.py against tests/golden/encoder_spine.npz).
+Workload picture: the full-width top band (--rows CTU rows, default 8 = 7728x512, the band BASELINE.md's CPU plan encodes) of the synthetic 7728x5368
+lenslet frame, coded as a picture; the whole frame (--rows 84) takes about ten times as long per step and keeps more rows in flight.
+Multi-GPU (--gpus N, launched by torch.distributed.run): every rank codes its own band of the frame as an independent picture (no data-path collective;
+"scaling": "weak").  An exchange of reconstructed borders between GPUs inside ONE picture is not built: the lag-5 wavefront of one picture keeps at most 24
+CTU rows in flight, which one GPU serves.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): the frame's CTU rows are dealt round-robin to the
-ranks (the frozen SS reference is replicated), no data-path collective; value = 10 164 CTUs x steps / max-rank
-time -> "scaling": "strong".
+--kernels: round 1's kernel-throughput mode (search kernels over a frozen, fully reconstructed SS reference: all CTUs independent).  It measures the
+kernels, not the encode; its JSON says so.
 """
 import argparse
 import ctypes
@@ -111,17 +107,7 @@ def gt_iters(w, h):
     return it
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=FRAME_W)     # smaller frames only for rehearsal; the JSON names them
-    ap.add_argument("--height", type=int, default=FRAME_H)
-    ap.add_argument("--cpu-ctus", type=int, default=10, help="CTUs of the bounded cpu_baseline sample")
-    ap.add_argument("--rqt", action="store_true", help="run the whole residual-quadtree search (hop_rqt_device, row a8b) of every 2Nx2N CU instead of its leaf step "
-                    "at the largest transform size; the JSON's config.workload says which")
-    args = ap.parse_args()
+def kernels_main(args):
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
@@ -386,7 +372,7 @@ def main():
         sad_ops = float(np.sum(win.astype(np.float64) * jobs["w"] * jobs["h"] / np.where(jobs["h"] > 8, 2, 1) / 2.0))   # v_sad_u16 lane-ops
         ss_tops = sad_ops * prof_steps / (prof["k_ss_search"]["total_ms"] * 1e-3) / 1e12 if prof["k_ss_search"]["total_ms"] else 0.0
         out = {
-            "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (hot-path kernels, frozen SS reference)",
+            "metric": "kernel throughput only (NOT the encode metric): CTUs/sec of the search kernels over a frozen, fully reconstructed SS reference, 7728x5368 lenslet @QP32",
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i16+f64", "data": "synthetic",
@@ -461,6 +447,167 @@ def cpu_baseline(hp, ctx, jobs, ctu_of_job, is2n, res_gpu, Y, W, H, wctu, lc, n_
     return {"value": len(sample) / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
             "sample": "%d interior CTUs (row %d) of the same frame, %d PU jobs: oracle hop_o_me_pu (+ hop_o_pred_inter on 2Nx2N) single thread, %.1f s" % (len(sample), r0, len(sel), dt),
             "gpu_vs_oracle_mismatches": int(mism)}
+
+
+def band_of_rank(frame_h, rows, rank):
+    """The independent pictures of the multi-GPU mode: the frame is cut into bands of `rows` CTU rows and rank k codes band k (mod the number of bands) as its picture.
+    Returns (band index, first luma row, band height)."""
+    hb = rows * 64
+    nb = max(1, frame_h // hb)
+    b = rank % nb
+    return b, b * hb, hb
+
+
+def encode_main(args):
+    """The default: BASELINE.json's metric, dependency-honest.  One step = hop_encode_frame over the workload picture: the RD search of TEncSlice::compressSlice --
+    every candidate of TEncCu::xCompressCU for every CTU, SS reference starting at the sentinel and growing CU by CU, coder contexts carried from CU to CU -- with the
+    CTU rows as a lag-5 wavefront (WaveFrontSynchro semantics: the result equals the reference run with one substream per CTU row, tests/test_gpu_spine.py)."""
+    import torch
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: for N > 1 launch it as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (one process per GPU)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libhophip has no CPU path")
+    ndev = torch.cuda.device_count()
+    shared = world > ndev
+    local = local % ndev
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo" if shared else "nccl", **({} if shared else {"device_id": dev}))
+    hp = _hophip()
+    W = args.width
+    rows = args.rows
+    Hb = rows * 64
+    # the whole synthetic frame is generated once; rank k takes the band of `rows` CTU rows number k as ITS picture (independent pictures: the split that shards
+    # naturally, SURVEY 8(e); at N = 1 this is the top band BASELINE.md's CPU plan encodes)
+    Yf, Cbf, Crf = lenslet_torch(W, min(args.height, FRAME_H), PITCH, 2, dev)
+    b, y0, _ = band_of_rank(int(Yf.shape[0]), rows, rank)
+    Y = Yf[y0:y0 + Hb].cpu().numpy(); Cb = Cbf[y0 // 2:(y0 + Hb) // 2].cpu().numpy(); Cr = Crf[y0 // 2:(y0 + Hb) // 2].cpu().numpy()
+    del Yf, Cbf, Crf
+    ctx = hp.Context(W, Hb, device=local)
+    ctx.upload_orig(Y, Cb, Cr)
+    wctu = (W + 63) // 64
+    n_ctu = wctu * rows
+
+    def barrier():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+
+    def step():
+        return ctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
+
+    for _ in range(args.warmup): step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cost, bits, dist_, parts, ncand = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = ctx.encode_stats()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = world * n_ctu * args.steps / dt
+        # ---- roofline of the dominant kernel: a separate, untimed pass with HIP events around every launch (graphs off while profiling), on a small picture ----
+        pw, ph = min(W, 1024), min(Hb, 256)
+        pctx = hp.Context(pw, ph, device=local)
+        pctx.upload_orig(Y[:ph, :pw], Cb[:ph // 2, :pw // 2], Cr[:ph // 2, :pw // 2])
+        L = pctx.L
+        L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
+        L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        pctx._chk(L.hop_profile_reset(pctx.h), "profile_reset"); pctx._chk(L.hop_profile_enable(pctx.h, 1), "profile_enable")
+        tp0 = time.perf_counter()
+        pctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
+        prof_s = time.perf_counter() - tp0
+        prof_ctus = ((pw + 63) // 64) * ((ph + 63) // 64)
+        names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_tu_rd (transform + setup + inverse + decide)", 7: "k_intra (rough search + predictors)", 8: "k_rdoq", 9: "k_coeff_bits + CU-level counting"}
+        prof = {}
+        for kid, name in names.items():
+            la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
+            pctx._chk(L.hop_profile_read(pctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
+            prof[name] = {"launches": la.value, "total_ms": ms.value, "units": un.value}
+        pctx._chk(L.hop_profile_enable(pctx.h, 0), "profile_disable")
+        pctx.close()
+        dom = max(prof, key=lambda k: prof[k]["total_ms"])
+        p = prof[dom]
+        avg_ms = p["total_ms"] / max(1, p["launches"])
+        ctus_per_launch = prof_ctus / max(1, p["launches"])
+        achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+        rv = stats.get("rendezvous", {"rounds": 0, "requests": 0})
+        out = {
+            "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (RD search of TEncSlice::compressSlice; decisions, per-CTU RD costs and reconstruction identical to the reference's)",
+            "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16+f64", "data": "synthetic",
+            "config": {"workload": "synthetic lenslet %dx%d (pitch %d), QP%d, cfg/3DHencoder_intra_main.cfg semantics (ISS slice, SS +-128 full search with FEN, half/quarter-pel, GT search, "
+                                   "merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, CABAC-counted bits): the full-width top band of %d CTU rows "
+                                   "(%dx%d, %d CTUs) of the 7728x5368 frame coded as a picture -- the band BASELINE.md's CPU plan encodes -- SS reference from the sentinel, every "
+                                   "candidate of xCompressCU, rows as a lag-%d wavefront with WaveFrontSynchro contexts; per rank one such picture" % (W, Hb, PITCH, QP, rows, W, Hb, n_ctu, args.lag),
+                       "ctus_per_picture": n_ctu, "candidates_per_picture": ncand, "parallelism": "independent-pictures x%d" % world,
+                       "full_frame_note": "the whole 7728x5368 frame (84 rows) keeps up to 24 rows in flight instead of %d: its rate is higher than this band's" % rows},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
+                         "note": "from a separate profiled pass over a %dx%d picture (%d CTUs, %.1f s, HIP events around every launch, graphs off); the encode is bound by the LENGTH of "
+                                 "its dependent launch chains, not by HBM or VALU: see request_ms" % (pw, ph, prof_ctus, prof_s)},
+            "kernels": prof,
+            "request_ms": {k: v for k, v in stats.items() if k != "rendezvous"},
+            "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTU rows in flight)",
+            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"])},
+            "cost_sum": float(cost.sum()),
+        }
+        if world == 1:
+            out["cpu_baseline"] = cpu_baseline_encode(W, Hb, Y, Cb, Cr, cost, args.cpu_ctus)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_encode(W, H, Y, Cb, Cr, gpu_cost, n_ctus):
+    """The same work on one host core: the RD spine over the CPU restatement (oracle/libhop_spine_cpu.so, kind "port") on the first n_ctus CTUs of the same picture (raster
+    order; top-row CTUs, whose SS windows hold only what lies to their left -- cheaper than interior CTUs, so this OVERstates the CPU rate).  Their RD costs must equal the GPU's."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhop_spine_cpu.so"], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libhop_spine_cpu.so"))
+    L.hop_spine_cpu_encode.restype = ctypes.c_long
+    L.hop_spine_cpu_encode.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(n, np.float64)
+    a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
+    t0 = time.perf_counter()
+    L.hop_spine_cpu_encode(W, H, QP, PITCH, n_ctus, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, None, cost.ctypes.data, None, None, None, None, None, None, None)
+    dt = time.perf_counter() - t0
+    return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
+            "sample": "the first %d CTUs of the same picture through the same RD spine over the CPU restatement, one thread, %.1f s (top-row CTUs: cheaper than interior ones); the reference "
+                      "encoder itself ran the HOP configuration at 0.78 CTU/s on one core of the build container (BASELINE.md, 256x256)" % (n_ctus, dt),
+            "gpu_vs_oracle_mismatches": int(np.sum(cost[:n_ctus] != gpu_cost[:n_ctus]))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--width", type=int, default=FRAME_W)     # smaller pictures only for rehearsal; the JSON names them
+    ap.add_argument("--height", type=int, default=FRAME_H)
+    ap.add_argument("--rows", type=int, default=8, help="CTU rows of the band that is coded as the workload picture (84 = the whole frame)")
+    ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
+    ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")
+    ap.add_argument("--kernels", action="store_true", help="kernel-throughput mode of round 1: the search kernels over a frozen, fully reconstructed SS reference (not the encode metric)")
+    ap.add_argument("--rqt", action="store_true", help="--kernels: run the whole residual-quadtree search of every 2Nx2N CU instead of its leaf step")
+    args = ap.parse_args()
+    if args.kernels:
+        if args.cpu_ctus is None: args.cpu_ctus = 10
+        if args.steps == 1 and args.warmup == 0: args.steps, args.warmup = 3, 1
+        kernels_main(args)
+    else:
+        if args.cpu_ctus is None: args.cpu_ctus = 6
+        encode_main(args)
 
 
 if __name__ == "__main__":

@@ -109,13 +109,37 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   return r;
 }
 
+// A second handle on the same pictures with its own stream and work areas: requests issued through different views run concurrently on the device.  The caller keeps
+// their rectangles apart (the RD spine's CTU rows are a wavefront lag apart) and destroys the views before the parent.
+int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
+  if (!parent || !out || parent->is_view) return hop_set_err(parent, HOP_ERR_ARG, "hop_ctx_create_view: bad argument");
+  *out = nullptr;
+  hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
+  c->pic_w = parent->pic_w; c->pic_h = parent->pic_h; c->bd_y = parent->bd_y; c->bd_c = parent->bd_c; c->device = parent->device;
+  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
+  c->org_y = parent->org_y; c->org_cb = parent->org_cb; c->org_cr = parent->org_cr;
+  for (int k = 0; k < 3; k++) { c->ss_alloc[k] = parent->ss_alloc[k]; c->ss_buf[k] = parent->ss_buf[k]; c->ss00[k] = parent->ss00[k]; c->pred[k] = parent->pred[k]; c->rec[k] = parent->rec[k]; }
+  c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots;
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int k = 0; k < HOP_MAX_LANES - 1 && e == hipSuccess; k++) { e = hipStreamCreateWithFlags(&c->xstream[k], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming); }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e != hipSuccess) { hop_set_err(parent, HOP_ERR_DEVICE, "hop_ctx_create_view: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
+  *out = c;
+  return HOP_OK;
+}
+
 void hop_ctx_destroy(hop_ctx* c) {
   if (!c) return;
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+  if (c->is_view) {                                                     // pictures, tables and stash are the parent's
+    c->org_y = c->org_cb = c->org_cr = nullptr; c->entropy_bits = nullptr; c->rdoq_scans = nullptr; c->stash = nullptr;
+    for (int k = 0; k < 3; k++) { c->ss_alloc[k] = nullptr; c->pred[k] = nullptr; c->rec[k] = nullptr; }
+  }
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
-                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits };
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits, c->stash };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < HOP_GRAPH_SLOTS; k++) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -43,6 +43,7 @@ struct hop_ctx {
   struct { uint64_t key; int seen; hipGraphExec_t exec; } graphs[HOP_GRAPH_SLOTS]; int graph_next; long graph_replays;
   // RD spine support (k_spine.hip): stash slots for reconstruction blocks (64 x 64 x 1.5 samples each), allocated on first use
   int16_t* stash; int stash_slots;
+  bool   is_view;                    // hop_ctx_create_view: pictures, tables and stash belong to the parent; stream, scratch areas, graphs and profiling are its own
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
   bool   prof_on;

@@ -592,8 +592,10 @@ __device__ __noinline__ static unsigned long long icu_count(CabacLds& sh, const 
   // xEncIntraHeader
   if (b_luma) {
     if (part0 == 0) {
-      CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
-      CBIN(CU_PRED, 1);                                              // MODE_INTRA
+      if (y.skip_ctx >= 0) {                                         // skip_ctx < 0: an I slice, which codes neither the skip flag nor the prediction mode
+        CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
+        CBIN(CU_PRED, 1);                                            // MODE_INTRA
+      }
       if (y.is_min_cu) CBIN(CU_PART, y.part_nxn ? 0 : 1);
     }
     if (!y.part_nxn) { if (part0 == 0) frac += icu_dir(sh, lane, y.luma_dir[0], y.preds[0], y.pred_num[0]); }
@@ -1355,8 +1357,10 @@ __global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const 
   const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
   const int32_t* cf = coef + (size_t)i * (cu2 + (cu2 >> 1));
   unsigned long long frac = RQ_LEFT();
-  CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
-  CBIN(CU_PRED, 1);
+  if (y.skip_ctx >= 0) {                                             // skip_ctx < 0: an I slice
+    CBIN(CU_SKIP + y.skip_ctx, y.skip_flag ? 1 : 0);
+    CBIN(CU_PRED, 1);
+  }
   if (y.is_min_cu) CBIN(CU_PART, y.part_nxn ? 0 : 1);
   for (int p = 0; p < (y.part_nxn ? 4 : 1); p++) frac += icu_dir(sh, lane, y.luma_dir[p], y.preds[p], y.pred_num[p]);
   if (y.chroma_is_dm) CBIN(CU_CPRED, 0); else { CBIN(CU_CPRED, 1); CEP(2); }

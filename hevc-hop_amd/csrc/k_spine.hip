@@ -9,6 +9,7 @@
 // All byte moving: one 2-byte element per thread-iteration, rows contiguous.
 #include <string.h>
 #include <chrono>
+#include <mutex>
 #include <vector>
 #include "hop_dev.h"
 #include "../host/hop_spine.h"
@@ -125,8 +126,10 @@ struct Bail { int code; };
 // wall time and calls per kind of request of the last hop_encode_frame (hop_encode_stats): 0 me_search, 1 pred_inter, 2 distortion, 3 valid_pattern, 4 inter_cu with
 // residual, 5 inter_cu without, 6 intra_cu, 7 recon stash, 8 commit
 double g_stat_ms[16]; double g_stat_calls[16];
+std::mutex g_stat_lock;
 struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int k) : k(k), t0(std::chrono::steady_clock::now()) {}
-              ~Tick() { g_stat_ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_stat_calls[k] += 1; } };
+              ~Tick() { const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                        std::lock_guard<std::mutex> g(g_stat_lock); g_stat_ms[k] += d; g_stat_calls[k] += 1; } };
 #define BK(call) do { int r_ = (call); if (r_ != HOP_OK) throw Bail{ r_ }; } while (0)
 #define BH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hop_set_err(c, HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); throw Bail{ HOP_ERR_DEVICE }; } } while (0)
 
@@ -294,23 +297,43 @@ void hop_encode_stats(double ms[16], double calls[16]) { memcpy(ms, g_stat_ms, s
 int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates) {
   if (!c || !p) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_encode_frame: hop_upload_orig has not been called");
-  if (c->bd_y != 8 || c->bd_c != 8) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: the HOP configuration is 8-bit (the GT warp clips to 255)");
+  if (!p->plain_intra && (c->bd_y != 8 || c->bd_c != 8)) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: the HOP configuration is 8-bit (the GT warp clips to 255)");
+  if (c->bd_y != c->bd_c) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: luma and chroma bit depths must be equal");
   if (p->qp < 0 || p->qp > 51 || p->mi_size <= 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: qp / micro-image size");
-  hopspine::EncConfig cfg; hopspine::default_hop_config(cfg, c->pic_w, c->pic_h, p->qp, p->mi_size);
+  hopspine::EncConfig cfg;
+  if (p->plain_intra) hopspine::default_plain_config(cfg, c->pic_w, c->pic_h, p->qp, c->bd_y); else hopspine::default_hop_config(cfg, c->pic_w, c->pic_h, p->qp, p->mi_size);
   cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
   if (cfg.wpp && p->wavefront_lag <= 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
+  // streams > 1: one view of the context (own stream, own work areas) per CTU row in flight; their launch chains overlap on the device
+  std::vector<hop_ctx*> views; std::vector<HipBackend*> vbe; std::vector<Backend*> lanes;
+  if (p->wavefront_lag > 0 && p->streams > 1) {
+    if (!c->stash) { HIPCHK(c, hipMalloc((void**)&c->stash, (size_t)STASH_SLOTS * STASH_SAMPLES * 2)); c->stash_slots = STASH_SLOTS; }
+    const int nv = p->streams > 64 ? 64 : p->streams;
+    for (int i = 0; i < nv; i++) {
+      hop_ctx* v = nullptr;
+      if (hop_ctx_create_view(c, &v) != HOP_OK) break;
+      HipBackend* b = new HipBackend(v);
+      if (!b->ok()) { delete b; hop_ctx_destroy(v); break; }
+      views.push_back(v); vbe.push_back(b); lanes.push_back(b);
+    }
+    if ((int)lanes.size() != nv) { for (auto b : vbe) delete b; for (auto v : views) hop_ctx_destroy(v); return hop_set_err(c, HOP_ERR_DEVICE, "hop_encode_frame: could not create %d views", nv); }
+  }
   memset(g_stat_ms, 0, sizeof(g_stat_ms)); memset(g_stat_calls, 0, sizeof(g_stat_calls));
   hopspine::Encoder enc(cfg, &be);
   FILE* tf = nullptr;
   if (p->trace_path && p->trace_path[0]) { tf = fopen(p->trace_path, "w"); enc.trace = tf; }
   int rc = HOP_OK;
   try {
-    if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(&be, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
+    if (!lanes.empty()) enc.encode_frame_wavefront_direct(lanes.data(), (int)lanes.size(), p->wavefront_lag);
+    else if (p->wavefront_lag > 0 && getenv("HOP_SPINE_LOG")) { hopspine::LogBackend lg(&be, getenv("HOP_SPINE_LOG")); enc.encode_frame_wavefront(&lg, p->wavefront_lag); }
+    else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(&be, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
     else enc.encode_frame(p->first_ctus);
   } catch (const Bail& b) { rc = b.code; } catch (...) { rc = c->err[0] ? HOP_ERR_DEVICE : HOP_ERR_STATE; }
   if (tf) fclose(tf);
+  for (auto b : vbe) delete b;
+  for (auto v : views) { if (rc != HOP_OK && v->err[0] && !c->err[0]) strncpy(c->err, v->err, sizeof(c->err) - 1); hop_ctx_destroy(v); }
   if (rc != HOP_OK) return rc;
   const int n = enc.n_ctu();
   if (ctu_cost) memcpy(ctu_cost, enc.ctu_cost.data(), n * sizeof(double));

@@ -101,7 +101,7 @@ CU_PART_DTYPE = np.dtype([("depth", "u1"), ("pred_mode", "u1"), ("part_size", "u
 
 class EncParams(ctypes.Structure):       # hop_enc_params
     _fields_ = [("qp", ctypes.c_int32), ("mi_size", ctypes.c_int32), ("first_ctus", ctypes.c_int32), ("wpp", ctypes.c_int32), ("wavefront_lag", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("trace_path", ctypes.c_char_p)]
+                ("plain_intra", ctypes.c_int32), ("streams", ctypes.c_int32), ("trace_path", ctypes.c_char_p)]
 
 
 _I16P = ctypes.POINTER(ctypes.c_int16)
@@ -267,7 +267,7 @@ class Context:
         self._chk(self.L.hop_recon_download(self.h, comp, a.ctypes.data), "hop_recon_download")
         return a
 
-    def encode_frame(self, qp=32, mi_size=16, first_ctus=0, trace_path=None, wpp=0, wavefront_lag=0):
+    def encode_frame(self, qp=32, mi_size=16, first_ctus=0, trace_path=None, wpp=0, wavefront_lag=0, streams=0, plain_intra=0):
         """hop_encode_frame: the RD spine over the kernels for the resident original.  Returns per-CTU (cost, bits, dist), parts (n_ctu, 256) CU_PART_DTYPE, candidates."""
         L = self.L
         L.hop_encode_frame.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_void_p]
@@ -275,7 +275,7 @@ class Context:
         n = ((self.W + 63) // 64) * ((self.H + 63) // 64)
         cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32); parts = np.zeros((n, 256), CU_PART_DTYPE)
         nc = ctypes.c_uint64(0)
-        p = EncParams(qp, mi_size, first_ctus, wpp, wavefront_lag, 0, trace_path.encode() if trace_path else None)
+        p = EncParams(qp, mi_size, first_ctus, wpp, wavefront_lag, plain_intra, streams, trace_path.encode() if trace_path else None)
         self._chk(L.hop_encode_frame(self.h, ctypes.byref(p), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data, parts.ctypes.data, ctypes.byref(nc)), "hop_encode_frame")
         return cost, bits, dist, parts, int(nc.value)
 

@@ -37,6 +37,12 @@ void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size)
   finish_config(c);
 }
 
+void default_plain_config(EncConfig& c, int pic_w, int pic_h, int qp, int bit_depth) {
+  default_hop_config(c, pic_w, pic_h, qp, 16);
+  c.slice_type = 2; c.bit_depth = bit_depth; c.mi_merge = 0;
+  finish_config(c);
+}
+
 void finish_config(EncConfig& c) {
   // TEncSlice::initEncSlice, TLibEncoder/TEncSlice.cpp:358-462: I / ISS slice at depth 0, GOP size 1, no QP offsets
   static const uint8_t chroma_scale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
@@ -136,6 +142,13 @@ struct AmvpInfo { int n; int16_t cand[3][2]; };
 class CtuWorker {
  public:
   uint64_t n_cand_ = 0;
+  // request tags: (sequence number of the quadtree node visit, candidate slot, step inside the candidate)
+  uint64_t tag_seq_ = 0; int tag_slot_ = 0;
+  static int node_index(int d, int abs_idx) { int i = 0; if (d >= 1) i += 1 + (abs_idx >> 6) * 21; if (d >= 2) i += 1 + ((abs_idx >> 4) & 3) * 5; if (d >= 3) i += 1 + ((abs_idx >> 2) & 3); return i; }
+  void tag_enter(int d, int abs_idx) { tag_seq_ = 2 * (uint64_t)node_index(d, abs_idx); tag_slot_ = 0; tag_step(0); }
+  void tag_exit(int d, int abs_idx) { static const int sub[4] = { 85, 21, 5, 1 }; tag_seq_ = 2 * (uint64_t)(node_index(d, abs_idx) + sub[d] - 1) + 1; tag_slot_ = 3 - d; tag_step(0); }
+  void tag_cand(int slot) { tag_slot_ = slot; tag_step(0); }
+  void tag_step(int step) { be->set_tag(lane_, (tag_seq_ << 20) | ((uint64_t)tag_slot_ << 8) | (uint64_t)step); }
   CtuWorker(Encoder& e, int lane, Backend* backend = NULL) : E(e), cfg(e.cfg_), be(backend ? backend : e.be_), lane_(lane) { for (int d = 0; d < 4; d++) { best_[d] = &store_[d][0]; temp_[d] = &store_[d][1]; } }
   void compress_ctu(int addr, const Coder& entry, Coder& exit);
  private:
@@ -247,7 +260,7 @@ void CtuWorker::check_best_mode(int d, bool save_recon) {
   trace_candidate(*temp_[d]);
   if (temp_[d]->cost < best_[d]->cost) {
     std::swap(best_[d], temp_[d]);
-    if (save_recon) be->recon_save(lane_, d, best_[d]->x, best_[d]->y, best_[d]->size);
+    if (save_recon) { tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y, best_[d]->size); }
     sb_[d][CI_NEXT] = sb_[d][CI_TEMP];
   }
 }
@@ -421,6 +434,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
           j.mv_x = mh; j.mv_y = mvv; j.use_gt = 0;
           ti[nt++] = i;
         }
+        tag_step(pu * 8 + 0);
         if (nt) be->pred_cost(lane_, nt, tj, HOP_DIST_SAD, sad);
         uint32_t cost[3] = { 0x7FFFFFFFu, 0x7FFFFFFFu, 0x7FFFFFFFu };
         for (int k = 0; k < nt; k++) {
@@ -443,6 +457,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       for (int i = 0; i < info.n; i++) { j.amvp[2 * i] = info.cand[i][0]; j.amvp[2 * i + 1] = info.cand[i][1]; }
       j.flags = (cfg.fen ? HOP_FLAG_FEN : 0) | (cfg.hadme ? HOP_FLAG_HADME : 0);
       hop_pu_result r; memset(&r, 0, sizeof(r));
+      tag_step(pu * 8 + 1);
       be->me_search(lane_, 1, &j, &r);
       not_valid = r.not_valid != 0;
       if (!not_valid) {
@@ -483,6 +498,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
     if (ps != SIZE_2Nx2N) {
       // ME against merge (:3977-4146)
       uint32_t me_cost = MAX_UINT;
+      tag_step(pu * 8 + 2);
       if (test_normal) { const uint32_t err = inter_pred_error(c, pu); me_cost = err + ((lam * me_bits) >> 16); }
       PuFields saved = me;
       if (!test_normal) { memset(&saved, 0, sizeof(saved)); saved.ref = -1; saved.mvp_idx = -1; saved.mvp_num = -1; }
@@ -501,6 +517,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
           j.use_gt = (!base.merge_flag && base.gt_flag) ? 1 : 0; for (int q = 0; q < 8; q++) j.gt[q] = base.gt[q];
           mi[nm++] = k;
         }
+        tag_step(pu * 8 + 3);
         if (nm) be->pred_cost(lane_, nm, mj, cfg.hadme ? HOP_DIST_HADS : HOP_DIST_SAD, err);
         for (int t = 0; t < nm; t++) {
           const int k = mi[t];
@@ -523,6 +540,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
         set_parts(c, ox, oy, w, h, apply_pu_fields, &f);
       }
     }
+    tag_step(pu * 8 + 4);
     motion_comp_pu(c, pu);                                                 // :4158
   }
   return true;
@@ -577,7 +595,9 @@ void CtuWorker::eval_inter(int d, bool skip_res) {
 void CtuWorker::check_inter(int d, int ps, bool use_mrg) {                 // TEncCu::xCheckRDCostInter (:1399-1453)
   CuData& c = *temp_[d];
   for (int i = 0; i < c.num_part; i++) { c.p[i].depth = (uint8_t)d; c.p[i].skip = 0; c.p[i].part_size = (uint8_t)ps; c.p[i].pred_mode = MODE_INTER; }
+  tag_cand(10 + ps);
   if (!pred_inter_search(c, ps, use_mrg)) { c.cost = MAX_DOUBLE; return; }
+  tag_step(60);
   eval_inter(d, false);
   check_best_mode(d, true);
 }
@@ -602,7 +622,9 @@ void CtuWorker::check_merge_2Nx2N(int d, bool* early_skip) {               // TE
         int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(*c, mh, mvv);
         if (!valid_pattern(c->x, c->y, c->size, c->size, mh, mvv)) { init_est(*c); continue; }
       }
+      tag_cand(nores * 5 + k);
       motion_comp_pu(*c, 0);
+      tag_step(60);
       eval_inter(d, nores != 0);
       const int root = (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1);
       if (nores == 0 && root == 0) buf[k] = 1;
@@ -631,6 +653,7 @@ void CtuWorker::fill_intra_eval(const CuData& c, int ps, IntraEval& e) {
   hop_intra_cu_syntax& y = e.syn;
   y.part_nxn = e.part_nxn; y.skip_flag = 0; y.is_min_cu = c.depth == 3;
   { const Part* l = nb_left(c, c.x, c.y); const Part* a = nb_above(c, c.x, c.y); y.skip_ctx = (l ? l->skip : 0) + (a ? a->skip : 0); }
+  if (cfg.slice_type == 2) y.skip_ctx = -1;                               // an I slice codes neither cu_skip_flag nor pred_mode_flag
   e.opt.ts_fast = cfg.ts_fast; e.opt.strong = cfg.strong_intra;
   auto flags_of = [&](int x, int yy, int size, uint8_t* fl) {
     const int u = size / 4;
@@ -672,6 +695,7 @@ void CtuWorker::fill_intra_eval(const CuData& c, int ps, IntraEval& e) {
 void CtuWorker::check_intra(int d, int ps) {                               // TEncCu::xCheckRDCostIntra (:1455-1507)
   CuData& c = *temp_[d];
   for (int i = 0; i < c.num_part; i++) { c.p[i].skip = 0; c.p[i].part_size = (uint8_t)ps; c.p[i].pred_mode = MODE_INTRA; }
+  tag_cand(ps == SIZE_2Nx2N ? 20 : 21);
   IntraEval e; fill_intra_eval(c, ps, e);
   EvalResult r; memset(&r, 0, sizeof(r));
   const Coder& in = sb_[d][CI_CURR];
@@ -695,6 +719,8 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   bool sub_branch = true, do_not_block_pu = true, early_skip = false, boundary = false;
   const bool inside = (x + size <= cfg.pic_w) && (y + size <= cfg.pic_h);
   const bool not_i = cfg.slice_type != 2;
+  const int node_abs = best_[d]->abs_idx;
+  tag_enter(d, node_abs);
   auto root_cbf = [](const CuData* c) { return (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1); };
   if (inside) {
     init_est(*temp_[d]);
@@ -780,6 +806,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
     split_is_best = best_[d] != before;
   }
   copy_to_pic(*best_[d]);
+  tag_exit(d, node_abs);
   if (!boundary) {
     if (!split_is_best) be->recon_restore(lane_, d, x, y, size);           // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture
     be->commit(lane_, x, y, size);                                         // xCopyYuv2SSRef (:872-880)
@@ -835,6 +862,19 @@ Encoder::Encoder(const EncConfig& cfg, Backend* be) : trace(NULL), n_candidates(
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
 }
 
+LogBackend::LogBackend(Backend* inner, const char* path) : in_(inner), f_(fopen(path, "wb")) {}
+LogBackend::~LogBackend() { if (f_) fclose(f_); }
+void LogBackend::rec(int kind, int n, const void* a, size_t na, const void* b, size_t nb) {
+  if (!f_) return;
+  const int32_t h[2] = { kind, n }; const uint32_t z[2] = { (uint32_t)na, (uint32_t)nb };
+  fwrite(h, 4, 2, f_); fwrite(z, 4, 2, f_); if (na) fwrite(a, 1, na, f_); if (nb) fwrite(b, 1, nb, f_);
+}
+void LogBackend::rec2(int kind, const void* a, size_t na, const void* a2, size_t na2, const void* b, size_t nb) {
+  if (!f_) return;
+  const int32_t h[2] = { kind, 1 }; const uint32_t z[2] = { (uint32_t)(na + na2), (uint32_t)nb };
+  fwrite(h, 4, 2, f_); fwrite(z, 4, 2, f_); fwrite(a, 1, na, f_); fwrite(a2, 1, na2, f_); fwrite(b, 1, nb, f_);
+}
+
 void intra_syntax_dirs(hop_intra_cu_syntax& syn, const hop_intra_search_job& sj, const int dirs[4]) {
   const int npu = syn.part_nxn ? 4 : 1;
   for (int pu = 0; pu < npu; pu++) {
@@ -873,12 +913,13 @@ void Encoder::encode_frame(int first_ctus) {
 // wavefront: one thread per CTU row, requests of the rows in flight rendezvous and are served in batches
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
-struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; };
+struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; uint64_t tag; };
 enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTORE, RQ_COMMIT, RQ_PCOST };
 
 class Rendezvous : public Backend {
  public:
-  Rendezvous(BatchInner* inner, int n_threads) : rounds(0), requests(0), inner_(inner), active_(n_threads), failed_(false) {}
+  Rendezvous(BatchInner* inner, int n_threads) : rounds(0), requests(0), inner_(inner), active_(n_threads), failed_(false) { memset(tag_of_, 0, sizeof(tag_of_)); }
+  void set_tag(int lane, uint64_t tag) { tag_of_[lane & 127] = tag; }
   // a row thread is about to block on another row's progress / has been released / has finished
   std::mutex m; std::condition_variable cv;
   void begin_frame() {}
@@ -903,7 +944,7 @@ class Rendezvous : public Backend {
   bool failed() const { return failed_; }
   uint64_t rounds, requests;
  private:
-  BatchInner* inner_; int active_; bool failed_; std::vector<Req*> pending_;
+  BatchInner* inner_; int active_; bool failed_; std::vector<Req*> pending_; uint64_t tag_of_[128];
   void idle(std::unique_lock<std::mutex>& lk) {       // the caller stops running; if it was the last one, it serves what is pending first
     active_--;
     while (active_ == 0 && !pending_.empty()) serve(lk);
@@ -911,6 +952,7 @@ class Rendezvous : public Backend {
   void submit(Req& q) {
     std::unique_lock<std::mutex> lk(m);
     if (failed_) throw 1;
+    q.tag = tag_of_[q.lane & 127];
     pending_.push_back(&q);
     active_--;
     while (active_ == 0 && !pending_.empty() && !q.done) serve(lk);
@@ -918,7 +960,11 @@ class Rendezvous : public Backend {
     if (failed_ && !q.done) throw 1;
   }
   void serve(std::unique_lock<std::mutex>&) {         // called with the lock held and every thread parked: one batch per kind / class
-    std::vector<Req*> v; v.swap(pending_);
+    // the requests with the smallest tag (the rows coded side by side have started their CTUs together: equal tags are the same operation); the others wait their turn
+    uint64_t tmin = ~0ull; for (Req* r : pending_) if (r->tag < tmin) tmin = r->tag;
+    std::vector<Req*> v, rest;
+    for (Req* r : pending_) (r->tag == tmin ? v : rest).push_back(r);
+    pending_.swap(rest);
     rounds++; requests += v.size();
     try {
       std::vector<char> used(v.size(), 0);
@@ -979,30 +1025,39 @@ class Rendezvous : public Backend {
 };
 }  // namespace
 
-void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int max_rows) {
-  if (!cfg_.wpp) throw 1;
-  inner->begin_frame();
+void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int max_rows) { wavefront(inner, NULL, 0, lag, max_rows); }
+void Encoder::encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag) { wavefront(NULL, lanes, n_lanes, lag, n_lanes); }
+
+void Encoder::wavefront(BatchInner* inner, Backend* const* lanes, int n_lanes, int lag, int max_rows) {
+  if (!cfg_.wpp || (!inner && n_lanes <= 0)) throw 1;
+  if (inner) inner->begin_frame(); else lanes[0]->begin_frame();
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
   std::fill(committed.begin(), committed.end(), (uint8_t)0);
   Coder init; memset(&init, 0, sizeof(init));
   hop_cabac_init(&init.r, cfg_.slice_type, cfg_.qp); hop_cabac_cu_init(&init.c, cfg_.slice_type, cfg_.qp); hop_cabac_split_init(init.split, cfg_.slice_type, cfg_.qp);
   const int rows = hctu_, cols = wctu_;
-  if (max_rows <= 0 || max_rows > 120) max_rows = 120;                  // stash slots: 128 lanes x 16
   Rendezvous rv(inner, rows);
-  std::vector<int> done(rows, 0);                                      // CTUs finished per row
+  // synchronous wavefront: step s holds the CTUs (r, c) with c + lag * r == s; a step starts when the previous one has finished, so that its CTUs start together
+  // (their requests then carry equal tags and meet in the batches) and every CTU finds rows above it coded up to column c + lag - 1
+  const int n_steps = cols + lag * (rows - 1);
+  std::vector<int> in_step(n_steps, 0), fin_step(n_steps, 0);
+  for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) if ((long)c + (long)lag * r < n_steps) in_step[c + lag * r]++;
+  int steps_complete = -1;                                             // all steps <= this one are finished
   std::vector<Coder> sync(rows);                                       // the coder after the second CTU of each row (WaveFrontSynchro)
   std::vector<uint64_t> cand(rows, 0);
   std::vector<std::thread> th;
+  (void)max_rows;
   for (int r = 0; r < rows; r++) {
     th.emplace_back([&, r]() {
-      CtuWorker* w = new CtuWorker(*this, r % 128, &rv);
+      CtuWorker* w = new CtuWorker(*this, r % 128, inner ? (Backend*)&rv : lanes[r % n_lanes]);
+      int c = 0;
       try {
         Coder k = init;
-        for (int c = 0; c < cols; c++) {
+        for (; c < cols; c++) {
+          const int st = c + lag * r;
           {
             std::unique_lock<std::mutex> lk(rv.m);
-            // row r - 1 far enough ahead (and not more rows in flight than lanes: row r - max_rows finished)
-            rv.wait_until(lk, [&] { return (r == 0 || done[r - 1] >= std::min(cols, c + lag)) && (r < max_rows || done[r - max_rows] >= cols); });
+            rv.wait_until(lk, [&] { return steps_complete >= st - 1; });
             if (rv.failed()) break;
             if (c == 0 && r > 0 && cols >= 2) { k = sync[r - 1]; coder_set_frac(k, 0); }   // loadContexts: the contexts of the row above after its second CTU, the row's own (fresh) bin coder
           }
@@ -1012,14 +1067,16 @@ void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int max_rows) {
           k = next;
           std::unique_lock<std::mutex> lk(rv.m);
           if (c == 1) sync[r] = k;
-          done[r] = c + 1;
+          fin_step[st]++;
+          while (steps_complete + 1 < n_steps && fin_step[steps_complete + 1] == in_step[steps_complete + 1]) steps_complete++;
           rv.cv.notify_all();
         }
       } catch (...) {}
       cand[r] = w->n_cand_;
       delete w;
       std::unique_lock<std::mutex> lk(rv.m);
-      done[r] = cols;                                                  // (also after a failure, so that nobody waits for this row)
+      for (; c < cols; c++) { fin_step[c + lag * r]++; }               // after a failure: nobody waits for this row
+      while (steps_complete + 1 < n_steps && fin_step[steps_complete + 1] == in_step[steps_complete + 1]) steps_complete++;
       rv.thread_done(lk);
       rv.cv.notify_all();
     });

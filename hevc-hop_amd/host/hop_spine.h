@@ -35,6 +35,7 @@ struct EncConfig {
   int qp_scaled[3];
 };
 void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size);   // cfg/3DHencoder_intra_main.cfg
+void default_plain_config(EncConfig& c, int pic_w, int pic_h, int qp, int bit_depth);   // cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg: I slice, no SS / GT
 void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
 
 typedef hop_cu_part Part;          // one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
@@ -66,6 +67,9 @@ class Backend {
  public:
   virtual ~Backend() {}
   virtual void begin_frame() = 0;                                                        // SS reference to the sentinel
+  // where the calling lane is in its CTU (a number that grows along the reference's order of operations and means the same operation in every CTU): a batching backend
+  // serves the requests with the smallest tag first, so that CTUs coded side by side stay in step and their requests meet
+  virtual void set_tag(int /*lane*/, uint64_t /*tag*/) {}
   virtual void me_search(int lane, int n, const hop_pu_job* jobs, hop_pu_result* res) = 0;   // SS + fractional + GT search
   virtual void pred_inter(int lane, int n, const hop_pred_job* jobs) = 0;                // into the prediction picture
   virtual void distortion(int lane, int n, const hop_dist_job* jobs, uint32_t* out) = 0; // original vs prediction picture
@@ -104,6 +108,38 @@ class BatchInner : public Backend {
   }
 };
 
+// A backend that forwards to another one and appends every request with its answer to a binary log (HOP_SPINE_LOG=<file>: diagnostics -- two backends serving the same
+// picture write the same log up to the first request they answer differently).  Record: int32 kind, int32 n, uint32 bytes in, uint32 bytes out, then the bytes.
+class LogBackend : public BatchInner {
+ public:
+  LogBackend(Backend* inner, const char* path);
+  ~LogBackend();
+  void begin_frame() { in_->begin_frame(); }
+  void me_search(int lane, int n, const hop_pu_job* jobs, hop_pu_result* res) { in_->me_search(lane, n, jobs, res); rec(0, n, jobs, n * sizeof(hop_pu_job), res, n * sizeof(hop_pu_result)); }
+  void pred_inter(int lane, int n, const hop_pred_job* jobs) { in_->pred_inter(lane, n, jobs); rec(1, n, jobs, n * sizeof(hop_pred_job), NULL, 0); }
+  void distortion(int lane, int n, const hop_dist_job* jobs, uint32_t* out) { in_->distortion(lane, n, jobs, out); rec(2, n, jobs, n * sizeof(hop_dist_job), out, n * 4); }
+  void valid_pattern(int lane, int n, const int32_t* q, uint8_t* out) { in_->valid_pattern(lane, n, q, out); rec(3, n, q, n * 24, out, n); }
+  void pred_cost(int lane, int n, const hop_pred_job* jobs, int kind, uint32_t* out) { in_->pred_cost(lane, n, jobs, kind, out); rec(9, n, jobs, n * sizeof(hop_pred_job), out, n * 4); }
+  // (fields of the answer the spine does not read are normalised in the log's copy: the cost, the split contexts, directions of PUs that do not exist)
+  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) {
+    in_->inter_cu(lane, e, in, out);
+    EvalResult o = out; o.cost = 0; o.after.split[0] = o.after.split[1] = o.after.split[2] = o.after.pad = 0; o.luma_dir[0] = o.luma_dir[1] = o.luma_dir[2] = o.luma_dir[3] = o.chroma_dir = 0;
+    rec2(4, &e, sizeof(e), &in, sizeof(in), &o, sizeof(o));
+  }
+  void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& out) {
+    in_->intra_cu(lane, e, in, out);
+    EvalResult o = out; o.cost = 0; o.after.split[0] = o.after.split[1] = o.after.split[2] = o.after.pad = 0; if (!e.part_nxn) o.luma_dir[1] = o.luma_dir[2] = o.luma_dir[3] = 0;
+    rec2(5, &e, sizeof(e), &in, sizeof(in), &o, sizeof(o));
+  }
+  void recon_save(int lane, int slot, int x, int y, int size) { in_->recon_save(lane, slot, x, y, size); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { in_->recon_restore(lane, slot, x, y, size); }
+  void commit(int lane, int x, int y, int size) { in_->commit(lane, x, y, size); }
+ private:
+  Backend* in_; FILE* f_;
+  void rec(int kind, int n, const void* a, size_t na, const void* b, size_t nb);
+  void rec2(int kind, const void* a, size_t na, const void* a2, size_t na2, const void* b, size_t nb);
+};
+
 // the luma directions of a finished intra search and their most probable modes (TComDataCU::getIntraDirLumaPredictor, TComDataCU.cpp:1772-1830) into the CU's
 // syntax elements: neighbours outside the CU from sj.left_dir / above_dir, inside it the PUs decided before
 void intra_syntax_dirs(hop_intra_cu_syntax& syn, const hop_intra_search_job& sj, const int dirs[4]);
@@ -117,6 +153,11 @@ class Encoder {
   // :1158-1161) and the result equals the reference run with one substream per row; without it the rows would need the coder of the previous row's END (raster order),
   // which serialises them: wavefront mode requires cfg.wpp.
   void encode_frame_wavefront(BatchInner* inner, int lag = 5, int max_rows_in_flight = 0);
+  // the same wavefront without batching: row r talks to lanes[r % n_lanes] directly (backends that run concurrently, e.g. one stream each); at most n_lanes rows in flight
+  void encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag = 5);
+ private:
+  void wavefront(BatchInner* inner, Backend* const* lanes, int n_lanes, int lag, int max_rows);
+ public:
   const EncConfig& config() const { return cfg_; }
   int n_ctu() const { return wctu_ * hctu_; }
   // results

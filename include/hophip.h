@@ -101,6 +101,9 @@ typedef struct {
  * and TComPicYuv::create for the SS reference (TLibCommon/TComPicYuv.cpp:69-120). */
 int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit_depth_c, int device);
 void hop_ctx_destroy(hop_ctx* ctx);
+/* A second handle on the same resident pictures with its own stream and work areas (no counterpart in the single-threaded reference): requests issued through different views
+ * run concurrently on the device; the caller keeps their rectangles apart.  Views are destroyed before their parent. */
+int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out);
 const char* hop_last_error(const hop_ctx* ctx);     /* ctx may be NULL: error of the failed create */
 int hop_sync(hop_ctx* ctx);
 void* hop_stream(hop_ctx* ctx);                     /* hipStream_t the *_device calls are ordered on */
@@ -427,7 +430,8 @@ int hop_inter_cu_bits(hop_ctx* ctx, int n, const hop_rqt_job* jobs, const hop_cu
  * for the transform units the tr_idx array describes).  No PCM, no transquant bypass, not an I slice (the skip flag and prediction mode are coded). */
 typedef struct {
   int32_t part_nxn;                /* 0: 2Nx2N, 1: NxN */
-  int32_t skip_flag, skip_ctx, is_min_cu;
+  int32_t skip_flag, skip_ctx, is_min_cu;          /* skip_ctx < 0: the slice is an I slice -- neither cu_skip_flag nor pred_mode_flag is coded (TEncEntropy::encodeSkipFlag,
+                                                      encodePredMode return at once, TLibEncoder/TEncEntropy.cpp:92-131) */
   int32_t luma_dir[4], preds[4][3], pred_num[4];   /* per PU: getLumaIntraDir, getIntraDirLumaPredictor */
   int32_t chroma_is_dm, chroma_dir;   /* chroma direction == DM_CHROMA_IDX; otherwise the direction (it selects the coefficient scan) */
   int32_t tr_depth, part;          /* the node: transform depth and first 4x4 partition (z-order inside the CU) */
@@ -616,7 +620,10 @@ typedef struct {
                              --WaveFrontSynchro=1 --WaveFrontSubstreams=<CTU rows>; 0: the shipped configuration (contexts run on in raster order, CTUs strictly serial) */
   int32_t wavefront_lag;  /* > 0 (implies wpp): the CTU rows run as a wavefront -- row r codes CTU c once row r - 1 has finished CTU c + lag - 1 -- and the candidate
                              evaluations of all rows in flight are batched into common launches; 5 covers the reach of the SS / GT search, so the result equals lag = infinity */
-  int32_t reserved;
+  int32_t plain_intra;    /* 1: the plain HM intra configurations (cfg/encoder_intra_main.cfg, encoder_intra_main10.cfg): an I slice without SS / GT search, at the context's
+                             bit depth (8 or 10); 0: the HOP configuration (8 bit only: the GT warp clips to 255, TComPrediction.cpp:969) */
+  int32_t streams;        /* wavefront mode: > 1 = that many views of the context (hop_ctx_create_view), one per CTU row in flight, each row's requests on its own stream so
+                             that the rows' launch chains overlap on the device; <= 1 = the rows' requests rendezvous and are served in batches on the context's stream */
   const char* trace_path;
 } hop_enc_params;
 int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates);

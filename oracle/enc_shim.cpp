@@ -603,8 +603,8 @@ UInt TEncSearch::xGetIntraBitsQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPar
 {
   g_calls9[0]++;
   TComSlice* sl = pcCU->getSlice();
-  if (bRealCoeff || sl->getSPS()->getUsePCM() || sl->getPPS()->getTransquantBypassEnableFlag() || sl->isIntra()) {
-    fprintf(stderr, "hop shim: xGetIntraBitsQT is replaced for the layer coefficients, no PCM, no transquant bypass, ISS slices\n"); abort();
+  if (bRealCoeff || sl->getSPS()->getUsePCM() || sl->getPPS()->getTransquantBypassEnableFlag()) {
+    fprintf(stderr, "hop shim: xGetIntraBitsQT is replaced for the layer coefficients, no PCM, no transquant bypass\n"); abort();
   }
   const UInt depth = pcCU->getDepth(0);
   hop_o_rqt_cfg cfg; memset(&cfg, 0, sizeof(cfg));
@@ -618,7 +618,7 @@ UInt TEncSearch::xGetIntraBitsQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPar
   for (int l = 0; l < 4; l++) { st.coef[l][0] = m_ppcQTTempCoeffY[l]; st.coef[l][1] = m_ppcQTTempCoeffCb[l]; st.coef[l][2] = m_ppcQTTempCoeffCr[l]; }
   hop_o_intra_syntax y; memset(&y, 0, sizeof(y));
   y.part_nxn = pcCU->getPartitionSize(0) == SIZE_NxN ? 1 : 0;
-  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = (int)pcCU->getCtxSkipFlag(0); y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth;
+  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = sl->isIntra() ? -1 : (int)pcCU->getCtxSkipFlag(0); y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth;   // -1: an I slice codes neither skip flag nor prediction mode
   for (int p = 0; p < (y.part_nxn ? 4 : 1); p++) {
     const UInt idx = p * (parts >> 2);
     y.luma_dir[p] = pcCU->getLumaIntraDir(idx);
@@ -666,7 +666,7 @@ void intra_env(TEncSearch* self, TComDataCU* pcCU, UInt uiTrDepth, UInt uiAbsPar
   const int cu = 1 << cfg.log2_cu, parts = (cu / 4) * (cu / 4);
   hop_o_intra_syntax y; memset(&y, 0, sizeof(y));
   y.part_nxn = pcCU->getPartitionSize(0) == SIZE_NxN ? 1 : 0;
-  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = (int)pcCU->getCtxSkipFlag(0); y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth;
+  y.skip_flag = pcCU->isSkipped(0) ? 1 : 0; y.skip_ctx = sl->isIntra() ? -1 : (int)pcCU->getCtxSkipFlag(0); y.is_min_cu = depth == g_uiMaxCUDepth - g_uiAddCUDepth;   // -1: an I slice codes neither skip flag nor prediction mode
   for (int p = 0; p < (y.part_nxn ? 4 : 1); p++) {
     const UInt idx = p * (parts >> 2);
     y.luma_dir[p] = pcCU->getLumaIntraDir(idx);
@@ -711,9 +711,9 @@ Void TEncSearch::xRecurIntraCodingQT(TComDataCU* pcCU, UInt uiTrDepth, UInt uiAb
   static const bool orig = hand_back("xRecurIntraCodingQT");
   if (orig) { hop_ref_orig_recur_intra(this, pcCU, uiTrDepth, uiAbsPartIdx, bLumaOnly, pcOrgYuv, pcPredYuv, pcResiYuv, ruiDistY, ruiDistC, bCheckFirst, dRDCost); return; }
   TComSlice* sl = pcCU->getSlice();
-  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() ||
+  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) ||
       sl->getSPS()->getUsePCM()) {
-    fprintf(stderr, "hop shim: xRecurIntraCodingQT is replaced for luma-only trees, RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+    fprintf(stderr, "hop shim: xRecurIntraCodingQT is replaced for luma-only trees, RDOQ + RDOQTS, no RD penalty, lossy\n"); abort();
   }
   g_calls11[0]++;
   hop_o_rqt_cfg cfg; hop_o_intra_syntax y; std::vector<uint8_t> avail;
@@ -788,9 +788,9 @@ Void TEncSearch::estIntraPredQT(TComDataCU* pcCU, TComYuv* pcOrgYuv, TComYuv* pc
   static const bool orig = hand_back("estIntraPredQT");
   if (orig) { hop_ref_orig_est_intra(this, pcCU, pcOrgYuv, pcPredYuv, pcResiYuv, pcRecoYuv, ruiDistC, bLumaOnly); return; }
   TComSlice* sl = pcCU->getSlice();
-  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() ||
+  if (!bLumaOnly || m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) ||
       sl->getSPS()->getUsePCM()) {
-    fprintf(stderr, "hop shim: estIntraPredQT is replaced for luma-only searches, RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+    fprintf(stderr, "hop shim: estIntraPredQT is replaced for luma-only searches, RDOQ + RDOQTS, no RD penalty, lossy\n"); abort();
   }
   g_calls12[0]++;
   const UInt uiDepth = pcCU->getDepth(0);
@@ -888,8 +888,8 @@ Void TEncSearch::estIntraPredChromaQT(TComDataCU* pcCU, TComYuv* pcOrgYuv, TComY
   static const bool orig = hand_back("estIntraPredChromaQT");
   if (orig) { hop_ref_orig_est_chroma(this, pcCU, pcOrgYuv, pcPredYuv, pcResiYuv, pcRecoYuv, uiPreCalcDistC); return; }
   TComSlice* sl = pcCU->getSlice();
-  if (m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->isIntra() || sl->getSPS()->getUsePCM()) {
-    fprintf(stderr, "hop shim: estIntraPredChromaQT is replaced for RDOQ + RDOQTS, no RD penalty, lossy, ISS slices\n"); abort();
+  if (m_pcEncCfg->getRDpenalty() || !m_pcEncCfg->getUseRDOQ() || !m_pcEncCfg->getUseRDOQTS() || pcCU->getCUTransquantBypass(0) || sl->getSPS()->getUsePCM()) {
+    fprintf(stderr, "hop shim: estIntraPredChromaQT is replaced for RDOQ + RDOQTS, no RD penalty, lossy\n"); abort();
   }
   g_calls13[0]++;
   const UInt uiDepth = pcCU->getDepth(0);
@@ -970,8 +970,8 @@ Void TEncCu::xCheckRDCostIntra(TComDataCU*& rpcBestCU, TComDataCU*& rpcTempCU, P
   static const bool orig = hand_back("xCheckRDCostIntra");
   if (orig) { hop_ref_orig_check_intra(this, rpcBestCU, rpcTempCU, eSize); return; }
   TComSlice* sl = rpcTempCU->getSlice();
-  if (sl->getPPS()->getTransquantBypassEnableFlag() || sl->getSPS()->getUsePCM() || getdQPFlag() || sl->isIntra()) {
-    fprintf(stderr, "hop shim: xCheckRDCostIntra is replaced without transquant bypass, PCM, cu_qp_delta, for ISS slices\n"); abort();
+  if (sl->getPPS()->getTransquantBypassEnableFlag() || sl->getSPS()->getUsePCM() || getdQPFlag()) {
+    fprintf(stderr, "hop shim: xCheckRDCostIntra is replaced without transquant bypass, PCM, cu_qp_delta\n"); abort();
   }
   g_calls14[0]++;
   const UInt uiDepth = rpcTempCU->getDepth(0);

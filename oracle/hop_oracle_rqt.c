@@ -507,8 +507,10 @@ uint32_t hop_o_intra_cu_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_syntax*
   coder->frac &= 32767;                                                 /* resetBits */
   if (b_luma) {
     if (part == 0) {
-      bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);             /* not an I slice: skip flag, prediction mode */
-      bin(&s, CU_PRED, 1);
+      if (y->skip_ctx >= 0) {                                           /* skip_ctx < 0: an I slice, which codes neither (TEncEntropy::encodeSkipFlag / encodePredMode) */
+        bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);
+        bin(&s, CU_PRED, 1);
+      }
       if (y->is_min_cu) bin(&s, CU_PART, y->part_nxn ? 0 : 1);          /* codePartSize, intra */
     }
     if (!y->part_nxn) { if (part == 0) intra_dir(&s, y->luma_dir[0], y->preds[0], y->pred_num[0]); }
@@ -895,8 +897,10 @@ uint32_t hop_o_intra_cu_total_bits(const hop_o_rqt_cfg* cfg, const hop_o_intra_s
 {
   Syn s = { coder, cu_ctx };
   coder->frac &= 32767;
-  bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);
-  bin(&s, CU_PRED, 1);
+  if (y->skip_ctx >= 0) {                                               /* skip_ctx < 0: an I slice */
+    bin(&s, CU_SKIP + y->skip_ctx, y->skip_flag ? 1 : 0);
+    bin(&s, CU_PRED, 1);
+  }
   if (y->is_min_cu) bin(&s, CU_PART, y->part_nxn ? 0 : 1);
   for (int p = 0; p < (y->part_nxn ? 4 : 1); p++) intra_dir(&s, y->luma_dir[p], y->preds[p], y->pred_num[p]);
   if (y->chroma_is_dm) bin(&s, CU_CPRED, 0); else { bin(&s, CU_CPRED, 1); ep(&s, 2); }

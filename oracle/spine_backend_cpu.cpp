@@ -237,7 +237,8 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   CpuBackend be(w, h, 8, y, cb, cr);
   Encoder enc(cfg, &be);
   if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
-  try { enc.encode_frame_wavefront(&be, lag > 0 ? lag : 1 << 20); } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
+  LogBackend* lg = getenv("HOP_SPINE_LOG") ? new LogBackend(&be, getenv("HOP_SPINE_LOG")) : NULL;
+  try { enc.encode_frame_wavefront(lg ? (BatchInner*)lg : (BatchInner*)&be, lag > 0 ? lag : 1 << 20); delete lg; } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
@@ -248,6 +249,25 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
   if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
   if (rounds_requests) { rounds_requests[0] = (double)enc.batch_rounds; rounds_requests[1] = (double)enc.batch_requests; }
+  return (long)enc.n_candidates;
+}
+// the plain intra configurations (cfg/encoder_intra_main.cfg, encoder_intra_main10.cfg): I slice, bit depth 8 or 10 (samples already at that depth), CTUs in raster order
+long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
+                                double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr) {
+  EncConfig cfg; default_plain_config(cfg, w, h, qp, bit_depth);
+  CpuBackend be(w, h, bit_depth, y, cb, cr);
+  Encoder enc(cfg, &be);
+  if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
+  enc.encode_frame(0);
+  if (enc.trace) fclose(enc.trace);
+  const int n = enc.n_ctu();
+  if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
+  if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
+  if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
+  if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
+  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
+  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
   return (long)enc.n_candidates;
 }
 int hop_spine_sizeof_part(void) { return (int)sizeof(Part); }

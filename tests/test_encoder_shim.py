@@ -88,3 +88,35 @@ def test_shim_encoder_on_sharp_content():
         ts += int(np.frombuffer(raw, "u1", 768, o + 1024).any()); n += 1
         o += 256 * 7 + cu * cu * 6
     assert n > 300 and ts > n // 2, (n, ts)
+
+
+def _encode_plain(exe, cfg, W, H, seed, qp, bd, td):
+    Y, Cb, Cr = lenslet(W, H, 16, seed, bitdepth=bd)
+    dt = np.uint8 if bd == 8 else np.dtype("<u2")
+    with open(os.path.join(td, "in.yuv"), "wb") as f:
+        f.write(Y.astype(dt).tobytes() + Cb.astype(dt).tobytes() + Cr.astype(dt).tobytes())
+    r = subprocess.run([exe, "-c", os.path.join(REF, "cfg", cfg), "-i", "in.yuv", "-wdt", str(W), "-hgt", str(H), "-fr", "30", "-f", "1", "-q", str(qp), "--InputBitDepth=%d" % bd,
+                        "--SEIDecodedPictureHash=1", "-b", "s.bin", "-o", "rec.yuv"], cwd=td, capture_output=True, text=True, env=dict(os.environ, HOP_SHIM_REPORT="1"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    md5 = lambda n: hashlib.md5(open(os.path.join(td, n), "rb").read()).hexdigest()
+    return md5("s.bin"), md5("rec.yuv"), r.stderr
+
+
+@pytest.mark.parametrize("cfg,bd,qp", [("encoder_intra_main.cfg", 8, 32), ("encoder_intra_main10.cfg", 10, 22), ("encoder_intra_main10.cfg", 10, 27),
+                                       ("encoder_intra_main10.cfg", 10, 32), ("encoder_intra_main10.cfg", 10, 37)])
+def test_shim_encoder_plain_intra_configurations(cfg, bd, qp):
+    """BASELINE configs 1 and 4: the plain HM intra configurations (I slices; 8 bit, and 10 bit at the four QPs of the RD sweep): the shim encoder -- composite restatements of
+    the intra searches, the intra CU's bit count, RDOQ, transforms, CABAC estimation in place of the reference's members -- against the unmodified encoder run beside it."""
+    exe = _shim()
+    ref = os.path.join(ROOT, "oracle", "_ref", "TAppEncoderRef")
+    with tempfile.TemporaryDirectory() as ta, tempfile.TemporaryDirectory() as tb:
+        a = _encode_plain(ref, cfg, 128, 128, 9, qp, bd, ta)
+        b = _encode_plain(exe, cfg, 128, 128, 9, qp, bd, tb)
+    calls = {}
+    for ln in b[2].splitlines():
+        if ln.startswith("hop shim calls:"):
+            t = ln.split(":")[1].split()
+            calls.update({t[i]: int(t[i + 1]) for i in range(0, len(t), 2)})
+    for k in ("intraSearch", "chromaSearch", "intraCu"):
+        assert calls.get(k, 0) > 100, (k, calls)
+    assert a[:2] == b[:2], calls

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from hoputil import ROOT
-from test_spine_cpu import FRAMES, FRAMES_WPP, check_against_golden, frame, key_of, run_cpu, run_cpu_wpp, spine_cpu
+from hoputil import lenslet
+from test_spine_cpu import FRAMES, FRAMES_WPP, PLAIN, check_against_golden, frame, key_of, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +39,7 @@ def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp):
         assert np.array_equal(ctx.recon_download(c), rec[c]), c
     m = 80
     assert np.array_equal(ctx.ssref_download(0)[m:m + H, m:m + W], rec[0])
-    print(key_of(W, H, seed, sharp), nc, "candidates", {k: (round(v["ms"], 1), v["calls"]) for k, v in ctx.encode_stats().items()})
+    print(key_of(W, H, seed, sharp), nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
     ctx.close()
 
 
@@ -59,4 +60,24 @@ def test_encode_frame_wavefront_equals_the_reference_with_wavefront_synchro(W, H
     for c in range(3):
         assert np.array_equal(ctx.recon_download(c), rec[c]), c
     print(key_of(W, H, seed, False), "wpp lag", lag, nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
+    ctx.close()
+
+
+@pytest.mark.parametrize("bd,qp", PLAIN)
+def test_encode_frame_plain_intra_configurations(bd, qp):
+    """BASELINE configs 1 and 4 on the GPU: I slices at 8 bit (QP 32) and 10 bit (QP 22 / 27 / 32 / 37) against the reference run with the plain intra configurations"""
+    hp = _hp()
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    W, H = 136, 72
+    Y, Cb, Cr = lenslet(W, H, 16, 9, bitdepth=bd)
+    ctx = hp.Context(W, H, bit_depth=bd)
+    ctx.upload_orig(Y, Cb, Cr)
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        cost, bits, dist, parts, nc = ctx.encode_frame(qp, 16, 0, tp, plain_intra=1)
+        text = open(tp, "rb").read()
+    check_against_golden(G, plain_key(bd, qp), cost, bits, dist, parts.view(np.dtype(parts.dtype.descr)), text)
+    rec = run_cpu_plain(spine_cpu(), W, H, Y, Cb, Cr, qp, bd)[4]
+    for c in range(3):
+        assert np.array_equal(ctx.recon_download(c), rec[c]), c
     ctx.close()

@@ -68,6 +68,29 @@ def run_cpu_wpp(L, W, H, Y, Cb, Cr, lag, qp=32, mi=16):
     return cost, bits, dist, parts, rec, text, rr
 
 
+PLAIN = [(8, 32), (10, 22), (10, 27), (10, 32), (10, 37)]          # bit depth, QP: cfg/encoder_intra_main.cfg and encoder_intra_main10.cfg (I slices), 136x72, seed 9
+
+
+def plain_key(bd, qp):
+    return "plain%d_qp%d_136x72_seed9" % (bd, qp)
+
+
+def run_cpu_plain(L, W, H, Y, Cb, Cr, qp, bd):
+    L.hop_spine_cpu_encode_plain.restype = ctypes.c_long
+    L.hop_spine_cpu_encode_plain.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 7
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32)
+    parts = np.zeros((n, 256), PART_DT)
+    rec = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+    a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        L.hop_spine_cpu_encode_plain(W, H, qp, bd, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, tp.encode(), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data,
+                                     parts.ctypes.data, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data)
+        text = open(tp, "rb").read()
+    return cost, bits, dist, parts, rec, text
+
+
 def spine_cpu():
     so = os.path.join(ROOT, "oracle", "libhop_spine_cpu.so")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhop_spine_cpu.so"], stdout=subprocess.DEVNULL)
@@ -111,3 +134,13 @@ def test_spine_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed,
     cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
     check_against_golden(G, key_of(W, H, seed, False) + "_wpp", cost, bits, dist, parts, text)
     if lag: assert rr[1] > rr[0]                                    # some rounds served more than one row
+
+
+@pytest.mark.parametrize("bd,qp", PLAIN)
+def test_spine_plain_intra_configurations(bd, qp):
+    """BASELINE configs 1 and 4: the plain HM intra configurations -- I slice (no skip flag / prediction mode in the syntax, the I row of the context tables), 8 bit at QP 32
+    and 10 bit at QP 22 / 27 / 32 / 37 -- against the reference encoder run with cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg"""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    Y, Cb, Cr = lenslet(136, 72, 16, 9, bitdepth=bd)
+    cost, bits, dist, parts, rec, text = run_cpu_plain(spine_cpu(), 136, 72, Y, Cb, Cr, qp, bd)
+    check_against_golden(G, plain_key(bd, qp), cost, bits, dist, parts, text)

@@ -303,7 +303,7 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   hopspine::EncConfig cfg;
   if (p->plain_intra) hopspine::default_plain_config(cfg, c->pic_w, c->pic_h, p->qp, c->bd_y); else hopspine::default_hop_config(cfg, c->pic_w, c->pic_h, p->qp, p->mi_size);
   cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
-  if (cfg.wpp && p->wavefront_lag <= 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
+  if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
   // streams > 1: one view of the context (own stream, own work areas) per CTU row in flight; their launch chains overlap on the device
@@ -321,16 +321,18 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
     if ((int)lanes.size() != nv) { for (auto b : vbe) delete b; for (auto v : views) hop_ctx_destroy(v); return hop_set_err(c, HOP_ERR_DEVICE, "hop_encode_frame: could not create %d views", nv); }
   }
   memset(g_stat_ms, 0, sizeof(g_stat_ms)); memset(g_stat_calls, 0, sizeof(g_stat_calls));
-  hopspine::Encoder enc(cfg, &be);
+  hopspine::LogBackend* lg = (lanes.empty() && getenv("HOP_SPINE_LOG")) ? new hopspine::LogBackend(&be, getenv("HOP_SPINE_LOG")) : nullptr;   // debugging aid: every request and its answer
+  hopspine::BatchInner* use = lg ? (hopspine::BatchInner*)lg : (hopspine::BatchInner*)&be;
+  hopspine::Encoder enc(cfg, use);
   FILE* tf = nullptr;
   if (p->trace_path && p->trace_path[0]) { tf = fopen(p->trace_path, "w"); enc.trace = tf; }
   int rc = HOP_OK;
   try {
     if (!lanes.empty()) enc.encode_frame_wavefront_direct(lanes.data(), (int)lanes.size(), p->wavefront_lag);
-    else if (p->wavefront_lag > 0 && getenv("HOP_SPINE_LOG")) { hopspine::LogBackend lg(&be, getenv("HOP_SPINE_LOG")); enc.encode_frame_wavefront(&lg, p->wavefront_lag); }
-    else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(&be, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
+    else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
     else enc.encode_frame(p->first_ctus);
   } catch (const Bail& b) { rc = b.code; } catch (...) { rc = c->err[0] ? HOP_ERR_DEVICE : HOP_ERR_STATE; }
+  delete lg;
   if (tf) fclose(tf);
   for (auto b : vbe) delete b;
   for (auto v : views) { if (rc != HOP_OK && v->err[0] && !c->err[0]) strncpy(c->err, v->err, sizeof(c->err) - 1); hop_ctx_destroy(v); }

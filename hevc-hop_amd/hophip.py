@@ -111,10 +111,26 @@ class HopError(RuntimeError):
     pass
 
 
+# every mirror of a hophip.h struct kept in this file, by the C name hop_sizeof() knows it under; load() refuses a library whose structs have another size
+MIRRORS = {"hop_pu_job": PU_JOB_DTYPE, "hop_pu_result": PU_RESULT_DTYPE, "hop_pred_job": PredJob, "hop_dist_job": DistJob, "hop_tu_job": TU_JOB_DTYPE, "hop_tu_result": TuResult,
+           "hop_intra_job": INTRA_JOB_DTYPE, "hop_rdoq_job": RDOQ_JOB_DTYPE, "hop_coeff_bits_job": COEFF_BITS_JOB_DTYPE, "hop_tu_rd_job": TU_RD_JOB_DTYPE,
+           "hop_tu_rd_result": TU_RD_RESULT_DTYPE, "hop_intra_modes_job": INTRA_MODES_JOB_DTYPE, "hop_intra_modes_result": INTRA_MODES_RESULT_DTYPE, "hop_rqt_job": RQT_JOB_DTYPE,
+           "hop_rqt_result": RQT_RESULT_DTYPE, "hop_cu_syntax": CU_SYNTAX_DTYPE, "hop_intra_cu_syntax": INTRA_CU_SYNTAX_DTYPE, "hop_intra_rqt_opt": INTRA_RQT_OPT_DTYPE,
+           "hop_intra_search_job": INTRA_SEARCH_JOB_DTYPE, "hop_intra_search_result": INTRA_SEARCH_RESULT_DTYPE, "hop_cu_part": CU_PART_DTYPE, "hop_enc_params": EncParams}
+
+
+def mirror_size(m):
+    return m.itemsize if isinstance(m, np.dtype) else ctypes.sizeof(m)
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise HopError("libhophip.so is not built (run `make -C hevc-hop_amd` or __graft_entry__.build()); there is no CPU fallback")
     L = ctypes.CDLL(LIB_PATH)
+    L.hop_sizeof.argtypes = [ctypes.c_char_p]
+    for name, m in MIRRORS.items():
+        if L.hop_sizeof(name.encode()) != mirror_size(m):
+            raise HopError("%s: this binding lays the struct out in %d bytes, libhophip.so in %d" % (name, mirror_size(m), L.hop_sizeof(name.encode())))
     L.hop_last_error.restype = ctypes.c_char_p
     L.hop_last_error.argtypes = [ctypes.c_void_p]
     L.hop_version.restype = ctypes.c_char_p

@@ -250,4 +250,41 @@ int hop_cabac_split_init(uint8_t split_ctx[3], int slice_type, int qp) {   // IN
   return HOP_OK;
 }
 
+// sizeof of every struct of hophip.h as this library was compiled: a binding checks its own mirror against it before the first call (hophip.py does, at load)
+int hop_sizeof(const char* name) {
+  if (!name) return -1;
+#define S(T) if (!strcmp(name, #T)) return (int)sizeof(T)
+  S(hop_pu_job);
+  S(hop_pu_result);
+  S(hop_pred_job);
+  S(hop_dist_job);
+  S(hop_tu_job);
+  S(hop_tu_result);
+  S(hop_intra_job);
+  S(hop_estbits);
+  S(hop_rdoq_job);
+  S(hop_cabac_ctx);
+  S(hop_coeff_bits_job);
+  S(hop_tu_rd_job);
+  S(hop_tu_rd_result);
+  S(hop_intra_modes_job);
+  S(hop_intra_modes_result);
+  S(hop_rqt_job);
+  S(hop_rqt_result);
+  S(hop_cu_final);
+  S(hop_cabac_cu_ctx);
+  S(hop_cu_syntax);
+  S(hop_intra_cu_syntax);
+  S(hop_intra_rqt_opt);
+  S(hop_intra_search_job);
+  S(hop_intra_search_result);
+  S(hop_intra_chroma_result);
+  S(hop_inter_class);
+  S(hop_intra_class);
+  S(hop_cu_part);
+  S(hop_enc_params);
+#undef S
+  return -1;
+}
+
 } // extern "C"

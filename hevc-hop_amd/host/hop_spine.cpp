@@ -899,10 +899,14 @@ void Encoder::encode_frame(int first_ctus) {
   hop_cabac_init(&k.r, cfg_.slice_type, cfg_.qp); hop_cabac_cu_init(&k.c, cfg_.slice_type, cfg_.qp); hop_cabac_split_init(k.split, cfg_.slice_type, cfg_.qp);
   CtuWorker* w = new CtuWorker(*this, 0);
   const int n = (first_ctus > 0 && first_ctus < n_ctu()) ? first_ctus : n_ctu();
+  Coder sync = k;                                                       // WaveFrontSynchro: the coder after the second CTU of the row above
   for (int a = 0; a < n; a++) {
+    const int col = a % wctu_;
+    if (cfg_.wpp && col == 0 && a > 0 && wctu_ >= 2) { k = sync; coder_set_frac(k, 0); }   // as in the wavefront below (TEncSlice.cpp:1057-1090)
     ctu_entry[a] = k;
     Coder next; w->compress_ctu(a, k, next);
     k = next;
+    if (cfg_.wpp && col == 1) sync = k;
     if (trace) { fputs(ctu_trace[a].c_str(), trace); ctu_trace[a].clear(); }
   }
   n_candidates += w->n_cand_;

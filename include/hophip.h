@@ -597,6 +597,9 @@ typedef struct {
   int16_t mv[2], mvd[2], gt[8];
 } hop_cu_part;
 int hop_sizeof_cu_part(void);
+/* sizeof(<name>) for any struct of this header ("hop_pu_job", "hop_rqt_job", ...) as the library was compiled, -1 for an unknown name: a binding in another language
+ * checks its mirror of each struct against it before its first call. */
+int hop_sizeof(const char* name);
 /* replaces: TComRdCost::isValidPattern (TLibCommon/TComRdCost.cpp:430-443) on the resident SS reference for n queries of 6 values: PU x, y, w, h, vector (quarter-pel, as
  * the caller clipped it): out[i] = 1 if the two probe samples below the displaced block are not the sentinel. */
 int hop_valid_pattern(hop_ctx* ctx, int n, const int32_t* xywh_mv, uint8_t* out);

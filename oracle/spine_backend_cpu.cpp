@@ -235,10 +235,11 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
                               double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, double* rounds_requests) {
   EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1;
   CpuBackend be(w, h, 8, y, cb, cr);
-  Encoder enc(cfg, &be);
-  if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
   LogBackend* lg = getenv("HOP_SPINE_LOG") ? new LogBackend(&be, getenv("HOP_SPINE_LOG")) : NULL;
-  try { enc.encode_frame_wavefront(lg ? (BatchInner*)lg : (BatchInner*)&be, lag > 0 ? lag : 1 << 20); delete lg; } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
+  BatchInner* use = lg ? (BatchInner*)lg : (BatchInner*)&be;
+  Encoder enc(cfg, use);
+  if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
+  try { if (lag > 0) enc.encode_frame_wavefront(use, lag); else enc.encode_frame(0); delete lg; } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));

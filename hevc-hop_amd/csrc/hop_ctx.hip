@@ -63,6 +63,7 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
   c->pic_w = pic_w; c->pic_h = pic_h; c->bd_y = bit_depth_y; c->bd_c = bit_depth_c; c->device = device;
   c->stride_y = pic_w + 2 * HOP_MARGIN_Y; c->stride_c = (pic_w >> 1) + 2 * HOP_MARGIN_C;
+  { const char* f = getenv("HOP_FUSED_LEAF"); c->fused_leaf_max = f ? atoi(f) : 8192; }
   { const char* f = getenv("HOP_SS_FAMILIES"); c->ss_families = !(f && f[0] == '0'); }   // developer switch: the results do not depend on it
   if (hipSetDevice(device) != hipSuccess) { free(c); return hop_set_err(nullptr, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
   hipDeviceProp_t prop;
@@ -116,7 +117,7 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   *out = nullptr;
   hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
   c->pic_w = parent->pic_w; c->pic_h = parent->pic_h; c->bd_y = parent->bd_y; c->bd_c = parent->bd_c; c->device = parent->device;
-  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
+  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->sub_h = parent->sub_h; c->sub_pitch = parent->sub_pitch; c->fused_leaf_max = parent->fused_leaf_max; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
   c->org_y = parent->org_y; c->org_cb = parent->org_cb; c->org_cr = parent->org_cr;
   for (int k = 0; k < 3; k++) { c->ss_alloc[k] = parent->ss_alloc[k]; c->ss_buf[k] = parent->ss_buf[k]; c->ss00[k] = parent->ss00[k]; c->pred[k] = parent->pred[k]; c->rec[k] = parent->rec[k]; }
   c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots;
@@ -126,6 +127,21 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e != hipSuccess) { hop_set_err(parent, HOP_ERR_DEVICE, "hop_ctx_create_view: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
   *out = c;
+  return HOP_OK;
+}
+
+// Several independent pictures of equal size in one context, so that one batch of requests serves CTUs of all of them (hop_encode_frame codes them side by side): the
+// context's picture is their stack, picture k at rows k * sub_pitch .. k * sub_pitch + sub_h - 1, the rows between them unused.  The gap keeps every sample a picture's
+// searches, margins and prefetches can touch (its margin + guard rows above and below) away from its neighbours', so each picture is coded exactly as in a context of its own.
+int hop_set_fused_leaf(hop_ctx* c, int max_tus) { if (!c || max_tus < 0) return hop_set_err(c, HOP_ERR_ARG, "hop_set_fused_leaf: bad argument"); c->fused_leaf_max = max_tus; return HOP_OK; }
+
+int hop_stack_pitch(int sub_h) { return ((sub_h + 63) / 64) * 64 + 64 * ((2 * (HOP_MARGIN_Y + HOP_GUARD_ROWS) + 63) / 64); }
+int hop_ctx_set_stack(hop_ctx* c, int sub_h, int sub_pitch) {
+  if (!c || c->is_view) return hop_set_err(c, HOP_ERR_ARG, "hop_ctx_set_stack: bad argument");
+  if (sub_h == 0 && sub_pitch == 0) { c->sub_h = c->sub_pitch = 0; return HOP_OK; }
+  if (sub_h <= 0 || (sub_h & 7) || (sub_pitch & 63) || sub_pitch < hop_stack_pitch(sub_h) || c->pic_h < sub_h || (c->pic_h - sub_h) % sub_pitch)
+    return hop_set_err(c, HOP_ERR_ARG, "hop_ctx_set_stack: a %d-row context is not a stack of %d-row pictures %d rows apart (pitch: a multiple of 64, at least hop_stack_pitch)", c->pic_h, sub_h, sub_pitch);
+  c->sub_h = sub_h; c->sub_pitch = sub_pitch;
   return HOP_OK;
 }
 

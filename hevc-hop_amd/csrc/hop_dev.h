@@ -18,6 +18,8 @@
 struct hop_ctx {
   int pic_w, pic_h, bd_y, bd_c, device;
   int stride_y, stride_c;            // SS-ref strides (with margins)
+  int fused_leaf_max;                // hop_set_fused_leaf: leaf batches of up to this many TUs run as the one-kernel form (default 8192; 0 = always staged)
+  int sub_h, sub_pitch;              // hop_ctx_set_stack: the picture is a stack of independent pictures of sub_h rows, origins sub_pitch rows apart (0, 0: one picture)
   hipStream_t stream;
   // device pictures
   int16_t *org_y, *org_cb, *org_cr;  // original, pitch pic_w / pic_w/2, no margins
@@ -186,6 +188,9 @@ const int32_t* hop_entropy_bits_host(void);
 static inline const int32_t* hop_entropy_bits_device(const hop_ctx* c) { return c->entropy_bits; }
 int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
                      int32_t* d_levels, hop_tu_rd_result* d_res);
+// the same leaf step as one kernel, a workgroup per TU (k_leaf_fused.inl): hop_launch_tu_rd takes it for batches of up to c->fused_leaf_max TUs
+int hop_launch_tu_rd_fused(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
+                           int32_t* d_levels, hop_tu_rd_result* d_res);
 int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx, const int32_t* d_coef,
                           unsigned long long* d_bits, hop_cabac_ctx* d_ctx_out);
 #define HOP_RDOQ_SCAN_ENTRIES (4080 + 255)

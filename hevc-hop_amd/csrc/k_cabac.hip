@@ -275,4 +275,5 @@ int hop_launch_intra_modes(hop_ctx* c, int n, const hop_intra_modes_job* d_jobs,
   return HOP_OK;
 }
 
+#include "k_leaf_fused.inl"
 #include "k_rqt.inl"

@@ -1,0 +1,83 @@
+// k_leaf_fused.inl -- the transform-unit leaf step (row a8b: residual, xT, estBit, RDOQ, counted bits, inverse path, cbf-zero decision; the stages of hop_launch_tu_rd)
+// as ONE kernel, one workgroup per TU.  Included by k_cabac.hip.
+// The staged pipeline of k_tq.hip / k_rdoq.hip is 13 launches per batch and lays its serial stages (RDOQ, bit counting) out one LANE per TU: right for the thousands of
+// TUs of a frozen-reference search, wrong for the RD spine, whose batches hold one TU per CTU in flight and which walks a chain of thousands of such batches per CTU -- there
+// the launches ARE the time.  Here a workgroup takes its TU through all stages: the transforms on all 256 threads (or one wave for 4x4 / 8x8), the serial stages on thread 0
+// in between.  The arithmetic is the staged kernels' own (the shared bodies of k_turd_dev.inl, k_rdoq_dev.inl, cb_code_tu), so the results are identical by construction;
+// tests/test_gpu_tq_intra.py runs both.
+#include "k_turd_dev.inl"
+#include "k_rdoq_dev.inl"
+
+#define LEAF_WORK_PER_TU ((size_t)1024 * RQ_WORK_PER_COEF)           // the RDOQ work area of a 32x32 TU at ws = 1
+
+struct LeafShared {
+  union { TurdFwdShared big; TurdSmallShared small; } t;
+  CabacLds cab;                                                       // column 0: the TU's context states
+  uint16_t scan[1024]; uint16_t scanCG[64]; double cgSig[64];
+};
+
+__global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                    const int64_t* __restrict__ coef_off, const int32_t* __restrict__ entropy_bits, const uint16_t* __restrict__ scans,
+                                                    int32_t* __restrict__ coef, int32_t* __restrict__ levels, uint32_t* __restrict__ zs, uint32_t* __restrict__ ns,
+                                                    uint32_t* __restrict__ as, unsigned long long* __restrict__ fr, hop_estbits* __restrict__ tables,
+                                                    hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb, char* __restrict__ work,
+                                                    hop_tu_rd_result* __restrict__ res, int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
+  __shared__ LeafShared L;
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const hop_tu_rd_job jb = jobs[j];
+  if (jb.log2_size < 2 || jb.log2_size > 5) return;                   // an empty slot of a job table (k_rqt.inl); uniform over the workgroup
+  const bool small = jb.log2_size <= 3;
+  const int LOG2 = jb.log2_size, N2 = 1 << (2 * LOG2), CGN = N2 >> 4;
+  // residual, forward transform (or the transform-skip scaling), distortion of the zero block
+  if (small) { if (tid < 64) turd_forward_small_body(L.t.small, 0, tid, j, jobs, n, pic, coef_off, coef, zs); }
+  else turd_forward_body(L.t.big, j, jobs, pic, coef_off, coef, zs);
+  { const uint16_t* s0 = rq_scan(scans, jb.scan_idx, LOG2); const uint16_t* s1 = rq_scan_cg(scans, jb.scan_idx, LOG2);
+    for (int i = tid; i < N2; i += 256) L.scan[i] = s0[i];
+    for (int i = tid; i < CGN; i += 256) L.scanCG[i] = s1[i]; }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {                                                     // the serial stages
+    turd_setup_body(j, jobs, n, ctx_in, coef_off, entropy_bits, tables, rq, cb);
+    const hop_rdoq_job rj = rq[j];
+    double* wd = (double*)(work + (size_t)j * LEAF_WORK_PER_TU);
+    if (LOG2 == 2) rdoq_tu<2>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
+    else if (LOG2 == 3) rdoq_tu<3>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
+    else if (LOG2 == 4) rdoq_tu<4>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
+    else rdoq_tu<5>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
+    const hop_coeff_bits_job bj = cb[j];
+    { const uint8_t* src = ctx_in[bj.ctx_index].state; for (int i = 0; i < 152; i++) L.cab.st[i][0] = src[i]; }
+    fr[j] = cb_code_tu(L.cab, 0, levels + bj.coeff_offset, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, scans);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // dequantisation, inverse transform, reconstruction (intra) and the distortion of the coded block
+  if (small) { if (tid < 64) turd_inverse_small_body(L.t.small, 0, tid, j, jobs, n, pic, coef_off, levels, as, ns, rec_y, rec_cb, rec_cr); }
+  else turd_inverse_body(L.t.big, j, jobs, pic, coef_off, levels, as, ns, rec_y, rec_cb, rec_cr);
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) turd_decide_body(j, jobs, n, ctx_in, coef_off, entropy_bits, as, fr, zs, ns, levels, res);
+}
+
+size_t hop_tu_rd_fused_scratch(int n, size_t n_coeff) {
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  return al(n_coeff * 4) + 4 * al((size_t)n * 4) + al((size_t)n * 8) + al((size_t)n * sizeof(hop_estbits)) + al((size_t)n * sizeof(hop_rdoq_job)) +
+         al((size_t)n * sizeof(hop_coeff_bits_job)) + (size_t)n * LEAF_WORK_PER_TU + 256;
+}
+
+int hop_launch_tu_rd_fused(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
+                           int32_t* d_levels, hop_tu_rd_result* d_res) {
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_coef = 0, o_zs = al(o_coef + n_coeff * 4), o_ns = al(o_zs + (size_t)n * 4), o_as = al(o_ns + (size_t)n * 4), o_fr = al(o_as + (size_t)n * 4);
+  const size_t o_tab = al(o_fr + (size_t)n * 8), o_rq = al(o_tab + (size_t)n * sizeof(hop_estbits)), o_cb = al(o_rq + (size_t)n * sizeof(hop_rdoq_job));
+  const size_t o_wk = al(o_cb + (size_t)n * sizeof(hop_coeff_bits_job));
+  void* sc; int r = hop_scratch(c, o_wk + (size_t)n * LEAF_WORK_PER_TU + 256, &sc); if (r) return r;
+  char* b = (char*)sc;
+  const int pr = hop_prof_begin(c, HOP_K_TQ, (uint64_t)n);
+  hipLaunchKernelGGL(k_turd_fused, dim3(n), dim3(256), 0, c->stream, d_jobs, n, hop_make_pics(c), d_ctx, d_coef_off, hop_entropy_bits_device(c), c->rdoq_scans,
+                     (int32_t*)(b + o_coef), d_levels, (uint32_t*)(b + o_zs), (uint32_t*)(b + o_ns), (uint32_t*)(b + o_as), (unsigned long long*)(b + o_fr),
+                     (hop_estbits*)(b + o_tab), (hop_rdoq_job*)(b + o_rq), (hop_coeff_bits_job*)(b + o_cb), b + o_wk, d_res, c->rec[0], c->rec[1], c->rec[2]);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "tu_rd (fused) launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

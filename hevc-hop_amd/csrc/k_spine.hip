@@ -10,13 +10,14 @@
 #include <string.h>
 #include <chrono>
 #include <mutex>
+#include <string>
 #include <vector>
 #include "hop_dev.h"
 #include "../host/hop_spine.h"
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hop_set_err((c), HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 #define STASH_SAMPLES 6144          // 64 x 64 luma + 2 x 32 x 32 chroma
-#define STASH_SLOTS 2048
+#define STASH_SLOTS (16 * hopspine::SPINE_LANES)   // 16 per CTU row in flight
 
 __global__ void k_valid_pattern(const int32_t* __restrict__ q, int n, const int16_t* __restrict__ y00, int stride, uint8_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,7 +136,7 @@ struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int
 
 class HipBackend : public BatchInner {
  public:
-  enum { MAXN = 64, MAXP = 1024 };
+  enum { MAXN = 512, MAXP = 16384 };   // candidates of one class / predictor jobs in one batch (one per CTU row in flight, all pictures together)
   explicit HipBackend(hop_ctx* ctx) : c(ctx), arena(nullptr) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
@@ -300,15 +301,18 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   if (!p->plain_intra && (c->bd_y != 8 || c->bd_c != 8)) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: the HOP configuration is 8-bit (the GT warp clips to 255)");
   if (c->bd_y != c->bd_c) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: luma and chroma bit depths must be equal");
   if (p->qp < 0 || p->qp > 51 || p->mi_size <= 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: qp / micro-image size");
+  // a stacked context (hop_ctx_set_stack): its pictures are coded side by side, every one as a picture of its own
+  const int n_pic = c->sub_pitch ? (c->pic_h - c->sub_h) / c->sub_pitch + 1 : 1, pic_h = c->sub_pitch ? c->sub_h : c->pic_h;
+  if (n_pic > 1 && p->wavefront_lag <= 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: the pictures of a stacked context are coded as wavefronts (wavefront_lag > 0)");
   hopspine::EncConfig cfg;
-  if (p->plain_intra) hopspine::default_plain_config(cfg, c->pic_w, c->pic_h, p->qp, c->bd_y); else hopspine::default_hop_config(cfg, c->pic_w, c->pic_h, p->qp, p->mi_size);
+  if (p->plain_intra) hopspine::default_plain_config(cfg, c->pic_w, pic_h, p->qp, c->bd_y); else hopspine::default_hop_config(cfg, c->pic_w, pic_h, p->qp, p->mi_size);
   cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
   if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
   // streams > 1: one view of the context (own stream, own work areas) per CTU row in flight; their launch chains overlap on the device
   std::vector<hop_ctx*> views; std::vector<HipBackend*> vbe; std::vector<Backend*> lanes;
-  if (p->wavefront_lag > 0 && p->streams > 1) {
+  if (p->wavefront_lag > 0 && p->streams > 1 && n_pic == 1) {
     if (!c->stash) { HIPCHK(c, hipMalloc((void**)&c->stash, (size_t)STASH_SLOTS * STASH_SAMPLES * 2)); c->stash_slots = STASH_SLOTS; }
     const int nv = p->streams > 64 ? 64 : p->streams;
     for (int i = 0; i < nv; i++) {
@@ -323,27 +327,39 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   memset(g_stat_ms, 0, sizeof(g_stat_ms)); memset(g_stat_calls, 0, sizeof(g_stat_calls));
   hopspine::LogBackend* lg = (lanes.empty() && getenv("HOP_SPINE_LOG")) ? new hopspine::LogBackend(&be, getenv("HOP_SPINE_LOG")) : nullptr;   // debugging aid: every request and its answer
   hopspine::BatchInner* use = lg ? (hopspine::BatchInner*)lg : (hopspine::BatchInner*)&be;
-  hopspine::Encoder enc(cfg, use);
-  FILE* tf = nullptr;
-  if (p->trace_path && p->trace_path[0]) { tf = fopen(p->trace_path, "w"); enc.trace = tf; }
+  std::vector<hopspine::Encoder*> encs;
+  for (int k = 0; k < n_pic; k++) { cfg.y_origin = k * c->sub_pitch; encs.push_back(new hopspine::Encoder(cfg, use)); }
+  hopspine::Encoder& enc = *encs[0];
+  std::vector<FILE*> tfs;                                                  // candidate traces: trace_path, for the pictures of a stack trace_path.<k>
+  if (p->trace_path && p->trace_path[0]) for (int k = 0; k < n_pic; k++) {
+    std::string name = p->trace_path; if (n_pic > 1) name += "." + std::to_string(k);
+    FILE* f = fopen(name.c_str(), "w"); tfs.push_back(f); encs[k]->trace = f;
+  }
   int rc = HOP_OK;
   try {
-    if (!lanes.empty()) enc.encode_frame_wavefront_direct(lanes.data(), (int)lanes.size(), p->wavefront_lag);
+    if (n_pic > 1) { hopspine::Encoder::encode_pictures_wavefront(encs.data(), n_pic, use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
+    else if (!lanes.empty()) enc.encode_frame_wavefront_direct(lanes.data(), (int)lanes.size(), p->wavefront_lag);
     else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; }
     else enc.encode_frame(p->first_ctus);
   } catch (const Bail& b) { rc = b.code; } catch (...) { rc = c->err[0] ? HOP_ERR_DEVICE : HOP_ERR_STATE; }
   delete lg;
-  if (tf) fclose(tf);
+  for (FILE* f : tfs) if (f) fclose(f);
   for (auto b : vbe) delete b;
   for (auto v : views) { if (rc != HOP_OK && v->err[0] && !c->err[0]) strncpy(c->err, v->err, sizeof(c->err) - 1); hop_ctx_destroy(v); }
-  if (rc != HOP_OK) return rc;
-  const int n = enc.n_ctu();
-  if (ctu_cost) memcpy(ctu_cost, enc.ctu_cost.data(), n * sizeof(double));
-  if (ctu_bits) memcpy(ctu_bits, enc.ctu_bits.data(), n * 4);
-  if (ctu_dist) memcpy(ctu_dist, enc.ctu_dist.data(), n * 4);
-  if (parts) memcpy(parts, enc.pic.data(), enc.pic.size() * sizeof(hopspine::Part));
-  if (n_candidates) *n_candidates = enc.n_candidates;
-  return HOP_OK;
+  if (rc == HOP_OK) {
+    const int n = enc.n_ctu();
+    if (n_candidates) *n_candidates = 0;
+    for (int k = 0; k < n_pic; k++) {                                     // picture k's results at [k * n, (k + 1) * n)
+      const hopspine::Encoder& e = *encs[k];
+      if (ctu_cost) memcpy(ctu_cost + (size_t)k * n, e.ctu_cost.data(), n * sizeof(double));
+      if (ctu_bits) memcpy(ctu_bits + (size_t)k * n, e.ctu_bits.data(), n * 4);
+      if (ctu_dist) memcpy(ctu_dist + (size_t)k * n, e.ctu_dist.data(), n * 4);
+      if (parts) memcpy(parts + (size_t)k * n * 256, e.pic.data(), e.pic.size() * sizeof(hopspine::Part));
+      if (n_candidates) *n_candidates += e.n_candidates;
+    }
+  }
+  for (auto e : encs) delete e;
+  return rc;
 }
 
 }  // extern "C"

@@ -199,13 +199,34 @@ def load():
 class Context:
     """Thin RAII wrapper over hop_ctx_* for the tests and the bench."""
 
-    def __init__(self, pic_w, pic_h, bit_depth=8, device=0, lib=None):
+    def __init__(self, pic_w, pic_h, bit_depth=8, device=0, lib=None, pictures=1):
+        """pictures > 1: a stacked context (hop_ctx_set_stack) of that many independent pic_w x pic_h pictures; self.H is the height of the stack, self.sub_h / self.pitch
+        the pictures' height and spacing, picture k at rows k * pitch."""
         self.L = lib or load()
         self.h = ctypes.c_void_p()
+        self.pictures, self.sub_h, self.pitch = pictures, pic_h, 0
+        if pictures > 1:
+            self.pitch = self.L.hop_stack_pitch(pic_h)
+            pic_h = (pictures - 1) * self.pitch + pic_h
         self.W, self.H = pic_w, pic_h
         r = self.L.hop_ctx_create(ctypes.byref(self.h), pic_w, pic_h, bit_depth, bit_depth, device)
         if r != 0:
             raise HopError("hop_ctx_create: %d %s" % (r, self.L.hop_last_error(None).decode()))
+        if pictures > 1:
+            self.L.hop_ctx_set_stack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            self._chk(self.L.hop_ctx_set_stack(self.h, self.sub_h, self.pitch), "hop_ctx_set_stack")
+
+    def stack(self, planes, chroma=False):
+        """the pictures' planes (a list of arrays) laid out as the context's stack"""
+        sh, pt = (self.sub_h >> 1, self.pitch >> 1) if chroma else (self.sub_h, self.pitch)
+        out = np.zeros(((self.pictures - 1) * pt + sh, planes[0].shape[1]), np.int16)
+        for k, a in enumerate(planes):
+            out[k * pt:k * pt + sh] = a
+        return out
+
+    def unstack(self, plane, chroma=False):
+        sh, pt = (self.sub_h >> 1, self.pitch >> 1) if chroma else (self.sub_h, self.pitch)
+        return [plane[k * pt:k * pt + sh] for k in range(self.pictures)]
 
     def close(self):
         if self.h:
@@ -288,7 +309,7 @@ class Context:
         L = self.L
         L.hop_encode_frame.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_void_p]
         assert L.hop_sizeof_cu_part() == CU_PART_DTYPE.itemsize
-        n = ((self.W + 63) // 64) * ((self.H + 63) // 64)
+        n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures      # a stacked context: picture k's CTUs at [k * n / pictures, ...)
         cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32); parts = np.zeros((n, 256), CU_PART_DTYPE)
         nc = ctypes.c_uint64(0)
         p = EncParams(qp, mi_size, first_ctus, wpp, wavefront_lag, plain_intra, streams, trace_path.encode() if trace_path else None)

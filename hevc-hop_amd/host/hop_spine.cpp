@@ -260,7 +260,7 @@ void CtuWorker::check_best_mode(int d, bool save_recon) {
   trace_candidate(*temp_[d]);
   if (temp_[d]->cost < best_[d]->cost) {
     std::swap(best_[d], temp_[d]);
-    if (save_recon) { tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y, best_[d]->size); }
+    if (save_recon) { tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y + cfg.y_origin, best_[d]->size); }
     sb_[d][CI_NEXT] = sb_[d][CI_TEMP];
   }
 }
@@ -389,7 +389,7 @@ void CtuWorker::pu_pred_job(const CuData& c, int pu, hop_pred_job& j) {
   int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
   const Part& p = *part_at(c, c.x + ox, c.y + oy);
   memset(&j, 0, sizeof(j));
-  j.pu_x = c.x + ox; j.pu_y = c.y + oy; j.w = w; j.h = h;
+  j.pu_x = c.x + ox; j.pu_y = c.y + oy + cfg.y_origin; j.w = w; j.h = h;
   int mh = p.mv[0], mvv = p.mv[1]; clip_mv(c, mh, mvv);
   j.mv_x = mh; j.mv_y = mvv; j.use_gt = (!p.merge_flag && p.gt_flag) ? 1 : 0;
   for (int k = 0; k < 8; k++) j.gt[k] = p.gt[k];
@@ -429,7 +429,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
         for (int i = 0; i < info.n; i++) {
           if (!valid_pattern(px, py, w, h, info.cand[i][0], info.cand[i][1])) continue;
           hop_pred_job& j = tj[nt]; memset(&j, 0, sizeof(j));
-          j.pu_x = px; j.pu_y = py; j.w = w; j.h = h;
+          j.pu_x = px; j.pu_y = py + cfg.y_origin; j.w = w; j.h = h;
           int mh = info.cand[i][0], mvv = info.cand[i][1]; clip_mv(c, mh, mvv);
           j.mv_x = mh; j.mv_y = mvv; j.use_gt = 0;
           ti[nt++] = i;
@@ -448,7 +448,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       bits += 1;                                                          // m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS]
       // xMotionEstimation (:4479-4683)
       hop_pu_job j; memset(&j, 0, sizeof(j));
-      j.pu_x = px; j.pu_y = py; j.w = w; j.h = h;
+      j.pu_x = px; j.pu_y = py + cfg.y_origin; j.w = w; j.h = h;
       int offx, offy; part_offset(ps, c.size, pu, offx, offy);
       int r6[6];
       hop_set_search_range(cfg.pic_w, cfg.pic_h, c.x, c.y, c.size, c.ctu_addr, E.wctu_, pred[0], pred[1], cfg.search_range, offx, offy, c.y == 0, c.x == 0, r6);
@@ -513,7 +513,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
           int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(c, mh, mvv);
           if (mc.f[k].ref == 0 && !valid_pattern(px, py, w, h, mh, mvv)) continue;
           hop_pred_job& j = mj[nm]; memset(&j, 0, sizeof(j));
-          j.pu_x = px; j.pu_y = py; j.w = w; j.h = h; j.mv_x = mh; j.mv_y = mvv;
+          j.pu_x = px; j.pu_y = py + cfg.y_origin; j.w = w; j.h = h; j.mv_x = mh; j.mv_y = mvv;
           j.use_gt = (!base.merge_flag && base.gt_flag) ? 1 : 0; for (int q = 0; q < 8; q++) j.gt[q] = base.gt[q];
           mi[nm++] = k;
         }
@@ -549,7 +549,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
 // ---- candidate evaluation through the backend ----
 static void fill_rqt_job(const EncConfig& cfg, const CuData& c, bool intra, int part_size, hop_rqt_job& j) {
   memset(&j, 0, sizeof(j));
-  j.x = c.x; j.y = c.y; j.log2_cu = 6 - c.depth;
+  j.x = c.x; j.y = c.y + cfg.y_origin; j.log2_cu = 6 - c.depth;
   for (int k = 0; k < 3; k++) { j.qp_scaled[k] = cfg.qp_scaled[k]; j.lambda_rdoq[k] = cfg.lambda_rdoq[k]; }
   j.ctx_index = 0; j.sign_hide = cfg.sign_hide; j.use_ts = cfg.use_ts; j.log2_max_tu = cfg.log2_max_tu;
   // TComDataCU::getQuadtreeTULog2MinSizeInCU (TComDataCU.cpp:1860-1886)
@@ -808,8 +808,8 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   copy_to_pic(*best_[d]);
   tag_exit(d, node_abs);
   if (!boundary) {
-    if (!split_is_best) be->recon_restore(lane_, d, x, y, size);           // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture
-    be->commit(lane_, x, y, size);                                         // xCopyYuv2SSRef (:872-880)
+    if (!split_is_best) be->recon_restore(lane_, d, x, y + cfg.y_origin, size);           // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture
+    be->commit(lane_, x, y + cfg.y_origin, size);                                         // xCopyYuv2SSRef (:872-880)
     for (int yy = y >> 3; yy < (y + size) >> 3; yy++) memset(&E.committed[(size_t)yy * (cfg.pic_w >> 3) + (x >> 3)], 1, size >> 3);
   }
 }
@@ -923,7 +923,7 @@ enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTOR
 class Rendezvous : public Backend {
  public:
   Rendezvous(BatchInner* inner, int n_threads) : rounds(0), requests(0), inner_(inner), active_(n_threads), failed_(false) { memset(tag_of_, 0, sizeof(tag_of_)); }
-  void set_tag(int lane, uint64_t tag) { tag_of_[lane & 127] = tag; }
+  void set_tag(int lane, uint64_t tag) { tag_of_[lane % SPINE_LANES] = tag; }
   // a row thread is about to block on another row's progress / has been released / has finished
   std::mutex m; std::condition_variable cv;
   void begin_frame() {}
@@ -948,7 +948,7 @@ class Rendezvous : public Backend {
   bool failed() const { return failed_; }
   uint64_t rounds, requests;
  private:
-  BatchInner* inner_; int active_; bool failed_; std::vector<Req*> pending_; uint64_t tag_of_[128];
+  BatchInner* inner_; int active_; bool failed_; std::vector<Req*> pending_; uint64_t tag_of_[SPINE_LANES];
   void idle(std::unique_lock<std::mutex>& lk) {       // the caller stops running; if it was the last one, it serves what is pending first
     active_--;
     while (active_ == 0 && !pending_.empty()) serve(lk);
@@ -956,7 +956,7 @@ class Rendezvous : public Backend {
   void submit(Req& q) {
     std::unique_lock<std::mutex> lk(m);
     if (failed_) throw 1;
-    q.tag = tag_of_[q.lane & 127];
+    q.tag = tag_of_[q.lane % SPINE_LANES];
     pending_.push_back(&q);
     active_--;
     while (active_ == 0 && !pending_.empty() && !q.done) serve(lk);
@@ -1029,31 +1029,42 @@ class Rendezvous : public Backend {
 };
 }  // namespace
 
-void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int max_rows) { wavefront(inner, NULL, 0, lag, max_rows); }
-void Encoder::encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag) { wavefront(NULL, lanes, n_lanes, lag, n_lanes); }
+void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int) { Encoder* e = this; wavefront_many(&e, 1, inner, NULL, 0, lag); }
+void Encoder::encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag) { Encoder* e = this; wavefront_many(&e, 1, NULL, lanes, n_lanes, lag); }
+void Encoder::encode_pictures_wavefront(Encoder* const* encs, int n, BatchInner* inner, int lag) { wavefront_many(encs, n, inner, NULL, 0, lag); }
 
-void Encoder::wavefront(BatchInner* inner, Backend* const* lanes, int n_lanes, int lag, int max_rows) {
-  if (!cfg_.wpp || (!inner && n_lanes <= 0)) throw 1;
+// n pictures of equal geometry side by side (n = 1: one picture): one thread per CTU row of every picture, all of them on one rendezvous
+void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner, Backend* const* lanes, int n_lanes, int lag) {
+  if (n_pic <= 0 || (!inner && n_lanes <= 0) || lag <= 0) throw 1;
+  Encoder& E0 = *encs[0];
+  const int rows = E0.hctu_, cols = E0.wctu_;
+  for (int p = 0; p < n_pic; p++) if (!encs[p]->cfg_.wpp || encs[p]->hctu_ != rows || encs[p]->wctu_ != cols) throw 1;
+  if (lag > cols) lag = cols;                                          // lag = cols is raster order already
+  const int rif = (cols + lag - 1) / lag + 1;                          // rows of one picture that can be in flight together (+ 1 spare)
+  if ((long)n_pic * (rif < rows ? rif : rows) > SPINE_LANES) throw 1;
   if (inner) inner->begin_frame(); else lanes[0]->begin_frame();
-  for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
-  std::fill(committed.begin(), committed.end(), (uint8_t)0);
   Coder init; memset(&init, 0, sizeof(init));
-  hop_cabac_init(&init.r, cfg_.slice_type, cfg_.qp); hop_cabac_cu_init(&init.c, cfg_.slice_type, cfg_.qp); hop_cabac_split_init(init.split, cfg_.slice_type, cfg_.qp);
-  const int rows = hctu_, cols = wctu_;
-  Rendezvous rv(inner, rows);
-  // synchronous wavefront: step s holds the CTUs (r, c) with c + lag * r == s; a step starts when the previous one has finished, so that its CTUs start together
-  // (their requests then carry equal tags and meet in the batches) and every CTU finds rows above it coded up to column c + lag - 1
+  hop_cabac_init(&init.r, E0.cfg_.slice_type, E0.cfg_.qp); hop_cabac_cu_init(&init.c, E0.cfg_.slice_type, E0.cfg_.qp); hop_cabac_split_init(init.split, E0.cfg_.slice_type, E0.cfg_.qp);
+  for (int p = 0; p < n_pic; p++) {
+    Encoder& E = *encs[p];
+    for (size_t i = 0; i < E.pic.size(); i++) part_init(E.pic[i], 0);
+    std::fill(E.committed.begin(), E.committed.end(), (uint8_t)0);
+  }
+  Rendezvous rv(inner, rows * n_pic);
+  // synchronous wavefront: step s holds the CTUs (r, c) with c + lag * r == s of every picture; a step starts when the previous one has finished, so that its CTUs start
+  // together (their requests then carry equal tags and meet in the batches) and every CTU finds the rows above it coded up to column c + lag - 1
   const int n_steps = cols + lag * (rows - 1);
   std::vector<int> in_step(n_steps, 0), fin_step(n_steps, 0);
-  for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) if ((long)c + (long)lag * r < n_steps) in_step[c + lag * r]++;
+  for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) in_step[c + lag * r] += n_pic;
   int steps_complete = -1;                                             // all steps <= this one are finished
-  std::vector<Coder> sync(rows);                                       // the coder after the second CTU of each row (WaveFrontSynchro)
-  std::vector<uint64_t> cand(rows, 0);
+  std::vector<Coder> sync((size_t)rows * n_pic);                       // the coder after the second CTU of each row (WaveFrontSynchro)
+  std::vector<uint64_t> cand((size_t)rows * n_pic, 0);
   std::vector<std::thread> th;
-  (void)max_rows;
-  for (int r = 0; r < rows; r++) {
-    th.emplace_back([&, r]() {
-      CtuWorker* w = new CtuWorker(*this, r % 128, inner ? (Backend*)&rv : lanes[r % n_lanes]);
+  for (int p = 0; p < n_pic; p++) for (int r = 0; r < rows; r++) {
+    th.emplace_back([&, p, r]() {
+      Encoder& E = *encs[p];
+      const int lane = p * (rif < rows ? rif : rows) + r % rif;
+      CtuWorker* w = new CtuWorker(E, lane, inner ? (Backend*)&rv : lanes[(p * rows + r) % n_lanes]);
       int c = 0;
       try {
         Coder k = init;
@@ -1063,20 +1074,20 @@ void Encoder::wavefront(BatchInner* inner, Backend* const* lanes, int n_lanes, i
             std::unique_lock<std::mutex> lk(rv.m);
             rv.wait_until(lk, [&] { return steps_complete >= st - 1; });
             if (rv.failed()) break;
-            if (c == 0 && r > 0 && cols >= 2) { k = sync[r - 1]; coder_set_frac(k, 0); }   // loadContexts: the contexts of the row above after its second CTU, the row's own (fresh) bin coder
+            if (c == 0 && r > 0 && cols >= 2) { k = sync[(size_t)p * rows + r - 1]; coder_set_frac(k, 0); }   // loadContexts: the contexts of the row above after its second CTU, the row's own (fresh) bin coder
           }
           const int a = r * cols + c;
-          ctu_entry[a] = k;
+          E.ctu_entry[a] = k;
           Coder next; w->compress_ctu(a, k, next);
           k = next;
           std::unique_lock<std::mutex> lk(rv.m);
-          if (c == 1) sync[r] = k;
+          if (c == 1) sync[(size_t)p * rows + r] = k;
           fin_step[st]++;
           while (steps_complete + 1 < n_steps && fin_step[steps_complete + 1] == in_step[steps_complete + 1]) steps_complete++;
           rv.cv.notify_all();
         }
       } catch (...) {}
-      cand[r] = w->n_cand_;
+      cand[(size_t)p * rows + r] = w->n_cand_;
       delete w;
       std::unique_lock<std::mutex> lk(rv.m);
       for (; c < cols; c++) { fin_step[c + lag * r]++; }               // after a failure: nobody waits for this row
@@ -1086,9 +1097,12 @@ void Encoder::wavefront(BatchInner* inner, Backend* const* lanes, int n_lanes, i
     });
   }
   for (auto& t : th) t.join();
-  for (int r = 0; r < rows; r++) n_candidates += cand[r];
-  batch_rounds = rv.rounds; batch_requests = rv.requests;
-  if (trace) for (int a = 0; a < n_ctu(); a++) { fputs(ctu_trace[a].c_str(), trace); ctu_trace[a].clear(); }
+  for (int p = 0; p < n_pic; p++) {
+    Encoder& E = *encs[p];
+    for (int r = 0; r < rows; r++) E.n_candidates += cand[(size_t)p * rows + r];
+    E.batch_rounds = rv.rounds; E.batch_requests = rv.requests;
+    if (E.trace) for (int a = 0; a < E.n_ctu(); a++) { fputs(E.ctu_trace[a].c_str(), E.trace); E.ctu_trace[a].clear(); }
+  }
   if (rv.failed()) throw 1;
 }
 

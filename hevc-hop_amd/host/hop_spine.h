@@ -28,6 +28,7 @@ struct EncConfig {
   int amp, fen, hadme, fdm, esd, cfm, ecu;
   int log2_max_tu, log2_min_tu, tu_max_depth_inter, tu_max_depth_intra;
   int sign_hide, use_ts, ts_fast, strong_intra;
+  int y_origin;                    // added to the y coordinate of every request: the picture's first row in a stacked context (hop_ctx_set_stack), else 0
   int wpp;                         // 0: contexts run on from CTU to CTU in raster order (shipped configurations); 1: WaveFrontSynchro rows
   // derived by finish_config()
   double lambda, sqrt_lambda, lambda_rdoq[3], dist_weight[2];
@@ -38,6 +39,7 @@ void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size)
 void default_plain_config(EncConfig& c, int pic_w, int pic_h, int qp, int bit_depth);   // cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg: I slice, no SS / GT
 void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
 
+enum { SPINE_LANES = 512 };       // CTU rows in flight at once (all pictures together); a lane owns 16 stash slots
 typedef hop_cu_part Part;          // one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
 
 struct CuData {                    // TComDataCU as the RD search uses it (one CU of the quadtree, or the whole CTU)
@@ -155,8 +157,11 @@ class Encoder {
   void encode_frame_wavefront(BatchInner* inner, int lag = 5, int max_rows_in_flight = 0);
   // the same wavefront without batching: row r talks to lanes[r % n_lanes] directly (backends that run concurrently, e.g. one stream each); at most n_lanes rows in flight
   void encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag = 5);
+  // n independent pictures of equal geometry (their configurations differ in y_origin: a stacked context) coded side by side: the rows of all of them on one
+  // rendezvous, so that a batch serves CTUs of every picture; each picture's result is what encode_frame_wavefront gives for it alone
+  static void encode_pictures_wavefront(Encoder* const* encs, int n, BatchInner* inner, int lag = 5);
  private:
-  void wavefront(BatchInner* inner, Backend* const* lanes, int n_lanes, int lag, int max_rows);
+  static void wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner, Backend* const* lanes, int n_lanes, int lag);
  public:
   const EncConfig& config() const { return cfg_; }
   int n_ctu() const { return wctu_ * hctu_; }

@@ -108,6 +108,19 @@ const char* hop_last_error(const hop_ctx* ctx);     /* ctx may be NULL: error of
 int hop_sync(hop_ctx* ctx);
 void* hop_stream(hop_ctx* ctx);                     /* hipStream_t the *_device calls are ordered on */
 
+/* The transform-unit leaf step (hop_tu_rd and everything built on it) has two forms with identical results: a pipeline of 13 kernels that lays the serial stages out one
+ * lane per TU (batches of thousands of TUs) and one kernel with a workgroup per TU (the launch-bound batches of the RD search).  Batches of up to max_tus TUs take the
+ * one-kernel form (default 8192, or the environment's HOP_FUSED_LEAF); 0 = always the pipeline. */
+int hop_set_fused_leaf(hop_ctx* ctx, int max_tus);
+
+/* Several independent pictures of equal size in ONE context (no counterpart in the reference, which codes one picture at a time: the pictures of an all-intra sequence do
+ * not depend on each other, TAppEncTop.cpp:432-520 codes them in a loop).  The context is created with the height of the stack: picture k occupies rows
+ * k * sub_pitch .. k * sub_pitch + sub_h - 1, sub_pitch = hop_stack_pitch(sub_h) or more (a multiple of 64), pic_h = (n - 1) * sub_pitch + sub_h; the rows between the
+ * pictures are never read.  Every entry point keeps taking coordinates in the stack; hop_encode_frame codes the pictures side by side, one batch of requests serving CTUs
+ * of all of them, each exactly as in a context of its own.  sub_h = sub_pitch = 0 returns to one picture. */
+int hop_stack_pitch(int sub_h);
+int hop_ctx_set_stack(hop_ctx* ctx, int sub_h, int sub_pitch);
+
 /* ---- picture residency ---- */
 /* replaces: the host copy of the original into TComPic (TLibEncoder/TEncTop.cpp:363-368) */
 int hop_upload_orig(hop_ctx* ctx, const int16_t* y, int stride_y, const int16_t* cb, const int16_t* cr, int stride_c);
@@ -616,7 +629,9 @@ int hop_ssref_commit_recon(hop_ctx* ctx, int n, const int32_t* rect4);
  * from CTU to CTU): every candidate is evaluated by this library's kernels, the decisions are taken by the host spine (host/hop_spine.cpp).  The original must be resident
  * (hop_upload_orig).  ctu_cost / ctu_bits / ctu_dist: getTotalCost / Bits / Distortion of every CTU (what the reference appends to cost.csv, TEncSlice.cpp:183-191);
  * parts: 256 hop_cu_part per CTU in z-order; afterwards hop_recon_download gives the reconstruction before the loop filters.  first_ctus > 0: stop after that many CTUs.
- * trace_path (may be NULL): one text line per candidate that reaches xCheckBestMode. */
+ * trace_path (may be NULL): one text line per candidate that reaches xCheckBestMode.
+ * A stacked context (hop_ctx_set_stack, n pictures): wavefront_lag > 0 is required; the rows of all pictures form one wavefront whose batches serve CTUs of every picture;
+ * the output arrays hold picture k's CTUs at [k * ctus_per_picture, ...), the traces go to trace_path.<k>; each picture's results are those of a context of its own. */
 typedef struct {
   int32_t qp, mi_size, first_ctus;
   int32_t wpp;            /* 1: the rows' coders are synchronised as WaveFrontSynchro does (TEncSlice.cpp:1027-1051, :1158-1161): the result equals the reference run with

@@ -252,6 +252,49 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   if (rounds_requests) { rounds_requests[0] = (double)enc.batch_rounds; rounds_requests[1] = (double)enc.batch_requests; }
   return (long)enc.n_candidates;
 }
+// A stack of independent pictures (what hop_ctx_set_stack makes of a context): every request goes to its own picture's backend, its coordinates back in that
+// picture's own frame.  The default n-forms of BatchInner loop over the single forms below, so a batch that mixes pictures is split here.
+class StackRouter : public BatchInner {
+ public:
+  StackRouter(std::vector<CpuBackend*>& b, int pitch) : be(b), pitch_(pitch) {}
+  void begin_frame() { for (auto b : be) b->begin_frame(); }
+  void me_search(int lane, int n, const hop_pu_job* jobs, hop_pu_result* res) { for (int i = 0; i < n; i++) { hop_pu_job j = jobs[i]; const int k = j.pu_y / pitch_; j.pu_y -= k * pitch_; be[k]->me_search(lane, 1, &j, res + i); } }
+  void pred_inter(int lane, int n, const hop_pred_job* jobs) { for (int i = 0; i < n; i++) { hop_pred_job j = jobs[i]; const int k = j.pu_y / pitch_; j.pu_y -= k * pitch_; be[k]->pred_inter(lane, 1, &j); } }
+  void distortion(int lane, int n, const hop_dist_job* jobs, uint32_t* out) { for (int i = 0; i < n; i++) { hop_dist_job j = jobs[i]; const int k = j.y / pitch_; j.y -= k * pitch_; be[k]->distortion(lane, 1, &j, out + i); } }
+  void valid_pattern(int, int, const int32_t*, uint8_t*) { throw 1; }   // the spine answers these from its own map
+  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) { InterEval q = e; const int k = q.job.y / pitch_; q.job.y -= k * pitch_; be[k]->inter_cu(lane, q, in, out); }
+  void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& out) { IntraEval q = e; const int k = q.job.y / pitch_; q.job.y -= k * pitch_; be[k]->intra_cu(lane, q, in, out); }
+  void recon_save(int lane, int slot, int x, int y, int size) { const int k = y / pitch_; be[k]->recon_save(lane, slot, x, y - k * pitch_, size); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { const int k = y / pitch_; be[k]->recon_restore(lane, slot, x, y - k * pitch_, size); }
+  void commit(int lane, int x, int y, int size) { const int k = y / pitch_; be[k]->commit(lane, x, y - k * pitch_, size); }
+ private:
+  std::vector<CpuBackend*>& be; int pitch_;
+};
+// n_pic pictures (planes back to back: picture k's luma at y + k * w * h, ...) coded side by side as a wavefront of lag `lag`, picture k's requests carrying y + k * pitch;
+// outputs per picture back to back.  Each picture's result must be what hop_spine_cpu_encode_wpp gives for it alone.
+long hop_spine_cpu_encode_stack(int w, int h, int n_pic, int pitch, int qp, int mi_size, int lag, const int16_t* y, const int16_t* cb, const int16_t* cr,
+                                double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, double* rounds_requests) {
+  std::vector<CpuBackend*> bes; std::vector<Encoder*> encs;
+  for (int k = 0; k < n_pic; k++) bes.push_back(new CpuBackend(w, h, 8, y + (size_t)k * w * h, cb + (size_t)k * (w / 2) * (h / 2), cr + (size_t)k * (w / 2) * (h / 2)));
+  StackRouter router(bes, pitch);
+  for (int k = 0; k < n_pic; k++) { EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1; cfg.y_origin = k * pitch; encs.push_back(new Encoder(cfg, &router)); }
+  long total = 0;
+  try { Encoder::encode_pictures_wavefront(&encs[0], n_pic, &router, lag); } catch (...) { total = -1; }
+  const int n = encs[0]->n_ctu();
+  for (int k = 0; k < n_pic && total >= 0; k++) {
+    Encoder& e = *encs[k];
+    if (ctu_cost) memcpy(ctu_cost + (size_t)k * n, &e.ctu_cost[0], n * sizeof(double));
+    if (ctu_bits) memcpy(ctu_bits + (size_t)k * n, &e.ctu_bits[0], n * 4);
+    if (ctu_dist) memcpy(ctu_dist + (size_t)k * n, &e.ctu_dist[0], n * 4);
+    if (parts) memcpy((char*)parts + (size_t)k * n * 256 * sizeof(Part), &e.pic[0], e.pic.size() * sizeof(Part));
+    if (rec_y) memcpy(rec_y + (size_t)k * w * h, &bes[k]->rec[0][0], (size_t)w * h * 2);
+    total += (long)e.n_candidates;
+  }
+  if (rounds_requests) { rounds_requests[0] = (double)encs[0]->batch_rounds; rounds_requests[1] = (double)encs[0]->batch_requests; }
+  for (auto e : encs) delete e;
+  for (auto b : bes) delete b;
+  return total;
+}
 // the plain intra configurations (cfg/encoder_intra_main.cfg, encoder_intra_main10.cfg): I slice, bit depth 8 or 10 (samples already at that depth), CTUs in raster order
 long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
                                 double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr) {

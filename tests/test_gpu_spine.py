@@ -81,3 +81,40 @@ def test_encode_frame_plain_intra_configurations(bd, qp):
     for c in range(3):
         assert np.array_equal(ctx.recon_download(c), rec[c]), c
     ctx.close()
+
+
+def test_stacked_pictures_are_coded_as_pictures_of_their_own():
+    """three independent pictures in one stacked context (hop_ctx_set_stack), coded side by side by one hop_encode_frame: picture 0 against the reference's golden run,
+    the others against contexts of their own; reconstruction and SS reference (with the margins each picture extends at ITS edges) included"""
+    hp = _hp()
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    W, H, lag = 192, 128, 5
+    pics = [frame(W, H, 7, False), frame(W, H, 8, False), frame(W, H, 11, False)]
+    ctx = hp.Context(W, H, pictures=3)
+    ctx.upload_orig(ctx.stack([p[0] for p in pics]), ctx.stack([p[1] for p in pics], True), ctx.stack([p[2] for p in pics], True))
+    n = 6
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        cost, bits, dist, parts, nc = ctx.encode_frame(32, 16, 0, tp, wpp=1, wavefront_lag=lag)
+        text0 = open(tp + ".0", "rb").read()
+    pv = parts.view(np.dtype(parts.dtype.descr))
+    check_against_golden(G, "192x128_seed7_wpp", cost[:n], bits[:n], dist[:n], pv[:n], text0)
+    rec = [ctx.unstack(ctx.recon_download(c), c > 0) for c in range(3)]
+    ss = ctx.ssref_download(0)
+    stats = ctx.encode_stats()
+    ctx.close()
+    for k, (Y, Cb, Cr) in enumerate(pics):
+        one = hp.Context(W, H)
+        one.upload_orig(Y, Cb, Cr)
+        c1, b1, d1, p1, _ = one.encode_frame(32, 16, 0, None, wpp=1, wavefront_lag=lag)
+        assert np.array_equal(cost[k * n:(k + 1) * n], c1) and np.array_equal(bits[k * n:(k + 1) * n], b1) and np.array_equal(dist[k * n:(k + 1) * n], d1), k
+        assert parts[k * n:(k + 1) * n].tobytes() == p1.tobytes(), k
+        for c in range(3):
+            assert np.array_equal(rec[c][k], one.recon_download(c)), (k, c)
+        # the picture's padded SS plane (margin 80 on every side) inside the stack's plane
+        s1 = one.ssref_download(0)
+        assert np.array_equal(ss[k * ctx.pitch:k * ctx.pitch + H + 160], s1), k
+        one.close()
+    rv = stats["rendezvous"]
+    print("stack of 3:", nc, "candidates, avg batch", rv["requests"] / max(1, rv["rounds"]))
+    assert rv["requests"] / max(1, rv["rounds"]) > 2.0

@@ -15,12 +15,23 @@ pytestmark = pytest.mark.gpu
 VP = ctypes.c_void_p
 
 
-@pytest.fixture(scope="module")
-def hp():
+@pytest.fixture(scope="module", params=["leaf-fused", "leaf-staged"])
+def hp(request):
+    """every test of this file twice: with the transform-unit leaf step as one kernel per batch (a workgroup per TU, the default for the launch-bound batches of the RD
+    search) and as the staged pipeline (one lane per TU, the form for batches of thousands) -- hop_set_fused_leaf / HOP_FUSED_LEAF, read when a context is created"""
     spec = importlib.util.spec_from_file_location("hophip", os.path.join(ROOT, "hevc-hop_amd", "hophip.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    return m
+    old = os.environ.get("HOP_FUSED_LEAF")
+    if request.param == "leaf-staged":
+        os.environ["HOP_FUSED_LEAF"] = "0"
+    else:
+        os.environ.pop("HOP_FUSED_LEAF", None)
+    yield m
+    if old is None:
+        os.environ.pop("HOP_FUSED_LEAF", None)
+    else:
+        os.environ["HOP_FUSED_LEAF"] = old
 
 
 def test_intra_rough_golden(hp):

@@ -144,3 +144,33 @@ def test_spine_plain_intra_configurations(bd, qp):
     Y, Cb, Cr = lenslet(136, 72, 16, 9, bitdepth=bd)
     cost, bits, dist, parts, rec, text = run_cpu_plain(spine_cpu(), 136, 72, Y, Cb, Cr, qp, bd)
     check_against_golden(G, plain_key(bd, qp), cost, bits, dist, parts, text)
+
+
+def run_cpu_stack(L, W, H, pics, pitch, lag, qp=32, mi=16):
+    """pics: list of (Y, Cb, Cr); the pictures coded side by side (requests of picture k carry y + k * pitch)"""
+    L.hop_spine_cpu_encode_stack.restype = ctypes.c_long
+    L.hop_spine_cpu_encode_stack.argtypes = [ctypes.c_int] * 7 + [ctypes.c_void_p] * 9
+    P = len(pics); n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(P * n, np.float64); bits = np.zeros(P * n, np.uint32); dist = np.zeros(P * n, np.uint32); parts = np.zeros((P * n, 256), PART_DT)
+    rec = np.zeros((P, H, W), np.int16); rr = np.zeros(2, np.float64)
+    a = [np.ascontiguousarray(np.stack([p[c] for p in pics]), np.int16) for c in range(3)]
+    nc = L.hop_spine_cpu_encode_stack(W, H, P, pitch, qp, mi, lag, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, cost.ctypes.data, bits.ctypes.data, dist.ctypes.data,
+                                      parts.ctypes.data, rec.ctypes.data, rr.ctypes.data)
+    assert nc > 0
+    return cost.reshape(P, n), bits.reshape(P, n), dist.reshape(P, n), parts.reshape(P, n, 256), rec, rr
+
+
+def test_stacked_pictures_equal_the_pictures_alone():
+    """two independent pictures coded side by side on one rendezvous (a stacked context's mode, hop_ctx_set_stack): every picture's result is what it gets alone -- the
+    first one's is pinned to the reference by the golden run with one substream per row"""
+    L = spine_cpu()
+    W, H, lag, pitch = 192, 128, 5, 448
+    pics = [frame(W, H, 7, False), frame(W, H, 8, False)]
+    cost, bits, dist, parts, rec, rr = run_cpu_stack(L, W, H, pics, pitch, lag)
+    for k, (Y, Cb, Cr) in enumerate(pics):
+        c1, b1, d1, p1, r1, text, _ = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+        assert np.array_equal(cost[k], c1) and np.array_equal(bits[k], b1) and np.array_equal(dist[k], d1), k
+        assert parts[k].tobytes() == p1.tobytes() and np.array_equal(rec[k], r1[0]), k
+        if k == 0:
+            check_against_golden(np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz")), "192x128_seed7_wpp", c1, b1, d1, p1, text)
+    assert rr[1] / rr[0] > 1.5                    # requests of both pictures met in the batches

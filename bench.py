@@ -450,7 +450,7 @@ def cpu_baseline(hp, ctx, jobs, ctu_of_job, is2n, res_gpu, Y, W, H, wctu, lc, n_
 
 
 def band_of_rank(frame_h, rows, rank):
-    """The independent pictures of the multi-GPU mode: the frame is cut into bands of `rows` CTU rows and rank k codes band k (mod the number of bands) as its picture.
+    """(kept for tests/test_multi_rank.py) the frame cut into bands of `rows` CTU rows; rank k codes band k (mod the number of bands) as its picture.
     Returns (band index, first luma row, band height)."""
     hb = rows * 64
     nb = max(1, frame_h // hb)
@@ -458,10 +458,18 @@ def band_of_rank(frame_h, rows, rank):
     return b, b * hb, hb
 
 
+def tiles_of_rank(frame_w, frame_h, tile_w, tile_h, pictures, rank):
+    """The independent pictures of a rank: the frame is cut into tile_w x tile_h pictures (whole ones only, raster order); rank k codes pictures
+    k * pictures ... (k + 1) * pictures - 1 (mod the number of tiles).  Returns [(x0, y0), ...]."""
+    tx, ty = max(1, frame_w // tile_w), max(1, frame_h // tile_h)
+    return [(((rank * pictures + i) % (tx * ty)) % tx * tile_w, ((rank * pictures + i) % (tx * ty)) // tx * tile_h) for i in range(pictures)]
+
+
 def encode_main(args):
-    """The default: BASELINE.json's metric, dependency-honest.  One step = hop_encode_frame over the workload picture: the RD search of TEncSlice::compressSlice --
-    every candidate of TEncCu::xCompressCU for every CTU, SS reference starting at the sentinel and growing CU by CU, coder contexts carried from CU to CU -- with the
-    CTU rows as a lag-5 wavefront (WaveFrontSynchro semantics: the result equals the reference run with one substream per CTU row, tests/test_gpu_spine.py)."""
+    """The default: BASELINE.json's metric, dependency-honest.  One step = one hop_encode_frame over a stacked context of `--pictures` independent pictures -- tiles of the
+    7728x5368 frame -- each coded as TEncSlice::compressSlice codes a picture: every candidate of TEncCu::xCompressCU for every CTU, SS reference starting at the sentinel
+    and growing CU by CU, coder contexts carried from CU to CU, CTU rows as a lag-5 wavefront with WaveFrontSynchro contexts.  The rows of ALL pictures form one wavefront:
+    a batch of requests serves one CU of every CTU in flight (the launch chains are the time; what one chain serves is the throughput)."""
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -479,19 +487,19 @@ def encode_main(args):
         import torch.distributed as dist
         dist.init_process_group("gloo" if shared else "nccl", **({} if shared else {"device_id": dev}))
     hp = _hophip()
-    W = args.width
-    rows = args.rows
-    Hb = rows * 64
-    # the whole synthetic frame is generated once; rank k takes the band of `rows` CTU rows number k as ITS picture (independent pictures: the split that shards
-    # naturally; at N = 1 this is the top band BASELINE.md's CPU plan encodes)
-    Yf, Cbf, Crf = lenslet_torch(W, min(args.height, FRAME_H), PITCH, 2, dev)
-    b, y0, _ = band_of_rank(int(Yf.shape[0]), rows, rank)
-    Y = Yf[y0:y0 + Hb].cpu().numpy(); Cb = Cbf[y0 // 2:(y0 + Hb) // 2].cpu().numpy(); Cr = Crf[y0 // 2:(y0 + Hb) // 2].cpu().numpy()
+    fw, fh = args.width, min(args.height, FRAME_H)
+    tw, th, P = min(args.tile_w, fw), min(args.rows * 64, fh // 8 * 8), args.pictures
+    Yf, Cbf, Crf = lenslet_torch(fw, fh, PITCH, 2, dev)
+    tiles = tiles_of_rank(fw, fh, tw, th, P, rank)
+    pics = [(Yf[y:y + th, x:x + tw].cpu().numpy(), Cbf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy(), Crf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy()) for x, y in tiles]
     del Yf, Cbf, Crf
-    ctx = hp.Context(W, Hb, device=local)
-    ctx.upload_orig(Y, Cb, Cr)
-    wctu = (W + 63) // 64
-    n_ctu = wctu * rows
+    ctx = hp.Context(tw, th, device=local, pictures=P)
+    if P > 1:
+        ctx.upload_orig(ctx.stack([p[0] for p in pics]), ctx.stack([p[1] for p in pics], True), ctx.stack([p[2] for p in pics], True))
+    else:
+        ctx.upload_orig(*pics[0])
+    wctu, hctu = (tw + 63) // 64, (th + 63) // 64
+    n_ctu = wctu * hctu * P
 
     def barrier():
         ctx.sync(); torch.cuda.synchronize()
@@ -514,10 +522,10 @@ def encode_main(args):
         dt = float(t.item())
     if rank == 0:
         value = world * n_ctu * args.steps / dt
-        # ---- roofline of the dominant kernel: a separate, untimed pass with HIP events around every launch (graphs off while profiling), on a small picture ----
-        pw, ph = min(W, 1024), min(Hb, 256)
-        pctx = hp.Context(pw, ph, device=local)
-        pctx.upload_orig(Y[:ph, :pw], Cb[:ph // 2, :pw // 2], Cr[:ph // 2, :pw // 2])
+        # ---- roofline of the dominant kernel: a separate, untimed pass over ONE of the pictures with HIP events around every launch (graphs off while profiling) ----
+        Y0, Cb0, Cr0 = pics[0]
+        pctx = hp.Context(tw, th, device=local)
+        pctx.upload_orig(Y0, Cb0, Cr0)
         L = pctx.L
         L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
         L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -525,8 +533,9 @@ def encode_main(args):
         tp0 = time.perf_counter()
         pctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
         prof_s = time.perf_counter() - tp0
-        prof_ctus = ((pw + 63) // 64) * ((ph + 63) // 64)
-        names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_tu_rd (transform + setup + inverse + decide)", 7: "k_intra (rough search + predictors)", 8: "k_rdoq", 9: "k_coeff_bits + CU-level counting"}
+        prof_ctus = wctu * hctu
+        names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_turd_fused (transform unit leaf step: transform, estBit, RDOQ, counted bits, inverse, decision)",
+                 7: "k_intra (rough search + predictors)", 8: "k_rdoq (staged form)", 9: "k_coeff_bits + CU-level counting"}
         prof = {}
         for kid, name in names.items():
             la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
@@ -545,23 +554,24 @@ def encode_main(args):
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16+f64", "data": "synthetic",
             "config": {"workload": "synthetic lenslet %dx%d (pitch %d), QP%d, cfg/3DHencoder_intra_main.cfg semantics (ISS slice, SS +-128 full search with FEN, half/quarter-pel, GT search, "
-                                   "merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, CABAC-counted bits): the full-width top band of %d CTU rows "
-                                   "(%dx%d, %d CTUs) of the 7728x5368 frame coded as a picture -- the band BASELINE.md's CPU plan encodes -- SS reference from the sentinel, every "
-                                   "candidate of xCompressCU, rows as a lag-%d wavefront with WaveFrontSynchro contexts; per rank one such picture" % (W, Hb, PITCH, QP, rows, W, Hb, n_ctu, args.lag),
-                       "ctus_per_picture": n_ctu, "candidates_per_picture": ncand, "parallelism": "independent-pictures x%d" % world,
-                       "full_frame_note": "the whole 7728x5368 frame (84 rows) keeps up to 24 rows in flight instead of %d: its rate is higher than this band's" % rows},
+                                   "merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, CABAC-counted bits), cut into independent %dx%d pictures (tiles): "
+                                   "%d of them per GPU (%d CTUs) coded side by side in one stacked context -- each exactly as a picture of its own (SS reference from the sentinel, every "
+                                   "candidate of xCompressCU, rows as a lag-%d wavefront with WaveFrontSynchro contexts; tests/test_gpu_spine.py pins that to the reference encoder)"
+                                   % (fw, fh, PITCH, QP, tw, th, P, n_ctu, args.lag),
+                       "pictures_per_gpu": P, "picture": [tw, th], "ctus_per_step": n_ctu, "candidates_per_step": ncand, "parallelism": "independent-pictures x%d per GPU, x%d GPUs" % (P, world),
+                       "whole_frame_note": "--width 7728 --rows 84 --pictures 1 codes the 7728x5368 frame as ONE picture: at most 24 CTU rows in flight (lag 5), 536 wavefront steps; see DESIGN.md for its rate"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
-                         "note": "from a separate profiled pass over a %dx%d picture (%d CTUs, %.1f s, HIP events around every launch, graphs off); the encode is bound by the LENGTH of "
-                                 "its dependent launch chains, not by HBM or VALU: see request_ms" % (pw, ph, prof_ctus, prof_s)},
+                         "note": "from a separate profiled pass over one %dx%d picture (%d CTUs, %.1f s, HIP events around every launch, graphs off); the encode is bound by the LENGTH of "
+                                 "its dependent launch chains and the serial lane speed inside them, not by HBM or VALU throughput: see request_ms" % (tw, th, prof_ctus, prof_s)},
             "kernels": prof,
             "request_ms": {k: v for k, v in stats.items() if k != "rendezvous"},
-            "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTU rows in flight)",
+            "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTUs in flight, all pictures together)",
             "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"])},
             "cost_sum": float(cost.sum()),
         }
         if world == 1:
-            out["cpu_baseline"] = cpu_baseline_encode(W, Hb, Y, Cb, Cr, cost, args.cpu_ctus)
+            out["cpu_baseline"] = cpu_baseline_encode(tw, th, Y0, Cb0, Cr0, cost, args.cpu_ctus)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
@@ -595,7 +605,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--width", type=int, default=FRAME_W)     # smaller pictures only for rehearsal; the JSON names them
     ap.add_argument("--height", type=int, default=FRAME_H)
-    ap.add_argument("--rows", type=int, default=8, help="CTU rows of the band that is coded as the workload picture (84 = the whole frame)")
+    ap.add_argument("--rows", type=int, default=4, help="CTU rows of one picture (tile); 84 with --tile-w 7728 --pictures 1 = the whole frame as one picture")
+    ap.add_argument("--tile-w", type=int, default=1024, help="width of one picture (tile)")
+    ap.add_argument("--pictures", type=int, default=64, help="independent pictures coded side by side per GPU (one stacked context)")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
     ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")
     ap.add_argument("--kernels", action="store_true", help="kernel-throughput mode of round 1: the search kernels over a frozen, fully reconstructed SS reference (not the encode metric)")

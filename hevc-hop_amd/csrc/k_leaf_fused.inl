@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restr
     turd_setup_body(j, jobs, n, ctx_in, coef_off, entropy_bits, tables, rq, cb);
     const hop_rdoq_job rj = rq[j];
     double* wd = (double*)(work + (size_t)j * LEAF_WORK_PER_TU);
-    if (LOG2 == 2) rdoq_tu<2>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
-    else if (LOG2 == 3) rdoq_tu<3>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
-    else if (LOG2 == 4) rdoq_tu<4>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
-    else rdoq_tu<5>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1);
+    if (LOG2 == 2) rdoq_tu<2>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
+    else if (LOG2 == 3) rdoq_tu<3>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
+    else if (LOG2 == 4) rdoq_tu<4>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
+    else rdoq_tu<5>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
     const hop_coeff_bits_job bj = cb[j];
     { const uint8_t* src = ctx_in[bj.ctx_index].state; for (int i = 0; i < 152; i++) L.cab.st[i][0] = src[i]; }
     fr[j] = cb_code_tu(L.cab, 0, levels + bj.coeff_offset, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, scans);

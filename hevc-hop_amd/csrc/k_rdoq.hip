@@ -29,13 +29,13 @@ __global__ __launch_bounds__(64) void k_rdoq(const hop_rdoq_job* __restrict__ jo
   for (int i = lane; i < 3 * CGN; i += 64) s_scanCG[i / CGN][i % CGN] = rq_scan_cg(scans, i / CGN, LOG2)[i % CGN];
   __syncthreads();
   // this block's slice of the work area: arrays [scan position][lane], so that the lanes of a step touch consecutive words
-  double* const wd = (double*)(work + (size_t)blockIdx.x * ((size_t)N2 * 64 * RQ_WORK_PER_COEF)) + lane;
+  double* const wd = (double*)(work + (size_t)blockIdx.x * ((size_t)N2 * 64 * RQ_WORK_PER_COEF));
   for (int g = blockIdx.x; g * 64 < count; g += gridDim.x) {
     const int idx = g * 64 + lane;
     if (idx >= count) continue;                                           // no barrier below: a lane only ever reads what it wrote itself
     const int ti = list[idx];
     const hop_rdoq_job jb = jobs[ti];
-    rdoq_tu<LOG2>(jb, tables + jb.estbits_index, s_scan[jb.scan_idx], s_scanCG[jb.scan_idx], &s_cgSig[0][lane], 64, src_all, dst_all, abs_sum_out + ti, wd, 64);
+    rdoq_tu<LOG2>(jb, tables + jb.estbits_index, s_scan[jb.scan_idx], s_scanCG[jb.scan_idx], &s_cgSig[0][lane], 64, src_all, dst_all, abs_sum_out + ti, wd, 64, lane);
   }
 }
 

@@ -24,6 +24,12 @@ struct RqtWork {                                                      // per CU:
   uint32_t zero_dist; uint8_t best_skip[4][4];
 };
 
+// The kernels that walk a CU's coder serially take one LANE per CU (64 CUs per wave: batches of thousands of CUs) or, launched with one workgroup per CU (grid = n), one
+// WAVE per CU with lane 0 working: the lanes of a wave serialise wherever their CUs' paths differ, so a small batch -- the RD spine's, one CU per CTU in flight -- runs in
+// the time of ONE CU only when every CU has a wave of its own.  rqt_grid() picks the launch; the kernel tells the two apart by its grid.
+#define RQT_LANE_OR_BLOCK(n_) const bool spread_ = (n_) > 1 && gridDim.x == (unsigned)(n_); if (spread_ && threadIdx.x) return; \
+                              const int lane = spread_ ? 0 : (int)threadIdx.x, i = spread_ ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x)
+static inline int rqt_grid(const hop_ctx* c, int n) { return (n > 1 && n <= c->fused_leaf_max) ? n : (n + 63) / 64; }
 __device__ static inline int rqt_zx(int p) { int x = 0; for (int b = 0; b < 4; b++) x |= ((p >> (2 * b)) & 1) << b; return 4 * x; }
 __device__ static inline int rqt_zy(int p) { int y = 0; for (int b = 0; b < 4; b++) y |= ((p >> (2 * b + 1)) & 1) << b; return 4 * y; }
 __device__ static inline double rqt_cost(uint32_t bits, uint32_t dist, double lambda) { return (double)(uint32_t)floor((double)dist + (double)((int)(bits * lambda + .5))); }
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const
                                                    RqtWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2,
                                                    int32_t* __restrict__ coef, size_t ts_base, const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;                                                // no barrier in this kernel
   const hop_rqt_job jb = jobs[i];
   hop_rqt_result* r = res + i; RqtWork* w = work + i;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(64) void k_rqt_close(RqtClass k, RqtNode nd, const 
                                                   const hop_cabac_ctx* __restrict__ root, const hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
                                                   RqtWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const hop_rqt_job jb = jobs[i];
   hop_rqt_result* r = res + i; RqtWork* w = work + i;
@@ -277,13 +283,13 @@ static int rqt_run_class(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job
     nd.add_zero = zero_open && nd.check_full;
     nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
     nd.ts_c = (k.use_ts && nd.check_full && nd.code_chroma && (log2 == 2 || log2 == 3)) ? 1 : 0;
-    const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, ncomp = nd.code_chroma ? 3 : 1, nts = nd.ts_y + 2 * nd.ts_c;
+    const int g256 = (n + 255) / 256, ncomp = nd.code_chroma ? 3 : 1, nts = nd.ts_y + 2 * nd.ts_c;
     hipLaunchKernelGGL(k_rqt_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, d_jobs, n, c->bd_y, c->bd_c, cur, root[d], d_res, work, tuj, off, tuj2, off2, ts_base);
     if (nd.check_full) {
       const int hint = log2 <= 3 ? 1 : (log2 == 5 ? 2 : 0);          // 16x16 luma comes with 8x8 chroma
       int r = hop_launch_tu_rd(c, n * ncomp, tuj, root[d], off, n_coeff, coef, tr, hint); if (r) return r;
       if (nts) { r = hop_launch_tu_rd(c, n * nts, tuj2, root[d], off2, n_coeff, coef, tr2, 1); if (r) return r; }
-      hipLaunchKernelGGL(k_rqt_single, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, tr, tr2, coef, ts_base, c->rdoq_scans);
+      hipLaunchKernelGGL(k_rqt_single, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, tr, tr2, coef, ts_base, c->rdoq_scans);
     }
     if (nd.check_split) {
       const int q = (parts >> (2 * d)) >> 2;
@@ -291,7 +297,7 @@ static int rqt_run_class(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job
         const int r = go(c, k, n, d_jobs, d_res, cur, root, test, work, tuj, tuj2, off, off2, tr, tr2, coef, n_coeff, ts_base, parts, part + kk * q, d + 1, log2 - 1, zero_open && !nd.check_full);
         if (r) return r;
       }
-      hipLaunchKernelGGL(k_rqt_close, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, coef, c->rdoq_scans);
+      hipLaunchKernelGGL(k_rqt_close, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, coef, c->rdoq_scans);
     }
     return HOP_OK;
   } };
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt
                                                 uint32_t* __restrict__ bits_out, uint32_t* __restrict__ skipped_out, hop_cabac_ctx* __restrict__ ctx_out,
                                                 hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]);
@@ -554,7 +560,7 @@ int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu
                        uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = inter_split; k.sign_hide = sign_hide; k.use_ts = use_ts;
   const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_cu_bits, dim3((n + 63) / 64), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_skipped, d_ctx_out, d_cu_out, c->rdoq_scans);
+  hipLaunchKernelGGL(k_cu_bits, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_skipped, d_ctx_out, d_cu_out, c->rdoq_scans);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "cu_bits launch: %s", hipGetErrorString(e));
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(64) void k_intra_cu_bits(RqtClass k, int n, const h
                                                       const hop_cabac_cu_ctx* __restrict__ cu_in, uint32_t* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out,
                                                       hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]);
@@ -673,7 +679,7 @@ int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_
                              hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_intra_cu_bits, dim3((n + 63) / 64), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_ctx_out, d_cu_out, c->rdoq_scans);
+  hipLaunchKernelGGL(k_intra_cu_bits, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_ctx_out, d_cu_out, c->rdoq_scans);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_cu_bits launch: %s", hipGetErrorString(e));
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, cons
                                                     int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans,
                                                     const uint8_t* __restrict__ active) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n || (active && !active[i])) return;
   const hop_intra_cu_syntax y = syn[i];
   const double lambda = jobs[i].lambda_rd;
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const
                                                    hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans,
                                                    const uint8_t* __restrict__ active) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n || (active && !active[i])) return;
   const hop_intra_cu_syntax y = syn[i];
   hop_rqt_result* r = res + i;
@@ -909,7 +915,7 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
     nd.check_full = log2 <= k.log2_max_tu;
     nd.check_split = log2 > k.log2_min_tu && !(check_first && nd.check_full);
     nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
-    const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, pitch = c->pic_w;
+    const int g256 = (n + 255) / 256, pitch = c->pic_w;
     hipLaunchKernelGGL(k_irqt_begin, dim3(g256), dim3(256), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, c->bd_y, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, d_res, B.work,
                        B.pj, B.modes, B.tuj, B.off, B.tuj2, B.off2, B.ts_base, B.active);
     if (nd.check_full) {
@@ -921,13 +927,13 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
       }
       r = hop_launch_tu_rd(c, n, B.tuj, B.root[d].a, B.off, B.n_coeff, B.coef, B.tr, hint); if (r) return r;
       if (nd.check_split) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 0, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
-      hipLaunchKernelGGL(k_irqt_single, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b,
+      hipLaunchKernelGGL(k_irqt_single, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b,
                          d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base, c->rec[0], pitch, B.park, c->rdoq_scans, B.active);
     }
     if (nd.check_split) {
       const int q = ((1 << (2 * (k.log2_cu - 2))) >> (2 * d)) >> 2;
       for (int kk = 0; kk < 4; kk++) { const int r = go(c, k, n, check_first, d_jobs, d_syn, d_opt, d_res, B, rel + kk * q, d + 1, log2 - 1); if (r) return r; }
-      hipLaunchKernelGGL(k_irqt_close, dim3(g64), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b, d_res,
+      hipLaunchKernelGGL(k_irqt_close, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b, d_res,
                          B.work, B.coef, c->rdoq_scans, B.active);
       if (nd.check_full) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 2, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
     }
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(64) void k_ic_single(RqtClass k, RqtNode nd, int co
                                                   const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base, int16_t* __restrict__ rec, int pitch,
                                                   const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   hop_rqt_result* r = res + i;
   if (!ic_leaf_here(k, r, nd.part, nd.d)) return;
@@ -1220,7 +1226,7 @@ __global__ __launch_bounds__(64) void k_ic_bits(RqtClass k, const hop_rqt_job* _
                                                 const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_rqt_result* __restrict__ res,
                                                 IcWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]); IRQ_CU_LOAD(cu_in[ci]);
@@ -1293,7 +1299,7 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search: %s", hipGetErrorString(e));
   e = hipMemsetAsync(B.coef, 0, n_coeff * 4, c->stream);
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra chroma search: %s", hipGetErrorString(e));
-  const int g64 = (n + 63) / 64, g256 = (n + 255) / 256, pitch = c->pic_w >> 1;
+  const int g256 = (n + 255) / 256, pitch = c->pic_w >> 1;
   struct Rec { static int go(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job* d_jobs, const hop_intra_rqt_opt* d_opt, hop_rqt_result* d_res, Bufs& B, int part, int d, int log2) {
     RqtNode nd; memset(&nd, 0, sizeof(nd));
     nd.part = part; nd.d = d; nd.log2 = log2;
@@ -1311,7 +1317,7 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
         }
         const int lgc = log2 == 2 ? 2 : log2 - 1;
         r = hop_launch_tu_rd(c, n, B.tuj, B.cur, B.off, B.n_coeff, B.coef, B.tr, lgc <= 3 ? 1 : 0); if (r) return r;
-        hipLaunchKernelGGL(k_ic_single, dim3(g64), dim3(64), 0, c->stream, k, nd, comp, d_jobs, B.syn, d_opt, n, B.cur, B.root, d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base,
+        hipLaunchKernelGGL(k_ic_single, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, comp, d_jobs, B.syn, d_opt, n, B.cur, B.root, d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base,
                            c->rec[comp], pitch, B.park, c->rdoq_scans);
       }
     }
@@ -1327,7 +1333,7 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
     hipLaunchKernelGGL(k_ic_mode, dim3(g256), dim3(256), 0, c->stream, m, d_jobs, n, d_ctx_in, B.cur, B.syn, B.work);
     const int rc = Rec::go(c, k, n, d_jobs, d_opt, d_res, B, 0, 0, k.log2_cu);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ic_bits, dim3(g64), dim3(64), 0, c->stream, k, d_jobs, B.syn, n, d_ctx_in, d_cu_in, d_res, B.work, B.coef, c->rdoq_scans);
+    hipLaunchKernelGGL(k_ic_bits, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, d_jobs, B.syn, n, d_ctx_in, d_cu_in, d_res, B.work, B.coef, c->rdoq_scans);
     hipLaunchKernelGGL(k_ic_keep, dim3(n), dim3(64), 0, c->stream, k, d_jobs, n, d_res, B.work, B.coef, c->rec[1], c->rec[2], pitch, d_coef_out, d_reco_out);
   }
   hipLaunchKernelGGL(k_ic_commit, dim3(n), dim3(64), 0, c->stream, k, n, B.work, d_res, d_cres, d_syn_update);
@@ -1347,7 +1353,7 @@ __global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const 
                                                        double* __restrict__ cost_out, hop_cabac_ctx* __restrict__ ctx_out, hop_cabac_cu_ctx* __restrict__ cu_out,
                                                        const uint16_t* __restrict__ scans) {
   __shared__ CabacLds sh;
-  const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]); IRQ_CU_LOAD(cu_in[ci]);
@@ -1414,7 +1420,7 @@ int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2
                               uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_intra_cu_total, dim3((n + 63) / 64), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_dist, d_bits, d_cost, d_ctx_out, d_cu_out,
+  hipLaunchKernelGGL(k_intra_cu_total, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_dist, d_bits, d_cost, d_ctx_out, d_cu_out,
                      c->rdoq_scans);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();

@@ -148,29 +148,41 @@ class HipBackend : public BatchInner {
     o_ctx_out = take(MAXN * sizeof(hop_cabac_ctx)); o_cu_out = take(MAXN * sizeof(hop_cabac_cu_ctx)); o_fin = take(MAXN * sizeof(hop_cu_final));
     o_bits = take(MAXN * 4); o_skipped = take(MAXN * 4); o_cost = take(MAXN * 8); o_dist = take(MAXN * 4);
     o_pjobs = take(MAXP * sizeof(hop_pred_job)); o_djobs = take(MAXP * sizeof(hop_dist_job)); o_pout = take(MAXP * 4);
+    // what a candidate batch sends and gets back travels as ONE copy each way between pinned host memory and these two regions, packed for the batch's n
+    io_bytes = (size_t)MAXN * (sizeof(hop_rqt_job) + sizeof(hop_intra_cu_syntax) + sizeof(hop_intra_rqt_opt) + sizeof(hop_intra_search_job) + sizeof(hop_rqt_result) +
+                               sizeof(hop_intra_search_result) + sizeof(hop_intra_chroma_result) + 2 * sizeof(hop_cabac_ctx) + 2 * sizeof(hop_cabac_cu_ctx) + sizeof(hop_cu_final) + 64) + 16 * 256;
+    o_in = take(io_bytes); o_out = take(io_bytes);
     bytes = o;
-    if (hipMalloc((void**)&arena, bytes) != hipSuccess) { arena = nullptr; hop_set_err(c, HOP_ERR_DEVICE, "spine arena allocation failed"); }
+    hin = hout = nullptr;
+    if (hipMalloc((void**)&arena, bytes) != hipSuccess || hipHostMalloc((void**)&hin, io_bytes) != hipSuccess || hipHostMalloc((void**)&hout, io_bytes) != hipSuccess) {
+      if (arena) (void)hipFree(arena);
+      arena = nullptr; hop_set_err(c, HOP_ERR_DEVICE, "spine arena allocation failed");
+    }
   }
-  ~HipBackend() { if (arena) (void)hipFree(arena); }
+  ~HipBackend() { if (arena) (void)hipFree(arena); if (hin) (void)hipHostFree(hin); if (hout) (void)hipHostFree(hout); }
   bool ok() const { return arena != nullptr; }
 
-  void begin_frame() { BK(hop_ssref_reset(c)); BK(hop_sync(c)); }
-  void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) { Tick t(0); BK(hop_me_search(c, n, jobs, res, HOP_STAGE_GT)); }
-  void pred_inter(int, int n, const hop_pred_job* jobs) { Tick t(1); BK(hop_pred_inter(c, n, jobs, nullptr, nullptr, nullptr)); }
-  void distortion(int, int n, const hop_dist_job* jobs, uint32_t* out) { Tick t(2); BK(hop_distortion(c, n, jobs, out)); }
-  void valid_pattern(int, int n, const int32_t* q, uint8_t* out) { Tick t(3); BK(hop_valid_pattern(c, n, q, out)); }
-  void recon_save(int lane, int slot, int x, int y, int size) { Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 0)); }
-  void recon_restore(int lane, int slot, int x, int y, int size) { Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 1)); }
-  void commit(int, int x, int y, int size) { Tick t(8); const int32_t r[4] = { x, y, size, 0 }; BK(hop_ssref_commit_recon(c, 1, r)); }
+  void on_device() { if (hipSetDevice(c->device) != hipSuccess) { hop_set_err(c, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", c->device); throw Bail{ HOP_ERR_DEVICE }; } }   // batches are served by whichever worker thread arrives last: the current device is per-thread state
+  void begin_frame() { on_device(); BK(hop_ssref_reset(c)); BK(hop_sync(c)); }
+  void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) { on_device(); Tick t(0); BK(hop_me_search(c, n, jobs, res, HOP_STAGE_GT)); }
+  void pred_inter(int, int n, const hop_pred_job* jobs) { on_device(); Tick t(1); BK(hop_pred_inter(c, n, jobs, nullptr, nullptr, nullptr)); }
+  void distortion(int, int n, const hop_dist_job* jobs, uint32_t* out) { on_device(); Tick t(2); BK(hop_distortion(c, n, jobs, out)); }
+  void valid_pattern(int, int n, const int32_t* q, uint8_t* out) { on_device(); Tick t(3); BK(hop_valid_pattern(c, n, q, out)); }
+  void recon_save(int lane, int slot, int x, int y, int size) { on_device(); Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 0)); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { on_device(); Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 1)); }
+  void commit(int, int x, int y, int size) { on_device(); Tick t(8); const int32_t r[4] = { x, y, size, 0 }; BK(hop_ssref_commit_recon(c, 1, r)); }
 
   void pred_cost(int, int n, const hop_pred_job* jobs, int kind, uint32_t* out) { pred_cost_n(1, &n, jobs, &kind, out); }
   // step k of every sequence in one predictor launch + one distortion launch; the steps in order; one synchronisation at the end
   void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {
+    on_device();
     Tick t(1);
     int total = 0, maxlen = 0; for (int s = 0; s < m; s++) { total += len[s]; if (len[s] > maxlen) maxlen = len[s]; }
     if (total == 0) return;
     if (total > MAXP) throw Bail{ HOP_ERR_ARG };
-    std::vector<hop_pred_job> pj(total); std::vector<hop_dist_job> dj(total); std::vector<int> src(total), first(maxlen + 1, 0);
+    if ((size_t)total * (sizeof(hop_pred_job) + sizeof(hop_dist_job)) + 512 > io_bytes) throw Bail{ HOP_ERR_ARG };
+    hop_pred_job* pj = (hop_pred_job*)hin; hop_dist_job* dj = (hop_dist_job*)(hin + (((size_t)total * sizeof(hop_pred_job) + 255) & ~(size_t)255));   // pinned staging
+    std::vector<int> src(total), first(maxlen + 1, 0);
     int at = 0;
     for (int k = 0; k < maxlen; k++) {
       first[k] = at;
@@ -182,106 +194,108 @@ class HipBackend : public BatchInner {
     }
     first[maxlen] = at;
     hipStream_t st = c->stream;
-    BH(hipMemcpyAsync(arena + o_pjobs, pj.data(), total * sizeof(hop_pred_job), hipMemcpyHostToDevice, st));
-    BH(hipMemcpyAsync(arena + o_djobs, dj.data(), total * sizeof(hop_dist_job), hipMemcpyHostToDevice, st));
+    BH(hipMemcpyAsync(arena + o_pjobs, pj, total * sizeof(hop_pred_job), hipMemcpyHostToDevice, st));
+    BH(hipMemcpyAsync(arena + o_djobs, dj, total * sizeof(hop_dist_job), hipMemcpyHostToDevice, st));
     for (int k = 0; k < maxlen; k++) {
       const int nk = first[k + 1] - first[k];
       BK(hop_pred_inter_device(c, nk, (const hop_pred_job*)(arena + o_pjobs) + first[k]));
       BK(hop_distortion_device(c, nk, (const hop_dist_job*)(arena + o_djobs) + first[k], (uint32_t*)(arena + o_pout) + first[k]));
     }
-    std::vector<uint32_t> o(total);
-    BH(hipMemcpyAsync(o.data(), arena + o_pout, total * 4, hipMemcpyDeviceToHost, st));
+    uint32_t* o = (uint32_t*)hout;
+    BH(hipMemcpyAsync(o, arena + o_pout, total * 4, hipMemcpyDeviceToHost, st));
     BH(hipStreamSynchronize(st));
     for (int i = 0; i < total; i++) out[src[i]] = o[i];
   }
-  void stash_n(int n, const int32_t* rect4, int restore) { Tick t(7); BK(hop_recon_stash(c, n, rect4, restore)); }
-  void commit_n(int n, const int32_t* rect4) { Tick t(8); BK(hop_ssref_commit_recon(c, n, rect4)); }
+  void stash_n(int n, const int32_t* rect4, int restore) { on_device(); Tick t(7); BK(hop_recon_stash(c, n, rect4, restore)); }
+  void commit_n(int n, const int32_t* rect4) { on_device(); Tick t(8); BK(hop_ssref_commit_recon(c, n, rect4)); }
   void inter_cu(int, const InterEval& e, const Coder& in, EvalResult& out) { const InterEval* pe = &e; const Coder* pi = &in; EvalResult* po = &out; inter_n(1, &pe, &pi, &po); }
   void intra_cu(int, const IntraEval& e, const Coder& in, EvalResult& out) { const IntraEval* pe = &e; const Coder* pi = &in; EvalResult* po = &out; intra_n(1, &pe, &pi, &po); }
 
   // n candidates of ONE class (CU size; with or without residual)
   void inter_n(int n, const InterEval* const* e, const Coder* const* in, EvalResult* const* out) {
     if (n > MAXN) throw Bail{ HOP_ERR_ARG };
+    on_device();
     Tick t(e[0]->skip_res ? 5 : 4);
     hipStream_t s = c->stream;
-    std::vector<hop_rqt_job> jobs(n); std::vector<hop_cu_syntax> syn(n); std::vector<hop_cabac_ctx> cx(n); std::vector<hop_cabac_cu_ctx> cu(n);
-    for (int i = 0; i < n; i++) { jobs[i] = e[i]->job; jobs[i].ctx_index = i; syn[i] = e[i]->syn; cx[i] = in[i]->r; cu[i] = in[i]->c; }
-    BH(hipMemcpyAsync(arena + o_jobs, jobs.data(), n * sizeof(hop_rqt_job), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_syn, syn.data(), n * sizeof(hop_cu_syntax), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_ctx_in, cx.data(), n * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_cu_in, cu.data(), n * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, s));
-    std::vector<hop_cu_final> fin(n); std::vector<uint32_t> bits(n), skipped(n, 1); std::vector<hop_rqt_result> res;
-    if (e[0]->skip_res) {
-      BK(hop_inter_cu_skip_device(c, n, (const hop_rqt_job*)(arena + o_jobs), (const hop_cu_syntax*)(arena + o_syn), (const hop_cabac_ctx*)(arena + o_ctx_in),
-                                  (const hop_cabac_cu_ctx*)(arena + o_cu_in), (hop_cu_final*)(arena + o_fin), (uint32_t*)(arena + o_bits), (double*)(arena + o_cost),
-                                  (hop_cabac_ctx*)(arena + o_ctx_out), (hop_cabac_cu_ctx*)(arena + o_cu_out)));
+    const bool skip = e[0]->skip_res != 0;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t i_jobs = take(n * sizeof(hop_rqt_job)), i_syn = take(n * sizeof(hop_cu_syntax)), i_cx = take(n * sizeof(hop_cabac_ctx)), i_cu = take(n * sizeof(hop_cabac_cu_ctx)), in_bytes = o;
+    o = 0;
+    const size_t r_fin = take(n * sizeof(hop_cu_final)), r_bits = take(n * 4), r_skipped = take(n * 4), r_cx = take(n * sizeof(hop_cabac_ctx)), r_cu = take(n * sizeof(hop_cabac_cu_ctx)),
+                 r_res = take(skip ? 0 : n * sizeof(hop_rqt_result)), out_bytes = o;
+    hop_rqt_job* hj = (hop_rqt_job*)(hin + i_jobs); hop_cu_syntax* hs = (hop_cu_syntax*)(hin + i_syn); hop_cabac_ctx* hx = (hop_cabac_ctx*)(hin + i_cx); hop_cabac_cu_ctx* hu = (hop_cabac_cu_ctx*)(hin + i_cu);
+    for (int i = 0; i < n; i++) { hj[i] = e[i]->job; hj[i].ctx_index = i; hs[i] = e[i]->syn; hx[i] = in[i]->r; hu[i] = in[i]->c; }
+    char* din = arena + o_in; char* dout = arena + o_out;
+    BH(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, s));
+    const hop_rqt_job* d_jobs = (const hop_rqt_job*)(din + i_jobs); const hop_cu_syntax* d_syn = (const hop_cu_syntax*)(din + i_syn);
+    const hop_cabac_ctx* d_cx = (const hop_cabac_ctx*)(din + i_cx); const hop_cabac_cu_ctx* d_cu = (const hop_cabac_cu_ctx*)(din + i_cu);
+    if (skip) {
+      BK(hop_inter_cu_skip_device(c, n, d_jobs, d_syn, d_cx, d_cu, (hop_cu_final*)(dout + r_fin), (uint32_t*)(dout + r_bits), (double*)(arena + o_cost),
+                                  (hop_cabac_ctx*)(dout + r_cx), (hop_cabac_cu_ctx*)(dout + r_cu)));
     } else {
       hop_inter_class k; memset(&k, 0, sizeof(k));
-      k.n = n; k.cls = jobs[0]; k.cls.x = 0; k.cls.y = 0; k.cls.ctx_index = 0;
-      k.d_jobs = (const hop_rqt_job*)(arena + o_jobs); k.d_syntax = (const hop_cu_syntax*)(arena + o_syn); k.d_results = (hop_rqt_result*)(arena + o_res);
-      k.d_coef = (int32_t*)(arena + o_coef); k.d_ctx_after = (hop_cabac_ctx*)(arena + o_ctx_after); k.d_finals = (hop_cu_final*)(arena + o_fin);
-      k.d_bits = (uint32_t*)(arena + o_bits); k.d_skipped = (uint32_t*)(arena + o_skipped); k.d_cost = (double*)(arena + o_cost);
-      k.d_ctx_out = (hop_cabac_ctx*)(arena + o_ctx_out); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(arena + o_cu_out);
-      BK(hop_inter_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(arena + o_ctx_in), (const hop_cabac_cu_ctx*)(arena + o_cu_in)));
-      res.resize(n);
-      BH(hipMemcpyAsync(res.data(), arena + o_res, n * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, s));
-      BH(hipMemcpyAsync(skipped.data(), arena + o_skipped, n * 4, hipMemcpyDeviceToHost, s));
+      k.n = n; k.cls = hj[0]; k.cls.x = 0; k.cls.y = 0; k.cls.ctx_index = 0;
+      k.d_jobs = d_jobs; k.d_syntax = d_syn; k.d_results = (hop_rqt_result*)(dout + r_res);
+      k.d_coef = (int32_t*)(arena + o_coef); k.d_ctx_after = (hop_cabac_ctx*)(arena + o_ctx_after); k.d_finals = (hop_cu_final*)(dout + r_fin);
+      k.d_bits = (uint32_t*)(dout + r_bits); k.d_skipped = (uint32_t*)(dout + r_skipped); k.d_cost = (double*)(arena + o_cost);
+      k.d_ctx_out = (hop_cabac_ctx*)(dout + r_cx); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(dout + r_cu);
+      BK(hop_inter_cu_device_classes(c, 1, &k, d_cx, d_cu));
     }
-    BH(hipMemcpyAsync(fin.data(), arena + o_fin, n * sizeof(hop_cu_final), hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(bits.data(), arena + o_bits, n * 4, hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(cx.data(), arena + o_ctx_out, n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(cu.data(), arena + o_cu_out, n * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, s));
     BH(hipStreamSynchronize(s));
+    const hop_cu_final* fin = (const hop_cu_final*)(hout + r_fin); const uint32_t* bits = (const uint32_t*)(hout + r_bits); const uint32_t* skipped = (const uint32_t*)(hout + r_skipped);
+    const hop_cabac_ctx* cx = (const hop_cabac_ctx*)(hout + r_cx); const hop_cabac_cu_ctx* cu = (const hop_cabac_cu_ctx*)(hout + r_cu); const hop_rqt_result* res = (const hop_rqt_result*)(hout + r_res);
     for (int i = 0; i < n; i++) {
-      EvalResult& o = *out[i];
-      o.bits = bits[i]; o.dist = fin[i].dist[0] + fin[i].dist[1] + fin[i].dist[2]; o.cost = 0; o.skipped = (int)skipped[i]; o.root_cbf = (int)fin[i].root_cbf;
-      if (e[0]->skip_res) { memset(o.tr_idx, 0, sizeof(o.tr_idx)); memset(o.cbf, 0, sizeof(o.cbf)); memset(o.tskip, 0, sizeof(o.tskip)); }
-      else { memcpy(o.tr_idx, res[i].tr_idx, 256); memcpy(o.cbf, res[i].cbf, 768); memcpy(o.tskip, res[i].tskip, 768); }
-      o.after = *in[i]; o.after.r = cx[i]; o.after.c = cu[i];
+      EvalResult& r = *out[i];
+      r.bits = bits[i]; r.dist = fin[i].dist[0] + fin[i].dist[1] + fin[i].dist[2]; r.cost = 0; r.skipped = skip ? 1 : (int)skipped[i]; r.root_cbf = (int)fin[i].root_cbf;
+      if (skip) { memset(r.tr_idx, 0, sizeof(r.tr_idx)); memset(r.cbf, 0, sizeof(r.cbf)); memset(r.tskip, 0, sizeof(r.tskip)); }
+      else { memcpy(r.tr_idx, res[i].tr_idx, 256); memcpy(r.cbf, res[i].cbf, 768); memcpy(r.tskip, res[i].tskip, 768); }
+      r.after = *in[i]; r.after.r = cx[i]; r.after.c = cu[i];
     }
   }
   void intra_n(int n, const IntraEval* const* e, const Coder* const* in, EvalResult* const* out) {
     if (n > MAXN) throw Bail{ HOP_ERR_ARG };
+    on_device();
     Tick t(6);
     hipStream_t s = c->stream;
-    std::vector<hop_rqt_job> jobs(n); std::vector<hop_intra_cu_syntax> syn(n); std::vector<hop_intra_rqt_opt> opt(n); std::vector<hop_intra_search_job> sj(n);
-    std::vector<hop_cabac_ctx> cx(n); std::vector<hop_cabac_cu_ctx> cu(n);
-    for (int i = 0; i < n; i++) { jobs[i] = e[i]->job; jobs[i].ctx_index = i; syn[i] = e[i]->syn; opt[i] = e[i]->opt; sj[i] = e[i]->sjob; cx[i] = in[i]->r; cu[i] = in[i]->c; }
-    BH(hipMemcpyAsync(arena + o_jobs, jobs.data(), n * sizeof(hop_rqt_job), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_isyn, syn.data(), n * sizeof(hop_intra_cu_syntax), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_opts, opt.data(), n * sizeof(hop_intra_rqt_opt), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_sjobs, sj.data(), n * sizeof(hop_intra_search_job), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_ctx_in, cx.data(), n * sizeof(hop_cabac_ctx), hipMemcpyHostToDevice, s));
-    BH(hipMemcpyAsync(arena + o_cu_in, cu.data(), n * sizeof(hop_cabac_cu_ctx), hipMemcpyHostToDevice, s));
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t i_jobs = take(n * sizeof(hop_rqt_job)), i_syn = take(n * sizeof(hop_intra_cu_syntax)), i_opt = take(n * sizeof(hop_intra_rqt_opt)), i_sj = take(n * sizeof(hop_intra_search_job)),
+                 i_cx = take(n * sizeof(hop_cabac_ctx)), i_cu = take(n * sizeof(hop_cabac_cu_ctx)), in_bytes = o;
+    o = 0;
+    const size_t r_res = take(n * sizeof(hop_rqt_result)), r_sres = take(n * sizeof(hop_intra_search_result)), r_cres = take(n * sizeof(hop_intra_chroma_result)), r_bits = take(n * 4),
+                 r_dist = take(n * 4), r_cx = take(n * sizeof(hop_cabac_ctx)), r_cu = take(n * sizeof(hop_cabac_cu_ctx)), out_bytes = o;
+    hop_rqt_job* hj = (hop_rqt_job*)(hin + i_jobs); hop_intra_cu_syntax* hs = (hop_intra_cu_syntax*)(hin + i_syn); hop_intra_rqt_opt* ho = (hop_intra_rqt_opt*)(hin + i_opt);
+    hop_intra_search_job* hq = (hop_intra_search_job*)(hin + i_sj); hop_cabac_ctx* hx = (hop_cabac_ctx*)(hin + i_cx); hop_cabac_cu_ctx* hu = (hop_cabac_cu_ctx*)(hin + i_cu);
+    for (int i = 0; i < n; i++) { hj[i] = e[i]->job; hj[i].ctx_index = i; hs[i] = e[i]->syn; ho[i] = e[i]->opt; hq[i] = e[i]->sjob; hx[i] = in[i]->r; hu[i] = in[i]->c; }
+    char* din = arena + o_in; char* dout = arena + o_out;
+    BH(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, s));
     hop_intra_class k; memset(&k, 0, sizeof(k));
-    k.n = n; k.part_nxn = e[0]->part_nxn; k.num_full_rd = e[0]->sjob.num_full_rd; k.cls = jobs[0]; k.cls.x = 0; k.cls.y = 0; k.cls.ctx_index = 0;
-    k.d_jobs = (const hop_rqt_job*)(arena + o_jobs); k.d_syntax = (const hop_intra_cu_syntax*)(arena + o_isyn); k.d_opts = (const hop_intra_rqt_opt*)(arena + o_opts);
-    k.d_sjobs = (const hop_intra_search_job*)(arena + o_sjobs); k.d_sresults = (hop_intra_search_result*)(arena + o_sres); k.d_results = (hop_rqt_result*)(arena + o_res);
-    k.d_cresults = (hop_intra_chroma_result*)(arena + o_cres); k.d_coef = (int32_t*)(arena + o_coef); k.d_reco_y = (int16_t*)(arena + o_reco_y); k.d_reco_c = (int16_t*)(arena + o_reco_c);
-    k.d_syntax_out = (hop_intra_cu_syntax*)(arena + o_isyn_out); k.d_dist = (uint32_t*)(arena + o_dist); k.d_bits = (uint32_t*)(arena + o_bits); k.d_cost = (double*)(arena + o_cost);
-    k.d_ctx_out = (hop_cabac_ctx*)(arena + o_ctx_out); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(arena + o_cu_out);
-    BK(hop_intra_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(arena + o_ctx_in), (const hop_cabac_cu_ctx*)(arena + o_cu_in)));
+    k.n = n; k.part_nxn = e[0]->part_nxn; k.num_full_rd = e[0]->sjob.num_full_rd; k.cls = hj[0]; k.cls.x = 0; k.cls.y = 0; k.cls.ctx_index = 0;
+    k.d_jobs = (const hop_rqt_job*)(din + i_jobs); k.d_syntax = (const hop_intra_cu_syntax*)(din + i_syn); k.d_opts = (const hop_intra_rqt_opt*)(din + i_opt);
+    k.d_sjobs = (const hop_intra_search_job*)(din + i_sj); k.d_sresults = (hop_intra_search_result*)(dout + r_sres); k.d_results = (hop_rqt_result*)(dout + r_res);
+    k.d_cresults = (hop_intra_chroma_result*)(dout + r_cres); k.d_coef = (int32_t*)(arena + o_coef); k.d_reco_y = (int16_t*)(arena + o_reco_y); k.d_reco_c = (int16_t*)(arena + o_reco_c);
+    k.d_syntax_out = (hop_intra_cu_syntax*)(arena + o_isyn_out); k.d_dist = (uint32_t*)(dout + r_dist); k.d_bits = (uint32_t*)(dout + r_bits); k.d_cost = (double*)(arena + o_cost);
+    k.d_ctx_out = (hop_cabac_ctx*)(dout + r_cx); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(dout + r_cu);
+    BK(hop_intra_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(din + i_cx), (const hop_cabac_cu_ctx*)(din + i_cu)));
     BK(hop_recon_put_device(c, n, k.d_jobs, k.d_reco_y, k.d_reco_c));
-    std::vector<hop_rqt_result> res(n); std::vector<hop_intra_search_result> sres(n); std::vector<hop_intra_chroma_result> cres(n); std::vector<uint32_t> bits(n), dist(n);
-    BH(hipMemcpyAsync(res.data(), arena + o_res, n * sizeof(hop_rqt_result), hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(sres.data(), arena + o_sres, n * sizeof(hop_intra_search_result), hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(cres.data(), arena + o_cres, n * sizeof(hop_intra_chroma_result), hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(bits.data(), arena + o_bits, n * 4, hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(dist.data(), arena + o_dist, n * 4, hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(cx.data(), arena + o_ctx_out, n * sizeof(hop_cabac_ctx), hipMemcpyDeviceToHost, s));
-    BH(hipMemcpyAsync(cu.data(), arena + o_cu_out, n * sizeof(hop_cabac_cu_ctx), hipMemcpyDeviceToHost, s));
+    BH(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, s));
     BH(hipStreamSynchronize(s));
+    const hop_rqt_result* res = (const hop_rqt_result*)(hout + r_res); const hop_intra_search_result* sres = (const hop_intra_search_result*)(hout + r_sres);
+    const hop_intra_chroma_result* cres = (const hop_intra_chroma_result*)(hout + r_cres); const uint32_t* bits = (const uint32_t*)(hout + r_bits); const uint32_t* dist = (const uint32_t*)(hout + r_dist);
+    const hop_cabac_ctx* cx = (const hop_cabac_ctx*)(hout + r_cx); const hop_cabac_cu_ctx* cu = (const hop_cabac_cu_ctx*)(hout + r_cu);
     for (int i = 0; i < n; i++) {
-      EvalResult& o = *out[i];
-      o.bits = bits[i]; o.dist = dist[i]; o.cost = 0; o.skipped = 0; o.root_cbf = 1;
-      memcpy(o.tr_idx, res[i].tr_idx, 256); memcpy(o.cbf, res[i].cbf, 768); memcpy(o.tskip, res[i].tskip, 768);
-      for (int p = 0; p < 4; p++) o.luma_dir[p] = sres[i].best_dir[p];
-      o.chroma_dir = cres[i].best_mode;
-      o.after = *in[i]; o.after.r = cx[i]; o.after.c = cu[i];
+      EvalResult& r = *out[i];
+      r.bits = bits[i]; r.dist = dist[i]; r.cost = 0; r.skipped = 0; r.root_cbf = 1;
+      memcpy(r.tr_idx, res[i].tr_idx, 256); memcpy(r.cbf, res[i].cbf, 768); memcpy(r.tskip, res[i].tskip, 768);
+      for (int p = 0; p < 4; p++) r.luma_dir[p] = sres[i].best_dir[p];
+      r.chroma_dir = cres[i].best_mode;
+      r.after = *in[i]; r.after.r = cx[i]; r.after.c = cu[i];
     }
   }
  private:
-  hop_ctx* c; char* arena; size_t bytes;
+  hop_ctx* c; char* arena; size_t bytes; char* hin; char* hout; size_t io_bytes, o_in, o_out;
   size_t o_jobs, o_syn, o_isyn, o_isyn_out, o_opts, o_sjobs, o_sres, o_res, o_cres, o_coef, o_reco_y, o_reco_c, o_ctx_in, o_cu_in, o_ctx_after, o_ctx_out, o_cu_out, o_fin, o_bits, o_skipped,
          o_cost, o_dist, o_pjobs, o_djobs, o_pout;
 };

@@ -17,6 +17,9 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <functional>
+#include <ucontext.h>
 
 namespace hopspine {
 
@@ -917,8 +920,49 @@ void Encoder::encode_frame(int first_ctus) {
 // wavefront: one thread per CTU row, requests of the rows in flight rendezvous and are served in batches
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
-struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; uint64_t tag; };
+struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; uint64_t tag; std::condition_variable* wake; };   // wake: the submitting thread's own (only it is woken when the request is done)
 enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTORE, RQ_COMMIT, RQ_PCOST };
+
+// one group of requests of the same kind (and class) as one call of the batching backend
+static void run_group(BatchInner* inner_, std::vector<Req*>& g) {
+  const int kind = g[0]->kind;
+  if (kind == RQ_ME) {
+    std::vector<hop_pu_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pu_job*)r->a, (const hop_pu_job*)r->a + r->n);
+    std::vector<hop_pu_result> o(j.size());
+    inner_->me_search(0, (int)j.size(), j.data(), o.data());
+    size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], sizeof(hop_pu_result) * r->n); at += r->n; }
+  } else if (kind == RQ_PRED) {
+    std::vector<hop_pred_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pred_job*)r->a, (const hop_pred_job*)r->a + r->n);
+    inner_->pred_inter(0, (int)j.size(), j.data());
+  } else if (kind == RQ_DIST) {
+    std::vector<hop_dist_job> j; for (Req* r : g) j.insert(j.end(), (const hop_dist_job*)r->a, (const hop_dist_job*)r->a + r->n);
+    std::vector<uint32_t> o(j.size());
+    inner_->distortion(0, (int)j.size(), j.data(), o.data());
+    size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], 4 * r->n); at += r->n; }
+  } else if (kind == RQ_VALID) {
+    std::vector<int32_t> j; for (Req* r : g) j.insert(j.end(), (const int32_t*)r->a, (const int32_t*)r->a + 6 * r->n);
+    std::vector<uint8_t> o(j.size() / 6);
+    inner_->valid_pattern(0, (int)o.size(), j.data(), o.data());
+    size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], r->n); at += r->n; }
+  } else if (kind == RQ_PCOST) {
+    std::vector<int> len, kinds; std::vector<hop_pred_job> j;
+    for (Req* r : g) { len.push_back(r->n); kinds.push_back(r->i0); j.insert(j.end(), (const hop_pred_job*)r->a, (const hop_pred_job*)r->a + r->n); }
+    std::vector<uint32_t> o(j.size());
+    inner_->pred_cost_n((int)g.size(), len.data(), j.data(), kinds.data(), o.data());
+    size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], 4 * r->n); at += r->n; }
+  } else if (kind == RQ_INTER) {
+    std::vector<const InterEval*> e; std::vector<const Coder*> in; std::vector<EvalResult*> o;
+    for (Req* r : g) { e.push_back((const InterEval*)r->a); in.push_back((const Coder*)r->b); o.push_back((EvalResult*)r->out); }
+    inner_->inter_n((int)g.size(), e.data(), in.data(), o.data());
+  } else if (kind == RQ_INTRA) {
+    std::vector<const IntraEval*> e; std::vector<const Coder*> in; std::vector<EvalResult*> o;
+    for (Req* r : g) { e.push_back((const IntraEval*)r->a); in.push_back((const Coder*)r->b); o.push_back((EvalResult*)r->out); }
+    inner_->intra_n((int)g.size(), e.data(), in.data(), o.data());
+  } else {
+    std::vector<int32_t> rc; for (Req* r : g) { rc.push_back(r->i0); rc.push_back(r->i1); rc.push_back(r->i2); rc.push_back(r->i3); }
+    if (kind == RQ_COMMIT) inner_->commit_n((int)g.size(), rc.data()); else inner_->stash_n((int)g.size(), rc.data(), kind == RQ_RESTORE);
+  }
+}
 
 class Rendezvous : public Backend {
  public:
@@ -957,11 +1001,12 @@ class Rendezvous : public Backend {
     std::unique_lock<std::mutex> lk(m);
     if (failed_) throw 1;
     q.tag = tag_of_[q.lane % SPINE_LANES];
+    std::condition_variable mine; q.wake = &mine;
     pending_.push_back(&q);
     active_--;
     while (active_ == 0 && !pending_.empty() && !q.done) serve(lk);
-    cv.wait(lk, [&] { return q.done || failed_; });
-    if (failed_ && !q.done) throw 1;
+    mine.wait(lk, [&] { return q.done || failed_; });
+    if (failed_ && !q.done) { for (size_t i = 0; i < pending_.size(); i++) if (pending_[i] == &q) { pending_.erase(pending_.begin() + i); break; } throw 1; }
   }
   void serve(std::unique_lock<std::mutex>&) {         // called with the lock held and every thread parked: one batch per kind / class
     // the requests with the smallest tag (the rows coded side by side have started their CTUs together: equal tags are the same operation); the others wait their turn
@@ -980,52 +1025,135 @@ class Rendezvous : public Backend {
           if ((v[i]->kind == RQ_INTER || v[i]->kind == RQ_INTRA) && (v[k]->i0 != v[i]->i0 || v[k]->i1 != v[i]->i1)) continue;
           used[k] = 1; g.push_back(v[k]);
         }
-        run_group(g);
+        run_group(inner_, g);
       }
     } catch (...) { failed_ = true; }
-    for (size_t i = 0; i < v.size(); i++) v[i]->done = true;
+    for (size_t i = 0; i < v.size(); i++) { v[i]->done = true; v[i]->wake->notify_one(); }
     active_ += (int)v.size();
-    cv.notify_all();
+    if (failed_) { for (Req* r : pending_) r->wake->notify_one(); cv.notify_all(); }   // everybody gives up
   }
-  void run_group(std::vector<Req*>& g) {
-    const int kind = g[0]->kind;
-    if (kind == RQ_ME) {
-      std::vector<hop_pu_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pu_job*)r->a, (const hop_pu_job*)r->a + r->n);
-      std::vector<hop_pu_result> o(j.size());
-      inner_->me_search(0, (int)j.size(), j.data(), o.data());
-      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], sizeof(hop_pu_result) * r->n); at += r->n; }
-    } else if (kind == RQ_PRED) {
-      std::vector<hop_pred_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pred_job*)r->a, (const hop_pred_job*)r->a + r->n);
-      inner_->pred_inter(0, (int)j.size(), j.data());
-    } else if (kind == RQ_DIST) {
-      std::vector<hop_dist_job> j; for (Req* r : g) j.insert(j.end(), (const hop_dist_job*)r->a, (const hop_dist_job*)r->a + r->n);
-      std::vector<uint32_t> o(j.size());
-      inner_->distortion(0, (int)j.size(), j.data(), o.data());
-      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], 4 * r->n); at += r->n; }
-    } else if (kind == RQ_VALID) {
-      std::vector<int32_t> j; for (Req* r : g) j.insert(j.end(), (const int32_t*)r->a, (const int32_t*)r->a + 6 * r->n);
-      std::vector<uint8_t> o(j.size() / 6);
-      inner_->valid_pattern(0, (int)o.size(), j.data(), o.data());
-      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], r->n); at += r->n; }
-    } else if (kind == RQ_PCOST) {
-      std::vector<int> len, kinds; std::vector<hop_pred_job> j;
-      for (Req* r : g) { len.push_back(r->n); kinds.push_back(r->i0); j.insert(j.end(), (const hop_pred_job*)r->a, (const hop_pred_job*)r->a + r->n); }
-      std::vector<uint32_t> o(j.size());
-      inner_->pred_cost_n((int)g.size(), len.data(), j.data(), kinds.data(), o.data());
-      size_t at = 0; for (Req* r : g) { memcpy(r->out, &o[at], 4 * r->n); at += r->n; }
-    } else if (kind == RQ_INTER) {
-      std::vector<const InterEval*> e; std::vector<const Coder*> in; std::vector<EvalResult*> o;
-      for (Req* r : g) { e.push_back((const InterEval*)r->a); in.push_back((const Coder*)r->b); o.push_back((EvalResult*)r->out); }
-      inner_->inter_n((int)g.size(), e.data(), in.data(), o.data());
-    } else if (kind == RQ_INTRA) {
-      std::vector<const IntraEval*> e; std::vector<const Coder*> in; std::vector<EvalResult*> o;
-      for (Req* r : g) { e.push_back((const IntraEval*)r->a); in.push_back((const Coder*)r->b); o.push_back((EvalResult*)r->out); }
-      inner_->intra_n((int)g.size(), e.data(), in.data(), o.data());
-    } else {
-      std::vector<int32_t> rc; for (Req* r : g) { rc.push_back(r->i0); rc.push_back(r->i1); rc.push_back(r->i2); rc.push_back(r->i3); }
-      if (kind == RQ_COMMIT) inner_->commit_n((int)g.size(), rc.data()); else inner_->stash_n((int)g.size(), rc.data(), kind == RQ_RESTORE);
+};
+
+// The same rendezvous without a thread per CTU row: the rows are FIBERS (ucontext) spread over a few worker threads.  A row that submits a request, or waits for the
+// wavefront to advance, switches back to its worker's scheduler; a worker whose rows are all waiting joins a barrier; when every worker is there the requests with the
+// smallest tag are served as one batch per kind (exactly as above) and the workers go round again.  A request costs two context switches in user space instead of a futex
+// sleep and wake-up per row thread -- with hundreds of rows in flight (several pictures side by side) those wake-ups were the largest single cost of the host side.
+class FiberPool : public Backend {
+ public:
+  struct Fiber { ucontext_t ctx; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool; };
+  FiberPool(BatchInner* inner, int n_workers) : rounds(0), requests(0), steps_complete(-1), inner_(inner), T_(n_workers), failed_(false), finished_(false), arrived_(0), gen_(0), left_(0), idle_rounds_(0) {
+    memset(tag_of_, 0, sizeof(tag_of_)); sched_.resize(T_); mine_.resize(T_); local_.resize(T_);
+  }
+  ~FiberPool() { for (Fiber* f : all_) { free(f->stack); delete f; } }
+  void add(std::function<void()> body) {
+    Fiber* f = new Fiber(); f->stack = (char*)malloc(STACK); f->body = body; f->done = false; f->req = NULL; f->wait_step = -1; f->worker = (int)(all_.size() % T_); f->pool = this;
+    all_.push_back(f); mine_[f->worker].push_back(f); left_++;
+  }
+  void run() {                                                          // all fibers to completion
+    std::vector<std::thread> th;
+    for (int w = 0; w < T_; w++) th.emplace_back([this, w]() { worker(w); });
+    for (auto& t : th) t.join();
+  }
+  bool failed() const { return failed_; }
+  // ---- called from inside fibers ----
+  void set_tag(int lane, uint64_t tag) { tag_of_[lane % SPINE_LANES] = tag; }
+  void begin_frame() {}
+  void me_search(int lane, int n, const hop_pu_job* j, hop_pu_result* r) { Req q = { RQ_ME, lane, n, j, NULL, r, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
+  void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
+  void distortion(int lane, int n, const hop_dist_job* j, uint32_t* o) { Req q = { RQ_DIST, lane, n, j, NULL, o, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
+  void valid_pattern(int lane, int n, const int32_t* v, uint8_t* o) { Req q = { RQ_VALID, lane, n, v, NULL, o, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
+  void pred_cost(int lane, int n, const hop_pred_job* j, int kind, uint32_t* o) { Req q = { RQ_PCOST, lane, n, j, NULL, o, kind, 0, 0, 0, false, 0, NULL }; submit(q); }
+  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTER, lane, 1, &e, &in, &o, e.job.log2_cu, e.skip_res, 0, 0, false, 0, NULL }; submit(q); }
+  void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTRA, lane, 1, &e, &in, &o, e.job.log2_cu, e.part_nxn, 0, 0, false, 0, NULL }; submit(q); }
+  void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; submit(q); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; submit(q); }
+  void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; submit(q); }
+  void wait_step(int st) {                                              // until every wavefront step <= st is finished
+    if (steps_complete.load() >= st) return;
+    Fiber* f = current(); f->wait_step = st;
+    swapcontext(&f->ctx, &sched_[f->worker]);
+    if (failed_) throw 1;
+  }
+  uint64_t rounds, requests;
+  std::atomic<int> steps_complete;
+  std::mutex steps_m;                                                   // guards the callers' step counters
+ private:
+  enum { STACK = 512 * 1024 };
+  static Fiber*& current() { static thread_local Fiber* cur = NULL; return cur; }
+  static void tramp(unsigned lo, unsigned hi) {
+    Fiber* f = (Fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    try { f->body(); } catch (...) { f->pool->failed_ = true; }
+    f->done = true; f->pool->left_--;
+    // returning ends the context: uc_link takes the worker's scheduler up where it left off
+  }
+  void submit(Req& q) {
+    if (failed_) throw 1;
+    Fiber* f = current();
+    q.tag = tag_of_[q.lane % SPINE_LANES];
+    local_[f->worker].push_back(&q);
+    f->req = &q;
+    swapcontext(&f->ctx, &sched_[f->worker]);
+    if (!q.done) throw 1;                                               // resumed without an answer: the pool has failed
+  }
+  void worker(int w) {
+    for (Fiber* f : mine_[w]) {
+      getcontext(&f->ctx);
+      f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = STACK; f->ctx.uc_link = &sched_[w];
+      makecontext(&f->ctx, (void (*)())tramp, 2, (unsigned)((uintptr_t)f & 0xFFFFFFFFu), (unsigned)((uintptr_t)f >> 32));
+    }
+    for (;;) {
+      bool ran = false;
+      for (Fiber* f : mine_[w]) {
+        if (f->done) continue;
+        if (f->req) { if (!f->req->done && !failed_) continue; f->req = NULL; }
+        else if (f->wait_step >= 0) { if (steps_complete.load() < f->wait_step && !failed_) continue; f->wait_step = -1; }
+        current() = f;
+        swapcontext(&sched_[w], &f->ctx);                               // until it submits, waits or ends
+        ran = true;
+      }
+      if (ran) continue;                                                // what ran may have released others of this worker
+      if (!barrier(w)) break;
     }
   }
+  bool barrier(int) {                                                   // false: everything has finished
+    std::unique_lock<std::mutex> lk(bm_);
+    const uint64_t gen = gen_;
+    if (++arrived_ == T_) {                                             // every worker is out of runnable rows: serve, or finish
+      for (int k = 0; k < T_; k++) { pending_.insert(pending_.end(), local_[k].begin(), local_[k].end()); local_[k].clear(); }
+      if (left_.load() == 0) finished_ = true;
+      else if (failed_) { for (Req* r : pending_) (void)r; pending_.clear(); }
+      else if (!pending_.empty()) { serve(); idle_rounds_ = 0; }
+      else if (++idle_rounds_ > 100000) failed_ = true;                 // rows waiting for a step nobody can finish
+      arrived_ = 0; gen_++;
+      bcv_.notify_all();
+    } else bcv_.wait(lk, [&] { return gen_ != gen; });
+    return !finished_;
+  }
+  void serve() {
+    uint64_t tmin = ~0ull; for (Req* r : pending_) if (r->tag < tmin) tmin = r->tag;
+    std::vector<Req*> v, rest;
+    for (Req* r : pending_) (r->tag == tmin ? v : rest).push_back(r);
+    pending_.swap(rest);
+    rounds++; requests += v.size();
+    try {
+      std::vector<char> used(v.size(), 0);
+      for (size_t i = 0; i < v.size(); i++) {
+        if (used[i]) continue;
+        std::vector<Req*> g;
+        for (size_t k = i; k < v.size(); k++) {
+          if (used[k] || v[k]->kind != v[i]->kind) continue;
+          if ((v[i]->kind == RQ_INTER || v[i]->kind == RQ_INTRA) && (v[k]->i0 != v[i]->i0 || v[k]->i1 != v[i]->i1)) continue;
+          used[k] = 1; g.push_back(v[k]);
+        }
+        run_group(inner_, g);
+      }
+      for (size_t i = 0; i < v.size(); i++) v[i]->done = true;
+    } catch (...) { failed_ = true; }
+  }
+  BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
+  std::vector<ucontext_t> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
+  std::mutex bm_; std::condition_variable bcv_; int arrived_; uint64_t gen_; std::atomic<int> left_; int idle_rounds_;
+  uint64_t tag_of_[SPINE_LANES];
 };
 }  // namespace
 
@@ -1049,6 +1177,62 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     Encoder& E = *encs[p];
     for (size_t i = 0; i < E.pic.size(); i++) part_init(E.pic[i], 0);
     std::fill(E.committed.begin(), E.committed.end(), (uint8_t)0);
+  }
+  if (inner) {                                                          // the batching form: rows as fibers on a few worker threads
+    int T = (int)std::thread::hardware_concurrency(); if (T > 12) T = 12; if (T < 1) T = 1;
+    if (const char* e = getenv("HOP_SPINE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) T = v; }
+    if (T > rows * n_pic) T = rows * n_pic;
+    FiberPool pool(inner, T);
+    const int n_steps = cols + lag * (rows - 1);
+    std::vector<int> in_step(n_steps, 0), fin_step(n_steps, 0);
+    for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) in_step[c + lag * r] += n_pic;
+    std::vector<Coder> sync((size_t)rows * n_pic);
+    std::vector<uint64_t> cand((size_t)rows * n_pic, 0);
+    for (int p = 0; p < n_pic; p++) for (int r = 0; r < rows; r++) {
+      pool.add([&, p, r]() {
+        Encoder& E = *encs[p];
+        const int lane = p * (rif < rows ? rif : rows) + r % rif;
+        CtuWorker* w = new CtuWorker(E, lane, &pool);
+        int c = 0;
+        try {
+          Coder k = init;
+          for (; c < cols; c++) {
+            const int st = c + lag * r;
+            pool.wait_step(st - 1);
+            if (c == 0 && r > 0 && cols >= 2) { std::lock_guard<std::mutex> g(pool.steps_m); k = sync[(size_t)p * rows + r - 1]; coder_set_frac(k, 0); }   // loadContexts (see below)
+            const int a = r * cols + c;
+            E.ctu_entry[a] = k;
+            Coder next; w->compress_ctu(a, k, next);
+            k = next;
+            std::lock_guard<std::mutex> g(pool.steps_m);
+            if (c == 1) sync[(size_t)p * rows + r] = k;
+            fin_step[st]++;
+            int sc = pool.steps_complete.load();
+            while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
+            pool.steps_complete.store(sc);
+          }
+        } catch (...) {
+          std::lock_guard<std::mutex> g(pool.steps_m);
+          for (; c < cols; c++) fin_step[c + lag * r]++;               // after a failure: nobody waits for this row
+          int sc = pool.steps_complete.load();
+          while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
+          pool.steps_complete.store(sc);
+          cand[(size_t)p * rows + r] = w->n_cand_; delete w;
+          throw;
+        }
+        cand[(size_t)p * rows + r] = w->n_cand_;
+        delete w;
+      });
+    }
+    pool.run();
+    for (int p = 0; p < n_pic; p++) {
+      Encoder& E = *encs[p];
+      for (int r = 0; r < rows; r++) E.n_candidates += cand[(size_t)p * rows + r];
+      E.batch_rounds = pool.rounds; E.batch_requests = pool.requests;
+      if (E.trace) for (int a = 0; a < E.n_ctu(); a++) { fputs(E.ctu_trace[a].c_str(), E.trace); E.ctu_trace[a].clear(); }
+    }
+    if (pool.failed()) throw 1;
+    return;
   }
   Rendezvous rv(inner, rows * n_pic);
   // synchronous wavefront: step s holds the CTUs (r, c) with c + lag * r == s of every picture; a step starts when the previous one has finished, so that its CTUs start

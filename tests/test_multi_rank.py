@@ -135,3 +135,18 @@ def test_independent_pictures_world2():
         cost = run_cpu_wpp(spine_cpu(), W, hb, Y[y0:y0 + hb], Cb[y0 // 2:(y0 + hb) // 2], Cr[y0 // 2:(y0 + hb) // 2], 0)[0]
         assert g[1:] == cost.tolist(), b
     assert tmax == 2.0
+
+
+def test_tiles_of_rank_partition_the_frame():
+    """the default mode's split: the frame cut into whole tiles, `pictures` per rank, consecutive ranks taking consecutive tiles (no tile twice until all are used)"""
+    import bench
+    fw, fh, tw, th, P = 7728, 5368, 1024, 256, 8
+    seen = []
+    for rank in range(8):
+        t = bench.tiles_of_rank(fw, fh, tw, th, P, rank)
+        assert len(t) == P
+        for x, y in t:
+            assert x % tw == 0 and y % th == 0 and x + tw <= fw and y + th <= fh
+        seen += t
+    assert len(set(seen)) == 64                       # 7 x 20 = 140 tiles in the frame: 8 ranks x 8 pictures are all different
+    assert bench.tiles_of_rank(fw, fh, tw, th, 140, 0)[-1] == (6 * 1024, 19 * 256) and bench.tiles_of_rank(fw, fh, tw, th, 1, 140) == [(0, 0)]

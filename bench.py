@@ -493,7 +493,7 @@ def encode_main(args):
     tiles = tiles_of_rank(fw, fh, tw, th, P, rank)
     pics = [(Yf[y:y + th, x:x + tw].cpu().numpy(), Cbf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy(), Crf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy()) for x, y in tiles]
     del Yf, Cbf, Crf
-    ctx = hp.Context(tw, th, device=local, pictures=P)
+    ctx = hp.Context(tw, th, device=local, pictures=P, slots=args.slots)
     if P > 1:
         ctx.upload_orig(ctx.stack([p[0] for p in pics]), ctx.stack([p[1] for p in pics], True), ctx.stack([p[2] for p in pics], True))
     else:
@@ -524,7 +524,7 @@ def encode_main(args):
         value = world * n_ctu * args.steps / dt
         # ---- roofline of the dominant kernel: a separate, untimed pass over ONE of the pictures with HIP events around every launch (graphs off while profiling) ----
         Y0, Cb0, Cr0 = pics[0]
-        pctx = hp.Context(tw, th, device=local)
+        pctx = hp.Context(tw, th, device=local, slots=args.slots)
         pctx.upload_orig(Y0, Cb0, Cr0)
         L = pctx.L
         L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
@@ -558,7 +558,7 @@ def encode_main(args):
                                    "%d of them per GPU (%d CTUs) coded side by side in one stacked context -- each exactly as a picture of its own (SS reference from the sentinel, every "
                                    "candidate of xCompressCU, rows as a lag-%d wavefront with WaveFrontSynchro contexts; tests/test_gpu_spine.py pins that to the reference encoder)"
                                    % (fw, fh, PITCH, QP, tw, th, P, n_ctu, args.lag),
-                       "pictures_per_gpu": P, "picture": [tw, th], "ctus_per_step": n_ctu, "candidates_per_step": ncand, "parallelism": "independent-pictures x%d per GPU, x%d GPUs" % (P, world),
+                       "pictures_per_gpu": P, "picture": [tw, th], "candidate_slots": args.slots, "ctus_per_step": n_ctu, "candidates_per_step": ncand, "parallelism": "independent-pictures x%d per GPU, x%d GPUs" % (P, world),
                        "whole_frame_note": "--width 7728 --rows 84 --pictures 1 codes the 7728x5368 frame as ONE picture: at most 24 CTU rows in flight (lag 5), 536 wavefront steps; see DESIGN.md for its rate"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
@@ -607,6 +607,7 @@ def main():
     ap.add_argument("--height", type=int, default=FRAME_H)
     ap.add_argument("--rows", type=int, default=4, help="CTU rows of one picture (tile); 84 with --tile-w 7728 --pictures 1 = the whole frame as one picture")
     ap.add_argument("--tile-w", type=int, default=1024, help="width of one picture (tile)")
+    ap.add_argument("--slots", type=int, default=16, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
     ap.add_argument("--pictures", type=int, default=64, help="independent pictures coded side by side per GPU (one stacked context)")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
     ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")

@@ -117,7 +117,7 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   *out = nullptr;
   hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
   c->pic_w = parent->pic_w; c->pic_h = parent->pic_h; c->bd_y = parent->bd_y; c->bd_c = parent->bd_c; c->device = parent->device;
-  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->sub_h = parent->sub_h; c->sub_pitch = parent->sub_pitch; c->fused_leaf_max = parent->fused_leaf_max; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
+  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->sub_h = parent->sub_h; c->sub_pitch = parent->sub_pitch; c->slots = parent->slots; c->fused_leaf_max = parent->fused_leaf_max; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
   c->org_y = parent->org_y; c->org_cb = parent->org_cb; c->org_cr = parent->org_cr;
   for (int k = 0; k < 3; k++) { c->ss_alloc[k] = parent->ss_alloc[k]; c->ss_buf[k] = parent->ss_buf[k]; c->ss00[k] = parent->ss00[k]; c->pred[k] = parent->pred[k]; c->rec[k] = parent->rec[k]; }
   c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots;
@@ -133,6 +133,25 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
 // Several independent pictures of equal size in one context, so that one batch of requests serves CTUs of all of them (hop_encode_frame codes them side by side): the
 // context's picture is their stack, picture k at rows k * sub_pitch .. k * sub_pitch + sub_h - 1, the rows between them unused.  The gap keeps every sample a picture's
 // searches, margins and prefetches can touch (its margin + guard rows above and below) away from its neighbours', so each picture is coded exactly as in a context of its own.
+// Candidate slots: the original, prediction and reconstruction pictures are laid out slots + 1 times one below the other (copy k at rows k * pic_h; the original is the
+// same in all of them).  A request whose y coordinate is y + k * pic_h then works on copy k: candidates of one CU evaluated side by side predict, transform and
+// reconstruct in copies of their own while searching the one SS reference (the predictor kernel takes the copy as hop_pred_job.dst_row_off).  Call before hop_upload_orig.
+int hop_ctx_set_slots(hop_ctx* c, int slots) {
+  if (!c || c->is_view || slots < 0 || slots > 64) return hop_set_err(c, HOP_ERR_ARG, "hop_ctx_set_slots: bad argument");
+  if (slots == c->slots) return HOP_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t ny = (size_t)c->pic_w * c->pic_h * (slots + 1), nc = ny >> 2;
+  int16_t** planes[9] = { &c->org_y, &c->org_cb, &c->org_cr, &c->pred[0], &c->pred[1], &c->pred[2], &c->rec[0], &c->rec[1], &c->rec[2] };
+  for (int k = 0; k < 9; k++) {
+    if (*planes[k]) (void)hipFree(*planes[k]);
+    *planes[k] = nullptr;
+    hipError_t e = hipMalloc((void**)planes[k], ((k % 3) ? nc : ny) * 2);
+    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_ctx_set_slots: %s", hipGetErrorString(e));
+  }
+  c->slots = slots; c->have_orig = false;
+  return HOP_OK;
+}
+
 int hop_set_fused_leaf(hop_ctx* c, int max_tus) { if (!c || max_tus < 0) return hop_set_err(c, HOP_ERR_ARG, "hop_set_fused_leaf: bad argument"); c->fused_leaf_max = max_tus; return HOP_OK; }
 
 int hop_stack_pitch(int sub_h) { return ((sub_h + 63) / 64) * 64 + 64 * ((2 * (HOP_MARGIN_Y + HOP_GUARD_ROWS) + 63) / 64); }
@@ -177,6 +196,12 @@ int hop_upload_orig(hop_ctx* c, const int16_t* y, int stride_y, const int16_t* c
   HIPCHK(c, hipMemcpy2DAsync(c->org_y, (size_t)c->pic_w * 2, y, (size_t)stride_y * 2, (size_t)c->pic_w * 2, c->pic_h, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpy2DAsync(c->org_cb, (size_t)c->pic_w, cb, (size_t)stride_c * 2, (size_t)c->pic_w, c->pic_h >> 1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpy2DAsync(c->org_cr, (size_t)c->pic_w, cr, (size_t)stride_c * 2, (size_t)c->pic_w, c->pic_h >> 1, hipMemcpyHostToDevice, c->stream));
+  for (int k = 1; k <= c->slots; k++) {                                  // the copies of the candidate slots
+    const size_t ny = (size_t)c->pic_w * c->pic_h, nc = ny >> 2;
+    HIPCHK(c, hipMemcpyAsync(c->org_y + k * ny, c->org_y, ny * 2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->org_cb + k * nc, c->org_cb, nc * 2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->org_cr + k * nc, c->org_cr, nc * 2, hipMemcpyDeviceToDevice, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_orig = true;
   return HOP_OK;
@@ -364,6 +389,7 @@ int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, 
     const hop_pred_job& j = jobs[i];
     if (!legal_dim(j.w) || !legal_dim(j.h) || j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3) || j.pu_x + j.w > c->pic_w || j.pu_y + j.h > c->pic_h)
       return hop_set_err(c, HOP_ERR_ARG, "pred job %d: illegal PU rectangle", i);
+    if (j.dst_row_off < 0 || j.dst_row_off % c->pic_h || j.dst_row_off / c->pic_h > c->slots) return hop_set_err(c, HOP_ERR_ARG, "pred job %d: dst_row_off %d is not one of the context's %d candidate slots", i, j.dst_row_off, c->slots);
     // reach of the doubled patch + 8-tap filter must stay in the margin
     int ix = j.pu_x + (j.mv_x >> 2), iy = j.pu_y + (j.mv_y >> 2);
     const int lim = HOP_MARGIN_Y + HOP_GUARD_ROWS - 4;      // rows may use the guard band, columns wrap linearly like the reference

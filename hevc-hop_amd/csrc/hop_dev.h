@@ -18,6 +18,7 @@
 struct hop_ctx {
   int pic_w, pic_h, bd_y, bd_c, device;
   int stride_y, stride_c;            // SS-ref strides (with margins)
+  int slots;                         // hop_ctx_set_slots: the original, prediction and reconstruction pictures exist slots + 1 times, copy k at rows k * pic_h (0: once)
   int fused_leaf_max;                // hop_set_fused_leaf: leaf batches of up to this many TUs run as the one-kernel form (default 8192; 0 = always staged)
   int sub_h, sub_pitch;              // hop_ctx_set_stack: the picture is a stack of independent pictures of sub_h rows, origins sub_pitch rows apart (0, 0: one picture)
   hipStream_t stream;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_pred_inter(const hop_pred_job* __restri
   const int ix = jb.mv_x >> ish, iy = jb.mv_y >> ish, xf = jb.mv_x & fmask, yf = jb.mv_y & fmask;
   bool any = false;
   for (int k = 0; k < 8; k++) any = any || jb.gt[k] != 0;
-  dst += (size_t)by * dpitch + bx;
+  dst += (size_t)(by + (chroma ? jb.dst_row_off >> 1 : jb.dst_row_off)) * dpitch + bx;   // dst_row_off: the candidate slot's copy of the prediction picture
   if (!jb.use_gt || !any) {                                   // plain motion compensation, :650-678 / :1246-1289
     const int16_t* r = ref + (ptrdiff_t)(by + iy) * rstride + bx + ix;
     for (int i = tid; i < bw * bh; i += 256) {
@@ -167,7 +167,7 @@ __global__ void k_pred_jobs_from_results(int n, const int32_t* __restrict__ inde
   const hop_pu_job jb = jobs[k];
   const hop_pu_result r = res[k];
   hop_pred_job p;
-  p.pu_x = jb.pu_x; p.pu_y = jb.pu_y; p.w = jb.w; p.h = jb.h;
+  p.pu_x = jb.pu_x; p.pu_y = jb.pu_y; p.w = jb.w; p.h = jb.h; p.dst_row_off = 0;
   if (r.not_valid) { p.mv_x = 0; p.mv_y = 0; p.use_gt = 0; for (int q = 0; q < 8; q++) p.gt[q] = 0; }
   else {
     p.mv_x = (r.mv_final[0] << 2) + (r.half_final[0] << 1) + r.qter_final[0];      // TEncSearch.cpp:4654-4656

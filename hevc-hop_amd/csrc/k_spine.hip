@@ -80,7 +80,7 @@ int hop_recon_stash(hop_ctx* c, int n, const int32_t* rect4, int restore) {
   if (n == 0) return HOP_OK;
   for (int i = 0; i < n; i++) {
     const int x = rect4[4 * i], y = rect4[4 * i + 1], s = rect4[4 * i + 2], slot = rect4[4 * i + 3];
-    if ((s != 8 && s != 16 && s != 32 && s != 64) || x < 0 || y < 0 || (x % s) || (y % s) || x + s > c->pic_w || y + s > c->pic_h || slot < 0 || slot >= STASH_SLOTS)
+    if ((s != 8 && s != 16 && s != 32 && s != 64) || x < 0 || y < 0 || (x % s) || ((y % c->pic_h) % s) || x + s > c->pic_w || y % c->pic_h + s > c->pic_h || y / c->pic_h > c->slots || slot < 0 || slot >= STASH_SLOTS)   // y may name a candidate slot's copy (hop_ctx_set_slots)
       return hop_set_err(c, HOP_ERR_ARG, "hop_recon_stash: block %d", i);
   }
   if (!c->stash) { HIPCHK(c, hipMalloc((void**)&c->stash, (size_t)STASH_SLOTS * STASH_SAMPLES * 2)); c->stash_slots = STASH_SLOTS; }
@@ -136,7 +136,7 @@ struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int
 
 class HipBackend : public BatchInner {
  public:
-  enum { MAXN = 512, MAXP = 16384 };   // candidates of one class / predictor jobs in one batch (one per CTU row in flight, all pictures together)
+  enum { MAXN = 2048, MAXP = 32768 };   // candidates of one class / predictor jobs in one batch (one per CTU row in flight, all pictures together)
   explicit HipBackend(hop_ctx* ctx) : c(ctx), arena(nullptr) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
@@ -176,11 +176,15 @@ class HipBackend : public BatchInner {
   // step k of every sequence in one predictor launch + one distortion launch; the steps in order; one synchronisation at the end
   void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {
     on_device();
-    Tick t(1);
     int total = 0, maxlen = 0; for (int s = 0; s < m; s++) { total += len[s]; if (len[s] > maxlen) maxlen = len[s]; }
     if (total == 0) return;
-    if (total > MAXP) throw Bail{ HOP_ERR_ARG };
-    if ((size_t)total * (sizeof(hop_pred_job) + sizeof(hop_dist_job)) + 512 > io_bytes) throw Bail{ HOP_ERR_ARG };
+    if (total > MAXP || (size_t)total * (sizeof(hop_pred_job) + sizeof(hop_dist_job)) + 512 > io_bytes) {   // larger batches in parts (whole sequences)
+      if (m == 1) throw Bail{ HOP_ERR_ARG };
+      int h = m / 2, at = 0; for (int s = 0; s < h; s++) at += len[s];
+      pred_cost_n(h, len, jobs, kinds, out); pred_cost_n(m - h, len + h, jobs + at, kinds + h, out + at);
+      return;
+    }
+    Tick t(1);
     hop_pred_job* pj = (hop_pred_job*)hin; hop_dist_job* dj = (hop_dist_job*)(hin + (((size_t)total * sizeof(hop_pred_job) + 255) & ~(size_t)255));   // pinned staging
     std::vector<int> src(total), first(maxlen + 1, 0);
     int at = 0;
@@ -189,7 +193,7 @@ class HipBackend : public BatchInner {
       for (int s = 0, base = 0; s < m; base += len[s], s++) {
         if (len[s] <= k) continue;
         const hop_pred_job& j = jobs[base + k];
-        pj[at] = j; dj[at].x = j.pu_x; dj[at].y = j.pu_y; dj[at].w = j.w; dj[at].h = j.h; dj[at].comp = 0; dj[at].kind = kinds[s]; src[at] = base + k; at++;
+        pj[at] = j; dj[at].x = j.pu_x; dj[at].y = j.pu_y + j.dst_row_off; dj[at].w = j.w; dj[at].h = j.h; dj[at].comp = 0; dj[at].kind = kinds[s]; src[at] = base + k; at++;
       }
     }
     first[maxlen] = at;
@@ -213,7 +217,7 @@ class HipBackend : public BatchInner {
 
   // n candidates of ONE class (CU size; with or without residual)
   void inter_n(int n, const InterEval* const* e, const Coder* const* in, EvalResult* const* out) {
-    if (n > MAXN) throw Bail{ HOP_ERR_ARG };
+    if (n > MAXN) { for (int o = 0; o < n; o += MAXN) inter_n(n - o < MAXN ? n - o : MAXN, e + o, in + o, out + o); return; }   // larger batches in parts
     on_device();
     Tick t(e[0]->skip_res ? 5 : 4);
     hipStream_t s = c->stream;
@@ -255,7 +259,7 @@ class HipBackend : public BatchInner {
     }
   }
   void intra_n(int n, const IntraEval* const* e, const Coder* const* in, EvalResult* const* out) {
-    if (n > MAXN) throw Bail{ HOP_ERR_ARG };
+    if (n > MAXN) { for (int o = 0; o < n; o += MAXN) intra_n(n - o < MAXN ? n - o : MAXN, e + o, in + o, out + o); return; }
     on_device();
     Tick t(6);
     hipStream_t s = c->stream;
@@ -321,6 +325,7 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   hopspine::EncConfig cfg;
   if (p->plain_intra) hopspine::default_plain_config(cfg, c->pic_w, pic_h, p->qp, c->bd_y); else hopspine::default_hop_config(cfg, c->pic_w, pic_h, p->qp, p->mi_size);
   cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
+  if (c->slots > 0 && !p->plain_intra) { cfg.spec_slots = c->slots; cfg.slot_pitch = c->pic_h; }   // hop_ctx_set_slots: the SS/GT candidates of a CU side by side
   if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;

@@ -34,7 +34,7 @@ class PuResult(ctypes.Structure):
 
 class PredJob(ctypes.Structure):
     _fields_ = [("pu_x", ctypes.c_int32), ("pu_y", ctypes.c_int32), ("w", ctypes.c_int32), ("h", ctypes.c_int32),
-                ("mv_x", ctypes.c_int32), ("mv_y", ctypes.c_int32), ("use_gt", ctypes.c_int32), ("gt", ctypes.c_int32 * 8)]
+                ("mv_x", ctypes.c_int32), ("mv_y", ctypes.c_int32), ("use_gt", ctypes.c_int32), ("gt", ctypes.c_int32 * 8), ("dst_row_off", ctypes.c_int32)]
 
 
 class DistJob(ctypes.Structure):
@@ -199,7 +199,7 @@ def load():
 class Context:
     """Thin RAII wrapper over hop_ctx_* for the tests and the bench."""
 
-    def __init__(self, pic_w, pic_h, bit_depth=8, device=0, lib=None, pictures=1):
+    def __init__(self, pic_w, pic_h, bit_depth=8, device=0, lib=None, pictures=1, slots=0):
         """pictures > 1: a stacked context (hop_ctx_set_stack) of that many independent pic_w x pic_h pictures; self.H is the height of the stack, self.sub_h / self.pitch
         the pictures' height and spacing, picture k at rows k * pitch."""
         self.L = lib or load()
@@ -215,6 +215,10 @@ class Context:
         if pictures > 1:
             self.L.hop_ctx_set_stack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
             self._chk(self.L.hop_ctx_set_stack(self.h, self.sub_h, self.pitch), "hop_ctx_set_stack")
+        self.slots = slots
+        if slots:                     # candidate slots (hop_ctx_set_slots): hop_encode_frame evaluates the SS/GT candidates of a CU side by side
+            self.L.hop_ctx_set_slots.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            self._chk(self.L.hop_ctx_set_slots(self.h, slots), "hop_ctx_set_slots")
 
     def stack(self, planes, chroma=False):
         """the pictures' planes (a list of arrays) laid out as the context's stack"""

@@ -156,6 +156,8 @@ class CtuWorker {
   void compress_ctu(int addr, const Coder& entry, Coder& exit);
  private:
   Encoder& E; const EncConfig& cfg; Backend* be; int lane_;
+  int slot_ = 0;                                                          // candidate slot this worker predicts and reconstructs in (0: the pictures themselves)
+  int row_off() const { return slot_ * cfg.slot_pitch; }
   CuData store_[4][2]; CuData* best_[4]; CuData* temp_[4];
   enum { CI_CURR = 0, CI_NEXT = 1, CI_TEMP = 2 };
   Coder sb_[4][3]; Coder goon_;
@@ -163,7 +165,7 @@ class CtuWorker {
 
   // data model
   void init_cu(CuData& c, int abs_idx, int depth, int x, int y);
-  void init_est(CuData& c) { for (int i = 0; i < c.num_part; i++) part_init(c.p[i], c.depth); c.cost = MAX_DOUBLE; c.bits = 0; c.dist = 0; }
+  void init_est(CuData& c) { for (int i = 0; i < c.num_part; i++) part_init(c.p[i], c.depth); c.cost = MAX_DOUBLE; c.bits = 0; c.dist = 0; c.slot = 0; }
   Part& pic_part(int px, int py) { return E.pic[(size_t)((py >> 6) * E.wctu_ + (px >> 6)) * 256 + zpix(px, py)]; }
   const Part* part_at(const CuData& c, int px, int py) {
     if (px >= c.x && px < c.x + c.size && py >= c.y && py < c.y + c.size) return &c.p[zpix(px, py) - c.abs_idx];
@@ -203,6 +205,11 @@ class CtuWorker {
   void check_merge_2Nx2N(int d, bool* early_skip);
   void check_inter(int d, int part_size, bool use_mrg);
   void check_intra(int d, int part_size);
+  struct SpecCand;
+  void spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot);
+  void spec_adopt(int d, SpecCand& sc);
+  void spec_inter_phase(int d, std::vector<SpecCand>& cands);
+  void check_merge_and_inter_spec(int d);
   bool pred_inter_search(CuData& c, int part_size, bool use_mrg);
   void fill_mvp_cand(const CuData& c, int pu, AmvpInfo& info);
   void merge_candidates(const CuData& c, int pu, MergeCands& mc);
@@ -223,7 +230,7 @@ class CtuWorker {
 void CtuWorker::init_cu(CuData& c, int abs_idx, int depth, int x, int y) {
   c.ctu_addr = ctu_addr_; c.ctu_x = ctu_x_; c.ctu_y = ctu_y_; c.abs_idx = abs_idx; c.depth = depth; c.x = x; c.y = y; c.size = CTU >> depth; c.num_part = 256 >> (2 * depth);
   for (int i = 0; i < c.num_part; i++) { part_init(c.p[i], depth); c.fbits[i] = 0; }
-  c.cost = MAX_DOUBLE; c.bits = 0; c.dist = 0;
+  c.cost = MAX_DOUBLE; c.bits = 0; c.dist = 0; c.slot = 0;
 }
 
 void CtuWorker::clip_mv(const CuData& c, int& h, int& v) const {          // TComDataCU::clipMv, TComDataCU.cpp:3492-3504 (the CU's position)
@@ -263,7 +270,7 @@ void CtuWorker::check_best_mode(int d, bool save_recon) {
   trace_candidate(*temp_[d]);
   if (temp_[d]->cost < best_[d]->cost) {
     std::swap(best_[d], temp_[d]);
-    if (save_recon) { tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y + cfg.y_origin, best_[d]->size); }
+    if (save_recon) { tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y + cfg.y_origin + best_[d]->slot * cfg.slot_pitch, best_[d]->size); }
     sb_[d][CI_NEXT] = sb_[d][CI_TEMP];
   }
 }
@@ -392,7 +399,7 @@ void CtuWorker::pu_pred_job(const CuData& c, int pu, hop_pred_job& j) {
   int ox, oy, w, h; pu_rect(c.p[0].part_size, c.size, pu, ox, oy, w, h);
   const Part& p = *part_at(c, c.x + ox, c.y + oy);
   memset(&j, 0, sizeof(j));
-  j.pu_x = c.x + ox; j.pu_y = c.y + oy + cfg.y_origin; j.w = w; j.h = h;
+  j.pu_x = c.x + ox; j.pu_y = c.y + oy + cfg.y_origin; j.dst_row_off = row_off(); j.w = w; j.h = h;
   int mh = p.mv[0], mvv = p.mv[1]; clip_mv(c, mh, mvv);
   j.mv_x = mh; j.mv_y = mvv; j.use_gt = (!p.merge_flag && p.gt_flag) ? 1 : 0;
   for (int k = 0; k < 8; k++) j.gt[k] = p.gt[k];
@@ -432,7 +439,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
         for (int i = 0; i < info.n; i++) {
           if (!valid_pattern(px, py, w, h, info.cand[i][0], info.cand[i][1])) continue;
           hop_pred_job& j = tj[nt]; memset(&j, 0, sizeof(j));
-          j.pu_x = px; j.pu_y = py + cfg.y_origin; j.w = w; j.h = h;
+          j.pu_x = px; j.pu_y = py + cfg.y_origin; j.dst_row_off = row_off(); j.w = w; j.h = h;
           int mh = info.cand[i][0], mvv = info.cand[i][1]; clip_mv(c, mh, mvv);
           j.mv_x = mh; j.mv_y = mvv; j.use_gt = 0;
           ti[nt++] = i;
@@ -516,7 +523,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
           int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(c, mh, mvv);
           if (mc.f[k].ref == 0 && !valid_pattern(px, py, w, h, mh, mvv)) continue;
           hop_pred_job& j = mj[nm]; memset(&j, 0, sizeof(j));
-          j.pu_x = px; j.pu_y = py + cfg.y_origin; j.w = w; j.h = h; j.mv_x = mh; j.mv_y = mvv;
+          j.pu_x = px; j.pu_y = py + cfg.y_origin; j.dst_row_off = row_off(); j.w = w; j.h = h; j.mv_x = mh; j.mv_y = mvv;
           j.use_gt = (!base.merge_flag && base.gt_flag) ? 1 : 0; for (int q = 0; q < 8; q++) j.gt[q] = base.gt[q];
           mi[nm++] = k;
         }
@@ -550,9 +557,9 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
 }
 
 // ---- candidate evaluation through the backend ----
-static void fill_rqt_job(const EncConfig& cfg, const CuData& c, bool intra, int part_size, hop_rqt_job& j) {
+static void fill_rqt_job(const EncConfig& cfg, const CuData& c, bool intra, int part_size, hop_rqt_job& j, int row_off = 0) {
   memset(&j, 0, sizeof(j));
-  j.x = c.x; j.y = c.y + cfg.y_origin; j.log2_cu = 6 - c.depth;
+  j.x = c.x; j.y = c.y + cfg.y_origin + row_off; j.log2_cu = 6 - c.depth;
   for (int k = 0; k < 3; k++) { j.qp_scaled[k] = cfg.qp_scaled[k]; j.lambda_rdoq[k] = cfg.lambda_rdoq[k]; }
   j.ctx_index = 0; j.sign_hide = cfg.sign_hide; j.use_ts = cfg.use_ts; j.log2_max_tu = cfg.log2_max_tu;
   // TComDataCU::getQuadtreeTULog2MinSizeInCU (TComDataCU.cpp:1860-1886)
@@ -569,7 +576,8 @@ void CtuWorker::eval_inter(int d, bool skip_res) {
   CuData& c = *temp_[d];
   InterEval e; memset(&e, 0, sizeof(e));
   const int ps = c.p[0].part_size;
-  fill_rqt_job(cfg, c, false, ps, e.job);
+  fill_rqt_job(cfg, c, false, ps, e.job, row_off());
+  c.slot = slot_;
   e.skip_res = skip_res ? 1 : 0;
   hop_cu_syntax& y = e.syn;
   y.part_size = ps; y.n_pu = num_pus(ps); y.skip_flag = c.p[0].skip;
@@ -716,6 +724,112 @@ void CtuWorker::check_intra(int d, int ps) {                               // TE
   check_best_mode(d, true);
 }
 
+// ---- SS/GT candidates of one CU side by side (cfg.spec_slots > 0) ----
+// Every candidate of xCompressCU starts from the same coder state (CI_CURR_BEST of the depth) and from a freshly initialised temporary CU, and reads nothing another
+// candidate of the same CU has written except through the prediction / reconstruction pictures: with a copy of those per candidate (a slot) the candidates are independent
+// evaluations.  Which of them the reference would test, and in which order their results meet xCheckBestMode, is decided afterwards exactly as in the serial path; a
+// candidate the reference would have skipped was evaluated for nothing and is dropped.  Each candidate runs as a worker of its own through Backend::fork_join.
+struct CtuWorker::SpecCand {
+  int merge_k, nores;                // merge candidate k (>= 0) with / without residual, or
+  int ps; bool use_mrg;              // an SS/GT search of this partition size
+  bool ok;                           // false: predInterSearch found no valid candidate (the reference does not rate the mode then)
+  MvField mf; uint8_t mdir;
+  CuData cu; Coder after, goon;
+};
+
+void CtuWorker::spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot) {
+  CtuWorker* w = new CtuWorker(E, lane_, be);
+  w->ctu_addr_ = ctu_addr_; w->ctu_x_ = ctu_x_; w->ctu_y_ = ctu_y_; w->slot_ = slot; w->tag_seq_ = tag_seq_;
+  w->sb_[d][CI_CURR] = sb_[d][CI_CURR]; w->goon_ = goon_;
+  CuData* c = w->temp_[d];
+  *c = tmpl;
+  try {
+    if (sc.merge_k >= 0) {                                                // one pass of the loop of xCheckRDCostMerge2Nx2N
+      for (int i = 0; i < c->num_part; i++) {
+        Part& p = c->p[i];
+        p.pred_mode = MODE_INTER; p.part_size = SIZE_2Nx2N; p.merge_flag = 1; p.merge_idx = (uint8_t)sc.merge_k; p.inter_dir = sc.mdir;
+        p.mv[0] = sc.mf.mv[0]; p.mv[1] = sc.mf.mv[1]; p.ref_idx = sc.mf.ref;
+      }
+      w->tag_cand(sc.nores * 5 + sc.merge_k);
+      w->motion_comp_pu(*c, 0);
+      w->tag_step(60);
+      w->eval_inter(d, sc.nores != 0);
+      const int root = (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1);
+      for (int i = 0; i < c->num_part; i++) c->p[i].skip = root == 0;
+      sc.ok = true;
+    } else {                                                              // xCheckRDCostInter up to the comparison
+      for (int i = 0; i < c->num_part; i++) { c->p[i].depth = (uint8_t)d; c->p[i].skip = 0; c->p[i].part_size = (uint8_t)sc.ps; c->p[i].pred_mode = MODE_INTER; }
+      w->tag_cand(10 + sc.ps);
+      sc.ok = w->pred_inter_search(*c, sc.ps, sc.use_mrg);
+      if (sc.ok) { w->tag_step(60); w->eval_inter(d, false); }
+    }
+  } catch (...) { delete w; throw; }
+  sc.cu = *c; sc.after = w->sb_[d][CI_TEMP]; sc.goon = w->goon_;
+  delete w;
+}
+
+// the candidate's result as the serial path would have left it in the temporary CU, then xCheckBestMode
+void CtuWorker::spec_adopt(int d, SpecCand& sc) {
+  *temp_[d] = sc.cu; sb_[d][CI_TEMP] = sc.after; goon_ = sc.goon;
+  check_best_mode(d, true);
+}
+
+void CtuWorker::spec_inter_phase(int d, std::vector<SpecCand>& cands) {
+  const CuData tmpl = *temp_[d];                                          // after init_est
+  const int n = (int)cands.size();
+  if (n > cfg.spec_slots) throw 1;
+  be->fork_join(n, [&](int i) { spec_run(d, cands[i], tmpl, i + 1); });
+}
+
+// xCheckRDCostMerge2Nx2N, then xCheckRDCostInter for 2Nx2N, Nx2N and 2NxN (the order of xCompressCU without early skip detection and CBF fast mode)
+void CtuWorker::check_merge_and_inter_spec(int d) {
+  CuData* c = temp_[d];
+  for (int i = 0; i < c->num_part; i++) c->p[i].part_size = SIZE_2Nx2N;
+  MergeCands mc; merge_candidates(*c, 0, mc);
+  init_est(*temp_[d]);
+  bool valid[5] = { false, false, false, false, false };
+  std::vector<SpecCand> cands; cands.reserve(13);
+  int idx[5][2];
+  for (int k = 0; k < mc.n; k++) {
+    valid[k] = true;
+    if (mc.f[k].ref == 0) { int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(*c, mh, mvv); valid[k] = valid_pattern(c->x, c->y, c->size, c->size, mh, mvv); }
+    if (!valid[k]) continue;
+    for (int nores = 0; nores < 2; nores++) {
+      SpecCand sc; sc.merge_k = k; sc.nores = nores; sc.ps = SIZE_2Nx2N; sc.use_mrg = false; sc.ok = false; sc.mf = mc.f[k]; sc.mdir = mc.dir[k];
+      idx[k][nores] = (int)cands.size(); cands.push_back(sc);
+    }
+  }
+  int first_inter = (int)cands.size();
+  static const int inter_ps[3] = { SIZE_2Nx2N, SIZE_Nx2N, SIZE_2NxN };
+  for (int q = 0; q < 3; q++) { SpecCand sc; sc.merge_k = -1; sc.nores = 0; sc.ps = inter_ps[q]; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
+  spec_inter_phase(d, cands);
+  // ---- the decisions, in the serial order ----
+  int buf[5] = { 0, 0, 0, 0, 0 };
+  bool best_is_skip = false;
+  for (int nores = 0; nores < 2; nores++) {
+    for (int k = 0; k < mc.n; k++) {
+      if (nores == 1 && buf[k] == 1) continue;
+      if (best_is_skip && nores == 0) continue;
+      if (!valid[k]) { init_est(*temp_[d]); continue; }
+      SpecCand& sc = cands[idx[k][nores]];
+      const int root = (sc.cu.p[0].cbf[0] & 1) | (sc.cu.p[0].cbf[1] & 1) | (sc.cu.p[0].cbf[2] & 1);
+      if (nores == 0 && root == 0) buf[k] = 1;
+      spec_adopt(d, sc);
+      init_est(*temp_[d]);
+      if (cfg.fdm && !best_is_skip) {
+        const Part& b = best_[d]->p[0];
+        best_is_skip = ((b.cbf[0] & 1) | (b.cbf[1] & 1) | (b.cbf[2] & 1)) == 0;
+      }
+    }
+  }
+  init_est(*temp_[d]);
+  for (int q = 0; q < 3; q++) {
+    SpecCand& sc = cands[first_inter + q];
+    if (sc.ok) spec_adopt(d, sc);
+    init_est(*temp_[d]);
+  }
+}
+
 // TEncCu::xCompressCU (:371-892)
 void CtuWorker::compress_cu(int d, int parent_ps) {
   const int x = best_[d]->x, y = best_[d]->y, size = best_[d]->size;
@@ -725,9 +839,12 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   const int node_abs = best_[d]->abs_idx;
   tag_enter(d, node_abs);
   auto root_cbf = [](const CuData* c) { return (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1); };
+  // SS/GT candidates side by side: the configurations without early skip detection / CBF fast mode (the shipped ones), whose candidate list does not depend on results
+  const bool spec = cfg.spec_slots >= 13 && not_i && !cfg.esd && !cfg.cfm && !(size != 8 && d == 3);
   if (inside) {
     init_est(*temp_[d]);
-    if (not_i) {
+    if (spec) { check_merge_and_inter_spec(d); }
+    else if (not_i) {
       if (cfg.esd) { check_inter(d, SIZE_2Nx2N, false); init_est(*temp_[d]); }
       check_merge_2Nx2N(d, &early_skip); init_est(*temp_[d]);
       if (!cfg.esd) {
@@ -738,6 +855,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
     if (!early_skip) {
       init_est(*temp_[d]);
       if (not_i) {
+        if (!spec) {
         if (size != 8 && d == 3 && do_not_block_pu) { check_inter(d, SIZE_NxN, false); init_est(*temp_[d]); }
         if (do_not_block_pu) {
           check_inter(d, SIZE_Nx2N, false); init_est(*temp_[d]);
@@ -746,6 +864,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
         if (do_not_block_pu) {
           check_inter(d, SIZE_2NxN, false); init_est(*temp_[d]);
           if (cfg.cfm && best_[d]->p[0].part_size == SIZE_2NxN) do_not_block_pu = root_cbf(best_[d]) != 0;
+        }
         }
         if (cfg.amp && d < 3) {                                            // getAMPAcc(depth)
           // deriveTestModeAMP (:292-356)
@@ -761,8 +880,10 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
           }
           if (b.part_size == SIZE_2Nx2N && !b.skip) { mhor = true; mver = true; }
           if (size == 64) { hor = false; ver = false; }
+          std::vector<SpecCand> amps;                                        // spec: the AMP shapes the derivation asks for, side by side
           auto amp = [&](int ps, bool mrg, bool cfm_check) {
             if (!do_not_block_pu) return;
+            if (spec) { SpecCand sc; sc.merge_k = -1; sc.nores = 0; sc.ps = ps; sc.use_mrg = mrg; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; amps.push_back(sc); return; }
             check_inter(d, ps, mrg); init_est(*temp_[d]);
             if (cfm_check && cfg.cfm && best_[d]->p[0].part_size == ps) do_not_block_pu = root_cbf(best_[d]) != 0;
           };
@@ -770,6 +891,10 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
           else if (mhor) { amp(SIZE_2NxnU, true, true); amp(SIZE_2NxnD, true, true); }
           if (ver) { amp(SIZE_nLx2N, false, true); amp(SIZE_nRx2N, false, false); }
           else if (mver) { amp(SIZE_nLx2N, true, true); amp(SIZE_nRx2N, true, false); }
+          if (spec && !amps.empty()) {
+            spec_inter_phase(d, amps);
+            for (size_t q = 0; q < amps.size(); q++) { if (amps[q].ok) spec_adopt(d, amps[q]); init_est(*temp_[d]); }
+          }
         }
       }
       const Part& b = best_[d]->p[0];
@@ -1040,14 +1165,38 @@ class Rendezvous : public Backend {
 // sleep and wake-up per row thread -- with hundreds of rows in flight (several pictures side by side) those wake-ups were the largest single cost of the host side.
 class FiberPool : public Backend {
  public:
-  struct Fiber { ucontext_t ctx; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool; };
+  struct Fiber { ucontext_t ctx; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool;
+                 Fiber* parent; int live_children; bool wait_children; uint64_t tag; };   // parent: a child of fork_join (recycled when done)
   FiberPool(BatchInner* inner, int n_workers) : rounds(0), requests(0), steps_complete(-1), inner_(inner), T_(n_workers), failed_(false), finished_(false), arrived_(0), gen_(0), left_(0), idle_rounds_(0) {
-    memset(tag_of_, 0, sizeof(tag_of_)); sched_.resize(T_); mine_.resize(T_); local_.resize(T_);
+    sched_.resize(T_); mine_.resize(T_); local_.resize(T_); free_.resize(T_); kids_.resize(T_);
   }
-  ~FiberPool() { for (Fiber* f : all_) { free(f->stack); delete f; } }
+  ~FiberPool() { for (Fiber* f : all_) { free(f->stack); delete f; } for (auto& v : kids_) for (Fiber* f : v) { free(f->stack); delete f; } }
   void add(std::function<void()> body) {
     Fiber* f = new Fiber(); f->stack = (char*)malloc(STACK); f->body = body; f->done = false; f->req = NULL; f->wait_step = -1; f->worker = (int)(all_.size() % T_); f->pool = this;
+    f->parent = NULL; f->live_children = 0; f->wait_children = false; f->tag = 0;
     all_.push_back(f); mine_[f->worker].push_back(f); left_++;
+  }
+  // fn(0) ... fn(n - 1) as fibers of their own on the caller's worker; the caller goes on when all have ended
+  void fork_join(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (failed_) throw 1;
+    Fiber* me = current();
+    const int w = me->worker;
+    me->live_children = n;
+    for (int i = 0; i < n; i++) {
+      Fiber* f;
+      if (!free_[w].empty()) { f = free_[w].back(); free_[w].pop_back(); }
+      else { f = new Fiber(); f->stack = (char*)malloc(STACK); kids_[w].push_back(f); }
+      f->body = [&fn, i]() { fn(i); };
+      f->done = false; f->req = NULL; f->wait_step = -1; f->worker = w; f->pool = this; f->parent = me; f->live_children = 0; f->wait_children = false; f->tag = me->tag;
+      getcontext(&f->ctx);
+      f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = STACK; f->ctx.uc_link = &sched_[w];
+      makecontext(&f->ctx, (void (*)())tramp, 2, (unsigned)((uintptr_t)f & 0xFFFFFFFFu), (unsigned)((uintptr_t)f >> 32));
+      mine_[w].push_back(f);
+    }
+    me->wait_children = true;
+    swapcontext(&me->ctx, &sched_[w]);
+    if (failed_) throw 1;
   }
   void run() {                                                          // all fibers to completion
     std::vector<std::thread> th;
@@ -1056,7 +1205,7 @@ class FiberPool : public Backend {
   }
   bool failed() const { return failed_; }
   // ---- called from inside fibers ----
-  void set_tag(int lane, uint64_t tag) { tag_of_[lane % SPINE_LANES] = tag; }
+  void set_tag(int, uint64_t tag) { current()->tag = tag; }            // the tag belongs to the fiber (children of fork_join carry their own)
   void begin_frame() {}
   void me_search(int lane, int n, const hop_pu_job* j, hop_pu_result* r) { Req q = { RQ_ME, lane, n, j, NULL, r, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
@@ -1075,6 +1224,7 @@ class FiberPool : public Backend {
     if (failed_) throw 1;
   }
   uint64_t rounds, requests;
+  int tag_shift = 0;
   std::atomic<int> steps_complete;
   std::mutex steps_m;                                                   // guards the callers' step counters
  private:
@@ -1083,13 +1233,14 @@ class FiberPool : public Backend {
   static void tramp(unsigned lo, unsigned hi) {
     Fiber* f = (Fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
     try { f->body(); } catch (...) { f->pool->failed_ = true; }
-    f->done = true; f->pool->left_--;
+    f->done = true;
+    if (f->parent) f->parent->live_children--; else f->pool->left_--;
     // returning ends the context: uc_link takes the worker's scheduler up where it left off
   }
   void submit(Req& q) {
     if (failed_) throw 1;
     Fiber* f = current();
-    q.tag = tag_of_[q.lane % SPINE_LANES];
+    q.tag = f->tag;
     local_[f->worker].push_back(&q);
     f->req = &q;
     swapcontext(&f->ctx, &sched_[f->worker]);
@@ -1102,14 +1253,21 @@ class FiberPool : public Backend {
       makecontext(&f->ctx, (void (*)())tramp, 2, (unsigned)((uintptr_t)f & 0xFFFFFFFFu), (unsigned)((uintptr_t)f >> 32));
     }
     for (;;) {
-      bool ran = false;
-      for (Fiber* f : mine_[w]) {
-        if (f->done) continue;
+      bool ran = false, ended = false;
+      for (size_t i = 0; i < mine_[w].size(); i++) {                     // (fork_join appends to the list while this loop runs)
+        Fiber* f = mine_[w][i];
+        if (f->done) { ended |= f->parent != NULL; continue; }
         if (f->req) { if (!f->req->done && !failed_) continue; f->req = NULL; }
         else if (f->wait_step >= 0) { if (steps_complete.load() < f->wait_step && !failed_) continue; f->wait_step = -1; }
+        else if (f->wait_children) { if (f->live_children > 0) continue; f->wait_children = false; }
         current() = f;
         swapcontext(&sched_[w], &f->ctx);                               // until it submits, waits or ends
         ran = true;
+      }
+      if (ended) {                                                      // children that have ended: out of the list, their stacks free for the next fork
+        size_t k = 0;
+        for (size_t i = 0; i < mine_[w].size(); i++) { Fiber* f = mine_[w][i]; if (f->done && f->parent) free_[w].push_back(f); else mine_[w][k++] = f; }
+        mine_[w].resize(k);
       }
       if (ran) continue;                                                // what ran may have released others of this worker
       if (!barrier(w)) break;
@@ -1130,9 +1288,11 @@ class FiberPool : public Backend {
     return !finished_;
   }
   void serve() {
-    uint64_t tmin = ~0ull; for (Req* r : pending_) if (r->tag < tmin) tmin = r->tag;
+    // the requests with the smallest tag; with candidates side by side (tag_shift = 20) the tag is cut down to the quadtree node: the candidates of a node are at
+    // different steps of their chains at any moment, and all of them are served -- one launch chain per kind and class present
+    uint64_t tmin = ~0ull; for (Req* r : pending_) if ((r->tag >> tag_shift) < tmin) tmin = r->tag >> tag_shift;
     std::vector<Req*> v, rest;
-    for (Req* r : pending_) (r->tag == tmin ? v : rest).push_back(r);
+    for (Req* r : pending_) ((r->tag >> tag_shift) == tmin ? v : rest).push_back(r);
     pending_.swap(rest);
     rounds++; requests += v.size();
     try {
@@ -1153,7 +1313,7 @@ class FiberPool : public Backend {
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
   std::vector<ucontext_t> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
   std::mutex bm_; std::condition_variable bcv_; int arrived_; uint64_t gen_; std::atomic<int> left_; int idle_rounds_;
-  uint64_t tag_of_[SPINE_LANES];
+  std::vector<std::vector<Fiber*> > free_, kids_;
 };
 }  // namespace
 
@@ -1183,6 +1343,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     if (const char* e = getenv("HOP_SPINE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) T = v; }
     if (T > rows * n_pic) T = rows * n_pic;
     FiberPool pool(inner, T);
+    if (E0.cfg_.spec_slots > 0) pool.tag_shift = 20;
     const int n_steps = cols + lag * (rows - 1);
     std::vector<int> in_step(n_steps, 0), fin_step(n_steps, 0);
     for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) in_step[c + lag * r] += n_pic;

@@ -5,6 +5,7 @@
 // instantiate the same spine over the CPU restatement (oracle/spine_backend_cpu.cpp) to pin it against the reference encoder.
 #pragma once
 #include <stdint.h>
+#include <functional>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@ struct EncConfig {
   int amp, fen, hadme, fdm, esd, cfm, ecu;
   int log2_max_tu, log2_min_tu, tu_max_depth_inter, tu_max_depth_intra;
   int sign_hide, use_ts, ts_fast, strong_intra;
+  int spec_slots, slot_pitch;      // > 0: the SS/GT candidates of a CU are evaluated side by side, candidate k in copy k of the prediction / reconstruction pictures (rows k * slot_pitch, hop_ctx_set_slots)
   int y_origin;                    // added to the y coordinate of every request: the picture's first row in a stacked context (hop_ctx_set_stack), else 0
   int wpp;                         // 0: contexts run on from CTU to CTU in raster order (shipped configurations); 1: WaveFrontSynchro rows
   // derived by finish_config()
@@ -39,7 +41,7 @@ void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size)
 void default_plain_config(EncConfig& c, int pic_w, int pic_h, int qp, int bit_depth);   // cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg: I slice, no SS / GT
 void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
 
-enum { SPINE_LANES = 512 };       // CTU rows in flight at once (all pictures together); a lane owns 16 stash slots
+enum { SPINE_LANES = 2048 };       // CTU rows in flight at once (all pictures together); a lane owns 16 stash slots
 typedef hop_cu_part Part;          // one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
 
 struct CuData {                    // TComDataCU as the RD search uses it (one CU of the quadtree, or the whole CTU)
@@ -47,6 +49,7 @@ struct CuData {                    // TComDataCU as the RD search uses it (one C
   Part p[256];
   uint64_t fbits[256];             // at a coded CU's first partition: the fractional bits of its syntax (what the final pass of the CTU adds to the coder's fraction)
   double cost; uint32_t bits, dist;
+  int slot;                        // the candidate slot its reconstruction lies in
 };
 
 // ---- candidate evaluation requests (the boundary between the spine and the kernels) ----
@@ -81,7 +84,7 @@ class Backend {
   virtual void pred_cost(int lane, int n, const hop_pred_job* jobs, int kind, uint32_t* out) {
     for (int i = 0; i < n; i++) {
       pred_inter(lane, 1, jobs + i);
-      hop_dist_job d; d.x = jobs[i].pu_x; d.y = jobs[i].pu_y; d.w = jobs[i].w; d.h = jobs[i].h; d.comp = 0; d.kind = kind;
+      hop_dist_job d; d.x = jobs[i].pu_x; d.y = jobs[i].pu_y + jobs[i].dst_row_off; d.w = jobs[i].w; d.h = jobs[i].h; d.comp = 0; d.kind = kind;
       distortion(lane, 1, &d, out + i);
     }
   }
@@ -92,6 +95,9 @@ class Backend {
   virtual void recon_save(int lane, int slot, int x, int y, int size) = 0;
   virtual void recon_restore(int lane, int slot, int x, int y, int size) = 0;
   virtual void commit(int lane, int x, int y, int size) = 0;                             // reconstruction picture -> SS reference (xCopyYuv2SSRef)
+  // fn(0) ... fn(n - 1), each issuing requests of its own: a backend that batches runs them side by side (their requests then meet in the batches), the others one
+  // after the other -- the answers, and so the results, are the same
+  virtual void fork_join(int n, const std::function<void(int)>& fn) { for (int i = 0; i < n; i++) fn(i); }
 };
 
 // The n-forms a backend may offer so that requests of several CTUs in flight are served by one launch chain.  The defaults loop over the single forms.

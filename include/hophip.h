@@ -83,6 +83,7 @@ typedef struct {
   int32_t mv_x, mv_y;      /* quarter-pel */
   int32_t use_gt;
   int32_t gt[8];
+  int32_t dst_row_off;     /* the prediction is written dst_row_off luma rows below the PU (candidate slots, hop_ctx_set_slots: k * picture height); 0: at the PU */
 } hop_pred_job;
 
 /* distortion kinds for hop_distortion (TLibCommon/TComRdCost.cpp) */
@@ -107,6 +108,12 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out);
 const char* hop_last_error(const hop_ctx* ctx);     /* ctx may be NULL: error of the failed create */
 int hop_sync(hop_ctx* ctx);
 void* hop_stream(hop_ctx* ctx);                     /* hipStream_t the *_device calls are ordered on */
+
+/* Candidate slots (no counterpart in the reference, whose candidates run one after the other through m_ppcPredYuvTemp / m_ppcRecoYuvTemp): the original, prediction and
+ * reconstruction pictures exist slots + 1 times, copy k at rows k * pic_h.  A request whose y is y + k * pic_h works on copy k, so candidates of one CU evaluated side by
+ * side do not overwrite each other; the searches and the predictor read the one SS reference at the true position (hop_pred_job.dst_row_off names the copy the
+ * prediction goes to).  Call before hop_upload_orig; hop_encode_frame then evaluates the SS/GT candidates of a CU side by side.  0 <= slots <= 64. */
+int hop_ctx_set_slots(hop_ctx* ctx, int slots);
 
 /* The transform-unit leaf step (hop_tu_rd and everything built on it) has two forms with identical results: a pipeline of 13 kernels that lays the serial stages out one
  * lane per TU (batches of thousands of TUs) and one kernel with a workgroup per TU (the launch-bound batches of the RD search).  Batches of up to max_tus TUs take the

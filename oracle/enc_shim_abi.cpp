@@ -124,7 +124,7 @@ Void TComPrediction::xPredInterLumaBlk(TComDataCU* cu, TComPicYuv* refPic, UInt 
   const UInt z = cu->getZorderIdxInCU() + partAddr;
   j.pu_x = cu->getPic()->getCU(cu->getAddr())->getCUPelX() + g_auiRasterToPelX[g_auiZscanToRaster[z]];
   j.pu_y = cu->getPic()->getCU(cu->getAddr())->getCUPelY() + g_auiRasterToPelY[g_auiZscanToRaster[z]];
-  j.w = width; j.h = height; j.mv_x = mv->getHor(); j.mv_y = mv->getVer(); j.use_gt = bUseGT ? 1 : 0;
+  j.w = width; j.h = height; j.mv_x = mv->getHor(); j.mv_y = mv->getVer(); j.use_gt = bUseGT ? 1 : 0; j.dst_row_off = 0;
   const TComMv* g[4] = { mGT0, mGT1, mGT2, mGT3 };
   for (int k = 0; k < 4; k++) { j.gt[2 * k] = g[k]->getHor(); j.gt[2 * k + 1] = g[k]->getVer(); }
   std::vector<int16_t> y((size_t)width * height);

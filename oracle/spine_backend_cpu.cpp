@@ -20,11 +20,12 @@ struct Plane { int w, h, stride, margin; std::vector<int16_t> buf; int16_t* p00;
 
 class CpuBackend : public BatchInner {
  public:
-  CpuBackend(int W, int H, int bd, const int16_t* y, const int16_t* cb, const int16_t* cr) : W(W), H(H), bd(bd) {
+  // slots: the original, prediction and reconstruction pictures exist slots + 1 times, copy k at rows k * H (what hop_ctx_set_slots makes of a context)
+  CpuBackend(int W, int H, int bd, const int16_t* y, const int16_t* cb, const int16_t* cr, int slots = 0) : W(W), H(H), bd(bd) {
     for (int c = 0; c < 3; c++) {
       const int w = c ? W / 2 : W, h = c ? H / 2 : H;
-      org[c].assign((size_t)w * h, 0); pred[c].assign((size_t)w * h, 0); rec[c].assign((size_t)w * h, 0);
-      memcpy(&org[c][0], c == 0 ? y : c == 1 ? cb : cr, (size_t)w * h * 2);
+      org[c].assign((size_t)w * h * (slots + 1), 0); pred[c].assign((size_t)w * h * (slots + 1), 0); rec[c].assign((size_t)w * h * (slots + 1), 0);
+      for (int k = 0; k <= slots; k++) memcpy(&org[c][(size_t)k * w * h], c == 0 ? y : c == 1 ? cb : cr, (size_t)w * h * 2);
       const int m = c ? 40 : 80, G = 64;                                   // the reference's margins + guard rows (see tests/hoputil.py:Planes)
       ss[c].w = w; ss[c].h = h; ss[c].margin = m; ss[c].stride = w + 2 * m;
       ss[c].buf.assign((size_t)ss[c].stride * (h + 2 * m + 2 * G), -1);
@@ -62,10 +63,11 @@ class CpuBackend : public BatchInner {
       std::vector<int16_t> py((size_t)j.w * j.h), pb((size_t)j.w * j.h / 4), pr((size_t)j.w * j.h / 4);
       int gt[8]; for (int k = 0; k < 8; k++) gt[k] = j.gt[k];
       hop_o_pred_inter(ss[0].p00, ss[0].stride, ss[1].p00, ss[2].p00, ss[1].stride, j.pu_x, j.pu_y, j.w, j.h, j.mv_x, j.mv_y, j.use_gt, gt, bd, bd, &py[0], &pb[0], &pr[0]);
-      for (int r = 0; r < j.h; r++) memcpy(&pred[0][(size_t)(j.pu_y + r) * W + j.pu_x], &py[(size_t)r * j.w], j.w * 2);
+      const int dy = j.pu_y + j.dst_row_off;                                // the candidate slot's copy
+      for (int r = 0; r < j.h; r++) memcpy(&pred[0][(size_t)(dy + r) * W + j.pu_x], &py[(size_t)r * j.w], j.w * 2);
       for (int r = 0; r < j.h / 2; r++) {
-        memcpy(&pred[1][(size_t)(j.pu_y / 2 + r) * (W / 2) + j.pu_x / 2], &pb[(size_t)r * (j.w / 2)], j.w);
-        memcpy(&pred[2][(size_t)(j.pu_y / 2 + r) * (W / 2) + j.pu_x / 2], &pr[(size_t)r * (j.w / 2)], j.w);
+        memcpy(&pred[1][(size_t)(dy / 2 + r) * (W / 2) + j.pu_x / 2], &pb[(size_t)r * (j.w / 2)], j.w);
+        memcpy(&pred[2][(size_t)(dy / 2 + r) * (W / 2) + j.pu_x / 2], &pr[(size_t)r * (j.w / 2)], j.w);
       }
     }
   }
@@ -203,6 +205,9 @@ class CpuBackend : public BatchInner {
 
 }  // namespace
 
+// HOP_SPEC_SLOTS=<n> (tests): the SS/GT candidates of a CU side by side in n candidate slots (EncConfig::spec_slots), as hop_ctx_set_slots + hop_encode_frame do on the device
+static int spec_slots_env() { const char* e = getenv("HOP_SPEC_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }
+
 extern "C" {
 
 // One frame through the spine on the CPU restatement.  y / cb / cr: the original (pitch w, w/2).  Outputs (any may be NULL): ctu_cost / ctu_bits / ctu_dist per CTU,
@@ -213,7 +218,8 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
 long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
                           double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, void* entry) {
   EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size);
-  CpuBackend be(w, h, 8, y, cb, cr);
+  const int slots = spec_slots_env(); cfg.spec_slots = slots; cfg.slot_pitch = h;
+  CpuBackend be(w, h, 8, y, cb, cr, slots);
   Encoder enc(cfg, &be);
   if (trace_path && *trace_path) enc.trace = fopen(trace_path, "w");
   enc.encode_frame(first_ctus);
@@ -224,9 +230,9 @@ long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, con
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
   if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
   if (entry) memcpy(entry, &enc.ctu_entry[0], n * sizeof(Coder));
-  if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
-  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
-  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], (size_t)w * h * 2);
+  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], (size_t)(w / 2) * (h / 2) * 2);
+  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], (size_t)(w / 2) * (h / 2) * 2);
   return (long)enc.n_candidates;
 }
 // the same with WaveFrontSynchro semantics (one substream per CTU row): lag 0 = the CTUs in raster order on one thread, lag > 0 = the rows as a wavefront of threads whose
@@ -234,7 +240,8 @@ long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, con
 long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
                               double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, double* rounds_requests) {
   EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1;
-  CpuBackend be(w, h, 8, y, cb, cr);
+  const int slots = spec_slots_env(); cfg.spec_slots = slots; cfg.slot_pitch = h;
+  CpuBackend be(w, h, 8, y, cb, cr, slots);
   LogBackend* lg = getenv("HOP_SPINE_LOG") ? new LogBackend(&be, getenv("HOP_SPINE_LOG")) : NULL;
   BatchInner* use = lg ? (BatchInner*)lg : (BatchInner*)&be;
   Encoder enc(cfg, use);
@@ -246,9 +253,9 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
   if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
-  if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
-  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
-  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], (size_t)w * h * 2);
+  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], (size_t)(w / 2) * (h / 2) * 2);
+  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], (size_t)(w / 2) * (h / 2) * 2);
   if (rounds_requests) { rounds_requests[0] = (double)enc.batch_rounds; rounds_requests[1] = (double)enc.batch_requests; }
   return (long)enc.n_candidates;
 }
@@ -309,9 +316,9 @@ long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
   if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
-  if (rec_y) memcpy(rec_y, &be.rec[0][0], be.rec[0].size() * 2);
-  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], be.rec[1].size() * 2);
-  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], be.rec[2].size() * 2);
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], (size_t)w * h * 2);
+  if (rec_cb) memcpy(rec_cb, &be.rec[1][0], (size_t)(w / 2) * (h / 2) * 2);
+  if (rec_cr) memcpy(rec_cr, &be.rec[2][0], (size_t)(w / 2) * (h / 2) * 2);
   return (long)enc.n_candidates;
 }
 int hop_spine_sizeof_part(void) { return (int)sizeof(Part); }

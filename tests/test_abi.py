@@ -100,7 +100,7 @@ def test_reference_binding_marshals_every_field():
     assert len(recs[1]) == 1 and np.frombuffer(recs[1][0], "<i4").tolist() == [W, H, 8, 8, 0]          # hop_ctx_create once, with the picture's geometry
     assert len(recs[2]) == 1 and np.frombuffer(recs[2][0], "<i4")[2] == int(Y[0, 0])                     # hop_upload_orig once per picture, pointing at the original
     jobs = np.frombuffer(b"".join(recs[4]), hophip.PU_JOB_DTYPE)
-    preds = np.frombuffer(b"".join(recs[5]), np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"), ("use_gt", "<i4"), ("gt", "<i4", 8)]))
+    preds = np.frombuffer(b"".join(recs[5]), np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"), ("use_gt", "<i4"), ("gt", "<i4", 8), ("dst_row_off", "<i4")]))
     rects = np.frombuffer(b"".join(recs[3]), "<i4").reshape(-1, 4)
     assert len(jobs) > 300 and len(rects) >= 4
     poison = np.uint32(0xA5A5A5A5).astype(np.uint32)

@@ -21,12 +21,16 @@ def _hp():
     return m
 
 
+SLOTS = [0, 16]         # 16: candidate slots (hop_ctx_set_slots) -- the SS/GT candidates of a CU are evaluated side by side; the results must not change
+
+
+@pytest.mark.parametrize("slots", SLOTS)
 @pytest.mark.parametrize("W,H,seed,sharp", FRAMES)
-def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp):
+def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp, slots):
     hp = _hp()
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
     Y, Cb, Cr = frame(W, H, seed, sharp)
-    ctx = hp.Context(W, H)
+    ctx = hp.Context(W, H, slots=slots)
     ctx.upload_orig(Y, Cb, Cr)
     with tempfile.TemporaryDirectory() as td:
         tp = os.path.join(td, "t.txt")
@@ -43,13 +47,14 @@ def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp):
     ctx.close()
 
 
+@pytest.mark.parametrize("slots", SLOTS)
 @pytest.mark.parametrize("W,H,seed,lag", FRAMES_WPP)
-def test_encode_frame_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed, lag):
+def test_encode_frame_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed, lag, slots):
     """wpp without / with the wavefront of rows (their candidate evaluations batched into common launches) against the reference run with one substream per CTU row"""
     hp = _hp()
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
     Y, Cb, Cr = frame(W, H, seed, False)
-    ctx = hp.Context(W, H)
+    ctx = hp.Context(W, H, slots=slots)
     ctx.upload_orig(Y, Cb, Cr)
     with tempfile.TemporaryDirectory() as td:
         tp = os.path.join(td, "t.txt")
@@ -83,14 +88,15 @@ def test_encode_frame_plain_intra_configurations(bd, qp):
     ctx.close()
 
 
-def test_stacked_pictures_are_coded_as_pictures_of_their_own():
+@pytest.mark.parametrize("slots", SLOTS)
+def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
     """three independent pictures in one stacked context (hop_ctx_set_stack), coded side by side by one hop_encode_frame: picture 0 against the reference's golden run,
     the others against contexts of their own; reconstruction and SS reference (with the margins each picture extends at ITS edges) included"""
     hp = _hp()
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
     W, H, lag = 192, 128, 5
     pics = [frame(W, H, 7, False), frame(W, H, 8, False), frame(W, H, 11, False)]
-    ctx = hp.Context(W, H, pictures=3)
+    ctx = hp.Context(W, H, pictures=3, slots=slots)
     ctx.upload_orig(ctx.stack([p[0] for p in pics]), ctx.stack([p[1] for p in pics], True), ctx.stack([p[2] for p in pics], True))
     n = 6
     with tempfile.TemporaryDirectory() as td:

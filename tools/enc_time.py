@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
-"""tools/enc_time.py W H [lag [streams [pictures]]] -- time hop_encode_frame on a synthetic lenslet (pitch 15, seed 2 like bench.py): raster order, or the wavefront with batching."""
+"""tools/enc_time.py W H [lag [streams [pictures [slots]]]] -- time hop_encode_frame on a synthetic lenslet (pitch 15, seed 2 like bench.py): raster order, or the wavefront with batching."""
 import importlib.util, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from hoputil import lenslet
 spec = importlib.util.spec_from_file_location("hophip", os.path.join(ROOT, "hevc-hop_amd", "hophip.py")); hp = importlib.util.module_from_spec(spec); spec.loader.exec_module(hp)
-W, H = int(sys.argv[1]), int(sys.argv[2]); lag = int(sys.argv[3]) if len(sys.argv) > 3 else 0; streams = int(sys.argv[4]) if len(sys.argv) > 4 else 0; P = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+W, H = int(sys.argv[1]), int(sys.argv[2]); lag = int(sys.argv[3]) if len(sys.argv) > 3 else 0; streams = int(sys.argv[4]) if len(sys.argv) > 4 else 0; P = int(sys.argv[5]) if len(sys.argv) > 5 else 1; S = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 if P > 1:                                                    # a stack of P pictures: bands of one tall lenslet frame
     Yf, Cbf, Crf = lenslet(W, H * P, 15, 2)
-    ctx = hp.Context(W, H, pictures=P)
+    ctx = hp.Context(W, H, pictures=P, slots=S)
     ctx.upload_orig(ctx.stack([Yf[k * H:(k + 1) * H] for k in range(P)]), ctx.stack([Cbf[k * H // 2:(k + 1) * H // 2] for k in range(P)], True), ctx.stack([Crf[k * H // 2:(k + 1) * H // 2] for k in range(P)], True))
 else:
     Y, Cb, Cr = lenslet(W, H, 15, 2)
-    ctx = hp.Context(W, H); ctx.upload_orig(Y, Cb, Cr)
+    ctx = hp.Context(W, H, slots=S); ctx.upload_orig(Y, Cb, Cr)
 t0 = time.time()
 cost, bits, dist, parts, nc = ctx.encode_frame(32, 15, 0, None, wpp=1 if lag else 0, wavefront_lag=lag, streams=streams)
 dt = time.time() - t0
 n = len(cost)
-print(json.dumps({"W": W, "H": H, "lag": lag, "streams": streams, "pictures": P, "ctus": n, "s": dt, "ctu_per_s": n / dt, "candidates": nc, "cost_sum": float(cost.sum()), "stats": ctx.encode_stats()}))
+print(json.dumps({"W": W, "H": H, "lag": lag, "streams": streams, "pictures": P, "slots": S, "ctus": n, "s": dt, "ctu_per_s": n / dt, "candidates": nc, "cost_sum": float(cost.sum()), "stats": ctx.encode_stats()}))

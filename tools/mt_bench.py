@@ -21,7 +21,7 @@ L.hop_distortion_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void
 L.hop_distortion.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 K = int(os.environ.get("MT_ITERS", "2000"))
 def worker(i, view, variant, out):
-    pj = np.zeros(1, np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"), ("use_gt", "<i4"), ("gt", "<i4", 8)]))
+    pj = np.zeros(1, np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"), ("use_gt", "<i4"), ("gt", "<i4", 8), ("dst_row_off", "<i4")]))
     pj["pu_x"], pj["pu_y"], pj["w"], pj["h"], pj["mv_x"], pj["mv_y"] = 256 + 64 * i, 256, 32, 32, -60, -4
     dj = np.array([(256 + 64 * i, 256, 32, 32, 0, 2)], np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("comp", "<i4"), ("kind", "<i4")]))
     d_pj = torch.from_numpy(pj.view(np.uint8)).cuda(); d_dj = torch.from_numpy(dj.view(np.uint8)).cuda(); d_out = torch.zeros(4, dtype=torch.int32, device="cuda")

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <chrono>
 #include <mutex>
+#include <functional>
 #include <string>
 #include <vector>
 #include "hop_dev.h"
@@ -49,6 +50,19 @@ __global__ __launch_bounds__(256) void k_recon_put(const hop_rqt_job* __restrict
   const int16_t* src = comp == 0 ? reco_y + (size_t)i * S * S : reco_c + (size_t)i * (S * S / 2) + (comp == 2 ? s * s : 0);
   int16_t* pic = comp == 0 ? ry : comp == 1 ? rcb : rcr;
   for (int k = threadIdx.x; k < s * s; k += blockDim.x) { const int r = k / s, c = k - r * s; pic[(size_t)(y + r) * pitch + x + c] = src[k]; }
+}
+
+// grid (n, 3): CU i lies in a candidate slot (its y names copy k = y / pic_h of the pictures, hop_ctx_set_slots): the row above it and the column to its left -- what
+// intra prediction inside the CU can read from outside it, 2 * size + 1 / 2 * size samples -- from the reconstruction picture into that copy
+__global__ __launch_bounds__(128) void k_slot_prepare(const hop_rqt_job* __restrict__ jobs, int16_t* __restrict__ ry, int16_t* __restrict__ rcb, int16_t* __restrict__ rcr, int pic_w, int pic_h) {
+  const int i = blockIdx.x, comp = blockIdx.y, sh = comp ? 1 : 0;
+  const int slot = jobs[i].y / pic_h;
+  if (slot == 0) return;
+  const int w = pic_w >> sh, h = pic_h >> sh, n = (1 << jobs[i].log2_cu) >> sh, px = jobs[i].x >> sh, py = (jobs[i].y % pic_h) >> sh;
+  int16_t* pic = comp == 0 ? ry : comp == 1 ? rcb : rcr;
+  int16_t* cpy = pic + (size_t)slot * h * w;
+  if (py > 0) for (int k = threadIdx.x; k <= 2 * n; k += blockDim.x) { const int xx = px - 1 + k; if (xx >= 0 && xx < w) cpy[(size_t)(py - 1) * w + xx] = pic[(size_t)(py - 1) * w + xx]; }
+  if (px > 0) for (int k = threadIdx.x; k < 2 * n; k += blockDim.x) { const int yy = py + k; if (yy < h) cpy[(size_t)yy * w + px - 1] = pic[(size_t)yy * w + px - 1]; }
 }
 
 static int spine_stage(hop_ctx* c, size_t bytes, void** out) {      // a small staging area of its own (the host-array entries keep theirs)
@@ -137,7 +151,7 @@ struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int
 class HipBackend : public BatchInner {
  public:
   enum { MAXN = 2048, MAXP = 32768 };   // candidates of one class / predictor jobs in one batch (one per CTU row in flight, all pictures together)
-  explicit HipBackend(hop_ctx* ctx) : c(ctx), arena(nullptr) {
+  explicit HipBackend(hop_ctx* ctx, bool sub = false) : c(ctx), arena(nullptr), is_sub_(sub), rr_(0) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     o_jobs = take(MAXN * sizeof(hop_rqt_job)); o_syn = take(MAXN * sizeof(hop_cu_syntax)); o_isyn = take(MAXN * sizeof(hop_intra_cu_syntax)); o_isyn_out = take(MAXN * sizeof(hop_intra_cu_syntax));
@@ -159,7 +173,26 @@ class HipBackend : public BatchInner {
       arena = nullptr; hop_set_err(c, HOP_ERR_DEVICE, "spine arena allocation failed");
     }
   }
-  ~HipBackend() { if (arena) (void)hipFree(arena); if (hin) (void)hipHostFree(hin); if (hout) (void)hipHostFree(hout); }
+  ~HipBackend() {
+    for (auto b : subs_) delete b;
+    for (auto v : views_) hop_ctx_destroy(v);
+    if (arena) (void)hipFree(arena); if (hin) (void)hipHostFree(hin); if (hout) (void)hipHostFree(hout);
+  }
+  // k further streams (views of the context, each with a backend of its own): the candidate evaluations of one round -- SS/GT candidates with and without residual,
+  // intra 2Nx2N, intra NxN: chains that touch different candidate slots -- are issued one per stream and collected in end_round()
+  bool add_streams(int k) {
+    for (int i = 0; i < k; i++) {
+      hop_ctx* v = nullptr;
+      if (hop_ctx_create_view(c, &v) != HOP_OK) return false;
+      HipBackend* b = new HipBackend(v, true);
+      if (!b->ok()) { delete b; hop_ctx_destroy(v); return false; }
+      views_.push_back(v); subs_.push_back(b);
+    }
+    return true;
+  }
+  void end_round() {
+    for (auto b : subs_) if (b->collect_) { std::function<void()> f; f.swap(b->collect_); f(); if (b->c->err[0] && !c->err[0]) strncpy(c->err, b->c->err, sizeof(c->err) - 1); }
+  }
   bool ok() const { return arena != nullptr; }
 
   void on_device() { if (hipSetDevice(c->device) != hipSuccess) { hop_set_err(c, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", c->device); throw Bail{ HOP_ERR_DEVICE }; } }   // batches are served by whichever worker thread arrives last: the current device is per-thread state
@@ -218,6 +251,7 @@ class HipBackend : public BatchInner {
   // n candidates of ONE class (CU size; with or without residual)
   void inter_n(int n, const InterEval* const* e, const Coder* const* in, EvalResult* const* out) {
     if (n > MAXN) { for (int o = 0; o < n; o += MAXN) inter_n(n - o < MAXN ? n - o : MAXN, e + o, in + o, out + o); return; }   // larger batches in parts
+    if (!subs_.empty()) { HipBackend* b = subs_[rr_++ % subs_.size()]; if (b->collect_) { std::function<void()> f; f.swap(b->collect_); f(); } b->inter_n(n, e, in, out); return; }
     on_device();
     Tick t(e[0]->skip_res ? 5 : 4);
     hipStream_t s = c->stream;
@@ -247,19 +281,24 @@ class HipBackend : public BatchInner {
       BK(hop_inter_cu_device_classes(c, 1, &k, d_cx, d_cu));
     }
     BH(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, s));
-    BH(hipStreamSynchronize(s));
-    const hop_cu_final* fin = (const hop_cu_final*)(hout + r_fin); const uint32_t* bits = (const uint32_t*)(hout + r_bits); const uint32_t* skipped = (const uint32_t*)(hout + r_skipped);
-    const hop_cabac_ctx* cx = (const hop_cabac_ctx*)(hout + r_cx); const hop_cabac_cu_ctx* cu = (const hop_cabac_cu_ctx*)(hout + r_cu); const hop_rqt_result* res = (const hop_rqt_result*)(hout + r_res);
-    for (int i = 0; i < n; i++) {
-      EvalResult& r = *out[i];
-      r.bits = bits[i]; r.dist = fin[i].dist[0] + fin[i].dist[1] + fin[i].dist[2]; r.cost = 0; r.skipped = skip ? 1 : (int)skipped[i]; r.root_cbf = (int)fin[i].root_cbf;
-      if (skip) { memset(r.tr_idx, 0, sizeof(r.tr_idx)); memset(r.cbf, 0, sizeof(r.cbf)); memset(r.tskip, 0, sizeof(r.tskip)); }
-      else { memcpy(r.tr_idx, res[i].tr_idx, 256); memcpy(r.cbf, res[i].cbf, 768); memcpy(r.tskip, res[i].tskip, 768); }
-      r.after = *in[i]; r.after.r = cx[i]; r.after.c = cu[i];
-    }
+    std::vector<const Coder*> inv(in, in + n); std::vector<EvalResult*> outv(out, out + n);
+    auto collect = [this, s, n, skip, r_fin, r_bits, r_skipped, r_cx, r_cu, r_res, inv, outv]() {
+      BH(hipStreamSynchronize(s));
+      const hop_cu_final* fin = (const hop_cu_final*)(hout + r_fin); const uint32_t* bits = (const uint32_t*)(hout + r_bits); const uint32_t* skipped = (const uint32_t*)(hout + r_skipped);
+      const hop_cabac_ctx* cx = (const hop_cabac_ctx*)(hout + r_cx); const hop_cabac_cu_ctx* cu = (const hop_cabac_cu_ctx*)(hout + r_cu); const hop_rqt_result* res = (const hop_rqt_result*)(hout + r_res);
+      for (int i = 0; i < n; i++) {
+        EvalResult& r = *outv[i];
+        r.bits = bits[i]; r.dist = fin[i].dist[0] + fin[i].dist[1] + fin[i].dist[2]; r.cost = 0; r.skipped = skip ? 1 : (int)skipped[i]; r.root_cbf = (int)fin[i].root_cbf;
+        if (skip) { memset(r.tr_idx, 0, sizeof(r.tr_idx)); memset(r.cbf, 0, sizeof(r.cbf)); memset(r.tskip, 0, sizeof(r.tskip)); }
+        else { memcpy(r.tr_idx, res[i].tr_idx, 256); memcpy(r.cbf, res[i].cbf, 768); memcpy(r.tskip, res[i].tskip, 768); }
+        r.after = *inv[i]; r.after.r = cx[i]; r.after.c = cu[i];
+      }
+    };
+    if (is_sub_) collect_ = collect; else collect();                      // a sub-backend's batch is collected in the owner's end_round()
   }
   void intra_n(int n, const IntraEval* const* e, const Coder* const* in, EvalResult* const* out) {
     if (n > MAXN) { for (int o = 0; o < n; o += MAXN) intra_n(n - o < MAXN ? n - o : MAXN, e + o, in + o, out + o); return; }
+    if (!subs_.empty()) { HipBackend* b = subs_[rr_++ % subs_.size()]; if (b->collect_) { std::function<void()> f; f.swap(b->collect_); f(); } b->intra_n(n, e, in, out); return; }
     on_device();
     Tick t(6);
     hipStream_t s = c->stream;
@@ -282,24 +321,33 @@ class HipBackend : public BatchInner {
     k.d_cresults = (hop_intra_chroma_result*)(dout + r_cres); k.d_coef = (int32_t*)(arena + o_coef); k.d_reco_y = (int16_t*)(arena + o_reco_y); k.d_reco_c = (int16_t*)(arena + o_reco_c);
     k.d_syntax_out = (hop_intra_cu_syntax*)(arena + o_isyn_out); k.d_dist = (uint32_t*)(dout + r_dist); k.d_bits = (uint32_t*)(dout + r_bits); k.d_cost = (double*)(arena + o_cost);
     k.d_ctx_out = (hop_cabac_ctx*)(dout + r_cx); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(dout + r_cu);
+    if (c->slots > 0) {                                                   // candidates in slots: their neighbouring row and column first
+      hipLaunchKernelGGL(k_slot_prepare, dim3(n, 3), dim3(128), 0, s, k.d_jobs, c->rec[0], c->rec[1], c->rec[2], c->pic_w, c->pic_h);
+      BH(hipGetLastError());
+    }
     BK(hop_intra_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(din + i_cx), (const hop_cabac_cu_ctx*)(din + i_cu)));
     BK(hop_recon_put_device(c, n, k.d_jobs, k.d_reco_y, k.d_reco_c));
     BH(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, s));
-    BH(hipStreamSynchronize(s));
-    const hop_rqt_result* res = (const hop_rqt_result*)(hout + r_res); const hop_intra_search_result* sres = (const hop_intra_search_result*)(hout + r_sres);
-    const hop_intra_chroma_result* cres = (const hop_intra_chroma_result*)(hout + r_cres); const uint32_t* bits = (const uint32_t*)(hout + r_bits); const uint32_t* dist = (const uint32_t*)(hout + r_dist);
-    const hop_cabac_ctx* cx = (const hop_cabac_ctx*)(hout + r_cx); const hop_cabac_cu_ctx* cu = (const hop_cabac_cu_ctx*)(hout + r_cu);
-    for (int i = 0; i < n; i++) {
-      EvalResult& r = *out[i];
-      r.bits = bits[i]; r.dist = dist[i]; r.cost = 0; r.skipped = 0; r.root_cbf = 1;
-      memcpy(r.tr_idx, res[i].tr_idx, 256); memcpy(r.cbf, res[i].cbf, 768); memcpy(r.tskip, res[i].tskip, 768);
-      for (int p = 0; p < 4; p++) r.luma_dir[p] = sres[i].best_dir[p];
-      r.chroma_dir = cres[i].best_mode;
-      r.after = *in[i]; r.after.r = cx[i]; r.after.c = cu[i];
-    }
+    std::vector<const Coder*> inv(in, in + n); std::vector<EvalResult*> outv(out, out + n);
+    auto collect = [this, s, n, r_res, r_sres, r_cres, r_bits, r_dist, r_cx, r_cu, inv, outv]() {
+      BH(hipStreamSynchronize(s));
+      const hop_rqt_result* res = (const hop_rqt_result*)(hout + r_res); const hop_intra_search_result* sres = (const hop_intra_search_result*)(hout + r_sres);
+      const hop_intra_chroma_result* cres = (const hop_intra_chroma_result*)(hout + r_cres); const uint32_t* bits = (const uint32_t*)(hout + r_bits); const uint32_t* dist = (const uint32_t*)(hout + r_dist);
+      const hop_cabac_ctx* cx = (const hop_cabac_ctx*)(hout + r_cx); const hop_cabac_cu_ctx* cu = (const hop_cabac_cu_ctx*)(hout + r_cu);
+      for (int i = 0; i < n; i++) {
+        EvalResult& r = *outv[i];
+        r.bits = bits[i]; r.dist = dist[i]; r.cost = 0; r.skipped = 0; r.root_cbf = 1;
+        memcpy(r.tr_idx, res[i].tr_idx, 256); memcpy(r.cbf, res[i].cbf, 768); memcpy(r.tskip, res[i].tskip, 768);
+        for (int p = 0; p < 4; p++) r.luma_dir[p] = sres[i].best_dir[p];
+        r.chroma_dir = cres[i].best_mode;
+        r.after = *inv[i]; r.after.r = cx[i]; r.after.c = cu[i];
+      }
+    };
+    if (is_sub_) collect_ = collect; else collect();
   }
  private:
   hop_ctx* c; char* arena; size_t bytes; char* hin; char* hout; size_t io_bytes, o_in, o_out;
+  bool is_sub_; int rr_; std::vector<hop_ctx*> views_; std::vector<HipBackend*> subs_; std::function<void()> collect_;   // collect_: the second half of a batch issued on this (sub) backend
   size_t o_jobs, o_syn, o_isyn, o_isyn_out, o_opts, o_sjobs, o_sres, o_res, o_cres, o_coef, o_reco_y, o_reco_c, o_ctx_in, o_cu_in, o_ctx_after, o_ctx_out, o_cu_out, o_fin, o_bits, o_skipped,
          o_cost, o_dist, o_pjobs, o_djobs, o_pout;
 };
@@ -329,6 +377,10 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
+  if (c->slots > 0 && p->wavefront_lag > 0 && !p->plain_intra) {         // candidates side by side: their evaluation chains of one round on streams of their own
+    int k = 4; if (const char* e = getenv("HOP_SPINE_STREAMS")) k = atoi(e);
+    if (k > 1 && !be.add_streams(k > 8 ? 8 : k)) return hop_set_err(c, HOP_ERR_DEVICE, "hop_encode_frame: could not create the evaluation streams");
+  }
   // streams > 1: one view of the context (own stream, own work areas) per CTU row in flight; their launch chains overlap on the device
   std::vector<hop_ctx*> views; std::vector<HipBackend*> vbe; std::vector<Backend*> lanes;
   if (p->wavefront_lag > 0 && p->streams > 1 && n_pic == 1) {

@@ -161,6 +161,7 @@ class CtuWorker {
   CuData store_[4][2]; CuData* best_[4]; CuData* temp_[4];
   enum { CI_CURR = 0, CI_NEXT = 1, CI_TEMP = 2 };
   Coder sb_[4][3]; Coder goon_;
+  struct SpecCand; std::vector<SpecCand> spec_intra_[4];                   // candidate slots: the intra candidates of the node, evaluated with the first batch
   int ctu_addr_, ctu_x_, ctu_y_;
 
   // data model
@@ -205,7 +206,7 @@ class CtuWorker {
   void check_merge_2Nx2N(int d, bool* early_skip);
   void check_inter(int d, int part_size, bool use_mrg);
   void check_intra(int d, int part_size);
-  struct SpecCand;
+  void eval_intra(int d, int part_size);
   void spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot);
   void spec_adopt(int d, SpecCand& sc);
   void spec_inter_phase(int d, std::vector<SpecCand>& cands);
@@ -659,7 +660,7 @@ void CtuWorker::check_merge_2Nx2N(int d, bool* early_skip) {               // TE
 
 void CtuWorker::fill_intra_eval(const CuData& c, int ps, IntraEval& e) {
   memset(&e, 0, sizeof(e));
-  fill_rqt_job(cfg, c, true, ps, e.job);
+  fill_rqt_job(cfg, c, true, ps, e.job, row_off());                      // (in a candidate slot the backend first copies the CU's neighbouring row and column there)
   e.part_nxn = ps == SIZE_NxN ? 1 : 0;
   hop_intra_cu_syntax& y = e.syn;
   y.part_nxn = e.part_nxn; y.skip_flag = 0; y.is_min_cu = c.depth == 3;
@@ -704,6 +705,10 @@ void CtuWorker::fill_intra_eval(const CuData& c, int ps, IntraEval& e) {
 }
 
 void CtuWorker::check_intra(int d, int ps) {                               // TEncCu::xCheckRDCostIntra (:1455-1507)
+  eval_intra(d, ps);
+  check_best_mode(d, true);
+}
+void CtuWorker::eval_intra(int d, int ps) {                                // ... up to the comparison
   CuData& c = *temp_[d];
   for (int i = 0; i < c.num_part; i++) { c.p[i].skip = 0; c.p[i].part_size = (uint8_t)ps; c.p[i].pred_mode = MODE_INTRA; }
   tag_cand(ps == SIZE_2Nx2N ? 20 : 21);
@@ -721,7 +726,7 @@ void CtuWorker::check_intra(int d, int ps) {                               // TE
   r.after.split[0] = in.split[0]; r.after.split[1] = in.split[1]; r.after.split[2] = in.split[2];
   goon_ = r.after; sb_[d][CI_TEMP] = r.after;
   c.fbits[0] = ((uint64_t)r.bits << 15) + coder_frac(r.after) - coder_frac(in);
-  check_best_mode(d, true);
+  c.slot = slot_;
 }
 
 // ---- SS/GT candidates of one CU side by side (cfg.spec_slots > 0) ----
@@ -731,7 +736,8 @@ void CtuWorker::check_intra(int d, int ps) {                               // TE
 // candidate the reference would have skipped was evaluated for nothing and is dropped.  Each candidate runs as a worker of its own through Backend::fork_join.
 struct CtuWorker::SpecCand {
   int merge_k, nores;                // merge candidate k (>= 0) with / without residual, or
-  int ps; bool use_mrg;              // an SS/GT search of this partition size
+  int ps; bool use_mrg;              // an SS/GT search of this partition size, or
+  int intra_ps;                      // (>= 0) the intra candidate of this partition size
   bool ok;                           // false: predInterSearch found no valid candidate (the reference does not rate the mode then)
   MvField mf; uint8_t mdir;
   CuData cu; Coder after, goon;
@@ -744,7 +750,10 @@ void CtuWorker::spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot) {
   CuData* c = w->temp_[d];
   *c = tmpl;
   try {
-    if (sc.merge_k >= 0) {                                                // one pass of the loop of xCheckRDCostMerge2Nx2N
+    if (sc.intra_ps >= 0) {                                               // xCheckRDCostIntra up to the comparison
+      w->eval_intra(d, sc.intra_ps);
+      sc.ok = true;
+    } else if (sc.merge_k >= 0) {                                         // one pass of the loop of xCheckRDCostMerge2Nx2N
       for (int i = 0; i < c->num_part; i++) {
         Part& p = c->p[i];
         p.pred_mode = MODE_INTER; p.part_size = SIZE_2Nx2N; p.merge_flag = 1; p.merge_idx = (uint8_t)sc.merge_k; p.inter_dir = sc.mdir;
@@ -776,9 +785,14 @@ void CtuWorker::spec_adopt(int d, SpecCand& sc) {
 
 void CtuWorker::spec_inter_phase(int d, std::vector<SpecCand>& cands) {
   const CuData tmpl = *temp_[d];                                          // after init_est
+  // slots: 1, 2, ... for the SS/GT candidates; the two highest for the intra candidates, whose reconstructions wait there until the decisions reach them (the AMP
+  // candidates in between reuse the low slots)
   const int n = (int)cands.size();
-  if (n > cfg.spec_slots) throw 1;
-  be->fork_join(n, [&](int i) { spec_run(d, cands[i], tmpl, i + 1); });
+  int n_inter = 0; for (int i = 0; i < n; i++) n_inter += cands[i].intra_ps < 0;
+  if (n_inter > cfg.spec_slots - 2) throw 1;
+  std::vector<int> slot(n);
+  for (int i = 0, k = 0; i < n; i++) slot[i] = cands[i].intra_ps < 0 ? ++k : (cands[i].intra_ps == SIZE_2Nx2N ? cfg.spec_slots - 1 : cfg.spec_slots);
+  be->fork_join(n, [&](int i) { spec_run(d, cands[i], tmpl, slot[i]); });
 }
 
 // xCheckRDCostMerge2Nx2N, then xCheckRDCostInter for 2Nx2N, Nx2N and 2NxN (the order of xCompressCU without early skip detection and CBF fast mode)
@@ -795,14 +809,19 @@ void CtuWorker::check_merge_and_inter_spec(int d) {
     if (mc.f[k].ref == 0) { int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(*c, mh, mvv); valid[k] = valid_pattern(c->x, c->y, c->size, c->size, mh, mvv); }
     if (!valid[k]) continue;
     for (int nores = 0; nores < 2; nores++) {
-      SpecCand sc; sc.merge_k = k; sc.nores = nores; sc.ps = SIZE_2Nx2N; sc.use_mrg = false; sc.ok = false; sc.mf = mc.f[k]; sc.mdir = mc.dir[k];
+      SpecCand sc; sc.intra_ps = -1; sc.merge_k = k; sc.nores = nores; sc.ps = SIZE_2Nx2N; sc.use_mrg = false; sc.ok = false; sc.mf = mc.f[k]; sc.mdir = mc.dir[k];
       idx[k][nores] = (int)cands.size(); cands.push_back(sc);
     }
   }
   int first_inter = (int)cands.size();
   static const int inter_ps[3] = { SIZE_2Nx2N, SIZE_Nx2N, SIZE_2NxN };
-  for (int q = 0; q < 3; q++) { SpecCand sc; sc.merge_k = -1; sc.nores = 0; sc.ps = inter_ps[q]; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
+  for (int q = 0; q < 3; q++) { SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = inter_ps[q]; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
+  // the intra candidates join the same batch: in an ISS slice xCompressCU always tests them, after every SS/GT candidate (their results wait in spec_intra_)
+  const int first_intra = (int)cands.size();
+  const int n_intra = (d == 3 && c->size > (1 << cfg.log2_min_tu)) ? 2 : 1;
+  for (int q = 0; q < n_intra; q++) { SpecCand sc; sc.intra_ps = q ? SIZE_NxN : SIZE_2Nx2N; sc.merge_k = -1; sc.nores = 0; sc.ps = 0; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
   spec_inter_phase(d, cands);
+  spec_intra_[d].assign(cands.begin() + first_intra, cands.end());
   // ---- the decisions, in the serial order ----
   int buf[5] = { 0, 0, 0, 0, 0 };
   bool best_is_skip = false;
@@ -840,7 +859,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   tag_enter(d, node_abs);
   auto root_cbf = [](const CuData* c) { return (c->p[0].cbf[0] & 1) | (c->p[0].cbf[1] & 1) | (c->p[0].cbf[2] & 1); };
   // SS/GT candidates side by side: the configurations without early skip detection / CBF fast mode (the shipped ones), whose candidate list does not depend on results
-  const bool spec = cfg.spec_slots >= 13 && not_i && !cfg.esd && !cfg.cfm && !(size != 8 && d == 3);
+  const bool spec = cfg.spec_slots >= 15 && cfg.slice_type == 3 && not_i && !cfg.esd && !cfg.cfm && !(size != 8 && d == 3);
   if (inside) {
     init_est(*temp_[d]);
     if (spec) { check_merge_and_inter_spec(d); }
@@ -883,7 +902,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
           std::vector<SpecCand> amps;                                        // spec: the AMP shapes the derivation asks for, side by side
           auto amp = [&](int ps, bool mrg, bool cfm_check) {
             if (!do_not_block_pu) return;
-            if (spec) { SpecCand sc; sc.merge_k = -1; sc.nores = 0; sc.ps = ps; sc.use_mrg = mrg; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; amps.push_back(sc); return; }
+            if (spec) { SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = ps; sc.use_mrg = mrg; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; amps.push_back(sc); return; }
             check_inter(d, ps, mrg); init_est(*temp_[d]);
             if (cfm_check && cfg.cfm && best_[d]->p[0].part_size == ps) do_not_block_pu = root_cbf(best_[d]) != 0;
           };
@@ -898,7 +917,10 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
         }
       }
       const Part& b = best_[d]->p[0];
-      if (!not_i || b.cbf[0] != 0 || b.cbf[1] != 0 || b.cbf[2] != 0 || cfg.slice_type == 3 || b.part_size == SIZE_NONE) {
+      if (spec) {                                                          // (slice_type 3: always tested)
+        for (size_t q = 0; q < spec_intra_[d].size(); q++) { spec_adopt(d, spec_intra_[d][q]); init_est(*temp_[d]); }
+        spec_intra_[d].clear();
+      } else if (!not_i || b.cbf[0] != 0 || b.cbf[1] != 0 || b.cbf[2] != 0 || cfg.slice_type == 3 || b.part_size == SIZE_NONE) {
         check_intra(d, SIZE_2Nx2N); init_est(*temp_[d]);
         if (d == 3 && size > (1 << cfg.log2_min_tu)) { check_intra(d, SIZE_NxN); init_est(*temp_[d]); }
       }
@@ -1293,6 +1315,12 @@ class FiberPool : public Backend {
     uint64_t tmin = ~0ull; for (Req* r : pending_) if ((r->tag >> tag_shift) < tmin) tmin = r->tag >> tag_shift;
     std::vector<Req*> v, rest;
     for (Req* r : pending_) ((r->tag >> tag_shift) == tmin ? v : rest).push_back(r);
+    if (tag_shift) {
+      // candidates side by side: their searches and predictions (short chains) first, the candidate evaluations (long chains) once nothing else of the node is
+      // waiting -- then the evaluations of all candidates of the node, of every CTU in flight, are ONE chain per class instead of one per candidate
+      bool light = false; for (Req* r : v) light |= (r->kind != RQ_INTER && r->kind != RQ_INTRA);
+      if (light) { std::vector<Req*> keep; for (Req* r : v) (r->kind != RQ_INTER && r->kind != RQ_INTRA ? keep : rest).push_back(r); v.swap(keep); }
+    }
     pending_.swap(rest);
     rounds++; requests += v.size();
     try {
@@ -1307,6 +1335,7 @@ class FiberPool : public Backend {
         }
         run_group(inner_, g);
       }
+      inner_->end_round();
       for (size_t i = 0; i < v.size(); i++) v[i]->done = true;
     } catch (...) { failed_ = true; }
   }

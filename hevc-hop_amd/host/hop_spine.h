@@ -109,6 +109,8 @@ class BatchInner : public Backend {
     for (int i = 0; i < n; i++) { const int32_t* r = rect4 + 4 * i; if (restore) recon_restore(r[3] >> 4, r[3] & 15, r[0], r[1], r[2]); else recon_save(r[3] >> 4, r[3] & 15, r[0], r[1], r[2]); }
   }
   virtual void commit_n(int n, const int32_t* rect4) { for (int i = 0; i < n; i++) commit(0, rect4[4 * i], rect4[4 * i + 1], rect4[4 * i + 2]); }
+  // the groups of one round have all been handed over: a backend that issues them on separate streams waits for them here and fills in the answers
+  virtual void end_round() {}
   // m sequences of pred_cost requests (different CTUs, so their rectangles are disjoint): step k of all sequences may run together, the steps in order.
   // jobs / kinds / out: concatenated sequence after sequence, len[s] jobs each
   virtual void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {

@@ -154,6 +154,15 @@ class CpuBackend : public BatchInner {
   void intra_cu(int, const IntraEval& e, const Coder& in, EvalResult& out) {
     hop_o_rqt_cfg cfg; cfg_of(e.job, bd, cfg);
     const int cu = 1 << cfg.log2_cu, x = e.job.x, y = e.job.y, parts = (cu / 4) * (cu / 4), half = cu / 2;
+    if (y >= H) {                                                          // a candidate slot: the row above the CU and the column to its left from the picture into the copy
+      const int slot = y / H;
+      for (int c = 0; c < 3; c++) {
+        const int s = c ? 1 : 0, w = W >> s, h = H >> s, n = cu >> s, px = x >> s, py = (y % H) >> s;
+        int16_t* pic = &rec[c][0]; int16_t* cpy = pic + (size_t)slot * h * w;
+        if (py > 0) for (int k = 0; k <= 2 * n; k++) { const int xx = px - 1 + k; if (xx >= 0 && xx < w) cpy[(size_t)(py - 1) * w + xx] = pic[(size_t)(py - 1) * w + xx]; }
+        if (px > 0) for (int k = 0; k < 2 * n; k++) { const int yy = py + k; if (yy < h) cpy[(size_t)yy * w + px - 1] = pic[(size_t)yy * w + px - 1]; }
+      }
+    }
     hop_o_intra_syntax syn; memset(&syn, 0, sizeof(syn));
     syn.part_nxn = e.syn.part_nxn; syn.skip_flag = e.syn.skip_flag; syn.skip_ctx = e.syn.skip_ctx; syn.is_min_cu = e.syn.is_min_cu;
     std::vector<uint8_t> avail((size_t)341 * HOP_O_AVAIL_PITCH, 0);

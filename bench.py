@@ -524,8 +524,12 @@ def encode_main(args):
         value = world * n_ctu * args.steps / dt
         # ---- roofline of the dominant kernel: a separate, untimed pass over ONE of the pictures with HIP events around every launch (graphs off while profiling) ----
         Y0, Cb0, Cr0 = pics[0]
-        pctx = hp.Context(tw, th, device=local, slots=args.slots)
-        pctx.upload_orig(Y0, Cb0, Cr0)
+        Pp = min(P, args.profile_pictures)
+        pctx = hp.Context(tw, th, device=local, pictures=Pp, slots=args.slots)
+        if Pp > 1:
+            pctx.upload_orig(pctx.stack([p[0] for p in pics[:Pp]]), pctx.stack([p[1] for p in pics[:Pp]], True), pctx.stack([p[2] for p in pics[:Pp]], True))
+        else:
+            pctx.upload_orig(Y0, Cb0, Cr0)
         L = pctx.L
         L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
         L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -533,7 +537,7 @@ def encode_main(args):
         tp0 = time.perf_counter()
         pctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
         prof_s = time.perf_counter() - tp0
-        prof_ctus = wctu * hctu
+        prof_ctus = wctu * hctu * Pp
         names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_turd_fused (transform unit leaf step: transform, estBit, RDOQ, counted bits, inverse, decision)",
                  7: "k_intra (rough search + predictors)", 8: "k_rdoq (staged form)", 9: "k_coeff_bits + CU-level counting"}
         prof = {}
@@ -562,8 +566,8 @@ def encode_main(args):
                        "whole_frame_note": "--width 7728 --rows 84 --pictures 1 codes the 7728x5368 frame as ONE picture: at most 24 CTU rows in flight (lag 5), 536 wavefront steps; see DESIGN.md for its rate"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
-                         "note": "from a separate profiled pass over one %dx%d picture (%d CTUs, %.1f s, HIP events around every launch, graphs off); the encode is bound by the LENGTH of "
-                                 "its dependent launch chains and the serial lane speed inside them, not by HBM or VALU throughput: see request_ms" % (tw, th, prof_ctus, prof_s)},
+                         "note": "from a separate profiled pass over %d of the %dx%d pictures (%d CTUs, %.1f s, HIP events around every launch, graphs off); the encode is bound by the LENGTH of "
+                                 "its dependent launch chains and the serial lane speed inside them, not by HBM or VALU throughput: see request_ms" % (Pp, tw, th, prof_ctus, prof_s)},
             "kernels": prof,
             "request_ms": {k: v for k, v in stats.items() if k != "rendezvous"},
             "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTUs in flight, all pictures together)",
@@ -608,7 +612,8 @@ def main():
     ap.add_argument("--rows", type=int, default=4, help="CTU rows of one picture (tile); 84 with --tile-w 7728 --pictures 1 = the whole frame as one picture")
     ap.add_argument("--tile-w", type=int, default=1024, help="width of one picture (tile)")
     ap.add_argument("--slots", type=int, default=16, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
-    ap.add_argument("--pictures", type=int, default=64, help="independent pictures coded side by side per GPU (one stacked context)")
+    ap.add_argument("--profile-pictures", type=int, default=16, help="pictures of the separate profiled pass behind the roofline object")
+    ap.add_argument("--pictures", type=int, default=128, help="independent pictures coded side by side per GPU (one stacked context)")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
     ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")
     ap.add_argument("--kernels", action="store_true", help="kernel-throughput mode of round 1: the search kernels over a frozen, fully reconstructed SS reference (not the encode metric)")

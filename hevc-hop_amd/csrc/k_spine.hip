@@ -139,7 +139,7 @@ using namespace hopspine;
 
 struct Bail { int code; };
 // wall time and calls per kind of request of the last hop_encode_frame (hop_encode_stats): 0 me_search, 1 pred_inter, 2 distortion, 3 valid_pattern, 4 inter_cu with
-// residual, 5 inter_cu without, 6 intra_cu, 7 recon stash, 8 commit
+// residual, 5 inter_cu without, 6 intra_cu, 7 recon stash, 8 commit, 9 the wait for the evaluation chains issued on streams of their own (then 4 - 6 hold the issue time only)
 double g_stat_ms[16]; double g_stat_calls[16];
 std::mutex g_stat_lock;
 struct Tick { int k; std::chrono::steady_clock::time_point t0; explicit Tick(int k) : k(k), t0(std::chrono::steady_clock::now()) {}
@@ -191,6 +191,9 @@ class HipBackend : public BatchInner {
     return true;
   }
   void end_round() {
+    bool any = false; for (auto b : subs_) any |= (bool)b->collect_;
+    if (!any) return;
+    Tick t(9);                                                            // the wait for the evaluation chains of the round
     for (auto b : subs_) if (b->collect_) { std::function<void()> f; f.swap(b->collect_); f(); if (b->c->err[0] && !c->err[0]) strncpy(c->err, b->c->err, sizeof(c->err) - 1); }
   }
   bool ok() const { return arena != nullptr; }
@@ -379,6 +382,7 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   if (!be.ok()) return HOP_ERR_DEVICE;
   if (c->slots > 0 && p->wavefront_lag > 0 && !p->plain_intra) {         // candidates side by side: their evaluation chains of one round on streams of their own
     int k = 4; if (const char* e = getenv("HOP_SPINE_STREAMS")) k = atoi(e);
+    if (c->prof_on) k = 1;                                               // profiling (hop_profile_*) records on the context's own stream
     if (k > 1 && !be.add_streams(k > 8 ? 8 : k)) return hop_set_err(c, HOP_ERR_DEVICE, "hop_encode_frame: could not create the evaluation streams");
   }
   // streams > 1: one view of the context (own stream, own work areas) per CTU row in flight; their launch chains overlap on the device

@@ -323,7 +323,7 @@ class Context:
     def encode_stats(self):
         ms, calls = (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
         self.L.hop_encode_stats(ms, calls)
-        names = ("me_search", "pred_inter", "distortion", "valid_pattern", "inter_cu", "inter_cu_skip", "intra_cu", "recon_stash", "commit")
+        names = ("me_search", "pred_inter", "distortion", "valid_pattern", "inter_cu", "inter_cu_skip", "intra_cu", "recon_stash", "commit", "evaluation_wait")
         d = {k: {"ms": ms[i], "calls": int(calls[i])} for i, k in enumerate(names)}
         d["rendezvous"] = {"rounds": int(calls[14]), "requests": int(calls[15])}
         return d

@@ -191,7 +191,7 @@ int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_c
                      int32_t* d_levels, hop_tu_rd_result* d_res);
 // the same leaf step as one kernel, a workgroup per TU (k_leaf_fused.inl): hop_launch_tu_rd takes it for batches of up to c->fused_leaf_max TUs
 int hop_launch_tu_rd_fused(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
-                           int32_t* d_levels, hop_tu_rd_result* d_res);
+                           int32_t* d_levels, hop_tu_rd_result* d_res, int all_small /* every TU is 4x4 or 8x8: a wave per TU */);
 int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, const hop_cabac_ctx* d_ctx, const int32_t* d_coef,
                           unsigned long long* d_bits, hop_cabac_ctx* d_ctx_out);
 #define HOP_RDOQ_SCAN_ENTRIES (4080 + 255)

@@ -59,13 +59,25 @@ struct CabacLds { uint8_t st[172][64]; uint16_t absCoeff[16][64]; };      // row
                           sh.st[i_][lane] = ((s_ & 1) == b_) ? c_next_mps[s_] : c_next_lps[s_]; } while (0)
 
 // counted bits of one TU on the lane's context states: the coded_block_flag if asked for (encodeQtCbf), then codeCoeffNxN
-__device__ static unsigned long long cb_code_tu(CabacLds& sh, const int lane, const int32_t* __restrict__ coef, const int log2, const int chroma, const int scan_idx,
+struct CabacLds1 { uint8_t st[172][1]; uint16_t absCoeff[16][1]; };         // the same for ONE lane (a TU or CU with a wave of its own): 204 bytes instead of 13 KB
+
+template <class LDS>
+__device__ static unsigned long long cb_code_tu_at(LDS& sh, const int lane, const int32_t* __restrict__ coef, const int log2, const int chroma, const int scan_idx,
+                                                   const int sign_hide, const int use_ts, const int ts_flag, const int cbf_ctx_plus1,
+                                                   const uint16_t* __restrict__ scan, const uint16_t* __restrict__ scanCG);
+template <class LDS>
+__device__ static unsigned long long cb_code_tu(LDS& sh, const int lane, const int32_t* __restrict__ coef, const int log2, const int chroma, const int scan_idx,
                                                 const int sign_hide, const int use_ts, const int ts_flag, const int cbf_ctx_plus1, const uint16_t* __restrict__ scans) {
+  const int so = (log2 == 2) ? 0 : (log2 == 3) ? 16 : (log2 == 4) ? 80 : 336, co = (log2 == 2) ? 0 : (log2 == 3) ? 1 : (log2 == 4) ? 5 : 21;
+  return cb_code_tu_at(sh, lane, coef, log2, chroma, scan_idx, sign_hide, use_ts, ts_flag, cbf_ctx_plus1, scans + scan_idx * 1360 + so, scans + 4080 + scan_idx * 85 + co);
+}
+// the same with the TU's scan and coefficient-group scan given (a caller that holds them in LDS)
+template <class LDS>
+__device__ static unsigned long long cb_code_tu_at(LDS& sh, const int lane, const int32_t* __restrict__ coef, const int log2, const int chroma, const int scan_idx,
+                                                   const int sign_hide, const int use_ts, const int ts_flag, const int cbf_ctx_plus1,
+                                                   const uint16_t* __restrict__ scan, const uint16_t* __restrict__ scanCG) {
   unsigned long long frac = 0;
   const int width = 1 << log2, nco = width * width;
-  const int so = (log2 == 2) ? 0 : (log2 == 3) ? 16 : (log2 == 4) ? 80 : 336, co = (log2 == 2) ? 0 : (log2 == 3) ? 1 : (log2 == 4) ? 5 : 21;
-  const uint16_t* scan = scans + scan_idx * 1360 + so;
-  const uint16_t* scanCG = scans + 4080 + scan_idx * 85 + co;
   int numSig = 0;
   for (int i = 0; i < nco; i++) numSig += coef[i] != 0;
   if (cbf_ctx_plus1) CBIN(CX_QT_CBF + cbf_ctx_plus1 - 1, numSig != 0 ? 1 : 0);      // encodeQtCbf (TEncSbac.cpp:1596-1600)

@@ -37,13 +37,14 @@ __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restr
   __threadfence_block();
   __syncthreads();
   if (tid == 0) {                                                     // the serial stages
-    turd_setup_body(j, jobs, n, ctx_in, coef_off, entropy_bits, tables, rq, cb);
+    turd_setup_body(j, jobs, n, ctx_in, coef_off, entropy_bits, tables + j, rq, cb);
     const hop_rdoq_job rj = rq[j];
     double* wd = (double*)(work + (size_t)j * LEAF_WORK_PER_TU);
-    if (LOG2 == 2) rdoq_tu<2>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
-    else if (LOG2 == 3) rdoq_tu<3>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
-    else if (LOG2 == 4) rdoq_tu<4>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
-    else rdoq_tu<5>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, coef, levels, as + j, wd, 1, 0);
+    const int32_t* src = coef + rj.coeff_offset; int32_t* dst = levels + rj.coeff_offset;
+    if (LOG2 == 2) rdoq_tu<2>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
+    else if (LOG2 == 3) rdoq_tu<3>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
+    else if (LOG2 == 4) rdoq_tu<4>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
+    else rdoq_tu<5>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
     const hop_coeff_bits_job bj = cb[j];
     { const uint8_t* src = ctx_in[bj.ctx_index].state; for (int i = 0; i < 152; i++) L.cab.st[i][0] = src[i]; }
     fr[j] = cb_code_tu(L.cab, 0, levels + bj.coeff_offset, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, scans);
@@ -58,6 +59,53 @@ __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restr
   if (tid == 0) turd_decide_body(j, jobs, n, ctx_in, coef_off, entropy_bits, as, fr, zs, ns, levels, res);
 }
 
+// The same for batches whose TUs are all 4x4 or 8x8 (size_hint 1: most of the quadtree steps of 8x8 CUs, every chroma step of CUs up to 16x16): ONE wave per TU and
+// 1.4 KB of LDS, so that a compute unit holds 32 TUs instead of 7 -- in the large batches of many CTUs in flight the leaf step is bound by how many serial walks the
+// GPU holds at once.
+struct LeafSmallShared { TurdSmallShared t; CabacLds1 cab; uint16_t scan[64]; uint16_t scanCG[4]; double cgSig[4];
+                         double work[64 * RQ_WORK_PER_COEF / 8]; hop_estbits eb; int32_t src[64], lev[64], ebits[128]; uint8_t ctx[152]; };   // everything the serial walk touches
+
+__global__ __launch_bounds__(64) void k_turd_fused_small(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                         const int64_t* __restrict__ coef_off, const int32_t* __restrict__ entropy_bits, const uint16_t* __restrict__ scans,
+                                                         int32_t* __restrict__ coef, int32_t* __restrict__ levels, uint32_t* __restrict__ zs, uint32_t* __restrict__ ns,
+                                                         uint32_t* __restrict__ as, unsigned long long* __restrict__ fr, hop_estbits* __restrict__ tables,
+                                                         hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb, char* __restrict__ work,
+                                                         hop_tu_rd_result* __restrict__ res, int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
+  __shared__ LeafSmallShared L;
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const hop_tu_rd_job jb = jobs[j];
+  if (jb.log2_size < 2 || jb.log2_size > 3) return;                   // an empty slot; (larger TUs never come here: size_hint 1)
+  const int LOG2 = jb.log2_size, N2 = 1 << (2 * LOG2), CGN = N2 >> 4;
+  turd_forward_small_body(L.t, 0, tid, j, jobs, n, pic, coef_off, coef, zs);
+  { const uint16_t* s0 = rq_scan(scans, jb.scan_idx, LOG2); const uint16_t* s1 = rq_scan_cg(scans, jb.scan_idx, LOG2);
+    if (tid < N2) L.scan[tid] = s0[tid];
+    if (tid < CGN) L.scanCG[tid] = s1[tid]; }
+  __threadfence_block();
+  __syncthreads();
+  // the coefficients, the context states and the entropy table into LDS (a lane's dependent loads from HBM would be most of the serial walk's time)
+  const int64_t off = coef_off[j];
+  if (tid < N2) L.src[tid] = coef[off + tid];
+  { const uint8_t* st = ctx_in[jb.ctx_index].state; for (int i = tid; i < 152; i += 64) { const uint8_t v = st[i]; L.ctx[i] = v; L.cab.st[i][0] = v; } }
+  for (int i = tid; i < 128; i += 64) L.ebits[i] = entropy_bits[i];
+  __syncthreads();
+  if (tid == 0) {
+    turd_setup_body(j, jobs, n, ctx_in, coef_off, L.ebits, &L.eb, rq, cb, L.ctx);
+    const hop_rdoq_job rj = rq[j];
+    if (LOG2 == 2) rdoq_tu<2>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, L.work, 1, 0);
+    else rdoq_tu<3>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, L.work, 1, 0);
+    const hop_coeff_bits_job bj = cb[j];
+    fr[j] = cb_code_tu_at(L.cab, 0, L.lev, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, L.scan, L.scanCG);
+  }
+  __syncthreads();
+  if (tid < N2) levels[off + tid] = L.lev[tid];
+  __threadfence_block();
+  __syncthreads();
+  turd_inverse_small_body(L.t, 0, tid, j, jobs, n, pic, coef_off, levels, as, ns, rec_y, rec_cb, rec_cr);
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) turd_decide_body(j, jobs, n, ctx_in, coef_off, entropy_bits, as, fr, zs, ns, levels, res);
+}
+
 size_t hop_tu_rd_fused_scratch(int n, size_t n_coeff) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   return al(n_coeff * 4) + 4 * al((size_t)n * 4) + al((size_t)n * 8) + al((size_t)n * sizeof(hop_estbits)) + al((size_t)n * sizeof(hop_rdoq_job)) +
@@ -65,7 +113,7 @@ size_t hop_tu_rd_fused_scratch(int n, size_t n_coeff) {
 }
 
 int hop_launch_tu_rd_fused(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
-                           int32_t* d_levels, hop_tu_rd_result* d_res) {
+                           int32_t* d_levels, hop_tu_rd_result* d_res, int all_small) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_coef = 0, o_zs = al(o_coef + n_coeff * 4), o_ns = al(o_zs + (size_t)n * 4), o_as = al(o_ns + (size_t)n * 4), o_fr = al(o_as + (size_t)n * 4);
   const size_t o_tab = al(o_fr + (size_t)n * 8), o_rq = al(o_tab + (size_t)n * sizeof(hop_estbits)), o_cb = al(o_rq + (size_t)n * sizeof(hop_rdoq_job));
@@ -73,6 +121,11 @@ int hop_launch_tu_rd_fused(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const
   void* sc; int r = hop_scratch(c, o_wk + (size_t)n * LEAF_WORK_PER_TU + 256, &sc); if (r) return r;
   char* b = (char*)sc;
   const int pr = hop_prof_begin(c, HOP_K_TQ, (uint64_t)n);
+  if (all_small)
+    hipLaunchKernelGGL(k_turd_fused_small, dim3(n), dim3(64), 0, c->stream, d_jobs, n, hop_make_pics(c), d_ctx, d_coef_off, hop_entropy_bits_device(c), c->rdoq_scans,
+                       (int32_t*)(b + o_coef), d_levels, (uint32_t*)(b + o_zs), (uint32_t*)(b + o_ns), (uint32_t*)(b + o_as), (unsigned long long*)(b + o_fr),
+                       (hop_estbits*)(b + o_tab), (hop_rdoq_job*)(b + o_rq), (hop_coeff_bits_job*)(b + o_cb), b + o_wk, d_res, c->rec[0], c->rec[1], c->rec[2]);
+  else
   hipLaunchKernelGGL(k_turd_fused, dim3(n), dim3(256), 0, c->stream, d_jobs, n, hop_make_pics(c), d_ctx, d_coef_off, hop_entropy_bits_device(c), c->rdoq_scans,
                      (int32_t*)(b + o_coef), d_levels, (uint32_t*)(b + o_zs), (uint32_t*)(b + o_ns), (uint32_t*)(b + o_as), (unsigned long long*)(b + o_fr),
                      (hop_estbits*)(b + o_tab), (hop_rdoq_job*)(b + o_rq), (hop_coeff_bits_job*)(b + o_cb), b + o_wk, d_res, c->rec[0], c->rec[1], c->rec[2]);

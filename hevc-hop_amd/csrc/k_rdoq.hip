@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) void k_rdoq(const hop_rdoq_job* __restrict__ jo
     if (idx >= count) continue;                                           // no barrier below: a lane only ever reads what it wrote itself
     const int ti = list[idx];
     const hop_rdoq_job jb = jobs[ti];
-    rdoq_tu<LOG2>(jb, tables + jb.estbits_index, s_scan[jb.scan_idx], s_scanCG[jb.scan_idx], &s_cgSig[0][lane], 64, src_all, dst_all, abs_sum_out + ti, wd, 64, lane);
+    rdoq_tu<LOG2>(jb, tables + jb.estbits_index, s_scan[jb.scan_idx], s_scanCG[jb.scan_idx], &s_cgSig[0][lane], 64, src_all + jb.coeff_offset, dst_all + jb.coeff_offset, abs_sum_out + ti, wd, 64, lane);
   }
 }
 

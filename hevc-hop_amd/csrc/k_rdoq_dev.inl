@@ -114,12 +114,12 @@ __device__ static inline double rq_rate_last(const hop_estbits* eb, double lambd
 // level, |coeff| * Q, and the four sign-hiding terms (int)
 #define RQ_WORK_PER_COEF 40
 
-// One TU on the calling lane.  scan / scanCG: the TU's coefficient and coefficient-group scans; cgSig: CGN doubles `cgs` apart (the cost of each group's
+// One TU on the calling lane.  src / dst: its coefficients and levels; scan / scanCG: the TU's coefficient and coefficient-group scans; cgSig: CGN doubles `cgs` apart (the cost of each group's
 // coded_sub_block_flag); wd: a work area of N2 * ws * RQ_WORK_PER_COEF bytes laid out [array][scan position][ws lanes], wl: the calling lane's column in it (ws = 64: the lanes of a
 // wave side by side, k_rdoq; ws = 1: a TU of its own, k_turd_fused).  A lane only ever reads what it wrote itself: no barrier in here.
 template <int LOG2>
 __device__ static void rdoq_tu(const hop_rdoq_job& jb, const hop_estbits* __restrict__ eb, const uint16_t* __restrict__ scan, const uint16_t* __restrict__ scanCG,
-                               double* __restrict__ cgSig, const int cgs, const int32_t* __restrict__ src_all, int32_t* __restrict__ dst_all,
+                               double* __restrict__ cgSig, const int cgs, const int32_t* __restrict__ src, int32_t* __restrict__ dst,
                                uint32_t* __restrict__ abs_sum_out, double* __restrict__ wd, const int ws, const int wl) {
   constexpr int N2 = 1 << (2 * LOG2), WCG = (1 << LOG2) >> 2, CGN = N2 >> 4;
   double* const wcc = wd + wl; double* const wcs = wd + (size_t)N2 * ws + wl;
@@ -127,8 +127,6 @@ __device__ static void rdoq_tu(const hop_rdoq_job& jb, const hop_estbits* __rest
   int* const wlvl = wi; int* const wlvlD = wi + (size_t)N2 * ws; int* const wrUp = wi + (size_t)2 * N2 * ws;
   int* const wrDn = wi + (size_t)3 * N2 * ws; int* const wsDelta = wi + (size_t)4 * N2 * ws; int* const wdU = wi + (size_t)5 * N2 * ws;
 #define W(a, sp) a[(size_t)(sp) * ws]
-  const int32_t* src = src_all + jb.coeff_offset;
-  int32_t* dst = dst_all + jb.coeff_offset;
   const bool is_luma = jb.comp == 0;
   const int scan_idx = jb.scan_idx;
   const int per = jb.qp_scaled / 6, rem = jb.qp_scaled % 6;

@@ -136,13 +136,14 @@ __global__ __launch_bounds__(256) void k_turd_forward(const hop_tu_rd_job* __res
 __global__ __launch_bounds__(256) void k_turd_inverse(const hop_tu_rd_job* __restrict__ jobs, hop_pics pic, const int64_t* __restrict__ coef_off,                                                       const int32_t* __restrict__ levels, const uint32_t* __restrict__ abs_sum, uint32_t* __restrict__ nz_sse,                                                       int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) { __shared__ TurdFwdShared sh; turd_inverse_body(sh, blockIdx.x, jobs, pic, coef_off, levels, abs_sum, nz_sse, rec_y, rec_cb, rec_cr); }
 __global__ __launch_bounds__(256) void k_turd_forward_small(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const int64_t* __restrict__ coef_off,                                                             int32_t* __restrict__ coef, uint32_t* __restrict__ zero_sse) { __shared__ TurdSmallShared sh; turd_forward_small_body(sh, threadIdx.x >> 6, threadIdx.x & 63, blockIdx.x * 4 + (threadIdx.x >> 6), jobs, n, pic, coef_off, coef, zero_sse); }
 __global__ __launch_bounds__(256) void k_turd_inverse_small(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const int64_t* __restrict__ coef_off,                                                             const int32_t* __restrict__ levels, const uint32_t* __restrict__ abs_sum, uint32_t* __restrict__ nz_sse,                                                             int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) { __shared__ TurdSmallShared sh; turd_inverse_small_body(sh, threadIdx.x >> 6, threadIdx.x & 63, blockIdx.x * 4 + (threadIdx.x >> 6), jobs, n, pic, coef_off, levels, abs_sum, nz_sse, rec_y, rec_cb, rec_cr); }
-__global__ void k_turd_setup(const hop_tu_rd_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const int64_t* __restrict__ coef_off,                              const int32_t* __restrict__ entropy_bits, hop_estbits* __restrict__ tables, hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb) { turd_setup_body(blockIdx.x * blockDim.x + threadIdx.x, jobs, n, ctx_in, coef_off, entropy_bits, tables, rq, cb); }
+__global__ void k_turd_setup(const hop_tu_rd_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const int64_t* __restrict__ coef_off,                              const int32_t* __restrict__ entropy_bits, hop_estbits* __restrict__ tables, hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb) { turd_setup_body(blockIdx.x * blockDim.x + threadIdx.x, jobs, n, ctx_in, coef_off, entropy_bits, tables + (blockIdx.x * blockDim.x + threadIdx.x), rq, cb); }
 __global__ void k_turd_decide(const hop_tu_rd_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const int64_t* __restrict__ coef_off,                               const int32_t* __restrict__ entropy_bits, const uint32_t* __restrict__ abs_sum, const unsigned long long* __restrict__ frac,                               const uint32_t* __restrict__ zero_sse, const uint32_t* __restrict__ nz_sse, int32_t* __restrict__ levels,                               hop_tu_rd_result* __restrict__ res) { turd_decide_body(blockIdx.x * blockDim.x + threadIdx.x, jobs, n, ctx_in, coef_off, entropy_bits, abs_sum, frac, zero_sse, nz_sse, levels, res); }
 
 // size_hint: 0 = transform sizes unknown / mixed, 1 = every TU is 4x4 or 8x8 (one wave per TU), 2 = every TU is 16x16 or 32x32
 int hop_launch_tu_rd(hop_ctx* c, int n, const hop_tu_rd_job* d_jobs, const hop_cabac_ctx* d_ctx, const int64_t* d_coef_off, size_t n_coeff,
                      int32_t* d_levels, hop_tu_rd_result* d_res, int size_hint) {
-  if (n <= c->fused_leaf_max) return hop_launch_tu_rd_fused(c, n, d_jobs, d_ctx, d_coef_off, n_coeff, d_levels, d_res);   // launch-bound batches: one kernel
+  // (a wave per small TU stays the better form far beyond the workgroup-per-TU one's range: 8 x as many fit a compute unit, and the lanes of the staged form diverge)
+  if (n <= c->fused_leaf_max || (size_hint == 1 && c->fused_leaf_max > 0 && n <= 8 * c->fused_leaf_max)) return hop_launch_tu_rd_fused(c, n, d_jobs, d_ctx, d_coef_off, n_coeff, d_levels, d_res, size_hint == 1);   // launch-bound batches: one kernel
   // scratch: coefficients, zero / non-zero SSE, abs sums, counted bits, the bit-estimate tables and the job records of the inner stages
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_coef = 0, o_zs = al(o_coef + n_coeff * 4), o_ns = al(o_zs + (size_t)n * 4), o_as = al(o_ns + (size_t)n * 4), o_fr = al(o_as + (size_t)n * 4);

@@ -249,11 +249,11 @@ __device__ static void turd_inverse_small_body(TurdSmallShared& sh, const int w,
 
 // one thread per TU: the bit-estimate table of its snapshot (TEncSbac::estBit as hop_cabac_est_bits) and the job records
 __device__ static void turd_setup_body(const int i, const hop_tu_rd_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const int64_t* __restrict__ coef_off,
-                             const int32_t* __restrict__ entropy_bits, hop_estbits* __restrict__ tables, hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb) {
+                             const int32_t* __restrict__ entropy_bits, hop_estbits* __restrict__ eb, hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb,
+                             const uint8_t* __restrict__ state_at = nullptr /* the TU's context states, if the caller holds a copy (LDS) */) {
   if (i >= n) return;
   const hop_tu_rd_job jb = jobs[i];
-  const uint8_t* s = ctx_in[jb.ctx_index].state;
-  hop_estbits* eb = tables + i;
+  const uint8_t* s = state_at ? state_at : ctx_in[jb.ctx_index].state;
   const int width = 1 << jb.log2_size, chroma = jb.comp != 0;
   int32_t* w = (int32_t*)eb;
   for (int k = 0; k < (int)(sizeof(hop_estbits) / 4); k++) w[k] = 0;

@@ -450,9 +450,14 @@ void hop_o_calc_param_projective_c(const double x[4], const double y[4], double 
  * W,H are the DOUBLED block dimensions; refCentre addresses the patch sample co-located with the
  * block's top-left; `clipPatch`: 0 = read the source as is, 1 = clamp each source sample to
  * [0,(1<<bitDepth)-1] first (what the encoder's m_filteredBlock[0][0] holds, see hop_o_gt_search). */
+/* candidate warps evaluated since the last reset (tests: how many the GT searches of a run went through) */
+static long g_warp_count = 0;
+long hop_o_warp_counter(int reset) { long v = g_warp_count; if (reset) g_warp_count = 0; return v; }
+
 static void projective_transform(const int16_t* refCentre, int16_t* aux, const double h[9], int W, int H, int stride,
                                  int nssWindow, int clipPatch, int bitDepth)
 {
+  g_warp_count++;
   int offsetX = W / 2 - (W / 2 / 2);
   int offsetY = H / 2 - (H / 2 / 2);
   int m = nssWindow / 2, wv = W / 2, hv = H / 2;

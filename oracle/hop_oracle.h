@@ -33,6 +33,7 @@ int hop_o_gt_search(const int16_t* org, int orgStride, const int16_t* refPU, int
 void hop_o_pred_inter(const int16_t* refY, int strideY, const int16_t* refCb, const int16_t* refCr, int strideC,
                       int puX, int puY, int w, int h, int mvx, int mvy, int useGT, const int gt[8],
                       int bitDepthY, int bitDepthC, int16_t* predY, int16_t* predCb, int16_t* predCr);
+long hop_o_warp_counter(int reset);   /* warps evaluated by hop_o_gt_search / hop_o_projective_transform since the last reset */
 int hop_o_me_pu(const int16_t* org, int orgStride, const int16_t* refY00, int refStride, int puX, int puY, int w, int h,
                 int rngL, int rngR, int rngT, int rngB, int offX, int offY,
                 int predX, int predY, int nAmvp, const int* amvpXY, uint32_t lambdaCost,

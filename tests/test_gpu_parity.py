@@ -411,3 +411,68 @@ def test_encoder_calls_replay(hp):
         n += 1
     ctx.close()
     assert n >= 90
+
+
+def _warp_jobs(hp, O, rng, W, H, lc, n):
+    """n random PUs of every PU shape of the RD tree (incl. AMP) inside the coded part of the plane, random predictors"""
+    shapes = [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (32, 64), (32, 16), (16, 32), (16, 8), (8, 16), (8, 4), (4, 8), (12, 16), (16, 12), (4, 16), (16, 4),
+              (24, 32), (32, 24), (8, 32), (32, 8), (48, 64), (64, 48), (16, 64), (64, 16)]
+    jobs = np.zeros(n, hp.PU_JOB_DTYPE)
+    for i in range(n):
+        w, h = shapes[i % len(shapes)]
+        cuS = 64 if max(w, h) > 32 else 32 if max(w, h) > 16 else 16 if max(w, h) > 8 else 8
+        cuX, cuY = 64 * int(rng.integers(1, 3)), 128
+        puX, puY = cuX + (cuS - w) * int(rng.integers(0, 2)), cuY + (cuS - h) * int(rng.integers(0, 2))
+        pred = (int(rng.integers(-120, 120)), int(rng.integers(-260, -40)))
+        o6 = (ctypes.c_int * 6)()
+        O.hop_o_set_search_range(W, H, cuX, cuY, cuS, 2 * 4 + cuX // 64, 4, pred[0], pred[1], 128, puX - cuX, puY - cuY, 0, 0, o6)
+        j = jobs[i]
+        j["pu_x"], j["pu_y"], j["w"], j["h"] = puX, puY, w, h
+        j["rng_left"], j["rng_right"], j["rng_top"], j["rng_bottom"], j["off_x"], j["off_y"] = list(o6)
+        j["pred_x"], j["pred_y"], j["lambda_cost"], j["n_amvp"] = pred[0], pred[1], lc, 2
+        j["amvp"] = [pred[0], pred[1], int(rng.integers(-80, 80)), int(rng.integers(-300, -60))]
+        j["flags"] = hp.HOP_FLAG_FEN | hp.HOP_FLAG_HADME
+    return jobs
+
+
+def test_integer_warp_vs_double_warp_100k_candidates(hp):
+    """The GT search kernel evaluates its candidate warps in exact integer arithmetic (k_gt_search.hip: a proof of equivalence, not the reference's doubles); the
+    restatement evaluates them as the reference does (double homography, x86 truncation).  Seeded random PUs of all 24 PU shapes, random predictors, on lenslet content
+    with a sentinel hole: every field of every result must be equal -- a single sample of a single candidate warp rounding the other way changes a cost -- over at least
+    1e5 candidate warps (counted by the restatement)."""
+    O = oracle()
+    O.hop_o_warp_counter.restype = ctypes.c_long
+    W, H = 256, 192
+    total, pus = 0, 0
+    for seed in range(3):
+        Y, Cb, Cr = lenslet(W, H, 13 + seed, 500 + seed)
+        rng = np.random.default_rng(900 + seed)
+        pl = Planes(W, H)
+        pl.y00()[:128, :W] = Y[:128]
+        pl.y00()[128:192, :64] = Y[128:192, :64]
+        pl.y00()[70:80, 100:140] = -1
+        by = np.ascontiguousarray(pl.y00()[0:8, 0:8]); z = np.zeros((4, 4), np.int16) - 1
+        O.hop_o_ssref_commit_cu(pl.ptr00(0), pl.ptr00(1), pl.ptr00(2), W, H, 0, 0, 8, p16(by), p16(z), p16(z))
+        lam, lc = lambda_for_qp(int(rng.integers(24, 40)))
+        ctx = hp.Context(W, H)
+        ctx.upload_orig(Y, Cb, Cr)
+        ctx.ssref_upload(0, pl.bufY)
+        jobs = _warp_jobs(hp, O, rng, W, H, lc, 240)
+        res = ctx.me_search(jobs, 3)
+        O.hop_o_warp_counter(1)
+        for j, r in zip(jobs, res):
+            out = (ctypes.c_int64 * 32)()
+            org = np.ascontiguousarray(Y[j["pu_y"]:j["pu_y"] + j["h"], j["pu_x"]:j["pu_x"] + j["w"]])
+            O.hop_o_me_pu(p16(org), int(j["w"]), pl.ptr00(0), pl.sy, int(j["pu_x"]), int(j["pu_y"]), int(j["w"]), int(j["h"]),
+                          int(j["rng_left"]), int(j["rng_right"]), int(j["rng_top"]), int(j["rng_bottom"]), int(j["off_x"]), int(j["off_y"]),
+                          int(j["pred_x"]), int(j["pred_y"]), 2, (ctypes.c_int * 4)(*[int(v) for v in j["amvp"]]), lc, 1, 1, 8, 3, out)
+            want, got = list(out)[:27], _res_row(r)
+            if want[3]:
+                assert got[2:4] == want[2:4]
+            else:
+                assert got[:25] == want[:25], (seed, [int(j[k]) for k in ("pu_x", "pu_y", "w", "h")], got, want)
+                pus += 1
+        total += O.hop_o_warp_counter(1)
+        ctx.close()
+    print("GT searches compared: %d PUs, %d candidate warps" % (pus, total))
+    assert total >= 100000, total

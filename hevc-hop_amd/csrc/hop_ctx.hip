@@ -448,7 +448,7 @@ int hop_tu_roundtrip(hop_ctx* c, int n, const hop_tu_job* jobs, hop_tu_result* r
     const hop_tu_job& j = jobs[i];
     const int N = 1 << j.log2_size, sh = j.comp ? 1 : 0;
     if (j.comp < 0 || j.comp > 2 || j.log2_size < 2 || j.log2_size > 5 || j.x < 0 || j.y < 0 || ((j.x >> sh) & 3) || ((j.y >> sh) & 3) ||
-        (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || (j.use_dst && (j.log2_size != 2 || j.comp != 0)))
+        (j.x >> sh) + N > (c->pic_w >> sh) || (j.y >> sh) + N > (c->pic_h >> sh) || j.qp_scaled < 0 || j.qp_scaled > 87 || (j.use_dst && (j.log2_size != 2 || j.comp != 0)) || j.scan_idx < 0 || j.scan_idx > 2)
       return hop_set_err(c, HOP_ERR_ARG, "TU job %d: illegal transform unit", i);
     offs[i] = (int64_t)tot; tot += (size_t)N * N;
   }

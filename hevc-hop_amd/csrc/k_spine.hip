@@ -190,6 +190,7 @@ class HipBackend : public BatchInner {
     }
     return true;
   }
+  bool can_defer() { return !subs_.empty(); }
   void end_round() {
     bool any = false; for (auto b : subs_) any |= (bool)b->collect_;
     if (!any) return;

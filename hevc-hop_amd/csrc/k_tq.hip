@@ -14,9 +14,9 @@
 #include "k_turd_dev.inl"
 __constant__ int c_quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };      // TComRom.cpp:164-167
 
-struct TqShared { int16_t a[32 * 32]; int16_t b[32 * 32]; int32_t lv[32 * 32]; int16_t T[32 * 32]; unsigned int acc[2]; };
+struct TqShared { int16_t a[32 * 32]; int16_t b[32 * 32]; int32_t lv[32 * 32]; int16_t T[32 * 32]; unsigned int acc[2]; int32_t q[32 * 32]; int32_t du[32 * 32]; };   // q / du: levels and the quantiser's remainders (sign-bit hiding)
 
-__global__ __launch_bounds__(256) void k_tu_roundtrip(const hop_tu_job* __restrict__ jobs, hop_pics pic, int16_t* __restrict__ rec_y,
+__global__ __launch_bounds__(256) void k_tu_roundtrip(const hop_tu_job* __restrict__ jobs, hop_pics pic, const uint16_t* __restrict__ scans, int16_t* __restrict__ rec_y,
                                                       int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr,
                                                       hop_tu_result* __restrict__ res, int32_t* __restrict__ levels, const int64_t* __restrict__ level_off) {
   __shared__ TqShared sh;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_tu_roundtrip(const hop_tu_job* __restri
     }
   }
   __syncthreads();
-  // flat quantiser :1079-1107 and dequantiser :1171-1182
+  // flat quantiser :1079-1107 (with the remainders deltaU :1100), sign-bit hiding :868-990 if asked for, dequantiser :1171-1182
   {
     const int per = jb.qp_scaled / 6, rem = jb.qp_scaled % 6;
     const int qBits = 14 + per + transformShift;
@@ -64,13 +64,54 @@ __global__ __launch_bounds__(256) void k_tu_roundtrip(const hop_tu_job* __restri
       int c = sh.lv[i], sign = c < 0 ? -1 : 1;
       long long t = (long long)(c < 0 ? -c : c) * c_quant_scales[rem];
       int lv = (int)((t + add) >> qBits);
+      sh.du[i] = (int)((t - ((long long)lv << qBits)) >> (qBits - 8));
       part += (unsigned)lv;
-      lv = clip16(lv * sign);
-      if (levels) levels[level_off[blockIdx.x] + i] = lv;
-      sh.lv[i] = clip16((lv * scale + dadd) >> dshift);              // dequantised coefficient
+      sh.q[i] = clip16(lv * sign);
     }
     part = (unsigned)hopd_wave_sum((int)part);
     if ((tid & 63) == 0) atomicAdd(&sh.acc[0], part);
+    __syncthreads();
+    if (jb.sign_hide && sh.acc[0] >= 2 && tid == 0) {                  // signBitHidingHDQ: a serial walk over the coefficient groups of the scan (rows a10's rarely used corner)
+      const uint16_t* scan = scans + jb.scan_idx * 1360 + (log2N == 2 ? 0 : log2N == 3 ? 16 : log2N == 4 ? 80 : 336);
+      int lastCG = -1;
+      for (int subSet = (NN - 1) >> 4; subSet >= 0; subSet--) {
+        const int subPos = subSet << 4;
+        int firstNZ = 16, lastNZ = -1, absSum = 0, n;
+        for (n = 15; n >= 0; --n) if (sh.q[scan[n + subPos]]) { lastNZ = n; break; }
+        for (n = 0; n < 16; n++) if (sh.q[scan[n + subPos]]) { firstNZ = n; break; }
+        for (n = firstNZ; n <= lastNZ; n++) absSum += sh.q[scan[n + subPos]];
+        if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
+        if (lastNZ - firstNZ >= 4) {
+          const unsigned signbit = sh.q[scan[subPos + firstNZ]] > 0 ? 0 : 1;
+          if (signbit != (unsigned)(absSum & 1)) {
+            int minCostInc = 0x7FFFFFFF, minPos = -1, finalChange = 0, curCost = 0x7FFFFFFF, curChange = 0;
+            for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
+              const int blkPos = scan[n + subPos];
+              const int qv = sh.q[blkPos], du = sh.du[blkPos];
+              if (qv != 0) {
+                if (du > 0) { curCost = -du; curChange = 1; }
+                else if (n == firstNZ && (qv == 1 || qv == -1)) curCost = 0x7FFFFFFF;
+                else { curCost = du; curChange = -1; }
+              } else if (n < firstNZ) {
+                const unsigned thisSign = sh.lv[blkPos] >= 0 ? 0 : 1;
+                if (thisSign != signbit) curCost = 0x7FFFFFFF;
+                else { curCost = -du; curChange = 1; }
+              } else { curCost = -du; curChange = 1; }
+              if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = blkPos; }
+            }
+            if (sh.q[minPos] == 32767 || sh.q[minPos] == -32768) finalChange = -1;
+            if (sh.lv[minPos] >= 0) sh.q[minPos] += finalChange; else sh.q[minPos] -= finalChange;
+          }
+        }
+        if (lastCG == 1) lastCG = 0;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < NN; i += 256) {
+      const int lv = sh.q[i];
+      if (levels) levels[level_off[blockIdx.x] + i] = lv;
+      sh.lv[i] = clip16((lv * scale + dadd) >> dshift);              // dequantised coefficient
+    }
   }
   __syncthreads();
   if (jb.transform_skip) {                                           // xITransformSkip :1442-1460
@@ -111,7 +152,7 @@ __global__ __launch_bounds__(256) void k_tu_roundtrip(const hop_tu_job* __restri
 
 int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off) {
   const int pr = hop_prof_begin(c, HOP_K_TQ, (uint64_t)n);
-  hipLaunchKernelGGL(k_tu_roundtrip, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), c->rec[0], c->rec[1], c->rec[2], d_res, d_levels, d_level_off);
+  hipLaunchKernelGGL(k_tu_roundtrip, dim3(n), dim3(256), 0, c->stream, d_jobs, hop_make_pics(c), c->rdoq_scans, c->rec[0], c->rec[1], c->rec[2], d_res, d_levels, d_level_off);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "tu_roundtrip launch: %s", hipGetErrorString(e));

@@ -44,7 +44,8 @@ class DistJob(ctypes.Structure):
 
 class TuJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("comp", ctypes.c_int32), ("log2_size", ctypes.c_int32),
-                ("use_dst", ctypes.c_int32), ("transform_skip", ctypes.c_int32), ("qp_scaled", ctypes.c_int32), ("is_i_slice", ctypes.c_int32)]
+                ("use_dst", ctypes.c_int32), ("transform_skip", ctypes.c_int32), ("qp_scaled", ctypes.c_int32), ("is_i_slice", ctypes.c_int32),
+                ("sign_hide", ctypes.c_int32), ("scan_idx", ctypes.c_int32)]
 
 
 class TuResult(ctypes.Structure):
@@ -83,7 +84,7 @@ INTRA_SEARCH_RESULT_DTYPE = np.dtype([("best_dir", "<i4", (4,)), ("n_cand", "<i4
 TU_RD_RESULT_DTYPE = np.dtype([("abs_sum", "<u4"), ("cbf", "<u4"), ("dist", "<u4"), ("zero_dist", "<u4"), ("nonzero_dist", "<u4"), ("bits", "<u4"),
                                ("null_bits", "<u4"), ("pad", "<u4"), ("cost", "<f8")])
 TU_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("comp", "<i4"), ("log2_size", "<i4"), ("use_dst", "<i4"), ("transform_skip", "<i4"),
-                         ("qp_scaled", "<i4"), ("is_i_slice", "<i4")])
+                         ("qp_scaled", "<i4"), ("is_i_slice", "<i4"), ("sign_hide", "<i4"), ("scan_idx", "<i4")])
 INTRA_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("size", "<i4"), ("strong", "<i4"), ("flags", "u1", (68,))])
 assert TU_JOB_DTYPE.itemsize == ctypes.sizeof(TuJob) and INTRA_JOB_DTYPE.itemsize == ctypes.sizeof(IntraJob)
 PU_JOB_DTYPE = np.dtype([("pu_x", "<i4"), ("pu_y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("rng_left", "<i4"), ("rng_right", "<i4"),

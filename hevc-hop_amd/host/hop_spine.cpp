@@ -1302,7 +1302,7 @@ class FiberPool : public Backend {
       for (int k = 0; k < T_; k++) { pending_.insert(pending_.end(), local_[k].begin(), local_[k].end()); local_[k].clear(); }
       if (left_.load() == 0) finished_ = true;
       else if (failed_) { for (Req* r : pending_) (void)r; pending_.clear(); }
-      else if (!pending_.empty()) { serve(); idle_rounds_ = 0; }
+      else if (!pending_.empty() || !inflight_.empty()) { serve(); idle_rounds_ = 0; }
       else if (++idle_rounds_ > 100000) failed_ = true;                 // rows waiting for a step nobody can finish
       arrived_ = 0; gen_++;
       bcv_.notify_all();
@@ -1315,15 +1315,36 @@ class FiberPool : public Backend {
     uint64_t tmin = ~0ull; for (Req* r : pending_) if ((r->tag >> tag_shift) < tmin) tmin = r->tag >> tag_shift;
     std::vector<Req*> v, rest;
     for (Req* r : pending_) ((r->tag >> tag_shift) == tmin ? v : rest).push_back(r);
+    std::vector<Req*> early;                                            // intra evaluations issued ahead (below)
     if (tag_shift) {
       // candidates side by side: their searches and predictions (short chains) first, the candidate evaluations (long chains) once nothing else of the node is
-      // waiting -- then the evaluations of all candidates of the node, of every CTU in flight, are ONE chain per class instead of one per candidate
+      // waiting -- then the evaluations of all candidates of the node, of every CTU in flight, are ONE chain per class instead of one per candidate.  The intra
+      // evaluations need nothing from the searches: they are handed over at once (a backend with streams of its own runs them beside the short rounds) and their
+      // answers are collected with the round that ends the node's evaluations.
       bool light = false; for (Req* r : v) light |= (r->kind != RQ_INTER && r->kind != RQ_INTRA);
-      if (light) { std::vector<Req*> keep; for (Req* r : v) (r->kind != RQ_INTER && r->kind != RQ_INTRA ? keep : rest).push_back(r); v.swap(keep); }
+      if (light) {
+        std::vector<Req*> keep;
+        for (Req* r : v) {
+          if (r->kind == RQ_INTER) rest.push_back(r);
+          else if (r->kind == RQ_INTRA) { if (inner_->can_defer()) early.push_back(r); else rest.push_back(r); }
+          else keep.push_back(r);
+        }
+        v.swap(keep);
+      }
     }
     pending_.swap(rest);
-    rounds++; requests += v.size();
+    rounds++; requests += v.size() + early.size();
     try {
+      if (!early.empty()) {                                               // one group per class, issued and left in flight
+        std::vector<char> used(early.size(), 0);
+        for (size_t i = 0; i < early.size(); i++) {
+          if (used[i]) continue;
+          std::vector<Req*> g;
+          for (size_t k = i; k < early.size(); k++) if (!used[k] && early[k]->i0 == early[i]->i0 && early[k]->i1 == early[i]->i1) { used[k] = 1; g.push_back(early[k]); }
+          run_group(inner_, g);
+        }
+        inflight_.insert(inflight_.end(), early.begin(), early.end());
+      }
       std::vector<char> used(v.size(), 0);
       for (size_t i = 0; i < v.size(); i++) {
         if (used[i]) continue;
@@ -1335,10 +1356,18 @@ class FiberPool : public Backend {
         }
         run_group(inner_, g);
       }
-      inner_->end_round();
+      // a round without evaluations leaves what was issued ahead in flight; one with evaluations (or one that has nothing else to wait for) collects everything
+      bool heavy = v.empty(); for (Req* r : v) heavy |= (r->kind == RQ_INTER || r->kind == RQ_INTRA);
+      for (Req* r : inflight_) heavy |= (r->tag >> tag_shift) < tmin;     // nothing else of that node is waiting any more
+      if (heavy || inflight_.empty()) {
+        inner_->end_round();
+        for (Req* r : inflight_) r->done = true;
+        inflight_.clear();
+      }
       for (size_t i = 0; i < v.size(); i++) v[i]->done = true;
     } catch (...) { failed_ = true; }
   }
+  std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
   std::vector<ucontext_t> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
   std::mutex bm_; std::condition_variable bcv_; int arrived_; uint64_t gen_; std::atomic<int> left_; int idle_rounds_;

@@ -111,6 +111,8 @@ class BatchInner : public Backend {
   virtual void commit_n(int n, const int32_t* rect4) { for (int i = 0; i < n; i++) commit(0, rect4[4 * i], rect4[4 * i + 1], rect4[4 * i + 2]); }
   // the groups of one round have all been handed over: a backend that issues them on separate streams waits for them here and fills in the answers
   virtual void end_round() {}
+  // true: inter_n / intra_n only ISSUE their batch (on a stream of the backend's own) and end_round() completes it, so a batch may be handed over rounds ahead
+  virtual bool can_defer() { return false; }
   // m sequences of pred_cost requests (different CTUs, so their rectangles are disjoint): step k of all sequences may run together, the steps in order.
   // jobs / kinds / out: concatenated sequence after sequence, len[s] jobs each
   virtual void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {

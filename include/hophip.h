@@ -195,7 +195,7 @@ int hop_distortion_device(hop_ctx* ctx, int n, const hop_dist_job* d_jobs, uint3
  * transform skip, flat quantisation, dequantisation, inverse transform, reconstruction clip into the context's
  * reconstruction picture, SSE against the original.
  * replaces: TComTrQuant::transformNxN / invtransformNxN (TLibCommon/TComTrQuant.cpp:1204-1283) with xTrMxN/xITrMxN
- * (:786-863), the non-RDOQ branch of xQuant (:1071-1107, flat scaling list, sign-bit hiding off) and xDeQuant
+ * (:786-863), the non-RDOQ branch of xQuant (:1071-1116, flat scaling list, with signBitHidingHDQ :868-990 if sign_hide) and xDeQuant
  * (:1124-1183), in the order TEncSearch::xIntraCodingLumaBlk uses them (TLibEncoder/TEncSearch.cpp:1082-1160).
  * qp_scaled is what setQPforQuant hands to setQpParam (:192-214); is_i_slice selects the rounding offset 171/85
  * (an ISS slice is NOT an I slice, :1079). */
@@ -207,6 +207,8 @@ typedef struct {
   int32_t transform_skip;
   int32_t qp_scaled;
   int32_t is_i_slice;
+  int32_t sign_hide;       /* the PPS's sign_data_hiding flag: TComTrQuant::signBitHidingHDQ (TLibCommon/TComTrQuant.cpp:868-990, called :1110-1116) after the quantiser */
+  int32_t scan_idx;        /* 0 diagonal, 1 horizontal, 2 vertical: the scan the hiding walks (getCoefScanIdx) */
 } hop_tu_job;
 typedef struct { uint32_t abs_sum; uint32_t sse; } hop_tu_result;
 /* levels_out (may be NULL): quantised levels of job i at levels_out[sum_{k<i} size_k^2 ...] (TCoeff = int32) */

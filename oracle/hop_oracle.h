@@ -56,6 +56,9 @@ void hop_o_inv_transform(int bitDepth, const int16_t* coeff, int16_t* block, int
 void hop_o_transform_skip(int bitDepth, const int16_t* resi, int32_t* coef, int N);
 void hop_o_inv_transform_skip(int bitDepth, const int32_t* coef, int16_t* resi, int N);
 uint32_t hop_o_quant_flat(int bitDepth, int qpScaled, int isISlice, const int32_t* coef, int32_t* level, int N);
+uint32_t hop_o_tu_roundtrip_sbh(int bitDepth, int qpScaled, int isISlice, int useDst, int transformSkip, int N, int signHide, int scanIdx,
+                                const int16_t* org, const int16_t* pred, int32_t* level, int16_t* recon, uint32_t* sse);
+uint32_t hop_o_quant_flat_sbh(int bitDepth, int qpScaled, int isISlice, const int32_t* coef, int32_t* level, int N, int scan_idx);   /* + signBitHidingHDQ */
 void hop_o_dequant_flat(int bitDepth, int qpScaled, const int32_t* level, int32_t* coef, int N);
 /* ---- a11: rate-distortion optimised quantisation (hop_oracle_rdoq.c) ---- */
 /* the reference's estBitsSbacStruct (TLibCommon/TComTrQuant.h:59-70), same member order and sizes */

@@ -102,6 +102,69 @@ uint32_t hop_o_quant_flat(int bitDepth, int qpScaled, int isISlice, const int32_
   return acSum;
 }
 
+/* TComTrQuant::signBitHidingHDQ (TComTrQuant.cpp:868-990): per coefficient group of the scan whose first and last non-zero level lie at least SBH_THRESHOLD (4)
+ * positions apart, the parity of the group's level sum has to equal the sign of its first non-zero level; where it does not, the level whose change costs least in
+ * distortion (deltaU, the quantiser's remainder in 1/256 steps) moves by one.  No rate is considered. */
+const uint32_t* hop_o_scan(int scan_idx, int log2_size);
+static void sign_bit_hiding_hdq(int32_t* q, const int32_t* coef, const uint32_t* scan, const int* deltaU, int N)
+{
+  int lastCG = -1;
+  for (int subSet = (N * N - 1) >> 4; subSet >= 0; subSet--) {
+    const int subPos = subSet << 4;
+    int firstNZ = 16, lastNZ = -1, absSum = 0, n;
+    for (n = 15; n >= 0; --n) if (q[scan[n + subPos]]) { lastNZ = n; break; }
+    for (n = 0; n < 16; n++) if (q[scan[n + subPos]]) { firstNZ = n; break; }
+    for (n = firstNZ; n <= lastNZ; n++) absSum += q[scan[n + subPos]];
+    if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
+    if (lastNZ - firstNZ >= 4) {
+      const unsigned signbit = q[scan[subPos + firstNZ]] > 0 ? 0 : 1;
+      if (signbit != (unsigned)(absSum & 1)) {
+        int minCostInc = 0x7FFFFFFF, minPos = -1, finalChange = 0, curCost = 0x7FFFFFFF, curChange = 0;
+        for (n = (lastCG == 1 ? lastNZ : 15); n >= 0; --n) {
+          const uint32_t blkPos = scan[n + subPos];
+          if (q[blkPos] != 0) {
+            if (deltaU[blkPos] > 0) { curCost = -deltaU[blkPos]; curChange = 1; }
+            else if (n == firstNZ && abs(q[blkPos]) == 1) curCost = 0x7FFFFFFF;
+            else { curCost = deltaU[blkPos]; curChange = -1; }
+          } else if (n < firstNZ) {
+            const unsigned thisSign = coef[blkPos] >= 0 ? 0 : 1;
+            if (thisSign != signbit) curCost = 0x7FFFFFFF;
+            else { curCost = -deltaU[blkPos]; curChange = 1; }
+          } else { curCost = -deltaU[blkPos]; curChange = 1; }
+          if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = (int)blkPos; }
+        }
+        if (q[minPos] == 32767 || q[minPos] == -32768) finalChange = -1;
+        if (coef[minPos] >= 0) q[minPos] += finalChange; else q[minPos] -= finalChange;
+      }
+    }
+    if (lastCG == 1) lastCG = 0;
+  }
+}
+
+/* xQuant, the non-RDOQ branch with sign-bit hiding (TComTrQuant.cpp:1071-1116): the flat quantiser above, the remainders deltaU (:1100), and signBitHidingHDQ along
+ * the TU's scan when the level sum is at least 2.  Returns uiAcSum (the sum before the hiding, as the reference reports it). */
+uint32_t hop_o_quant_flat_sbh(int bitDepth, int qpScaled, int isISlice, const int32_t* coef, int32_t* level, int N, int scan_idx)
+{
+  int log2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+  int per = qpScaled / 6, rem = qpScaled % 6;
+  int transformShift = 15 - bitDepth - log2N;
+  int qBits = 14 + per + transformShift, qBits8 = qBits - 8;
+  int add = (isISlice ? 171 : 85) << (qBits - 9);
+  uint32_t acSum = 0;
+  int deltaU[32 * 32];
+  for (int n = 0; n < N * N; n++) {
+    int c = coef[n], sign = c < 0 ? -1 : 1;
+    int64_t t = (int64_t)abs(c) * kQuantScales[rem];
+    int lv = (int)((t + add) >> qBits);
+    deltaU[n] = (int)((t - ((int64_t)lv << qBits)) >> qBits8);   /* the reference shifts an Int: lv << qBits stays below 2^31 for 16-bit levels and qBits <= 29 only in its own use; kept 64-bit exact here, equal wherever the reference's does not overflow */
+    acSum += (uint32_t)lv;
+    lv *= sign;
+    level[n] = clip16(lv);
+  }
+  if (acSum >= 2) sign_bit_hiding_hdq(level, coef, hop_o_scan(scan_idx, log2N), deltaU, N);
+  return acSum;
+}
+
 /* xDeQuant, flat scaling list branch, TComTrQuant.cpp:1171-1182 */
 void hop_o_dequant_flat(int bitDepth, int qpScaled, const int32_t* level, int32_t* coef, int N)
 {
@@ -135,15 +198,21 @@ void hop_o_inv_transform_skip(int bitDepth, const int32_t* coef, int16_t* resi, 
  * residual = org - pred (TEncSearch.cpp:1082-1096 / :6688), transformNxN (xT + flat xQuant, TComTrQuant.cpp:1204-1258),
  * invtransformNxN (xDeQuant + xIT, :1260-1283), recon = Clip(pred + resi) (TEncSearch.cpp:1128-1151),
  * SSE(org, recon) (:1160).  All blocks contiguous NxN.  Returns uiAbsSum; *sse receives the distortion. */
+uint32_t hop_o_tu_roundtrip_sbh(int bitDepth, int qpScaled, int isISlice, int useDst, int transformSkip, int N, int signHide, int scanIdx,
+                                const int16_t* org, const int16_t* pred, int32_t* level, int16_t* recon, uint32_t* sse);
 uint32_t hop_o_tu_roundtrip(int bitDepth, int qpScaled, int isISlice, int useDst, int transformSkip, int N,
                             const int16_t* org, const int16_t* pred, int32_t* level, int16_t* recon, uint32_t* sse)
+{ return hop_o_tu_roundtrip_sbh(bitDepth, qpScaled, isISlice, useDst, transformSkip, N, 0, 0, org, pred, level, recon, sse); }
+/* the same with the PPS's sign_data_hiding flag (signHide) along scan scanIdx */
+uint32_t hop_o_tu_roundtrip_sbh(int bitDepth, int qpScaled, int isISlice, int useDst, int transformSkip, int N, int signHide, int scanIdx,
+                                const int16_t* org, const int16_t* pred, int32_t* level, int16_t* recon, uint32_t* sse)
 {
   int16_t resi[32 * 32] = {0}, c16[32 * 32], r2[32 * 32];
   int32_t c32[32 * 32], dq[32 * 32];
   for (int i = 0; i < N * N; i++) resi[i] = (int16_t)(org[i] - pred[i]);
   if (transformSkip) hop_o_transform_skip(bitDepth, resi, c32, N);
   else { hop_o_fwd_transform(bitDepth, resi, c16, N, useDst); for (int i = 0; i < N * N; i++) c32[i] = c16[i]; }
-  uint32_t absSum = hop_o_quant_flat(bitDepth, qpScaled, isISlice, c32, level, N);
+  uint32_t absSum = signHide ? hop_o_quant_flat_sbh(bitDepth, qpScaled, isISlice, c32, level, N, scanIdx) : hop_o_quant_flat(bitDepth, qpScaled, isISlice, c32, level, N);
   hop_o_dequant_flat(bitDepth, qpScaled, level, dq, N);
   if (transformSkip) hop_o_inv_transform_skip(bitDepth, dq, r2, N);
   else { for (int i = 0; i < N * N; i++) c16[i] = (int16_t)dq[i]; hop_o_inv_transform(bitDepth, c16, r2, N, useDst); }

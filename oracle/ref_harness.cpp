@@ -381,7 +381,14 @@ int ref_rdoq(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, in
 // row a10: TComTrQuant::xQuant, the non-RDOQ branch (TComTrQuant.cpp:1022-1119) -- the reference's own function with RDOQ switched off.  The branch takes its shift
 // from the slice's QP base (ADAPTIVE_QP_SELECTION, :1032-1063) and its scale from m_cQP: both are set from the same qpScaled here (a CU at the slice QP).
 // ttype: 0 TEXT_LUMA, 2 TEXT_CHROMA_U, 3 TEXT_CHROMA_V.  Sign-bit hiding off.  Returns uiAcSum.
+static unsigned ref_quant_flat_impl(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, int isISlice, int qpScaled, int bitDepthY, int bitDepthC, int signHide, int lumaDir);
 unsigned ref_quant_flat(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, int isISlice, int qpScaled, int bitDepthY, int bitDepthC)
+{ return ref_quant_flat_impl(src, dst, N, ttype, isIntra, isISlice, qpScaled, bitDepthY, bitDepthC, 0, 0); }
+// the same with the PPS's sign_data_hiding flag on: xQuant then runs signBitHidingHDQ (TComTrQuant.cpp:868-990, called :1110-1116) along the TU's scan, which
+// getCoefScanIdx derives from the intra direction (lumaDir; 4x4 / 8x8 luma: 6..14 -> vertical scan, 22..30 -> horizontal, TComDataCU.cpp:4001-4056)
+unsigned ref_quant_flat_sbh(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, int isISlice, int qpScaled, int bitDepthY, int bitDepthC, int lumaDir)
+{ return ref_quant_flat_impl(src, dst, N, ttype, isIntra, isISlice, qpScaled, bitDepthY, bitDepthC, 1, lumaDir); }
+static unsigned ref_quant_flat_impl(const int32_t* src, int32_t* dst, int N, int ttype, int isIntra, int isISlice, int qpScaled, int bitDepthY, int bitDepthC, int signHide, int lumaDir)
 {
   static Char predMode[1]; static UChar trIdxA[1], lumaDirA[1], chromaDirA[1], depthA[1], tsA[3][1];
   static TComSlice* slice = NULL; static TComPPS* pps = NULL; static TComSPS* sps = NULL;
@@ -392,7 +399,7 @@ unsigned ref_quant_flat(const int32_t* src, int32_t* dst, int N, int ttype, int 
   t.m_cQP.setQpParam(qpScaled);
   t.setUseScalingList(false);
   t.setFlatScalingList();
-  pps->setSignHideFlag(0); pps->setChromaCbQpOffset(0); pps->setChromaCrQpOffset(0);
+  pps->setSignHideFlag(signHide); pps->setChromaCbQpOffset(0); pps->setChromaCrQpOffset(0);
   sps->setQpBDOffsetY(0); sps->setQpBDOffsetC(0);
   slice->setSliceType(isISlice ? I_SLICE : P_SLICE);
   // the slice QP base that maps to qpScaled: luma directly; chroma through g_aucChromaScale (identity below 30, so the tests keep chroma QPs there or use the inverse)
@@ -402,7 +409,7 @@ unsigned ref_quant_flat(const int32_t* src, int32_t* dst, int N, int ttype, int 
   TComDataCU& cu = g->cu;
   Char* sPred = cu.m_pePredMode; UChar* sTr = cu.m_puhTrIdx; UChar* sL = cu.m_puhLumaIntraDir; UChar* sC = cu.m_puhChromaIntraDir; UChar* sD = cu.m_puhDepth; TComSlice* sS = cu.m_pcSlice;
   UChar* sT[3] = { cu.m_puhTransformSkip[0], cu.m_puhTransformSkip[1], cu.m_puhTransformSkip[2] };
-  predMode[0] = isIntra ? MODE_INTRA : MODE_INTER; trIdxA[0] = 0; lumaDirA[0] = 0; chromaDirA[0] = 0; depthA[0] = 0; tsA[0][0] = tsA[1][0] = tsA[2][0] = 0;
+  predMode[0] = isIntra ? MODE_INTRA : MODE_INTER; trIdxA[0] = 0; lumaDirA[0] = (UChar)lumaDir; chromaDirA[0] = 0; depthA[0] = 0; tsA[0][0] = tsA[1][0] = tsA[2][0] = 0;
   cu.m_pePredMode = predMode; cu.m_puhTrIdx = trIdxA; cu.m_puhLumaIntraDir = lumaDirA; cu.m_puhChromaIntraDir = chromaDirA; cu.m_puhDepth = depthA; cu.m_pcSlice = slice;
   for (int k = 0; k < 3; k++) cu.m_puhTransformSkip[k] = tsA[k];
   std::vector<Int> in(src, src + N * N), arl(N * N, 0);

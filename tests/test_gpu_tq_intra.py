@@ -93,6 +93,44 @@ def test_tu_roundtrip_vs_oracle(hp, bd):
     ctx.close()
 
 
+def test_tu_roundtrip_sign_bit_hiding_vs_oracle(hp):
+    """row a10 with the PPS's sign_data_hiding flag (TComTrQuant::signBitHidingHDQ after the flat quantiser): hop_tu_roundtrip with sign_hide against the restatement,
+    which tests/test_oracle_golden2.py pins to the reference's own xQuant on 600 golden blocks: every TU size, the three scans, DCT / DST / transform skip, both
+    rounding offsets; the hiding must have changed levels in a good part of the blocks"""
+    O = oracle()
+    O.hop_o_tu_roundtrip_sbh.restype = ctypes.c_uint32; O.hop_o_tu_roundtrip.restype = ctypes.c_uint32
+    W, H, bd = 128, 128, 8
+    Y, Cb, Cr = lenslet(W, H, 15, 44)
+    rng = np.random.default_rng(77)
+    P = [np.clip(a + rng.integers(-40, 41, a.shape), 0, 255).astype(np.int16) for a in (Y, Cb, Cr)]
+    ctx = hp.Context(W, H)
+    ctx.upload_orig(Y, Cb, Cr)
+    for c in range(3):
+        ctx.plane_upload("pred", c, P[c])
+    changed = 0; total = 0
+    for log2 in (2, 3, 4, 5):
+        N = 1 << log2
+        for comp in (0, 1, 2):
+            for k in range(8):
+                lim = (W if comp == 0 else W // 2) - N
+                xs, ys = int(rng.integers(0, lim // 4 + 1)) * 4, int(rng.integers(0, lim // 4 + 1)) * 4
+                x, y = (xs, ys) if comp == 0 else (2 * xs, 2 * ys)
+                qp = int(rng.choice([10, 17, 22, 27, 32]))
+                scan = int(rng.integers(0, 3)) if log2 <= 3 else 0
+                j = hp.TuJob(x, y, comp, log2, int(log2 == 2 and comp == 0 and k % 2 == 0), int(log2 == 2 and k == 3), qp, k % 2, 1, scan)
+                res, lv = ctx.tu_roundtrip([j])
+                o_, p_ = (Y, Cb, Cr)[comp], P[comp]
+                org = np.ascontiguousarray(o_[ys:ys + N, xs:xs + N]); prd = np.ascontiguousarray(p_[ys:ys + N, xs:xs + N])
+                lvo = np.zeros(N * N, np.int32); lv0 = np.zeros(N * N, np.int32); rec = np.zeros((N, N), np.int16); sse = ctypes.c_uint32(); s0 = ctypes.c_uint32()
+                s = O.hop_o_tu_roundtrip_sbh(bd, qp, k % 2, j.use_dst, j.transform_skip, N, 1, scan, p16(org), p16(prd), lvo.ctypes.data_as(VP), p16(rec), ctypes.byref(sse))
+                assert res[0] == (s, sse.value) and np.array_equal(lv, lvo), (comp, N, scan, res, s, sse.value)
+                assert np.array_equal(ctx.recon_download(comp)[ys:ys + N, xs:xs + N], rec)
+                O.hop_o_tu_roundtrip(bd, qp, k % 2, j.use_dst, j.transform_skip, N, p16(org), p16(prd), lv0.ctypes.data_as(VP), p16(np.zeros((N, N), np.int16)), ctypes.byref(s0))
+                changed += int(not np.array_equal(lv0, lvo)); total += 1
+    assert changed > total // 4, (changed, total)
+    ctx.close()
+
+
 def test_tu_golden_transform_identity(hp):
     """reference-generated forward-transform vectors through the kernel: with prediction = 0 and a QP whose flat
     quantiser is the identity on the tested range the levels expose the forward transform output exactly.

@@ -77,3 +77,21 @@ def test_flat_quantiser_golden():
         src = np.ascontiguousarray(g["src"][off:off + N * N], np.int32); d = np.zeros(N * N, np.int32)
         a = O.hop_o_quant_flat(int(bd), int(qp), int(isI), src.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p), N)
         assert a == int(asum) and np.array_equal(d, g["out"][off:off + N * N]), (N, bd, qp, isI)
+
+
+def test_flat_quantiser_sign_bit_hiding_golden():
+    """row a10 with the PPS's sign_data_hiding flag: hop_o_quant_flat_sbh (flat quantiser, remainders, TComTrQuant::signBitHidingHDQ along the TU's scan) against 600 blocks
+    quantised by the reference's own xQuant with RDOQ off and sign hiding on (tests/golden/quant_flat_sbh.npz, oracle/make_golden20.py: every size, 8 / 10 bit, the three
+    scans); unreachable in the shipped configurations (they quantise with RDOQ, row a11, which has its own hiding) but part of the row"""
+    import ctypes
+    g = load("quant_flat_sbh.npz")
+    O = oracle(); O.hop_o_quant_flat_sbh.restype = ctypes.c_uint32; O.hop_o_quant_flat.restype = ctypes.c_uint32
+    changed = 0
+    for N, bd, qp, isI, asum, off, scan in g["par"]:
+        N, off = int(N), int(off)
+        src = np.ascontiguousarray(g["src"][off:off + N * N], np.int32); d = np.zeros(N * N, np.int32); d0 = np.zeros(N * N, np.int32)
+        a = O.hop_o_quant_flat_sbh(int(bd), int(qp), int(isI), src.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p), N, int(scan))
+        assert a == int(asum) and np.array_equal(d, g["out"][off:off + N * N]), (N, bd, qp, isI, scan)
+        O.hop_o_quant_flat(int(bd), int(qp), int(isI), src.ctypes.data_as(ctypes.c_void_p), d0.ctypes.data_as(ctypes.c_void_p), N)
+        changed += int(not np.array_equal(d, d0))
+    assert changed > 300

@@ -27,6 +27,7 @@ int hop_scratch(hop_ctx* c, size_t bytes, void** out) {
     if (c->scratch) HIPCHK(c, hipFree(c->scratch));
     c->scratch = nullptr; c->scratch_bytes = 0;
     size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(c, hipSetDevice(c->device));                                  // (the calling thread's current device may be another context's)
     HIPCHK(c, hipMalloc(&c->scratch, want));
     c->scratch_bytes = want;
   }
@@ -39,6 +40,7 @@ static int hop_stage(hop_ctx* c, size_t bytes, void** out) {
     if (c->stage) HIPCHK(c, hipFree(c->stage));
     c->stage = nullptr; c->stage_bytes = 0;
     size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->stage, want));
     c->stage_bytes = want;
   }
@@ -139,6 +141,7 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
 int hop_ctx_set_slots(hop_ctx* c, int slots) {
   if (!c || c->is_view || slots < 0 || slots > 64) return hop_set_err(c, HOP_ERR_ARG, "hop_ctx_set_slots: bad argument");
   if (slots == c->slots) return HOP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t ny = (size_t)c->pic_w * c->pic_h * (slots + 1), nc = ny >> 2;
   int16_t** planes[9] = { &c->org_y, &c->org_cb, &c->org_cr, &c->pred[0], &c->pred[1], &c->pred[2], &c->rec[0], &c->rec[1], &c->rec[2] };
@@ -627,6 +630,7 @@ int hop_rqt_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop_rqt_j
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
     c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
     c->rqt_bytes = wb + wb / 8;
   }
@@ -728,6 +732,7 @@ int hop_rqt_finish_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const ho
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
     c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
     c->rqt_bytes = wb + wb / 8;
   }
@@ -859,6 +864,7 @@ int hop_intra_rqt_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const hop
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
     c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
     c->rqt_bytes = wb + wb / 8;
   }
@@ -947,6 +953,7 @@ int hop_intra_luma_search_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
     c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
     c->rqt_bytes = wb + wb / 8;
   }
@@ -1036,6 +1043,7 @@ int hop_intra_chroma_search_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
     c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
     c->rqt_bytes = wb + wb / 8;
   }
@@ -1254,6 +1262,7 @@ static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rqt_buf) HIPCHK(c, hipFree(c->rqt_buf));
     c->rqt_buf = nullptr; c->rqt_bytes = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(&c->rqt_buf, wb + wb / 8));
     c->rqt_bytes = wb + wb / 8;
   }

@@ -29,6 +29,9 @@ struct RqtWork {                                                      // per CU:
 // the time of ONE CU only when every CU has a wave of its own.  rqt_grid() picks the launch; the kernel tells the two apart by its grid.
 #define RQT_LANE_OR_BLOCK(n_) const bool spread_ = (n_) > 1 && gridDim.x == (unsigned)(n_); if (spread_ && threadIdx.x) return; \
                               const int lane = spread_ ? 0 : (int)threadIdx.x, i = spread_ ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x)
+// (a wave per CU needs one column of context states: CabacLds1, 204 bytes -- a compute unit then holds 32 such CUs instead of 12)
+#define RQT_LAUNCH(K, c_, n_, ...) do { if ((n_) > 1 && rqt_grid(c_, n_) == (n_)) hipLaunchKernelGGL((K<CabacLds1>), dim3(n_), dim3(64), 0, (c_)->stream, __VA_ARGS__); \
+                                        else hipLaunchKernelGGL((K<CabacLds>), dim3(rqt_grid(c_, n_)), dim3(64), 0, (c_)->stream, __VA_ARGS__); } while (0)
 static inline int rqt_grid(const hop_ctx* c, int n) { return (n > 1 && n <= c->fused_leaf_max) ? n : (n + 63) / 64; }
 __device__ static inline int rqt_zx(int p) { int x = 0; for (int b = 0; b < 4; b++) x |= ((p >> (2 * b)) & 1) << b; return 4 * x; }
 __device__ static inline int rqt_zy(int p) { int y = 0; for (int b = 0; b < 4; b++) y |= ((p >> (2 * b + 1)) & 1) << b; return 4 * y; }
@@ -86,18 +89,20 @@ __global__ void k_rqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restric
 
 #define RQ_LOAD(src) do { const uint8_t* s_ = (src).state; for (int q_ = 0; q_ < 152; q_++) sh.st[q_][lane] = s_[q_]; } while (0)
 #define RQ_LEFT() ((unsigned)sh.st[150][lane] | ((unsigned)sh.st[151][lane] << 8))
-__device__ static inline void rqt_store(CabacLds& sh, int lane, unsigned long long frac_total, hop_cabac_ctx* dst) {
+template <class LDS>
+__device__ static inline void rqt_store(LDS& sh, int lane, unsigned long long frac_total, hop_cabac_ctx* dst) {
   for (int q = 0; q < 150; q++) dst->state[q] = sh.st[q][lane];
   const unsigned left = (unsigned)(frac_total & 32767ull);
   dst->state[150] = (uint8_t)(left & 0xFF); dst->state[151] = (uint8_t)(left >> 8);
 }
 __device__ static inline int rqt_cbf_ctx(int comp, int d) { return CX_QT_CBF + (comp ? 4 + d : (d == 0 ? 1 : 0)); }     // getCtxQtCbf, TComDataCU.cpp:1848-1859
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
                                                    const hop_cabac_ctx* __restrict__ root, hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
                                                    RqtWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2,
                                                    int32_t* __restrict__ coef, size_t ts_base, const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;                                                // no barrier in this kernel
   const hop_rqt_job jb = jobs[i];
@@ -150,7 +155,8 @@ __global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const
 }
 
 // xEncodeResidualQT on the lane's coder: the subtree below (part, d0) as the arrays describe it; flags (subdiv_and_cbf) or one component's levels
-__device__ static unsigned long long rqt_encode_tree(CabacLds& sh, const int lane, const RqtClass& k, const int i, const hop_rqt_result* r, const int32_t* coef,
+template <class LDS>
+__device__ static unsigned long long rqt_encode_tree(LDS& sh, const int lane, const RqtClass& k, const int i, const hop_rqt_result* r, const int32_t* coef,
                                                      const int part0, const int d0, const int log2_0, const int subdiv_and_cbf, const int comp, const uint16_t* scans) {
   unsigned long long frac = 0;
   const int parts = 1 << (2 * (k.log2_cu - 2));
@@ -192,10 +198,11 @@ __device__ static unsigned long long rqt_encode_tree(CabacLds& sh, const int lan
   return frac;
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_rqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
                                                   const hop_cabac_ctx* __restrict__ root, const hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
                                                   RqtWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const hop_rqt_job jb = jobs[i];
@@ -289,7 +296,7 @@ static int rqt_run_class(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job
       const int hint = log2 <= 3 ? 1 : (log2 == 5 ? 2 : 0);          // 16x16 luma comes with 8x8 chroma
       int r = hop_launch_tu_rd(c, n * ncomp, tuj, root[d], off, n_coeff, coef, tr, hint); if (r) return r;
       if (nts) { r = hop_launch_tu_rd(c, n * nts, tuj2, root[d], off2, n_coeff, coef, tr2, 1); if (r) return r; }
-      hipLaunchKernelGGL(k_rqt_single, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, tr, tr2, coef, ts_base, c->rdoq_scans);
+      RQT_LAUNCH(k_rqt_single, c, n, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, tr, tr2, coef, ts_base, c->rdoq_scans);
     }
     if (nd.check_split) {
       const int q = (parts >> (2 * d)) >> 2;
@@ -297,7 +304,7 @@ static int rqt_run_class(hop_ctx* c, const RqtClass& k, int n, const hop_rqt_job
         const int r = go(c, k, n, d_jobs, d_res, cur, root, test, work, tuj, tuj2, off, off2, tr, tr2, coef, n_coeff, ts_base, parts, part + kk * q, d + 1, log2 - 1, zero_open && !nd.check_full);
         if (r) return r;
       }
-      hipLaunchKernelGGL(k_rqt_close, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, coef, c->rdoq_scans);
+      RQT_LAUNCH(k_rqt_close, c, n, k, nd, d_jobs, n, cur, root[d], test[d], d_res, work, coef, c->rdoq_scans);
     }
     return HOP_OK;
   } };
@@ -448,25 +455,28 @@ int hop_launch_rqt_finish(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min
 #define CEP(nbins) do { frac += 32768ull * (unsigned long long)(nbins); } while (0)
 
 __device__ static inline int cu_eg_bins(unsigned sym, int kk) { int nb = 0; while (sym >= (1u << kk)) { nb++; sym -= 1u << kk; kk++; } return nb + 1 + kk; }   // xWriteEpExGolomb
-__device__ static unsigned long long cu_vec(CabacLds& sh, const int lane, const int base, const int32_t* v, const int ncomp) {    // codeMvd / codeGT
+template <class LDS>
+__device__ static unsigned long long cu_vec(LDS& sh, const int lane, const int base, const int32_t* v, const int ncomp) {    // codeMvd / codeGT
   unsigned long long frac = 0;
   for (int i = 0; i < ncomp; i++) CBIN(base, v[i] != 0);
   for (int i = 0; i < ncomp; i++) if (v[i]) CBIN(base + 1, (v[i] < 0 ? -v[i] : v[i]) > 1);
   for (int i = 0; i < ncomp; i++) if (v[i]) { const int a = v[i] < 0 ? -v[i] : v[i]; if (a > 1) CEP(cu_eg_bins((unsigned)a - 2, 1)); CEP(1); }
   return frac;
 }
-__device__ static unsigned long long cu_merge_index(CabacLds& sh, const int lane, const int idx, const int num) {
+template <class LDS>
+__device__ static unsigned long long cu_merge_index(LDS& sh, const int lane, const int idx, const int num) {
   unsigned long long frac = 0;
   if (num <= 1) return 0;
   for (int ui = 0; ui < num - 1; ui++) { const int sym = ui == idx ? 0 : 1; if (ui == 0) CBIN(CU_MERGE_IDX, sym); else CEP(1); if (!sym) break; }
   return frac;
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ res,
                                                 const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
                                                 uint32_t* __restrict__ bits_out, uint32_t* __restrict__ skipped_out, hop_cabac_ctx* __restrict__ ctx_out,
                                                 hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
@@ -560,7 +570,7 @@ int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu
                        uint32_t* d_bits, uint32_t* d_skipped, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = inter_split; k.sign_hide = sign_hide; k.use_ts = use_ts;
   const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_cu_bits, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_skipped, d_ctx_out, d_cu_out, c->rdoq_scans);
+  RQT_LAUNCH(k_cu_bits, c, n, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_skipped, d_ctx_out, d_cu_out, c->rdoq_scans);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "cu_bits launch: %s", hipGetErrorString(e));
@@ -580,7 +590,8 @@ __device__ static inline int icu_scan(const hop_intra_cu_syntax& y, int parts, i
   const int dv = dir - 26, dh = dir - 10;
   return (dv < 0 ? -dv : dv) < 5 ? 1 : ((dh < 0 ? -dh : dh) < 5 ? 2 : 0);
 }
-__device__ static unsigned long long icu_dir(CabacLds& sh, const int lane, const int dir, const int32_t* preds, const int pred_num) {   // codeIntraDirLumaAng, one PU
+template <class LDS>
+__device__ static unsigned long long icu_dir(LDS& sh, const int lane, const int dir, const int32_t* preds, const int pred_num) {   // codeIntraDirLumaAng, one PU
   unsigned long long frac = 0;
   int idx = -1;
   for (int q = 0; q < pred_num; q++) if (dir == preds[q]) idx = q;
@@ -590,7 +601,8 @@ __device__ static unsigned long long icu_dir(CabacLds& sh, const int lane, const
 }
 
 // the counting itself, from the node (tr0, part0) downwards; levels either in the CU layout (cf) or in the layer buffers of the quadtree searches (layered, CU i)
-__device__ __noinline__ static unsigned long long icu_count(CabacLds& sh, const int lane, const RqtClass& k, const hop_intra_cu_syntax& y, const int tr0, const int part0, const int b_luma,
+template <class LDS>
+__device__ __noinline__ static unsigned long long icu_count(LDS& sh, const int lane, const RqtClass& k, const hop_intra_cu_syntax& y, const int tr0, const int part0, const int b_luma,
                                                const int b_chroma, const hop_rqt_result* r, const int32_t* cf, const int32_t* layered, const int i, const uint16_t* scans) {
   const int parts = 1 << (2 * (k.log2_cu - 2));
   const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
@@ -653,11 +665,12 @@ __device__ __noinline__ static unsigned long long icu_count(CabacLds& sh, const 
   return frac;
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_intra_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
                                                       const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
                                                       const hop_cabac_cu_ctx* __restrict__ cu_in, uint32_t* __restrict__ bits_out, hop_cabac_ctx* __restrict__ ctx_out,
                                                       hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
@@ -679,7 +692,7 @@ int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_
                              hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_intra_cu_bits, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_ctx_out, d_cu_out, c->rdoq_scans);
+  RQT_LAUNCH(k_intra_cu_bits, c, n, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_bits, d_ctx_out, d_cu_out, c->rdoq_scans);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra_cu_bits launch: %s", hipGetErrorString(e));
@@ -775,6 +788,7 @@ __global__ __launch_bounds__(256) void k_irqt_copy(int mode, RqtClass k, RqtNode
   }
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
                                                     const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur,
                                                     const hop_cabac_ctx* __restrict__ root, const hop_cabac_cu_ctx* __restrict__ curoot, hop_cabac_ctx* __restrict__ test,
@@ -782,7 +796,7 @@ __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, cons
                                                     const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base,
                                                     int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans,
                                                     const uint8_t* __restrict__ active) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n || (active && !active[i])) return;
   const hop_intra_cu_syntax y = syn[i];
@@ -826,12 +840,13 @@ __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, cons
   else { rqt_store(sh, lane, frac, cur + i); IRQ_CU_STORE(cucur[i]); w->sub_cost[nd.d] += cost; w->sub_dist[nd.d] += dist; }
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
                                                    hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, const hop_cabac_ctx* __restrict__ root,
                                                    const hop_cabac_cu_ctx* __restrict__ curoot, const hop_cabac_ctx* __restrict__ test, const hop_cabac_cu_ctx* __restrict__ cutest,
                                                    hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans,
                                                    const uint8_t* __restrict__ active) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n || (active && !active[i])) return;
   const hop_intra_cu_syntax y = syn[i];
@@ -927,13 +942,13 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
       }
       r = hop_launch_tu_rd(c, n, B.tuj, B.root[d].a, B.off, B.n_coeff, B.coef, B.tr, hint); if (r) return r;
       if (nd.check_split) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 0, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
-      hipLaunchKernelGGL(k_irqt_single, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, d_opt, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b,
+      RQT_LAUNCH(k_irqt_single, c, n, k, nd, d_jobs, d_syn, d_opt, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b,
                          d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base, c->rec[0], pitch, B.park, c->rdoq_scans, B.active);
     }
     if (nd.check_split) {
       const int q = ((1 << (2 * (k.log2_cu - 2))) >> (2 * d)) >> 2;
       for (int kk = 0; kk < 4; kk++) { const int r = go(c, k, n, check_first, d_jobs, d_syn, d_opt, d_res, B, rel + kk * q, d + 1, log2 - 1); if (r) return r; }
-      hipLaunchKernelGGL(k_irqt_close, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, d_jobs, d_syn, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b, d_res,
+      RQT_LAUNCH(k_irqt_close, c, n, k, nd, d_jobs, d_syn, n, B.cur.a, B.cur.b, B.root[d].a, B.root[d].b, B.test[d].a, B.test[d].b, d_res,
                          B.work, B.coef, c->rdoq_scans, B.active);
       if (nd.check_full) hipLaunchKernelGGL(k_irqt_copy, dim3(n), dim3(256), 0, c->stream, 2, k, nd, d_jobs, d_syn, n, B.work, c->rec[0], pitch, B.recl, B.park, B.active);
     }
@@ -1170,12 +1185,13 @@ __global__ __launch_bounds__(64) void k_ic_park(RqtClass k, RqtNode nd, const ho
   park[(size_t)i * 16 + e] = rec[(size_t)(((jobs[i].y + rqt_zy(nd.part)) >> 1) + (e >> 2)) * pitch + ((jobs[i].x + rqt_zx(nd.part)) >> 1) + (e & 3)];
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_ic_single(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
                                                   const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, const hop_cabac_ctx* __restrict__ root,
                                                   hop_rqt_result* __restrict__ res, IcWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr,
                                                   const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base, int16_t* __restrict__ rec, int pitch,
                                                   const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   hop_rqt_result* r = res + i;
@@ -1222,10 +1238,11 @@ __global__ void k_ic_fold(RqtClass k, RqtNode nd, int n, hop_rqt_result* __restr
   for (int p = 0; p < nparts; p++) { r->cbf[1][nd.part + p] |= (uint8_t)(su << nd.d); r->cbf[2][nd.part + p] |= (uint8_t)(sv << nd.d); }
 }
 
+template <class LDS>
 __global__ __launch_bounds__(64) void k_ic_bits(RqtClass k, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
                                                 const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_rqt_result* __restrict__ res,
                                                 IcWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
@@ -1317,7 +1334,7 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
         }
         const int lgc = log2 == 2 ? 2 : log2 - 1;
         r = hop_launch_tu_rd(c, n, B.tuj, B.cur, B.off, B.n_coeff, B.coef, B.tr, lgc <= 3 ? 1 : 0); if (r) return r;
-        hipLaunchKernelGGL(k_ic_single, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, nd, comp, d_jobs, B.syn, d_opt, n, B.cur, B.root, d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base,
+        RQT_LAUNCH(k_ic_single, c, n, k, nd, comp, d_jobs, B.syn, d_opt, n, B.cur, B.root, d_res, B.work, B.tr, B.tr2, B.coef, B.ts_base,
                            c->rec[comp], pitch, B.park, c->rdoq_scans);
       }
     }
@@ -1333,7 +1350,7 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
     hipLaunchKernelGGL(k_ic_mode, dim3(g256), dim3(256), 0, c->stream, m, d_jobs, n, d_ctx_in, B.cur, B.syn, B.work);
     const int rc = Rec::go(c, k, n, d_jobs, d_opt, d_res, B, 0, 0, k.log2_cu);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ic_bits, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, d_jobs, B.syn, n, d_ctx_in, d_cu_in, d_res, B.work, B.coef, c->rdoq_scans);
+    RQT_LAUNCH(k_ic_bits, c, n, k, d_jobs, B.syn, n, d_ctx_in, d_cu_in, d_res, B.work, B.coef, c->rdoq_scans);
     hipLaunchKernelGGL(k_ic_keep, dim3(n), dim3(64), 0, c->stream, k, d_jobs, n, d_res, B.work, B.coef, c->rec[1], c->rec[2], pitch, d_coef_out, d_reco_out);
   }
   hipLaunchKernelGGL(k_ic_commit, dim3(n), dim3(64), 0, c->stream, k, n, B.work, d_res, d_cres, d_syn_update);
@@ -1347,12 +1364,13 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
 // directions of all PUs and the chroma direction (encodePredInfo), then encodeCoeff = xEncodeTransform (TEncEntropy.cpp:219-420) on the CU's final levels with the
 // intra rules (the split of an NxN CU inferred, the luma cbf always coded, scans by direction).  One lane per CU; cost = calcRdCost(bits, distortion).
 // =====================================================================================================================
+template <class LDS>
 __global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
                                                        const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
                                                        const hop_cabac_cu_ctx* __restrict__ cu_in, const uint32_t* __restrict__ dist, uint32_t* __restrict__ bits_out,
                                                        double* __restrict__ cost_out, hop_cabac_ctx* __restrict__ ctx_out, hop_cabac_cu_ctx* __restrict__ cu_out,
                                                        const uint16_t* __restrict__ scans) {
-  __shared__ CabacLds sh;
+  __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
   const int ci = jobs[i].ctx_index;
@@ -1420,7 +1438,7 @@ int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2
                               uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out) {
   RqtClass k; k.log2_cu = log2_cu; k.log2_max_tu = log2_max_tu; k.log2_min_tu = log2_min_tu; k.inter_split = 0; k.sign_hide = sign_hide; k.use_ts = use_ts;
   const int pr = hop_prof_begin(c, HOP_K_CABAC, (uint64_t)n);
-  hipLaunchKernelGGL(k_intra_cu_total, dim3(rqt_grid(c, n)), dim3(64), 0, c->stream, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_dist, d_bits, d_cost, d_ctx_out, d_cu_out,
+  RQT_LAUNCH(k_intra_cu_total, c, n, k, n, d_jobs, d_syn, d_res, d_coef, d_ctx_in, d_cu_in, d_dist, d_bits, d_cost, d_ctx_out, d_cu_out,
                      c->rdoq_scans);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 on gloo: the N>1 paths of bench.py.  Default mode: every rank codes its own band of the frame as an independent picture (here through the RD spine
+"""CPU, world_size 2 on gloo: the N>1 paths of bench.py.  Default mode: every rank codes its own tiles of the frame as independent pictures (here through the RD spine
 over the CPU restatement, since the kernels need a GPU), the per-rank results are gathered and must equal the single-process runs, barrier + MAX reduction of the step time.
 --kernels mode: CTU rows dealt round-robin to the ranks, every rank enumerating the PU jobs of its rows through the C ABI's host logic."""
 import ctypes
@@ -92,16 +92,16 @@ def test_enumeration_interior_ctu():
     assert kr > 0 and int(j["w"].max()) <= 32          # the 64x64 CU crosses the border: split without a mode test
 
 
-def _band_worker(rank, world, port, W, Hf, rows, q):
+def _tile_worker(rank, world, port, FW, FH, tw, th, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
     from hoputil import lenslet
     from test_spine_cpu import run_cpu_wpp, spine_cpu
-    Y, Cb, Cr = lenslet(W, Hf, 16, 11)
-    b, y0, hb = bench.band_of_rank(Hf, rows, rank)
-    cost, bits, dist_, parts, rec, text, rr = run_cpu_wpp(spine_cpu(), W, hb, Y[y0:y0 + hb], Cb[y0 // 2:(y0 + hb) // 2], Cr[y0 // 2:(y0 + hb) // 2], 5)
-    mine = torch.tensor(np.concatenate([[float(b)], cost]), dtype=torch.float64)
+    Y, Cb, Cr = lenslet(FW, FH, 16, 11)
+    (x, y), = bench.tiles_of_rank(FW, FH, tw, th, 1, rank)           # this rank's picture: a tile of the frame, as bench.py's default mode deals them out
+    cost = run_cpu_wpp(spine_cpu(), tw, th, Y[y:y + th, x:x + tw], Cb[y // 2:(y + th) // 2, x // 2:(x + tw) // 2], Cr[y // 2:(y + th) // 2, x // 2:(x + tw) // 2], 5)[0]
+    mine = torch.tensor(np.concatenate([[float(x), float(y)], cost]), dtype=torch.float64)
     got = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)                                   # the merge of the per-rank results (bench.py itself only reduces the time)
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
@@ -113,27 +113,26 @@ def _band_worker(rank, world, port, W, Hf, rows, q):
 
 
 def test_independent_pictures_world2():
-    """two ranks, two bands of one frame: each band coded as a picture by its rank; gathered costs == the single-process runs of the bands"""
-    W, Hf, rows = 128, 128, 1
+    """two ranks, each coding ITS tile of the frame as a picture (the default mode's sharding: no data-path collective); gathered costs == the single-process runs"""
+    FW, FH, tw, th = 256, 64, 128, 64
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, W, Hf, rows, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, FW, FH, tw, th, q)) for r in range(2)]
     for p in procs:
         p.start()
     got, tmax = q.get(timeout=600)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    import bench
     from hoputil import lenslet
     from test_spine_cpu import run_cpu_wpp, spine_cpu
-    Y, Cb, Cr = lenslet(W, Hf, 16, 11)
-    assert sorted(int(g[0]) for g in got) == [0, 1]
+    Y, Cb, Cr = lenslet(FW, FH, 16, 11)
+    assert sorted((int(g[0]), int(g[1])) for g in got) == [(0, 0), (128, 0)]
     for g in got:
-        b, y0, hb = bench.band_of_rank(Hf, rows, int(g[0]))
-        cost = run_cpu_wpp(spine_cpu(), W, hb, Y[y0:y0 + hb], Cb[y0 // 2:(y0 + hb) // 2], Cr[y0 // 2:(y0 + hb) // 2], 0)[0]
-        assert g[1:] == cost.tolist(), b
+        x, y = int(g[0]), int(g[1])
+        cost = run_cpu_wpp(spine_cpu(), tw, th, Y[y:y + th, x:x + tw], Cb[y // 2:(y + th) // 2, x // 2:(x + tw) // 2], Cr[y // 2:(y + th) // 2, x // 2:(x + tw) // 2], 0)[0]
+        assert g[2:] == cost.tolist(), (x, y)
     assert tmax == 2.0
 
 

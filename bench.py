@@ -459,10 +459,14 @@ def band_of_rank(frame_h, rows, rank):
 
 
 def tiles_of_rank(frame_w, frame_h, tile_w, tile_h, pictures, rank):
-    """The independent pictures of a rank: the frame is cut into tile_w x tile_h pictures (whole ones only, raster order); rank k codes pictures
-    k * pictures ... (k + 1) * pictures - 1 (mod the number of tiles).  Returns [(x0, y0), ...]."""
+    """The independent pictures of a rank: every frame of the sequence is cut into tile_w x tile_h pictures (whole ones only, raster order) and the pictures are numbered
+    through the frames; rank k codes pictures k * pictures ... (k + 1) * pictures - 1.  Returns [(frame, x0, y0), ...]."""
     tx, ty = max(1, frame_w // tile_w), max(1, frame_h // tile_h)
-    return [(((rank * pictures + i) % (tx * ty)) % tx * tile_w, ((rank * pictures + i) % (tx * ty)) // tx * tile_h) for i in range(pictures)]
+    out = []
+    for i in range(pictures):
+        t = rank * pictures + i
+        out.append((t // (tx * ty), (t % (tx * ty)) % tx * tile_w, (t % (tx * ty)) // tx * tile_h))
+    return out
 
 
 def encode_main(args):
@@ -489,10 +493,13 @@ def encode_main(args):
     hp = _hophip()
     fw, fh = args.width, min(args.height, FRAME_H)
     tw, th, P = min(args.tile_w, fw), min(args.rows * 64, fh // 8 * 8), args.pictures
-    Yf, Cbf, Crf = lenslet_torch(fw, fh, PITCH, 2, dev)
     tiles = tiles_of_rank(fw, fh, tw, th, P, rank)
-    pics = [(Yf[y:y + th, x:x + tw].cpu().numpy(), Cbf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy(), Crf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy()) for x, y in tiles]
-    del Yf, Cbf, Crf
+    pics = []
+    for f in sorted(set(t[0] for t in tiles)):                     # frame f of the synthetic sequence: the same lenslet geometry, another texture seed
+        Yf, Cbf, Crf = lenslet_torch(fw, fh, PITCH, 2 + f, dev)
+        pics += [(Yf[y:y + th, x:x + tw].cpu().numpy(), Cbf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy(), Crf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy())
+                 for ff, x, y in tiles if ff == f]
+        del Yf, Cbf, Crf
     ctx = hp.Context(tw, th, device=local, pictures=P, slots=args.slots)
     if P > 1:
         ctx.upload_orig(ctx.stack([p[0] for p in pics]), ctx.stack([p[1] for p in pics], True), ctx.stack([p[2] for p in pics], True))
@@ -558,7 +565,7 @@ def encode_main(args):
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16+f64", "data": "synthetic",
             "config": {"workload": "synthetic lenslet %dx%d (pitch %d), QP%d, cfg/3DHencoder_intra_main.cfg semantics (ISS slice, SS +-128 full search with FEN, half/quarter-pel, GT search, "
-                                   "merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, CABAC-counted bits), cut into independent %dx%d pictures (tiles): "
+                                   "merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, CABAC-counted bits), cut into independent %dx%d pictures (tiles, numbered through the frames of the sequence): "
                                    "%d of them per GPU (%d CTUs) coded side by side in one stacked context -- each exactly as a picture of its own (SS reference from the sentinel, every "
                                    "candidate of xCompressCU, rows as a lag-%d wavefront with WaveFrontSynchro contexts; tests/test_gpu_spine.py pins that to the reference encoder)"
                                    % (fw, fh, PITCH, QP, tw, th, P, n_ctu, args.lag),
@@ -571,7 +578,7 @@ def encode_main(args):
             "kernels": prof,
             "request_ms": {k: v for k, v in stats.items() if k != "rendezvous"},
             "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTUs in flight, all pictures together)",
-            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"])},
+            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0)},
             "cost_sum": float(cost.sum()),
         }
         if world == 1:
@@ -613,7 +620,7 @@ def main():
     ap.add_argument("--tile-w", type=int, default=1024, help="width of one picture (tile)")
     ap.add_argument("--slots", type=int, default=16, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
     ap.add_argument("--profile-pictures", type=int, default=16, help="pictures of the separate profiled pass behind the roofline object")
-    ap.add_argument("--pictures", type=int, default=128, help="independent pictures coded side by side per GPU (one stacked context)")
+    ap.add_argument("--pictures", type=int, default=256, help="independent pictures coded side by side per GPU (one stacked context)")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
     ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")
     ap.add_argument("--kernels", action="store_true", help="kernel-throughput mode of round 1: the search kernels over a frozen, fully reconstructed SS reference (not the encode metric)")

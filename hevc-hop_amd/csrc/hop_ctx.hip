@@ -124,6 +124,8 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   for (int k = 0; k < 3; k++) { c->ss_alloc[k] = parent->ss_alloc[k]; c->ss_buf[k] = parent->ss_buf[k]; c->ss00[k] = parent->ss00[k]; c->pred[k] = parent->pred[k]; c->rec[k] = parent->rec[k]; }
   c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots;
   hipError_t e = hipSetDevice(c->device);
+  // (stream priorities -- views low, the parent high, so that the spine's short rounds would not queue behind its evaluation chains -- were measured and cost 10 %:
+  // the evaluation chains are the critical path of a node, not the short rounds)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int k = 0; k < HOP_MAX_LANES - 1 && e == hipSuccess; k++) { e = hipStreamCreateWithFlags(&c->xstream[k], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming); }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <functional>
 #include <ucontext.h>
+#include <chrono>
 
 namespace hopspine {
 
@@ -1246,6 +1247,7 @@ class FiberPool : public Backend {
     if (failed_) throw 1;
   }
   uint64_t rounds, requests;
+  double serve_s = 0;                                                   // wall time inside serve(): packing, issuing, waiting for the device, unpacking
   int tag_shift = 0;
   std::atomic<int> steps_complete;
   std::mutex steps_m;                                                   // guards the callers' step counters
@@ -1310,6 +1312,8 @@ class FiberPool : public Backend {
     return !finished_;
   }
   void serve() {
+    struct Clock { double& acc; std::chrono::steady_clock::time_point t0; explicit Clock(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+                   ~Clock() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } clock(serve_s);
     // the requests with the smallest tag; with candidates side by side (tag_shift = 20) the tag is cut down to the quadtree node: the candidates of a node are at
     // different steps of their chains at any moment, and all of them are served -- one launch chain per kind and class present
     uint64_t tmin = ~0ull; for (Req* r : pending_) if ((r->tag >> tag_shift) < tmin) tmin = r->tag >> tag_shift;
@@ -1447,7 +1451,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     for (int p = 0; p < n_pic; p++) {
       Encoder& E = *encs[p];
       for (int r = 0; r < rows; r++) E.n_candidates += cand[(size_t)p * rows + r];
-      E.batch_rounds = pool.rounds; E.batch_requests = pool.requests;
+      E.batch_rounds = pool.rounds; E.batch_requests = pool.requests; E.batch_serve_s = pool.serve_s;
       if (E.trace) for (int a = 0; a < E.n_ctu(); a++) { fputs(E.ctu_trace[a].c_str(), E.trace); E.ctu_trace[a].clear(); }
     }
     if (pool.failed()) throw 1;

@@ -99,7 +99,7 @@ def _tile_worker(rank, world, port, FW, FH, tw, th, q):
     from hoputil import lenslet
     from test_spine_cpu import run_cpu_wpp, spine_cpu
     Y, Cb, Cr = lenslet(FW, FH, 16, 11)
-    (x, y), = bench.tiles_of_rank(FW, FH, tw, th, 1, rank)           # this rank's picture: a tile of the frame, as bench.py's default mode deals them out
+    (_, x, y), = bench.tiles_of_rank(FW, FH, tw, th, 1, rank)           # this rank's picture: a tile of the frame, as bench.py's default mode deals them out
     cost = run_cpu_wpp(spine_cpu(), tw, th, Y[y:y + th, x:x + tw], Cb[y // 2:(y + th) // 2, x // 2:(x + tw) // 2], Cr[y // 2:(y + th) // 2, x // 2:(x + tw) // 2], 5)[0]
     mine = torch.tensor(np.concatenate([[float(x), float(y)], cost]), dtype=torch.float64)
     got = [torch.zeros_like(mine) for _ in range(world)]
@@ -137,15 +137,16 @@ def test_independent_pictures_world2():
 
 
 def test_tiles_of_rank_partition_the_frame():
-    """the default mode's split: the frame cut into whole tiles, `pictures` per rank, consecutive ranks taking consecutive tiles (no tile twice until all are used)"""
+    """the default mode's split: every frame cut into whole tiles, numbered through the frames, `pictures` per rank, consecutive ranks taking consecutive pictures"""
     import bench
     fw, fh, tw, th, P = 7728, 5368, 1024, 256, 8
     seen = []
     for rank in range(8):
         t = bench.tiles_of_rank(fw, fh, tw, th, P, rank)
         assert len(t) == P
-        for x, y in t:
-            assert x % tw == 0 and y % th == 0 and x + tw <= fw and y + th <= fh
+        for f, x, y in t:
+            assert f == 0 and x % tw == 0 and y % th == 0 and x + tw <= fw and y + th <= fh
         seen += t
-    assert len(set(seen)) == 64                       # 7 x 20 = 140 tiles in the frame: 8 ranks x 8 pictures are all different
-    assert bench.tiles_of_rank(fw, fh, tw, th, 140, 0)[-1] == (6 * 1024, 19 * 256) and bench.tiles_of_rank(fw, fh, tw, th, 1, 140) == [(0, 0)]
+    assert len(set(seen)) == 64                       # 7 x 20 = 140 tiles in a frame: 8 ranks x 8 pictures are all different
+    big = bench.tiles_of_rank(fw, fh, tw, th, 256, 1)  # 256 pictures per rank: rank 1 holds pictures 256..511 = frame 1 from tile 116 on, frame 2, frame 3 up to tile 91
+    assert big[0] == (1, (116 % 7) * 1024, (116 // 7) * 256) and big[-1] == (3, (91 % 7) * 1024, (91 // 7) * 256) and len(set(big)) == 256

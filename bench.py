@@ -578,7 +578,7 @@ def encode_main(args):
             "kernels": prof,
             "request_ms": {k: v for k, v in stats.items() if k != "rendezvous"},
             "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTUs in flight, all pictures together)",
-            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0)},
+            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0), "run_ms": rv.get("run_ms", 0.0)},
             "cost_sum": float(cost.sum()),
         }
         if world == 1:

@@ -413,9 +413,9 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   }
   int rc = HOP_OK;
   try {
-    if (n_pic > 1) { hopspine::Encoder::encode_pictures_wavefront(encs.data(), n_pic, use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; }
+    if (n_pic > 1) { hopspine::Encoder::encode_pictures_wavefront(encs.data(), n_pic, use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; g_stat_ms[13] = enc.batch_run_s * 1e3; }
     else if (!lanes.empty()) enc.encode_frame_wavefront_direct(lanes.data(), (int)lanes.size(), p->wavefront_lag);
-    else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; }
+    else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; g_stat_ms[13] = enc.batch_run_s * 1e3; }
     else enc.encode_frame(p->first_ctus);
   } catch (const Bail& b) { rc = b.code; } catch (...) { rc = c->err[0] ? HOP_ERR_DEVICE : HOP_ERR_STATE; }
   delete lg;

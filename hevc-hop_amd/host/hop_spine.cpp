@@ -1447,11 +1447,13 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
         delete w;
       });
     }
+    const std::chrono::steady_clock::time_point run_t0 = std::chrono::steady_clock::now();
     pool.run();
+    const double run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count();
     for (int p = 0; p < n_pic; p++) {
       Encoder& E = *encs[p];
       for (int r = 0; r < rows; r++) E.n_candidates += cand[(size_t)p * rows + r];
-      E.batch_rounds = pool.rounds; E.batch_requests = pool.requests; E.batch_serve_s = pool.serve_s;
+      E.batch_rounds = pool.rounds; E.batch_requests = pool.requests; E.batch_serve_s = pool.serve_s; E.batch_run_s = run_s;
       if (E.trace) for (int a = 0; a < E.n_ctu(); a++) { fputs(E.ctu_trace[a].c_str(), E.trace); E.ctu_trace[a].clear(); }
     }
     if (pool.failed()) throw 1;

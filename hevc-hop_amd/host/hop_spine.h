@@ -185,6 +185,7 @@ class Encoder {
   std::vector<std::string> ctu_trace;                // the lines of each CTU while the picture is in flight
   std::vector<uint8_t>  committed;                   // per 8x8 block: its reconstruction is in the SS reference (what TComRdCost::isValidPattern's sentinel test sees)
   uint64_t batch_rounds, batch_requests;             // wavefront mode: rendezvous rounds and requests served
+  double batch_run_s = 0;                            // ... the wall time of the whole wavefront (rows' host work + serving)
   double batch_serve_s = 0;                          // ... and the wall time spent serving them (one thread; the rows' own host work runs between the rounds)
  private:
   friend class CtuWorker;

@@ -153,13 +153,20 @@ class CtuWorker {
   void tag_exit(int d, int abs_idx) { static const int sub[4] = { 85, 21, 5, 1 }; tag_seq_ = 2 * (uint64_t)(node_index(d, abs_idx) + sub[d] - 1) + 1; tag_slot_ = 3 - d; tag_step(0); }
   void tag_cand(int slot) { tag_slot_ = slot; tag_step(0); }
   void tag_step(int step) { be->set_tag(lane_, (tag_seq_ << 20) | ((uint64_t)tag_slot_ << 8) | (uint64_t)step); }
-  CtuWorker(Encoder& e, int lane, Backend* backend = NULL) : E(e), cfg(e.cfg_), be(backend ? backend : e.be_), lane_(lane) { for (int d = 0; d < 4; d++) { best_[d] = &store_[d][0]; temp_[d] = &store_[d][1]; } }
+  // kid: a worker that evaluates ONE candidate of its parent (candidate slots): it gets the CU storage of the depth it works at only
+  CtuWorker(Encoder& e, int lane, Backend* backend = NULL, bool kid = false) : E(e), cfg(e.cfg_), be(backend ? backend : e.be_), lane_(lane) {
+    for (int d = 0; d < 4; d++) { store_[d][0] = store_[d][1] = NULL; best_[d] = temp_[d] = NULL; if (!kid) ensure(d); }
+  }
+  ~CtuWorker() { for (int d = 0; d < 4; d++) { delete store_[d][0]; delete store_[d][1]; } for (size_t i = 0; i < kids_.size(); i++) delete kids_[i]; }
+  void ensure(int d) { if (!store_[d][0]) { store_[d][0] = new CuData; store_[d][1] = new CuData; best_[d] = store_[d][0]; temp_[d] = store_[d][1]; } }
   void compress_ctu(int addr, const Coder& entry, Coder& exit);
  private:
   Encoder& E; const EncConfig& cfg; Backend* be; int lane_;
   int slot_ = 0;                                                          // candidate slot this worker predicts and reconstructs in (0: the pictures themselves)
   int row_off() const { return slot_ * cfg.slot_pitch; }
-  CuData store_[4][2]; CuData* best_[4]; CuData* temp_[4];
+  CuData* store_[4][2]; CuData* best_[4]; CuData* temp_[4];
+  std::vector<CtuWorker*> kids_;                                          // the candidate workers of this worker, by slot; made once, used for every node
+  CtuWorker(const CtuWorker&); CtuWorker& operator=(const CtuWorker&);    // (not copyable)
   enum { CI_CURR = 0, CI_NEXT = 1, CI_TEMP = 2 };
   Coder sb_[4][3]; Coder goon_;
   struct SpecCand; std::vector<SpecCand> spec_intra_[4];                   // candidate slots: the intra candidates of the node, evaluated with the first batch
@@ -228,6 +235,13 @@ class CtuWorker {
   void trace_candidate(const CuData& c);
   uint64_t final_walk(int x, int y, int size, int d, Coder& k);
 };
+
+// a CU's data without the partitions it does not have (an 8x8 CU owns 4 of the 256)
+static inline void cu_copy(CuData& dst, const CuData& src) {
+  dst.ctu_addr = src.ctu_addr; dst.ctu_x = src.ctu_x; dst.ctu_y = src.ctu_y; dst.abs_idx = src.abs_idx; dst.depth = src.depth; dst.x = src.x; dst.y = src.y; dst.size = src.size;
+  dst.num_part = src.num_part; dst.cost = src.cost; dst.bits = src.bits; dst.dist = src.dist; dst.slot = src.slot;
+  memcpy(dst.p, src.p, sizeof(Part) * src.num_part); memcpy(dst.fbits, src.fbits, sizeof(uint64_t) * src.num_part);
+}
 
 void CtuWorker::init_cu(CuData& c, int abs_idx, int depth, int x, int y) {
   c.ctu_addr = ctu_addr_; c.ctu_x = ctu_x_; c.ctu_y = ctu_y_; c.abs_idx = abs_idx; c.depth = depth; c.x = x; c.y = y; c.size = CTU >> depth; c.num_part = 256 >> (2 * depth);
@@ -741,16 +755,19 @@ struct CtuWorker::SpecCand {
   int intra_ps;                      // (>= 0) the intra candidate of this partition size
   bool ok;                           // false: predInterSearch found no valid candidate (the reference does not rate the mode then)
   MvField mf; uint8_t mdir;
-  CuData cu; Coder after, goon;
+  CtuWorker* w;                      // the kid that evaluated it: the result is its temporary CU of the depth, its CI_TEMP coder and its go-on coder
 };
 
 void CtuWorker::spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot) {
-  CtuWorker* w = new CtuWorker(E, lane_, be);
-  w->ctu_addr_ = ctu_addr_; w->ctu_x_ = ctu_x_; w->ctu_y_ = ctu_y_; w->slot_ = slot; w->tag_seq_ = tag_seq_;
+  CtuWorker* w = kids_[slot];
+  w->ensure(d);
+  w->temp_[d] = w->store_[d][1]; w->best_[d] = w->store_[d][0];
+  w->ctu_addr_ = ctu_addr_; w->ctu_x_ = ctu_x_; w->ctu_y_ = ctu_y_; w->slot_ = slot; w->tag_seq_ = tag_seq_; w->lane_ = lane_;
   w->sb_[d][CI_CURR] = sb_[d][CI_CURR]; w->goon_ = goon_;
   CuData* c = w->temp_[d];
-  *c = tmpl;
-  try {
+  cu_copy(*c, tmpl);
+  sc.w = w;
+  {
     if (sc.intra_ps >= 0) {                                               // xCheckRDCostIntra up to the comparison
       w->eval_intra(d, sc.intra_ps);
       sc.ok = true;
@@ -773,19 +790,18 @@ void CtuWorker::spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot) {
       sc.ok = w->pred_inter_search(*c, sc.ps, sc.use_mrg);
       if (sc.ok) { w->tag_step(60); w->eval_inter(d, false); }
     }
-  } catch (...) { delete w; throw; }
-  sc.cu = *c; sc.after = w->sb_[d][CI_TEMP]; sc.goon = w->goon_;
-  delete w;
+  }
 }
 
 // the candidate's result as the serial path would have left it in the temporary CU, then xCheckBestMode
 void CtuWorker::spec_adopt(int d, SpecCand& sc) {
-  *temp_[d] = sc.cu; sb_[d][CI_TEMP] = sc.after; goon_ = sc.goon;
+  cu_copy(*temp_[d], *sc.w->temp_[d]); sb_[d][CI_TEMP] = sc.w->sb_[d][CI_TEMP]; goon_ = sc.w->goon_;
   check_best_mode(d, true);
 }
 
 void CtuWorker::spec_inter_phase(int d, std::vector<SpecCand>& cands) {
-  const CuData tmpl = *temp_[d];                                          // after init_est
+  const CuData& tmpl = *temp_[d];                                         // after init_est (this worker waits in fork_join while its kids read it)
+  if ((int)kids_.size() <= cfg.spec_slots) { const size_t k0 = kids_.size(); kids_.resize(cfg.spec_slots + 1, NULL); for (size_t k = k0; k < kids_.size(); k++) kids_[k] = new CtuWorker(E, lane_, be, true); }
   // slots: 1, 2, ... for the SS/GT candidates; the two highest for the intra candidates, whose reconstructions wait there until the decisions reach them (the AMP
   // candidates in between reuse the low slots)
   const int n = (int)cands.size();
@@ -832,7 +848,8 @@ void CtuWorker::check_merge_and_inter_spec(int d) {
       if (best_is_skip && nores == 0) continue;
       if (!valid[k]) { init_est(*temp_[d]); continue; }
       SpecCand& sc = cands[idx[k][nores]];
-      const int root = (sc.cu.p[0].cbf[0] & 1) | (sc.cu.p[0].cbf[1] & 1) | (sc.cu.p[0].cbf[2] & 1);
+      const Part& q0 = sc.w->temp_[d]->p[0];
+      const int root = (q0.cbf[0] & 1) | (q0.cbf[1] & 1) | (q0.cbf[2] & 1);
       if (nores == 0 && root == 0) buf[k] = 1;
       spec_adopt(d, sc);
       init_est(*temp_[d]);
@@ -1299,16 +1316,32 @@ class FiberPool : public Backend {
   }
   bool barrier(int) {                                                   // false: everything has finished
     std::unique_lock<std::mutex> lk(bm_);
-    const uint64_t gen = gen_;
+    const uint64_t gen = gen_.load();
     if (++arrived_ == T_) {                                             // every worker is out of runnable rows: serve, or finish
+      lk.unlock();                                                      // (the others only watch gen_ from here on)
       for (int k = 0; k < T_; k++) { pending_.insert(pending_.end(), local_[k].begin(), local_[k].end()); local_[k].clear(); }
       if (left_.load() == 0) finished_ = true;
       else if (failed_) { for (Req* r : pending_) (void)r; pending_.clear(); }
       else if (!pending_.empty() || !inflight_.empty()) { serve(); idle_rounds_ = 0; }
       else if (++idle_rounds_ > 100000) failed_ = true;                 // rows waiting for a step nobody can finish
-      arrived_ = 0; gen_++;
+      lk.lock();
+      arrived_ = 0; gen_.store(gen + 1);
+      lk.unlock();
       bcv_.notify_all();
-    } else bcv_.wait(lk, [&] { return gen_ != gen; });
+      return !finished_;
+    }
+    lk.unlock();
+    // a round takes about a millisecond: watch the generation for a while before going to sleep (a futex sleep and wake-up costs a good part of that)
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0; gen_.load(std::memory_order_acquire) == gen; spin++) {
+      __builtin_ia32_pause();
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(3000)) {
+        lk.lock();
+        bcv_.wait(lk, [&] { return gen_.load() != gen; });
+        lk.unlock();
+        break;
+      }
+    }
     return !finished_;
   }
   void serve() {
@@ -1374,7 +1407,7 @@ class FiberPool : public Backend {
   std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
   std::vector<ucontext_t> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
-  std::mutex bm_; std::condition_variable bcv_; int arrived_; uint64_t gen_; std::atomic<int> left_; int idle_rounds_;
+  std::mutex bm_; std::condition_variable bcv_; int arrived_; std::atomic<uint64_t> gen_; std::atomic<int> left_; int idle_rounds_;
   std::vector<std::vector<Fiber*> > free_, kids_;
 };
 }  // namespace

@@ -19,7 +19,6 @@
 #include <thread>
 #include <atomic>
 #include <functional>
-#include <ucontext.h>
 #include <chrono>
 
 namespace hopspine {
@@ -1203,9 +1202,18 @@ class Rendezvous : public Backend {
 // wavefront to advance, switches back to its worker's scheduler; a worker whose rows are all waiting joins a barrier; when every worker is there the requests with the
 // smallest tag are served as one batch per kind (exactly as above) and the workers go round again.  A request costs two context switches in user space instead of a futex
 // sleep and wake-up per row thread -- with hundreds of rows in flight (several pictures side by side) those wake-ups were the largest single cost of the host side.
+// The context switch: callee-saved registers on the leaving stack, stack pointers exchanged.  (glibc's swapcontext also saves and restores the signal mask, two
+// system calls per switch: at four switches per request that was most of the rows' host time.)  x86-64 System V, like everything else here.
+extern "C" void hop_fiber_switch(void** save_sp, void* load_sp);
+asm(".text\n.globl hop_fiber_switch\n.type hop_fiber_switch,@function\nhop_fiber_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size hop_fiber_switch, .-hop_fiber_switch\n");
+
 class FiberPool : public Backend {
  public:
-  struct Fiber { ucontext_t ctx; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool;
+  struct Fiber { void* sp; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool;
                  Fiber* parent; int live_children; bool wait_children; uint64_t tag; };   // parent: a child of fork_join (recycled when done)
   FiberPool(BatchInner* inner, int n_workers) : rounds(0), requests(0), steps_complete(-1), inner_(inner), T_(n_workers), failed_(false), finished_(false), arrived_(0), gen_(0), left_(0), idle_rounds_(0) {
     sched_.resize(T_); mine_.resize(T_); local_.resize(T_); free_.resize(T_); kids_.resize(T_);
@@ -1229,13 +1237,11 @@ class FiberPool : public Backend {
       else { f = new Fiber(); f->stack = (char*)malloc(STACK); kids_[w].push_back(f); }
       f->body = [&fn, i]() { fn(i); };
       f->done = false; f->req = NULL; f->wait_step = -1; f->worker = w; f->pool = this; f->parent = me; f->live_children = 0; f->wait_children = false; f->tag = me->tag;
-      getcontext(&f->ctx);
-      f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = STACK; f->ctx.uc_link = &sched_[w];
-      makecontext(&f->ctx, (void (*)())tramp, 2, (unsigned)((uintptr_t)f & 0xFFFFFFFFu), (unsigned)((uintptr_t)f >> 32));
+      start(f);
       mine_[w].push_back(f);
     }
     me->wait_children = true;
-    swapcontext(&me->ctx, &sched_[w]);
+    hop_fiber_switch(&me->sp, sched_[w]);
     if (failed_) throw 1;
   }
   void run() {                                                          // all fibers to completion
@@ -1260,7 +1266,7 @@ class FiberPool : public Backend {
   void wait_step(int st) {                                              // until every wavefront step <= st is finished
     if (steps_complete.load() >= st) return;
     Fiber* f = current(); f->wait_step = st;
-    swapcontext(&f->ctx, &sched_[f->worker]);
+    hop_fiber_switch(&f->sp, sched_[f->worker]);
     if (failed_) throw 1;
   }
   uint64_t rounds, requests;
@@ -1271,12 +1277,21 @@ class FiberPool : public Backend {
  private:
   enum { STACK = 512 * 1024 };
   static Fiber*& current() { static thread_local Fiber* cur = NULL; return cur; }
-  static void tramp(unsigned lo, unsigned hi) {
-    Fiber* f = (Fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+  static void tramp() {                                                 // a fiber's first frame: entered by the first switch to it
+    Fiber* f = current();
     try { f->body(); } catch (...) { f->pool->failed_ = true; }
     f->done = true;
     if (f->parent) f->parent->live_children--; else f->pool->left_--;
-    // returning ends the context: uc_link takes the worker's scheduler up where it left off
+    hop_fiber_switch(&f->sp, f->pool->sched_[f->worker]);               // for good (the stack is reused by the next fork)
+    abort();
+  }
+  // a fresh stack whose first switch "returns" into tramp: six callee-saved registers, the return address, and the slot a call would have pushed (alignment)
+  static void start(Fiber* f) {
+    uintptr_t top = ((uintptr_t)f->stack + STACK) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 64);
+    for (int i = 0; i < 6; i++) sp[i] = NULL;
+    sp[6] = (void*)&tramp; sp[7] = NULL;
+    f->sp = sp;
   }
   void submit(Req& q) {
     if (failed_) throw 1;
@@ -1284,14 +1299,12 @@ class FiberPool : public Backend {
     q.tag = f->tag;
     local_[f->worker].push_back(&q);
     f->req = &q;
-    swapcontext(&f->ctx, &sched_[f->worker]);
+    hop_fiber_switch(&f->sp, sched_[f->worker]);
     if (!q.done) throw 1;                                               // resumed without an answer: the pool has failed
   }
   void worker(int w) {
     for (Fiber* f : mine_[w]) {
-      getcontext(&f->ctx);
-      f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = STACK; f->ctx.uc_link = &sched_[w];
-      makecontext(&f->ctx, (void (*)())tramp, 2, (unsigned)((uintptr_t)f & 0xFFFFFFFFu), (unsigned)((uintptr_t)f >> 32));
+      start(f);
     }
     for (;;) {
       bool ran = false, ended = false;
@@ -1302,7 +1315,7 @@ class FiberPool : public Backend {
         else if (f->wait_step >= 0) { if (steps_complete.load() < f->wait_step && !failed_) continue; f->wait_step = -1; }
         else if (f->wait_children) { if (f->live_children > 0) continue; f->wait_children = false; }
         current() = f;
-        swapcontext(&sched_[w], &f->ctx);                               // until it submits, waits or ends
+        hop_fiber_switch(&sched_[w], f->sp);                            // until it submits, waits or ends
         ran = true;
       }
       if (ended) {                                                      // children that have ended: out of the list, their stacks free for the next fork
@@ -1406,7 +1419,7 @@ class FiberPool : public Backend {
   }
   std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
-  std::vector<ucontext_t> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
+  std::vector<void*> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
   std::mutex bm_; std::condition_variable bcv_; int arrived_; std::atomic<uint64_t> gen_; std::atomic<int> left_; int idle_rounds_;
   std::vector<std::vector<Fiber*> > free_, kids_;
 };

@@ -545,7 +545,7 @@ def encode_main(args):
         pctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
         prof_s = time.perf_counter() - tp0
         prof_ctus = wctu * hctu * Pp
-        names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_turd_fused (transform unit leaf step: transform, estBit, RDOQ, counted bits, inverse, decision)",
+        names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_turd_fused + k_turd_fused_small (transform unit leaf step: transform, estBit, RDOQ, counted bits, inverse, decision)",
                  7: "k_intra (rough search + predictors)", 8: "k_rdoq (staged form)", 9: "k_coeff_bits + CU-level counting"}
         prof = {}
         for kid, name in names.items():

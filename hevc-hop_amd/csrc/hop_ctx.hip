@@ -122,7 +122,7 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->sub_h = parent->sub_h; c->sub_pitch = parent->sub_pitch; c->slots = parent->slots; c->fused_leaf_max = parent->fused_leaf_max; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
   c->org_y = parent->org_y; c->org_cb = parent->org_cb; c->org_cr = parent->org_cr;
   for (int k = 0; k < 3; k++) { c->ss_alloc[k] = parent->ss_alloc[k]; c->ss_buf[k] = parent->ss_buf[k]; c->ss00[k] = parent->ss00[k]; c->pred[k] = parent->pred[k]; c->rec[k] = parent->rec[k]; }
-  c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots;
+  c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots; c->coefpic = parent->coefpic; c->coef_stash = parent->coef_stash;
   hipError_t e = hipSetDevice(c->device);
   // (stream priorities -- views low, the parent high, so that the spine's short rounds would not queue behind its evaluation chains -- were measured and cost 10 %:
   // the evaluation chains are the critical path of a node, not the short rounds)
@@ -173,13 +173,13 @@ void hop_ctx_destroy(hop_ctx* c) {
   if (!c) return;
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
   if (c->is_view) {                                                     // pictures, tables and stash are the parent's
-    c->org_y = c->org_cb = c->org_cr = nullptr; c->entropy_bits = nullptr; c->rdoq_scans = nullptr; c->stash = nullptr;
+    c->org_y = c->org_cb = c->org_cr = nullptr; c->entropy_bits = nullptr; c->rdoq_scans = nullptr; c->stash = nullptr; c->coefpic = nullptr; c->coef_stash = nullptr;
     for (int k = 0; k < 3; k++) { c->ss_alloc[k] = nullptr; c->pred[k] = nullptr; c->rec[k] = nullptr; }
   }
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
-                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits, c->stash };
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits, c->stash, c->coefpic, c->coef_stash };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < HOP_GRAPH_SLOTS; k++) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -46,6 +46,9 @@ struct hop_ctx {
   struct { uint64_t key; int seen; hipGraphExec_t exec; } graphs[HOP_GRAPH_SLOTS]; int graph_next; long graph_replays;
   // RD spine support (k_spine.hip): stash slots for reconstruction blocks (64 x 64 x 1.5 samples each), allocated on first use
   int16_t* stash; int stash_slots;
+  // the levels of the pictures as the reference keeps them (TComDataCU::m_pcTrCoeffY / Cb / Cr): per 64x64 CTU of the (stacked) picture 4096 + 1024 + 1024 TCoeff, a CU's at
+  // 16 x / 4 x its partition index; one such image per candidate slot; and their part of the stash slots.  Allocated by hop_encode_frame.
+  int32_t* coefpic; int32_t* coef_stash;
   bool   is_view;                    // hop_ctx_create_view: pictures, tables and stash belong to the parent; stream, scratch areas, graphs and profiling are its own
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read

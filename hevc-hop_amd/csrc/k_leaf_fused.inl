@@ -12,8 +12,11 @@
 
 struct LeafShared {
   union { TurdFwdShared big; TurdSmallShared small; } t;
-  CabacLds cab;                                                       // column 0: the TU's context states
+  CabacLds1 cab;                                                      // the TU's context states
   uint16_t scan[1024]; uint16_t scanCG[64]; double cgSig[64];
+  // everything the serial walk touches (a lane's dependent loads from HBM were most of its time): coefficients, levels, bit-estimate table, context states, the
+  // entropy table, and the RDOQ work area of TUs up to 16x16 (a 32x32 TU's 40 KB stay in HBM)
+  int32_t src[1024], lev[1024], ebits[128]; hop_estbits eb; uint8_t ctx[152]; double work[256 * RQ_WORK_PER_COEF / 8];
 };
 
 __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const hop_cabac_ctx* __restrict__ ctx_in,
@@ -36,19 +39,24 @@ __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restr
     for (int i = tid; i < CGN; i += 256) L.scanCG[i] = s1[i]; }
   __threadfence_block();
   __syncthreads();
+  const int64_t off = coef_off[j];
+  for (int i = tid; i < N2; i += 256) L.src[i] = coef[off + i];
+  { const uint8_t* st = ctx_in[jb.ctx_index].state; for (int i = tid; i < 152; i += 256) { const uint8_t v = st[i]; L.ctx[i] = v; L.cab.st[i][0] = v; } }
+  for (int i = tid; i < 128; i += 256) L.ebits[i] = entropy_bits[i];
+  __syncthreads();
   if (tid == 0) {                                                     // the serial stages
-    turd_setup_body(j, jobs, n, ctx_in, coef_off, entropy_bits, tables + j, rq, cb);
+    turd_setup_body(j, jobs, n, ctx_in, coef_off, L.ebits, &L.eb, rq, cb, L.ctx);
     const hop_rdoq_job rj = rq[j];
-    double* wd = (double*)(work + (size_t)j * LEAF_WORK_PER_TU);
-    const int32_t* src = coef + rj.coeff_offset; int32_t* dst = levels + rj.coeff_offset;
-    if (LOG2 == 2) rdoq_tu<2>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
-    else if (LOG2 == 3) rdoq_tu<3>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
-    else if (LOG2 == 4) rdoq_tu<4>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
-    else rdoq_tu<5>(rj, tables + j, L.scan, L.scanCG, L.cgSig, 1, src, dst, as + j, wd, 1, 0);
+    double* wd = LOG2 <= 4 ? L.work : (double*)(work + (size_t)j * LEAF_WORK_PER_TU);
+    if (LOG2 == 2) rdoq_tu<2>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, wd, 1, 0);
+    else if (LOG2 == 3) rdoq_tu<3>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, wd, 1, 0);
+    else if (LOG2 == 4) rdoq_tu<4>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, wd, 1, 0);
+    else rdoq_tu<5>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, wd, 1, 0);
     const hop_coeff_bits_job bj = cb[j];
-    { const uint8_t* src = ctx_in[bj.ctx_index].state; for (int i = 0; i < 152; i++) L.cab.st[i][0] = src[i]; }
-    fr[j] = cb_code_tu(L.cab, 0, levels + bj.coeff_offset, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, scans);
+    fr[j] = cb_code_tu_at(L.cab, 0, L.lev, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, L.scan, L.scanCG);
   }
+  __syncthreads();
+  for (int i = tid; i < N2; i += 256) levels[off + i] = L.lev[i];
   __threadfence_block();
   __syncthreads();
   // dequantisation, inverse transform, reconstruction (intra) and the distortion of the coded block

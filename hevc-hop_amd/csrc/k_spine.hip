@@ -42,6 +42,36 @@ __global__ __launch_bounds__(256) void k_recon_stash(const int32_t* __restrict__
   }
 }
 
+// ---- the levels of the chosen CUs (what TEncSearch / TEncCu leave in TComDataCU::m_pcTrCoeff*) ----
+#define COEF_PER_CTU 6144           // 64 x 64 luma + 2 x 32 x 32 chroma TCoeff
+__device__ static inline int spine_zidx(int x4, int y4) { int z = 0; for (int b = 0; b < 4; b++) z |= (((x4 >> b) & 1) << (2 * b)) | (((y4 >> b) & 1) << (2 * b + 1)); return z; }
+// where the levels of the CU at (x, y) start in the image of its slot: Y; Cb at + 4096 - 12 * abs ... computed by the callers from abs
+__device__ static inline int32_t* spine_coef_at(int32_t* coefpic, int x, int y, int pic_w, int pic_h, int& abs_idx) {
+  const int slot = y / pic_h, yr = y - slot * pic_h, wctu = (pic_w + 63) >> 6, hctu = (pic_h + 63) >> 6;
+  abs_idx = spine_zidx((x & 63) >> 2, (yr & 63) >> 2);
+  return coefpic + ((size_t)slot * wctu * hctu + (size_t)(yr >> 6) * wctu + (x >> 6)) * COEF_PER_CTU;
+}
+// grid (n): the levels of candidate i (cu^2 luma, cu^2 / 4 Cb, cu^2 / 4 Cr TCoeff at i * 1.5 cu^2; coef == NULL: a candidate without residual) into the image of its slot
+__global__ __launch_bounds__(256) void k_coef_put(const hop_rqt_job* __restrict__ jobs, const int32_t* __restrict__ coef, int32_t* __restrict__ coefpic, int pic_w, int pic_h) {
+  const int i = blockIdx.x, cu2 = 1 << (2 * jobs[i].log2_cu);
+  int abs_idx; int32_t* ctu = spine_coef_at(coefpic, jobs[i].x, jobs[i].y, pic_w, pic_h, abs_idx);
+  const int32_t* src = coef ? coef + (size_t)i * (cu2 + (cu2 >> 1)) : nullptr;
+  for (int k = threadIdx.x; k < cu2; k += blockDim.x) ctu[16 * abs_idx + k] = src ? src[k] : 0;
+  for (int k = threadIdx.x; k < (cu2 >> 2); k += blockDim.x) { ctu[4096 + 4 * abs_idx + k] = src ? src[cu2 + k] : 0; ctu[5120 + 4 * abs_idx + k] = src ? src[cu2 + (cu2 >> 2) + k] : 0; }
+}
+// grid (n): block i between the image of the slot its y names and its stash slot; rect4 = x, y, size, slot
+template <bool RESTORE>
+__global__ __launch_bounds__(256) void k_coef_stash(const int32_t* __restrict__ rect4, int32_t* __restrict__ coefpic, int pic_w, int pic_h, int32_t* __restrict__ stash) {
+  const int i = blockIdx.x, cu2 = rect4[4 * i + 2] * rect4[4 * i + 2];
+  int abs_idx; int32_t* ctu = spine_coef_at(coefpic, rect4[4 * i], rect4[4 * i + 1], pic_w, pic_h, abs_idx);
+  int32_t* st = stash + (size_t)rect4[4 * i + 3] * COEF_PER_CTU;
+  for (int k = threadIdx.x; k < cu2; k += blockDim.x) { if (RESTORE) ctu[16 * abs_idx + k] = st[k]; else st[k] = ctu[16 * abs_idx + k]; }
+  for (int k = threadIdx.x; k < (cu2 >> 2); k += blockDim.x) {
+    if (RESTORE) { ctu[4096 + 4 * abs_idx + k] = st[4096 + k]; ctu[5120 + 4 * abs_idx + k] = st[5120 + k]; }
+    else { st[4096 + k] = ctu[4096 + 4 * abs_idx + k]; st[5120 + k] = ctu[5120 + 4 * abs_idx + k]; }
+  }
+}
+
 // grid (n, 3): the packed reconstruction of CU i (size^2 luma samples at i * size^2; size^2 / 2 chroma samples, Cb then Cr, at i * size^2 / 2) into the picture
 __global__ __launch_bounds__(256) void k_recon_put(const hop_rqt_job* __restrict__ jobs, const int16_t* __restrict__ reco_y, const int16_t* __restrict__ reco_c,
                                                    int16_t* __restrict__ ry, int16_t* __restrict__ rcb, int16_t* __restrict__ rcr, int pic_w) {
@@ -102,6 +132,10 @@ int hop_recon_stash(hop_ctx* c, int n, const int32_t* rect4, int restore) {
   HIPCHK(c, hipMemcpyAsync(st, rect4, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   if (restore) hipLaunchKernelGGL(k_recon_stash<true>, dim3(n, 3), dim3(256), 0, c->stream, (const int32_t*)st, c->rec[0], c->rec[1], c->rec[2], c->pic_w, c->stash);
   else hipLaunchKernelGGL(k_recon_stash<false>, dim3(n, 3), dim3(256), 0, c->stream, (const int32_t*)st, c->rec[0], c->rec[1], c->rec[2], c->pic_w, c->stash);
+  if (c->coefpic) {                                                    // the candidate's levels travel with its reconstruction
+    if (restore) hipLaunchKernelGGL(k_coef_stash<true>, dim3(n), dim3(256), 0, c->stream, (const int32_t*)st, c->coefpic, c->pic_w, c->pic_h, c->coef_stash);
+    else hipLaunchKernelGGL(k_coef_stash<false>, dim3(n), dim3(256), 0, c->stream, (const int32_t*)st, c->coefpic, c->pic_w, c->pic_h, c->coef_stash);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));                        // the staging area is the context's scratch: the next call may reuse it
   return HOP_OK;
@@ -112,6 +146,28 @@ int hop_recon_put_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const int
   if (n == 0) return HOP_OK;
   hipLaunchKernelGGL(k_recon_put, dim3(n, 3), dim3(256), 0, c->stream, d_jobs, d_reco_y, d_reco_c, c->rec[0], c->rec[1], c->rec[2], c->pic_w);
   HIPCHK(c, hipGetLastError());
+  return HOP_OK;
+}
+
+int hop_coef_put_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const int32_t* d_coef) {
+  if (!c || n < 0 || (n && !d_jobs)) return hop_set_err(c, HOP_ERR_ARG, "hop_coef_put_device: bad argument");
+  if (n == 0 || !c->coefpic) return HOP_OK;
+  hipLaunchKernelGGL(k_coef_put, dim3(n), dim3(256), 0, c->stream, d_jobs, d_coef, c->coefpic, c->pic_w, c->pic_h);
+  HIPCHK(c, hipGetLastError());
+  return HOP_OK;
+}
+
+// the levels hop_encode_frame left: per CTU (the pictures of a stacked context one after the other, each in raster order) 4096 luma + 1024 Cb + 1024 Cr TCoeff in the
+// reference's per-CTU layout (TComDataCU::m_pcTrCoeffY / Cb / Cr: a CU's block at 16 x / 4 x its z-order partition index, a TU's coefficients in raster order inside it)
+int hop_levels_download(hop_ctx* c, int32_t* out) {
+  if (!c || !out) return hop_set_err(c, HOP_ERR_ARG, "hop_levels_download: bad argument");
+  if (!c->coefpic) return hop_set_err(c, HOP_ERR_STATE, "hop_levels_download: hop_encode_frame has not run on this context");
+  const int wctu = (c->pic_w + 63) >> 6, n_pic = c->sub_pitch ? (c->pic_h - c->sub_h) / c->sub_pitch + 1 : 1, ph = c->sub_pitch ? c->sub_h : c->pic_h, hctu = (ph + 63) >> 6;
+  for (int k = 0; k < n_pic; k++) {
+    const size_t first = (size_t)(k * (c->sub_pitch >> 6)) * wctu;      // the picture's first CTU in the stack's CTU grid (pitch: a multiple of 64)
+    HIPCHK(c, hipMemcpyAsync(out + (size_t)k * wctu * hctu * COEF_PER_CTU, c->coefpic + first * COEF_PER_CTU, (size_t)wctu * hctu * COEF_PER_CTU * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return HOP_OK;
 }
 
@@ -284,6 +340,7 @@ class HipBackend : public BatchInner {
       k.d_ctx_out = (hop_cabac_ctx*)(dout + r_cx); k.d_cu_ctx_out = (hop_cabac_cu_ctx*)(dout + r_cu);
       BK(hop_inter_cu_device_classes(c, 1, &k, d_cx, d_cu));
     }
+    BK(hop_coef_put_device(c, n, d_jobs, skip ? nullptr : (const int32_t*)(arena + o_coef)));   // the candidate's levels into the image of its slot
     BH(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, s));
     std::vector<const Coder*> inv(in, in + n); std::vector<EvalResult*> outv(out, out + n);
     auto collect = [this, s, n, skip, r_fin, r_bits, r_skipped, r_cx, r_cu, r_res, inv, outv]() {
@@ -331,6 +388,7 @@ class HipBackend : public BatchInner {
     }
     BK(hop_intra_cu_device_classes(c, 1, &k, (const hop_cabac_ctx*)(din + i_cx), (const hop_cabac_cu_ctx*)(din + i_cu)));
     BK(hop_recon_put_device(c, n, k.d_jobs, k.d_reco_y, k.d_reco_c));
+    BK(hop_coef_put_device(c, n, k.d_jobs, k.d_coef));
     BH(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, s));
     std::vector<const Coder*> inv(in, in + n); std::vector<EvalResult*> outv(out, out + n);
     auto collect = [this, s, n, r_res, r_sres, r_cres, r_bits, r_dist, r_cx, r_cu, inv, outv]() {
@@ -379,6 +437,14 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
   if (c->slots > 0 && !p->plain_intra) { cfg.spec_slots = c->slots; cfg.slot_pitch = c->pic_h; }   // hop_ctx_set_slots: the SS/GT candidates of a CU side by side
   if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
+  {                                                                      // the images of the levels (one per candidate slot) and their part of the stash
+    const size_t ctus = (size_t)((c->pic_w + 63) >> 6) * ((c->pic_h + 63) >> 6), want = ctus * (c->slots + 1) * COEF_PER_CTU * 4;
+    if (c->coefpic) { (void)hipFree(c->coefpic); c->coefpic = nullptr; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc((void**)&c->coefpic, want));
+    HIPCHK(c, hipMemsetAsync(c->coefpic, 0, want, c->stream));
+    if (!c->coef_stash) HIPCHK(c, hipMalloc((void**)&c->coef_stash, (size_t)STASH_SLOTS * COEF_PER_CTU * 4));
+  }
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
   if (c->slots > 0 && p->wavefront_lag > 0 && !p->plain_intra) {         // candidates side by side: their evaluation chains of one round on streams of their own

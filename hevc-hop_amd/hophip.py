@@ -321,6 +321,14 @@ class Context:
         self._chk(L.hop_encode_frame(self.h, ctypes.byref(p), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data, parts.ctypes.data, ctypes.byref(nc)), "hop_encode_frame")
         return cost, bits, dist, parts, int(nc.value)
 
+    def levels_download(self):
+        """hop_levels_download: (n_ctu, 6144) int32 -- per CTU 4096 luma + 1024 Cb + 1024 Cr levels in the reference's TComDataCU layout"""
+        n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures
+        a = np.zeros((n, 6144), np.int32)
+        self.L.hop_levels_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_levels_download(self.h, a.ctypes.data), "hop_levels_download")
+        return a
+
     def encode_stats(self):
         ms, calls = (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
         self.L.hop_encode_stats(ms, calls)

@@ -653,6 +653,10 @@ typedef struct {
                              that the rows' launch chains overlap on the device; <= 1 = the rows' requests rendezvous and are served in batches on the context's stream */
   const char* trace_path;
 } hop_enc_params;
+/* The quantised levels of the picture(s) hop_encode_frame coded, as TEncCu leaves them in TComDataCU::m_pcTrCoeffY / Cb / Cr (what TEncSlice::encodeSlice codes): per CTU
+ * 6144 TCoeff -- 4096 luma, 1024 Cb, 1024 Cr --, a CU's block at 16 x (luma) / 4 x (chroma) its z-order partition index, a TU's coefficients in raster order inside it;
+ * CTUs in raster order, the pictures of a stacked context one after the other.  out: n_ctu * 6144 int32. */
+int hop_levels_download(hop_ctx* ctx, int32_t* out);
 int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates);
 /* diagnostics of the last hop_encode_frame of this process: host wall time (ms) and number of requests per kind -- 0 ME chain, 1 predictor, 2 distortion, 3 validity
  * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */

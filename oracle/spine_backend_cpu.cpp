@@ -26,6 +26,7 @@ class CpuBackend : public BatchInner {
       const int w = c ? W / 2 : W, h = c ? H / 2 : H;
       org[c].assign((size_t)w * h * (slots + 1), 0); pred[c].assign((size_t)w * h * (slots + 1), 0); rec[c].assign((size_t)w * h * (slots + 1), 0);
       for (int k = 0; k <= slots; k++) memcpy(&org[c][(size_t)k * w * h], c == 0 ? y : c == 1 ? cb : cr, (size_t)w * h * 2);
+      if (c == 0) coefpic.assign((size_t)(slots + 1) * ((W + 63) / 64) * ((H + 63) / 64) * 6144, 0);
       const int m = c ? 40 : 80, G = 64;                                   // the reference's margins + guard rows (see tests/hoputil.py:Planes)
       ss[c].w = w; ss[c].h = h; ss[c].margin = m; ss[c].stride = w + 2 * m;
       ss[c].buf.assign((size_t)ss[c].stride * (h + 2 * m + 2 * G), -1);
@@ -111,6 +112,17 @@ class CpuBackend : public BatchInner {
       for (int r = 0; r < w; r++) memcpy(&out[c][(size_t)r * w], &src[c][(size_t)((y >> s) + r) * st + (x >> s)], w * 2);
     }
   }
+  static int zidx(int x4, int y4) { int z = 0; for (int b = 0; b < 4; b++) z |= (((x4 >> b) & 1) << (2 * b)) | (((y4 >> b) & 1) << (2 * b + 1)); return z; }
+  int32_t* coef_ctu(int x, int y, int& abs_idx) {
+    const int slot = y / H, yr = y % H, wctu = (W + 63) / 64, hctu = (H + 63) / 64;
+    abs_idx = zidx((x & 63) >> 2, (yr & 63) >> 2);
+    return &coefpic[((size_t)slot * wctu * hctu + (size_t)(yr >> 6) * wctu + (x >> 6)) * 6144];
+  }
+  void put_coef(const int32_t* coef /* Y | Cb | Cr of the CU, or NULL */, int x, int y, int cu) {
+    int a; int32_t* ctu = coef_ctu(x, y, a); const int cu2 = cu * cu;
+    for (int k = 0; k < cu2; k++) ctu[16 * a + k] = coef ? coef[k] : 0;
+    for (int k = 0; k < cu2 / 4; k++) { ctu[4096 + 4 * a + k] = coef ? coef[cu2 + k] : 0; ctu[5120 + 4 * a + k] = coef ? coef[cu2 + cu2 / 4 + k] : 0; }
+  }
   void put_rec(const std::vector<int16_t> in[3], int x, int y, int cu) {
     for (int c = 0; c < 3; c++) {
       const int s = c ? 1 : 0, w = cu >> s, st = c ? W / 2 : W;
@@ -130,7 +142,7 @@ class CpuBackend : public BatchInner {
       uint32_t d3[3]; double cost = 0;
       const uint32_t bits = hop_o_inter_cu_skip(&cfg, e.syn.skip_ctx, e.syn.pu[0].merge_idx, e.syn.max_merge_cand, pp, oo, &coder, cuctx, d3, &cost);
       out.bits = bits; out.dist = d3[0] + d3[1] + d3[2]; out.cost = cost; out.skipped = 1; out.root_cbf = 0;
-      put_rec(pr, x, y, cu);
+      put_rec(pr, x, y, cu); put_coef(NULL, x, y, cu);
       coder_out(coder, cuctx, out.after);
       return;
     }
@@ -148,7 +160,7 @@ class CpuBackend : public BatchInner {
     const uint32_t cbits = hop_o_inter_cu_bits(&cfg, &syn, &st, &coef[0], &coder, cuctx, &skipped);
     out.bits = cbits; out.dist = d3[0] + d3[1] + d3[2]; out.cost = hop_o_calc_rd_cost(cbits, out.dist, cfg.lambda_rd); out.skipped = skipped; out.root_cbf = root;
     memcpy(out.tr_idx, st.tr_idx, parts); for (int c = 0; c < 3; c++) { memcpy(out.cbf[c], st.cbf[c], parts); memcpy(out.tskip[c], st.tskip[c], parts); }
-    put_rec(rc, x, y, cu);
+    put_rec(rc, x, y, cu); put_coef(&coef[0], x, y, cu);
     coder_out(coder, cuctx, out.after);
   }
   void intra_cu(int, const IntraEval& e, const Coder& in, EvalResult& out) {
@@ -197,16 +209,22 @@ class CpuBackend : public BatchInner {
     memcpy(out.tr_idx, st.tr_idx, parts); for (int c = 0; c < 3; c++) { memcpy(out.cbf[c], st.cbf[c], parts); memcpy(out.tskip[c], st.tskip[c], parts); }
     for (int p = 0; p < 4; p++) out.luma_dir[p] = best_dir[p];
     out.chroma_dir = best_mode;
-    put_rec(rc, x, y, cu);
+    put_rec(rc, x, y, cu); put_coef(&coef[0], x, y, cu);
     coder_out(coder, cuctx, out.after);
   }
-  void recon_save(int lane, int slot, int x, int y, int size) { std::vector<int16_t>* s = stash[lane * 16 + slot]; cu_planes(rec, x, y, size, s); }
-  void recon_restore(int lane, int slot, int x, int y, int size) { put_rec(stash[lane * 16 + slot], x, y, size); }
+  void recon_save(int lane, int slot, int x, int y, int size) {
+    std::vector<int16_t>* s = stash[lane * 16 + slot]; cu_planes(rec, x, y, size, s);
+    int a; const int32_t* ctu = coef_ctu(x, y, a); std::vector<int32_t>& cs = coef_stash[lane * 16 + slot]; cs.resize((size_t)size * size * 3 / 2);
+    memcpy(&cs[0], ctu + 16 * a, (size_t)size * size * 4); memcpy(&cs[(size_t)size * size], ctu + 4096 + 4 * a, (size_t)size * size); memcpy(&cs[(size_t)size * size * 5 / 4], ctu + 5120 + 4 * a, (size_t)size * size);
+  }
+  void recon_restore(int lane, int slot, int x, int y, int size) { put_rec(stash[lane * 16 + slot], x, y, size); put_coef(&coef_stash[lane * 16 + slot][0], x, y, size); }
   void commit(int, int x, int y, int size) {
     std::vector<int16_t> b[3]; cu_planes(rec, x, y, size, b);
     hop_o_ssref_commit_cu(ss[0].p00, ss[1].p00, ss[2].p00, W, H, x, y, size, &b[0][0], &b[1][0], &b[2][0]);
   }
   int W, H, bd;
+  std::vector<int32_t> coefpic;                                            // the levels, per slot and CTU 6144 TCoeff in the reference's layout (hop_levels_download)
+  std::map<int, std::vector<int32_t> > coef_stash;
   std::vector<int16_t> org[3], pred[3], rec[3];
   Plane ss[3];
   std::map<int, std::vector<int16_t>[3]> stash;
@@ -215,6 +233,8 @@ class CpuBackend : public BatchInner {
 }  // namespace
 
 // HOP_SPEC_SLOTS=<n> (tests): the SS/GT candidates of a CU side by side in n candidate slots (EncConfig::spec_slots), as hop_ctx_set_slots + hop_encode_frame do on the device
+static std::vector<int32_t> g_last_levels;   // the levels of the last picture(s) coded through an entry below (slot 0: the decided CUs), for hop_spine_cpu_last_levels
+static void keep_levels(const CpuBackend& be, bool append = false) { const size_t n = (size_t)((be.W + 63) / 64) * ((be.H + 63) / 64) * 6144; if (!append) g_last_levels.clear(); g_last_levels.insert(g_last_levels.end(), be.coefpic.begin(), be.coefpic.begin() + n); }
 static int spec_slots_env() { const char* e = getenv("HOP_SPEC_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }
 
 extern "C" {
@@ -234,6 +254,7 @@ long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, con
   enc.encode_frame(first_ctus);
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
+  keep_levels(be);
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
@@ -258,6 +279,7 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   try { if (lag > 0) enc.encode_frame_wavefront(use, lag); else enc.encode_frame(0); delete lg; } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
+  keep_levels(be);
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
@@ -304,6 +326,7 @@ long hop_spine_cpu_encode_stack(int w, int h, int n_pic, int pitch, int qp, int 
     if (ctu_dist) memcpy(ctu_dist + (size_t)k * n, &e.ctu_dist[0], n * 4);
     if (parts) memcpy((char*)parts + (size_t)k * n * 256 * sizeof(Part), &e.pic[0], e.pic.size() * sizeof(Part));
     if (rec_y) memcpy(rec_y + (size_t)k * w * h, &bes[k]->rec[0][0], (size_t)w * h * 2);
+    keep_levels(*bes[k], k > 0);
     total += (long)e.n_candidates;
   }
   if (rounds_requests) { rounds_requests[0] = (double)encs[0]->batch_rounds; rounds_requests[1] = (double)encs[0]->batch_requests; }
@@ -321,6 +344,7 @@ long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16
   enc.encode_frame(0);
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
+  keep_levels(be);
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
@@ -330,6 +354,8 @@ long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16
   if (rec_cr) memcpy(rec_cr, &be.rec[2][0], (size_t)(w / 2) * (h / 2) * 2);
   return (long)enc.n_candidates;
 }
+// the levels of the picture(s) the last entry coded: per CTU 6144 TCoeff in the reference's layout, as hop_levels_download hands them out; returns the count
+long hop_spine_cpu_last_levels(int32_t* out, long max_n) { const long n = (long)g_last_levels.size(); if (out && n <= max_n) memcpy(out, &g_last_levels[0], (size_t)n * 4); return n; }
 int hop_spine_sizeof_part(void) { return (int)sizeof(Part); }
 int hop_spine_sizeof_coder(void) { return (int)sizeof(Coder); }
 

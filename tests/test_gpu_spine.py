@@ -9,7 +9,7 @@ import pytest
 
 from hoputil import ROOT
 from hoputil import lenslet
-from test_spine_cpu import FRAMES, FRAMES_WPP, PLAIN, check_against_golden, frame, key_of, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
+from test_spine_cpu import FRAMES, FRAMES_WPP, PLAIN, check_against_golden, cpu_last_levels, frame, key_of, levels_match_cbf, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
 
 pytestmark = pytest.mark.gpu
 
@@ -38,9 +38,13 @@ def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp, slots):
         text = open(tp, "rb").read()
     check_against_golden(G, key_of(W, H, seed, sharp), cost, bits, dist, parts.view(np.dtype(parts.dtype.descr)), text)
     # the reconstruction (before the loop filters) and the SS reference it was committed to
-    _, _, _, _, rec, _ = run_cpu(spine_cpu(), W, H, Y, Cb, Cr)
+    Lc = spine_cpu()
+    _, _, _, _, rec, _ = run_cpu(Lc, W, H, Y, Cb, Cr)
     for c in range(3):
         assert np.array_equal(ctx.recon_download(c), rec[c]), c
+    # the levels of the chosen CUs (what encodeSlice would code): equal to the CPU spine's, and consistent with the cbf flags
+    lv = ctx.levels_download()
+    assert np.array_equal(lv, cpu_last_levels(Lc, len(cost))) and levels_match_cbf(lv, parts.view(np.dtype(parts.dtype.descr))) > 0
     m = 80
     assert np.array_equal(ctx.ssref_download(0)[m:m + H, m:m + W], rec[0])
     print(key_of(W, H, seed, sharp), nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
@@ -61,9 +65,11 @@ def test_encode_frame_wavefront_equals_the_reference_with_wavefront_synchro(W, H
         cost, bits, dist, parts, nc = ctx.encode_frame(32, 16, 0, tp, wpp=1, wavefront_lag=lag)
         text = open(tp, "rb").read()
     check_against_golden(G, key_of(W, H, seed, False) + "_wpp", cost, bits, dist, parts.view(np.dtype(parts.dtype.descr)), text)
-    _, _, _, _, rec, _, _ = run_cpu_wpp(spine_cpu(), W, H, Y, Cb, Cr, 0)
+    Lc = spine_cpu()
+    _, _, _, _, rec, _, _ = run_cpu_wpp(Lc, W, H, Y, Cb, Cr, 0)
     for c in range(3):
         assert np.array_equal(ctx.recon_download(c), rec[c]), c
+    assert np.array_equal(ctx.levels_download(), cpu_last_levels(Lc, len(cost)))
     print(key_of(W, H, seed, False), "wpp lag", lag, nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
     ctx.close()
 
@@ -106,6 +112,7 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
     pv = parts.view(np.dtype(parts.dtype.descr))
     check_against_golden(G, "192x128_seed7_wpp", cost[:n], bits[:n], dist[:n], pv[:n], text0)
     rec = [ctx.unstack(ctx.recon_download(c), c > 0) for c in range(3)]
+    levels = ctx.levels_download()
     ss = ctx.ssref_download(0)
     stats = ctx.encode_stats()
     ctx.close()
@@ -117,6 +124,7 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
         assert parts[k * n:(k + 1) * n].tobytes() == p1.tobytes(), k
         for c in range(3):
             assert np.array_equal(rec[c][k], one.recon_download(c)), (k, c)
+        assert np.array_equal(levels[k * n:(k + 1) * n], one.levels_download()), k
         # the picture's padded SS plane (margin 80 on every side) inside the stack's plane
         s1 = one.ssref_download(0)
         assert np.array_equal(ss[k * ctx.pitch:k * ctx.pitch + H + 160], s1), k

@@ -146,6 +146,34 @@ def test_spine_plain_intra_configurations(bd, qp):
     check_against_golden(G, plain_key(bd, qp), cost, bits, dist, parts, text)
 
 
+def cpu_last_levels(L, n_ctu):
+    """the levels of the picture(s) the last hop_spine_cpu_* call coded: (n_ctu, 6144) int32"""
+    L.hop_spine_cpu_last_levels.restype = ctypes.c_long
+    L.hop_spine_cpu_last_levels.argtypes = [ctypes.c_void_p, ctypes.c_long]
+    a = np.zeros((n_ctu, 6144), np.int32)
+    assert L.hop_spine_cpu_last_levels(a.ctypes.data, a.size) == a.size
+    return a
+
+
+def levels_match_cbf(levels, parts):
+    """the exported levels against the exported partition data, CU by CU (z-order walk of every CTU): a component of a CU holds a non-zero level exactly when one of the
+    CU's partitions has a cbf bit of that component set; partitions outside the picture hold nothing"""
+    n_cu = 0
+    for a in range(parts.shape[0]):
+        p, lv = parts[a], levels[a]
+        i = 0
+        while i < 256:
+            if p["pred_mode"][i] == 15:                                  # MODE_NONE: outside the picture
+                assert not lv[16 * i:16 * i + 16].any() and not lv[4096 + 4 * i:4096 + 4 * i + 4].any() and not lv[5120 + 4 * i:5120 + 4 * i + 4].any(), (a, i)
+                i += 1; continue
+            q = 256 >> (2 * int(p["depth"][i]))
+            for c, (base, per) in enumerate(((0, 16), (4096, 4), (5120, 4))):
+                nz = bool(lv[base + per * i:base + per * (i + q)].any())
+                assert nz == bool(p["cbf"][i:i + q, c].any()), (a, i, q, c, nz)
+            i += q; n_cu += 1
+    return n_cu
+
+
 def run_cpu_stack(L, W, H, pics, pitch, lag, qp=32, mi=16):
     """pics: list of (Y, Cb, Cr); the pictures coded side by side (requests of picture k carry y + k * pitch)"""
     L.hop_spine_cpu_encode_stack.restype = ctypes.c_long
@@ -158,6 +186,23 @@ def run_cpu_stack(L, W, H, pics, pitch, lag, qp=32, mi=16):
                                       parts.ctypes.data, rec.ctypes.data, rr.ctypes.data)
     assert nc > 0
     return cost.reshape(P, n), bits.reshape(P, n), dist.reshape(P, n), parts.reshape(P, n, 256), rec, rr
+
+
+def test_exported_levels_agree_with_the_partition_data():
+    """the levels the spine keeps for the chosen CUs (hop_levels_download's CPU twin): consistent with the cbf flags of the finished partition data, in raster order,
+    with candidate slots, and as a wavefront"""
+    L = spine_cpu()
+    W, H = 200, 136
+    Y, Cb, Cr = frame(W, H, 5, False)
+    cost, bits, dist, parts, rec, text = run_cpu(L, W, H, Y, Cb, Cr)
+    lv0 = cpu_last_levels(L, len(cost))
+    assert levels_match_cbf(lv0, parts) > 100 and np.abs(lv0).sum() > 0
+    os.environ["HOP_SPEC_SLOTS"] = "16"
+    try:
+        run_cpu(L, W, H, Y, Cb, Cr)
+        assert np.array_equal(cpu_last_levels(L, len(cost)), lv0)         # candidates side by side: the same levels
+    finally:
+        del os.environ["HOP_SPEC_SLOTS"]
 
 
 def test_stacked_pictures_equal_the_pictures_alone():

@@ -620,7 +620,7 @@ def main():
     ap.add_argument("--tile-w", type=int, default=1024, help="width of one picture (tile)")
     ap.add_argument("--slots", type=int, default=16, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
     ap.add_argument("--profile-pictures", type=int, default=16, help="pictures of the separate profiled pass behind the roofline object")
-    ap.add_argument("--pictures", type=int, default=256, help="independent pictures coded side by side per GPU (one stacked context)")
+    ap.add_argument("--pictures", type=int, default=384, help="independent pictures coded side by side per GPU (one stacked context)")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
     ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")
     ap.add_argument("--kernels", action="store_true", help="kernel-throughput mode of round 1: the search kernels over a frozen, fully reconstructed SS reference (not the encode metric)")

@@ -1447,7 +1447,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     std::fill(E.committed.begin(), E.committed.end(), (uint8_t)0);
   }
   if (inner) {                                                          // the batching form: rows as fibers on a few worker threads
-    int T = (int)std::thread::hardware_concurrency(); if (T > 12) T = 12; if (T < 1) T = 1;
+    int T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; if (T < 1) T = 1;
     if (const char* e = getenv("HOP_SPINE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) T = v; }
     if (T > rows * n_pic) T = rows * n_pic;
     FiberPool pool(inner, T);

@@ -177,7 +177,7 @@ void hop_ctx_destroy(hop_ctx* c) {
     for (int k = 0; k < 3; k++) { c->ss_alloc[k] = nullptr; c->pred[k] = nullptr; c->rec[k] = nullptr; }
   }
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
-  free(c->prof_recs);
+  free(c->prof_recs); free(c->rd_fraction);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
                    c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits, c->stash, c->coefpic, c->coef_stash };
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -49,6 +49,7 @@ struct hop_ctx {
   // the levels of the pictures as the reference keeps them (TComDataCU::m_pcTrCoeffY / Cb / Cr): per 64x64 CTU of the (stacked) picture 4096 + 1024 + 1024 TCoeff, a CU's at
   // 16 x / 4 x its partition index; one such image per candidate slot; and their part of the stash slots.  Allocated by hop_encode_frame.
   int32_t* coefpic; int32_t* coef_stash;
+  uint16_t* rd_fraction; int rd_fraction_n;   // host: hop_encode_frame's per-CTU carried fraction of the RD coder (hop_rd_fraction_download)
   bool   is_view;                    // hop_ctx_create_view: pictures, tables and stash belong to the parent; stream, scratch areas, graphs and profiling are its own
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read

@@ -159,6 +159,12 @@ int hop_coef_put_device(hop_ctx* c, int n, const hop_rqt_job* d_jobs, const int3
 
 // the levels hop_encode_frame left: per CTU (the pictures of a stacked context one after the other, each in raster order) 4096 luma + 1024 Cb + 1024 Cr TCoeff in the
 // reference's per-CTU layout (TComDataCU::m_pcTrCoeffY / Cb / Cr: a CU's block at 16 x / 4 x its z-order partition index, a TU's coefficients in raster order inside it)
+int hop_rd_fraction_download(hop_ctx* c, uint16_t* out) {
+  if (!c || !out) return hop_set_err(c, HOP_ERR_ARG, "hop_rd_fraction_download: bad argument");
+  if (!c->rd_fraction) return hop_set_err(c, HOP_ERR_STATE, "hop_rd_fraction_download: hop_encode_frame has not run on this context");
+  memcpy(out, c->rd_fraction, (size_t)c->rd_fraction_n * sizeof(uint16_t));
+  return HOP_OK;
+}
 int hop_levels_download(hop_ctx* c, int32_t* out) {
   if (!c || !out) return hop_set_err(c, HOP_ERR_ARG, "hop_levels_download: bad argument");
   if (!c->coefpic) return hop_set_err(c, HOP_ERR_STATE, "hop_levels_download: hop_encode_frame has not run on this context");
@@ -491,12 +497,14 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   if (rc == HOP_OK) {
     const int n = enc.n_ctu();
     if (n_candidates) *n_candidates = 0;
+    free(c->rd_fraction); c->rd_fraction = (uint16_t*)malloc((size_t)n_pic * n * sizeof(uint16_t)); c->rd_fraction_n = c->rd_fraction ? n_pic * n : 0;
     for (int k = 0; k < n_pic; k++) {                                     // picture k's results at [k * n, (k + 1) * n)
       const hopspine::Encoder& e = *encs[k];
       if (ctu_cost) memcpy(ctu_cost + (size_t)k * n, e.ctu_cost.data(), n * sizeof(double));
       if (ctu_bits) memcpy(ctu_bits + (size_t)k * n, e.ctu_bits.data(), n * 4);
       if (ctu_dist) memcpy(ctu_dist + (size_t)k * n, e.ctu_dist.data(), n * 4);
       if (parts) memcpy(parts + (size_t)k * n * 256, e.pic.data(), e.pic.size() * sizeof(hopspine::Part));
+      if (c->rd_fraction) memcpy(c->rd_fraction + (size_t)k * n, e.ctu_rd_fraction.data(), n * sizeof(uint16_t));
       if (n_candidates) *n_candidates += e.n_candidates;
     }
   }

@@ -329,6 +329,14 @@ class Context:
         self._chk(self.L.hop_levels_download(self.h, a.ctypes.data), "hop_levels_download")
         return a
 
+    def rd_fraction_download(self):
+        """hop_rd_fraction_download: per CTU the fraction of a bit the RD search's counting coder carries when the CTU is done"""
+        n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures
+        a = np.zeros(n, np.uint16)
+        self.L.hop_rd_fraction_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_rd_fraction_download(self.h, a.ctypes.data), "hop_rd_fraction_download")
+        return a
+
     def encode_stats(self):
         ms, calls = (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
         self.L.hop_encode_stats(ms, calls)

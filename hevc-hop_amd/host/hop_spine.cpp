@@ -1010,6 +1010,7 @@ void CtuWorker::compress_ctu(int addr, const Coder& entry, Coder& exit) {
   sb_[0][CI_CURR] = entry; sb_[0][CI_NEXT] = entry; sb_[0][CI_TEMP] = entry; goon_ = entry;
   compress_cu(0, SIZE_NONE);
   E.ctu_cost[addr] = best_[0]->cost; E.ctu_bits[addr] = best_[0]->bits; E.ctu_dist[addr] = best_[0]->dist;
+  E.ctu_rd_fraction[addr] = (uint16_t)(coder_frac(goon_) & 32767);
   // the coder the next CTU starts from
   exit = sb_[0][CI_NEXT];
   memcpy(exit.split, entry.split, 3);
@@ -1024,7 +1025,7 @@ void CtuWorker::compress_ctu(int addr, const Coder& entry, Coder& exit) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 Encoder::Encoder(const EncConfig& cfg, Backend* be) : trace(NULL), n_candidates(0), cfg_(cfg), be_(be) {
   wctu_ = (cfg.pic_w + 63) / 64; hctu_ = (cfg.pic_h + 63) / 64;
-  ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0); ctu_trace.resize(n_ctu()); batch_rounds = batch_requests = 0;
+  ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0); ctu_rd_fraction.assign(n_ctu(), 0); ctu_trace.resize(n_ctu()); batch_rounds = batch_requests = 0;
   pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu()); committed.assign((size_t)(cfg.pic_w >> 3) * (cfg.pic_h >> 3), 0);
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
 }

@@ -178,6 +178,7 @@ class Encoder {
   // results
   std::vector<double>   ctu_cost;                    // per CTU: getTotalCost of compressCU (what cost.csv records)
   std::vector<uint32_t> ctu_bits, ctu_dist;
+  std::vector<uint16_t> ctu_rd_fraction;             // the go-on coder's carried fraction (m_fracBits & 32767) when each CTU's compressCU returns
   std::vector<Part>     pic;                         // 256 parts per CTU, z-order
   std::vector<Coder>    ctu_entry;                   // coder at the start of every CTU
   FILE* trace;                                       // optional: one line per candidate that reaches xCheckBestMode (written CTU by CTU in raster order)

@@ -657,6 +657,12 @@ typedef struct {
  * 6144 TCoeff -- 4096 luma, 1024 Cb, 1024 Cr --, a CU's block at 16 x (luma) / 4 x (chroma) its z-order partition index, a TU's coefficients in raster order inside it;
  * CTUs in raster order, the pictures of a stacked context one after the other.  out: n_ctu * 6144 int32. */
 int hop_levels_download(hop_ctx* ctx, int32_t* out);
+/* The one piece of state the RD search leaves behind besides the picture's data: the fraction of a bit (15 bits, TEncBinCABAC::m_fracBits & 32767) the counting coder of the
+ * RD search (TEncTop::m_cRDGoOnSbacCoder over TEncBinCABACCounter) carries when a CTU's compressCU returns.  The reference never clears it (resetBits keeps it,
+ * TEncBinCoderCABAC.cpp:163-170), and the SAO parameter decision that follows the CTU loop starts its rate count from it (TEncSampleAdaptiveOffset.cpp:594, :643: whole
+ * bits of fraction + rate), so a caller that lets the reference's SAO encoder run after hop_encode_frame sets the coder's m_fracBits to the LAST CTU's value first
+ * (oracle/enc_shim_pic.cpp); without it an SAO offset can come out different.  out: one uint16 per CTU, CTUs and pictures ordered as in hop_encode_frame's outputs. */
+int hop_rd_fraction_download(hop_ctx* ctx, uint16_t* out);
 int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates);
 /* diagnostics of the last hop_encode_frame of this process: host wall time (ms) and number of requests per kind -- 0 ME chain, 1 predictor, 2 distortion, 3 validity
  * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */

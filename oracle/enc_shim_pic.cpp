@@ -1,0 +1,203 @@
+// oracle/enc_shim_pic.cpp -- the PICTURE-level reference-side binding of include/hophip.h, compiled against the reference's own headers.
+//
+// One member of the reference encoder is re-defined:
+//   TEncCu::compressCU   TLibEncoder/TEncCu.cpp:246-264 (xCompressCU :371-892 and everything below it)
+// At the first CTU of a picture the whole picture goes through hop_encode_frame (original uploaded, RD search of every CTU on the device, decisions by the library's host
+// spine); each compressCU call then only fills the CTU's TComDataCU -- the per-partition arrays of TComDataCU.h:96-170 from hop_cu_part, the levels m_pcTrCoeffY / Cb / Cr
+// from hop_levels_download, getTotalCost / Bits / Distortion from the per-CTU outputs -- and copies the CTU's reconstruction into the picture (what xCopyYuv2Pic leaves
+// there, TEncCu.cpp:1623-1662).  Everything after it is the reference's own object code: the counting pass of TEncSlice::compressSlice, TEncSlice::encodeSlice, the loop
+// filters, SAO, the picture hash, the bitstream writer.
+// oracle/Makefile.ref links this file with the reference's objects (compressCU weakened with objcopy, nothing of the reference edited or copied) and with libhophip.so
+// into oracle/_ref/TAppEncoderPic.  That program runs on the GPU box (tests/test_gpu_encoder_pic.py): the bitstream and the reconstruction it writes must be, byte for
+// byte, those of the unmodified reference encoder (tests/golden/encoder_hop_qp32.json) -- every decision, level and reconstructed sample the entropy coder and the loop
+// filters consume came out of hop_encode_frame.
+// With -DHOP_PIC_CPU the six hop_* entries the binding calls are adapters inside this file over the CPU spine (oracle/libhop_spine_cpu.so, named by HOP_PIC_SPINE):
+// oracle/_ref/TAppEncoderPicCpu runs in the build container (tests/test_encoder_pic.py), so the marshalling below is checked without a GPU, and the CPU spine's levels and
+// partition data are pinned to the reference's bitstream as well.
+// This file never touches the CPU restatement except through those adapters.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cassert>
+#include <vector>
+#include <list>
+#include <map>
+#include <string>
+#include <sstream>
+#include <iostream>
+#include <fstream>
+#include <algorithm>
+#include <stdint.h>
+#define private public
+#define protected public
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComPic.h"
+#include "TLibEncoder/TEncCfg.h"
+#include "TLibEncoder/TEncCu.h"
+#include "TLibEncoder/TEncSbac.h"
+#include "TLibEncoder/TEncBinCoderCABAC.h"
+#undef private
+#undef protected
+#include "../include/hophip.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+// HOP_PIC_CHECK runs the reference's own RD search, whose GT search reads past the end of its reference picture buffer (TEncSearch::xExtDIFUpSamplingH under xPatternSearchGT,
+// TEncSearch.cpp:4686-): when that lands on an unmapped page the process dies -- the unmodified encoder does too, now and then.  Say so and exit with a code of its own.
+static void reference_faulted(int) { static const char m[] = "hop pic check: the reference's own code faulted\n"; if (write(2, m, sizeof(m) - 1)) {} void* bt[40]; backtrace_symbols_fd(bt, backtrace(bt, 40), 2); _exit(77); }
+
+#ifdef HOP_PIC_CPU
+#include <dlfcn.h>
+// the six entries of the library the binding uses, over the CPU spine (same argument meaning; the context is a record of the picture)
+struct hop_ctx { int w, h; std::vector<int16_t> org[3], rec[3]; };
+namespace {
+typedef long (*enc_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, void*);
+typedef long (*wpp_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, double*);
+typedef long (*lev_fn)(int32_t*, long); typedef long (*frac_fn)(uint16_t*, long);
+enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; std::string g_err = "no error";
+}
+extern "C" {
+int hop_ctx_create(hop_ctx** out, int w, int h, int bdy, int bdc, int) {
+  const char* so = getenv("HOP_PIC_SPINE");
+  void* lib = so ? dlopen(so, RTLD_NOW | RTLD_LOCAL) : NULL;
+  if (!lib) { g_err = so ? dlerror() : "HOP_PIC_SPINE names the CPU spine library"; return HOP_ERR_DEVICE; }
+  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction");
+  int (*szp)(void) = (int (*)(void))dlsym(lib, "hop_spine_sizeof_part");
+  if (!g_enc || !g_wpp || !g_lev || !g_frac || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != 8 || bdc != 8) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
+  *out = new hop_ctx(); (*out)->w = w; (*out)->h = h; return HOP_OK;
+}
+void hop_ctx_destroy(hop_ctx* c) { delete c; }
+const char* hop_last_error(const hop_ctx*) { return g_err.c_str(); }
+int hop_ctx_set_slots(hop_ctx*, int) { return HOP_OK; }
+int hop_upload_orig(hop_ctx* c, const int16_t* y, int sy, const int16_t* cb, const int16_t* cr, int sc) {
+  const int16_t* src[3] = { y, cb, cr };
+  for (int k = 0; k < 3; k++) { const int w = k ? c->w / 2 : c->w, h = k ? c->h / 2 : c->h, s = k ? sc : sy; c->org[k].resize((size_t)w * h); c->rec[k].assign((size_t)w * h, 0);
+                                for (int r = 0; r < h; r++) memcpy(&c->org[k][(size_t)r * w], src[k] + (size_t)r * s, w * 2); }
+  return HOP_OK;
+}
+int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* cost, uint32_t* bits, uint32_t* dist, hop_cu_part* parts, uint64_t* nc) {
+  if (p->plain_intra || p->first_ctus) { g_err = "the adapter covers the HOP configuration, whole pictures"; return HOP_ERR_ARG; }
+  const long n = (p->wpp || p->wavefront_lag) ? g_wpp(c->w, c->h, p->qp, p->mi_size, p->wavefront_lag, &c->org[0][0], &c->org[1][0], &c->org[2][0], p->trace_path, cost, bits, dist, parts,
+                                                      &c->rec[0][0], &c->rec[1][0], &c->rec[2][0], NULL)
+                                               : g_enc(c->w, c->h, p->qp, p->mi_size, 0, &c->org[0][0], &c->org[1][0], &c->org[2][0], p->trace_path, cost, bits, dist, parts,
+                                                      &c->rec[0][0], &c->rec[1][0], &c->rec[2][0], NULL);
+  if (n <= 0) { g_err = "the spine failed"; return HOP_ERR_DEVICE; }
+  if (nc) *nc = (uint64_t)n;
+  return HOP_OK;
+}
+int hop_levels_download(hop_ctx* c, int32_t* out) { const long n = (long)((c->w + 63) / 64) * ((c->h + 63) / 64) * 6144; return g_lev(out, n) == n ? HOP_OK : HOP_ERR_DEVICE; }
+int hop_rd_fraction_download(hop_ctx* c, uint16_t* out) { const long n = (long)((c->w + 63) / 64) * ((c->h + 63) / 64); return g_frac(out, n) == n ? HOP_OK : HOP_ERR_DEVICE; }
+int hop_recon_download(hop_ctx* c, int comp, int16_t* dst) { memcpy(dst, &c->rec[comp][0], c->rec[comp].size() * 2); return HOP_OK; }
+}
+#endif
+
+namespace {
+struct Binding {
+  hop_ctx* ctx; const TComPic* pic; int w, h, wctu, n;
+  std::vector<double> cost; std::vector<uint32_t> bits, dist; std::vector<hop_cu_part> parts; std::vector<int32_t> levels; std::vector<uint16_t> fraction; std::vector<int16_t> rec[3];
+  unsigned long pictures, ctus; unsigned long long candidates;
+  Binding() : ctx(NULL), pic(NULL), w(0), h(0), wctu(0), n(0), pictures(0), ctus(0), candidates(0) {}
+  ~Binding() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop pic binding: pictures %lu ctus %lu candidates %llu\n", pictures, ctus, candidates); if (ctx) hop_ctx_destroy(ctx); }
+  void fail(const char* what) { fprintf(stderr, "hop pic binding: %s failed: %s\n", what, hop_last_error(ctx)); exit(1); }
+  static int env_int(const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; }
+
+  // one picture through the library: TEncGOP::compressGOP has set the slice up (QP, lambda, ISS type); TEncSlice::compressSlice is about to loop over its CTUs
+  void code_picture(TEncCu* enc, TComDataCU* cu) {
+    TComSlice* sl = cu->getSlice(); TEncCfg* cfg = enc->m_pcEncCfg;
+    if (!sl->isIntraSS() || g_bitDepthY != 8 || g_bitDepthC != 8 || g_uiMaxCUWidth != 64 || g_uiMaxCUDepth != 4) { fprintf(stderr, "hop pic binding: bound for the 8-bit ISS pictures of cfg/3DHencoder_intra_main.cfg\n"); exit(1); }
+    if (!ctx) {
+      w = sl->getSPS()->getPicWidthInLumaSamples(); h = sl->getSPS()->getPicHeightInLumaSamples(); wctu = (w + 63) / 64; n = wctu * ((h + 63) / 64);
+      if (hop_ctx_create(&ctx, w, h, g_bitDepthY, g_bitDepthC, 0) != HOP_OK) fail("hop_ctx_create");
+      if (hop_ctx_set_slots(ctx, env_int("HOP_PIC_SLOTS", 16)) != HOP_OK) fail("hop_ctx_set_slots");              // the candidates of a CU side by side (no effect on the results)
+      cost.resize(n); bits.resize(n); dist.resize(n); parts.resize((size_t)n * 256); levels.resize((size_t)n * 6144); fraction.resize(n);
+      rec[0].resize((size_t)w * h); rec[1].resize((size_t)w * h / 4); rec[2].resize((size_t)w * h / 4);
+    }
+    pic = cu->getPic();
+    TComPicYuv* org = cu->getPic()->getPicYuvOrg();
+    if (hop_upload_orig(ctx, org->getLumaAddr(), org->getStride(), org->getCbAddr(), org->getCrAddr(), org->getCStride()) != HOP_OK) fail("hop_upload_orig");
+    hop_enc_params p; memset(&p, 0, sizeof(p));
+    p.qp = sl->getSliceQp(); p.mi_size = sl->getMicroImSize();
+    p.wpp = cfg->getWaveFrontsynchro() ? 1 : 0;                                                                    // TEncSlice.cpp:1027-1051: the rows' coders synchronised
+    p.wavefront_lag = p.wpp ? env_int("HOP_PIC_LAG", 5) : 0;                                                       // rows in flight together only where the reference's rows are independent
+    uint64_t nc = 0;
+    if (hop_encode_frame(ctx, &p, &cost[0], &bits[0], &dist[0], &parts[0], &nc) != HOP_OK) fail("hop_encode_frame");
+    if (hop_levels_download(ctx, &levels[0]) != HOP_OK) fail("hop_levels_download");
+    if (hop_rd_fraction_download(ctx, &fraction[0]) != HOP_OK) fail("hop_rd_fraction_download");
+    for (int k = 0; k < 3; k++) if (hop_recon_download(ctx, k, &rec[k][0]) != HOP_OK) fail("hop_recon_download");
+    pictures++; candidates += nc;
+  }
+
+  void fill(TComDataCU* c) {
+    const int addr = (int)c->getAddr(), qp = c->getSlice()->getSliceQp();
+    const hop_cu_part* pp = &parts[(size_t)addr * 256];
+    for (UInt i = 0; i < c->getTotalNumPart(); i++) {
+      const hop_cu_part& p = pp[i];
+      c->m_puhDepth[i] = p.depth; c->m_puhWidth[i] = c->m_puhHeight[i] = (UChar)(64 >> p.depth);
+      if (p.pred_mode == 15) continue;                                   // MODE_NONE: outside the picture -- initSubCU's values at the depth the quadtree left it (TEncCu.cpp:727-775)
+      c->m_pePartSize[i] = (Char)p.part_size; c->m_pePredMode[i] = (Char)p.pred_mode; c->m_skipFlag[i] = p.skip != 0;
+      c->m_pbMergeFlag[i] = p.merge_flag != 0; c->m_puhMergeIndex[i] = p.merge_idx; c->m_puhInterDir[i] = p.inter_dir;
+      c->m_acCUMvField[0].m_pcMv[i].set(p.mv[0], p.mv[1]); c->m_acCUMvField[0].m_pcMvd[i].set(p.mvd[0], p.mvd[1]); c->m_acCUMvField[0].m_piRefIdx[i] = p.ref_idx;
+      c->m_apiMVPIdx[0][i] = p.mvp_idx; c->m_apiMVPNum[0][i] = p.mvp_num;
+      c->m_gtFlag[i] = p.gt_flag != 0;
+      c->m_acCUGT0Field[0].m_pcMv[i].set(p.gt[0], p.gt[1]); c->m_acCUGT1Field[0].m_pcMv[i].set(p.gt[2], p.gt[3]);
+      c->m_acCUGT2Field[0].m_pcMv[i].set(p.gt[4], p.gt[5]); c->m_acCUGT3Field[0].m_pcMv[i].set(p.gt[6], p.gt[7]);
+      c->m_puhLumaIntraDir[i] = p.luma_dir; c->m_puhChromaIntraDir[i] = p.chroma_dir; c->m_puhTrIdx[i] = p.tr_idx;
+      for (int k = 0; k < 3; k++) { c->m_puhCbf[k][i] = p.cbf[k]; c->m_puhTransformSkip[k][i] = p.tskip[k]; }
+      c->m_phQP[i] = (Char)qp;
+    }
+    const int32_t* lv = &levels[(size_t)addr * 6144];
+    for (int k = 0; k < 4096; k++) c->m_pcTrCoeffY[k] = lv[k];
+    for (int k = 0; k < 1024; k++) { c->m_pcTrCoeffCb[k] = lv[4096 + k]; c->m_pcTrCoeffCr[k] = lv[5120 + k]; }
+    c->m_dTotalCost = cost[addr]; c->m_uiTotalBits = bits[addr]; c->m_uiTotalDistortion = dist[addr];
+    TComPicYuv* r = c->getPic()->getPicYuvRec();
+    const int x0 = (addr % wctu) * 64, y0 = (addr / wctu) * 64, bw = std::min(64, w - x0), bh = std::min(64, h - y0);
+    for (int y = 0; y < bh; y++) memcpy(r->getLumaAddr() + (size_t)(y0 + y) * r->getStride() + x0, &rec[0][(size_t)(y0 + y) * w + x0], bw * sizeof(Pel));
+    for (int y = 0; y < bh / 2; y++) { memcpy(r->getCbAddr() + (size_t)(y0 / 2 + y) * r->getCStride() + x0 / 2, &rec[1][(size_t)(y0 / 2 + y) * (w / 2) + x0 / 2], (bw / 2) * sizeof(Pel));
+                                       memcpy(r->getCrAddr() + (size_t)(y0 / 2 + y) * r->getCStride() + x0 / 2, &rec[2][(size_t)(y0 / 2 + y) * (w / 2) + x0 / 2], (bw / 2) * sizeof(Pel)); }
+    ctus++;
+  }
+} g_b;
+}
+
+extern "C" void hop_ref_orig_compress_cu(TEncCu*, TComDataCU*&);   // the reference's own definition (Makefile.ref), reached only by the diagnostic below
+namespace {
+// HOP_PIC_CHECK=1 (diagnostic): the reference's own compressCU codes the CTU first, and every field the binding is about to fill is compared with what it left
+void compare_with_reference(TEncCu* enc, TComDataCU*& cu) {
+  hop_ref_orig_compress_cu(enc, cu);
+  const int addr = (int)cu->getAddr(); const hop_cu_part* pp = &g_b.parts[(size_t)addr * 256]; const int32_t* lv = &g_b.levels[(size_t)addr * 6144];
+  int bad = 0;
+#define CMP(name, ref, ours) do { if ((long)(ref) != (long)(ours) && bad++ < 40) fprintf(stderr, "hop pic check: CTU %d part %u %s reference %ld binding %ld\n", addr, i, name, (long)(ref), (long)(ours)); } while (0)
+  for (UInt i = 0; i < cu->getTotalNumPart(); i++) {
+    const hop_cu_part& p = pp[i];
+    CMP("depth", cu->m_puhDepth[i], p.depth); CMP("width", cu->m_puhWidth[i], 64 >> p.depth);
+    if (p.pred_mode == 15) { CMP("pred_mode(outside)", cu->m_pePredMode[i], (Char)MODE_NONE); continue; }
+    CMP("part_size", cu->m_pePartSize[i], p.part_size); CMP("pred_mode", cu->m_pePredMode[i], p.pred_mode); CMP("skip", cu->m_skipFlag[i], p.skip);
+    CMP("merge_flag", cu->m_pbMergeFlag[i], p.merge_flag); CMP("merge_idx", cu->m_puhMergeIndex[i], p.merge_idx); CMP("inter_dir", cu->m_puhInterDir[i], p.inter_dir);
+    CMP("mv_x", cu->m_acCUMvField[0].m_pcMv[i].getHor(), p.mv[0]); CMP("mv_y", cu->m_acCUMvField[0].m_pcMv[i].getVer(), p.mv[1]);
+    CMP("mvd_x", cu->m_acCUMvField[0].m_pcMvd[i].getHor(), p.mvd[0]); CMP("mvd_y", cu->m_acCUMvField[0].m_pcMvd[i].getVer(), p.mvd[1]);
+    CMP("ref_idx", cu->m_acCUMvField[0].m_piRefIdx[i], p.ref_idx); CMP("mvp_idx", cu->m_apiMVPIdx[0][i], p.mvp_idx); CMP("mvp_num", cu->m_apiMVPNum[0][i], p.mvp_num);
+    CMP("gt_flag", cu->m_gtFlag[i], p.gt_flag); CMP("gt0x", cu->m_acCUGT0Field[0].m_pcMv[i].getHor(), p.gt[0]); CMP("gt3y", cu->m_acCUGT3Field[0].m_pcMv[i].getVer(), p.gt[7]);
+    CMP("luma_dir", cu->m_puhLumaIntraDir[i], p.luma_dir); CMP("chroma_dir", cu->m_puhChromaIntraDir[i], p.chroma_dir); CMP("tr_idx", cu->m_puhTrIdx[i], p.tr_idx);
+    for (int k = 0; k < 3; k++) { CMP("cbf", cu->m_puhCbf[k][i], p.cbf[k]); CMP("tskip", cu->m_puhTransformSkip[k][i], p.tskip[k]); }
+    for (int k = 0; k < 16; k++) CMP("level_y", cu->m_pcTrCoeffY[i * 16 + k], lv[i * 16 + k]);
+    for (int k = 0; k < 4; k++) { CMP("level_cb", cu->m_pcTrCoeffCb[i * 4 + k], lv[4096 + i * 4 + k]); CMP("level_cr", cu->m_pcTrCoeffCr[i * 4 + k], lv[5120 + i * 4 + k]); }
+  }
+  { UInt i = 0; CMP("bits", cu->m_uiTotalBits, g_b.bits[addr]); CMP("distortion", cu->m_uiTotalDistortion, g_b.dist[addr]); CMP("cost", (long)cu->m_dTotalCost, (long)g_b.cost[addr]);
+    CMP("rd coder fraction", ((TEncBinCABAC*)enc->m_pcRDGoOnSbacCoder->m_pcBinIf)->m_fracBits & 32767, g_b.fraction[addr]); }
+#undef CMP
+  fprintf(stderr, "hop pic check: CTU %d: %d differences\n", addr, bad);
+}
+}
+
+Void TEncCu::compressCU(TComDataCU*& rpcCU)
+{
+  static const bool check = getenv("HOP_PIC_CHECK") != NULL;
+  static bool once = false; if (check && !once) { once = true; signal(SIGSEGV, reference_faulted); }
+  if (g_b.pic != rpcCU->getPic() || rpcCU->getAddr() == 0) g_b.code_picture(this, rpcCU);
+  if (check) compare_with_reference(this, rpcCU);
+  g_b.fill(rpcCU);
+  // the state the RD search leaves in the encoder besides the CTU's data: the counting coder's carried fraction, which the SAO parameter decision after the CTU loop
+  // inherits (include/hophip.h: hop_rd_fraction_download)
+  ((TEncBinCABAC*)m_pcRDGoOnSbacCoder->m_pcBinIf)->m_fracBits = g_b.fraction[rpcCU->getAddr()];
+}

@@ -234,6 +234,8 @@ class CpuBackend : public BatchInner {
 
 // HOP_SPEC_SLOTS=<n> (tests): the SS/GT candidates of a CU side by side in n candidate slots (EncConfig::spec_slots), as hop_ctx_set_slots + hop_encode_frame do on the device
 static std::vector<int32_t> g_last_levels;   // the levels of the last picture(s) coded through an entry below (slot 0: the decided CUs), for hop_spine_cpu_last_levels
+static std::vector<uint16_t> g_last_fraction;   // ... and the RD coder's carried fraction per CTU, for hop_spine_cpu_last_rd_fraction
+static void keep_fraction(const Encoder& e, bool append = false) { if (!append) g_last_fraction.clear(); g_last_fraction.insert(g_last_fraction.end(), e.ctu_rd_fraction.begin(), e.ctu_rd_fraction.end()); }
 static void keep_levels(const CpuBackend& be, bool append = false) { const size_t n = (size_t)((be.W + 63) / 64) * ((be.H + 63) / 64) * 6144; if (!append) g_last_levels.clear(); g_last_levels.insert(g_last_levels.end(), be.coefpic.begin(), be.coefpic.begin() + n); }
 static int spec_slots_env() { const char* e = getenv("HOP_SPEC_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }
 
@@ -254,7 +256,7 @@ long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, con
   enc.encode_frame(first_ctus);
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
-  keep_levels(be);
+  keep_levels(be); keep_fraction(enc);
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
@@ -279,7 +281,7 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   try { if (lag > 0) enc.encode_frame_wavefront(use, lag); else enc.encode_frame(0); delete lg; } catch (...) { if (enc.trace) fclose(enc.trace); return -1; }
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
-  keep_levels(be);
+  keep_levels(be); keep_fraction(enc);
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
@@ -326,7 +328,7 @@ long hop_spine_cpu_encode_stack(int w, int h, int n_pic, int pitch, int qp, int 
     if (ctu_dist) memcpy(ctu_dist + (size_t)k * n, &e.ctu_dist[0], n * 4);
     if (parts) memcpy((char*)parts + (size_t)k * n * 256 * sizeof(Part), &e.pic[0], e.pic.size() * sizeof(Part));
     if (rec_y) memcpy(rec_y + (size_t)k * w * h, &bes[k]->rec[0][0], (size_t)w * h * 2);
-    keep_levels(*bes[k], k > 0);
+    keep_levels(*bes[k], k > 0); keep_fraction(e, k > 0);
     total += (long)e.n_candidates;
   }
   if (rounds_requests) { rounds_requests[0] = (double)encs[0]->batch_rounds; rounds_requests[1] = (double)encs[0]->batch_requests; }
@@ -344,7 +346,7 @@ long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16
   enc.encode_frame(0);
   if (enc.trace) fclose(enc.trace);
   const int n = enc.n_ctu();
-  keep_levels(be);
+  keep_levels(be); keep_fraction(enc);
   if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
   if (ctu_bits) memcpy(ctu_bits, &enc.ctu_bits[0], n * 4);
   if (ctu_dist) memcpy(ctu_dist, &enc.ctu_dist[0], n * 4);
@@ -356,6 +358,7 @@ long hop_spine_cpu_encode_plain(int w, int h, int qp, int bit_depth, const int16
 }
 // the levels of the picture(s) the last entry coded: per CTU 6144 TCoeff in the reference's layout, as hop_levels_download hands them out; returns the count
 long hop_spine_cpu_last_levels(int32_t* out, long max_n) { const long n = (long)g_last_levels.size(); if (out && n <= max_n) memcpy(out, &g_last_levels[0], (size_t)n * 4); return n; }
+long hop_spine_cpu_last_rd_fraction(uint16_t* out, long max_n) { const long n = (long)g_last_fraction.size(); if (out && n <= max_n) memcpy(out, &g_last_fraction[0], (size_t)n * 2); return n; }
 int hop_spine_sizeof_part(void) { return (int)sizeof(Part); }
 int hop_spine_sizeof_coder(void) { return (int)sizeof(Coder); }
 

@@ -152,3 +152,43 @@ def ref_load_planes(L, pl):
         assert st.value == buf.shape[1]
         base = ctypes.addressof(p.contents) - (m * st.value + m) * 2
         ctypes.memmove(base, buf.ctypes.data, buf.nbytes)
+
+
+# The HOP all-intra configuration (the settings cfg/3DHencoder_intra_main.cfg selects) as command-line options of the encoder application, so that a program built from
+# the reference can be run where the reference tree itself is absent (the GPU box).  tests/test_encoder_pic.py checks here that they give the configuration file's bitstream.
+HOP_ENCODER_OPTIONS = {
+    "MaxCUWidth": 64, "MaxCUHeight": 64, "MaxPartitionDepth": 4, "QuadtreeTULog2MaxSize": 5, "QuadtreeTULog2MinSize": 2, "QuadtreeTUMaxDepthInter": 3, "QuadtreeTUMaxDepthIntra": 3,
+    "IntraPeriod": 1, "HoloscopicIntra": 1, "MIMergeCand": 1, "DecodingRefreshType": 0, "GOPSize": 1,
+    "FastSearch": 0, "SearchRange": 128, "HadamardME": 1, "FEN": 1, "FDM": 1,
+    "MaxDeltaQP": 0, "MaxCuDQPDepth": 0, "DeltaQpRD": 0, "RDOQ": 1, "RDOQTS": 1,
+    "DeblockingFilterControlPresent": 0, "LoopFilterOffsetInPPS": 0, "LoopFilterDisable": 0, "LoopFilterBetaOffset_div2": 0, "LoopFilterTcOffset_div2": 0,
+    "InternalBitDepth": 8, "SAO": 1, "AMP": 1, "TransformSkip": 1, "TransformSkipFast": 1, "SAOLcuBoundary": 0,
+    "SliceMode": 0, "SliceArgument": 1500, "LFCrossSliceBoundaryFlag": 1, "PCMEnabledFlag": 0,
+    "UniformSpacingIdc": 0, "NumTileColumnsMinus1": 0, "NumTileRowsMinus1": 0, "LFCrossTileBoundaryFlag": 1, "WaveFrontSynchro": 0,
+    "ScalingList": 0, "TransquantBypassEnableFlag": 0,
+}
+
+
+def hop_encoder_args(W, H, qp=32, mi=16, **over):
+    o = dict(HOP_ENCODER_OPTIONS, **over)
+    return ["--%s=%s" % kv for kv in o.items()] + ["-i", "in.yuv", "-wdt", str(W), "-hgt", str(H), "-fr", "30", "-f", "1", "-q", str(qp), "--MIsize=%d" % mi,
+                                                   "--SEIDecodedPictureHash=1", "-b", "s.bin", "-o", "rec.yuv"]
+
+
+# the pictures of the picture-level binding tests (golden: tests/golden/encoder_hop_pic.json, made by oracle/make_golden21.py with the unmodified reference encoder)
+PIC_CASES = {
+    "64x64_raster":    {"W": 64, "H": 64, "seed": 1234, "frames": 1, "over": {}, "extra": []},
+    "192x128_raster":  {"W": 192, "H": 128, "seed": 7, "frames": 1, "over": {}, "extra": []},
+    "192x128_wpp":     {"W": 192, "H": 128, "seed": 7, "frames": 1, "over": {"WaveFrontSynchro": 1, "WaveFrontSubstreams": 2}, "extra": []},
+    "200x104_raster":  {"W": 200, "H": 104, "seed": 11, "frames": 1, "over": {}, "extra": []},                 # neither dimension a multiple of the CTU: partial CTUs right and below
+    "448x192_wpp":     {"W": 448, "H": 192, "seed": 3, "frames": 1, "over": {"WaveFrontSynchro": 1, "WaveFrontSubstreams": 3}, "extra": []},
+    "128x64_2frames":  {"W": 128, "H": 64, "seed": 5, "frames": 2, "over": {}, "extra": ["-f", "2"]},          # the context and the binding's buffers reused for a second picture
+}
+
+
+def pic_case_input(c):
+    raw = b""
+    for f in range(c["frames"]):
+        Y, Cb, Cr = lenslet(c["W"], c["H"], 16, c["seed"] + 100 * f)
+        raw += Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes()
+    return raw

@@ -1,0 +1,27 @@
+"""GPU: the reference encoder with its whole RD search replaced by hop_encode_frame writes the reference's bitstream.
+
+oracle/_ref/TAppEncoderPic is the reference encoder application, built in the build container from the reference's sources by oracle/Makefile.ref, with ONE member replaced
+(oracle/enc_shim_pic.cpp, the picture-level binding of INTEGRATION.md section 4): TEncCu::compressCU.  A picture goes through libhophip.so -- hop_ctx_create, hop_upload_orig,
+hop_encode_frame, hop_levels_download, hop_recon_download, hop_rd_fraction_download -- and each CTU's TComDataCU is filled from what came back.  The counting pass, the
+entropy coder of encodeSlice, deblocking, SAO, the picture hash and the NAL writer are the reference's own object code; nothing of the CPU restatement is linked into the
+program.  The bitstream and the reconstruction it writes must be byte-identical to those of the UNMODIFIED reference encoder (tests/golden/encoder_hop_pic.json, made in the
+build container by oracle/make_golden21.py): raster order and WaveFrontSynchro (coded as a wavefront with the rows' requests batched), pictures with partial CTUs on the
+right and below, two pictures through one context.  A wrong level, flag, vector or reconstructed sample anywhere changes the md5."""
+import os
+
+import pytest
+
+from hoputil import PIC_CASES, ROOT
+from test_encoder_pic import check, run_binding
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPic")
+
+
+@pytest.mark.parametrize("key", list(PIC_CASES))
+def test_reference_encoder_over_the_library_writes_the_reference_bitstream(key):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/TAppEncoderPic was not built (it is built where the reference tree is present and travels with the snapshot)")
+    got, counts = run_binding(EXE, key, {})
+    check(key, got, counts)

@@ -9,7 +9,7 @@ import pytest
 
 from hoputil import ROOT
 from hoputil import lenslet
-from test_spine_cpu import FRAMES, FRAMES_WPP, PLAIN, check_against_golden, cpu_last_levels, frame, key_of, levels_match_cbf, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
+from test_spine_cpu import FRAMES, FRAMES_WPP, PLAIN, check_against_golden, cpu_last_levels, cpu_last_rd_fraction, frame, key_of, levels_match_cbf, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +45,7 @@ def test_encode_frame_equals_the_reference_encoder(W, H, seed, sharp, slots):
     # the levels of the chosen CUs (what encodeSlice would code): equal to the CPU spine's, and consistent with the cbf flags
     lv = ctx.levels_download()
     assert np.array_equal(lv, cpu_last_levels(Lc, len(cost))) and levels_match_cbf(lv, parts.view(np.dtype(parts.dtype.descr))) > 0
+    assert np.array_equal(ctx.rd_fraction_download(), cpu_last_rd_fraction(Lc, len(cost)))
     m = 80
     assert np.array_equal(ctx.ssref_download(0)[m:m + H, m:m + W], rec[0])
     print(key_of(W, H, seed, sharp), nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
@@ -69,7 +70,7 @@ def test_encode_frame_wavefront_equals_the_reference_with_wavefront_synchro(W, H
     _, _, _, _, rec, _, _ = run_cpu_wpp(Lc, W, H, Y, Cb, Cr, 0)
     for c in range(3):
         assert np.array_equal(ctx.recon_download(c), rec[c]), c
-    assert np.array_equal(ctx.levels_download(), cpu_last_levels(Lc, len(cost)))
+    assert np.array_equal(ctx.levels_download(), cpu_last_levels(Lc, len(cost))) and np.array_equal(ctx.rd_fraction_download(), cpu_last_rd_fraction(Lc, len(cost)))
     print(key_of(W, H, seed, False), "wpp lag", lag, nc, "candidates", {k: tuple(v.values()) for k, v in ctx.encode_stats().items()})
     ctx.close()
 
@@ -112,7 +113,7 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
     pv = parts.view(np.dtype(parts.dtype.descr))
     check_against_golden(G, "192x128_seed7_wpp", cost[:n], bits[:n], dist[:n], pv[:n], text0)
     rec = [ctx.unstack(ctx.recon_download(c), c > 0) for c in range(3)]
-    levels = ctx.levels_download()
+    levels = ctx.levels_download(); fraction = ctx.rd_fraction_download()
     ss = ctx.ssref_download(0)
     stats = ctx.encode_stats()
     ctx.close()
@@ -124,7 +125,7 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
         assert parts[k * n:(k + 1) * n].tobytes() == p1.tobytes(), k
         for c in range(3):
             assert np.array_equal(rec[c][k], one.recon_download(c)), (k, c)
-        assert np.array_equal(levels[k * n:(k + 1) * n], one.levels_download()), k
+        assert np.array_equal(levels[k * n:(k + 1) * n], one.levels_download()) and np.array_equal(fraction[k * n:(k + 1) * n], one.rd_fraction_download()), k
         # the picture's padded SS plane (margin 80 on every side) inside the stack's plane
         s1 = one.ssref_download(0)
         assert np.array_equal(ss[k * ctx.pitch:k * ctx.pitch + H + 160], s1), k

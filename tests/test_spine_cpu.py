@@ -146,6 +146,15 @@ def test_spine_plain_intra_configurations(bd, qp):
     check_against_golden(G, plain_key(bd, qp), cost, bits, dist, parts, text)
 
 
+def cpu_last_rd_fraction(L, n_ctu):
+    """per CTU the fraction of a bit the RD search's counting coder carried when the CTU was done, for the picture(s) of the last hop_spine_cpu_* call"""
+    L.hop_spine_cpu_last_rd_fraction.restype = ctypes.c_long
+    L.hop_spine_cpu_last_rd_fraction.argtypes = [ctypes.c_void_p, ctypes.c_long]
+    a = np.zeros(n_ctu, np.uint16)
+    assert L.hop_spine_cpu_last_rd_fraction(a.ctypes.data, a.size) == a.size
+    return a
+
+
 def cpu_last_levels(L, n_ctu):
     """the levels of the picture(s) the last hop_spine_cpu_* call coded: (n_ctu, 6144) int32"""
     L.hop_spine_cpu_last_levels.restype = ctypes.c_long

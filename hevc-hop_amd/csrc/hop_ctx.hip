@@ -115,7 +115,7 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
 // A second handle on the same pictures with its own stream and work areas: requests issued through different views run concurrently on the device.  The caller keeps
 // their rectangles apart (the RD spine's CTU rows are a wavefront lag apart) and destroys the views before the parent.
 int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
-  if (!parent || !out || parent->is_view) return hop_set_err(parent, HOP_ERR_ARG, "hop_ctx_create_view: bad argument");
+  if (!parent || !out) return hop_set_err(parent, HOP_ERR_ARG, "hop_ctx_create_view: bad argument");          // (a view of a view is one more view of the same pictures)
   *out = nullptr;
   hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
   c->pic_w = parent->pic_w; c->pic_h = parent->pic_h; c->bd_y = parent->bd_y; c->bd_c = parent->bd_c; c->device = parent->device;

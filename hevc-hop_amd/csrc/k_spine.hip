@@ -10,6 +10,7 @@
 #include <string.h>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <functional>
 #include <string>
 #include <vector>
@@ -475,8 +476,28 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   memset(g_stat_ms, 0, sizeof(g_stat_ms)); memset(g_stat_calls, 0, sizeof(g_stat_calls));
   hopspine::LogBackend* lg = (lanes.empty() && getenv("HOP_SPINE_LOG")) ? new hopspine::LogBackend(&be, getenv("HOP_SPINE_LOG")) : nullptr;   // debugging aid: every request and its answer
   hopspine::BatchInner* use = lg ? (hopspine::BatchInner*)lg : (hopspine::BatchInner*)&be;
+  // a stacked context in groups (HOP_SPINE_GROUPS, default 1): the pictures are dealt to G groups, each with a backend on a view of the context (streams, pinned buffers and
+  // work areas of its own) and a rendezvous of its own on its own worker threads, all running side by side -- one group packs and unpacks while another one's launches
+  // run.  The pictures stay independent of each other, so the results do not depend on G.
+  int G = 1;
+  if (n_pic > 1 && !lg && !c->prof_on) { if (const char* e = getenv("HOP_SPINE_GROUPS")) G = atoi(e); if (G > 8) G = 8; if (G > n_pic) G = n_pic; if (G < 1) G = 1; }
+  std::vector<hop_ctx*> gviews; std::vector<HipBackend*> gbe(1, &be);
+  if (G > 1) {
+    if (!c->stash) { HIPCHK(c, hipMalloc((void**)&c->stash, (size_t)STASH_SLOTS * STASH_SAMPLES * 2)); c->stash_slots = STASH_SLOTS; }
+    int ks = 4; if (const char* e = getenv("HOP_SPINE_STREAMS")) ks = atoi(e);
+    bool ok = true;
+    for (int g = 1; g < G && ok; g++) {
+      hop_ctx* v = nullptr;
+      if (hop_ctx_create_view(c, &v) != HOP_OK) { ok = false; break; }
+      gviews.push_back(v);
+      HipBackend* b = new HipBackend(v); gbe.push_back(b);
+      ok = b->ok() && (c->slots <= 0 || p->plain_intra || ks <= 1 || b->add_streams(ks > 8 ? 8 : ks));
+    }
+    if (!ok) { for (size_t g = 1; g < gbe.size(); g++) delete gbe[g]; for (auto v : gviews) hop_ctx_destroy(v); return hop_set_err(c, HOP_ERR_DEVICE, "hop_encode_frame: could not create the %d picture groups", G); }
+  }
+  std::vector<int> g_off(G + 1, 0); for (int g = 0; g < G; g++) g_off[g + 1] = g_off[g] + n_pic / G + (g < n_pic % G ? 1 : 0);
   std::vector<hopspine::Encoder*> encs;
-  for (int k = 0; k < n_pic; k++) { cfg.y_origin = k * c->sub_pitch; encs.push_back(new hopspine::Encoder(cfg, use)); }
+  for (int k = 0, g = 0; k < n_pic; k++) { while (k >= g_off[g + 1]) g++; cfg.y_origin = k * c->sub_pitch; encs.push_back(new hopspine::Encoder(cfg, G > 1 ? (hopspine::Backend*)gbe[g] : (hopspine::Backend*)use)); }
   hopspine::Encoder& enc = *encs[0];
   std::vector<FILE*> tfs;                                                  // candidate traces: trace_path, for the pictures of a stack trace_path.<k>
   if (p->trace_path && p->trace_path[0]) for (int k = 0; k < n_pic; k++) {
@@ -485,13 +506,34 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   }
   int rc = HOP_OK;
   try {
-    if (n_pic > 1) { hopspine::Encoder::encode_pictures_wavefront(encs.data(), n_pic, use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; g_stat_ms[13] = enc.batch_run_s * 1e3; }
+    if (G > 1) {
+      const int cols = enc.n_ctu() / ((pic_h + 63) / 64), rows = (pic_h + 63) / 64, lag = p->wavefront_lag > cols ? cols : p->wavefront_lag, rif = (cols + lag - 1) / lag + 1, lanes_per_pic = rif < rows ? rif : rows;
+      int hw = (int)std::thread::hardware_concurrency(); if (hw > 16) hw = 16; if (hw < 1) hw = 1;
+      const int threads = hw / G > 2 ? hw / G : 2;
+      be.begin_frame();                                                    // once for all groups: the SS reference back to the sentinel
+      std::vector<int> grc(G, HOP_OK); std::vector<std::thread> th;
+      for (int g = 0; g < G; g++) th.emplace_back([&, g]() {
+        (void)hipSetDevice(c->device);
+        try { hopspine::Encoder::encode_pictures_wavefront(encs.data() + g_off[g], g_off[g + 1] - g_off[g], gbe[g], p->wavefront_lag, g_off[g] * lanes_per_pic, false, threads); }
+        catch (const Bail& b) { grc[g] = b.code; } catch (...) { grc[g] = HOP_ERR_STATE; }
+      });
+      for (auto& t : th) t.join();
+      for (int g = 0; g < G; g++) {
+        const hopspine::Encoder& e0 = *encs[g_off[g]];
+        g_stat_calls[14] += (double)e0.batch_rounds; g_stat_calls[15] += (double)e0.batch_requests; g_stat_ms[14] += e0.batch_serve_s * 1e3; if (e0.batch_run_s * 1e3 > g_stat_ms[13]) g_stat_ms[13] = e0.batch_run_s * 1e3;
+        if (grc[g] != HOP_OK && rc == HOP_OK) { rc = grc[g]; if (g > 0 && gviews[g - 1]->err[0] && !c->err[0]) strncpy(c->err, gviews[g - 1]->err, sizeof(c->err) - 1); }
+      }
+      if (rc != HOP_OK && !c->err[0]) rc = HOP_ERR_STATE;
+    }
+    else if (n_pic > 1) { hopspine::Encoder::encode_pictures_wavefront(encs.data(), n_pic, use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; g_stat_ms[13] = enc.batch_run_s * 1e3; }
     else if (!lanes.empty()) enc.encode_frame_wavefront_direct(lanes.data(), (int)lanes.size(), p->wavefront_lag);
     else if (p->wavefront_lag > 0) { enc.encode_frame_wavefront(use, p->wavefront_lag); g_stat_calls[14] = (double)enc.batch_rounds; g_stat_calls[15] = (double)enc.batch_requests; g_stat_ms[14] = enc.batch_serve_s * 1e3; g_stat_ms[13] = enc.batch_run_s * 1e3; }
     else enc.encode_frame(p->first_ctus);
   } catch (const Bail& b) { rc = b.code; } catch (...) { rc = c->err[0] ? HOP_ERR_DEVICE : HOP_ERR_STATE; }
   delete lg;
   for (FILE* f : tfs) if (f) fclose(f);
+  for (size_t g = 1; g < gbe.size(); g++) delete gbe[g];
+  for (auto v : gviews) hop_ctx_destroy(v);
   for (auto b : vbe) delete b;
   for (auto v : views) { if (rc != HOP_OK && v->err[0] && !c->err[0]) strncpy(c->err, v->err, sizeof(c->err) - 1); hop_ctx_destroy(v); }
   if (rc == HOP_OK) {

@@ -1428,18 +1428,18 @@ class FiberPool : public Backend {
 
 void Encoder::encode_frame_wavefront(BatchInner* inner, int lag, int) { Encoder* e = this; wavefront_many(&e, 1, inner, NULL, 0, lag); }
 void Encoder::encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag) { Encoder* e = this; wavefront_many(&e, 1, NULL, lanes, n_lanes, lag); }
-void Encoder::encode_pictures_wavefront(Encoder* const* encs, int n, BatchInner* inner, int lag) { wavefront_many(encs, n, inner, NULL, 0, lag); }
+void Encoder::encode_pictures_wavefront(Encoder* const* encs, int n, BatchInner* inner, int lag, int lane_base, bool begin, int threads) { wavefront_many(encs, n, inner, NULL, 0, lag, lane_base, begin, threads); }
 
 // n pictures of equal geometry side by side (n = 1: one picture): one thread per CTU row of every picture, all of them on one rendezvous
-void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner, Backend* const* lanes, int n_lanes, int lag) {
+void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner, Backend* const* lanes, int n_lanes, int lag, int lane_base, bool begin, int threads) {
   if (n_pic <= 0 || (!inner && n_lanes <= 0) || lag <= 0) throw 1;
   Encoder& E0 = *encs[0];
   const int rows = E0.hctu_, cols = E0.wctu_;
   for (int p = 0; p < n_pic; p++) if (!encs[p]->cfg_.wpp || encs[p]->hctu_ != rows || encs[p]->wctu_ != cols) throw 1;
   if (lag > cols) lag = cols;                                          // lag = cols is raster order already
   const int rif = (cols + lag - 1) / lag + 1;                          // rows of one picture that can be in flight together (+ 1 spare)
-  if ((long)n_pic * (rif < rows ? rif : rows) > SPINE_LANES) throw 1;
-  if (inner) inner->begin_frame(); else lanes[0]->begin_frame();
+  if (lane_base < 0 || lane_base + (long)n_pic * (rif < rows ? rif : rows) > SPINE_LANES) throw 1;
+  if (begin) { if (inner) inner->begin_frame(); else lanes[0]->begin_frame(); }
   Coder init; memset(&init, 0, sizeof(init));
   hop_cabac_init(&init.r, E0.cfg_.slice_type, E0.cfg_.qp); hop_cabac_cu_init(&init.c, E0.cfg_.slice_type, E0.cfg_.qp); hop_cabac_split_init(init.split, E0.cfg_.slice_type, E0.cfg_.qp);
   for (int p = 0; p < n_pic; p++) {
@@ -1449,6 +1449,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
   }
   if (inner) {                                                          // the batching form: rows as fibers on a few worker threads
     int T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; if (T < 1) T = 1;
+    if (threads > 0) T = threads;
     if (const char* e = getenv("HOP_SPINE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) T = v; }
     if (T > rows * n_pic) T = rows * n_pic;
     FiberPool pool(inner, T);
@@ -1461,7 +1462,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     for (int p = 0; p < n_pic; p++) for (int r = 0; r < rows; r++) {
       pool.add([&, p, r]() {
         Encoder& E = *encs[p];
-        const int lane = p * (rif < rows ? rif : rows) + r % rif;
+        const int lane = lane_base + p * (rif < rows ? rif : rows) + r % rif;
         CtuWorker* w = new CtuWorker(E, lane, &pool);
         int c = 0;
         try {

@@ -169,9 +169,11 @@ class Encoder {
   void encode_frame_wavefront_direct(Backend* const* lanes, int n_lanes, int lag = 5);
   // n independent pictures of equal geometry (their configurations differ in y_origin: a stacked context) coded side by side: the rows of all of them on one
   // rendezvous, so that a batch serves CTUs of every picture; each picture's result is what encode_frame_wavefront gives for it alone
-  static void encode_pictures_wavefront(Encoder* const* encs, int n, BatchInner* inner, int lag = 5);
+  // lane_base: first lane number (stash slots are per lane) when several groups of pictures run side by side on one context, each on a backend of its own;
+  // begin = false: the caller has called begin_frame() for all of them
+  static void encode_pictures_wavefront(Encoder* const* encs, int n, BatchInner* inner, int lag = 5, int lane_base = 0, bool begin = true, int threads = 0);
  private:
-  static void wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner, Backend* const* lanes, int n_lanes, int lag);
+  static void wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner, Backend* const* lanes, int n_lanes, int lag, int lane_base = 0, bool begin = true, int threads = 0);
  public:
   const EncConfig& config() const { return cfg_; }
   int n_ctu() const { return wctu_ * hctu_; }

@@ -95,11 +95,13 @@ def test_encode_frame_plain_intra_configurations(bd, qp):
     ctx.close()
 
 
-@pytest.mark.parametrize("slots", SLOTS)
-def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
+@pytest.mark.parametrize("slots,groups", [(0, 1), (16, 1), (16, 2)])
+def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots, groups, monkeypatch):
     """three independent pictures in one stacked context (hop_ctx_set_stack), coded side by side by one hop_encode_frame: picture 0 against the reference's golden run,
-    the others against contexts of their own; reconstruction and SS reference (with the margins each picture extends at ITS edges) included"""
+    the others against contexts of their own; reconstruction and SS reference (with the margins each picture extends at ITS edges) included.  groups = 2: the pictures
+    dealt to two groups with a backend, streams and worker threads each (HOP_SPINE_GROUPS), running side by side"""
     hp = _hp()
+    monkeypatch.setenv("HOP_SPINE_GROUPS", str(groups))
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
     W, H, lag = 192, 128, 5
     pics = [frame(W, H, 7, False), frame(W, H, 8, False), frame(W, H, 11, False)]
@@ -132,4 +134,4 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots):
         one.close()
     rv = stats["rendezvous"]
     print("stack of 3:", nc, "candidates, avg batch", rv["requests"] / max(1, rv["rounds"]))
-    assert rv["requests"] / max(1, rv["rounds"]) > 2.0
+    assert rv["requests"] / max(1, rv["rounds"]) > (2.0 if groups == 1 else 1.2)

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """tools/enc_time.py W H [lag [streams [pictures [slots]]]] -- time hop_encode_frame on a synthetic lenslet (pitch 15, seed 2 like bench.py): raster order, or the wavefront with batching."""
 import importlib.util, json, os, sys, time
 import numpy as np

@@ -105,6 +105,11 @@ class EncParams(ctypes.Structure):       # hop_enc_params
                 ("plain_intra", ctypes.c_int32), ("streams", ctypes.c_int32), ("trace_path", ctypes.c_char_p)]
 
 
+class DeblockParams(ctypes.Structure):   # hop_deblock_params
+    _fields_ = [("qp", ctypes.c_int32), ("beta_offset_div2", ctypes.c_int32), ("tc_offset_div2", ctypes.c_int32), ("cb_qp_offset", ctypes.c_int32), ("cr_qp_offset", ctypes.c_int32),
+                ("disable", ctypes.c_int32)]
+
+
 _I16P = ctypes.POINTER(ctypes.c_int16)
 
 
@@ -117,7 +122,8 @@ MIRRORS = {"hop_pu_job": PU_JOB_DTYPE, "hop_pu_result": PU_RESULT_DTYPE, "hop_pr
            "hop_intra_job": INTRA_JOB_DTYPE, "hop_rdoq_job": RDOQ_JOB_DTYPE, "hop_coeff_bits_job": COEFF_BITS_JOB_DTYPE, "hop_tu_rd_job": TU_RD_JOB_DTYPE,
            "hop_tu_rd_result": TU_RD_RESULT_DTYPE, "hop_intra_modes_job": INTRA_MODES_JOB_DTYPE, "hop_intra_modes_result": INTRA_MODES_RESULT_DTYPE, "hop_rqt_job": RQT_JOB_DTYPE,
            "hop_rqt_result": RQT_RESULT_DTYPE, "hop_cu_syntax": CU_SYNTAX_DTYPE, "hop_intra_cu_syntax": INTRA_CU_SYNTAX_DTYPE, "hop_intra_rqt_opt": INTRA_RQT_OPT_DTYPE,
-           "hop_intra_search_job": INTRA_SEARCH_JOB_DTYPE, "hop_intra_search_result": INTRA_SEARCH_RESULT_DTYPE, "hop_cu_part": CU_PART_DTYPE, "hop_enc_params": EncParams}
+           "hop_intra_search_job": INTRA_SEARCH_JOB_DTYPE, "hop_intra_search_result": INTRA_SEARCH_RESULT_DTYPE, "hop_cu_part": CU_PART_DTYPE, "hop_enc_params": EncParams,
+           "hop_deblock_params": DeblockParams}
 
 
 def mirror_size(m):
@@ -328,6 +334,15 @@ class Context:
         self.L.hop_levels_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self._chk(self.L.hop_levels_download(self.h, a.ctypes.data), "hop_levels_download")
         return a
+
+    def deblock_frame(self, parts, qp, beta_offset_div2=0, tc_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0, disable=0):
+        """hop_deblock_frame: the deblocking filter over the resident reconstruction picture(s), in place; parts as encode_frame returned them"""
+        parts = np.ascontiguousarray(parts)
+        n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures
+        assert parts.nbytes == n * 256 * CU_PART_DTYPE.itemsize, (parts.shape, parts.dtype, n)
+        p = DeblockParams(qp, beta_offset_div2, tc_offset_div2, cb_qp_offset, cr_qp_offset, disable)
+        self.L.hop_deblock_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_deblock_frame(self.h, ctypes.byref(p), parts.ctypes.data), "hop_deblock_frame")
 
     def rd_fraction_download(self):
         """hop_rd_fraction_download: per CTU the fraction of a bit the RD search's counting coder carries when the CTU is done"""

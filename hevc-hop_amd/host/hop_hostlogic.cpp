@@ -283,6 +283,7 @@ int hop_sizeof(const char* name) {
   S(hop_intra_class);
   S(hop_cu_part);
   S(hop_enc_params);
+  S(hop_deblock_params);
 #undef S
   return -1;
 }

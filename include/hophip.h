@@ -668,6 +668,17 @@ int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cos
  * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */
 void hop_encode_stats(double ms[16], double calls[16]);
 
+/* ---- after the search: the loop filter over the resident reconstruction ---- */
+/* replaces: TComLoopFilter::loopFilterPic (TLibCommon/TComLoopFilter.cpp:129-153; xDeblockCU :166-227, xGetBoundaryStrengthSingle :395-519, xEdgeFilterLuma :522-632,
+ * xEdgeFilterChroma :635-737) as TEncGOP::compressGOP calls it after the CTU loop (TLibEncoder/TEncGOP.cpp:1192-1197): the context's reconstruction picture (what
+ * hop_encode_frame left there, or hop_recon_upload) is filtered in place -- all vertical edges of the 8x8 grid, then all horizontal ones --; hop_recon_download then gives
+ * the picture SAO starts from.  parts: the per-partition data of the picture(s) as hop_encode_frame returned it (256 hop_cu_part per CTU; the pictures of a stacked context
+ * one after the other): CU depth, partition shape, transform depth, prediction mode, luma cbf, vector and reference index are read.  qp: the slice QP every CU is coded at
+ * (MaxDeltaQP 0); offsets: slice_beta_offset_div2 / slice_tc_offset_div2 (-6..6), pps_cb_qp_offset / pps_cr_qp_offset; disable: slice_deblocking_filter_disabled_flag
+ * (the picture is left as it is).  One slice, one tile, no PCM / lossless CUs: the configurations of the path. */
+typedef struct { int32_t qp, beta_offset_div2, tc_offset_div2, cb_qp_offset, cr_qp_offset, disable; } hop_deblock_params;
+int hop_deblock_frame(hop_ctx* ctx, const hop_deblock_params* params, const hop_cu_part* parts);
+
 /* ---- profiling (bench.py roofline): HIP events around every kernel launch on the context stream ---- */
 #define HOP_K_SS_SEARCH 0
 #define HOP_K_FRAC      1
@@ -679,7 +690,8 @@ void hop_encode_stats(double ms[16], double calls[16]);
 #define HOP_K_INTRA     7
 #define HOP_K_RDOQ      8
 #define HOP_K_CABAC     9
-#define HOP_K_COUNT     10
+#define HOP_K_DEBLOCK   10
+#define HOP_K_COUNT     11
 int hop_profile_enable(hop_ctx* ctx, int on);
 /* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
 int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);

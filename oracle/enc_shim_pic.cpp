@@ -37,6 +37,7 @@
 #include "TLibEncoder/TEncCu.h"
 #include "TLibEncoder/TEncSbac.h"
 #include "TLibEncoder/TEncBinCoderCABAC.h"
+#include "TLibCommon/TComLoopFilter.h"
 #undef private
 #undef protected
 #include "../include/hophip.h"
@@ -55,16 +56,17 @@ namespace {
 typedef long (*enc_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, void*);
 typedef long (*wpp_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, double*);
 typedef long (*lev_fn)(int32_t*, long); typedef long (*frac_fn)(uint16_t*, long);
-enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; std::string g_err = "no error";
+typedef int (*dbk_fn)(int, int, int, int, int, int, int, int, int, const void*, int16_t*, int16_t*, int16_t*);
+enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; dbk_fn g_dbk = NULL; std::string g_err = "no error";
 }
 extern "C" {
 int hop_ctx_create(hop_ctx** out, int w, int h, int bdy, int bdc, int) {
   const char* so = getenv("HOP_PIC_SPINE");
   void* lib = so ? dlopen(so, RTLD_NOW | RTLD_LOCAL) : NULL;
   if (!lib) { g_err = so ? dlerror() : "HOP_PIC_SPINE names the CPU spine library"; return HOP_ERR_DEVICE; }
-  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction");
+  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction"); g_dbk = (dbk_fn)dlsym(lib, "hop_o_deblock_frame");
   int (*szp)(void) = (int (*)(void))dlsym(lib, "hop_spine_sizeof_part");
-  if (!g_enc || !g_wpp || !g_lev || !g_frac || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != 8 || bdc != 8) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
+  if (!g_enc || !g_wpp || !g_lev || !g_frac || !g_dbk || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != 8 || bdc != 8) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
   *out = new hop_ctx(); (*out)->w = w; (*out)->h = h; return HOP_OK;
 }
 void hop_ctx_destroy(hop_ctx* c) { delete c; }
@@ -88,6 +90,10 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* cost, uint32_t
 }
 int hop_levels_download(hop_ctx* c, int32_t* out) { const long n = (long)((c->w + 63) / 64) * ((c->h + 63) / 64) * 6144; return g_lev(out, n) == n ? HOP_OK : HOP_ERR_DEVICE; }
 int hop_rd_fraction_download(hop_ctx* c, uint16_t* out) { const long n = (long)((c->w + 63) / 64) * ((c->h + 63) / 64); return g_frac(out, n) == n ? HOP_OK : HOP_ERR_DEVICE; }
+int hop_deblock_frame(hop_ctx* c, const hop_deblock_params* p, const hop_cu_part* parts) {
+  return g_dbk(c->w, c->h, 8, p->qp, p->beta_offset_div2, p->tc_offset_div2, p->cb_qp_offset, p->cr_qp_offset, p->disable, parts, &c->rec[0][0], &c->rec[1][0], &c->rec[2][0]) == 0 ? HOP_OK : HOP_ERR_DEVICE;
+}
+int hop_recon_upload(hop_ctx* c, int comp, const int16_t* src) { memcpy(&c->rec[comp][0], src, c->rec[comp].size() * 2); return HOP_OK; }
 int hop_recon_download(hop_ctx* c, int comp, int16_t* dst) { memcpy(dst, &c->rec[comp][0], c->rec[comp].size() * 2); return HOP_OK; }
 }
 #endif
@@ -96,9 +102,9 @@ namespace {
 struct Binding {
   hop_ctx* ctx; const TComPic* pic; int w, h, wctu, n;
   std::vector<double> cost; std::vector<uint32_t> bits, dist; std::vector<hop_cu_part> parts; std::vector<int32_t> levels; std::vector<uint16_t> fraction; std::vector<int16_t> rec[3];
-  unsigned long pictures, ctus; unsigned long long candidates;
-  Binding() : ctx(NULL), pic(NULL), w(0), h(0), wctu(0), n(0), pictures(0), ctus(0), candidates(0) {}
-  ~Binding() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop pic binding: pictures %lu ctus %lu candidates %llu\n", pictures, ctus, candidates); if (ctx) hop_ctx_destroy(ctx); }
+  unsigned long pictures, ctus, deblocked; unsigned long long candidates;
+  Binding() : ctx(NULL), pic(NULL), w(0), h(0), wctu(0), n(0), pictures(0), ctus(0), deblocked(0), candidates(0) {}
+  ~Binding() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop pic binding: pictures %lu ctus %lu candidates %llu deblocked %lu\n", pictures, ctus, candidates, deblocked); if (ctx) hop_ctx_destroy(ctx); }
   void fail(const char* what) { fprintf(stderr, "hop pic binding: %s failed: %s\n", what, hop_last_error(ctx)); exit(1); }
   static int env_int(const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; }
 
@@ -200,4 +206,116 @@ Void TEncCu::compressCU(TComDataCU*& rpcCU)
   // the state the RD search leaves in the encoder besides the CTU's data: the counting coder's carried fraction, which the SAO parameter decision after the CTU loop
   // inherits (include/hophip.h: hop_rd_fraction_download)
   ((TEncBinCABAC*)m_pcRDGoOnSbacCoder->m_pcBinIf)->m_fracBits = g_b.fraction[rpcCU->getAddr()];
+}
+
+// HOP_PIC_DEBLOCK=1: TComLoopFilter::loopFilterPic (TLibCommon/TComLoopFilter.cpp:129-153) replaced as well -- hop_deblock_frame filters the reconstruction the context
+// still holds from hop_encode_frame, with the partition data that call returned; the picture's planes are then the library's.  SAO, the picture hash and the bitstream
+// follow in the reference's own code, so the md5 of rec.yuv and of the bitstream (SAO parameters, hash SEI) pin the filter.  With HOP_PIC_CHECK the reference's own
+// loopFilterPic runs too and the planes are compared sample by sample.
+extern "C" void hop_ref_orig_loop_filter_pic(TComLoopFilter*, TComPic*);
+namespace {
+// HOP_PIC_LF_FUZZ="seed:qp:beta_offset_div2:tc_offset_div2:cb_qp_offset:cr_qp_offset": before the filters run, the picture's partition data and reconstruction are
+// replaced by random ones -- a random coding quadtree per CTU (forced splits at the picture border), intra / inter CUs with every partition shape the size allows, random
+// transform trees with random luma cbf, small vectors around the 4-quarter-sample threshold, now and then no reference index; planes of flat 8x8 blocks with small steps
+// between them plus noise, so that every branch of the decisions (no filter / weak / strong, second sample on either side) is taken somewhere -- written into the
+// reference's TComDataCU / TComPicYuv and into the library's context alike.  Both filters then run on the same input (HOP_PIC_CHECK compares).  HOP_PIC_LF_DUMP=<file>:
+// the input and the REFERENCE's output are written out: the fixtures of tests/golden/deblock_ref.npz (oracle/make_golden22.py) for the GPU test.
+struct Fuzz {
+  uint64_t s; int w, h, wctu;
+  uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
+  int below(int n) { return (int)(next() % (uint32_t)n); }
+  static int z(int ux, int uy) { int v = 0; for (int b = 0; b < 4; b++) v |= (((ux >> b) & 1) << (2 * b)) | (((uy >> b) & 1) << (2 * b + 1)); return v; }
+  void tu_tree(hop_cu_part* ctu, int ux, int uy, int su, int t, int min_t, int max_t) {
+    if (t < min_t || (t < max_t && su > 1 && below(100) < 45)) { const int h = su >> 1; for (int q = 0; q < 4; q++) tu_tree(ctu, ux + (q & 1) * h, uy + (q >> 1) * h, h, t + 1, min_t, max_t); return; }
+    const int coded = below(100) < 50;
+    for (int y = 0; y < su; y++) for (int x = 0; x < su; x++) { hop_cu_part& p = ctu[z(ux + x, uy + y)]; p.tr_idx = (uint8_t)t; p.cbf[0] = (uint8_t)(coded ? ((1 << (t + 1)) - 1) : below(1 << t)); p.cbf[1] = p.cbf[2] = (uint8_t)below(2); }
+  }
+  void cu_tree(hop_cu_part* ctu, int cx, int cy, int ux, int uy, int su, int d) {
+    const int x = cx + ux * 4, y = cy + uy * 4, size = su * 4;
+    if (x >= w || y >= h) { for (int yy = 0; yy < su; yy++) for (int xx = 0; xx < su; xx++) { hop_cu_part& p = ctu[z(ux + xx, uy + yy)]; memset(&p, 0, sizeof(p)); p.depth = (uint8_t)d; p.pred_mode = 15; p.part_size = 15; p.ref_idx = -1; } return; }
+    const bool crosses = x + size > w || y + size > h;
+    if (crosses || (d < 3 && below(100) < 55)) { const int hh = su >> 1; for (int q = 0; q < 4; q++) cu_tree(ctu, cx, cy, ux + (q & 1) * hh, uy + (q >> 1) * hh, hh, d + 1); return; }
+    const bool intra = below(100) < 35;
+    int ps = 0;
+    if (intra) ps = (d == 3 && below(2)) ? 3 : 0; else { ps = below(size >= 16 ? 8 : 3); if (ps == 3) ps = 0; }
+    for (int yy = 0; yy < su; yy++) for (int xx = 0; xx < su; xx++) {
+      hop_cu_part& p = ctu[z(ux + xx, uy + yy)]; memset(&p, 0, sizeof(p));
+      p.depth = (uint8_t)d; p.pred_mode = intra ? 1 : 0; p.part_size = (uint8_t)ps; p.ref_idx = -1; p.luma_dir = 1; p.chroma_dir = 36; p.mvp_idx = p.mvp_num = -1;
+    }
+    if (!intra) {                                                          // one vector per PU
+      const int npu = ps == 0 ? 1 : 2;
+      int16_t mv[2][2]; int8_t ref[2];
+      for (int k = 0; k < npu; k++) { mv[k][0] = (int16_t)(below(13) - 6); mv[k][1] = (int16_t)(below(13) - 6); ref[k] = below(100) < 6 ? -1 : 0; }
+      for (int yy = 0; yy < su; yy++) for (int xx = 0; xx < su; xx++) {
+        int k = 0;
+        switch (ps) { case 1: k = yy >= su / 2; break; case 2: k = xx >= su / 2; break; case 4: k = yy >= su / 4; break; case 5: k = yy >= su - su / 4; break; case 6: k = xx >= su / 4; break; case 7: k = xx >= su - su / 4; break; default: break; }
+        hop_cu_part& p = ctu[z(ux + xx, uy + yy)]; p.mv[0] = mv[k][0]; p.mv[1] = mv[k][1]; p.ref_idx = ref[k]; p.inter_dir = 1;
+      }
+    }
+    int max_t = 0; while (max_t < 3 && (size >> (max_t + 1)) >= 4) max_t++;
+    tu_tree(ctu, ux, uy, su, 0, ((intra && ps == 3) || size == 64) ? 1 : 0, max_t < 2 ? max_t : 2);
+  }
+};
+void fuzz_picture(TComPic* pic, const char* spec) {
+  long v[6] = { 1, 32, 0, 0, 0, 0 }; { const char* q = spec; for (int k = 0; k < 6 && q && *q; k++) { v[k] = strtol(q, (char**)&q, 10); if (*q == ':') q++; } }
+  Fuzz f; f.s = 0x9E3779B97F4A7C15ull ^ (uint64_t)v[0] * 0x100000001B3ull; f.w = g_b.w; f.h = g_b.h; f.wctu = g_b.wctu;
+  for (int k = 0; k < 8; k++) f.next();
+  TComSlice* sl = pic->getSlice(0);
+  sl->setSliceQp((Int)v[1]); sl->setDeblockingFilterBetaOffsetDiv2((Int)v[2]); sl->setDeblockingFilterTcOffsetDiv2((Int)v[3]); sl->getPPS()->setChromaCbQpOffset((Int)v[4]); sl->getPPS()->setChromaCrQpOffset((Int)v[5]);
+  for (int a = 0; a < g_b.n; a++) f.cu_tree(&g_b.parts[(size_t)a * 256], (a % g_b.wctu) * 64, (a / g_b.wctu) * 64, 0, 0, 16, 0);
+  for (int c = 0; c < 3; c++) {
+    const int pw = c ? g_b.w / 2 : g_b.w, ph = c ? g_b.h / 2 : g_b.h, bs = c ? 4 : 8, bw = (pw + bs - 1) / bs;
+    std::vector<int> base((size_t)bw * ((ph + bs - 1) / bs));
+    for (size_t i = 0; i < base.size(); i++) { const int left = (i % bw) ? base[i - 1] : 60 + f.below(130); const int step = f.below(100) < 55 ? f.below(9) - 4 : f.below(41) - 20; base[i] = std::min(250, std::max(5, left + step)); }
+    const int noise = 1 + f.below(3);
+    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) g_b.rec[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, base[(size_t)(y / bs) * bw + x / bs] + f.below(2 * noise + 1) - noise));
+    if (hop_recon_upload(g_b.ctx, c, &g_b.rec[c][0]) != HOP_OK) g_b.fail("hop_recon_upload");
+  }
+  std::fill(g_b.levels.begin(), g_b.levels.end(), 0);
+  for (int a = 0; a < g_b.n; a++) { TComDataCU* cu = pic->getCU(a); cu->initCU(pic, a); g_b.fill(cu); }
+}
+void dump_fixture(const char* path, const hop_deblock_params& p, const std::vector<int16_t> before[3], TComPicYuv* after) {
+  FILE* f = fopen(path, "ab"); if (!f) return;
+  const int32_t hd[9] = { g_b.w, g_b.h, p.qp, p.beta_offset_div2, p.tc_offset_div2, p.cb_qp_offset, p.cr_qp_offset, g_b.n, (int32_t)sizeof(hop_cu_part) };
+  fwrite(hd, 4, 9, f); fwrite(&g_b.parts[0], sizeof(hop_cu_part), g_b.parts.size(), f);
+  for (int c = 0; c < 3; c++) fwrite(&before[c][0], 2, before[c].size(), f);
+  for (int y = 0; y < g_b.h; y++) fwrite(after->getLumaAddr() + (size_t)y * after->getStride(), 2, g_b.w, f);
+  for (int y = 0; y < g_b.h / 2; y++) fwrite(after->getCbAddr() + (size_t)y * after->getCStride(), 2, g_b.w / 2, f);
+  for (int y = 0; y < g_b.h / 2; y++) fwrite(after->getCrAddr() + (size_t)y * after->getCStride(), 2, g_b.w / 2, f);
+  fclose(f);
+}
+}
+Void TComLoopFilter::loopFilterPic(TComPic* pcPic)
+{
+  static const bool on = getenv("HOP_PIC_DEBLOCK") != NULL, check = getenv("HOP_PIC_CHECK") != NULL;
+  if (!on || g_b.pic != pcPic || !g_b.ctx) { hop_ref_orig_loop_filter_pic(this, pcPic); return; }
+  if (const char* fz = getenv("HOP_PIC_LF_FUZZ")) fuzz_picture(pcPic, fz);
+  std::vector<int16_t> before[3]; if (getenv("HOP_PIC_LF_DUMP") || getenv("HOP_PIC_LF_FUZZ")) for (int k = 0; k < 3; k++) { before[k].resize(g_b.rec[k].size()); if (hop_recon_download(g_b.ctx, k, &before[k][0]) != HOP_OK) g_b.fail("hop_recon_download"); }
+  TComSlice* sl = pcPic->getSlice(0);
+  hop_deblock_params p; memset(&p, 0, sizeof(p));
+  p.qp = sl->getSliceQp(); p.beta_offset_div2 = sl->getDeblockingFilterBetaOffsetDiv2(); p.tc_offset_div2 = sl->getDeblockingFilterTcOffsetDiv2();
+  p.cb_qp_offset = sl->getPPS()->getChromaCbQpOffset(); p.cr_qp_offset = sl->getPPS()->getChromaCrQpOffset(); p.disable = sl->getDeblockingFilterDisable() ? 1 : 0;
+  if (hop_deblock_frame(g_b.ctx, &p, &g_b.parts[0]) != HOP_OK) g_b.fail("hop_deblock_frame");
+  for (int k = 0; k < 3; k++) if (hop_recon_download(g_b.ctx, k, &g_b.rec[k][0]) != HOP_OK) g_b.fail("hop_recon_download");
+  TComPicYuv* r = pcPic->getPicYuvRec();
+  const int w = g_b.w, h = g_b.h;
+  if (check) {
+    hop_ref_orig_loop_filter_pic(this, pcPic);
+    if (const char* dp = getenv("HOP_PIC_LF_DUMP")) dump_fixture(dp, p, before, r);
+    long bad = 0;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) if (r->getLumaAddr()[(size_t)y * r->getStride() + x] != g_b.rec[0][(size_t)y * w + x] && bad++ < 10) fprintf(stderr, "hop pic check: deblocked luma (%d, %d) reference %d library %d\n", x, y, r->getLumaAddr()[(size_t)y * r->getStride() + x], g_b.rec[0][(size_t)y * w + x]);
+    for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) {
+      if (r->getCbAddr()[(size_t)y * r->getCStride() + x] != g_b.rec[1][(size_t)y * (w / 2) + x] && bad++ < 10) fprintf(stderr, "hop pic check: deblocked Cb (%d, %d) differs\n", x, y);
+      if (r->getCrAddr()[(size_t)y * r->getCStride() + x] != g_b.rec[2][(size_t)y * (w / 2) + x] && bad++ < 10) fprintf(stderr, "hop pic check: deblocked Cr (%d, %d) differs\n", x, y);
+    }
+    fprintf(stderr, "hop pic check: deblocked picture: %ld differences\n", bad);
+    if (getenv("HOP_PIC_LF_FUZZ")) {                                       // the random picture is not an encodable one: stop here
+      long changed = 0; if (!before[0].empty()) for (int k = 0; k < 3; k++) for (size_t i = 0; i < before[k].size(); i++) changed += before[k][i] != g_b.rec[k][i];
+      fprintf(stderr, "hop pic check: fuzz: the filter changed %ld samples\n", changed); fflush(stderr); _exit(bad ? 1 : 0);
+    }
+  }
+  for (int y = 0; y < h; y++) memcpy(r->getLumaAddr() + (size_t)y * r->getStride(), &g_b.rec[0][(size_t)y * w], w * sizeof(Pel));
+  for (int y = 0; y < h / 2; y++) { memcpy(r->getCbAddr() + (size_t)y * r->getCStride(), &g_b.rec[1][(size_t)y * (w / 2)], (w / 2) * sizeof(Pel));
+                                    memcpy(r->getCrAddr() + (size_t)y * r->getCStride(), &g_b.rec[2][(size_t)y * (w / 2)], (w / 2) * sizeof(Pel)); }
+  g_b.deblocked++;
 }

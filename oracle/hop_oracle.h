@@ -192,6 +192,17 @@ int hop_o_coef_scan_idx(int width, int is_luma, int is_intra, int dir);
 int hop_o_rdoq(const int32_t* src, int32_t* dst, int log2_size, int comp, int is_intra, int scan_idx, int tr_depth,
                int qp_scaled, int bit_depth, int sign_hide, double lambda, const hop_o_estbits* eb, uint32_t* abs_sum);
 
+/* ---- after the search: the deblocking filter, hop_oracle_lf.c ---- */
+/* one 4x4 unit of a finished picture: the layout of hop_cu_part (include/hophip.h) */
+typedef struct {
+  uint8_t depth, pred_mode, part_size, skip, merge_flag, merge_idx, gt_flag, inter_dir;
+  int8_t  ref_idx, mvp_idx, mvp_num; uint8_t luma_dir, chroma_dir, tr_idx;
+  uint8_t cbf[3], tskip[3];
+  int16_t mv[2], mvd[2], gt[8];
+} hop_o_cu_part;
+int hop_o_deblock_frame(int w, int h, int bit_depth, int qp, int beta_offset_div2, int tc_offset_div2, int cb_qp_offset, int cr_qp_offset, int disable,
+                        const hop_o_cu_part* parts, int16_t* y, int16_t* cb, int16_t* cr);
+
 #ifdef __cplusplus
 }
 #endif

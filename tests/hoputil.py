@@ -192,3 +192,36 @@ def pic_case_input(c):
         Y, Cb, Cr = lenslet(c["W"], c["H"], 16, c["seed"] + 100 * f)
         raw += Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes()
     return raw
+
+
+# ---- deblocking: fixtures from the reference's own loop filter (tests/golden/deblock_ref.npz, oracle/make_golden22.py) and random pictures ----
+def deblock_cases():
+    G = np.load(os.path.join(ROOT, "tests", "golden", "deblock_ref.npz"))
+    keys = sorted(set(k.split("/")[0] for k in G.files))
+    out = []
+    for k in keys:
+        W, H, qp, beta, tc, cbo, cro = [int(v) for v in G[k + "/geo"]]
+        planes_in = [G[k + "/in_" + n].astype(np.int16).reshape((H, W) if n == "y" else (H // 2, W // 2)) for n in ("y", "cb", "cr")]
+        planes_out = [G[k + "/out_" + n].astype(np.int16).reshape((H, W) if n == "y" else (H // 2, W // 2)) for n in ("y", "cb", "cr")]
+        out.append((k, W, H, (qp, beta, tc, cbo, cro), np.ascontiguousarray(G[k + "/parts"]), planes_in, planes_out))
+    return out
+
+
+def oracle_deblock(W, H, params, parts, planes, bit_depth=8, disable=0):
+    """hop_o_deblock_frame on copies of the planes; parts: (n_ctu, 256, 44) uint8 or the structured array of hop_cu_part"""
+    O = oracle()
+    p = [np.ascontiguousarray(a, np.int16).copy() for a in planes]
+    parts = np.ascontiguousarray(parts)
+    O.hop_o_deblock_frame.argtypes = [ctypes.c_int] * 9 + [ctypes.c_void_p] * 4
+    assert O.hop_o_deblock_frame(W, H, bit_depth, *[int(v) for v in params], disable, parts.ctypes.data, p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data) == 0
+    return p
+
+
+def tile_deblock_case(case, nx, ny):
+    """a picture of nx x ny copies of a CTU-aligned fixture picture (partition data and planes side by side): the seams are new edges between unrelated CUs"""
+    _, W, H, params, parts, pin, _ = case
+    assert W % 64 == 0 and H % 64 == 0
+    wc, hc = W // 64, H // 64
+    P = parts.reshape(hc, wc, 256, -1)
+    big = np.ascontiguousarray(np.tile(P, (ny, nx, 1, 1))).reshape(ny * hc * nx * wc, 256, -1)
+    return W * nx, H * ny, params, big, [np.ascontiguousarray(np.tile(a, (ny, nx))) for a in pin]

@@ -54,6 +54,17 @@ def test_reference_encoder_over_the_cpu_spine_writes_the_reference_bitstream(key
     check(key, got, counts)
 
 
+def test_reference_encoder_with_the_restated_deblocking_filter():
+    """HOP_PIC_DEBLOCK: loopFilterPic replaced as well (here by the restatement, oracle/hop_oracle_lf.c): same bitstream, same reconstruction"""
+    if not os.path.isdir(REF):
+        pytest.skip("the reference tree is not present (GPU box)")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhop_spine_cpu.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j4", "_ref/TAppEncoderPicCpu"], stdout=subprocess.DEVNULL)
+    got, counts = run_binding(os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu"), "200x104_raster", {"HOP_PIC_SPINE": os.path.join(ROOT, "oracle", "libhop_spine_cpu.so"), "HOP_PIC_DEBLOCK": "1"})
+    assert counts["deblocked"] == 1
+    check("200x104_raster", got, counts)
+
+
 def test_golden_of_the_binding_agrees_with_the_configuration_file():
     """the options of hoputil.HOP_ENCODER_OPTIONS select the configuration of cfg/3DHencoder_intra_main.cfg: the two goldens made with one and with the other agree where they
     hold the same picture"""

@@ -25,3 +25,14 @@ def test_reference_encoder_over_the_library_writes_the_reference_bitstream(key):
         pytest.skip("oracle/_ref/TAppEncoderPic was not built (it is built where the reference tree is present and travels with the snapshot)")
     got, counts = run_binding(EXE, key, {})
     check(key, got, counts)
+
+
+@pytest.mark.parametrize("key", ["200x104_raster", "448x192_wpp", "128x64_2frames"])
+def test_reference_encoder_with_the_library_deblocking_too(key):
+    """HOP_PIC_DEBLOCK: TComLoopFilter::loopFilterPic replaced as well, by hop_deblock_frame on the reconstruction the context holds; SAO, the hash and the bitstream are the
+    reference's and see the library's deblocked picture: same md5s"""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/TAppEncoderPic was not built")
+    got, counts = run_binding(EXE, key, {"HOP_PIC_DEBLOCK": "1"})
+    assert counts["deblocked"] == PIC_CASES[key]["frames"]
+    check(key, got, counts)

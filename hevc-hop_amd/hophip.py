@@ -105,6 +105,13 @@ class EncParams(ctypes.Structure):       # hop_enc_params
                 ("plain_intra", ctypes.c_int32), ("streams", ctypes.c_int32), ("trace_path", ctypes.c_char_p)]
 
 
+SAO_PARAM_DTYPE = np.dtype([("mode", "i1"), ("type", "i1"), ("aux", "i1"), ("pad", "i1"), ("offset", "i1", 32)])          # hop_sao_param
+
+
+class SaoParams(ctypes.Structure):       # hop_sao_params
+    _fields_ = [("lambda", ctypes.c_double * 3), ("enabled", ctypes.c_int32 * 3), ("slice_type", ctypes.c_int32), ("qp", ctypes.c_int32), ("rd_fraction", ctypes.c_uint32)]
+
+
 class DeblockParams(ctypes.Structure):   # hop_deblock_params
     _fields_ = [("qp", ctypes.c_int32), ("beta_offset_div2", ctypes.c_int32), ("tc_offset_div2", ctypes.c_int32), ("cb_qp_offset", ctypes.c_int32), ("cr_qp_offset", ctypes.c_int32),
                 ("disable", ctypes.c_int32)]
@@ -123,7 +130,7 @@ MIRRORS = {"hop_pu_job": PU_JOB_DTYPE, "hop_pu_result": PU_RESULT_DTYPE, "hop_pr
            "hop_tu_rd_result": TU_RD_RESULT_DTYPE, "hop_intra_modes_job": INTRA_MODES_JOB_DTYPE, "hop_intra_modes_result": INTRA_MODES_RESULT_DTYPE, "hop_rqt_job": RQT_JOB_DTYPE,
            "hop_rqt_result": RQT_RESULT_DTYPE, "hop_cu_syntax": CU_SYNTAX_DTYPE, "hop_intra_cu_syntax": INTRA_CU_SYNTAX_DTYPE, "hop_intra_rqt_opt": INTRA_RQT_OPT_DTYPE,
            "hop_intra_search_job": INTRA_SEARCH_JOB_DTYPE, "hop_intra_search_result": INTRA_SEARCH_RESULT_DTYPE, "hop_cu_part": CU_PART_DTYPE, "hop_enc_params": EncParams,
-           "hop_deblock_params": DeblockParams}
+           "hop_deblock_params": DeblockParams, "hop_sao_param": SAO_PARAM_DTYPE, "hop_sao_params": SaoParams}
 
 
 def mirror_size(m):
@@ -343,6 +350,30 @@ class Context:
         p = DeblockParams(qp, beta_offset_div2, tc_offset_div2, cb_qp_offset, cr_qp_offset, disable)
         self.L.hop_deblock_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self._chk(self.L.hop_deblock_frame(self.h, ctypes.byref(p), parts.ctypes.data), "hop_deblock_frame")
+
+    def _n_ctu(self):
+        return ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures
+
+    def sao_stats(self):
+        """hop_sao_stats: (n_ctu, 3, 5, 32, 2) int32 -- per CTU, component, type, class: count and sum of (original - reconstruction)"""
+        a = np.zeros((self._n_ctu(), 3, 5, 32, 2), np.int32)
+        self.L.hop_sao_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_sao_stats(self.h, a.ctypes.data), "hop_sao_stats")
+        return a
+
+    def sao_frame(self, lambdas, slice_type, qp, rd_fraction, enabled=(1, 1, 1)):
+        """hop_sao_frame: statistics, decision, offsets for the resident picture(s); returns the coded parameters (n_ctu, 3) SAO_PARAM_DTYPE"""
+        p = SaoParams((ctypes.c_double * 3)(*lambdas), (ctypes.c_int32 * 3)(*enabled), slice_type, qp, rd_fraction)
+        coded = np.zeros((self._n_ctu(), 3), SAO_PARAM_DTYPE)
+        self.L.hop_sao_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_sao_frame(self.h, ctypes.byref(p), coded.ctypes.data), "hop_sao_frame")
+        return coded
+
+    def sao_apply(self, recon):
+        recon = np.ascontiguousarray(recon)
+        assert recon.nbytes == self._n_ctu() * 3 * SAO_PARAM_DTYPE.itemsize
+        self.L.hop_sao_apply.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_sao_apply(self.h, recon.ctypes.data), "hop_sao_apply")
 
     def rd_fraction_download(self):
         """hop_rd_fraction_download: per CTU the fraction of a bit the RD search's counting coder carries when the CTU is done"""

@@ -284,6 +284,8 @@ int hop_sizeof(const char* name) {
   S(hop_cu_part);
   S(hop_enc_params);
   S(hop_deblock_params);
+  S(hop_sao_param);
+  S(hop_sao_params);
 #undef S
   return -1;
 }

@@ -679,6 +679,32 @@ void hop_encode_stats(double ms[16], double calls[16]);
 typedef struct { int32_t qp, beta_offset_div2, tc_offset_div2, cb_qp_offset, cr_qp_offset, disable; } hop_deblock_params;
 int hop_deblock_frame(hop_ctx* ctx, const hop_deblock_params* params, const hop_cu_part* parts);
 
+/* Sample adaptive offset, the encoder side (TEncGOP.cpp:1748-1758): statistics of the deblocked picture against the original, the per-CTU parameter decision, the
+ * offsets applied.  hop_sao_param: one component of one CTU, as SAOOffset (TLibCommon/TypeDef.h:351-368): mode 0 off, 1 new, 2 merge; type: new: 0..3 edge offset
+ * 0 / 90 / 135 / 45 degrees, 4 band offset; merge: 0 left, 1 above; aux: sao_band_position; offset: per edge class (0 full valley, 1 half valley, 2 plain = 0, 3 half peak,
+ * 4 full peak) or per band (32). */
+typedef struct { int8_t mode, type, aux, pad; int8_t offset[32]; } hop_sao_param;
+typedef struct {
+  double  lambda[3];      /* TComSlice::getLambdas(): Y, Cb, Cr */
+  int32_t enabled[3];     /* slice_sao_luma_flag / slice_sao_chroma_flag as decidePicParams left them (TEncSampleAdaptiveOffset.cpp:354-379) */
+  int32_t slice_type;     /* as hop_cabac_init: the initial state of the two SAO contexts */
+  int32_t qp;
+  uint32_t rd_fraction;   /* the RD coder's carried fraction after the picture's last CTU (hop_rd_fraction_download) */
+} hop_sao_params;
+/* replaces: TEncSampleAdaptiveOffset::getStatistics (TLibEncoder/TEncSampleAdaptiveOffset.cpp:305-352, getBlkStats :862-1383; SAOLcuBoundary 0) between the context's
+ * reconstruction picture (deblocked: hop_deblock_frame) and the resident original.  stats (host): per CTU, component, type (5) and class (32) the pair count, sum of
+ * (original - reconstruction), int32: n_ctu x 3 x 5 x 32 x 2; the pictures of a stacked context one after the other. */
+int hop_sao_stats(hop_ctx* ctx, int32_t* stats);
+/* replaces: TEncSampleAdaptiveOffset::decideBlkParams (:754-860) for one picture of n_ctu CTUs: coded = what encodeSlice writes (SAOBlkParam per CTU: 3 hop_sao_param),
+ * recon = the same with merges resolved and offsets scaled (what offsetCTU applies).  Host only. */
+int hop_sao_decide(int n_ctu, int ctus_per_row, int bit_depth, const int32_t* stats, const hop_sao_params* params, hop_sao_param* coded, hop_sao_param* recon);
+/* replaces: TComSampleAdaptiveOffset::offsetCTU for every CTU (TLibCommon/TComSampleAdaptiveOffset.cpp:655-707, offsetBlock :365-653): recon (host, 3 per CTU) applied
+ * to the context's reconstruction picture in place (the kernel reads an untouched copy, as the reference reads its m_tempPicYuv). */
+int hop_sao_apply(hop_ctx* ctx, const hop_sao_param* recon);
+/* the three steps for the picture(s) of the context: coded (n_ctu x 3 per picture) out; afterwards hop_recon_download gives the final reconstruction.
+ * replaces: TEncSampleAdaptiveOffset::SAOProcess (:251-283) after decidePicParams. */
+int hop_sao_frame(hop_ctx* ctx, const hop_sao_params* params, hop_sao_param* coded);
+
 /* ---- profiling (bench.py roofline): HIP events around every kernel launch on the context stream ---- */
 #define HOP_K_SS_SEARCH 0
 #define HOP_K_FRAC      1
@@ -691,7 +717,8 @@ int hop_deblock_frame(hop_ctx* ctx, const hop_deblock_params* params, const hop_
 #define HOP_K_RDOQ      8
 #define HOP_K_CABAC     9
 #define HOP_K_DEBLOCK   10
-#define HOP_K_COUNT     11
+#define HOP_K_SAO       11
+#define HOP_K_COUNT     12
 int hop_profile_enable(hop_ctx* ctx, int on);
 /* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
 int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);

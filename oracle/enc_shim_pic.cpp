@@ -38,6 +38,7 @@
 #include "TLibEncoder/TEncSbac.h"
 #include "TLibEncoder/TEncBinCoderCABAC.h"
 #include "TLibCommon/TComLoopFilter.h"
+#include "TLibEncoder/TEncSampleAdaptiveOffset.h"
 #undef private
 #undef protected
 #include "../include/hophip.h"
@@ -57,16 +58,18 @@ typedef long (*enc_fn)(int, int, int, int, int, const int16_t*, const int16_t*, 
 typedef long (*wpp_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, double*);
 typedef long (*lev_fn)(int32_t*, long); typedef long (*frac_fn)(uint16_t*, long);
 typedef int (*dbk_fn)(int, int, int, int, int, int, int, int, int, const void*, int16_t*, int16_t*, int16_t*);
-enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; dbk_fn g_dbk = NULL; std::string g_err = "no error";
+typedef int (*sst_fn)(int, int, int, const int16_t* const*, const int16_t* const*, int32_t*); typedef int (*sap_fn)(int, int, int, const int16_t* const*, const void*, int16_t* const*);
+typedef int (*sdc_fn)(int, int, int, const int32_t*, const hop_sao_params*, hop_sao_param*, hop_sao_param*);
+enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; dbk_fn g_dbk = NULL; sst_fn g_sst = NULL; sap_fn g_sap = NULL; sdc_fn g_sdc = NULL; std::string g_err = "no error";
 }
 extern "C" {
 int hop_ctx_create(hop_ctx** out, int w, int h, int bdy, int bdc, int) {
   const char* so = getenv("HOP_PIC_SPINE");
   void* lib = so ? dlopen(so, RTLD_NOW | RTLD_LOCAL) : NULL;
   if (!lib) { g_err = so ? dlerror() : "HOP_PIC_SPINE names the CPU spine library"; return HOP_ERR_DEVICE; }
-  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction"); g_dbk = (dbk_fn)dlsym(lib, "hop_o_deblock_frame");
+  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction"); g_dbk = (dbk_fn)dlsym(lib, "hop_o_deblock_frame"); g_sst = (sst_fn)dlsym(lib, "hop_o_sao_stats"); g_sap = (sap_fn)dlsym(lib, "hop_o_sao_apply"); g_sdc = (sdc_fn)dlsym(lib, "hop_sao_decide");
   int (*szp)(void) = (int (*)(void))dlsym(lib, "hop_spine_sizeof_part");
-  if (!g_enc || !g_wpp || !g_lev || !g_frac || !g_dbk || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != 8 || bdc != 8) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
+  if (!g_enc || !g_wpp || !g_lev || !g_frac || !g_dbk || !g_sst || !g_sap || !g_sdc || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != 8 || bdc != 8) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
   *out = new hop_ctx(); (*out)->w = w; (*out)->h = h; return HOP_OK;
 }
 void hop_ctx_destroy(hop_ctx* c) { delete c; }
@@ -93,6 +96,17 @@ int hop_rd_fraction_download(hop_ctx* c, uint16_t* out) { const long n = (long)(
 int hop_deblock_frame(hop_ctx* c, const hop_deblock_params* p, const hop_cu_part* parts) {
   return g_dbk(c->w, c->h, 8, p->qp, p->beta_offset_div2, p->tc_offset_div2, p->cb_qp_offset, p->cr_qp_offset, p->disable, parts, &c->rec[0][0], &c->rec[1][0], &c->rec[2][0]) == 0 ? HOP_OK : HOP_ERR_DEVICE;
 }
+int hop_sao_stats(hop_ctx* c, int32_t* stats) { const int16_t* s[3] = { &c->rec[0][0], &c->rec[1][0], &c->rec[2][0] }; const int16_t* o[3] = { &c->org[0][0], &c->org[1][0], &c->org[2][0] }; return g_sst(c->w, c->h, 8, s, o, stats) == 0 ? HOP_OK : HOP_ERR_DEVICE; }
+int hop_sao_frame(hop_ctx* c, const hop_sao_params* p, hop_sao_param* coded) {      // the product's three steps: statistics and offsetting by the restatement, the decision by the product's host logic
+  const int wctu = (c->w + 63) / 64, n = wctu * ((c->h + 63) / 64);
+  std::vector<int32_t> st((size_t)n * 3 * 5 * 32 * 2); std::vector<hop_sao_param> recon((size_t)n * 3);
+  if (hop_sao_stats(c, &st[0]) != HOP_OK || g_sdc(n, wctu, 8, &st[0], p, coded, &recon[0]) != HOP_OK) return HOP_ERR_DEVICE;
+  std::vector<int16_t> out[3]; const int16_t* s[3]; int16_t* d[3];
+  for (int k = 0; k < 3; k++) { out[k].resize(c->rec[k].size()); s[k] = &c->rec[k][0]; d[k] = &out[k][0]; }
+  if (g_sap(c->w, c->h, 8, s, &recon[0], d) != 0) return HOP_ERR_DEVICE;
+  for (int k = 0; k < 3; k++) c->rec[k] = out[k];
+  return HOP_OK;
+}
 int hop_recon_upload(hop_ctx* c, int comp, const int16_t* src) { memcpy(&c->rec[comp][0], src, c->rec[comp].size() * 2); return HOP_OK; }
 int hop_recon_download(hop_ctx* c, int comp, int16_t* dst) { memcpy(dst, &c->rec[comp][0], c->rec[comp].size() * 2); return HOP_OK; }
 }
@@ -102,9 +116,9 @@ namespace {
 struct Binding {
   hop_ctx* ctx; const TComPic* pic; int w, h, wctu, n;
   std::vector<double> cost; std::vector<uint32_t> bits, dist; std::vector<hop_cu_part> parts; std::vector<int32_t> levels; std::vector<uint16_t> fraction; std::vector<int16_t> rec[3];
-  unsigned long pictures, ctus, deblocked; unsigned long long candidates;
-  Binding() : ctx(NULL), pic(NULL), w(0), h(0), wctu(0), n(0), pictures(0), ctus(0), deblocked(0), candidates(0) {}
-  ~Binding() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop pic binding: pictures %lu ctus %lu candidates %llu deblocked %lu\n", pictures, ctus, candidates, deblocked); if (ctx) hop_ctx_destroy(ctx); }
+  unsigned long pictures, ctus, deblocked, sao; unsigned long long candidates;
+  Binding() : ctx(NULL), pic(NULL), w(0), h(0), wctu(0), n(0), pictures(0), ctus(0), deblocked(0), sao(0), candidates(0) {}
+  ~Binding() { if (getenv("HOP_SHIM_REPORT")) fprintf(stderr, "hop pic binding: pictures %lu ctus %lu candidates %llu deblocked %lu sao %lu\n", pictures, ctus, candidates, deblocked, sao); if (ctx) hop_ctx_destroy(ctx); }
   void fail(const char* what) { fprintf(stderr, "hop pic binding: %s failed: %s\n", what, hop_last_error(ctx)); exit(1); }
   static int env_int(const char* k, int dflt) { const char* v = getenv(k); return v && *v ? atoi(v) : dflt; }
 
@@ -318,4 +332,131 @@ Void TComLoopFilter::loopFilterPic(TComPic* pcPic)
   for (int y = 0; y < h / 2; y++) { memcpy(r->getCbAddr() + (size_t)y * r->getCStride(), &g_b.rec[1][(size_t)y * (w / 2)], (w / 2) * sizeof(Pel));
                                     memcpy(r->getCrAddr() + (size_t)y * r->getCStride(), &g_b.rec[2][(size_t)y * (w / 2)], (w / 2) * sizeof(Pel)); }
   g_b.deblocked++;
+}
+
+// HOP_PIC_SAO=1: TEncSampleAdaptiveOffset::SAOProcess (TLibEncoder/TEncSampleAdaptiveOffset.cpp:251-283) replaced as well: the deblocked picture goes to the context,
+// hop_sao_frame gathers the statistics, decides every CTU's parameters (starting from the fraction the RD coder carries) and applies the offsets; the parameters go into
+// the picture's SAOBlkParam array, from which the reference's encodeSlice writes them, the planes into the reconstruction.  With HOP_PIC_CHECK the reference's own
+// SAOProcess runs on the same input afterwards and statistics, parameters and planes are compared.
+extern "C" void hop_ref_orig_sao_process(TEncSampleAdaptiveOffset*, TComPic*, Bool*, const Double*, Bool);
+namespace {
+// HOP_PIC_SAO_FUZZ="seed:lambda_percent": the picture's original and deblocked planes are replaced by random ones made to spread the decisions -- per CTU one of: no
+// error, band-dependent shifts, ringing along one of the four edge directions, noise; often the same kind as the CTU to the left (merges) -- and the lambdas scaled; both SAO
+// encoders then run on the same input (HOP_PIC_CHECK compares).  HOP_PIC_SAO_DUMP=<file>: input and the REFERENCE's statistics, parameters and output planes are written
+// out (tests/golden/sao_ref.npz, oracle/make_golden23.py).
+void sao_fuzz(TComPic* pic, const char* spec, double scale_out[1]) {
+  long v[2] = { 1, 100 }; { const char* q = spec; for (int k = 0; k < 2 && q && *q; k++) { v[k] = strtol(q, (char**)&q, 10); if (*q == ':') q++; } }
+  scale_out[0] = (double)v[1] / 100.0;
+  Fuzz f; f.s = 0xD1B54A32D192ED03ull ^ (uint64_t)v[0] * 0x100000001B3ull; f.w = g_b.w; f.h = g_b.h; f.wctu = g_b.wctu; for (int k = 0; k < 8; k++) f.next();
+  std::vector<int> kind(g_b.n);
+  for (int a = 0; a < g_b.n; a++) kind[a] = (a % g_b.wctu && f.below(100) < 40) ? kind[a - 1] : f.below(7);
+  std::vector<int16_t> org[3];
+  for (int c = 0; c < 3; c++) {
+    const int pw = c ? g_b.w / 2 : g_b.w, ph = c ? g_b.h / 2 : g_b.h, cs = c ? 32 : 64;
+    org[c].resize((size_t)pw * ph);
+    const int fx = 3 + f.below(9), fy = 3 + f.below(9), amp = 20 + f.below(60), mid = 60 + f.below(130);
+    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
+      const int tri = abs(((x * 16 / fx) + (y * 16 / fy)) % 64 - 32) - 16;                 // a slanted triangle wave + texture
+      org[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, mid + tri * amp / 16 + f.below(7) - 3));
+    }
+    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
+      const int k = kind[(y / cs) * g_b.wctu + x / cs], o = org[c][(size_t)y * pw + x];
+      const int xl = std::max(0, x - 1), xr = std::min(pw - 1, x + 1), yu = std::max(0, y - 1), yd = std::min(ph - 1, y + 1);
+      int r = o;
+      switch (k) {
+        case 1: r = o + ((o >> 3) % 5 == 1 ? 3 : (o >> 3) % 5 == 2 ? -2 : (o >> 3) % 5 == 3 ? 1 : 0); break;                       // band-dependent shifts
+        case 2: case 3: case 4: case 5: {                                                                                             // ringing along one of the four edge directions
+          const int na = k == 2 ? org[c][(size_t)y * pw + xl] : k == 3 ? org[c][(size_t)yu * pw + x] : k == 4 ? org[c][(size_t)yu * pw + xl] : org[c][(size_t)yu * pw + xr];
+          const int nb = k == 2 ? org[c][(size_t)y * pw + xr] : k == 3 ? org[c][(size_t)yd * pw + x] : k == 4 ? org[c][(size_t)yd * pw + xr] : org[c][(size_t)yd * pw + xl];
+          r = o + ((o > na && o > nb) ? 4 : (o < na && o < nb) ? -4 : (o > na || o > nb) ? 1 : 0);
+        } break;
+        case 6: r = o + f.below(5) - 2; break;
+        default: break;
+      }
+      g_b.rec[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, r));
+    }
+  }
+  TComPicYuv* po = pic->getPicYuvOrg(); TComPicYuv* pr = pic->getPicYuvRec();
+  const int w = g_b.w, h = g_b.h;
+  for (int y = 0; y < h; y++) { memcpy(po->getLumaAddr() + (size_t)y * po->getStride(), &org[0][(size_t)y * w], w * 2); memcpy(pr->getLumaAddr() + (size_t)y * pr->getStride(), &g_b.rec[0][(size_t)y * w], w * 2); }
+  for (int y = 0; y < h / 2; y++) {
+    memcpy(po->getCbAddr() + (size_t)y * po->getCStride(), &org[1][(size_t)y * (w / 2)], w); memcpy(po->getCrAddr() + (size_t)y * po->getCStride(), &org[2][(size_t)y * (w / 2)], w);
+    memcpy(pr->getCbAddr() + (size_t)y * pr->getCStride(), &g_b.rec[1][(size_t)y * (w / 2)], w); memcpy(pr->getCrAddr() + (size_t)y * pr->getCStride(), &g_b.rec[2][(size_t)y * (w / 2)], w);
+  }
+  if (hop_upload_orig(g_b.ctx, &org[0][0], w, &org[1][0], &org[2][0], w / 2) != HOP_OK) g_b.fail("hop_upload_orig");
+}
+}
+Void TEncSampleAdaptiveOffset::SAOProcess(TComPic* pPic, Bool* sliceEnabled, const Double* lambdas, Bool isPreDBFSamplesUsed)
+{
+  static const bool on = getenv("HOP_PIC_SAO") != NULL, check = getenv("HOP_PIC_CHECK") != NULL;
+  if (!on || g_b.pic != pPic || !g_b.ctx || isPreDBFSamplesUsed) { hop_ref_orig_sao_process(this, pPic, sliceEnabled, lambdas, isPreDBFSamplesUsed); return; }
+  TComPicYuv* r = pPic->getPicYuvRec(); TComSlice* sl = pPic->getSlice(0);
+  const int w = g_b.w, h = g_b.h, n = g_b.n;
+  double lam[3] = { lambdas[0], lambdas[1], lambdas[2] };
+  if (const char* fz = getenv("HOP_PIC_SAO_FUZZ")) { double sc[1]; sao_fuzz(pPic, fz, sc); for (int k = 0; k < 3; k++) lam[k] *= sc[0]; lambdas = lam; }
+  for (int y = 0; y < h; y++) memcpy(&g_b.rec[0][(size_t)y * w], r->getLumaAddr() + (size_t)y * r->getStride(), w * sizeof(Pel));
+  for (int y = 0; y < h / 2; y++) { memcpy(&g_b.rec[1][(size_t)y * (w / 2)], r->getCbAddr() + (size_t)y * r->getCStride(), (w / 2) * sizeof(Pel));
+                                    memcpy(&g_b.rec[2][(size_t)y * (w / 2)], r->getCrAddr() + (size_t)y * r->getCStride(), (w / 2) * sizeof(Pel)); }
+  for (int k = 0; k < 3; k++) if (hop_recon_upload(g_b.ctx, k, &g_b.rec[k][0]) != HOP_OK) g_b.fail("hop_recon_upload");      // (a no-op's worth when hop_deblock_frame left it there)
+  decidePicParams(sliceEnabled, sl->getDepth());
+  hop_sao_params p; memset(&p, 0, sizeof(p));
+  for (int k = 0; k < 3; k++) { p.lambda[k] = lambdas[k]; p.enabled[k] = sliceEnabled[k] ? 1 : 0; }
+  p.slice_type = (int)sl->getSliceType(); p.qp = sl->getSliceQp();
+  p.rd_fraction = (uint32_t)(((TEncBinCABAC*)m_pcRDGoOnSbacCoder->m_pcBinIf)->m_fracBits & 32767);
+  std::vector<hop_sao_param> coded((size_t)n * 3);
+  std::vector<int32_t> stats;
+  if (check) { stats.resize((size_t)n * 3 * 5 * 32 * 2); if (hop_sao_stats(g_b.ctx, &stats[0]) != HOP_OK) g_b.fail("hop_sao_stats"); }
+  std::vector<int16_t> before[3]; for (int k = 0; k < 3; k++) before[k] = g_b.rec[k];
+  if (hop_sao_frame(g_b.ctx, &p, &coded[0]) != HOP_OK) g_b.fail("hop_sao_frame");
+  for (int k = 0; k < 3; k++) if (hop_recon_download(g_b.ctx, k, &g_b.rec[k][0]) != HOP_OK) g_b.fail("hop_recon_download");
+  SAOBlkParam* dst = pPic->getPicSym()->getSAOBlkParam();
+  if (check) {
+    Bool en[3]; hop_ref_orig_sao_process(this, pPic, en, lambdas, isPreDBFSamplesUsed);
+    long bad = 0;
+    for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) {
+      for (int t = 0; t < 5; t++) for (int k = 0; k < 32; k++) {
+        const int32_t* s = &stats[((((size_t)a * 3 + c) * 5 + t) * 32 + k) * 2];
+        if ((s[0] != m_statData[a][c][t].count[k] || s[1] != m_statData[a][c][t].diff[k]) && bad++ < 10) fprintf(stderr, "hop pic check: SAO statistics CTU %d comp %d type %d class %d: reference %ld / %ld library %d / %d\n", a, c, t, k, (long)m_statData[a][c][t].count[k], (long)m_statData[a][c][t].diff[k], s[0], s[1]);
+      }
+      const SAOOffset& o = dst[a][c]; const hop_sao_param& q = coded[(size_t)a * 3 + c];
+      bool same = o.modeIdc == q.mode && (o.modeIdc == SAO_MODE_OFF || (o.typeIdc == q.type && (o.modeIdc == SAO_MODE_MERGE || o.typeAuxInfo == q.aux)));
+      if (same && o.modeIdc == SAO_MODE_NEW) for (int k = 0; k < 32; k++) same = same && o.offset[k] == q.offset[k];
+      if (!same && bad++ < 20) fprintf(stderr, "hop pic check: SAO parameters CTU %d comp %d: reference mode %d type %d aux %d, library mode %d type %d aux %d\n", a, c, o.modeIdc, o.typeIdc, o.typeAuxInfo, q.mode, q.type, q.aux);
+    }
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) if (r->getLumaAddr()[(size_t)y * r->getStride() + x] != g_b.rec[0][(size_t)y * w + x] && bad++ < 30) fprintf(stderr, "hop pic check: SAO luma (%d, %d) reference %d library %d\n", x, y, r->getLumaAddr()[(size_t)y * r->getStride() + x], g_b.rec[0][(size_t)y * w + x]);
+    for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) {
+      if (r->getCbAddr()[(size_t)y * r->getCStride() + x] != g_b.rec[1][(size_t)y * (w / 2) + x] && bad++ < 30) fprintf(stderr, "hop pic check: SAO Cb (%d, %d) differs\n", x, y);
+      if (r->getCrAddr()[(size_t)y * r->getCStride() + x] != g_b.rec[2][(size_t)y * (w / 2) + x] && bad++ < 30) fprintf(stderr, "hop pic check: SAO Cr (%d, %d) differs\n", x, y);
+    }
+    fprintf(stderr, "hop pic check: SAO: %ld differences\n", bad);
+    if (getenv("HOP_PIC_SAO_FUZZ")) {
+      long modes[3] = { 0, 0, 0 }, types[5] = { 0, 0, 0, 0, 0 };
+      for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) { modes[dst[a][c].modeIdc]++; if (dst[a][c].modeIdc == SAO_MODE_NEW) types[dst[a][c].typeIdc]++; }
+      fprintf(stderr, "hop pic check: fuzz: off %ld new %ld merge %ld; edge 0/90/135/45 %ld %ld %ld %ld band %ld\n", modes[0], modes[1], modes[2], types[0], types[1], types[2], types[3], types[4]);
+      if (const char* dp = getenv("HOP_PIC_SAO_DUMP")) if (FILE* fo = fopen(dp, "ab")) {
+        const int32_t hd[6] = { w, h, n, p.slice_type, p.qp, (int32_t)p.rd_fraction };
+        fwrite(hd, 4, 6, fo); fwrite(p.lambda, 8, 3, fo);
+        TComPicYuv* po = pPic->getPicYuvOrg();
+        for (int y = 0; y < h; y++) fwrite(po->getLumaAddr() + (size_t)y * po->getStride(), 2, w, fo);
+        for (int y = 0; y < h / 2; y++) fwrite(po->getCbAddr() + (size_t)y * po->getCStride(), 2, w / 2, fo);
+        for (int y = 0; y < h / 2; y++) fwrite(po->getCrAddr() + (size_t)y * po->getCStride(), 2, w / 2, fo);
+        for (int k = 0; k < 3; k++) fwrite(&before[k][0], 2, before[k].size(), fo);
+        for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) for (int t = 0; t < 5; t++) for (int k = 0; k < 32; k++) { const int32_t s2[2] = { (int32_t)m_statData[a][c][t].count[k], (int32_t)m_statData[a][c][t].diff[k] }; fwrite(s2, 4, 2, fo); }
+        for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) { hop_sao_param q; memset(&q, 0, sizeof(q)); q.mode = (int8_t)dst[a][c].modeIdc; q.type = (int8_t)dst[a][c].typeIdc; q.aux = (int8_t)dst[a][c].typeAuxInfo; for (int k = 0; k < 32; k++) q.offset[k] = (int8_t)dst[a][c].offset[k]; fwrite(&q, sizeof(q), 1, fo); }
+        for (int y = 0; y < h; y++) fwrite(r->getLumaAddr() + (size_t)y * r->getStride(), 2, w, fo);
+        for (int y = 0; y < h / 2; y++) fwrite(r->getCbAddr() + (size_t)y * r->getCStride(), 2, w / 2, fo);
+        for (int y = 0; y < h / 2; y++) fwrite(r->getCrAddr() + (size_t)y * r->getCStride(), 2, w / 2, fo);
+        fclose(fo);
+      }
+      fflush(stderr); _exit(bad ? 1 : 0);
+    }
+  }
+  for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) {
+    SAOOffset& o = dst[a][c]; const hop_sao_param& q = coded[(size_t)a * 3 + c];
+    o.modeIdc = q.mode; o.typeIdc = q.type; o.typeAuxInfo = q.aux; for (int k = 0; k < MAX_NUM_SAO_CLASSES; k++) o.offset[k] = q.offset[k];
+  }
+  for (int y = 0; y < h; y++) memcpy(r->getLumaAddr() + (size_t)y * r->getStride(), &g_b.rec[0][(size_t)y * w], w * sizeof(Pel));
+  for (int y = 0; y < h / 2; y++) { memcpy(r->getCbAddr() + (size_t)y * r->getCStride(), &g_b.rec[1][(size_t)y * (w / 2)], (w / 2) * sizeof(Pel));
+                                    memcpy(r->getCrAddr() + (size_t)y * r->getCStride(), &g_b.rec[2][(size_t)y * (w / 2)], (w / 2) * sizeof(Pel)); }
+  g_b.sao++;
 }

@@ -203,6 +203,11 @@ typedef struct {
 int hop_o_deblock_frame(int w, int h, int bit_depth, int qp, int beta_offset_div2, int tc_offset_div2, int cb_qp_offset, int cr_qp_offset, int disable,
                         const hop_o_cu_part* parts, int16_t* y, int16_t* cb, int16_t* cr);
 
+/* ---- sample adaptive offset, hop_oracle_sao.c: the layout of hop_sao_param (include/hophip.h) ---- */
+typedef struct { int8_t mode, type, aux, pad; int8_t offset[32]; } hop_o_sao_param;
+int hop_o_sao_stats(int w, int h, int bit_depth, const int16_t* const src[3], const int16_t* const org[3], int32_t* stats);
+int hop_o_sao_apply(int w, int h, int bit_depth, const int16_t* const src[3], const hop_o_sao_param* params, int16_t* const dst[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -225,3 +225,35 @@ def tile_deblock_case(case, nx, ny):
     P = parts.reshape(hc, wc, 256, -1)
     big = np.ascontiguousarray(np.tile(P, (ny, nx, 1, 1))).reshape(ny * hc * nx * wc, 256, -1)
     return W * nx, H * ny, params, big, [np.ascontiguousarray(np.tile(a, (ny, nx))) for a in pin]
+
+
+# ---- SAO: fixtures from the reference's own SAO encoder (tests/golden/sao_ref.npz, oracle/make_golden23.py) ----
+SAO_PARAM_DTYPE = np.dtype([("mode", "i1"), ("type", "i1"), ("aux", "i1"), ("pad", "i1"), ("offset", "i1", 32)])          # hop_sao_param
+
+
+class SaoParams(ctypes.Structure):                                                                                       # hop_sao_params
+    _fields_ = [("lambda", ctypes.c_double * 3), ("enabled", ctypes.c_int32 * 3), ("slice_type", ctypes.c_int32), ("qp", ctypes.c_int32), ("rd_fraction", ctypes.c_uint32)]
+
+
+def sao_cases():
+    G = np.load(os.path.join(ROOT, "tests", "golden", "sao_ref.npz"))
+    out = []
+    for k in sorted(set(f.split("/")[0] for f in G.files)):
+        W, H, n, st, qp, frac = [int(v) for v in G[k + "/geo"]]
+        pl = lambda pre: [G[k + "/%s_%s" % (pre, c)].astype(np.int16).reshape((H, W) if c == "y" else (H // 2, W // 2)) for c in ("y", "cb", "cr")]
+        out.append({"key": k, "W": W, "H": H, "n": n, "slice_type": st, "qp": qp, "rd_fraction": frac, "lambda": [float(v) for v in G[k + "/lambda"]],
+                    "org": pl("org"), "in": pl("in"), "out": pl("out"), "stats": np.ascontiguousarray(G[k + "/stats"]), "coded": np.ascontiguousarray(G[k + "/coded"]).view(SAO_PARAM_DTYPE).reshape(n, 3)})
+    return out
+
+
+def sao_params_of(case):
+    return SaoParams((ctypes.c_double * 3)(*case["lambda"]), (ctypes.c_int32 * 3)(1, 1, 1), case["slice_type"], case["qp"], case["rd_fraction"])
+
+
+def same_coded(a, b):
+    """two arrays of hop_sao_param say the same thing to the entropy coder: mode; type for new and merge; band position and offsets for new"""
+    for x, y in zip(a.reshape(-1), b.reshape(-1)):
+        if x["mode"] != y["mode"]: return False
+        if x["mode"] != 0 and x["type"] != y["type"]: return False
+        if x["mode"] == 1 and (x["aux"] != y["aux"] or not np.array_equal(x["offset"], y["offset"])): return False
+    return True

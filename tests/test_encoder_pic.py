@@ -54,7 +54,7 @@ def test_reference_encoder_over_the_cpu_spine_writes_the_reference_bitstream(key
     check(key, got, counts)
 
 
-def test_reference_encoder_with_the_restated_deblocking_filter():
+def test_reference_encoder_with_the_restated_loop_filters():
     """HOP_PIC_DEBLOCK: loopFilterPic replaced as well (here by the restatement, oracle/hop_oracle_lf.c): same bitstream, same reconstruction"""
     if not os.path.isdir(REF):
         pytest.skip("the reference tree is not present (GPU box)")
@@ -63,6 +63,10 @@ def test_reference_encoder_with_the_restated_deblocking_filter():
     got, counts = run_binding(os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu"), "200x104_raster", {"HOP_PIC_SPINE": os.path.join(ROOT, "oracle", "libhop_spine_cpu.so"), "HOP_PIC_DEBLOCK": "1"})
     assert counts["deblocked"] == 1
     check("200x104_raster", got, counts)
+    # ... and SAOProcess (restated statistics / offsetting around the product's decision, hop_sao_decide)
+    got, counts = run_binding(os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu"), "128x64_2frames", {"HOP_PIC_SPINE": os.path.join(ROOT, "oracle", "libhop_spine_cpu.so"), "HOP_PIC_DEBLOCK": "1", "HOP_PIC_SAO": "1"})
+    assert counts["deblocked"] == 2 and counts["sao"] == 2
+    check("128x64_2frames", got, counts)
 
 
 def test_golden_of_the_binding_agrees_with_the_configuration_file():

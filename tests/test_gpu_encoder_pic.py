@@ -36,3 +36,15 @@ def test_reference_encoder_with_the_library_deblocking_too(key):
     got, counts = run_binding(EXE, key, {"HOP_PIC_DEBLOCK": "1"})
     assert counts["deblocked"] == PIC_CASES[key]["frames"]
     check(key, got, counts)
+
+
+@pytest.mark.parametrize("key", ["200x104_raster", "448x192_wpp", "128x64_2frames", "192x128_raster"])
+def test_reference_encoder_with_the_library_deblocking_and_sao(key):
+    """HOP_PIC_DEBLOCK + HOP_PIC_SAO: everything between the original and the entropy coder is the library's -- hop_encode_frame, hop_deblock_frame, hop_sao_frame (its
+    statistics and offsetting kernels, its decision starting from hop_rd_fraction_download's fraction); the reference writes the SAO parameters the library chose and hashes
+    the library's final picture: same md5s as the unmodified encoder"""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/TAppEncoderPic was not built")
+    got, counts = run_binding(EXE, key, {"HOP_PIC_DEBLOCK": "1", "HOP_PIC_SAO": "1"})
+    assert counts["deblocked"] == PIC_CASES[key]["frames"] and counts["sao"] == PIC_CASES[key]["frames"]
+    check(key, got, counts)

@@ -11,6 +11,8 @@
 //   k_sao_apply   a thread per sample: reads the untouched copy, writes the picture; the CTU's parameters (36 B per component) through the scalar cache.
 // Both are HBM-bound: 4 B per sample in (statistics), 2 + 2 B per sample (offsetting) plus the copy; DESIGN.md section 4.
 #include "hop_dev.h"
+#include <math.h>
+#include <vector>
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hop_set_err((c), HOP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
@@ -146,4 +148,49 @@ extern "C" int hop_sao_frame(hop_ctx* c, const hop_sao_params* p, hop_sao_param*
   if (rc == HOP_OK) rc = hop_sao_apply(c, recon);
   free(stats); free(recon);
   return rc;
+}
+
+// ---- PSNR: the sums of squared differences between the resident original and the reconstruction ----
+// replaces: the three loops of TEncGOP::xCalculateAddPSNR (TLibEncoder/TEncGOP.cpp:2383-2456).  One pass over both pictures (4 B per sample), a wave-level reduction and
+// one 64-bit atomic per workgroup and plane.
+__global__ __launch_bounds__(256) void k_ssd(SaoGeo g, const int16_t* __restrict__ rec_y, const int16_t* __restrict__ rec_cb, const int16_t* __restrict__ rec_cr,
+                                             const int16_t* __restrict__ org_y, const int16_t* __restrict__ org_cb, const int16_t* __restrict__ org_cr, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long part[4];
+  const int comp = blockIdx.y, pic = blockIdx.z, sh = comp ? 1 : 0;
+  const int pw = g.w >> sh, ph = g.h >> sh;
+  const size_t off = (size_t)pic * (g.pitch_rows >> sh) * pw, n = (size_t)pw * ph;
+  const int16_t* a = (comp == 0 ? rec_y : comp == 1 ? rec_cb : rec_cr) + off;
+  const int16_t* b = (comp == 0 ? org_y : comp == 1 ? org_cb : org_cr) + off;
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const int d = (int)b[i] - (int)a[i]; s += (unsigned long long)(d * d); }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[pic * 3 + comp], part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int hop_psnr(hop_ctx* c, uint64_t* ssd, double* psnr) {
+  if (!c || (!ssd && !psnr)) return hop_set_err(c, HOP_ERR_ARG, "hop_psnr: bad argument");
+  if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_psnr: hop_upload_orig has not been called");
+  SaoGeo g; int n_pic; const int rc = sao_geo(c, g, n_pic, "hop_psnr"); if (rc != HOP_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d, (size_t)n_pic * 3 * 8));
+  hipError_t e = hipMemsetAsync(d, 0, (size_t)n_pic * 3 * 8, c->stream);
+  std::vector<unsigned long long> h((size_t)n_pic * 3);
+  if (e == hipSuccess) {
+    const size_t n = (size_t)g.w * g.h; const unsigned blocks = (unsigned)((n / 256 / 8 < 1 ? 1 : n / 256 / 8) > 4096 ? 4096 : (n / 256 / 8 < 1 ? 1 : n / 256 / 8));
+    hipLaunchKernelGGL(k_ssd, dim3(blocks, 3, n_pic), dim3(256), 0, c->stream, g, c->rec[0], c->rec[1], c->rec[2], c->org_y, c->org_cb, c->org_cr, d);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "hop_psnr: %s", hipGetErrorString(e));
+  const double maxv = (double)(255 << (g.bd - 8)), size = (double)g.w * g.h;
+  for (int k = 0; k < n_pic * 3; k++) {
+    if (ssd) ssd[k] = h[k];
+    if (psnr) { const double ref = maxv * maxv * size / (k % 3 ? 4.0 : 1.0); psnr[k] = h[k] ? 10.0 * log10(ref / (double)h[k]) : 99.99; }   // :2449-2456
+  }
+  return HOP_OK;
 }

@@ -375,6 +375,13 @@ class Context:
         self.L.hop_sao_apply.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self._chk(self.L.hop_sao_apply(self.h, recon.ctypes.data), "hop_sao_apply")
 
+    def psnr(self):
+        """hop_psnr: (ssd (pictures, 3) uint64, psnr (pictures, 3) float64) between the resident original and the reconstruction"""
+        ssd = np.zeros((self.pictures, 3), np.uint64); ps = np.zeros((self.pictures, 3), np.float64)
+        self.L.hop_psnr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_psnr(self.h, ssd.ctypes.data, ps.ctypes.data), "hop_psnr")
+        return ssd, ps
+
     def rd_fraction_download(self):
         """hop_rd_fraction_download: per CTU the fraction of a bit the RD search's counting coder carries when the CTU is done"""
         n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures

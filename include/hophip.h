@@ -705,6 +705,11 @@ int hop_sao_apply(hop_ctx* ctx, const hop_sao_param* recon);
  * replaces: TEncSampleAdaptiveOffset::SAOProcess (:251-283) after decidePicParams. */
 int hop_sao_frame(hop_ctx* ctx, const hop_sao_params* params, hop_sao_param* coded);
 
+/* replaces: the distortion loops and the PSNR formula of TEncGOP::xCalculateAddPSNR (TLibEncoder/TEncGOP.cpp:2383-2456) between the resident original and the context's
+ * reconstruction picture (after hop_sao_frame: the final picture).  Per picture of the context and component (Y, Cb, Cr): ssd = the sum of squared differences, psnr in
+ * dB (99.99 for an exact picture).  Either output may be NULL. */
+int hop_psnr(hop_ctx* ctx, uint64_t* ssd, double* psnr);
+
 /* ---- profiling (bench.py roofline): HIP events around every kernel launch on the context stream ---- */
 #define HOP_K_SS_SEARCH 0
 #define HOP_K_FRAC      1

@@ -9,6 +9,7 @@ binding over libhophip.so on the GPU box.  Needs /root/reference to build (skipp
 import hashlib
 import json
 import os
+import re
 import subprocess
 import tempfile
 
@@ -30,6 +31,11 @@ def run_binding(exe, key, env):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         md5 = lambda n: hashlib.md5(open(os.path.join(td, n), "rb").read()).hexdigest()
         got = {"bin_md5": md5("s.bin"), "rec_md5": md5("rec.yuv"), "bin_bytes": os.path.getsize(os.path.join(td, "s.bin"))}
+    # the PSNR the binding computed for each final picture (HOP_PIC_SAO) against the three numbers the reference prints per picture
+    ours = [ln.split(":")[1].split() for ln in r.stderr.splitlines() if ln.startswith("hop pic psnr:")]
+    theirs = [re.findall(r"\[Y\s+([0-9.]+) dB\s+U\s+([0-9.]+) dB\s+V\s+([0-9.]+) dB\]", ln)[0] for ln in r.stdout.splitlines() if ln.startswith("POC")]
+    if ours:
+        assert [tuple(o) for o in ours] == [tuple(t) for t in theirs], (ours, theirs)
     rep = [ln for ln in r.stderr.splitlines() if ln.startswith("hop pic binding:")]
     assert len(rep) == 1, r.stderr[-1500:]
     t = rep[0].split(":")[1].split()

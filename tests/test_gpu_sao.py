@@ -5,6 +5,7 @@
 2. two pictures in one stacked context, each treated as a picture of its own;
 3. at the full frame size (7680 x 5376 tiled from a fixture: 10 080 CTUs) statistics and offsetting against the CPU restatement."""
 import ctypes
+import math
 import os
 import sys
 import time
@@ -92,4 +93,23 @@ def test_sao_full_size_against_the_restatement():
         assert np.array_equal(ctx.recon_download(c), out[c]), c
     modes = np.bincount(coded["mode"].reshape(-1).astype(np.int64), minlength=3)
     print("SAO %dx%d: statistics %.1f ms (with download), whole hop_sao_frame %.1f ms; off / new / merge %s" % (W, H, (t1 - t0) * 1e3, (t3 - t2) * 1e3, modes.tolist()))
+    ctx.close()
+
+
+def test_psnr_against_numpy():
+    """hop_psnr: the sums of squared differences and the reference's formula (TEncGOP.cpp:2449-2456), two stacked pictures, one of them exact"""
+    hp = _hp()
+    a = sao_cases()[0]
+    W, H = a["W"], a["H"]
+    ctx = hp.Context(W, H, pictures=2)
+    ctx.upload_orig(ctx.stack([a["org"][0], a["org"][0]]), ctx.stack([a["org"][1], a["org"][1]], True), ctx.stack([a["org"][2], a["org"][2]], True))
+    ctx.plane_upload("recon", 0, ctx.stack([a["in"][0], a["org"][0]]))
+    for c in (1, 2):
+        ctx.plane_upload("recon", c, ctx.stack([a["in"][c], a["org"][c]], True))
+    ssd, ps = ctx.psnr()
+    for c in range(3):
+        want = int(((a["org"][c].astype(np.int64) - a["in"][c].astype(np.int64)) ** 2).sum())
+        assert int(ssd[0, c]) == want and int(ssd[1, c]) == 0
+        ref = 255.0 * 255.0 * W * H / (4.0 if c else 1.0)
+        assert abs(ps[0, c] - 10.0 * math.log10(ref / want)) <= 1e-12 * ps[0, c] and ps[1, c] == 99.99          # the sums are exact; the dB value to 1e-12 relative (log10 of two libraries)
     ctx.close()

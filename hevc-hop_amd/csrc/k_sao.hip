@@ -7,7 +7,7 @@
 // lie inside the picture (one slice, one tile), its class is sgn(s - a) + sgn(s - b); the statistics leave out the columns / rows the right / lower neighbour CTU's
 // deblocking could still change (5 / 4 luma, 3 / 2 chroma: SAOLcuBoundary 0).
 //   k_sao_stats   a workgroup per CTU and component: 256 threads stride over the CTU's samples (rows contiguous: coalesced 2-byte loads of the deblocked and the original
-//                 plane, neighbours from the same rows +-1 out of L2), 5 x 32 (count, sum) pairs accumulated with LDS atomics, written once per workgroup.
+//                 plane, neighbours from the same rows +-1 out of L2), 5 x 32 (count, sum) pairs accumulated in lane-private LDS columns, written once per workgroup.
 //   k_sao_apply   a thread per sample: reads the untouched copy, writes the picture; the CTU's parameters (36 B per component) through the scalar cache.
 // Both are HBM-bound: 4 B per sample in (statistics), 2 + 2 B per sample (offsetting) plus the copy; DESIGN.md section 4.
 #include "hop_dev.h"
@@ -20,9 +20,18 @@ struct SaoGeo { int w, h, wctu, n_ctu, pitch_rows, bd; };
 
 __device__ __forceinline__ int sao_sgn(int v) { return (v > 0) - (v < 0); }
 
+// Every group of 4 lanes owns a private column of the histogram in LDS -- 20 edge bins (4 types x 5 classes) + 32 bands, each a packed (count << 20) + sum word: a column
+// sees at most 64 samples, so the sum stays inside +-2^19 at 8 and 10 bit -- laid out bin-major ([bin][column], rows 17 words apart), so the five ds_add per sample of a
+// wave spread over 16 addresses per bin instead of one (the first version kept one histogram per workgroup and spent its time in LDS atomics on a handful of hot bins:
+// 206 GB/s; a column per lane removed the contention but made clearing and reducing 54 KB per workgroup the larger part of the work).  At the end each
+// (bin, wave) row is unpacked and summed by one thread.
+#define SAO_BINS 52
+#define SAO_COLS 16      /* columns per wave: 4 lanes share one */
+#define SAO_ROW 17
 __global__ __launch_bounds__(256) void k_sao_stats(SaoGeo g, const int16_t* __restrict__ rec_y, const int16_t* __restrict__ rec_cb, const int16_t* __restrict__ rec_cr,
                                                    const int16_t* __restrict__ org_y, const int16_t* __restrict__ org_cb, const int16_t* __restrict__ org_cr, int32_t* __restrict__ stats) {
-  __shared__ int32_t acc[5 * 32 * 2];
+  __shared__ int32_t priv[4][SAO_BINS][SAO_ROW];
+  __shared__ int32_t sums[4][SAO_BINS][2];
   const int ctu = blockIdx.x, comp = blockIdx.y, pic = blockIdx.z, sh = comp ? 1 : 0;
   const int pw = g.w >> sh, ph = g.h >> sh, cs = 64 >> sh;
   const int x0 = (ctu % g.wctu) * cs, y0 = (ctu / g.wctu) * cs;
@@ -31,27 +40,39 @@ __global__ __launch_bounds__(256) void k_sao_stats(SaoGeo g, const int16_t* __re
   const size_t plane_off = (size_t)pic * (g.pitch_rows >> sh) * pw;
   const int16_t* src = (comp == 0 ? rec_y : comp == 1 ? rec_cb : rec_cr) + plane_off;
   const int16_t* org = (comp == 0 ? org_y : comp == 1 ? org_cb : org_cr) + plane_off;
-  for (int i = threadIdx.x; i < 5 * 32 * 2; i += 256) acc[i] = 0;
+  const int wave = threadIdx.x >> 6, lane = (threadIdx.x & 63) >> 2;
+  for (int i = threadIdx.x; i < 4 * SAO_BINS * SAO_ROW; i += 256) (&priv[0][0][0])[i] = 0;
   __syncthreads();
+  int32_t (*mine)[SAO_ROW] = priv[wave];
   for (int i = threadIdx.x; i < cs * end_y; i += 256) {
     const int x = i & (cs - 1), y = i / cs;
     if (x >= end_x) continue;
     const int X = x0 + x, Y = y0 + y;
     const int16_t* p = src + (size_t)Y * pw + X;
-    const int s = p[0], d = org[(size_t)Y * pw + X] - s;
+    const int s = p[0], d = org[(size_t)Y * pw + X] - s, add = (1 << 20) + d;
     const bool l = X > 0, r = X + 1 < pw, u = Y > 0, b = Y + 1 < ph;
-    if (l && r) { const int c = 2 + sao_sgn(s - p[-1]) + sao_sgn(s - p[1]); atomicAdd(&acc[(0 * 32 + c) * 2], 1); atomicAdd(&acc[(0 * 32 + c) * 2 + 1], d); }
-    if (u && b) { const int c = 2 + sao_sgn(s - p[-pw]) + sao_sgn(s - p[pw]); atomicAdd(&acc[(1 * 32 + c) * 2], 1); atomicAdd(&acc[(1 * 32 + c) * 2 + 1], d); }
+    if (l && r) atomicAdd(&mine[0 * 5 + 2 + sao_sgn(s - p[-1]) + sao_sgn(s - p[1])][lane], add);
+    if (u && b) atomicAdd(&mine[1 * 5 + 2 + sao_sgn(s - p[-pw]) + sao_sgn(s - p[pw])][lane], add);
     if (l && r && u && b) {
-      const int c2 = 2 + sao_sgn(s - p[-pw - 1]) + sao_sgn(s - p[pw + 1]); atomicAdd(&acc[(2 * 32 + c2) * 2], 1); atomicAdd(&acc[(2 * 32 + c2) * 2 + 1], d);
-      const int c3 = 2 + sao_sgn(s - p[-pw + 1]) + sao_sgn(s - p[pw - 1]); atomicAdd(&acc[(3 * 32 + c3) * 2], 1); atomicAdd(&acc[(3 * 32 + c3) * 2 + 1], d);
+      atomicAdd(&mine[2 * 5 + 2 + sao_sgn(s - p[-pw - 1]) + sao_sgn(s - p[pw + 1])][lane], add);
+      atomicAdd(&mine[3 * 5 + 2 + sao_sgn(s - p[-pw + 1]) + sao_sgn(s - p[pw - 1])][lane], add);
     }
-    const int band = s >> (g.bd - 5);
-    atomicAdd(&acc[(4 * 32 + band) * 2], 1); atomicAdd(&acc[(4 * 32 + band) * 2 + 1], d);
+    atomicAdd(&mine[20 + (s >> (g.bd - 5))][lane], add);                    // (ds_add without return: nothing waits for it)
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * SAO_BINS) {
+    const int wv = threadIdx.x / SAO_BINS, bin = threadIdx.x % SAO_BINS;
+    int cnt = 0, dif = 0;
+    for (int k = 0; k < SAO_COLS; k++) { const int v = priv[wv][bin][k]; const int c = (v + (1 << 19)) >> 20; cnt += c; dif += v - (c << 20); }
+    sums[wv][bin][0] = cnt; sums[wv][bin][1] = dif;
   }
   __syncthreads();
   int32_t* out = stats + (((size_t)pic * g.n_ctu + ctu) * 3 + comp) * 5 * 32 * 2;
-  for (int i = threadIdx.x; i < 5 * 32 * 2; i += 256) out[i] = acc[i];
+  for (int i = threadIdx.x; i < 5 * 32 * 2; i += 256) {
+    const int t = i >> 6, cls = (i >> 1) & 31, which = i & 1;
+    const int bin = t < 4 ? (cls < 5 ? t * 5 + cls : -1) : 20 + cls;
+    out[i] = bin < 0 ? 0 : sums[0][bin][which] + sums[1][bin][which] + sums[2][bin][which] + sums[3][bin][which];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_sao_apply(SaoGeo g, const hop_sao_param* __restrict__ params, const int16_t* __restrict__ src_y, const int16_t* __restrict__ src_cb,

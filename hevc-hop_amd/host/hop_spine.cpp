@@ -1328,6 +1328,7 @@ class FiberPool : public Backend {
       if (!barrier(w)) break;
     }
   }
+  int spin_us_ = [] { const char* e = getenv("HOP_SPINE_SPIN_US"); return e ? atoi(e) : 200; }();   // how long a waiting worker watches the generation before it sleeps
   bool barrier(int) {                                                   // false: everything has finished
     std::unique_lock<std::mutex> lk(bm_);
     const uint64_t gen = gen_.load();
@@ -1345,11 +1346,11 @@ class FiberPool : public Backend {
       return !finished_;
     }
     lk.unlock();
-    // a round takes about a millisecond: watch the generation for a while before going to sleep (a futex sleep and wake-up costs a good part of that)
+    // a round takes about a millisecond: watch the generation for a moment before going to sleep (3 ms, 200 us and no watching at all measured within 3 % of each other)
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0; gen_.load(std::memory_order_acquire) == gen; spin++) {
       __builtin_ia32_pause();
-      if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(3000)) {
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) {
         lk.lock();
         bcv_.wait(lk, [&] { return gen_.load() != gen; });
         lk.unlock();
@@ -1448,7 +1449,9 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     std::fill(E.committed.begin(), E.committed.end(), (uint8_t)0);
   }
   if (inner) {                                                          // the batching form: rows as fibers on a few worker threads
-    int T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; if (T < 1) T = 1;
+    // more workers than the 16 CPUs a GPU box gives a job: a worker spends most of a round asleep at the barrier (measured at 384 pictures: 16 / 24 / 32 workers 275 - 283 /
+    // 282 - 287 / 288 CTU/s)
+    int T = (int)std::thread::hardware_concurrency(); if (T > 32) T = 32; if (T < 1) T = 1;
     if (threads > 0) T = threads;
     if (const char* e = getenv("HOP_SPINE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) T = v; }
     if (T > rows * n_pic) T = rows * n_pic;

@@ -523,6 +523,27 @@ def encode_main(args):
     barrier()
     dt = time.perf_counter() - t0
     stats = ctx.encode_stats()
+    # ---- after the search, untimed and outside `value`: deblocking, the SAO encoder and PSNR over the pictures the last step left in the context ----
+    post = None
+    if rank == 0:
+        try:
+            lam = 0.57 * 2.0 ** ((QP - 12) / 3.0)                        # TEncSlice.cpp:358-462 for an all-intra sequence (no B pictures, lambda scale 1): 57.908 at QP 32
+            lam_c = lam / 2.0 ** ((QP - 31) / 3.0)                       # chroma weight 2^((QP - QPc) / 3) with QPc = g_aucChromaScale[32] = 31 (TEncSlice.cpp:426-441)
+            assert QP == 32
+            ctx.sync(); tq0 = time.perf_counter()
+            ctx.deblock_frame(parts, QP)
+            tq1 = time.perf_counter()
+            coded = ctx.sao_frame([lam, lam_c, lam_c], 3, QP, int(ctx.rd_fraction_download()[wctu * hctu - 1]))
+            tq2 = time.perf_counter()
+            ssd, psnr = ctx.psnr()
+            tq3 = time.perf_counter()
+            modes = np.bincount(coded["mode"].reshape(-1).astype(np.int64), minlength=3)
+            post = {"pictures": P, "ctus": n_ctu, "deblock_ms": (tq1 - tq0) * 1e3, "sao_ms": (tq2 - tq1) * 1e3, "psnr_ms": (tq3 - tq2) * 1e3,
+                    "sao_components_off_new_merge": [int(v) for v in modes], "psnr_db_mean": [float(v) for v in psnr.mean(axis=0)], "psnr_db_min": [float(v) for v in psnr.min(axis=0)],
+                    "note": "hop_deblock_frame, hop_sao_frame (statistics kernel, host decision, offsetting kernel) and hop_psnr over all pictures of the last step, wall time with "
+                            "uploads of the partition data and downloads of statistics and parameters; not part of `value`"}
+        except Exception as e:                                           # reporting only: never in the way of the metric
+            post = {"error": repr(e)}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -580,6 +601,7 @@ def encode_main(args):
             "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTUs in flight, all pictures together)",
             "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0), "run_ms": rv.get("run_ms", 0.0)},
             "cost_sum": float(cost.sum()),
+            "post_search": post,
         }
         if world == 1:
             out["cpu_baseline"] = cpu_baseline_encode(tw, th, Y0, Cb0, Cr0, cost, args.cpu_ctus)

@@ -163,7 +163,9 @@ extern "C" int hop_sao_frame(hop_ctx* c, const hop_sao_params* p, hop_sao_param*
   if (!stats || !recon) { free(stats); free(recon); return hop_set_err(c, HOP_ERR_DEVICE, "hop_sao_frame: out of host memory"); }
   rc = hop_sao_stats(c, stats);
   for (int k = 0; k < n_pic && rc == HOP_OK; k++) {                       // every picture of a stack is decided as a picture of its own
-    rc = hop_sao_decide(g.n_ctu, g.wctu, g.bd, stats + (size_t)k * per_pic * 5 * 32 * 2, p, coded + (size_t)k * per_pic, recon + (size_t)k * per_pic);
+    hop_sao_params pk = *p;                                               // a stack coded by hop_encode_frame on this context: every picture starts from the fraction ITS last CTU left
+    if (n_pic > 1 && c->rd_fraction && c->rd_fraction_n == n_pic * g.n_ctu) pk.rd_fraction = c->rd_fraction[(size_t)k * g.n_ctu + g.n_ctu - 1];
+    rc = hop_sao_decide(g.n_ctu, g.wctu, g.bd, stats + (size_t)k * per_pic * 5 * 32 * 2, &pk, coded + (size_t)k * per_pic, recon + (size_t)k * per_pic);
     if (rc != HOP_OK) hop_set_err(c, rc, "hop_sao_frame: hop_sao_decide refused its arguments");
   }
   if (rc == HOP_OK) rc = hop_sao_apply(c, recon);

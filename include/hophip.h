@@ -701,7 +701,8 @@ int hop_sao_decide(int n_ctu, int ctus_per_row, int bit_depth, const int32_t* st
 /* replaces: TComSampleAdaptiveOffset::offsetCTU for every CTU (TLibCommon/TComSampleAdaptiveOffset.cpp:655-707, offsetBlock :365-653): recon (host, 3 per CTU) applied
  * to the context's reconstruction picture in place (the kernel reads an untouched copy, as the reference reads its m_tempPicYuv). */
 int hop_sao_apply(hop_ctx* ctx, const hop_sao_param* recon);
-/* the three steps for the picture(s) of the context: coded (n_ctu x 3 per picture) out; afterwards hop_recon_download gives the final reconstruction.
+/* the three steps for the picture(s) of the context: coded (n_ctu x 3 per picture) out; afterwards hop_recon_download gives the final reconstruction.  The pictures of a
+ * stacked context that hop_encode_frame coded on this context each start from the fraction their own last CTU left (params->rd_fraction is for a single picture).
  * replaces: TEncSampleAdaptiveOffset::SAOProcess (:251-283) after decidePicParams. */
 int hop_sao_frame(hop_ctx* ctx, const hop_sao_params* params, hop_sao_param* coded);
 

@@ -52,25 +52,26 @@ static void reference_faulted(int) { static const char m[] = "hop pic check: the
 #ifdef HOP_PIC_CPU
 #include <dlfcn.h>
 // the six entries of the library the binding uses, over the CPU spine (same argument meaning; the context is a record of the picture)
-struct hop_ctx { int w, h; std::vector<int16_t> org[3], rec[3]; };
+struct hop_ctx { int w, h, bd; std::vector<int16_t> org[3], rec[3]; };
 namespace {
 typedef long (*enc_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, void*);
 typedef long (*wpp_fn)(int, int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*, double*);
 typedef long (*lev_fn)(int32_t*, long); typedef long (*frac_fn)(uint16_t*, long);
+typedef long (*plain_fn)(int, int, int, int, const int16_t*, const int16_t*, const int16_t*, const char*, double*, uint32_t*, uint32_t*, void*, int16_t*, int16_t*, int16_t*);
 typedef int (*dbk_fn)(int, int, int, int, int, int, int, int, int, const void*, int16_t*, int16_t*, int16_t*);
 typedef int (*sst_fn)(int, int, int, const int16_t* const*, const int16_t* const*, int32_t*); typedef int (*sap_fn)(int, int, int, const int16_t* const*, const void*, int16_t* const*);
 typedef int (*sdc_fn)(int, int, int, const int32_t*, const hop_sao_params*, hop_sao_param*, hop_sao_param*);
-enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; dbk_fn g_dbk = NULL; sst_fn g_sst = NULL; sap_fn g_sap = NULL; sdc_fn g_sdc = NULL; std::string g_err = "no error";
+enc_fn g_enc = NULL; wpp_fn g_wpp = NULL; lev_fn g_lev = NULL; frac_fn g_frac = NULL; dbk_fn g_dbk = NULL; sst_fn g_sst = NULL; sap_fn g_sap = NULL; sdc_fn g_sdc = NULL; plain_fn g_plain = NULL; std::string g_err = "no error";
 }
 extern "C" {
 int hop_ctx_create(hop_ctx** out, int w, int h, int bdy, int bdc, int) {
   const char* so = getenv("HOP_PIC_SPINE");
   void* lib = so ? dlopen(so, RTLD_NOW | RTLD_LOCAL) : NULL;
   if (!lib) { g_err = so ? dlerror() : "HOP_PIC_SPINE names the CPU spine library"; return HOP_ERR_DEVICE; }
-  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction"); g_dbk = (dbk_fn)dlsym(lib, "hop_o_deblock_frame"); g_sst = (sst_fn)dlsym(lib, "hop_o_sao_stats"); g_sap = (sap_fn)dlsym(lib, "hop_o_sao_apply"); g_sdc = (sdc_fn)dlsym(lib, "hop_sao_decide");
+  g_enc = (enc_fn)dlsym(lib, "hop_spine_cpu_encode"); g_wpp = (wpp_fn)dlsym(lib, "hop_spine_cpu_encode_wpp"); g_lev = (lev_fn)dlsym(lib, "hop_spine_cpu_last_levels"); g_frac = (frac_fn)dlsym(lib, "hop_spine_cpu_last_rd_fraction"); g_dbk = (dbk_fn)dlsym(lib, "hop_o_deblock_frame"); g_sst = (sst_fn)dlsym(lib, "hop_o_sao_stats"); g_sap = (sap_fn)dlsym(lib, "hop_o_sao_apply"); g_sdc = (sdc_fn)dlsym(lib, "hop_sao_decide"); g_plain = (plain_fn)dlsym(lib, "hop_spine_cpu_encode_plain");
   int (*szp)(void) = (int (*)(void))dlsym(lib, "hop_spine_sizeof_part");
-  if (!g_enc || !g_wpp || !g_lev || !g_frac || !g_dbk || !g_sst || !g_sap || !g_sdc || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != 8 || bdc != 8) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
-  *out = new hop_ctx(); (*out)->w = w; (*out)->h = h; return HOP_OK;
+  if (!g_enc || !g_wpp || !g_lev || !g_frac || !g_dbk || !g_sst || !g_sap || !g_sdc || !g_plain || !szp || szp() != (int)sizeof(hop_cu_part) || bdy != bdc || (bdy != 8 && bdy != 10)) { g_err = "not the spine library this binding was written for"; return HOP_ERR_DEVICE; }
+  *out = new hop_ctx(); (*out)->w = w; (*out)->h = h; (*out)->bd = bdy; return HOP_OK;
 }
 void hop_ctx_destroy(hop_ctx* c) { delete c; }
 const char* hop_last_error(const hop_ctx*) { return g_err.c_str(); }
@@ -82,8 +83,9 @@ int hop_upload_orig(hop_ctx* c, const int16_t* y, int sy, const int16_t* cb, con
   return HOP_OK;
 }
 int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* cost, uint32_t* bits, uint32_t* dist, hop_cu_part* parts, uint64_t* nc) {
-  if (p->plain_intra || p->first_ctus) { g_err = "the adapter covers the HOP configuration, whole pictures"; return HOP_ERR_ARG; }
-  const long n = (p->wpp || p->wavefront_lag) ? g_wpp(c->w, c->h, p->qp, p->mi_size, p->wavefront_lag, &c->org[0][0], &c->org[1][0], &c->org[2][0], p->trace_path, cost, bits, dist, parts,
+  if (p->first_ctus || (p->plain_intra && (p->wpp || p->wavefront_lag)) || (!p->plain_intra && c->bd != 8)) { g_err = "the adapter covers whole pictures: the HOP configuration (8 bit), the plain intra ones in raster order"; return HOP_ERR_ARG; }
+  const long n = p->plain_intra ? g_plain(c->w, c->h, p->qp, c->bd, &c->org[0][0], &c->org[1][0], &c->org[2][0], p->trace_path, cost, bits, dist, parts, &c->rec[0][0], &c->rec[1][0], &c->rec[2][0]) :
+                 (p->wpp || p->wavefront_lag) ? g_wpp(c->w, c->h, p->qp, p->mi_size, p->wavefront_lag, &c->org[0][0], &c->org[1][0], &c->org[2][0], p->trace_path, cost, bits, dist, parts,
                                                       &c->rec[0][0], &c->rec[1][0], &c->rec[2][0], NULL)
                                                : g_enc(c->w, c->h, p->qp, p->mi_size, 0, &c->org[0][0], &c->org[1][0], &c->org[2][0], p->trace_path, cost, bits, dist, parts,
                                                       &c->rec[0][0], &c->rec[1][0], &c->rec[2][0], NULL);
@@ -94,22 +96,22 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* cost, uint32_t
 int hop_levels_download(hop_ctx* c, int32_t* out) { const long n = (long)((c->w + 63) / 64) * ((c->h + 63) / 64) * 6144; return g_lev(out, n) == n ? HOP_OK : HOP_ERR_DEVICE; }
 int hop_rd_fraction_download(hop_ctx* c, uint16_t* out) { const long n = (long)((c->w + 63) / 64) * ((c->h + 63) / 64); return g_frac(out, n) == n ? HOP_OK : HOP_ERR_DEVICE; }
 int hop_deblock_frame(hop_ctx* c, const hop_deblock_params* p, const hop_cu_part* parts) {
-  return g_dbk(c->w, c->h, 8, p->qp, p->beta_offset_div2, p->tc_offset_div2, p->cb_qp_offset, p->cr_qp_offset, p->disable, parts, &c->rec[0][0], &c->rec[1][0], &c->rec[2][0]) == 0 ? HOP_OK : HOP_ERR_DEVICE;
+  return g_dbk(c->w, c->h, c->bd, p->qp, p->beta_offset_div2, p->tc_offset_div2, p->cb_qp_offset, p->cr_qp_offset, p->disable, parts, &c->rec[0][0], &c->rec[1][0], &c->rec[2][0]) == 0 ? HOP_OK : HOP_ERR_DEVICE;
 }
-int hop_sao_stats(hop_ctx* c, int32_t* stats) { const int16_t* s[3] = { &c->rec[0][0], &c->rec[1][0], &c->rec[2][0] }; const int16_t* o[3] = { &c->org[0][0], &c->org[1][0], &c->org[2][0] }; return g_sst(c->w, c->h, 8, s, o, stats) == 0 ? HOP_OK : HOP_ERR_DEVICE; }
+int hop_sao_stats(hop_ctx* c, int32_t* stats) { const int16_t* s[3] = { &c->rec[0][0], &c->rec[1][0], &c->rec[2][0] }; const int16_t* o[3] = { &c->org[0][0], &c->org[1][0], &c->org[2][0] }; return g_sst(c->w, c->h, c->bd, s, o, stats) == 0 ? HOP_OK : HOP_ERR_DEVICE; }
 int hop_sao_frame(hop_ctx* c, const hop_sao_params* p, hop_sao_param* coded) {      // the product's three steps: statistics and offsetting by the restatement, the decision by the product's host logic
   const int wctu = (c->w + 63) / 64, n = wctu * ((c->h + 63) / 64);
   std::vector<int32_t> st((size_t)n * 3 * 5 * 32 * 2); std::vector<hop_sao_param> recon((size_t)n * 3);
-  if (hop_sao_stats(c, &st[0]) != HOP_OK || g_sdc(n, wctu, 8, &st[0], p, coded, &recon[0]) != HOP_OK) return HOP_ERR_DEVICE;
+  if (hop_sao_stats(c, &st[0]) != HOP_OK || g_sdc(n, wctu, c->bd, &st[0], p, coded, &recon[0]) != HOP_OK) return HOP_ERR_DEVICE;
   std::vector<int16_t> out[3]; const int16_t* s[3]; int16_t* d[3];
   for (int k = 0; k < 3; k++) { out[k].resize(c->rec[k].size()); s[k] = &c->rec[k][0]; d[k] = &out[k][0]; }
-  if (g_sap(c->w, c->h, 8, s, &recon[0], d) != 0) return HOP_ERR_DEVICE;
+  if (g_sap(c->w, c->h, c->bd, s, &recon[0], d) != 0) return HOP_ERR_DEVICE;
   for (int k = 0; k < 3; k++) c->rec[k] = out[k];
   return HOP_OK;
 }
 int hop_psnr(hop_ctx* c, uint64_t*, double* psnr) {                        // (plain loops: the adapter has no restatement to call for three sums)
   for (int k = 0; k < 3; k++) { unsigned long long s = 0; for (size_t i = 0; i < c->rec[k].size(); i++) { const int d = c->org[k][i] - c->rec[k][i]; s += (unsigned long long)(d * d); }
-                                const double ref = 255.0 * 255.0 * c->w * c->h / (k ? 4.0 : 1.0); psnr[k] = s ? 10.0 * log10(ref / (double)s) : 99.99; }
+                                const double mv = (double)(255 << (c->bd - 8)), ref = mv * mv * c->w * c->h / (k ? 4.0 : 1.0); psnr[k] = s ? 10.0 * log10(ref / (double)s) : 99.99; }
   return HOP_OK;
 }
 int hop_recon_upload(hop_ctx* c, int comp, const int16_t* src) { memcpy(&c->rec[comp][0], src, c->rec[comp].size() * 2); return HOP_OK; }
@@ -130,11 +132,13 @@ struct Binding {
   // one picture through the library: TEncGOP::compressGOP has set the slice up (QP, lambda, ISS type); TEncSlice::compressSlice is about to loop over its CTUs
   void code_picture(TEncCu* enc, TComDataCU* cu) {
     TComSlice* sl = cu->getSlice(); TEncCfg* cfg = enc->m_pcEncCfg;
-    if (!sl->isIntraSS() || g_bitDepthY != 8 || g_bitDepthC != 8 || g_uiMaxCUWidth != 64 || g_uiMaxCUDepth != 4) { fprintf(stderr, "hop pic binding: bound for the 8-bit ISS pictures of cfg/3DHencoder_intra_main.cfg\n"); exit(1); }
+    // the HOP configuration (ISS slices, 8 bit) or the plain intra configurations (I slices, 8 or 10 bit: cfg/encoder_intra_main.cfg, encoder_intra_main10.cfg)
+    const bool iss = sl->isIntraSS();
+    if ((!iss && !sl->isIntra()) || g_bitDepthY != g_bitDepthC || (iss && g_bitDepthY != 8) || (g_bitDepthY != 8 && g_bitDepthY != 10) || g_uiMaxCUWidth != 64 || g_uiMaxCUDepth != 4) { fprintf(stderr, "hop pic binding: bound for ISS pictures at 8 bit and I pictures at 8 / 10 bit, 64x64 CTUs\n"); exit(1); }
     if (!ctx) {
       w = sl->getSPS()->getPicWidthInLumaSamples(); h = sl->getSPS()->getPicHeightInLumaSamples(); wctu = (w + 63) / 64; n = wctu * ((h + 63) / 64);
       if (hop_ctx_create(&ctx, w, h, g_bitDepthY, g_bitDepthC, 0) != HOP_OK) fail("hop_ctx_create");
-      if (hop_ctx_set_slots(ctx, env_int("HOP_PIC_SLOTS", 16)) != HOP_OK) fail("hop_ctx_set_slots");              // the candidates of a CU side by side (no effect on the results)
+      if (iss && hop_ctx_set_slots(ctx, env_int("HOP_PIC_SLOTS", 16)) != HOP_OK) fail("hop_ctx_set_slots");              // the candidates of a CU side by side (no effect on the results)
       cost.resize(n); bits.resize(n); dist.resize(n); parts.resize((size_t)n * 256); levels.resize((size_t)n * 6144); fraction.resize(n);
       rec[0].resize((size_t)w * h); rec[1].resize((size_t)w * h / 4); rec[2].resize((size_t)w * h / 4);
     }
@@ -142,7 +146,7 @@ struct Binding {
     TComPicYuv* org = cu->getPic()->getPicYuvOrg();
     if (hop_upload_orig(ctx, org->getLumaAddr(), org->getStride(), org->getCbAddr(), org->getCrAddr(), org->getCStride()) != HOP_OK) fail("hop_upload_orig");
     hop_enc_params p; memset(&p, 0, sizeof(p));
-    p.qp = sl->getSliceQp(); p.mi_size = sl->getMicroImSize();
+    p.qp = sl->getSliceQp(); p.mi_size = iss ? sl->getMicroImSize() : 16; p.plain_intra = iss ? 0 : 1;
     p.wpp = cfg->getWaveFrontsynchro() ? 1 : 0;                                                                    // TEncSlice.cpp:1027-1051: the rows' coders synchronised
     p.wavefront_lag = p.wpp ? env_int("HOP_PIC_LAG", 5) : 0;                                                       // rows in flight together only where the reference's rows are independent
     uint64_t nc = 0;

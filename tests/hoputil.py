@@ -175,6 +175,21 @@ def hop_encoder_args(W, H, qp=32, mi=16, **over):
                                                    "--SEIDecodedPictureHash=1", "-b", "s.bin", "-o", "rec.yuv"]
 
 
+def plain_encoder_args(W, H, qp, bit_depth, **over):
+    """the plain HM intra configurations (cfg/encoder_intra_main.cfg, encoder_intra_main10.cfg: I slices, no SS / GT search) as options: what differs from the HOP list"""
+    o = dict(HOP_ENCODER_OPTIONS, **over)
+    for k in ("HoloscopicIntra", "MIMergeCand"): del o[k]
+    o.update({"FastSearch": 1, "SearchRange": 64, "InternalBitDepth": bit_depth, "Profile": "main" if bit_depth == 8 else "main10"})
+    return ["--%s=%s" % kv for kv in o.items()] + ["-i", "in.yuv", "-wdt", str(W), "-hgt", str(H), "-fr", "30", "-f", "1", "-q", str(qp), "--InputBitDepth=%d" % bit_depth,
+                                                   "--SEIDecodedPictureHash=1", "-b", "s.bin", "-o", "rec.yuv"]
+
+
+def pic_case_args(c):
+    if "plain" in c:
+        return plain_encoder_args(c["W"], c["H"], c["plain"][1], c["plain"][0], **c["over"]) + c["extra"]
+    return hop_encoder_args(c["W"], c["H"], **c["over"]) + c["extra"]
+
+
 # the pictures of the picture-level binding tests (golden: tests/golden/encoder_hop_pic.json, made by oracle/make_golden21.py with the unmodified reference encoder)
 PIC_CASES = {
     "64x64_raster":    {"W": 64, "H": 64, "seed": 1234, "frames": 1, "over": {}, "extra": []},
@@ -183,14 +198,19 @@ PIC_CASES = {
     "200x104_raster":  {"W": 200, "H": 104, "seed": 11, "frames": 1, "over": {}, "extra": []},                 # neither dimension a multiple of the CTU: partial CTUs right and below
     "448x192_wpp":     {"W": 448, "H": 192, "seed": 3, "frames": 1, "over": {"WaveFrontSynchro": 1, "WaveFrontSubstreams": 3}, "extra": []},
     "128x64_2frames":  {"W": 128, "H": 64, "seed": 5, "frames": 2, "over": {}, "extra": ["-f", "2"]},          # the context and the binding's buffers reused for a second picture
+    # the plain HM intra configurations (BASELINE configs 1 and 4): I slices, 8 bit QP 32 and 10 bit QP 27, a picture with partial CTUs
+    "136x72_plain8":   {"W": 136, "H": 72, "seed": 9, "frames": 1, "over": {}, "extra": [], "plain": (8, 32)},
+    "136x72_plain10":  {"W": 136, "H": 72, "seed": 9, "frames": 1, "over": {}, "extra": [], "plain": (10, 27)},
 }
 
 
 def pic_case_input(c):
     raw = b""
+    bd = c["plain"][0] if "plain" in c else 8
+    dt = np.uint8 if bd == 8 else np.dtype("<u2")
     for f in range(c["frames"]):
-        Y, Cb, Cr = lenslet(c["W"], c["H"], 16, c["seed"] + 100 * f)
-        raw += Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes()
+        Y, Cb, Cr = lenslet(c["W"], c["H"], 16, c["seed"] + 100 * f, bitdepth=bd)
+        raw += Y.astype(dt).tobytes() + Cb.astype(dt).tobytes() + Cr.astype(dt).tobytes()
     return raw
 
 

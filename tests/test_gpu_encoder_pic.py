@@ -38,7 +38,7 @@ def test_reference_encoder_with_the_library_deblocking_too(key):
     check(key, got, counts)
 
 
-@pytest.mark.parametrize("key", ["200x104_raster", "448x192_wpp", "128x64_2frames", "192x128_raster"])
+@pytest.mark.parametrize("key", ["200x104_raster", "448x192_wpp", "128x64_2frames", "192x128_raster", "136x72_plain8", "136x72_plain10"])
 def test_reference_encoder_with_the_library_deblocking_and_sao(key):
     """HOP_PIC_DEBLOCK + HOP_PIC_SAO: everything between the original and the entropy coder is the library's -- hop_encode_frame, hop_deblock_frame, hop_sao_frame (its
     statistics and offsetting kernels, its decision starting from hop_rd_fraction_download's fraction); the reference writes the SAO parameters the library chose and hashes

@@ -244,7 +244,7 @@ namespace {
 // reference's TComDataCU / TComPicYuv and into the library's context alike.  Both filters then run on the same input (HOP_PIC_CHECK compares).  HOP_PIC_LF_DUMP=<file>:
 // the input and the REFERENCE's output are written out: the fixtures of tests/golden/deblock_ref.npz (oracle/make_golden22.py) for the GPU test.
 struct Fuzz {
-  uint64_t s; int w, h, wctu;
+  uint64_t s; int w, h, wctu; bool all_intra;   // all_intra: the carrier picture is an I slice (no reference picture: SS / GT CUs cannot occur in it)
   uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
   int below(int n) { return (int)(next() % (uint32_t)n); }
   static int z(int ux, int uy) { int v = 0; for (int b = 0; b < 4; b++) v |= (((ux >> b) & 1) << (2 * b)) | (((uy >> b) & 1) << (2 * b + 1)); return v; }
@@ -258,7 +258,7 @@ struct Fuzz {
     if (x >= w || y >= h) { for (int yy = 0; yy < su; yy++) for (int xx = 0; xx < su; xx++) { hop_cu_part& p = ctu[z(ux + xx, uy + yy)]; memset(&p, 0, sizeof(p)); p.depth = (uint8_t)d; p.pred_mode = 15; p.part_size = 15; p.ref_idx = -1; } return; }
     const bool crosses = x + size > w || y + size > h;
     if (crosses || (d < 3 && below(100) < 55)) { const int hh = su >> 1; for (int q = 0; q < 4; q++) cu_tree(ctu, cx, cy, ux + (q & 1) * hh, uy + (q >> 1) * hh, hh, d + 1); return; }
-    const bool intra = below(100) < 35;
+    const bool intra = all_intra ? true : below(100) < 35;
     int ps = 0;
     if (intra) ps = (d == 3 && below(2)) ? 3 : 0; else { ps = below(size >= 16 ? 8 : 3); if (ps == 3) ps = 0; }
     for (int yy = 0; yy < su; yy++) for (int xx = 0; xx < su; xx++) {
@@ -281,7 +281,7 @@ struct Fuzz {
 };
 void fuzz_picture(TComPic* pic, const char* spec) {
   long v[6] = { 1, 32, 0, 0, 0, 0 }; { const char* q = spec; for (int k = 0; k < 6 && q && *q; k++) { v[k] = strtol(q, (char**)&q, 10); if (*q == ':') q++; } }
-  Fuzz f; f.s = 0x9E3779B97F4A7C15ull ^ (uint64_t)v[0] * 0x100000001B3ull; f.w = g_b.w; f.h = g_b.h; f.wctu = g_b.wctu;
+  Fuzz f; f.s = 0x9E3779B97F4A7C15ull ^ (uint64_t)v[0] * 0x100000001B3ull; f.w = g_b.w; f.h = g_b.h; f.wctu = g_b.wctu; f.all_intra = !pic->getSlice(0)->isIntraSS();
   for (int k = 0; k < 8; k++) f.next();
   TComSlice* sl = pic->getSlice(0);
   sl->setSliceQp((Int)v[1]); sl->setDeblockingFilterBetaOffsetDiv2((Int)v[2]); sl->setDeblockingFilterTcOffsetDiv2((Int)v[3]); sl->getPPS()->setChromaCbQpOffset((Int)v[4]); sl->getPPS()->setChromaCrQpOffset((Int)v[5]);
@@ -291,7 +291,8 @@ void fuzz_picture(TComPic* pic, const char* spec) {
     std::vector<int> base((size_t)bw * ((ph + bs - 1) / bs));
     for (size_t i = 0; i < base.size(); i++) { const int left = (i % bw) ? base[i - 1] : 60 + f.below(130); const int step = f.below(100) < 55 ? f.below(9) - 4 : f.below(41) - 20; base[i] = std::min(250, std::max(5, left + step)); }
     const int noise = 1 + f.below(3);
-    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) g_b.rec[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, base[(size_t)(y / bs) * bw + x / bs] + f.below(2 * noise + 1) - noise));
+    const int up = g_bitDepthY - 8;                                          // a 10-bit picture: the same picture four times as large, with its own low bits
+    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) { const int v8 = std::min(255, std::max(0, base[(size_t)(y / bs) * bw + x / bs] + f.below(2 * noise + 1) - noise)); g_b.rec[c][(size_t)y * pw + x] = (int16_t)(up ? std::min((1 << g_bitDepthY) - 1, (v8 << up) + f.below(1 << up)) : v8); }
     if (hop_recon_upload(g_b.ctx, c, &g_b.rec[c][0]) != HOP_OK) g_b.fail("hop_recon_upload");
   }
   std::fill(g_b.levels.begin(), g_b.levels.end(), 0);
@@ -299,8 +300,8 @@ void fuzz_picture(TComPic* pic, const char* spec) {
 }
 void dump_fixture(const char* path, const hop_deblock_params& p, const std::vector<int16_t> before[3], TComPicYuv* after) {
   FILE* f = fopen(path, "ab"); if (!f) return;
-  const int32_t hd[9] = { g_b.w, g_b.h, p.qp, p.beta_offset_div2, p.tc_offset_div2, p.cb_qp_offset, p.cr_qp_offset, g_b.n, (int32_t)sizeof(hop_cu_part) };
-  fwrite(hd, 4, 9, f); fwrite(&g_b.parts[0], sizeof(hop_cu_part), g_b.parts.size(), f);
+  const int32_t hd[10] = { g_b.w, g_b.h, p.qp, p.beta_offset_div2, p.tc_offset_div2, p.cb_qp_offset, p.cr_qp_offset, g_b.n, (int32_t)sizeof(hop_cu_part), g_bitDepthY };
+  fwrite(hd, 4, 10, f); fwrite(&g_b.parts[0], sizeof(hop_cu_part), g_b.parts.size(), f);
   for (int c = 0; c < 3; c++) fwrite(&before[c][0], 2, before[c].size(), f);
   for (int y = 0; y < g_b.h; y++) fwrite(after->getLumaAddr() + (size_t)y * after->getStride(), 2, g_b.w, f);
   for (int y = 0; y < g_b.h / 2; y++) fwrite(after->getCbAddr() + (size_t)y * after->getCStride(), 2, g_b.w / 2, f);
@@ -356,7 +357,7 @@ namespace {
 void sao_fuzz(TComPic* pic, const char* spec, double scale_out[1]) {
   long v[2] = { 1, 100 }; { const char* q = spec; for (int k = 0; k < 2 && q && *q; k++) { v[k] = strtol(q, (char**)&q, 10); if (*q == ':') q++; } }
   scale_out[0] = (double)v[1] / 100.0;
-  Fuzz f; f.s = 0xD1B54A32D192ED03ull ^ (uint64_t)v[0] * 0x100000001B3ull; f.w = g_b.w; f.h = g_b.h; f.wctu = g_b.wctu; for (int k = 0; k < 8; k++) f.next();
+  Fuzz f; f.s = 0xD1B54A32D192ED03ull ^ (uint64_t)v[0] * 0x100000001B3ull; f.w = g_b.w; f.h = g_b.h; f.wctu = g_b.wctu; f.all_intra = false; for (int k = 0; k < 8; k++) f.next();
   std::vector<int> kind(g_b.n);
   for (int a = 0; a < g_b.n; a++) kind[a] = (a % g_b.wctu && f.below(100) < 40) ? kind[a - 1] : f.below(7);
   std::vector<int16_t> org[3];
@@ -366,7 +367,7 @@ void sao_fuzz(TComPic* pic, const char* spec, double scale_out[1]) {
     const int fx = 3 + f.below(9), fy = 3 + f.below(9), amp = 20 + f.below(60), mid = 60 + f.below(130);
     for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
       const int tri = abs(((x * 16 / fx) + (y * 16 / fy)) % 64 - 32) - 16;                 // a slanted triangle wave + texture
-      org[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, mid + tri * amp / 16 + f.below(7) - 3));
+      org[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, mid + tri * amp / 16 + f.below(7) - 3));                 // (8-bit values; scaled below)
     }
     for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
       const int k = kind[(y / cs) * g_b.wctu + x / cs], o = org[c][(size_t)y * pw + x];
@@ -383,6 +384,9 @@ void sao_fuzz(TComPic* pic, const char* spec, double scale_out[1]) {
         default: break;
       }
       g_b.rec[c][(size_t)y * pw + x] = (int16_t)std::min(255, std::max(0, r));
+    }
+    if (const int up = g_bitDepthY - 8) for (size_t i = 0; i < org[c].size(); i++) {   // a 10-bit picture: both planes four times as large, the same low bits in both plus a little noise in the reconstruction
+      const int lo = f.below(1 << up); org[c][i] = (int16_t)((org[c][i] << up) + lo); g_b.rec[c][i] = (int16_t)std::min((1 << g_bitDepthY) - 1, std::max(0, (g_b.rec[c][i] << up) + lo + f.below(3) - 1));
     }
   }
   TComPicYuv* po = pic->getPicYuvOrg(); TComPicYuv* pr = pic->getPicYuvRec();
@@ -443,8 +447,8 @@ Void TEncSampleAdaptiveOffset::SAOProcess(TComPic* pPic, Bool* sliceEnabled, con
       for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) { modes[dst[a][c].modeIdc]++; if (dst[a][c].modeIdc == SAO_MODE_NEW) types[dst[a][c].typeIdc]++; }
       fprintf(stderr, "hop pic check: fuzz: off %ld new %ld merge %ld; edge 0/90/135/45 %ld %ld %ld %ld band %ld\n", modes[0], modes[1], modes[2], types[0], types[1], types[2], types[3], types[4]);
       if (const char* dp = getenv("HOP_PIC_SAO_DUMP")) if (FILE* fo = fopen(dp, "ab")) {
-        const int32_t hd[6] = { w, h, n, p.slice_type, p.qp, (int32_t)p.rd_fraction };
-        fwrite(hd, 4, 6, fo); fwrite(p.lambda, 8, 3, fo);
+        const int32_t hd[7] = { w, h, n, p.slice_type, p.qp, (int32_t)p.rd_fraction, g_bitDepthY };
+        fwrite(hd, 4, 7, fo); fwrite(p.lambda, 8, 3, fo);
         TComPicYuv* po = pPic->getPicYuvOrg();
         for (int y = 0; y < h; y++) fwrite(po->getLumaAddr() + (size_t)y * po->getStride(), 2, w, fo);
         for (int y = 0; y < h / 2; y++) fwrite(po->getCbAddr() + (size_t)y * po->getCStride(), 2, w / 2, fo);

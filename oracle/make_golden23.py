@@ -9,39 +9,42 @@ import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from hoputil import hop_encoder_args, lenslet  # noqa: E402
+from hoputil import hop_encoder_args, lenslet, plain_encoder_args  # noqa: E402
 
-CASES = [(200, 104, "1:100"), (200, 104, "2:30"), (200, 104, "4:10"), (200, 104, "6:3"), (256, 192, "7:20"), (256, 192, "8:100"), (256, 192, "9:1")]
+CASES = [(200, 104, "1:100"), (200, 104, "2:30"), (200, 104, "4:10"), (200, 104, "6:3"), (256, 192, "7:20"), (256, 192, "8:100"), (256, 192, "9:1"),
+         # 10 bit (an I slice of cfg/encoder_intra_main10.cfg carries the picture): offsets up to 31, the distortion shift of 4 bits, 32 bands of 32 values
+         (136, 72, "11:30", 10), (136, 72, "12:100", 10), (136, 72, "13:5", 10)]
 PAR = 36
 out = {}
-for i, (W, H, spec) in enumerate(CASES):
+for i, case in enumerate(CASES):
+    W, H, spec = case[:3]; bd = case[3] if len(case) > 3 else 8
     with tempfile.TemporaryDirectory() as td:
-        Y, Cb, Cr = lenslet(W, H, 16, 11)
-        open(os.path.join(td, "in.yuv"), "wb").write(Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes())
+        Y, Cb, Cr = lenslet(W, H, 16, 11, bitdepth=bd); dt = np.uint8 if bd == 8 else np.dtype("<u2")
+        open(os.path.join(td, "in.yuv"), "wb").write(Y.astype(dt).tobytes() + Cb.astype(dt).tobytes() + Cr.astype(dt).tobytes())
         for attempt in range(6):            # the reference's GT search reads past its buffer; now and then that kills the check run (see enc_shim_pic.cpp)
-            r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu")] + hop_encoder_args(W, H), cwd=td, capture_output=True, text=True,
+            r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu")] + (hop_encoder_args(W, H) if bd == 8 else plain_encoder_args(W, H, 27, bd)), cwd=td, capture_output=True, text=True,
                                env=dict(os.environ, HOP_PIC_CHECK="1", HOP_PIC_SAO="1", HOP_PIC_SAO_FUZZ=spec, HOP_PIC_SAO_DUMP=os.path.join(td, "d.bin"),
                                         HOP_PIC_SPINE=os.path.join(ROOT, "oracle", "libhop_spine_cpu.so")))
             if r.returncode != 77: break
         assert r.returncode == 0 and "SAO: 0 differences" in r.stderr, r.stderr[-800:]
         raw = open(os.path.join(td, "d.bin"), "rb").read()
-    hd = np.frombuffer(raw, "<i4", 6); assert hd[0] == W and hd[1] == H, hd
-    n = int(hd[2]); o = 24
+    hd = np.frombuffer(raw, "<i4", 7); assert hd[0] == W and hd[1] == H and hd[6] == bd, hd
+    n = int(hd[2]); o = 28
     lam = np.frombuffer(raw, "<f8", 3, o); o += 24
     planes = []
     for k in range(6):
         cnt = W * H if k % 3 == 0 else W * H // 4
-        planes.append(np.frombuffer(raw, "<i2", cnt, o).astype(np.uint8)); o += cnt * 2
+        planes.append(np.frombuffer(raw, "<i2", cnt, o).astype(np.uint8 if bd == 8 else np.uint16)); o += cnt * 2
     stats = np.frombuffer(raw, "<i4", n * 3 * 5 * 32 * 2, o).reshape(n, 3, 5, 32, 2); o += stats.size * 4
     par = np.frombuffer(raw, np.int8, n * 3 * PAR, o).reshape(n, 3, PAR); o += par.size
     outp = []
     for k in range(3):
         cnt = W * H if k == 0 else W * H // 4
-        outp.append(np.frombuffer(raw, "<i2", cnt, o).astype(np.uint8)); o += cnt * 2
+        outp.append(np.frombuffer(raw, "<i2", cnt, o).astype(np.uint8 if bd == 8 else np.uint16)); o += cnt * 2
     assert o == len(raw), (o, len(raw))
     key = "c%d" % i
-    out[key + "/geo"] = hd.astype(np.int32); out[key + "/lambda"] = lam.copy(); out[key + "/stats"] = stats; out[key + "/coded"] = par
+    out[key + "/geo"] = hd[:6].astype(np.int32); out[key + "/bd"] = np.int32(bd); out[key + "/lambda"] = lam.copy(); out[key + "/stats"] = stats; out[key + "/coded"] = par
     for k, nm in enumerate(("y", "cb", "cr")): out[key + "/org_" + nm] = planes[k]; out[key + "/in_" + nm] = planes[3 + k]; out[key + "/out_" + nm] = outp[k]
-    print(key, W, H, spec, [ln for ln in r.stderr.splitlines() if "fuzz" in ln][0])
+    print(key, W, H, spec, bd, [ln for ln in r.stderr.splitlines() if "fuzz" in ln][0])
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "sao_ref.npz"), **out)
 print(os.path.getsize(os.path.join(ROOT, "tests", "golden", "sao_ref.npz")), "bytes")

@@ -223,7 +223,7 @@ def deblock_cases():
         W, H, qp, beta, tc, cbo, cro = [int(v) for v in G[k + "/geo"]]
         planes_in = [G[k + "/in_" + n].astype(np.int16).reshape((H, W) if n == "y" else (H // 2, W // 2)) for n in ("y", "cb", "cr")]
         planes_out = [G[k + "/out_" + n].astype(np.int16).reshape((H, W) if n == "y" else (H // 2, W // 2)) for n in ("y", "cb", "cr")]
-        out.append((k, W, H, (qp, beta, tc, cbo, cro), np.ascontiguousarray(G[k + "/parts"]), planes_in, planes_out))
+        out.append((k, W, H, (qp, beta, tc, cbo, cro), np.ascontiguousarray(G[k + "/parts"]), planes_in, planes_out, int(G[k + "/bd"])))
     return out
 
 
@@ -239,7 +239,7 @@ def oracle_deblock(W, H, params, parts, planes, bit_depth=8, disable=0):
 
 def tile_deblock_case(case, nx, ny):
     """a picture of nx x ny copies of a CTU-aligned fixture picture (partition data and planes side by side): the seams are new edges between unrelated CUs"""
-    _, W, H, params, parts, pin, _ = case
+    _, W, H, params, parts, pin, _, _ = case
     assert W % 64 == 0 and H % 64 == 0
     wc, hc = W // 64, H // 64
     P = parts.reshape(hc, wc, 256, -1)
@@ -261,7 +261,7 @@ def sao_cases():
     for k in sorted(set(f.split("/")[0] for f in G.files)):
         W, H, n, st, qp, frac = [int(v) for v in G[k + "/geo"]]
         pl = lambda pre: [G[k + "/%s_%s" % (pre, c)].astype(np.int16).reshape((H, W) if c == "y" else (H // 2, W // 2)) for c in ("y", "cb", "cr")]
-        out.append({"key": k, "W": W, "H": H, "n": n, "slice_type": st, "qp": qp, "rd_fraction": frac, "lambda": [float(v) for v in G[k + "/lambda"]],
+        out.append({"key": k, "W": W, "H": H, "n": n, "slice_type": st, "qp": qp, "rd_fraction": frac, "bd": int(G[k + "/bd"]), "lambda": [float(v) for v in G[k + "/lambda"]],
                     "org": pl("org"), "in": pl("in"), "out": pl("out"), "stats": np.ascontiguousarray(G[k + "/stats"]), "coded": np.ascontiguousarray(G[k + "/coded"]).view(SAO_PARAM_DTYPE).reshape(n, 3)})
     return out
 

@@ -22,8 +22,8 @@ def _hp():
     return hophip
 
 
-def _run(hp, W, H, params, parts, planes, disable=0, pictures=1):
-    ctx = hp.Context(W, H, pictures=pictures)
+def _run(hp, W, H, params, parts, planes, disable=0, pictures=1, bd=8):
+    ctx = hp.Context(W, H, bd, pictures=pictures)
     for c in range(3):
         ctx.plane_upload("recon", c, planes[c])
     t0 = time.time()
@@ -34,21 +34,21 @@ def _run(hp, W, H, params, parts, planes, disable=0, pictures=1):
     return out, dt
 
 
-@pytest.mark.parametrize("case", deblock_cases(), ids=lambda c: "%s_%dx%d_qp%d" % (c[0], c[1], c[2], c[3][0]))
+@pytest.mark.parametrize("case", deblock_cases(), ids=lambda c: "%s_%dx%d_qp%d_%dbit" % (c[0], c[1], c[2], c[3][0], c[7]))
 def test_deblock_equals_the_reference_filter(case):
     hp = _hp()
-    key, W, H, params, parts, pin, pout = case
-    got, _ = _run(hp, W, H, params, parts, pin)
+    key, W, H, params, parts, pin, pout, bd = case
+    got, _ = _run(hp, W, H, params, parts, pin, bd=bd)
     for c in range(3):
         assert np.array_equal(got[c], pout[c]), (key, c, np.argwhere(got[c] != pout[c])[:5])
-    off, _ = _run(hp, W, H, params, parts, pin, disable=1)
+    off, _ = _run(hp, W, H, params, parts, pin, disable=1, bd=bd)
     assert all(np.array_equal(a, b) for a, b in zip(off, pin))
 
 
 def test_deblock_stacked_pictures():
     hp = _hp()
     cases = [c for c in deblock_cases() if (c[1], c[2]) == (200, 104)][:2]
-    (_, W, H, params, parts0, pin0, pout0), (_, _, _, _, parts1, pin1, _) = cases
+    (_, W, H, params, parts0, pin0, pout0, _), (_, _, _, _, parts1, pin1, _, _) = cases
     want1 = oracle_deblock(W, H, params, parts1, pin1)                     # the second fixture with the first one's parameters
     ctx = hp.Context(W, H, pictures=2)
     ctx.plane_upload("recon", 0, ctx.stack([pin0[0], pin1[0]]))

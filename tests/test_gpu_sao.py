@@ -29,10 +29,10 @@ def _ptrs(ps):
     return a, (ctypes.c_void_p * 3)(*[p.ctypes.data for p in a])
 
 
-@pytest.mark.parametrize("case", sao_cases(), ids=lambda c: "%s_%dx%d" % (c["key"], c["W"], c["H"]))
+@pytest.mark.parametrize("case", sao_cases(), ids=lambda c: "%s_%dx%d_%dbit" % (c["key"], c["W"], c["H"], c["bd"]))
 def test_sao_equals_the_reference_encoder(case):
     hp = _hp()
-    ctx = hp.Context(case["W"], case["H"])
+    ctx = hp.Context(case["W"], case["H"], case["bd"])
     ctx.upload_orig(*case["org"])
     for c in range(3):
         ctx.plane_upload("recon", c, case["in"][c])

@@ -1,5 +1,5 @@
 """CPU: the SAO encoder in three pieces against the reference's own TEncSampleAdaptiveOffset::SAOProcess (tests/golden/sao_ref.npz, oracle/make_golden23.py: seven random
-pictures, two sizes -- one with partial CTUs --, lambdas from 1 % to 100 % of the slice's; the reference chose off / new / merge, all four edge directions and band offsets).
+pictures at 8 bit, two sizes -- one with partial CTUs --, and three at 10 bit; lambdas from 1 % to 100 % of the slice's; the reference chose off / new / merge, all four edge directions and band offsets).
 
 1. the restated statistics pass (oracle/hop_oracle_sao.c) equals the reference's m_statData, every count and sum;
 2. the product's decision (hop_sao_decide, host logic of libhophip.so -- it needs no GPU) on those statistics gives the parameters the reference coded;
@@ -22,22 +22,23 @@ def _planes(ps):
     return a, (ctypes.c_void_p * 3)(*[p.ctypes.data for p in a])
 
 
-@pytest.mark.parametrize("case", sao_cases(), ids=lambda c: "%s_%dx%d" % (c["key"], c["W"], c["H"]))
+@pytest.mark.parametrize("case", sao_cases(), ids=lambda c: "%s_%dx%d_%dbit" % (c["key"], c["W"], c["H"], c["bd"]))
 def test_sao_pieces_equal_the_reference_encoder(case):
     O = oracle(); L = hophip.load()
     W, H, n = case["W"], case["H"], case["n"]
     src, psrc = _planes(case["in"]); org, porg = _planes(case["org"])
     stats = np.zeros((n, 3, 5, 32, 2), np.int32)
-    assert O.hop_o_sao_stats(W, H, 8, psrc, porg, stats.ctypes.data_as(ctypes.c_void_p)) == 0
+    bd = case["bd"]
+    assert O.hop_o_sao_stats(W, H, bd, psrc, porg, stats.ctypes.data_as(ctypes.c_void_p)) == 0
     assert np.array_equal(stats, case["stats"]), np.argwhere(stats != case["stats"])[:5]
     coded = np.zeros((n, 3), SAO_PARAM_DTYPE); recon = np.zeros((n, 3), SAO_PARAM_DTYPE)
     p = sao_params_of(case)
     L.hop_sao_decide.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
-    assert L.hop_sao_decide(n, (W + 63) // 64, 8, case["stats"].ctypes.data, ctypes.addressof(p), coded.ctypes.data, recon.ctypes.data) == 0
+    assert L.hop_sao_decide(n, (W + 63) // 64, bd, case["stats"].ctypes.data, ctypes.addressof(p), coded.ctypes.data, recon.ctypes.data) == 0
     assert same_coded(coded, case["coded"])
     assert len(set(int(m) for m in coded["mode"].reshape(-1))) >= 2
     out = [np.zeros_like(a) for a in src]; pout = (ctypes.c_void_p * 3)(*[a.ctypes.data for a in out])
-    assert O.hop_o_sao_apply(W, H, 8, psrc, recon.ctypes.data_as(ctypes.c_void_p), pout) == 0
+    assert O.hop_o_sao_apply(W, H, bd, psrc, recon.ctypes.data_as(ctypes.c_void_p), pout) == 0
     for c in range(3):
         assert np.array_equal(out[c], case["out"][c]), (c, np.argwhere(out[c] != case["out"][c])[:5])
 

@@ -21,7 +21,7 @@ REF = "/root/reference"
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_hop_pic.json")))
 
 
-def run_binding(exe, key, env):
+def run_binding(exe, key, env, decoder=None):
     c = PIC_CASES[key]
     raw = pic_case_input(c)
     assert hashlib.md5(raw).hexdigest() == GOLD[key]["input_md5"]
@@ -31,6 +31,15 @@ def run_binding(exe, key, env):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         md5 = lambda n: hashlib.md5(open(os.path.join(td, n), "rb").read()).hexdigest()
         got = {"bin_md5": md5("s.bin"), "rec_md5": md5("rec.yuv"), "bin_bytes": os.path.getsize(os.path.join(td, "s.bin"))}
+        dec_report = {}
+        if decoder:             # the stream just written, through a decoder: the decoded pictures are the encoder's reconstruction
+            d = subprocess.run([decoder, "-b", "s.bin", "-o", "dec.yuv"], cwd=td, capture_output=True, text=True, env=dict(os.environ, HOP_SHIM_REPORT="1"))
+            assert d.returncode == 0, d.stdout[-1500:] + d.stderr[-1500:]
+            assert md5("dec.yuv") == got["rec_md5"], "decoded pictures differ from the encoder's reconstruction"
+            assert "ERROR" not in d.stdout and "***ERROR***" not in d.stderr
+            for ln in d.stderr.splitlines():
+                if ln.startswith("hop dec binding:"):
+                    t = ln.split(":")[1].split(); dec_report = {"dec_" + t[i]: int(t[i + 1]) for i in range(0, len(t), 2)}
     # the PSNR the binding computed for each final picture (HOP_PIC_SAO) against the three numbers the reference prints per picture
     ours = [ln.split(":")[1].split() for ln in r.stderr.splitlines() if ln.startswith("hop pic psnr:")]
     theirs = [re.findall(r"\[Y\s+([0-9.]+) dB\s+U\s+([0-9.]+) dB\s+V\s+([0-9.]+) dB\]", ln)[0] for ln in r.stdout.splitlines() if ln.startswith("POC")]
@@ -39,7 +48,7 @@ def run_binding(exe, key, env):
     rep = [ln for ln in r.stderr.splitlines() if ln.startswith("hop pic binding:")]
     assert len(rep) == 1, r.stderr[-1500:]
     t = rep[0].split(":")[1].split()
-    return got, {t[i]: int(t[i + 1]) for i in range(0, len(t), 2)}
+    return got, dict({t[i]: int(t[i + 1]) for i in range(0, len(t), 2)}, **dec_report)
 
 
 def check(key, got, counts):
@@ -56,7 +65,10 @@ def test_reference_encoder_over_the_cpu_spine_writes_the_reference_bitstream(key
         pytest.skip("the reference tree is not present (GPU box)")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhop_spine_cpu.so"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j4", "_ref/TAppEncoderPicCpu"], stdout=subprocess.DEVNULL)
-    got, counts = run_binding(os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu"), key, {"HOP_PIC_SPINE": os.path.join(ROOT, "oracle", "libhop_spine_cpu.so")})
+    # (and round the loop: the reference DECODER reads the stream back to the reconstruction)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j4", "_ref/TAppDecoderRef"], stdout=subprocess.DEVNULL)
+    got, counts = run_binding(os.path.join(ROOT, "oracle", "_ref", "TAppEncoderPicCpu"), key, {"HOP_PIC_SPINE": os.path.join(ROOT, "oracle", "libhop_spine_cpu.so")},
+                              decoder=os.path.join(ROOT, "oracle", "_ref", "TAppDecoderRef") if key in ("200x104_raster", "192x128_wpp") else None)   # (HOP streams: the fork's decoder does not survive a plain I-slice stream, not even its own encoder's)
     check(key, got, counts)
 
 

@@ -48,3 +48,19 @@ def test_reference_encoder_with_the_library_deblocking_and_sao(key):
     got, counts = run_binding(EXE, key, {"HOP_PIC_DEBLOCK": "1", "HOP_PIC_SAO": "1"})
     assert counts["deblocked"] == PIC_CASES[key]["frames"] and counts["sao"] == PIC_CASES[key]["frames"]
     check(key, got, counts)
+
+
+DEC = os.path.join(ROOT, "oracle", "_ref", "TAppDecoderAbi")
+
+
+@pytest.mark.parametrize("key", ["192x128_raster", "200x104_raster", "448x192_wpp", "128x64_2frames"])
+def test_reference_decoder_over_the_library_decodes_to_the_reconstruction(key):
+    """SURVEY 8(f)-4, the decoder side of the shared predictor: oracle/_ref/TAppDecoderAbi is the reference DECODER with TComPrediction::xPredInterLumaBlk / ChromaBlk
+    replaced by hop_pred_inter and TDecCu::xFindSSRef2Copy followed by hop_ssref_commit_cus (oracle/dec_shim_abi.cpp): every SS / GT prediction of the decode comes from
+    the SS reference resident on the device.  It decodes the stream the encoder-side binding has just written (itself the reference's stream, byte for byte) to exactly the
+    encoder's reconstruction, and the decoder's own check of the picture hash SEI passes."""
+    if not (os.path.exists(EXE) and os.path.exists(DEC)):
+        pytest.skip("oracle/_ref/TAppEncoderPic / TAppDecoderAbi were not built")
+    got, counts = run_binding(EXE, key, {"HOP_PIC_DEBLOCK": "1", "HOP_PIC_SAO": "1"}, decoder=DEC)
+    check(key, got, counts)
+    assert counts["dec_pictures"] == PIC_CASES[key]["frames"] and counts["dec_predictions"] > 20 and counts["dec_gt"] > 0 and counts["dec_commits"] > 10, counts

@@ -80,6 +80,22 @@ def test_reference_binding_links_against_the_library():
         assert re.search(r" T " + re.escape(member) + r"\(", syms), member
 
 
+def test_picture_level_and_decoder_bindings_link_against_the_library():
+    """oracle/_ref/TAppEncoderPic (compressCU, loopFilterPic, SAOProcess over the library) and oracle/_ref/TAppDecoderAbi (the decoder's predictor and SS-reference upkeep):
+    every hop_* symbol they call is exported, and the replaced members in the linked programs are the bindings'"""
+    enc, dec = _ref_build("TAppEncoderPic", "TAppDecoderAbi")
+    exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", hophip.LIB_PATH], text=True).splitlines() if " T hop_" in ln}
+    want = {enc: {"hop_encode_frame", "hop_levels_download", "hop_rd_fraction_download", "hop_recon_download", "hop_deblock_frame", "hop_sao_frame", "hop_sao_stats", "hop_psnr", "hop_upload_orig"},
+            dec: {"hop_pred_inter", "hop_ssref_commit_cus", "hop_ssref_reset", "hop_ctx_create"}}
+    members = {enc: ("TEncCu::compressCU", "TComLoopFilter::loopFilterPic", "TEncSampleAdaptiveOffset::SAOProcess"), dec: ("TComPrediction::xPredInterLumaBlk", "TDecCu::xFindSSRef2Copy")}
+    for exe in (enc, dec):
+        undefined = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--undefined-only", exe], text=True).splitlines() if " hop_" in ln}
+        assert want[exe] <= undefined <= exported, (exe, want[exe] - undefined, undefined - exported)
+        syms = subprocess.check_output(["nm", "-C", exe], text=True)
+        for m in members[exe]:
+            assert re.search(r" T " + re.escape(m) + r"\(", syms), (exe, m)
+
+
 
 
 def test_reference_binding_marshals_every_field():

@@ -14,6 +14,10 @@
 // With -DHOP_PIC_CPU the six hop_* entries the binding calls are adapters inside this file over the CPU spine (oracle/libhop_spine_cpu.so, named by HOP_PIC_SPINE):
 // oracle/_ref/TAppEncoderPicCpu runs in the build container (tests/test_encoder_pic.py), so the marshalling below is checked without a GPU, and the CPU spine's levels and
 // partition data are pinned to the reference's bitstream as well.
+// Further switches (all off by default; documented where they are implemented below): HOP_PIC_DEBLOCK / HOP_PIC_SAO replace TComLoopFilter::loopFilterPic and
+// TEncSampleAdaptiveOffset::SAOProcess by hop_deblock_frame / hop_sao_frame (+ hop_psnr); HOP_PIC_CHECK lets the reference's own member run on the same input and compares;
+// HOP_PIC_LF_FUZZ / HOP_PIC_SAO_FUZZ feed both with random pictures and HOP_PIC_LF_DUMP / HOP_PIC_SAO_DUMP write the reference's answers out as fixtures.  Besides the HOP
+// configuration (ISS slices, 8 bit) the binding carries the plain intra configurations (I slices, 8 and 10 bit) through hop_encode_frame's plain_intra mode.
 // This file never touches the CPU restatement except through those adapters.
 #include <cstdio>
 #include <cstdlib>

@@ -59,6 +59,21 @@ def test_struct_layout_matches_the_header():
     assert L.hop_sizeof(b"hop_no_such_struct") == -1
 
 
+def test_library_loads_and_exports_every_function_the_header_declares():
+    """every hop_* function declared in include/hophip.h (comments stripped) is a dynamic symbol of the built libhophip.so, the library loads without a GPU (no compute
+    call is made), and it exports nothing undeclared except the two internal entries named here"""
+    L = hophip.load()
+    text = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    declared = set(re.findall(r"\b(hop_\w+)\s*\(", text))
+    assert len(declared) >= 96
+    exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", hophip.LIB_PATH], text=True).splitlines() if " T hop_" in ln}
+    assert declared <= exported, sorted(declared - exported)
+    assert exported - declared <= {"hop_coef_put_device", "hop_fiber_switch"}, sorted(exported - declared)      # spine-internal helpers (k_spine.hip, the fibers' register switch)
+    for n in declared:
+        assert hasattr(L, n), n
+    assert b"gfx950" in L.hop_version()
+
+
 def _ref_build(*targets):
     if not os.path.isdir(REF):
         pytest.skip("the reference tree is not present (GPU box)")

@@ -10,6 +10,8 @@
 // the last candidate left it), the fields a PU carries while its merge candidates are rated (the GT vectors of its motion search), the partition
 // index handed to the micro-image candidates.
 #include "hop_spine.h"
+#include <map>
+#include <deque>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1085,7 +1087,7 @@ void Encoder::encode_frame(int first_ctus) {
 // wavefront: one thread per CTU row, requests of the rows in flight rendezvous and are served in batches
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
-struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; uint64_t tag; std::condition_variable* wake; };   // wake: the submitting thread's own (only it is woken when the request is done)
+struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; uint64_t tag; std::condition_variable* wake; bool posted; int worker; };   // wake: the submitting thread's own (only it is woken when the request is done)
 enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTORE, RQ_COMMIT, RQ_PCOST };
 
 // one group of requests of the same kind (and class) as one call of the batching backend
@@ -1217,7 +1219,7 @@ class FiberPool : public Backend {
   struct Fiber { void* sp; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool;
                  Fiber* parent; int live_children; bool wait_children; uint64_t tag; };   // parent: a child of fork_join (recycled when done)
   FiberPool(BatchInner* inner, int n_workers) : rounds(0), requests(0), steps_complete(-1), inner_(inner), T_(n_workers), failed_(false), finished_(false), arrived_(0), gen_(0), left_(0), idle_rounds_(0) {
-    sched_.resize(T_); mine_.resize(T_); local_.resize(T_); free_.resize(T_); kids_.resize(T_);
+    sched_.resize(T_); mine_.resize(T_); local_.resize(T_); free_.resize(T_); kids_.resize(T_); pstore_.resize(T_); pjobs_.resize(T_);
   }
   ~FiberPool() { for (Fiber* f : all_) { free(f->stack); delete f; } for (auto& v : kids_) for (Fiber* f : v) { free(f->stack); delete f; } }
   void add(std::function<void()> body) {
@@ -1255,15 +1257,15 @@ class FiberPool : public Backend {
   void set_tag(int, uint64_t tag) { current()->tag = tag; }            // the tag belongs to the fiber (children of fork_join carry their own)
   void begin_frame() {}
   void me_search(int lane, int n, const hop_pu_job* j, hop_pu_result* r) { Req q = { RQ_ME, lane, n, j, NULL, r, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
-  void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
+  void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; if (posted_mode_) post(q, j); else submit(q); }
   void distortion(int lane, int n, const hop_dist_job* j, uint32_t* o) { Req q = { RQ_DIST, lane, n, j, NULL, o, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void valid_pattern(int lane, int n, const int32_t* v, uint8_t* o) { Req q = { RQ_VALID, lane, n, v, NULL, o, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void pred_cost(int lane, int n, const hop_pred_job* j, int kind, uint32_t* o) { Req q = { RQ_PCOST, lane, n, j, NULL, o, kind, 0, 0, 0, false, 0, NULL }; submit(q); }
   void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTER, lane, 1, &e, &in, &o, e.job.log2_cu, e.skip_res, 0, 0, false, 0, NULL }; submit(q); }
   void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTRA, lane, 1, &e, &in, &o, e.job.log2_cu, e.part_nxn, 0, 0, false, 0, NULL }; submit(q); }
-  void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; submit(q); }
-  void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; submit(q); }
-  void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; submit(q); }
+  void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
+  void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void wait_step(int st) {                                              // until every wavefront step <= st is finished
     if (steps_complete.load() >= st) return;
     Fiber* f = current(); f->wait_step = st;
@@ -1293,6 +1295,19 @@ class FiberPool : public Backend {
     for (int i = 0; i < 6; i++) sp[i] = NULL;
     sp[6] = (void*)&tramp; sp[7] = NULL;
     f->sp = sp;
+  }
+  // A request without an answer (a prediction into the resident picture, a reconstruction put aside or brought back, a commit to the SS reference) need not stop its
+  // row: it is handed over and the row goes on; the next time requests are served, everything posted is issued first -- the stash / commit requests in the order each
+  // worker received them, then the predictions -- and only then the requests rows are waiting for.  A row's own order is kept (whatever consumes a posted request's effect
+  // is a waiting request of the same row, or a row of a later wavefront step, whose first request waits), and rounds that served nothing but such requests disappear
+  // (HOP_SPINE_POSTED=1; off by default until measured on the device: tests/test_spine_cpu.py runs both ways).
+  void post(Req& q, const hop_pred_job* jobs) {
+    if (failed_) throw 1;
+    Fiber* f = current(); const int w = f->worker;
+    q.tag = f->tag; q.posted = true; q.worker = w;
+    if (jobs) { pjobs_[w].emplace_back(jobs, jobs + q.n); q.a = pjobs_[w].back().data(); }
+    pstore_[w].push_back(q);
+    local_[w].push_back(&pstore_[w].back());
   }
   void submit(Req& q) {
     if (failed_) throw 1;
@@ -1335,7 +1350,7 @@ class FiberPool : public Backend {
     if (++arrived_ == T_) {                                             // every worker is out of runnable rows: serve, or finish
       lk.unlock();                                                      // (the others only watch gen_ from here on)
       for (int k = 0; k < T_; k++) { pending_.insert(pending_.end(), local_[k].begin(), local_[k].end()); local_[k].clear(); }
-      if (left_.load() == 0) finished_ = true;
+      if (left_.load() == 0) { if (posted_mode_ && !pending_.empty() && !failed_) { try { serve_posted(); } catch (...) { failed_ = true; } } finished_ = true; }
       else if (failed_) { for (Req* r : pending_) (void)r; pending_.clear(); }
       else if (!pending_.empty() || !inflight_.empty()) { serve(); idle_rounds_ = 0; }
       else if (++idle_rounds_ > 100000) failed_ = true;                 // rows waiting for a step nobody can finish
@@ -1359,9 +1374,29 @@ class FiberPool : public Backend {
     }
     return !finished_;
   }
+  void serve_posted() {                                                 // everything posted since the last serve, out of pending_
+    std::vector<std::vector<Req*> > seq(T_); std::vector<Req*> preds, rest;
+    for (Req* r : pending_) { if (!r->posted) rest.push_back(r); else if (r->kind == RQ_PRED) preds.push_back(r); else seq[r->worker].push_back(r); }
+    if (rest.size() == pending_.size()) return;
+    std::vector<size_t> at(T_, 0);
+    for (;;) {                                                            // stash / commit requests: waves of one kind, every worker's next run of that kind
+      int kind = -1; for (int w = 0; w < T_ && kind < 0; w++) if (at[w] < seq[w].size()) kind = seq[w][at[w]]->kind;
+      if (kind < 0) break;
+      std::vector<Req*> g;
+      for (int w = 0; w < T_; w++) while (at[w] < seq[w].size() && seq[w][at[w]]->kind == kind) g.push_back(seq[w][at[w]++]);
+      run_group(inner_, g); requests += g.size();
+    }
+    if (!preds.empty()) { run_group(inner_, preds); requests += preds.size(); }
+    pending_.swap(rest);
+    for (int w = 0; w < T_; w++) { pstore_[w].clear(); pjobs_[w].clear(); }
+  }
   void serve() {
     struct Clock { double& acc; std::chrono::steady_clock::time_point t0; explicit Clock(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
                    ~Clock() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } clock(serve_s);
+    if (posted_mode_) {
+      try { serve_posted(); } catch (...) { failed_ = true; }
+      if (failed_ || (pending_.empty() && inflight_.empty())) return;
+    }
     // the requests with the smallest tag; with candidates side by side (tag_shift = 20) the tag is cut down to the quadtree node: the candidates of a node are at
     // different steps of their chains at any moment, and all of them are served -- one launch chain per kind and class present
     uint64_t tmin = ~0ull; for (Req* r : pending_) if ((r->tag >> tag_shift) < tmin) tmin = r->tag >> tag_shift;
@@ -1397,6 +1432,7 @@ class FiberPool : public Backend {
         }
         inflight_.insert(inflight_.end(), early.begin(), early.end());
       }
+      { unsigned mask = 0; for (Req* r : v) mask |= 1u << r->kind; round_masks_[mask]++; }
       std::vector<char> used(v.size(), 0);
       for (size_t i = 0; i < v.size(); i++) {
         if (used[i]) continue;
@@ -1419,6 +1455,12 @@ class FiberPool : public Backend {
       for (size_t i = 0; i < v.size(); i++) v[i]->done = true;
     } catch (...) { failed_ = true; }
   }
+  std::map<unsigned, uint64_t> round_masks_;                            // HOP_SPINE_ROUND_STATS: how many rounds served which mix of request kinds
+ public:
+  void print_round_stats() { if (!getenv("HOP_SPINE_ROUND_STATS")) return; for (auto& kv : round_masks_) fprintf(stderr, "hop spine rounds: kinds %03x x %llu\n", kv.first, (unsigned long long)kv.second); }
+ private:
+  bool posted_mode_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); return e && atoi(e) != 0; }();
+  std::vector<std::deque<Req> > pstore_; std::vector<std::deque<std::vector<hop_pred_job> > > pjobs_;   // per worker: what was posted since the last serve (deques: addresses stay)
   std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
   std::vector<void*> sched_; std::vector<std::vector<Fiber*> > mine_; std::vector<std::vector<Req*> > local_; std::vector<Fiber*> all_; std::vector<Req*> pending_;
@@ -1499,7 +1541,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
       });
     }
     const std::chrono::steady_clock::time_point run_t0 = std::chrono::steady_clock::now();
-    pool.run();
+    pool.run(); pool.print_round_stats();
     const double run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count();
     for (int p = 0; p < n_pic; p++) {
       Encoder& E = *encs[p];

@@ -228,3 +228,39 @@ def test_stacked_pictures_equal_the_pictures_alone():
         if k == 0:
             check_against_golden(np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz")), "192x128_seed7_wpp", c1, b1, d1, p1, text)
     assert rr[1] / rr[0] > 1.5                    # requests of both pictures met in the batches
+
+
+@pytest.mark.parametrize("slots", ["0", "16"])
+def test_posted_requests_keep_every_result_and_save_rounds(slots, monkeypatch):
+    """HOP_SPINE_POSTED: requests without an answer (predictions, reconstructions put aside / brought back, commits) no longer stop their row; they are issued first whenever
+    requests are served.  The picture's candidates, costs, partition data, reconstruction, levels and the RD coder's fractions must be those of the reference run with
+    WaveFrontSynchro, and the rounds that served nothing else disappear (about a third of all rounds)."""
+    L = spine_cpu()
+    W, H, seed, lag = 192, 128, 7, 5
+    Y, Cb, Cr = frame(W, H, seed, False)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    monkeypatch.setenv("HOP_SPEC_SLOTS", slots)
+    out = {}
+    for posted in ("0", "1"):
+        monkeypatch.setenv("HOP_SPINE_POSTED", posted)
+        cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+        check_against_golden(G, key_of(W, H, seed, False) + "_wpp", cost, bits, dist, parts, text)
+        out[posted] = (cost, bits, dist, parts.tobytes(), [r.copy() for r in rec], cpu_last_levels(L, len(cost)), cpu_last_rd_fraction(L, len(cost)), rr.copy())
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4])) and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+    assert a[7][1] == b[7][1] and b[7][0] < 0.75 * a[7][0], (a[7], b[7])          # the same requests in fewer rounds
+    print("rounds", a[7][0], "->", b[7][0], "requests", a[7][1])
+
+
+def test_posted_requests_stacked_pictures(monkeypatch):
+    """the same with two pictures side by side on one rendezvous: each equals the picture coded alone"""
+    L = spine_cpu()
+    W, H, lag = 128, 64, 5
+    pics = [frame(W, H, 1234, False), frame(W, H, 21, False)]
+    monkeypatch.setenv("HOP_SPINE_POSTED", "1")
+    cost, bits, dist, parts, rec, rr = run_cpu_stack(L, W, H, pics, 64 + 320, lag)
+    monkeypatch.setenv("HOP_SPINE_POSTED", "0")
+    for k, (Y, Cb, Cr) in enumerate(pics):
+        c1, b1, d1, p1, r1, _, _ = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+        assert np.array_equal(cost[k], c1) and np.array_equal(bits[k], b1) and np.array_equal(dist[k], d1) and parts[k].tobytes() == p1.tobytes() and np.array_equal(rec[k], r1[0]), k

@@ -24,6 +24,7 @@ import json
 import os
 import sys
 import time
+PROC_T0 = time.time()
 
 import numpy as np
 
@@ -469,17 +470,167 @@ def tiles_of_rank(frame_w, frame_h, tile_w, tile_h, pictures, rank):
     return out
 
 
+def views_of_rank(n_views, world, rank):
+    """BASELINE config 5: the 13 x 13 sub-aperture views of the light field, dealt round-robin to the ranks (view v -> rank v % world); every view is an independent ISS picture"""
+    return [v for v in range(n_views) if v % world == rank]
+
+
+def wavefront_ramp_ctus(cols, rows, lag):
+    """CTUs a lag-`lag` wavefront of a cols x rows picture has retired when the number of rows in flight first reaches its maximum, and that maximum"""
+    rif = min(rows, (cols + lag - 1) // lag)
+    s_full = lag * (rif - 1)                                               # the wavefront step at which row rif - 1 starts
+    done = sum(min(cols, max(0, s_full - lag * r)) for r in range(rows))
+    return done, rif
+
+
+class EncodeRun:
+    """hop_encode_frame on a thread of its own (ctypes releases the GIL); the caller watches hop_encode_progress and ends the run with hop_encode_cancel"""
+    def __init__(self, ctx, lag, mi):
+        import threading
+        self.ctx, self.out, self.err = ctx, None, None
+        self.t0 = time.perf_counter()
+        self.th = threading.Thread(target=self._run, args=(lag, mi), daemon=True)
+        self.th.start()
+
+    def _run(self, lag, mi):
+        try:
+            self.out = self.ctx.encode_frame(QP, mi, 0, None, wpp=1, wavefront_lag=lag)
+        except BaseException as e:                                         # reported by the watcher
+            self.err = e
+
+    def wait_progress(self, target, deadline, poll=0.002):
+        """until `target` CTUs are retired (-> (time, retired)) or the deadline passes / the run ends (-> (time, retired) with retired < target)"""
+        while True:
+            n = self.ctx.encode_progress()
+            t = time.perf_counter()
+            if n >= target or t >= deadline or not self.th.is_alive():
+                return t, n
+            time.sleep(poll)
+
+    def finish(self):
+        self.ctx.encode_cancel()
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+        return self.out
+
+
+def frame_planes(fw, fh, seed):
+    """bench.py's frame: tests/hoputil.py:lenslet in numpy float64 on the host -- the SAME function oracle/make_golden24.py feeds the reference encoder with, so that
+    the per-CTU RD costs of a run can be compared with the reference's cost.csv (the GPU generator of --kernels mode is not reproducible on a CPU)"""
+    from hoputil import lenslet
+    return lenslet(fw, fh, PITCH, seed)
+
+
+def golden_costs(fh, Y, Cb, Cr):
+    """the reference encoder's per-CTU RD costs (cost.csv) for this frame, if a golden made from the same planes is committed (tests/golden/encoder_frame_mi15_rows*.npz):
+    (costs, meta, n_comparable) or (None, why, 0).  A golden of exactly this picture pins every CTU; one of a shorter full-width band of the same frame pins CTU row 0 only
+    (the first row is coded alike in both: nothing of row 0 depends on where the picture ends further down)."""
+    import glob, hashlib
+    md5 = lambda a: hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+    cols, cands = (Y.shape[1] + 63) // 64, []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "encoder_frame_mi15_rows*.npz"))):
+        g = np.load(path)
+        meta = json.loads(g["meta"].tobytes().decode())
+        if meta["W"] != Y.shape[1] or meta["H"] > fh: continue
+        cands.append((meta["H"] == fh, meta["H"], g["cost"], meta, path))
+    if not cands: return None, "no golden for this frame geometry", 0
+    exact, H, cost, meta, path = max(cands, key=lambda c: (c[0], c[1]))
+    if md5(Y[:H]) != meta["y_md5"] or md5(Cb[:H // 2]) != meta["cb_md5"] or md5(Cr[:H // 2]) != meta["cr_md5"]:
+        return None, "the frame generated on this host differs from the golden's input (numpy's sin / cos are not bit-reproducible across CPUs): comparison skipped", 0
+    meta["path"] = os.path.relpath(path, ROOT)
+    return cost, meta, (len(cost) if exact else cols)
+
+
+def cpu_baseline_reference(Y, Cb, Cr, crop_w, crop_h, budget_s):
+    """The unmodified reference encoder (oracle/_ref/TAppEncoderRef, built in the build container from /root/reference by oracle/Makefile.ref; it travels with the repository
+    snapshot) on one host core: an interior crop of the same frame, HOP configuration, --MIsize=15, QP 32.  CTU/s = CTUs / its own wall time.  Falls back to the port."""
+    import subprocess, tempfile
+    from hoputil import hop_encoder_args
+    exe = os.path.join(ROOT, "oracle", "_ref", "TAppEncoderRef")
+    if not os.path.exists(exe): return None
+    y0, x0 = (Y.shape[0] // 2) // 64 * 64, (Y.shape[1] // 2) // 64 * 64
+    cy, cb, cr = Y[y0:y0 + crop_h, x0:x0 + crop_w], Cb[y0 // 2:(y0 + crop_h) // 2, x0 // 2:(x0 + crop_w) // 2], Cr[y0 // 2:(y0 + crop_h) // 2, x0 // 2:(x0 + crop_w) // 2]
+    n = ((crop_w + 63) // 64) * ((crop_h + 63) // 64)
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "in.yuv"), "wb").write(cy.astype(np.uint8).tobytes() + cb.astype(np.uint8).tobytes() + cr.astype(np.uint8).tobytes())
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([exe] + hop_encoder_args(crop_w, crop_h, mi=PITCH), cwd=td, capture_output=True, text=True, timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            return {"error": "the reference encoder did not finish %d CTUs in %.0f s" % (n, budget_s)}
+        dt = time.perf_counter() - t0
+        if r.returncode != 0: return {"error": "TAppEncoderRef exited with %d" % r.returncode}
+        tot = [ln.strip() for ln in r.stdout.split("\n") if "Total Time" in ln]
+    return {"value": n / dt, "unit": "CTU/s", "cores": 1, "kind": "reference", "host_cpus": os.cpu_count(),
+            "sample": "oracle/_ref/TAppEncoderRef (the unmodified reference encoder, -O3, single-threaded by construction) on a %dx%d crop (%d CTUs) from the middle of the same frame as one "
+                      "picture, cfg/3DHencoder_intra_main.cfg semantics, --MIsize=%d, QP %d: %.1f s wall (%s); the crop's border CTUs see truncated SS windows, so this OVERstates "
+                      "the steady-state rate of interior CTUs of the 7728-wide frame" % (crop_w, crop_h, n, PITCH, QP, dt, tot[0] if tot else "")}
+
+
+def cpu_baseline_port(Y, Cb, Cr, n_ctus):
+    """fallback when the reference binary did not travel: the same RD spine over the CPU restatement (oracle/libhop_spine_cpu.so, built by __graft_entry__.build()), one core"""
+    path = os.path.join(ROOT, "oracle", "libhop_spine_cpu.so")
+    if not os.path.exists(path): return {"error": "neither oracle/_ref/TAppEncoderRef nor oracle/libhop_spine_cpu.so is present (run __graft_entry__.build())"}
+    L = ctypes.CDLL(path)
+    L.hop_spine_cpu_encode.restype = ctypes.c_long
+    L.hop_spine_cpu_encode.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
+    W, H = 1024, 128
+    a = [np.ascontiguousarray(p, np.int16) for p in (Y[:H, :W], Cb[:H // 2, :W // 2], Cr[:H // 2, :W // 2])]
+    cost = np.zeros(((W + 63) // 64) * ((H + 63) // 64), np.float64)
+    t0 = time.perf_counter()
+    L.hop_spine_cpu_encode(W, H, QP, PITCH, n_ctus, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, None, cost.ctypes.data, None, None, None, None, None, None, None)
+    dt = time.perf_counter() - t0
+    return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": "the first %d CTUs of the frame's top-left %dx%d through the same RD spine over the CPU restatement, one thread, %.1f s (top-row CTUs: cheaper than interior ones)" % (n_ctus, W, H, dt)}
+
+
+PROF_NAMES = {0: "k_ss_search / k_ss_family", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion",
+              6: "transform-unit leaf step + candidate walks (transform, estBit, RDOQ, counted bits, inverse, decisions)", 7: "k_intra (rough search + predictors)", 8: "k_rdoq (staged form)",
+              9: "k_coeff_bits + CU-level counting"}
+
+
+def profiled_pass(hp, local, Y, Cb, Cr, w, h, slots, lag):
+    """the roofline object's numbers: a separate, untimed encode of the frame's top-left w x h as one picture with HIP events around every launch (hop_profile_*)"""
+    pctx = hp.Context(w, h, device=local, slots=slots)
+    pctx.upload_orig(np.ascontiguousarray(Y[:h, :w]), np.ascontiguousarray(Cb[:h // 2, :w // 2]), np.ascontiguousarray(Cr[:h // 2, :w // 2]))
+    L = pctx.L
+    L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
+    L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    pctx._chk(L.hop_profile_reset(pctx.h), "profile_reset"); pctx._chk(L.hop_profile_enable(pctx.h, 1), "profile_enable")
+    t0 = time.perf_counter()
+    pctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=lag)
+    dt = time.perf_counter() - t0
+    prof = {}
+    for kid, name in PROF_NAMES.items():
+        la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
+        pctx._chk(L.hop_profile_read(pctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
+        prof[name] = {"launches": la.value, "total_ms": ms.value, "units": un.value}
+    pctx._chk(L.hop_profile_enable(pctx.h, 0), "profile_disable")
+    pctx.close()
+    return prof, ((w + 63) // 64) * ((h + 63) // 64), dt
+
+
 def encode_main(args):
-    """The default: BASELINE.json's metric, dependency-honest.  One step = one hop_encode_frame over a stacked context of `--pictures` independent pictures -- tiles of the
-    7728x5368 frame -- each coded as TEncSlice::compressSlice codes a picture: every candidate of TEncCu::xCompressCU for every CTU, SS reference starting at the sentinel
-    and growing CU by CU, coder contexts carried from CU to CU, CTU rows as a lag-5 wavefront with WaveFrontSynchro contexts.  The rows of ALL pictures form one wavefront:
-    a batch of requests serves one CU of every CTU in flight (the launch chains are the time; what one chain serves is the throughput)."""
-    import torch
+    """The default: BASELINE.json's metric on BASELINE's configuration -- the 7728 x 5368 lenslet frame coded as ONE picture, exactly as TEncSlice::compressSlice codes it with
+    cfg/3DHencoder_intra_main.cfg --MIsize=15 and WaveFrontSynchro (one substream per CTU row): every candidate of TEncCu::xCompressCU for every CTU, the SS reference starting at
+    the sentinel and growing CU by CU, coder contexts carried from CU to CU, the CTU rows as a lag-5 wavefront.  The picture takes minutes, so it is coded CONTINUOUSLY (one
+    hop_encode_frame on a thread of its own) and a STEP is a fixed quantum of retired CTUs (--step-ctus, default one CTU row = 121) read from hop_encode_progress: untimed are
+    the ramp (until the wavefront holds its maximum of rows) and `--warmup` steps; then `--steps` steps are timed; then the run is cancelled.  A wall-clock budget (--budget-s,
+    measured from process start) ends the timed region early if need be: `steps` in the JSON is what was timed.  With --gpus N every rank codes its own frame of the sequence."""
+    t_proc = time.perf_counter() - (time.time() - PROC_T0)
+    import threading
+    timp = threading.Thread(target=lambda: __import__("torch"), daemon=True); timp.start()     # (the first import on a fresh box takes a minute or two: beside the frame generation)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: for N > 1 launch it as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (one process per GPU)" % (args.gpus, world))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    deadline = t_proc + args.budget_s
+    fw, fh = args.width, min(args.height, args.rows * 64)
+    Y, Cb, Cr = frame_planes(fw, args.height, 2 + rank)                      # frame `rank` of the synthetic sequence: the same lenslet geometry, another texture seed
+    Y, Cb, Cr = np.ascontiguousarray(Y[:fh]), np.ascontiguousarray(Cb[:fh // 2]), np.ascontiguousarray(Cr[:fh // 2])
+    timp.join()
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libhophip has no CPU path")
     ndev = torch.cuda.device_count()
@@ -491,169 +642,170 @@ def encode_main(args):
         import torch.distributed as dist
         dist.init_process_group("gloo" if shared else "nccl", **({} if shared else {"device_id": dev}))
     hp = _hophip()
-    fw, fh = args.width, min(args.height, FRAME_H)
-    tw, th, P = min(args.tile_w, fw), min(args.rows * 64, fh // 8 * 8), args.pictures
-    tiles = tiles_of_rank(fw, fh, tw, th, P, rank)
-    pics = []
-    for f in sorted(set(t[0] for t in tiles)):                     # frame f of the synthetic sequence: the same lenslet geometry, another texture seed
-        Yf, Cbf, Crf = lenslet_torch(fw, fh, PITCH, 2 + f, dev)
-        pics += [(Yf[y:y + th, x:x + tw].cpu().numpy(), Cbf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy(), Crf[y // 2:(y + th) // 2, x // 2:(x + tw) // 2].cpu().numpy())
-                 for ff, x, y in tiles if ff == f]
-        del Yf, Cbf, Crf
-    ctx = hp.Context(tw, th, device=local, pictures=P, slots=args.slots)
-    if P > 1:
-        ctx.upload_orig(ctx.stack([p[0] for p in pics]), ctx.stack([p[1] for p in pics], True), ctx.stack([p[2] for p in pics], True))
-    else:
-        ctx.upload_orig(*pics[0])
-    wctu, hctu = (tw + 63) // 64, (th + 63) // 64
-    n_ctu = wctu * hctu * P
+    cols, rows = (fw + 63) // 64, (fh + 63) // 64
+    n_ctu = cols * rows
+    lag = min(args.lag, cols)
+    ramp_ctus, rif = wavefront_ramp_ctus(cols, rows, lag)
+    Q = args.step_ctus if args.step_ctus > 0 else cols
 
     def barrier():
-        ctx.sync(); torch.cuda.synchronize()
+        torch.cuda.synchronize()
         if world > 1: dist.barrier()
 
-    def step():
-        return ctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
-
-    for _ in range(args.warmup): step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cost, bits, dist_, parts, ncand = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    stats = ctx.encode_stats()
-    # ---- after the search, untimed and outside `value`: deblocking, the SAO encoder and PSNR over the pictures the last step left in the context ----
-    post = None
+    # ---- rank 0, before the timed run and bounded: the CPU baseline and the profiled pass behind the roofline object ----
+    extras = {}
     if rank == 0:
         try:
-            lam = 0.57 * 2.0 ** ((QP - 12) / 3.0)                        # TEncSlice.cpp:358-462 for an all-intra sequence (no B pictures, lambda scale 1): 57.908 at QP 32
-            lam_c = lam / 2.0 ** ((QP - 31) / 3.0)                       # chroma weight 2^((QP - QPc) / 3) with QPc = g_aucChromaScale[32] = 31 (TEncSlice.cpp:426-441)
-            assert QP == 32
-            ctx.sync(); tq0 = time.perf_counter()
-            ctx.deblock_frame(parts, QP)
-            tq1 = time.perf_counter()
-            coded = ctx.sao_frame([lam, lam_c, lam_c], 3, QP, int(ctx.rd_fraction_download()[wctu * hctu - 1]))
-            tq2 = time.perf_counter()
-            ssd, psnr = ctx.psnr()
-            tq3 = time.perf_counter()
-            modes = np.bincount(coded["mode"].reshape(-1).astype(np.int64), minlength=3)
-            post = {"pictures": P, "ctus": n_ctu, "deblock_ms": (tq1 - tq0) * 1e3, "sao_ms": (tq2 - tq1) * 1e3, "psnr_ms": (tq3 - tq2) * 1e3,
-                    "sao_components_off_new_merge": [int(v) for v in modes], "psnr_db_mean": [float(v) for v in psnr.mean(axis=0)], "psnr_db_min": [float(v) for v in psnr.min(axis=0)],
-                    "note": "hop_deblock_frame, hop_sao_frame (statistics kernel, host decision, offsetting kernel) and hop_psnr over all pictures of the last step, wall time with "
-                            "uploads of the partition data and downloads of statistics and parameters; not part of `value`"}
-        except Exception as e:                                           # reporting only: never in the way of the metric
-            post = {"error": repr(e)}
+            cb = cpu_baseline_reference(Y, Cb, Cr, args.cpu_crop[0], args.cpu_crop[1], args.cpu_budget_s) if not args.no_cpu else {"skipped": True}
+            if cb is None: cb = cpu_baseline_port(Y, Cb, Cr, 6)
+        except Exception as e:
+            cb = {"error": repr(e)}
+        extras["cpu_baseline"] = cb
+        try:
+            extras["prof"] = profiled_pass(hp, local, Y, Cb, Cr, min(fw, args.profile_w), min(fh, args.profile_h), args.slots, lag)
+        except Exception as e:
+            extras["prof_error"] = repr(e)
+    ctx = hp.Context(fw, fh, device=local, slots=args.slots)
+    ctx.upload_orig(Y, Cb, Cr)
+    ctx.sync()
+    barrier()
+    t_setup = time.perf_counter() - t_proc
+    # ---- the continuously running picture ----
+    run = EncodeRun(ctx, lag, PITCH)
+    ramp_deadline = min(deadline, time.perf_counter() + args.ramp_frac * max(1.0, deadline - time.perf_counter()))
+    t_r, n_r = run.wait_progress(min(ramp_ctus, n_ctu), ramp_deadline)          # ramp: the wavefront fills
+    t_w, n_w = run.wait_progress(min(n_r + args.warmup * Q, n_ctu), deadline)   # warm-up steps
+    if world > 1: dist.barrier()                                                # all ranks enter the timed region together (their pictures keep running meanwhile)
+    n0 = ctx.encode_progress(); t0 = time.perf_counter()
+    marks = [(t0, n0)]
+    for k in range(args.steps):
+        t, n = run.wait_progress(min(n0 + (k + 1) * Q, n_ctu), deadline)
+        if n < n0 + (k + 1) * Q: break                                          # budget spent (or the picture ended): the steps so far count
+        marks.append((t, n))
+    steps_done = len(marks) - 1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        sd = torch.tensor([steps_done], dtype=torch.int64, device="cpu" if shared else dev)
+        dist.all_reduce(sd, op=dist.ReduceOp.MIN)
+        steps_done = int(sd.item())
+    if steps_done < 1:
+        t, n = run.wait_progress(n_ctu, time.perf_counter())                    # nothing completed inside the budget: report what there is, as a fraction of a step
+        marks.append((t, n)); steps_done = 0
+    t1, n1 = marks[steps_done] if steps_done >= 1 else marks[-1]
+    dt, ctus_timed = t1 - t0, n1 - n0
+    cost, bits, dist_, parts, ncand = run.finish()
+    ctx.sync(); barrier()
+    stats = ctx.encode_stats()
+    retired = int(ctx.encode_progress())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cc = torch.tensor([ctus_timed], dtype=torch.int64, device="cpu" if shared else dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        ctus_all = int(cc.item())
+    else:
+        ctus_all = ctus_timed
     if rank == 0:
-        value = world * n_ctu * args.steps / dt
-        # ---- roofline of the dominant kernel: a separate, untimed pass over ONE of the pictures with HIP events around every launch (graphs off while profiling) ----
-        Y0, Cb0, Cr0 = pics[0]
-        Pp = min(P, args.profile_pictures)
-        pctx = hp.Context(tw, th, device=local, pictures=Pp, slots=args.slots)
-        if Pp > 1:
-            pctx.upload_orig(pctx.stack([p[0] for p in pics[:Pp]]), pctx.stack([p[1] for p in pics[:Pp]], True), pctx.stack([p[2] for p in pics[:Pp]], True))
+        value = ctus_all / dt if dt > 0 else 0.0
+        # ---- parity of what was measured: the retired CTUs' RD costs against the reference encoder's cost.csv for the same frame ----
+        gold, meta, m = golden_costs(fh, Y, Cb, Cr)
+        done = cost > 0
+        if gold is not None:
+            sel = done[:m]
+            parity = {"reference": "cost.csv of the unmodified reference encoder for %s this picture, %s (oracle/make_golden24.py)" % ("exactly" if m == len(cost) else "the first CTU row of", meta["path"]),
+                      "ctus_compared": int(sel.sum()), "mismatches": int(np.sum(cost[:m][sel] != gold[:m][sel])), "reference_one_core_ctu_per_s": meta.get("ctu_per_s_one_core"),
+                      "reference_cpu": meta.get("cpu")}
         else:
-            pctx.upload_orig(Y0, Cb0, Cr0)
-        L = pctx.L
-        L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
-        L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        pctx._chk(L.hop_profile_reset(pctx.h), "profile_reset"); pctx._chk(L.hop_profile_enable(pctx.h, 1), "profile_enable")
-        tp0 = time.perf_counter()
-        pctx.encode_frame(QP, PITCH, 0, None, wpp=1, wavefront_lag=args.lag)
-        prof_s = time.perf_counter() - tp0
-        prof_ctus = wctu * hctu * Pp
-        names = {0: "k_ss_search", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion", 6: "k_turd_fused + k_turd_fused_small (transform unit leaf step: transform, estBit, RDOQ, counted bits, inverse, decision)",
-                 7: "k_intra (rough search + predictors)", 8: "k_rdoq (staged form)", 9: "k_coeff_bits + CU-level counting"}
-        prof = {}
-        for kid, name in names.items():
-            la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
-            pctx._chk(L.hop_profile_read(pctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un)), "profile_read")
-            prof[name] = {"launches": la.value, "total_ms": ms.value, "units": un.value}
-        pctx._chk(L.hop_profile_enable(pctx.h, 0), "profile_disable")
-        pctx.close()
-        dom = max(prof, key=lambda k: prof[k]["total_ms"])
-        p = prof[dom]
-        avg_ms = p["total_ms"] / max(1, p["launches"])
-        ctus_per_launch = prof_ctus / max(1, p["launches"])
-        achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+            parity = {"reference": None, "note": meta}
+        prof, dom, roof = extras.get("prof"), None, None
+        if prof:
+            pk, prof_ctus, prof_s = prof
+            dom = max(pk, key=lambda k: pk[k]["total_ms"])
+            p = pk[dom]
+            avg_ms = p["total_ms"] / max(1, p["launches"])
+            ctus_per_launch = prof_ctus / max(1, p["launches"])
+            achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+            traffic, tsrc = None, None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+                traffic, tsrc = tj["hbm_bytes_per_launch"], tj["source"]
+            except Exception:
+                pass
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                    "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "launches_per_ctu": sum(v["launches"] for v in pk.values()) / prof_ctus,
+                    "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
+                    "note": "from a separate profiled pass over the frame's top-left %dx%d as one picture (%d CTUs, %.1f s, HIP events around every launch): the encode is bound by the LENGTH of its "
+                            "dependent chains (serial coder walks inside the candidate evaluations), not by HBM or VALU throughput -- see rendezvous / request_ms" % (min(fw, args.profile_w), min(fh, args.profile_h), prof_ctus, prof_s)}
         rv = stats.get("rendezvous", {"rounds": 0, "requests": 0})
         out = {
-            "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (RD search of TEncSlice::compressSlice; decisions, per-CTU RD costs and reconstruction identical to the reference's)",
-            "value": value, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (RD search of TEncSlice::compressSlice; per-CTU RD costs checked against the reference encoder's cost.csv in `parity`)",
+            "value": value, "unit": "CTU/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": (dt / steps_done * 1e3) if steps_done else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16+f64", "data": "synthetic",
-            "config": {"workload": "synthetic lenslet %dx%d (pitch %d), QP%d, cfg/3DHencoder_intra_main.cfg semantics (ISS slice, SS +-128 full search with FEN, half/quarter-pel, GT search, "
-                                   "merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, CABAC-counted bits), cut into independent %dx%d pictures (tiles, numbered through the frames of the sequence): "
-                                   "%d of them per GPU (%d CTUs) coded side by side in one stacked context -- each exactly as a picture of its own (SS reference from the sentinel, every "
-                                   "candidate of xCompressCU, rows as a lag-%d wavefront with WaveFrontSynchro contexts; tests/test_gpu_spine.py pins that to the reference encoder)"
-                                   % (fw, fh, PITCH, QP, tw, th, P, n_ctu, args.lag),
-                       "pictures_per_gpu": P, "picture": [tw, th], "candidate_slots": args.slots, "ctus_per_step": n_ctu, "candidates_per_step": ncand, "parallelism": "independent-pictures x%d per GPU, x%d GPUs" % (P, world),
-                       "whole_frame_note": "--width 7728 --rows 84 --pictures 1 codes the 7728x5368 frame as ONE picture: at most 24 CTU rows in flight (lag 5), 536 wavefront steps; see DESIGN.md for its rate"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
-                         "note": "from a separate profiled pass over %d of the %dx%d pictures (%d CTUs, %.1f s, HIP events around every launch, graphs off); the encode is bound by the LENGTH of "
-                                 "its dependent launch chains and the serial lane speed inside them, not by HBM or VALU throughput: see request_ms" % (Pp, tw, th, prof_ctus, prof_s)},
-            "kernels": prof,
+            "config": {"workload": "synthetic lenslet %dx%d (pitch %d, tests/hoputil.py:lenslet seed 2 + rank), QP%d, coded as ONE picture per GPU with cfg/3DHencoder_intra_main.cfg semantics and --MIsize=%d "
+                                   "(ISS slice, SS +-128 full search with FEN, half/quarter-pel, GT search, merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, "
+                                   "CABAC-counted bits), WaveFrontSynchro with one substream per CTU row, rows as a lag-%d wavefront (at most %d rows in flight); the picture is coded continuously, "
+                                   "a step = %d retired CTUs" % (fw, fh, PITCH, QP, PITCH, lag, rif, Q),
+                       "picture": [fw, fh], "ctus_per_picture": n_ctu, "ctus_per_step": Q, "candidate_slots": args.slots, "rows_in_flight_max": rif,
+                       "parallelism": "one picture per GPU x%d GPUs (frames of the sequence; no data-path collective)" % world},
+            "timed_region": {"ctus": ctus_all, "seconds": dt, "ctus_retired_before": n0, "ramp_ctus": n_r, "ramp_s": t_r - run.t0, "warmup_ctus": n_w - n_r, "warmup_s": t_w - t_r,
+                             "retired_total": retired, "budget_s": args.budget_s, "setup_s": t_setup,
+                             "note": "steps requested %d; steps timed %d (a wall-clock budget measured from process start ends the timed region early)" % (args.steps, steps_done)},
+            "parity": parity,
+            "roofline": roof,
+            "kernels": extras["prof"][0] if prof else {"error": extras.get("prof_error")},
             "request_ms": {k: v for k, v in stats.items() if k != "rendezvous"},
-            "request_note": "host wall time per kind of request of the last timed step, summed over the batches (one batch serves all CTUs in flight, all pictures together)",
-            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0), "run_ms": rv.get("run_ms", 0.0)},
-            "cost_sum": float(cost.sum()),
-            "post_search": post,
+            "request_note": "host wall time per kind of request of the whole run (ramp included), summed over the batches (one batch serves all CTUs in flight)",
+            "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0), "run_ms": rv.get("run_ms", 0.0),
+                           "rounds_per_retired_ctu": rv["rounds"] / max(1, retired)},
+            "candidates": ncand, "cost_sum_retired": float(cost[done].sum()),
+            "cpu_baseline": extras.get("cpu_baseline"),
         }
-        if world == 1:
-            out["cpu_baseline"] = cpu_baseline_encode(tw, th, Y0, Cb0, Cr0, cost, args.cpu_ctus)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline_encode(W, H, Y, Cb, Cr, gpu_cost, n_ctus):
-    """The same work on one host core: the RD spine over the CPU restatement (oracle/libhop_spine_cpu.so, kind "port") on the first n_ctus CTUs of the same picture (raster
-    order; top-row CTUs, whose SS windows hold only what lies to their left -- cheaper than interior CTUs, so this OVERstates the CPU rate).  Their RD costs must equal the GPU's."""
-    import subprocess
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhop_spine_cpu.so"], stdout=subprocess.DEVNULL)
-    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libhop_spine_cpu.so"))
-    L.hop_spine_cpu_encode.restype = ctypes.c_long
-    L.hop_spine_cpu_encode.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_char_p] + [ctypes.c_void_p] * 8
-    n = ((W + 63) // 64) * ((H + 63) // 64)
-    cost = np.zeros(n, np.float64)
-    a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
-    t0 = time.perf_counter()
-    L.hop_spine_cpu_encode(W, H, QP, PITCH, n_ctus, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, None, cost.ctypes.data, None, None, None, None, None, None, None)
-    dt = time.perf_counter() - t0
-    return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
-            "sample": "the first %d CTUs of the same picture through the same RD spine over the CPU restatement, one thread, %.1f s (top-row CTUs: cheaper than interior ones); the reference "
-                      "encoder itself ran the HOP configuration at 0.78 CTU/s on one core of the build container (BASELINE.md, 256x256)" % (n_ctus, dt),
-            "gpu_vs_oracle_mismatches": int(np.sum(cost[:n_ctus] != gpu_cost[:n_ctus]))}
+def spawn_ranks(argv, n):
+    """`bench.py --gpus N` without a launcher: N rank processes through torch.distributed.run, started BEFORE this process touches torch or HIP; rank 0's JSON line is
+    relayed.  (Never re-exec after GPU initialisation: this process stays a plain parent.)"""
+    import socket, subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.split("\n") if ln.startswith("{") and '"metric"' in ln]
+    if lines: print(lines[-1], flush=True)
+    sys.exit(r.returncode if not lines else 0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=FRAME_W)     # smaller pictures only for rehearsal; the JSON names them
     ap.add_argument("--height", type=int, default=FRAME_H)
-    ap.add_argument("--rows", type=int, default=4, help="CTU rows of one picture (tile); 84 with --tile-w 7728 --pictures 1 = the whole frame as one picture")
-    ap.add_argument("--tile-w", type=int, default=1024, help="width of one picture (tile)")
+    ap.add_argument("--rows", type=int, default=84, help="CTU rows of the picture: 84 = the whole 7728x5368 frame; fewer = its full-width top band as one picture")
+    ap.add_argument("--step-ctus", type=int, default=0, help="retired CTUs that make one step (0: one CTU row of the picture)")
+    ap.add_argument("--budget-s", type=float, default=430.0, help="wall-clock budget from process start: the timed region ends there at the latest (the driver's limit is 600 s)")
+    ap.add_argument("--ramp-frac", type=float, default=0.55, help="at most this share of the time left when the picture starts goes into the ramp")
     ap.add_argument("--slots", type=int, default=16, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
-    ap.add_argument("--profile-pictures", type=int, default=16, help="pictures of the separate profiled pass behind the roofline object")
-    ap.add_argument("--pictures", type=int, default=384, help="independent pictures coded side by side per GPU (one stacked context)")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
-    ap.add_argument("--cpu-ctus", type=int, default=None, help="CTUs of the bounded cpu_baseline sample")
+    ap.add_argument("--profile-w", type=int, default=1024); ap.add_argument("--profile-h", type=int, default=64)
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[256, 192], help="crop (from the middle of the frame) the reference CPU encoder is timed on")
+    ap.add_argument("--cpu-budget-s", type=float, default=60.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (development runs)")
+    ap.add_argument("--cpu-ctus", type=int, default=None, help="--kernels: CTUs of the bounded cpu_baseline sample")
     ap.add_argument("--kernels", action="store_true", help="kernel-throughput mode of round 1: the search kernels over a frozen, fully reconstructed SS reference (not the encode metric)")
     ap.add_argument("--rqt", action="store_true", help="--kernels: run the whole residual-quadtree search of every 2Nx2N CU instead of its leaf step")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(sys.argv[1:], args.gpus)
     if args.kernels:
         if args.cpu_ctus is None: args.cpu_ctus = 10
-        if args.steps == 1 and args.warmup == 0: args.steps, args.warmup = 3, 1
+        if args.steps == 4 and args.warmup == 1: args.steps, args.warmup = 3, 1
         kernels_main(args)
     else:
-        if args.cpu_ctus is None: args.cpu_ctus = 6
         encode_main(args)
 
 

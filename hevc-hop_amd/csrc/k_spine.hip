@@ -426,6 +426,12 @@ class HipBackend : public BatchInner {
 extern "C" {
 
 int hop_sizeof_cu_part(void) { return (int)sizeof(hopspine::Part); }
+int hop_encode_progress(hop_ctx* c, int64_t* ctus_retired) {
+  if (!c || !ctus_retired) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_progress: bad argument");
+  *ctus_retired = (int64_t)c->enc_progress.load();
+  return HOP_OK;
+}
+int hop_encode_cancel(hop_ctx* c) { if (!c) return HOP_ERR_ARG; c->enc_cancel.store(1); return HOP_OK; }
 void hop_encode_stats(double ms[16], double calls[16]) { memcpy(ms, g_stat_ms, sizeof(g_stat_ms)); memcpy(calls, g_stat_calls, sizeof(g_stat_calls)); }
 
 // One picture through the RD spine on the device: the original must be resident (hop_upload_orig).  Afterwards the reconstruction picture (hop_recon_download) holds the
@@ -442,6 +448,8 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   hopspine::EncConfig cfg;
   if (p->plain_intra) hopspine::default_plain_config(cfg, c->pic_w, pic_h, p->qp, c->bd_y); else hopspine::default_hop_config(cfg, c->pic_w, pic_h, p->qp, p->mi_size);
   cfg.wpp = (p->wpp || p->wavefront_lag > 0) ? 1 : 0;
+  c->enc_progress.store(0); c->enc_cancel.store(0);
+  cfg.progress = &c->enc_progress; cfg.cancel = &c->enc_cancel;
   if (c->slots > 0 && !p->plain_intra) { cfg.spec_slots = c->slots; cfg.slot_pitch = c->pic_h; }   // hop_ctx_set_slots: the SS/GT candidates of a CU side by side
   if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   {                                                                      // the images of the levels (one per candidate slot) and their part of the stash

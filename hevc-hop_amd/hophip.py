@@ -334,6 +334,18 @@ class Context:
         self._chk(L.hop_encode_frame(self.h, ctypes.byref(p), cost.ctypes.data, bits.ctypes.data, dist.ctypes.data, parts.ctypes.data, ctypes.byref(nc)), "hop_encode_frame")
         return cost, bits, dist, parts, int(nc.value)
 
+    def encode_progress(self):
+        """hop_encode_progress: CTUs the running (or last) hop_encode_frame has retired; callable from another thread"""
+        v = ctypes.c_int64(0)
+        self.L.hop_encode_progress.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.hop_encode_progress(self.h, ctypes.byref(v)), "hop_encode_progress")
+        return int(v.value)
+
+    def encode_cancel(self):
+        """hop_encode_cancel: the running hop_encode_frame (wavefront mode) starts no further CTU and returns what it has"""
+        self.L.hop_encode_cancel.argtypes = [ctypes.c_void_p]
+        self._chk(self.L.hop_encode_cancel(self.h), "hop_encode_cancel")
+
     def levels_download(self):
         """hop_levels_download: (n_ctu, 6144) int32 -- per CTU 4096 luma + 1024 Cb + 1024 Cr levels in the reference's TComDataCU layout"""
         n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures

@@ -22,6 +22,11 @@
 #include <atomic>
 #include <functional>
 #include <chrono>
+#include <sys/mman.h>
+
+#if !defined(__x86_64__)
+#error "hop_spine.cpp: the fiber switch (hop_fiber_switch) is written for x86-64 System V"
+#endif
 
 namespace hopspine {
 
@@ -1221,9 +1226,9 @@ class FiberPool : public Backend {
   FiberPool(BatchInner* inner, int n_workers) : rounds(0), requests(0), steps_complete(-1), inner_(inner), T_(n_workers), failed_(false), finished_(false), arrived_(0), gen_(0), left_(0), idle_rounds_(0) {
     sched_.resize(T_); mine_.resize(T_); local_.resize(T_); free_.resize(T_); kids_.resize(T_); pstore_.resize(T_); pjobs_.resize(T_);
   }
-  ~FiberPool() { for (Fiber* f : all_) { free(f->stack); delete f; } for (auto& v : kids_) for (Fiber* f : v) { free(f->stack); delete f; } }
+  ~FiberPool() { for (Fiber* f : all_) { stack_free(f->stack); delete f; } for (auto& v : kids_) for (Fiber* f : v) { stack_free(f->stack); delete f; } }
   void add(std::function<void()> body) {
-    Fiber* f = new Fiber(); f->stack = (char*)malloc(STACK); f->body = body; f->done = false; f->req = NULL; f->wait_step = -1; f->worker = (int)(all_.size() % T_); f->pool = this;
+    Fiber* f = new Fiber(); f->stack = stack_alloc(); f->body = body; f->done = false; f->req = NULL; f->wait_step = -1; f->worker = (int)(all_.size() % T_); f->pool = this;
     f->parent = NULL; f->live_children = 0; f->wait_children = false; f->tag = 0;
     all_.push_back(f); mine_[f->worker].push_back(f); left_++;
   }
@@ -1237,7 +1242,7 @@ class FiberPool : public Backend {
     for (int i = 0; i < n; i++) {
       Fiber* f;
       if (!free_[w].empty()) { f = free_[w].back(); free_[w].pop_back(); }
-      else { f = new Fiber(); f->stack = (char*)malloc(STACK); kids_[w].push_back(f); }
+      else { f = new Fiber(); f->stack = stack_alloc(); kids_[w].push_back(f); }
       f->body = [&fn, i]() { fn(i); };
       f->done = false; f->req = NULL; f->wait_step = -1; f->worker = w; f->pool = this; f->parent = me; f->live_children = 0; f->wait_children = false; f->tag = me->tag;
       start(f);
@@ -1278,7 +1283,15 @@ class FiberPool : public Backend {
   std::atomic<int> steps_complete;
   std::mutex steps_m;                                                   // guards the callers' step counters
  private:
-  enum { STACK = 512 * 1024 };
+  enum { STACK = 512 * 1024, GUARD = 4096 };
+  // a fiber's stack with an inaccessible page below it: an overflow (the recursion of compress_cu under a candidate child) faults instead of corrupting the heap
+  static char* stack_alloc() {
+    void* m = mmap(NULL, STACK + GUARD, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw 1;
+    mprotect(m, GUARD, PROT_NONE);
+    return (char*)m + GUARD;
+  }
+  static void stack_free(char* s) { if (s) munmap(s - GUARD, STACK + GUARD); }
   static Fiber*& current() { static thread_local Fiber* cur = NULL; return cur; }
   static void tramp() {                                                 // a fiber's first frame: entered by the first switch to it
     Fiber* f = current();
@@ -1515,11 +1528,20 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
           for (; c < cols; c++) {
             const int st = c + lag * r;
             pool.wait_step(st - 1);
+            if (E.cfg_.cancel && E.cfg_.cancel->load()) {                 // hop_encode_cancel: this row stops here; nobody waits for the CTUs it leaves uncoded
+              std::lock_guard<std::mutex> g(pool.steps_m);
+              for (; c < cols; c++) fin_step[c + lag * r]++;
+              int sc = pool.steps_complete.load();
+              while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
+              pool.steps_complete.store(sc);
+              break;
+            }
             if (c == 0 && r > 0 && cols >= 2) { std::lock_guard<std::mutex> g(pool.steps_m); k = sync[(size_t)p * rows + r - 1]; coder_set_frac(k, 0); }   // loadContexts (see below)
             const int a = r * cols + c;
             E.ctu_entry[a] = k;
             Coder next; w->compress_ctu(a, k, next);
             k = next;
+            if (E.cfg_.progress) E.cfg_.progress->fetch_add(1);
             std::lock_guard<std::mutex> g(pool.steps_m);
             if (c == 1) sync[(size_t)p * rows + r] = k;
             fin_step[st]++;

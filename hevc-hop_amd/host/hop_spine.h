@@ -5,6 +5,7 @@
 // instantiate the same spine over the CPU restatement (oracle/spine_backend_cpu.cpp) to pin it against the reference encoder.
 #pragma once
 #include <stdint.h>
+#include <atomic>
 #include <functional>
 #include <stdio.h>
 #include <string>
@@ -32,6 +33,9 @@ struct EncConfig {
   int spec_slots, slot_pitch;      // > 0: the SS/GT candidates of a CU are evaluated side by side, candidate k in copy k of the prediction / reconstruction pictures (rows k * slot_pitch, hop_ctx_set_slots)
   int y_origin;                    // added to the y coordinate of every request: the picture's first row in a stacked context (hop_ctx_set_stack), else 0
   int wpp;                         // 0: contexts run on from CTU to CTU in raster order (shipped configurations); 1: WaveFrontSynchro rows
+  // wavefront mode, both optional: *progress counts the CTUs whose compressCU has returned (all pictures together); once *cancel is non-zero no row starts another CTU
+  // (the CTUs in flight finish; the results of the finished CTUs are valid, the others stay 0) -- hop_encode_progress / hop_encode_cancel
+  std::atomic<long>* progress; std::atomic<int>* cancel;
   // derived by finish_config()
   double lambda, sqrt_lambda, lambda_rdoq[3], dist_weight[2];
   uint32_t lambda_sad;

@@ -664,6 +664,13 @@ int hop_levels_download(hop_ctx* ctx, int32_t* out);
  * (oracle/enc_shim_pic.cpp); without it an SAO offset can come out different.  out: one uint16 per CTU, CTUs and pictures ordered as in hop_encode_frame's outputs. */
 int hop_rd_fraction_download(hop_ctx* ctx, uint16_t* out);
 int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, hop_cu_part* parts, uint64_t* n_candidates);
+/* A picture takes as long as its wavefront (TEncSlice::compressSlice's CTU loop, TLibEncoder/TEncSlice.cpp:1000-1196, is the whole encode of an all-intra sequence): these two
+ * may be called from ANOTHER host thread while hop_encode_frame runs in wavefront mode on ctx.  hop_encode_progress: the number of CTUs whose compressCU has returned so far
+ * (all pictures of a stacked context together; 0 again when the next hop_encode_frame starts) -- a retired CTU's decisions, reconstruction and SS-reference commit are
+ * complete on the device.  hop_encode_cancel: no CTU row starts another CTU; the CTUs in flight finish, hop_encode_frame returns HOP_OK, and its outputs hold the finished
+ * CTUs (cost, bits and distortion of the others stay 0).  What bench.py's steps are made of: a step is a fixed number of retired CTUs of one continuously running picture. */
+int hop_encode_progress(hop_ctx* ctx, int64_t* ctus_retired);
+int hop_encode_cancel(hop_ctx* ctx);
 /* diagnostics of the last hop_encode_frame of this process: host wall time (ms) and number of requests per kind -- 0 ME chain, 1 predictor, 2 distortion, 3 validity
  * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */
 void hop_encode_stats(double ms[16], double calls[16]);

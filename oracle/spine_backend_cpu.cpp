@@ -7,6 +7,9 @@
 #include <string.h>
 #include <map>
 #include <vector>
+#include <thread>
+#include <chrono>
+#include <atomic>
 #include "../hevc-hop_amd/host/hop_spine.h"
 extern "C" {
 #include "hop_oracle.h"
@@ -269,10 +272,20 @@ long hop_spine_cpu_encode(int w, int h, int qp, int mi_size, int first_ctus, con
 }
 // the same with WaveFrontSynchro semantics (one substream per CTU row): lag 0 = the CTUs in raster order on one thread, lag > 0 = the rows as a wavefront of threads whose
 // requests are served in batches (what the product does on the GPU)
+// the progress counter and the cancel request of the wavefront (what hop_encode_progress / hop_encode_cancel reach in the product): the next hop_spine_cpu_encode_wpp call
+// is cancelled by a watcher thread as soon as `n` CTUs have been retired (n <= 0: never); hop_spine_cpu_last_progress gives the count the call ended with
+static std::atomic<long> g_progress(0); static std::atomic<int> g_cancel(0); static int g_cancel_after = 0;
+void hop_spine_cpu_cancel_after(int n) { g_cancel_after = n; }
+long hop_spine_cpu_last_progress(void) { return g_progress.load(); }
 long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const int16_t* y, const int16_t* cb, const int16_t* cr, const char* trace_path,
                               double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, double* rounds_requests) {
   EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1;
   const int slots = spec_slots_env(); cfg.spec_slots = slots; cfg.slot_pitch = h;
+  g_progress.store(0); g_cancel.store(0); cfg.progress = &g_progress; cfg.cancel = &g_cancel;
+  const int cancel_after = g_cancel_after; g_cancel_after = 0;
+  std::atomic<int> watch_stop(0);
+  std::thread watcher([&]() { while (!watch_stop.load()) { if (cancel_after > 0 && g_progress.load() >= cancel_after) g_cancel.store(1); std::this_thread::sleep_for(std::chrono::microseconds(200)); } });
+  struct Join { std::thread& t; std::atomic<int>& s; ~Join() { s.store(1); t.join(); } } join{ watcher, watch_stop };
   CpuBackend be(w, h, 8, y, cb, cr, slots);
   LogBackend* lg = getenv("HOP_SPINE_LOG") ? new LogBackend(&be, getenv("HOP_SPINE_LOG")) : NULL;
   BatchInner* use = lg ? (BatchInner*)lg : (BatchInner*)&be;

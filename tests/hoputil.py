@@ -201,6 +201,10 @@ PIC_CASES = {
     # the plain HM intra configurations (BASELINE configs 1 and 4): I slices, 8 bit QP 32 and 10 bit QP 27, a picture with partial CTUs
     "136x72_plain8":   {"W": 136, "H": 72, "seed": 9, "frames": 1, "over": {}, "extra": [], "plain": (8, 32)},
     "136x72_plain10":  {"W": 136, "H": 72, "seed": 9, "frames": 1, "over": {}, "extra": [], "plain": (10, 27)},
+    # the configuration bench.py measures: pitch-15 lenslets, --MIsize=15 (golden: tests/golden/encoder_hop_pic_mi15.json, oracle/make_golden24.py)
+    "200x136_seed5_mi15":     {"W": 200, "H": 136, "seed": 5, "frames": 1, "pitch": 15, "over": {"mi": 15}, "extra": []},
+    "192x128_seed7_mi15_wpp": {"W": 192, "H": 128, "seed": 7, "frames": 1, "pitch": 15, "over": {"mi": 15, "WaveFrontSynchro": 1, "WaveFrontSubstreams": 2}, "extra": []},
+    "448x192_seed3_mi15_wpp": {"W": 448, "H": 192, "seed": 3, "frames": 1, "pitch": 15, "over": {"mi": 15, "WaveFrontSynchro": 1, "WaveFrontSubstreams": 3}, "extra": []},
 }
 
 
@@ -209,7 +213,7 @@ def pic_case_input(c):
     bd = c["plain"][0] if "plain" in c else 8
     dt = np.uint8 if bd == 8 else np.dtype("<u2")
     for f in range(c["frames"]):
-        Y, Cb, Cr = lenslet(c["W"], c["H"], 16, c["seed"] + 100 * f, bitdepth=bd)
+        Y, Cb, Cr = lenslet(c["W"], c["H"], c.get("pitch", 16), c["seed"] + 100 * f, bitdepth=bd)
         raw += Y.astype(dt).tobytes() + Cb.astype(dt).tobytes() + Cr.astype(dt).tobytes()
     return raw
 

@@ -19,6 +19,7 @@ from hoputil import PIC_CASES, ROOT, hop_encoder_args, pic_case_args, pic_case_i
 
 REF = "/root/reference"
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_hop_pic.json")))
+GOLD.update(json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_hop_pic_mi15.json"))))     # the pictures coded with --MIsize=15 (oracle/make_golden24.py)
 
 
 def run_binding(exe, key, env, decoder=None):
@@ -59,7 +60,7 @@ def check(key, got, counts):
     assert got == want, key
 
 
-@pytest.mark.parametrize("key", ["64x64_raster", "192x128_wpp", "200x104_raster", "128x64_2frames", "136x72_plain8"])
+@pytest.mark.parametrize("key", ["64x64_raster", "192x128_wpp", "200x104_raster", "128x64_2frames", "136x72_plain8", "200x136_seed5_mi15", "192x128_seed7_mi15_wpp"])
 def test_reference_encoder_over_the_cpu_spine_writes_the_reference_bitstream(key):
     if not os.path.isdir(REF):
         pytest.skip("the reference tree is not present (GPU box)")

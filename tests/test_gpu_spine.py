@@ -9,7 +9,7 @@ import pytest
 
 from hoputil import ROOT
 from hoputil import lenslet
-from test_spine_cpu import FRAMES, FRAMES_WPP, PLAIN, check_against_golden, cpu_last_levels, cpu_last_rd_fraction, frame, key_of, levels_match_cbf, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
+from test_spine_cpu import FRAMES, FRAMES_MI15, FRAMES_WPP, PLAIN, key_mi15, check_against_golden, cpu_last_levels, cpu_last_rd_fraction, frame, key_of, levels_match_cbf, plain_key, run_cpu, run_cpu_plain, run_cpu_wpp, spine_cpu
 
 pytestmark = pytest.mark.gpu
 
@@ -135,3 +135,57 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots, groups, monk
     rv = stats["rendezvous"]
     print("stack of 3:", nc, "candidates, avg batch", rv["requests"] / max(1, rv["rounds"]))
     assert rv["requests"] / max(1, rv["rounds"]) > (2.0 if groups == 1 else 1.2)
+
+
+
+@pytest.mark.parametrize("W,H,seed,lag", FRAMES_MI15)
+def test_encode_frame_with_micro_image_size_15_equals_the_reference_encoder(W, H, seed, lag):
+    """the configuration bench.py measures (pitch-15 lenslets, --MIsize=15, candidate slots on): every candidate, cost and partition datum against the reference encoder's run
+    (tests/golden/encoder_spine_mi15.npz, oracle/make_golden24.py)"""
+    hp = _hp()
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine_mi15.npz"))
+    Y, Cb, Cr = lenslet(W, H, 15, seed)
+    ctx = hp.Context(W, H, slots=16)
+    ctx.upload_orig(Y, Cb, Cr)
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, "t.txt")
+        if lag is None: cost, bits, dist, parts, nc = ctx.encode_frame(32, 15, 0, tp)
+        else: cost, bits, dist, parts, nc = ctx.encode_frame(32, 15, 0, tp, wpp=1, wavefront_lag=lag)
+        text = open(tp, "rb").read()
+    check_against_golden(G, key_mi15(W, H, seed, lag), cost, bits, dist, parts.view(np.dtype(parts.dtype.descr)), text)
+    ctx.close()
+
+
+def test_bench_frame_top_rows_equal_the_reference_encoders_cost_csv():
+    """bench.py's own picture geometry: the 7728-wide frame (hoputil.lenslet(7728, 5368, 15, 2)), its top two CTU rows coded as ONE 7728x128 picture with WaveFrontSynchro and
+    candidate slots, exactly as bench.py codes the frame; all 242 per-CTU RD costs against cost.csv of the UNMODIFIED reference encoder for that picture
+    (tests/golden/encoder_frame_mi15_rows2.npz).  Also exercises hop_encode_progress / hop_encode_cancel the way bench.py uses them."""
+    import hashlib, json, threading, time
+    hp = _hp()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "encoder_frame_mi15_rows2.npz"))
+    meta = json.loads(g["meta"].tobytes().decode())
+    W, H = meta["W"], meta["H"]
+    Y, Cb, Cr = lenslet(W, 5368, 15, 2)
+    Y, Cb, Cr = np.ascontiguousarray(Y[:H]), np.ascontiguousarray(Cb[:H // 2]), np.ascontiguousarray(Cr[:H // 2])
+    if hashlib.md5(Y.tobytes()).hexdigest() != meta["y_md5"]:
+        pytest.skip("numpy's sin / cos on this host do not reproduce the golden's input frame bit for bit")
+    ctx = hp.Context(W, H, slots=16)
+    ctx.upload_orig(Y, Cb, Cr)
+    out = {}
+    th = threading.Thread(target=lambda: out.update(r=ctx.encode_frame(32, 15, 0, None, wpp=1, wavefront_lag=5)))
+    th.start()
+    seen = []
+    while th.is_alive():
+        seen.append(ctx.encode_progress()); time.sleep(0.05)
+    th.join()
+    cost = out["r"][0]
+    assert seen == sorted(seen) and ctx.encode_progress() == len(cost) == 242
+    assert np.array_equal(cost, g["cost"]), np.nonzero(cost != g["cost"])[0][:10]
+    # cancelled after a few CTUs: returns early, and what it retired is the reference's
+    th = threading.Thread(target=lambda: out.update(r=ctx.encode_frame(32, 15, 0, None, wpp=1, wavefront_lag=5)))
+    th.start()
+    while ctx.encode_progress() < 8 and th.is_alive(): time.sleep(0.01)
+    ctx.encode_cancel(); th.join()
+    c2 = out["r"][0]; done = c2 > 0
+    assert 8 <= int(done.sum()) == ctx.encode_progress() < 242 and np.array_equal(c2[done], g["cost"][done])
+    ctx.close()

@@ -266,3 +266,49 @@ def test_posted_requests_stacked_pictures(monkeypatch):
     for k, (Y, Cb, Cr) in enumerate(pics):
         c1, b1, d1, p1, r1, _, _ = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
         assert np.array_equal(cost[k], c1) and np.array_equal(bits[k], b1) and np.array_equal(dist[k], d1) and parts[k].tobytes() == p1.tobytes() and np.array_equal(rec[k], r1[0]), k
+
+
+def test_cancelled_wavefront_keeps_the_retired_ctus(monkeypatch):
+    """hop_encode_progress / hop_encode_cancel (what bench.py's steps are made of): a wavefront that is told to stop after a few retired CTUs starts no further CTU, returns
+    normally, and every CTU it did retire carries exactly the cost, bits and distortion of the full run (= the reference's, by the golden)."""
+    L = spine_cpu()
+    W, H, seed, lag = 448, 192, 3, 5
+    Y, Cb, Cr = frame(W, H, seed, False)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    key = key_of(W, H, seed, False) + "_wpp"
+    L.hop_spine_cpu_last_progress.restype = ctypes.c_long
+    L.hop_spine_cpu_cancel_after(3)
+    cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+    done = L.hop_spine_cpu_last_progress()
+    n = len(cost)
+    assert 3 <= done < n, (done, n)                                  # stopped early; the CTUs in flight when the request came were finished
+    ret = cost > 0
+    assert int(ret.sum()) == done
+    assert np.array_equal(cost[ret], G[key + "/cost"][ret]) and np.array_equal(bits[ret], G[key + "/bits"][ret]) and np.array_equal(dist[ret], G[key + "/dist"][ret])
+    assert not cost[~ret].any() and not bits[~ret].any()
+    # the next call is a full one again
+    cost2, bits2, dist2, parts2, rec2, text2, rr2 = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+    assert L.hop_spine_cpu_last_progress() == n
+    check_against_golden(G, key, cost2, bits2, dist2, parts2, text2)
+
+
+# ---- the configuration bench.py measures: pitch-15 lenslets coded with --MIsize=15 (BASELINE.md 3.2).  With 15 the micro-image candidates (hop_spine.cpp: mi_cand,
+# TLibCommon/TComDataCU.cpp:2620-2748) yield vectors of -15 / -30 / -45 / -75 samples -- not multiples of 4 -- which feed AMVP, merge and the SS start; goldens from the
+# reference encoder: oracle/make_golden24.py -> tests/golden/encoder_spine_mi15.npz ----
+FRAMES_MI15 = [(200, 136, 5, None), (192, 128, 7, 0), (448, 192, 3, 5)]     # W, H, seed, None = raster order / wavefront lag against the reference with WaveFrontSynchro
+
+
+def key_mi15(W, H, seed, lag):
+    return "%dx%d_seed%d_mi15%s" % (W, H, seed, "" if lag is None else "_wpp")
+
+
+@pytest.mark.parametrize("W,H,seed,lag", FRAMES_MI15)
+def test_spine_with_micro_image_size_15_equals_the_reference_encoder(W, H, seed, lag):
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine_mi15.npz"))
+    L = spine_cpu()
+    Y, Cb, Cr = lenslet(W, H, 15, seed)
+    if lag is None: cost, bits, dist, parts, rec, text = run_cpu(L, W, H, Y, Cb, Cr, mi=15)
+    else: cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag, mi=15)
+    check_against_golden(G, key_mi15(W, H, seed, lag), cost, bits, dist, parts, text)
+    mv = parts["mv"][parts["pred_mode"] == 0]
+    assert np.any(mv % 16 != 0)                                      # vectors that a 16-sample micro-image grid could not have produced did win somewhere

@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from hoputil import lenslet, sharp_frame
 
-def run_reference(W, H, seed, sharp, td, qp=32, mi=16, wpp=False):
-    Y, Cb, Cr = sharp_frame(W, H, seed) if sharp else lenslet(W, H, 16, seed)
+def run_reference(W, H, seed, sharp, td, qp=32, mi=16, wpp=False, pitch=16):
+    Y, Cb, Cr = sharp_frame(W, H, seed) if sharp else lenslet(W, H, pitch, seed)
     with open(os.path.join(td, "in.yuv"), "wb") as f:
         f.write(Y.astype(np.uint8).tobytes() + Cb.astype(np.uint8).tobytes() + Cr.astype(np.uint8).tobytes())
     env = dict(os.environ, HOP_SHIM_TRACE_BEST=os.path.join(td, "best.txt"), HOP_SHIM_TRACE_CTU=os.path.join(td, "ctu.bin"))

@@ -587,7 +587,9 @@ def cpu_baseline_port(Y, Cb, Cr, n_ctus):
 
 PROF_NAMES = {0: "k_ss_search / k_ss_family", 1: "k_frac", 2: "k_gt_search", 3: "k_pred_inter", 4: "k_ssref_commit", 5: "k_distortion",
               6: "transform-unit leaf step + candidate walks (transform, estBit, RDOQ, counted bits, inverse, decisions)", 7: "k_intra (rough search + predictors)", 8: "k_rdoq (staged form)",
-              9: "k_coeff_bits + CU-level counting"}
+              9: "k_coeff_bits + CU-level counting",
+              12: "k_inter_walk 8x8 (SS/GT candidate: residual quadtree, finish, CU bits)", 13: "k_inter_walk 16x16", 14: "k_inter_walk 32x32", 15: "k_inter_walk 64x64",
+              16: "k_intra_walk 8x8 2Nx2N (intra candidate: luma search, chroma search, CU bits)", 17: "k_intra_walk 16x16", 18: "k_intra_walk 32x32", 19: "k_intra_walk 64x64", 20: "k_intra_walk 8x8 NxN"}
 
 
 def profiled_pass(hp, local, Y, Cb, Cr, w, h, slots, lag):

@@ -66,6 +66,7 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   c->pic_w = pic_w; c->pic_h = pic_h; c->bd_y = bit_depth_y; c->bd_c = bit_depth_c; c->device = device;
   c->stride_y = pic_w + 2 * HOP_MARGIN_Y; c->stride_c = (pic_w >> 1) + 2 * HOP_MARGIN_C;
   { const char* f = getenv("HOP_FUSED_LEAF"); c->fused_leaf_max = f ? atoi(f) : 8192; }
+  { const char* f = getenv("HOP_WALK"); c->walk_max = f ? atoi(f) : 4096; }               // developer switch: the results do not depend on it
   { const char* f = getenv("HOP_SS_FAMILIES"); c->ss_families = !(f && f[0] == '0'); }   // developer switch: the results do not depend on it
   if (hipSetDevice(device) != hipSuccess) { free(c); return hop_set_err(nullptr, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", device); }
   hipDeviceProp_t prop;
@@ -119,7 +120,7 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   *out = nullptr;
   hop_ctx* c = (hop_ctx*)calloc(1, sizeof(hop_ctx));
   c->pic_w = parent->pic_w; c->pic_h = parent->pic_h; c->bd_y = parent->bd_y; c->bd_c = parent->bd_c; c->device = parent->device;
-  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->sub_h = parent->sub_h; c->sub_pitch = parent->sub_pitch; c->slots = parent->slots; c->fused_leaf_max = parent->fused_leaf_max; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
+  c->stride_y = parent->stride_y; c->stride_c = parent->stride_c; c->sub_h = parent->sub_h; c->sub_pitch = parent->sub_pitch; c->slots = parent->slots; c->fused_leaf_max = parent->fused_leaf_max; c->walk_max = parent->walk_max; c->ss_families = parent->ss_families; c->lanes = 1; c->is_view = true;
   c->org_y = parent->org_y; c->org_cb = parent->org_cb; c->org_cr = parent->org_cr;
   for (int k = 0; k < 3; k++) { c->ss_alloc[k] = parent->ss_alloc[k]; c->ss_buf[k] = parent->ss_buf[k]; c->ss00[k] = parent->ss00[k]; c->pred[k] = parent->pred[k]; c->rec[k] = parent->rec[k]; }
   c->entropy_bits = parent->entropy_bits; c->rdoq_scans = parent->rdoq_scans; c->have_orig = parent->have_orig; c->stash = parent->stash; c->stash_slots = parent->stash_slots; c->coefpic = parent->coefpic; c->coef_stash = parent->coef_stash;
@@ -179,15 +180,15 @@ void hop_ctx_destroy(hop_ctx* c) {
   for (int i = 0; i < c->prof_cap; i++) { if (c->prof_recs[i].a) (void)hipEventDestroy(c->prof_recs[i].a); if (c->prof_recs[i].b) (void)hipEventDestroy(c->prof_recs[i].b); }
   free(c->prof_recs); free(c->rd_fraction);
   void* ptrs[] = { c->org_y, c->org_cb, c->org_cr, c->ss_alloc[0], c->ss_alloc[1], c->ss_alloc[2], c->pred[0], c->pred[1], c->pred[2],
-                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->rdoq_scans, c->entropy_bits, c->stash, c->coefpic, c->coef_stash };
+                   c->rec[0], c->rec[1], c->rec[2], c->scratch, c->stage, c->rqt_buf, c->walk_buf, c->rdoq_scans, c->entropy_bits, c->stash, c->coefpic, c->coef_stash };
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (int k = 0; k < HOP_GRAPH_SLOTS; k++) if (c->graphs[k].exec) (void)hipGraphExecDestroy(c->graphs[k].exec);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
     if (c->xstream[k]) (void)hipStreamDestroy(c->xstream[k]);
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
     if (c->xscratch[k]) (void)hipFree(c->xscratch[k]);
     if (c->xrqt_buf[k]) (void)hipFree(c->xrqt_buf[k]);
+    if (c->xwalk_buf[k]) (void)hipFree(c->xwalk_buf[k]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   free(c);
@@ -655,10 +656,10 @@ int hop_rqt_device_classes(hop_ctx* c, int n_classes, const int* n, const hop_rq
     if (lane == 0) { rc = hop_rqt_device(c, n[i], d_jobs[i], cls + i, d_ctx_in, d_results[i], d_coef_out ? d_coef_out[i] : nullptr, d_ctx_out ? d_ctx_out[i] : nullptr); continue; }
     const int k = lane - 1;
     std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
-    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]); std::swap(c->walk_buf, c->xwalk_buf[k]); std::swap(c->walk_bytes, c->xwalk_bytes[k]);
     rc = hop_rqt_device(c, n[i], d_jobs[i], cls + i, d_ctx_in, d_results[i], d_coef_out ? d_coef_out[i] : nullptr, d_ctx_out ? d_ctx_out[i] : nullptr);
     std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
-    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]); std::swap(c->walk_buf, c->xwalk_buf[k]); std::swap(c->walk_bytes, c->xwalk_bytes[k]);
     used[k] = true;
   }
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
@@ -1247,6 +1248,18 @@ int hop_inter_cu_skip(hop_ctx* c, int n, const hop_rqt_job* jobs, const hop_cu_s
   return HOP_OK;
 }
 
+// grows c->walk_buf (synchronises the stream first when it has to reallocate)
+static int hop_walk_reserve(hop_ctx* c, size_t bytes) {
+  if (bytes <= c->walk_bytes) return HOP_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->walk_buf) HIPCHK(c, hipFree(c->walk_buf));
+  c->walk_buf = nullptr; c->walk_bytes = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(&c->walk_buf, bytes + bytes / 4));
+  c->walk_bytes = bytes + bytes / 4;
+  return HOP_OK;
+}
+
 // one class of intra candidates, device-resident from the rough search to the cost: luma search -> chroma search -> bits and cost, no host step in between
 static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
   const hop_rqt_job* cls = &k.cls;
@@ -1258,6 +1271,10 @@ static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop
       cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1 || cls->log2_cu - nxn < cls->log2_min_tu_in_cu || k.num_full_rd < 1 || k.num_full_rd > 8)
     return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: illegal CU class");
   if (k.n == 0) return HOP_OK;
+  if (k.n <= c->walk_max && !getenv("HOP_WALK_NO_INTRA")) {              // the RD spine's batches: one kernel per candidate (k_walk.inl)
+    int r = hop_walk_reserve(c, hop_intra_walk_bytes(cls->log2_cu, k.n)); if (r) return r;
+    return hop_launch_intra_walk(c, k, d_ctx_in, d_cu_ctx_in, c->walk_buf, c->walk_bytes);
+  }
   size_t wb = hop_intra_search_work_bytes(cls->log2_cu, k.n); const size_t wc = hop_intra_chroma_work_bytes(cls->log2_cu, k.n);
   if (wc > wb) wb = wc;
   if (wb > c->rqt_bytes) {
@@ -1284,73 +1301,26 @@ static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop
 
 static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
 
-// The candidate chains are thousands of small launches: a call that repeats - same descriptors, same buffers - is captured into a graph the second time it is seen and
-// replayed from then on.  HOP_GRAPHS=0 turns this off; so does profiling (its events are recorded around the launches).  desc / desc_bytes: what identifies the call.
-static int hop_graph_or_issue(hop_ctx* c, const char* what, const void* desc, size_t desc_bytes, const void* p0, const void* p1, const std::function<int()>& issue) {
-  static const bool graphs_on = !(getenv("HOP_GRAPHS") && getenv("HOP_GRAPHS")[0] == '0');
-  if (!graphs_on || c->prof_on) return issue();
-  uint64_t key = 1469598103934665603ull;
-  auto mix = [&](const void* p, size_t nbytes) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < nbytes; i++) { key ^= b[i]; key *= 1099511628211ull; } };
-  mix(what, strlen(what)); mix(desc, desc_bytes); mix(&p0, sizeof(void*)); mix(&p1, sizeof(void*));
-  mix(&c->scratch, sizeof(void*)); mix(&c->scratch_bytes, sizeof(size_t)); mix(&c->rqt_buf, sizeof(void*)); mix(&c->rqt_bytes, sizeof(size_t));
-  mix(c->xscratch, sizeof(c->xscratch)); mix(c->xscratch_bytes, sizeof(c->xscratch_bytes)); mix(c->xrqt_buf, sizeof(c->xrqt_buf)); mix(c->xrqt_bytes, sizeof(c->xrqt_bytes));
-  int slot = -1;
-  for (int i = 0; i < HOP_GRAPH_SLOTS; i++) if (c->graphs[i].seen && c->graphs[i].key == key) slot = i;
-  if (slot >= 0 && c->graphs[slot].exec) {
-    hipError_t e = hipGraphLaunch(c->graphs[slot].exec, c->stream);
-    if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "%s: graph launch: %s", what, hipGetErrorString(e));
-    c->graph_replays++;
-    return HOP_OK;
-  }
-  if (slot < 0) {                                                     // first sighting: run it the ordinary way (buffers reach their sizes), remember the call
-    slot = c->graph_next; c->graph_next = (c->graph_next + 1) % HOP_GRAPH_SLOTS;
-    if (c->graphs[slot].exec) {                                         // the evicted graph may still be running: wait before it is destroyed
-      (void)hipStreamSynchronize(c->stream);
-      (void)hipGraphExecDestroy(c->graphs[slot].exec); c->graphs[slot].exec = nullptr;
-    }
-    c->graphs[slot].key = key; c->graphs[slot].seen = 1;
-    return issue();
-  }
-  if (c->graphs[slot].seen < 0) return issue();                        // capture failed before: stay on the ordinary path
-  hipGraph_t g = nullptr;
-  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return issue(); }
-  const int rc = issue();
-  hipError_t e = hipStreamEndCapture(c->stream, &g);
-  if (rc != HOP_OK || e != hipSuccess || !g) {
-    (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g);
-    c->graphs[slot].seen = -1;
-    // the ordinary path may only be taken once no stream is capturing any more
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    bool capturing = hipStreamIsCapturing(c->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
-    for (int k = 0; k < HOP_MAX_LANES - 1 && !capturing; k++) capturing = hipStreamIsCapturing(c->xstream[k], &st) != hipSuccess || st != hipStreamCaptureStatusNone;
-    if (capturing) return hop_set_err(c, HOP_ERR_DEVICE, "%s: stream capture did not end", what);
-    return issue();
-  }
-  hipGraphExec_t ex = nullptr;
-  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (e != hipSuccess || !ex) { (void)hipGetLastError(); c->graphs[slot].seen = -1; return issue(); }
-  c->graphs[slot].exec = ex;
-  e = hipGraphLaunch(ex, c->stream);
-  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "%s: graph launch: %s", what, hipGetErrorString(e));
-  c->graph_replays++;
-  return HOP_OK;
-}
-
 int hop_intra_cu_device_classes(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
   if (!c || n_classes < 0 || (n_classes && (!classes || !d_ctx_in || !d_cu_ctx_in))) return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: bad argument");
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_intra_cu_device_classes: hop_upload_orig has not been called");
   if (n_classes == 0) return HOP_OK;
-  return hop_graph_or_issue(c, "hop_intra_cu_device_classes", classes, (size_t)n_classes * sizeof(hop_intra_class), d_ctx_in, d_cu_ctx_in,
-                            [&]() { return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in); });
+  return intra_classes_issue(c, n_classes, classes, d_ctx_in, d_cu_ctx_in);
 }
-
-long hop_graph_replays(hop_ctx* c) { return c ? c->graph_replays : 0; }
 
 static int inter_candidate_chain(hop_ctx* c, const hop_inter_class& k, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
   if (k.n < 0 || (k.n && (!k.d_jobs || !k.d_syntax || !k.d_results || !k.d_coef || !k.d_ctx_after || !k.d_finals || !k.d_bits || !k.d_skipped || !k.d_cost)))
     return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_device_classes: bad class descriptor");
   if (k.n == 0) return HOP_OK;
+  if (k.n <= c->walk_max && !getenv("HOP_WALK_NO_INTER")) {              // the RD spine's batches: one kernel per candidate (k_walk.inl)
+    const hop_rqt_job* cls = &k.cls;
+    if (cls->log2_cu < 3 || cls->log2_cu > 6 || cls->log2_max_tu < 2 || cls->log2_max_tu > 5 || cls->log2_min_tu_in_cu < 2 || cls->log2_min_tu_in_cu > cls->log2_max_tu ||
+        cls->log2_cu - cls->log2_min_tu_in_cu > 3 || cls->log2_cu - cls->log2_max_tu > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_inter_cu_device_classes: illegal CU class");
+    if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_inter_cu_device_classes: hop_upload_orig has not been called");
+    int r = hop_walk_reserve(c, hop_inter_walk_bytes(cls->log2_cu, cls->log2_max_tu, cls->log2_min_tu_in_cu, k.n)); if (r) return r;
+    return hop_launch_inter_walk(c, cls, k.n, k.d_jobs, k.d_syntax, d_ctx_in, d_cu_ctx_in, k.d_results, k.d_coef, k.d_ctx_after, k.d_finals, k.d_bits, k.d_skipped, k.d_cost, k.d_ctx_out,
+                                 k.d_cu_ctx_out, c->walk_buf, c->walk_bytes);
+  }
   int r = hop_rqt_device(c, k.n, k.d_jobs, &k.cls, d_ctx_in, k.d_results, k.d_coef, k.d_ctx_after); if (r) return r;
   r = hop_rqt_finish_device(c, k.n, k.d_jobs, &k.cls, k.d_results, k.d_coef, k.d_ctx_after, k.d_finals); if (r) return r;
   r = hop_inter_cu_bits_device(c, k.n, k.d_jobs, &k.cls, k.d_syntax, k.d_results, k.d_coef, d_ctx_in, d_cu_ctx_in, k.d_bits, k.d_skipped, k.d_ctx_out, k.d_cu_ctx_out); if (r) return r;
@@ -1362,7 +1332,7 @@ int hop_inter_cu_device_classes(hop_ctx* c, int n_classes, const hop_inter_class
   if (!c->have_orig) return hop_set_err(c, HOP_ERR_STATE, "hop_inter_cu_device_classes: hop_upload_orig has not been called");
   if (n_classes == 0) return HOP_OK;
   auto issue = [&]() -> int {
-    // only the lanes this call uses take part (a forked lane that is never joined would leave a stream capture with an unjoined participant)
+    // only the lanes this call uses take part
     const int n_fork = std::min(n_classes, HOP_MAX_LANES) - 1;
     if (n_fork > 0) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     for (int k = 0; k < n_fork; k++) HIPCHK(c, hipStreamWaitEvent(c->xstream[k], c->ev_fork, 0));
@@ -1373,10 +1343,10 @@ int hop_inter_cu_device_classes(hop_ctx* c, int n_classes, const hop_inter_class
       if (lane == 0) { rc = inter_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in); continue; }
       const int k = lane - 1;
       std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
-      std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+      std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]); std::swap(c->walk_buf, c->xwalk_buf[k]); std::swap(c->walk_bytes, c->xwalk_bytes[k]);
       rc = inter_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in);
       std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
-      std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+      std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]); std::swap(c->walk_buf, c->xwalk_buf[k]); std::swap(c->walk_bytes, c->xwalk_bytes[k]);
       used[k] = true;
     }
     for (int k = 0; k < HOP_MAX_LANES - 1; k++) {
@@ -1387,7 +1357,7 @@ int hop_inter_cu_device_classes(hop_ctx* c, int n_classes, const hop_inter_class
     }
     return rc;
   };
-  return hop_graph_or_issue(c, "hop_inter_cu_device_classes", classes, (size_t)n_classes * sizeof(hop_inter_class), d_ctx_in, d_cu_ctx_in, issue);
+  return issue();
 }
 
 static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in) {
@@ -1401,10 +1371,10 @@ static int intra_classes_issue(hop_ctx* c, int n_classes, const hop_intra_class*
     if (lane == 0) { rc = intra_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in); continue; }
     const int k = lane - 1;
     std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
-    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]); std::swap(c->walk_buf, c->xwalk_buf[k]); std::swap(c->walk_bytes, c->xwalk_bytes[k]);
     rc = intra_candidate_chain(c, classes[i], d_ctx_in, d_cu_ctx_in);
     std::swap(c->stream, c->xstream[k]); std::swap(c->scratch, c->xscratch[k]); std::swap(c->scratch_bytes, c->xscratch_bytes[k]);
-    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]);
+    std::swap(c->rqt_buf, c->xrqt_buf[k]); std::swap(c->rqt_bytes, c->xrqt_bytes[k]); std::swap(c->walk_buf, c->xwalk_buf[k]); std::swap(c->walk_bytes, c->xwalk_bytes[k]);
     used[k] = true;
   }
   for (int k = 0; k < HOP_MAX_LANES - 1; k++) {

@@ -14,7 +14,6 @@
 // they hold the sentinel and are not part of the reference layout.
 #define HOP_GUARD_ROWS 64
 #define HOP_MAX_LANES 4
-#define HOP_GRAPH_SLOTS 256  // instantiated graphs of launch-bound chains kept per context
 
 struct hop_ctx {
   int pic_w, pic_h, bd_y, bd_c, device;
@@ -34,6 +33,9 @@ struct hop_ctx {
   void*  scratch; size_t scratch_bytes;
   void*  stage;   size_t stage_bytes;   // staging for host-array entry points
   void*  rqt_buf; size_t rqt_bytes;     // state of the residual-quadtree search (k_rqt.inl); separate from scratch, which its leaf pipeline uses
+  void*  walk_buf; size_t walk_bytes;   // work areas of the candidate walks (k_walk.inl): one kernel per candidate for the RD spine's small batches
+  void*  xwalk_buf[HOP_MAX_LANES - 1]; size_t xwalk_bytes[HOP_MAX_LANES - 1];   // ... of the extra lanes (classes of one call on separate streams)
+  int    walk_max;                      // batches of up to this many candidates take the walk kernels (HOP_WALK, default 4096; 0 = always the batch-step form)
   void*  xrqt_buf[HOP_MAX_LANES - 1]; size_t xrqt_bytes[HOP_MAX_LANES - 1];
   // extra lanes for hop_me_search_device: the parts of a batch run on separate streams so that one part's kernel tails
   // and low-occupancy phases are filled by the other parts' kernels
@@ -43,8 +45,6 @@ struct hop_ctx {
   int32_t* entropy_bits;             // device: the 128 fractional-bit values of the CABAC states (ContextModel::m_entropyBits)
   uint16_t* rdoq_scans;              // device: the scan tables of the RDOQ kernel (hop_rdoq_build_scans)
   bool   ss_families;                // SS search: share one pass among the five symmetric PUs of a CU (HOP_SS_FAMILIES=0 turns it off)
-  // instantiated graphs of launch-bound chains (hop_intra_cu_device_classes): key = hash of the call's descriptors and of every buffer the chain touches
-  struct { uint64_t key; int seen; hipGraphExec_t exec; } graphs[HOP_GRAPH_SLOTS]; int graph_next; long graph_replays;
   // RD spine support (k_spine.hip): stash slots for reconstruction blocks (64 x 64 x 1.5 samples each), allocated on first use
   int16_t* stash; int stash_slots;
   // the levels of the pictures as the reference keeps them (TComDataCU::m_pcTrCoeffY / Cb / Cr): per 64x64 CTU of the (stacked) picture 4096 + 1024 + 1024 TCoeff, a CU's at
@@ -52,7 +52,7 @@ struct hop_ctx {
   int32_t* coefpic; int32_t* coef_stash;
   std::atomic<long> enc_progress; std::atomic<int> enc_cancel;   // hop_encode_progress / hop_encode_cancel: CTUs the running hop_encode_frame has retired; a request to stop it
   uint16_t* rd_fraction; int rd_fraction_n;   // host: hop_encode_frame's per-CTU carried fraction of the RD coder (hop_rd_fraction_download)
-  bool   is_view;                    // hop_ctx_create_view: pictures, tables and stash belong to the parent; stream, scratch areas, graphs and profiling are its own
+  bool   is_view;                    // hop_ctx_create_view: pictures, tables and stash belong to the parent; stream, scratch areas and profiling are its own
   char   err[512];
   // profiling (hop_profile_*): event pairs recorded around kernel launches, folded into the sums on read
   bool   prof_on;
@@ -145,6 +145,7 @@ int hop_launch_frac(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* 
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
 void hop_launch_size_classes(hop_ctx* c, int n, const hop_pu_job* d_jobs, const hop_pu_result* d_res, void* sc);
 int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs);
+int hop_launch_pred_cost(hop_ctx* c, int m, const int32_t* d_first, const hop_pred_job* d_jobs, const int32_t* d_kinds, uint32_t* d_out);   // sequences of candidates, one launch (k_pred.hip)
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out);
 int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off);
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
@@ -188,6 +189,12 @@ int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_
                              const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, uint32_t* d_bits,
                              hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);
 size_t hop_rqt_work_bytes(int log2_cu, int n);
+size_t hop_intra_walk_bytes(int log2_cu, int n);
+int hop_launch_intra_walk(hop_ctx* c, const hop_intra_class& q, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, void* buf, size_t buf_bytes);
+size_t hop_inter_walk_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n);
+int hop_launch_inter_walk(hop_ctx* c, const hop_rqt_job* cls, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syn, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
+                          hop_rqt_result* d_res, int32_t* d_coef, hop_cabac_ctx* d_ctx_after, hop_cu_final* d_fin, uint32_t* d_bits, uint32_t* d_skipped, double* d_cost,
+                          hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* buf, size_t buf_bytes);
 int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
                          const hop_cabac_ctx* d_ctx_in, hop_rqt_result* d_res, int32_t* d_coef_out, hop_cabac_ctx* d_ctx_out, void* buf, size_t buf_bytes);
 void hop_rdoq_build_scans(uint16_t* tabs);

@@ -244,9 +244,7 @@ int hop_launch_coeff_bits(hop_ctx* c, int n, const hop_coeff_bits_job* d_jobs, c
 // ---- the mode-decision half of the intra rough search (rest of row a7): TEncSearch::estIntraPredQT :2440-2493 ----
 // per block: for the 35 modes bits of the luma direction from the CI_CURR_BEST state (xModeBitsIntra :7734 = codeIntraDirLumaAng TEncSbac.cpp:770-831),
 // cost = SATD + bits * sqrt(lambda) in double (:2461), the sorted candidate list (xUpdateCandList :7747-7767), the MPMs appended if missing (:2466-2488).
-__global__ void k_intra_modes(const hop_intra_modes_job* __restrict__ jobs, int n, const uint32_t* __restrict__ satd, hop_intra_modes_result* __restrict__ res) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void intra_modes_body(const int i, const hop_intra_modes_job* jobs, const uint32_t* satd, hop_intra_modes_result* res) {
   const hop_intra_modes_job jb = jobs[i];
   const uint32_t* sd = satd + (size_t)i * 35;
   uint32_t modes[11]; double costs[8];
@@ -278,6 +276,10 @@ __global__ void k_intra_modes(const hop_intra_modes_job* __restrict__ jobs, int 
   for (int q = 0; q < 8; q++) r.costs[q] = costs[q];
   res[i] = r;
 }
+__global__ void k_intra_modes(const hop_intra_modes_job* __restrict__ jobs, int n, const uint32_t* __restrict__ satd, hop_intra_modes_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) intra_modes_body(i, jobs, satd, res);
+}
 int hop_launch_intra_modes(hop_ctx* c, int n, const hop_intra_modes_job* d_jobs, const uint32_t* d_satd, hop_intra_modes_result* d_res) {
   const int pr = hop_prof_begin(c, HOP_K_INTRA, 0);
   hipLaunchKernelGGL(k_intra_modes, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_jobs, n, d_satd, d_res);
@@ -287,5 +289,7 @@ int hop_launch_intra_modes(hop_ctx* c, int n, const hop_intra_modes_job* d_jobs,
   return HOP_OK;
 }
 
+#include "k_intra_dev.inl"
 #include "k_leaf_fused.inl"
 #include "k_rqt.inl"
+#include "k_walk.inl"

@@ -19,14 +19,11 @@ struct LeafShared {
   int32_t src[1024], lev[1024], ebits[128]; hop_estbits eb; uint8_t ctx[152]; double work[256 * RQ_WORK_PER_COEF / 8];
 };
 
-__global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const hop_cabac_ctx* __restrict__ ctx_in,
-                                                    const int64_t* __restrict__ coef_off, const int32_t* __restrict__ entropy_bits, const uint16_t* __restrict__ scans,
-                                                    int32_t* __restrict__ coef, int32_t* __restrict__ levels, uint32_t* __restrict__ zs, uint32_t* __restrict__ ns,
-                                                    uint32_t* __restrict__ as, unsigned long long* __restrict__ fr, hop_estbits* __restrict__ tables,
-                                                    hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb, char* __restrict__ work,
-                                                    hop_tu_rd_result* __restrict__ res, int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
-  __shared__ LeafShared L;
-  const int j = blockIdx.x, tid = threadIdx.x;
+// one TU through all stages on the 256 threads of the calling workgroup (every thread calls; barriers inside)
+__device__ static void turd_fused_body(LeafShared& L, const int j, const hop_tu_rd_job* jobs, int n, hop_pics pic, const hop_cabac_ctx* ctx_in, const int64_t* coef_off,
+                                       const int32_t* entropy_bits, const uint16_t* scans, int32_t* coef, int32_t* levels, uint32_t* zs, uint32_t* ns, uint32_t* as,
+                                       unsigned long long* fr, hop_rdoq_job* rq, hop_coeff_bits_job* cb, char* work, hop_tu_rd_result* res, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr) {
+  const int tid = threadIdx.x;
   const hop_tu_rd_job jb = jobs[j];
   if (jb.log2_size < 2 || jb.log2_size > 5) return;                   // an empty slot of a job table (k_rqt.inl); uniform over the workgroup
   const bool small = jb.log2_size <= 3;
@@ -65,6 +62,15 @@ __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restr
   __threadfence_block();
   __syncthreads();
   if (tid == 0) turd_decide_body(j, jobs, n, ctx_in, coef_off, entropy_bits, as, fr, zs, ns, levels, res);
+}
+__global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                    const int64_t* __restrict__ coef_off, const int32_t* __restrict__ entropy_bits, const uint16_t* __restrict__ scans,
+                                                    int32_t* __restrict__ coef, int32_t* __restrict__ levels, uint32_t* __restrict__ zs, uint32_t* __restrict__ ns,
+                                                    uint32_t* __restrict__ as, unsigned long long* __restrict__ fr, hop_estbits* __restrict__ tables,
+                                                    hop_rdoq_job* __restrict__ rq, hop_coeff_bits_job* __restrict__ cb, char* __restrict__ work,
+                                                    hop_tu_rd_result* __restrict__ res, int16_t* __restrict__ rec_y, int16_t* __restrict__ rec_cb, int16_t* __restrict__ rec_cr) {
+  __shared__ LeafShared L;
+  turd_fused_body(L, blockIdx.x, jobs, n, pic, ctx_in, coef_off, entropy_bits, scans, coef, levels, zs, ns, as, fr, rq, cb, work, res, rec_y, rec_cb, rec_cr);
 }
 
 // The same for batches whose TUs are all 4x4 or 8x8 (size_hint 1: most of the quadtree steps of 8x8 CUs, every chroma step of CUs up to 16x16): ONE wave per TU and

@@ -50,11 +50,9 @@ __device__ static inline int mc_sample(const int16_t* __restrict__ src, int stri
 
 struct PredShared { int16_t patch[128 * 130]; };
 
-// grid = (n jobs, 3 planes)
-__global__ __launch_bounds__(256) void k_pred_inter(const hop_pred_job* __restrict__ jobs, hop_pics pic) {
-  __shared__ PredShared sh;
-  const hop_pred_job jb = jobs[blockIdx.x];
-  const int comp = blockIdx.y, tid = threadIdx.x;
+// one job, one plane, on the 256 threads of the calling workgroup (a barrier inside the GT branch: uniform over the workgroup)
+__device__ static void pred_inter_body(PredShared& sh, const hop_pred_job& jb, const int comp, const hop_pics& pic) {
+  const int tid = threadIdx.x;
   const bool chroma = comp != 0;
   const int bw = chroma ? jb.w >> 1 : jb.w, bh = chroma ? jb.h >> 1 : jb.h;       // block size in this plane
   const int16_t* ref = comp == 0 ? pic.ss_y : comp == 1 ? pic.ss_cb : pic.ss_cr;
@@ -149,6 +147,12 @@ __global__ __launch_bounds__(256) void k_pred_inter(const hop_pred_job* __restri
     dst[(size_t)py * dpitch + px] = (int16_t)(v + 0.5);
   }
 }
+// grid = (n jobs, 3 planes)
+__global__ __launch_bounds__(256) void k_pred_inter(const hop_pred_job* __restrict__ jobs, hop_pics pic) {
+  __shared__ PredShared sh;
+  const hop_pred_job jb = jobs[blockIdx.x];
+  pred_inter_body(sh, jb, blockIdx.y, pic);
+}
 
 int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs) {
   const int pr = hop_prof_begin(c, HOP_K_PRED, (uint64_t)n);
@@ -192,9 +196,8 @@ extern "C" int hop_pred_jobs_from_results_device(hop_ctx* c, int n, const int32_
 // distortion between the original and the prediction picture (row a12):
 // SAD (TComRdCost.cpp:513-1011), SSE (:1018-1360), HADs (:1641-1708).  One workgroup per job.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_distortion(const hop_dist_job* __restrict__ jobs, hop_pics pic, uint32_t* __restrict__ out) {
-  __shared__ unsigned int acc;
-  const hop_dist_job jb = jobs[blockIdx.x];
+// one job on the 256 threads of the calling workgroup; thread 0 returns the value (barriers inside)
+__device__ static uint32_t distortion_body(unsigned int& acc, const hop_dist_job& jb, const hop_pics& pic) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool chroma = jb.comp != 0;
   const int w = chroma ? jb.w >> 1 : jb.w, h = chroma ? jb.h >> 1 : jb.h, x0 = chroma ? jb.x >> 1 : jb.x, y0 = chroma ? jb.y >> 1 : jb.y;
@@ -235,7 +238,44 @@ __global__ __launch_bounds__(256) void k_distortion(const hop_dist_job* __restri
     }
   }
   __syncthreads();
-  if (tid == 0) out[blockIdx.x] = (jb.kind == HOP_DIST_SSE) ? acc : (acc >> (bd - 8));
+  return (jb.kind == HOP_DIST_SSE) ? acc : (acc >> (bd - 8));
+}
+__global__ __launch_bounds__(256) void k_distortion(const hop_dist_job* __restrict__ jobs, hop_pics pic, uint32_t* __restrict__ out) {
+  __shared__ unsigned int acc;
+  const hop_dist_job jb = jobs[blockIdx.x];
+  const uint32_t v = distortion_body(acc, jb, pic);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+// Sequences of candidates rated one after the other (TEncSearch::xMergeEstimation TLibEncoder/TEncSearch.cpp:2992-3106, xGetTemplateCost :4411-4477 with xGetInterPredictionError
+// :2951-2977: every candidate of a PU is predicted into the same temporary block and its luma distortion taken): sequence s = jobs first[s] .. first[s + 1] - 1, all on the
+// PU's rectangle.  Grid (sequences, 3): plane 0 predicts and rates the candidates in order (out[j] per job); planes 1 / 2 predict the LAST candidate only -- afterwards the
+// prediction picture holds the last candidate's prediction in all planes, as after the reference's loop.
+__global__ __launch_bounds__(256) void k_pred_cost(const int32_t* __restrict__ first, const hop_pred_job* __restrict__ jobs, const int32_t* __restrict__ kinds, hop_pics pic,
+                                                   uint32_t* __restrict__ out) {
+  __shared__ PredShared sh;
+  __shared__ unsigned int acc;
+  const int s = blockIdx.x, comp = blockIdx.y, j0 = first[s], j1 = first[s + 1];
+  if (j1 <= j0) return;
+  if (comp) { const hop_pred_job jb = jobs[j1 - 1]; pred_inter_body(sh, jb, comp, pic); return; }
+  for (int j = j0; j < j1; j++) {
+    const hop_pred_job jb = jobs[j];
+    pred_inter_body(sh, jb, 0, pic);
+    __threadfence_block();
+    __syncthreads();
+    hop_dist_job d; d.x = jb.pu_x; d.y = jb.pu_y + jb.dst_row_off; d.w = jb.w; d.h = jb.h; d.comp = 0; d.kind = kinds[s];
+    const uint32_t v = distortion_body(acc, d, pic);
+    if (threadIdx.x == 0) out[j] = v;
+    __syncthreads();                                                    // (the patch and the accumulator are reused by the next candidate)
+  }
+}
+int hop_launch_pred_cost(hop_ctx* c, int m, const int32_t* d_first, const hop_pred_job* d_jobs, const int32_t* d_kinds, uint32_t* d_out) {
+  const int pr = hop_prof_begin(c, HOP_K_PRED, (uint64_t)m);
+  hipLaunchKernelGGL(k_pred_cost, dim3(m, 3), dim3(256), 0, c->stream, d_first, d_jobs, d_kinds, hop_make_pics(c), d_out);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "pred_cost launch: %s", hipGetErrorString(e));
+  return HOP_OK;
 }
 
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out) {

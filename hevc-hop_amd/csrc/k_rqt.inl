@@ -42,10 +42,8 @@ __device__ static inline size_t rqt_coef_at(const RqtClass& k, int i, int layer,
   return rqt_coef_base(k, i) + (size_t)layer * (cu2 + (cu2 >> 1)) + (comp == 0 ? 0 : comp == 1 ? cu2 : cu2 + (cu2 >> 2)) + (comp ? (size_t)((16 * part) >> 2) : (size_t)(16 * part));
 }
 
-__global__ void k_rqt_init(const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, hop_cabac_ctx* __restrict__ cur,
-                           RqtWork* __restrict__ work, hop_rqt_result* __restrict__ res) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// (the kernels of this file are thin wrappers around *_body functions: the candidate walks of k_walk.inl call the same bodies from ONE kernel per candidate)
+__device__ static inline void rqt_init_body(const int i, const hop_rqt_job* jobs, const hop_cabac_ctx* ctx_in, hop_cabac_ctx* cur, RqtWork* work, hop_rqt_result* res) {
   cur[i] = ctx_in[jobs[i].ctx_index];
   RqtWork w; memset(&w, 0, sizeof(w));
   work[i] = w;
@@ -53,13 +51,15 @@ __global__ void k_rqt_init(const hop_rqt_job* __restrict__ jobs, int n, const ho
   r->cost = 0; r->bits = r->dist = r->zero_dist = r->pad = 0;
   for (int p = 0; p < 256; p++) { r->tr_idx[p] = 0; for (int c = 0; c < 3; c++) { r->cbf[c][p] = 0; r->tskip[c][p] = 0; } }
 }
+__global__ void k_rqt_init(const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, hop_cabac_ctx* __restrict__ cur,
+                           RqtWork* __restrict__ work, hop_rqt_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rqt_init_body(i, jobs, ctx_in, cur, work, res);
+}
 
 // entry of a node: CI_QT_TRAFO_ROOT <- the coder; the node's transform units as leaf jobs
-__global__ void k_rqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, int bd_y, int bd_c, const hop_cabac_ctx* __restrict__ cur,
-                            hop_cabac_ctx* __restrict__ root, hop_rqt_result* __restrict__ res, RqtWork* __restrict__ work, hop_tu_rd_job* __restrict__ tuj,
-                            int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2, int64_t* __restrict__ off2, size_t ts_base) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void rqt_begin_body(const int i, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, int bd_y, int bd_c, const hop_cabac_ctx* cur,
+                                             hop_cabac_ctx* root, hop_rqt_result* res, RqtWork* work, hop_tu_rd_job* tuj, int64_t* off, hop_tu_rd_job* tuj2, int64_t* off2, size_t ts_base) {
   root[i] = cur[i];
   const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d);
   if (!nd.check_full) { work[i].single_cost[nd.d] = 1.7e+308; work[i].sub_dist[nd.d + 1] = 0; work[i].sub_cost[nd.d + 1] = 0; work[i].sub_bits[nd.d + 1] = 0; return; }
@@ -86,6 +86,12 @@ __global__ void k_rqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restric
     }
   }
 }
+__global__ void k_rqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, int bd_y, int bd_c, const hop_cabac_ctx* __restrict__ cur,
+                            hop_cabac_ctx* __restrict__ root, hop_rqt_result* __restrict__ res, RqtWork* __restrict__ work, hop_tu_rd_job* __restrict__ tuj,
+                            int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2, int64_t* __restrict__ off2, size_t ts_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rqt_begin_body(i, k, nd, jobs, bd_y, bd_c, cur, root, res, work, tuj, off, tuj2, off2, ts_base);
+}
 
 #define RQ_LOAD(src) do { const uint8_t* s_ = (src).state; for (int q_ = 0; q_ < 152; q_++) sh.st[q_][lane] = s_[q_]; } while (0)
 #define RQ_LEFT() ((unsigned)sh.st[150][lane] | ((unsigned)sh.st[151][lane] << 8))
@@ -98,13 +104,9 @@ __device__ static inline void rqt_store(LDS& sh, int lane, unsigned long long fr
 __device__ static inline int rqt_cbf_ctx(int comp, int d) { return CX_QT_CBF + (comp ? 4 + d : (d == 0 ? 1 : 0)); }     // getCtxQtCbf, TComDataCU.cpp:1848-1859
 
 template <class LDS>
-__global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
-                                                   const hop_cabac_ctx* __restrict__ root, hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
-                                                   RqtWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2,
-                                                   int32_t* __restrict__ coef, size_t ts_base, const uint16_t* __restrict__ scans) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n) return;                                                // no barrier in this kernel
+__device__ static void rqt_single_body(LDS& sh, const int lane, const int i, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, hop_cabac_ctx* cur,
+                                       const hop_cabac_ctx* root, hop_cabac_ctx* test, hop_rqt_result* res, RqtWork* work, const hop_tu_rd_result* tr, const hop_tu_rd_result* tr2,
+                                       int32_t* coef, size_t ts_base, const uint16_t* scans) {
   const hop_rqt_job jb = jobs[i];
   hop_rqt_result* r = res + i; RqtWork* w = work + i;
   const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), d = nd.d;
@@ -153,6 +155,16 @@ __global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const
     w->sub_cost[d] += singleCost; w->sub_bits[d] += singleBits; w->sub_dist[d] += singleDist;
   }
 }
+template <class LDS>
+__global__ __launch_bounds__(64) void k_rqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
+                                                   const hop_cabac_ctx* __restrict__ root, hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
+                                                   RqtWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2,
+                                                   int32_t* __restrict__ coef, size_t ts_base, const uint16_t* __restrict__ scans) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
+  if (i >= n) return;                                                // no barrier in this kernel
+  rqt_single_body(sh, lane, i, k, nd, jobs, cur, root, test, res, work, tr, tr2, coef, ts_base, scans);
+}
 
 // xEncodeResidualQT on the lane's coder: the subtree below (part, d0) as the arrays describe it; flags (subdiv_and_cbf) or one component's levels
 template <class LDS>
@@ -199,12 +211,8 @@ __device__ static unsigned long long rqt_encode_tree(LDS& sh, const int lane, co
 }
 
 template <class LDS>
-__global__ __launch_bounds__(64) void k_rqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
-                                                  const hop_cabac_ctx* __restrict__ root, const hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
-                                                  RqtWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n) return;
+__device__ static void rqt_close_body(LDS& sh, const int lane, const int i, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, hop_cabac_ctx* cur, const hop_cabac_ctx* root,
+                                      const hop_cabac_ctx* test, hop_rqt_result* res, RqtWork* work, const int32_t* coef, const uint16_t* scans) {
   const hop_rqt_job jb = jobs[i];
   hop_rqt_result* r = res + i; RqtWork* w = work + i;
   const int parts = 1 << (2 * (k.log2_cu - 2)), d = nd.d, nparts = parts >> (2 * d), q = nparts >> 2;
@@ -234,12 +242,19 @@ __global__ __launch_bounds__(64) void k_rqt_close(RqtClass k, RqtNode nd, const 
   cur[i] = test[i];
   w->sub_cost[d] += w->single_cost[d]; w->sub_bits[d] += w->single_bits[d]; w->sub_dist[d] += w->single_dist[d];
 }
+template <class LDS>
+__global__ __launch_bounds__(64) void k_rqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, int n, hop_cabac_ctx* __restrict__ cur,
+                                                  const hop_cabac_ctx* __restrict__ root, const hop_cabac_ctx* __restrict__ test, hop_rqt_result* __restrict__ res,
+                                                  RqtWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
+  if (i >= n) return;
+  rqt_close_body(sh, lane, i, k, nd, jobs, cur, root, test, res, work, coef, scans);
+}
 
 // results of the root + the chosen transform units' levels in the CU's coefficient layout (what xSetResidualQTData copies, :7658-7777)
-__global__ __launch_bounds__(64) void k_rqt_final(RqtClass k, int n, const RqtWork* __restrict__ work, hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef,
-                                                  int32_t* __restrict__ out, const hop_cabac_ctx* __restrict__ cur, hop_cabac_ctx* __restrict__ ctx_out) {
-  const int i = blockIdx.x, tid = threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void rqt_final_body(const int i, const int tid, const int nt, const RqtClass& k, const RqtWork* work, hop_rqt_result* res, const int32_t* coef, int32_t* out,
+                                             const hop_cabac_ctx* cur, hop_cabac_ctx* ctx_out) {
   hop_rqt_result* r = res + i;
   if (tid == 0) { r->cost = work[i].sub_cost[0]; r->bits = work[i].sub_bits[0]; r->dist = work[i].sub_dist[0]; r->zero_dist = work[i].zero_dist; if (ctx_out) ctx_out[i] = cur[i]; }
   if (!out) return;
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(64) void k_rqt_final(RqtClass k, int n, const RqtWo
   int32_t* o = out + (size_t)i * (cu2 + (cu2 >> 1));
   // a TU's block is contiguous from its first partition on (16 luma / 4 + 4 chroma coefficients per partition), so copying partition by
   // partition from the layer of the partition's transform depth copies every chosen block whole
-  for (int t = tid; t < parts * 16; t += 64) {
+  for (int t = tid; t < parts * 16; t += nt) {
     const int p = t >> 4, q = t & 15, layer = k.log2_max_tu - (k.log2_cu - r->tr_idx[p]);
     o[t] = coef[rqt_coef_at(k, i, layer, 0, p) + q];
     if (q < 4) {
@@ -256,6 +271,10 @@ __global__ __launch_bounds__(64) void k_rqt_final(RqtClass k, int n, const RqtWo
       o[cu2 + (cu2 >> 2) + 4 * p + q] = coef[rqt_coef_at(k, i, layer, 2, p) + q];
     }
   }
+}
+__global__ __launch_bounds__(64) void k_rqt_final(RqtClass k, int n, const RqtWork* __restrict__ work, hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef,
+                                                  int32_t* __restrict__ out, const hop_cabac_ctx* __restrict__ cur, hop_cabac_ctx* __restrict__ ctx_out) {
+  if ((int)blockIdx.x < n) rqt_final_body(blockIdx.x, threadIdx.x, 64, k, work, res, coef, out, cur, ctx_out);
 }
 
 // ---- host orchestration ----
@@ -340,10 +359,7 @@ int hop_launch_rqt_class(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
 //   k_turd_inverse(_small) in reconstruction mode: xDeQuant + xIT / xITransformSkip, Clip(prediction + residual), SSE against the original
 //   k_fin_sum      one lane per CU: the three distortions (getDistPart weights the chroma planes once per plane)
 // =====================================================================================================================
-__global__ void k_fin_decide(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ after, const int32_t* __restrict__ entropy_bits,
-                             hop_rqt_result* __restrict__ res, hop_cu_final* __restrict__ fin) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void fin_decide_body(const int i, const RqtClass& k, const hop_rqt_job* jobs, const hop_cabac_ctx* after, const int32_t* entropy_bits, hop_rqt_result* res, hop_cu_final* fin) {
   const uint8_t* s = after[i].state;
   const unsigned left = (unsigned)s[150] | ((unsigned)s[151] << 8);
   const uint32_t zeroBits = (uint32_t)((left + (unsigned long long)entropy_bits[s[CX_ROOT_CBF] ^ 0]) >> 15);     // encodeQtRootCbfZero
@@ -356,18 +372,23 @@ __global__ void k_fin_decide(RqtClass k, const hop_rqt_job* __restrict__ jobs, i
   }
   fin[i].root_cbf = (uint32_t)root;
 }
-
-__global__ __launch_bounds__(256) void k_fin_zero(RqtClass k, int n, const hop_cu_final* __restrict__ fin, int32_t* __restrict__ coef) {
-  const int i = blockIdx.x;
-  if (i >= n || fin[i].root_cbf) return;
-  const size_t m = ((size_t)3 << (2 * k.log2_cu)) / 2;
-  for (size_t q = threadIdx.x; q < m; q += 256) coef[(size_t)i * m + q] = 0;
+__global__ void k_fin_decide(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ after, const int32_t* __restrict__ entropy_bits,
+                             hop_rqt_result* __restrict__ res, hop_cu_final* __restrict__ fin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fin_decide_body(i, k, jobs, after, entropy_bits, res, fin);
 }
 
-__global__ void k_fin_emit(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, int bd_y, int bd_c, int d0, int d1, int nj, const hop_rqt_result* __restrict__ res,
-                           const hop_cu_final* __restrict__ fin, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, uint32_t* __restrict__ abs_flag) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void fin_zero_body(const int i, const int tid, const int nt, const RqtClass& k, const hop_cu_final* fin, int32_t* coef) {
+  if (fin[i].root_cbf) return;
+  const size_t m = ((size_t)3 << (2 * k.log2_cu)) / 2;
+  for (size_t q = tid; q < m; q += nt) coef[(size_t)i * m + q] = 0;
+}
+__global__ __launch_bounds__(256) void k_fin_zero(RqtClass k, int n, const hop_cu_final* __restrict__ fin, int32_t* __restrict__ coef) {
+  if ((int)blockIdx.x < n) fin_zero_body(blockIdx.x, threadIdx.x, 256, k, fin, coef);
+}
+
+__device__ static inline void fin_emit_body(const int i, const RqtClass& k, const hop_rqt_job* jobs, int bd_y, int bd_c, int d0, int d1, int nj, const hop_rqt_result* res,
+                                            const hop_cu_final* fin, hop_tu_rd_job* tuj, int64_t* off, uint32_t* abs_flag) {
   const hop_rqt_job jb = jobs[i];
   const hop_rqt_result* r = res + i;
   const int root = (int)fin[i].root_cbf, parts = 1 << (2 * (k.log2_cu - 2));
@@ -391,16 +412,23 @@ __global__ void k_fin_emit(RqtClass k, const hop_rqt_job* __restrict__ jobs, int
     }
   }
 }
-
-__global__ void k_fin_sum(const hop_rqt_job* __restrict__ jobs, int n, int nj, const hop_tu_rd_job* __restrict__ tuj, const uint32_t* __restrict__ sse, hop_cu_final* __restrict__ fin) {
+__global__ void k_fin_emit(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, int bd_y, int bd_c, int d0, int d1, int nj, const hop_rqt_result* __restrict__ res,
+                           const hop_cu_final* __restrict__ fin, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, uint32_t* __restrict__ abs_flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) fin_emit_body(i, k, jobs, bd_y, bd_c, d0, d1, nj, res, fin, tuj, off, abs_flag);
+}
+
+__device__ static inline void fin_sum_body(const int i, const hop_rqt_job* jobs, int nj, const hop_tu_rd_job* tuj, const uint32_t* sse, hop_cu_final* fin) {
   unsigned long long s3[3] = { 0, 0, 0 };
   for (int q = 0; q < nj; q++) if (tuj[(size_t)i * nj + q].log2_size >= 2) s3[q % 3] += sse[(size_t)i * nj + q];
   const hop_rqt_job jb = jobs[i];
   fin[i].dist[0] = (uint32_t)s3[0];
   fin[i].dist[1] = (uint32_t)(int)(jb.dist_weight[0] * (uint32_t)s3[1]);           // getDistPart, TComRdCost.cpp:493-497
   fin[i].dist[2] = (uint32_t)(int)(jb.dist_weight[1] * (uint32_t)s3[2]);
+}
+__global__ void k_fin_sum(const hop_rqt_job* __restrict__ jobs, int n, int nj, const hop_tu_rd_job* __restrict__ tuj, const uint32_t* __restrict__ sse, hop_cu_final* __restrict__ fin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fin_sum_body(i, jobs, nj, tuj, sse, fin);
 }
 
 static int rqt_jobs_per_cu(int log2_cu, int log2_max_tu, int log2_min_tu, int* d0, int* d1) {
@@ -472,13 +500,9 @@ __device__ static unsigned long long cu_merge_index(LDS& sh, const int lane, con
 }
 
 template <class LDS>
-__global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ res,
-                                                const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
-                                                uint32_t* __restrict__ bits_out, uint32_t* __restrict__ skipped_out, hop_cabac_ctx* __restrict__ ctx_out,
-                                                hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n) return;
+__device__ static void cu_bits_body(LDS& sh, const int lane, const int i, const RqtClass& k, const hop_rqt_job* jobs, const hop_cu_syntax* syn, const hop_rqt_result* res, const int32_t* coef,
+                                    const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_in, uint32_t* bits_out, uint32_t* skipped_out, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_out,
+                                    const uint16_t* scans) {
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]);
   for (int q = 0; q < 20; q++) sh.st[CUX + q][lane] = cu_in[ci].state[q];
@@ -563,6 +587,16 @@ __global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt
   skipped_out[i] = skipped;
   if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
   if (cu_out) for (int q = 0; q < 20; q++) cu_out[i].state[q] = sh.st[CUX + q][lane];
+}
+template <class LDS>
+__global__ __launch_bounds__(64) void k_cu_bits(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ res,
+                                                const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
+                                                uint32_t* __restrict__ bits_out, uint32_t* __restrict__ skipped_out, hop_cabac_ctx* __restrict__ ctx_out,
+                                                hop_cabac_cu_ctx* __restrict__ cu_out, const uint16_t* __restrict__ scans) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
+  if (i >= n) return;
+  cu_bits_body(sh, lane, i, k, jobs, syn, res, coef, ctx_in, cu_in, bits_out, skipped_out, ctx_out, cu_out, scans);
 }
 
 int hop_launch_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int inter_split, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs,
@@ -718,10 +752,8 @@ __host__ __device__ static inline int irq_node_index(int d, int log2, int part) 
 #define IRQ_CU_LOAD(src) do { for (int q_ = 0; q_ < 20; q_++) sh.st[CUX + q_][lane] = (src).state[q_]; } while (0)
 #define IRQ_CU_STORE(dst) do { for (int q_ = 0; q_ < 20; q_++) (dst).state[q_] = sh.st[CUX + q_][lane]; } while (0)
 
-__global__ void k_irqt_init(const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
-                            hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, IrqWork* __restrict__ work, hop_rqt_result* __restrict__ res) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void irqt_init_body(const int i, const hop_rqt_job* jobs, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_in, hop_cabac_ctx* cur, hop_cabac_cu_ctx* cucur,
+                                             IrqWork* work, hop_rqt_result* res) {
   cur[i] = ctx_in[jobs[i].ctx_index]; cucur[i] = cu_in[jobs[i].ctx_index];
   IrqWork w; memset(&w, 0, sizeof(w));
   work[i] = w;
@@ -729,14 +761,15 @@ __global__ void k_irqt_init(const hop_rqt_job* __restrict__ jobs, int n, const h
   r->cost = 0; r->bits = r->dist = r->zero_dist = r->pad = 0;
   for (int p = 0; p < 256; p++) { r->tr_idx[p] = 0; for (int c = 0; c < 3; c++) { r->cbf[c][p] = 0; r->tskip[c][p] = 0; } }
 }
-
-__global__ void k_irqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, const hop_intra_rqt_opt* __restrict__ opt,
-                             int n, int bd_y, const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ root,
-                             hop_cabac_cu_ctx* __restrict__ curoot, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, hop_intra_job* __restrict__ pj,
-                             int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2,
-                             int64_t* __restrict__ off2, size_t ts_base, const uint8_t* __restrict__ active) {
+__global__ void k_irqt_init(const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in,
+                            hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, IrqWork* __restrict__ work, hop_rqt_result* __restrict__ res) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) irqt_init_body(i, jobs, ctx_in, cu_in, cur, cucur, work, res);
+}
+
+__device__ static inline void irqt_begin_body(const int i, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn, const hop_intra_rqt_opt* opt, int bd_y,
+                                              const hop_cabac_ctx* cur, const hop_cabac_cu_ctx* cucur, hop_cabac_ctx* root, hop_cabac_cu_ctx* curoot, hop_rqt_result* res, IrqWork* work,
+                                              hop_intra_job* pj, int32_t* modes, hop_tu_rd_job* tuj, int64_t* off, hop_tu_rd_job* tuj2, int64_t* off2, size_t ts_base, const uint8_t* active) {
   if (active && !active[i]) {                                           // an idle PU of this pass: empty slots in the prediction and leaf batches
     hop_intra_job q0; memset(&q0, 0, sizeof(q0)); pj[i] = q0; modes[i] = 0;
     hop_tu_rd_job j0; memset(&j0, 0, sizeof(j0)); tuj[i] = j0; off[i] = 0; if (nd.ts_y) { tuj2[i] = j0; off2[i] = 0; }
@@ -769,36 +802,42 @@ __global__ void k_irqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restri
     tuj2[i] = j; off2[i] = (int64_t)(ts_base + (size_t)i * 16);
   }
 }
+__global__ void k_irqt_begin(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, const hop_intra_rqt_opt* __restrict__ opt,
+                             int n, int bd_y, const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ root,
+                             hop_cabac_cu_ctx* __restrict__ curoot, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, hop_intra_job* __restrict__ pj,
+                             int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off, hop_tu_rd_job* __restrict__ tuj2,
+                             int64_t* __restrict__ off2, size_t ts_base, const uint8_t* __restrict__ active) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) irqt_begin_body(i, k, nd, jobs, syn, opt, bd_y, cur, cucur, root, curoot, res, work, pj, modes, tuj, off, tuj2, off2, ts_base, active);
+}
 
 // mode 0: the node's block, picture -> layer plane; 1: the 4x4 block, picture -> transform-skip park; 2: layer plane -> picture where the single block has won
-__global__ __launch_bounds__(256) void k_irqt_copy(int mode, RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
-                                                   const IrqWork* __restrict__ work, int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ recl, int16_t* __restrict__ park,
-                                                   const uint8_t* __restrict__ active) {
-  const int i = blockIdx.x;
+__device__ static inline void irqt_copy_body(const int i, const int tid, const int nt, int mode, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn,
+                                             const IrqWork* work, int16_t* rec, int pitch, int16_t* recl, int16_t* park, const uint8_t* active) {
   if (active && !active[i]) return;
   if (mode == 2 && !work[i].restore[nd.d]) return;
   const int part = syn[i].part + nd.part, N = 1 << nd.log2, cu = 1 << k.log2_cu, x0 = rqt_zx(part), y0 = rqt_zy(part);
   int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
   int16_t* lay = recl + ((size_t)i * 4 + (size_t)(k.log2_max_tu - nd.log2)) * ((size_t)cu * cu) + (size_t)y0 * cu + x0;
-  for (int e = threadIdx.x; e < N * N; e += 256) {
+  for (int e = tid; e < N * N; e += nt) {
     const int rr = e >> nd.log2, cc = e & (N - 1);
     if (mode == 0) lay[(size_t)rr * cu + cc] = pic[(size_t)rr * pitch + cc];
     else if (mode == 1) park[(size_t)i * 16 + e] = pic[(size_t)rr * pitch + cc];
     else pic[(size_t)rr * pitch + cc] = lay[(size_t)rr * cu + cc];
   }
 }
+__global__ __launch_bounds__(256) void k_irqt_copy(int mode, RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
+                                                   const IrqWork* __restrict__ work, int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ recl, int16_t* __restrict__ park,
+                                                   const uint8_t* __restrict__ active) {
+  irqt_copy_body(blockIdx.x, threadIdx.x, 256, mode, k, nd, jobs, syn, work, rec, pitch, recl, park, active);
+}
 
 template <class LDS>
-__global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
-                                                    const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur,
-                                                    const hop_cabac_ctx* __restrict__ root, const hop_cabac_cu_ctx* __restrict__ curoot, hop_cabac_ctx* __restrict__ test,
-                                                    hop_cabac_cu_ctx* __restrict__ cutest, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work,
-                                                    const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base,
-                                                    int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans,
-                                                    const uint8_t* __restrict__ active) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n || (active && !active[i])) return;
+__device__ static void irqt_single_body(LDS& sh, const int lane, const int i, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn,
+                                        const hop_intra_rqt_opt* opt, hop_cabac_ctx* cur, hop_cabac_cu_ctx* cucur, const hop_cabac_ctx* root, const hop_cabac_cu_ctx* curoot,
+                                        hop_cabac_ctx* test, hop_cabac_cu_ctx* cutest, hop_rqt_result* res, IrqWork* work, const hop_tu_rd_result* tr, const hop_tu_rd_result* tr2,
+                                        int32_t* coef, size_t ts_base, int16_t* rec, int pitch, const int16_t* park, const uint16_t* scans, const uint8_t* active) {
+  if (active && !active[i]) return;
   const hop_intra_cu_syntax y = syn[i];
   const double lambda = jobs[i].lambda_rd;
   hop_rqt_result* r = res + i;
@@ -839,16 +878,25 @@ __global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, cons
   if (nd.check_split) { rqt_store(sh, lane, frac, test + i); IRQ_CU_STORE(cutest[i]); cur[i] = root[i]; cucur[i] = curoot[i]; }
   else { rqt_store(sh, lane, frac, cur + i); IRQ_CU_STORE(cucur[i]); w->sub_cost[nd.d] += cost; w->sub_dist[nd.d] += dist; }
 }
-
 template <class LDS>
-__global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
-                                                   hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, const hop_cabac_ctx* __restrict__ root,
-                                                   const hop_cabac_cu_ctx* __restrict__ curoot, const hop_cabac_ctx* __restrict__ test, const hop_cabac_cu_ctx* __restrict__ cutest,
-                                                   hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans,
-                                                   const uint8_t* __restrict__ active) {
+__global__ __launch_bounds__(64) void k_irqt_single(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                    const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur,
+                                                    const hop_cabac_ctx* __restrict__ root, const hop_cabac_cu_ctx* __restrict__ curoot, hop_cabac_ctx* __restrict__ test,
+                                                    hop_cabac_cu_ctx* __restrict__ cutest, hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work,
+                                                    const hop_tu_rd_result* __restrict__ tr, const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base,
+                                                    int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ park, const uint16_t* __restrict__ scans,
+                                                    const uint8_t* __restrict__ active) {
   __shared__ LDS sh;
   RQT_LANE_OR_BLOCK(n);
-  if (i >= n || (active && !active[i])) return;
+  if (i >= n) return;
+  irqt_single_body(sh, lane, i, k, nd, jobs, syn, opt, cur, cucur, root, curoot, test, cutest, res, work, tr, tr2, coef, ts_base, rec, pitch, park, scans, active);
+}
+
+template <class LDS>
+__device__ static void irqt_close_body(LDS& sh, const int lane, const int i, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn, hop_cabac_ctx* cur,
+                                       hop_cabac_cu_ctx* cucur, const hop_cabac_ctx* root, const hop_cabac_cu_ctx* curoot, const hop_cabac_ctx* test, const hop_cabac_cu_ctx* cutest,
+                                       hop_rqt_result* res, IrqWork* work, const int32_t* coef, const uint16_t* scans, const uint8_t* active) {
+  if (active && !active[i]) return;
   const hop_intra_cu_syntax y = syn[i];
   hop_rqt_result* r = res + i;
   IrqWork* w = work + i;
@@ -870,22 +918,37 @@ __global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const
   w->restore[nd.d] = 1;
   w->sub_cost[nd.d] += w->single_cost[nd.d]; w->sub_dist[nd.d] += w->single_dist[nd.d];
 }
+template <class LDS>
+__global__ __launch_bounds__(64) void k_irqt_close(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
+                                                   hop_cabac_ctx* __restrict__ cur, hop_cabac_cu_ctx* __restrict__ cucur, const hop_cabac_ctx* __restrict__ root,
+                                                   const hop_cabac_cu_ctx* __restrict__ curoot, const hop_cabac_ctx* __restrict__ test, const hop_cabac_cu_ctx* __restrict__ cutest,
+                                                   hop_rqt_result* __restrict__ res, IrqWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans,
+                                                   const uint8_t* __restrict__ active) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
+  if (i >= n) return;
+  irqt_close_body(sh, lane, i, k, nd, jobs, syn, cur, cucur, root, curoot, test, cutest, res, work, coef, scans, active);
+}
 
-__global__ __launch_bounds__(64) void k_irqt_final(RqtClass k, int d0, int n, const hop_intra_cu_syntax* __restrict__ syn, const IrqWork* __restrict__ work,
-                                                   hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, int32_t* __restrict__ coef_out,
-                                                   const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ ctx_out,
-                                                   hop_cabac_cu_ctx* __restrict__ cu_out, const uint8_t* __restrict__ active) {
-  const int i = blockIdx.x, t = threadIdx.x;
+__device__ static inline void irqt_final_body(const int i, const int t, const int nt, const RqtClass& k, int d0, const hop_intra_cu_syntax* syn, const IrqWork* work, hop_rqt_result* res,
+                                              const int32_t* coef, int32_t* coef_out, const hop_cabac_ctx* cur, const hop_cabac_cu_ctx* cucur, hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_out,
+                                              const uint8_t* active) {
   if (active && !active[i]) return;
   const int parts = 1 << (2 * (k.log2_cu - 2)), np = parts >> (2 * d0), p0 = syn[i].part;
   const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
   hop_rqt_result* r = res + i;
   if (t == 0) { r->cost = work[i].sub_cost[d0]; r->dist = work[i].sub_dist[d0]; if (ctx_out) ctx_out[i] = cur[i]; if (cu_out) cu_out[i] = cucur[i]; }
   if (!coef_out) return;
-  for (int e = t; e < 16 * np; e += 64) {
+  for (int e = t; e < 16 * np; e += nt) {
     const int p = p0 + (e >> 4), layer = k.log2_max_tu - (k.log2_cu - r->tr_idx[p]);
     coef_out[(size_t)i * (cu2 + (cu2 >> 1)) + (size_t)16 * p0 + e] = coef[rqt_coef_at(k, i, layer, 0, p) + (e & 15)];
   }
+}
+__global__ __launch_bounds__(64) void k_irqt_final(RqtClass k, int d0, int n, const hop_intra_cu_syntax* __restrict__ syn, const IrqWork* __restrict__ work,
+                                                   hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, int32_t* __restrict__ coef_out,
+                                                   const hop_cabac_ctx* __restrict__ cur, const hop_cabac_cu_ctx* __restrict__ cucur, hop_cabac_ctx* __restrict__ ctx_out,
+                                                   hop_cabac_cu_ctx* __restrict__ cu_out, const uint8_t* __restrict__ active) {
+  irqt_final_body(blockIdx.x, threadIdx.x, 64, k, d0, syn, work, res, coef, coef_out, cur, cucur, ctx_out, cu_out, active);
 }
 
 size_t hop_intra_rqt_work_bytes(int log2_cu, int n) {
@@ -974,11 +1037,9 @@ int hop_launch_intra_rqt(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_
 // =====================================================================================================================
 struct IsWork { double best_cost; uint32_t best_dist; int32_t best_mode; uint8_t tr[256], cbf[256], ts[256]; };
 
-__global__ void k_is_prep(RqtClass k, int pu, int nxn, const hop_rqt_job* __restrict__ jobs, const hop_intra_search_job* __restrict__ sj, const hop_intra_rqt_opt* __restrict__ opt, int n,
-                          const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_intra_search_result* __restrict__ sres,
-                          hop_intra_cu_syntax* __restrict__ syn, hop_intra_job* __restrict__ rj, hop_intra_modes_job* __restrict__ mj, IsWork* __restrict__ work) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void is_prep_body(const int i, const RqtClass& k, int pu, int nxn, const hop_rqt_job* jobs, const hop_intra_search_job* sj, const hop_intra_rqt_opt* opt,
+                                           const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_in, const hop_intra_search_result* sres, hop_intra_cu_syntax* syn, hop_intra_job* rj,
+                                           hop_intra_modes_job* mj, IsWork* work) {
   const int parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * nxn), part = pu * q, N = (1 << k.log2_cu) >> nxn;
   const int left = (nxn && (pu & 1)) ? sres[i].best_dir[pu - 1] : sj[i].left_dir[pu], above = (nxn && (pu & 2)) ? sres[i].best_dir[pu - 2] : sj[i].above_dir[pu];
   int p0, p1, p2, mpm;
@@ -998,43 +1059,56 @@ __global__ void k_is_prep(RqtClass k, int pu, int nxn, const hop_rqt_job* __rest
   mj[i] = m;
   work[i].best_cost = 1.7e+308; work[i].best_dist = 0; work[i].best_mode = 0;
 }
+__global__ void k_is_prep(RqtClass k, int pu, int nxn, const hop_rqt_job* __restrict__ jobs, const hop_intra_search_job* __restrict__ sj, const hop_intra_rqt_opt* __restrict__ opt, int n,
+                          const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_intra_search_result* __restrict__ sres,
+                          hop_intra_cu_syntax* __restrict__ syn, hop_intra_job* __restrict__ rj, hop_intra_modes_job* __restrict__ mj, IsWork* __restrict__ work) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) is_prep_body(i, k, pu, nxn, jobs, sj, opt, ctx_in, cu_in, sres, syn, rj, mj, work);
+}
 
 // pass < n_max: candidate `pass` of the list (CUs whose list is shorter sit the pass out); pass == n_max: the best mode so far
-__global__ void k_is_pick(int pu, int pass, int n_max, int n, const hop_intra_modes_result* __restrict__ mres, const IsWork* __restrict__ work, hop_intra_cu_syntax* __restrict__ syn,
-                          uint8_t* __restrict__ active) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void is_pick_body(const int i, int pu, int pass, int n_max, const hop_intra_modes_result* mres, const IsWork* work, hop_intra_cu_syntax* syn, uint8_t* active) {
   const int cnt = (int)mres[i].n;
   active[i] = (pass == n_max || pass < cnt) ? 1 : 0;
   syn[i].luma_dir[pu] = pass == n_max ? work[i].best_mode : (int)mres[i].modes[pass < cnt ? pass : cnt - 1];
 }
+__global__ void k_is_pick(int pu, int pass, int n_max, int n, const hop_intra_modes_result* __restrict__ mres, const IsWork* __restrict__ work, hop_intra_cu_syntax* __restrict__ syn,
+                          uint8_t* __restrict__ active) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) is_pick_body(i, pu, pass, n_max, mres, work, syn, active);
+}
 
-__global__ __launch_bounds__(64) void k_is_keep(RqtClass k, int pu, int nxn, int pass, int n_max, const hop_rqt_job* __restrict__ jobs, int n,
-                                                const hop_intra_modes_result* __restrict__ mres, const hop_intra_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ tmp,
-                                                const int32_t* __restrict__ coef_tmp, const int16_t* __restrict__ rec, int pitch, IsWork* __restrict__ work,
-                                                int32_t* __restrict__ coef_out, int16_t* __restrict__ reco_out) {
-  const int i = blockIdx.x, t = threadIdx.x;
+// (every thread of the workgroup calls: a barrier inside)
+__device__ static inline void is_keep_body(const int i, const int t, const int nt, const RqtClass& k, int pu, int nxn, int pass, int n_max, const hop_rqt_job* jobs,
+                                           const hop_intra_modes_result* mres, const hop_intra_cu_syntax* syn, const hop_rqt_result* tmp, const int32_t* coef_tmp, const int16_t* rec, int pitch,
+                                           IsWork* work, int32_t* coef_out, int16_t* reco_out) {
   const bool active = pass == n_max || pass < (int)mres[i].n;
   if (!active || !(tmp[i].cost < work[i].best_cost)) return;           // uniform per block; best_cost is written after the barrier below
   const int cu = 1 << k.log2_cu, parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * nxn), part = pu * q, N = cu >> nxn, x0 = rqt_zx(part), y0 = rqt_zy(part);
   const size_t cu2 = (size_t)cu * cu, cb = (size_t)i * (cu2 + (cu2 >> 1));
-  for (int e = t; e < q; e += 64) { work[i].tr[part + e] = tmp[i].tr_idx[part + e]; work[i].cbf[part + e] = tmp[i].cbf[0][part + e]; work[i].ts[part + e] = tmp[i].tskip[0][part + e]; }
-  for (int e = t; e < 16 * q; e += 64) coef_out[cb + (size_t)16 * part + e] = coef_tmp[cb + (size_t)16 * part + e];
+  for (int e = t; e < q; e += nt) { work[i].tr[part + e] = tmp[i].tr_idx[part + e]; work[i].cbf[part + e] = tmp[i].cbf[0][part + e]; work[i].ts[part + e] = tmp[i].tskip[0][part + e]; }
+  for (int e = t; e < 16 * q; e += nt) coef_out[cb + (size_t)16 * part + e] = coef_tmp[cb + (size_t)16 * part + e];
   const int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
-  for (int e = t; e < N * N; e += 64) { const int rr = e / N, cc = e % N; reco_out[(size_t)i * cu2 + (size_t)(y0 + rr) * cu + x0 + cc] = pic[(size_t)rr * pitch + cc]; }
+  for (int e = t; e < N * N; e += nt) { const int rr = e / N, cc = e % N; reco_out[(size_t)i * cu2 + (size_t)(y0 + rr) * cu + x0 + cc] = pic[(size_t)rr * pitch + cc]; }
   __syncthreads();
   if (t == 0) { work[i].best_cost = tmp[i].cost; work[i].best_dist = tmp[i].dist; work[i].best_mode = syn[i].luma_dir[pu]; }
 }
+__global__ __launch_bounds__(64) void k_is_keep(RqtClass k, int pu, int nxn, int pass, int n_max, const hop_rqt_job* __restrict__ jobs, int n,
+                                                const hop_intra_modes_result* __restrict__ mres, const hop_intra_cu_syntax* __restrict__ syn, const hop_rqt_result* __restrict__ tmp,
+                                                const int32_t* __restrict__ coef_tmp, const int16_t* __restrict__ rec, int pitch, IsWork* __restrict__ work,
+                                                int32_t* __restrict__ coef_out, int16_t* __restrict__ reco_out) {
+  is_keep_body(blockIdx.x, threadIdx.x, 64, k, pu, nxn, pass, n_max, jobs, mres, syn, tmp, coef_tmp, rec, pitch, work, coef_out, reco_out);
+}
 
-__global__ __launch_bounds__(64) void k_is_commit(RqtClass k, int pu, int nxn, const hop_rqt_job* __restrict__ jobs, int n, const IsWork* __restrict__ work,
-                                                  const hop_intra_modes_result* __restrict__ mres, hop_intra_cu_syntax* __restrict__ syn, hop_rqt_result* __restrict__ res,
-                                                  hop_intra_search_result* __restrict__ sres, int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ reco_out) {
-  const int i = blockIdx.x, t = threadIdx.x;
+// (every thread of the workgroup calls: barriers inside)
+__device__ static inline void is_commit_body(const int i, const int t, const int nt, const RqtClass& k, int pu, int nxn, const hop_rqt_job* jobs, const IsWork* work,
+                                             const hop_intra_modes_result* mres, hop_intra_cu_syntax* syn, hop_rqt_result* res, hop_intra_search_result* sres, int16_t* rec, int pitch,
+                                             const int16_t* reco_out) {
   const int cu = 1 << k.log2_cu, parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * nxn), part = pu * q, N = cu >> nxn, x0 = rqt_zx(part), y0 = rqt_zy(part), npu = nxn ? 4 : 1;
-  for (int e = t; e < q; e += 64) { res[i].tr_idx[part + e] = work[i].tr[part + e]; res[i].cbf[0][part + e] = work[i].cbf[part + e]; res[i].tskip[0][part + e] = work[i].ts[part + e]; }
+  for (int e = t; e < q; e += nt) { res[i].tr_idx[part + e] = work[i].tr[part + e]; res[i].cbf[0][part + e] = work[i].cbf[part + e]; res[i].tskip[0][part + e] = work[i].ts[part + e]; }
   if (pu != npu - 1) {
     int16_t* pic = rec + (size_t)(jobs[i].y + y0) * pitch + jobs[i].x + x0;
-    for (int e = t; e < N * N; e += 64) { const int rr = e / N, cc = e % N; pic[(size_t)rr * pitch + cc] = reco_out[(size_t)i * ((size_t)cu * cu) + (size_t)(y0 + rr) * cu + x0 + cc]; }
+    for (int e = t; e < N * N; e += nt) { const int rr = e / N, cc = e % N; pic[(size_t)rr * pitch + cc] = reco_out[(size_t)i * ((size_t)cu * cu) + (size_t)(y0 + rr) * cu + x0 + cc]; }
   }
   if (t == 0) {
     sres[i].best_dir[pu] = work[i].best_mode; sres[i].n_cand[pu] = (int)mres[i].n; syn[i].luma_dir[pu] = work[i].best_mode;
@@ -1046,8 +1120,13 @@ __global__ __launch_bounds__(64) void k_is_commit(RqtClass k, int pu, int nxn, c
     unsigned comb = 0;
     for (int p = 0; p < 4; p++) comb |= (res[i].cbf[0][p * q] >> 1) & 1u;
     __syncthreads();
-    for (int e = t; e < parts; e += 64) res[i].cbf[0][e] |= (uint8_t)comb;
+    for (int e = t; e < parts; e += nt) res[i].cbf[0][e] |= (uint8_t)comb;
   }
+}
+__global__ __launch_bounds__(64) void k_is_commit(RqtClass k, int pu, int nxn, const hop_rqt_job* __restrict__ jobs, int n, const IsWork* __restrict__ work,
+                                                  const hop_intra_modes_result* __restrict__ mres, hop_intra_cu_syntax* __restrict__ syn, hop_rqt_result* __restrict__ res,
+                                                  hop_intra_search_result* __restrict__ sres, int16_t* __restrict__ rec, int pitch, const int16_t* __restrict__ reco_out) {
+  is_commit_body(blockIdx.x, threadIdx.x, 64, k, pu, nxn, jobs, work, mres, syn, res, sres, rec, pitch, reco_out);
 }
 
 size_t hop_intra_search_work_bytes(int log2_cu, int n) {
@@ -1132,10 +1211,7 @@ __device__ static inline bool ic_ts_here(const RqtClass& k, const hop_rqt_result
   return nb > 0;
 }
 
-__global__ void k_ic_mode(int m, const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, hop_cabac_ctx* __restrict__ cur,
-                          hop_intra_cu_syntax* __restrict__ syn, IcWork* __restrict__ work) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ static inline void ic_mode_body(const int i, int m, const hop_rqt_job* jobs, const hop_cabac_ctx* ctx_in, hop_cabac_ctx* cur, hop_intra_cu_syntax* syn, IcWork* work) {
   int list[5] = { 0, 26, 10, 1, 36 };                                   // getAllowedChromaDir, TComDataCU.cpp:1746-1764
   for (int q = 0; q < 4; q++) if (syn[i].luma_dir[0] == list[q]) { list[q] = 34; break; }
   const int mode = list[m];
@@ -1145,13 +1221,15 @@ __global__ void k_ic_mode(int m, const hop_rqt_job* __restrict__ jobs, int n, co
   if (m == 0) { w->best_cost = 1.7e+308; w->best_dist = 0; w->best_mode = 0; }
   w->dist = 0; w->mode = mode; w->keep = 0; w->dir = mode == 36 ? syn[i].luma_dir[0] : mode;
 }
-
-__global__ void k_ic_begin(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, const hop_intra_rqt_opt* __restrict__ opt,
-                           int n, int bd_c, const hop_cabac_ctx* __restrict__ cur, hop_cabac_ctx* __restrict__ root, const hop_rqt_result* __restrict__ res,
-                           const IcWork* __restrict__ work, hop_intra_job* __restrict__ pj, int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off,
-                           hop_tu_rd_job* __restrict__ tuj2, int64_t* __restrict__ off2, size_t ts_base) {
+__global__ void k_ic_mode(int m, const hop_rqt_job* __restrict__ jobs, int n, const hop_cabac_ctx* __restrict__ ctx_in, hop_cabac_ctx* __restrict__ cur,
+                          hop_intra_cu_syntax* __restrict__ syn, IcWork* __restrict__ work) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) ic_mode_body(i, m, jobs, ctx_in, cur, syn, work);
+}
+
+__device__ static inline void ic_begin_body(const int i, const RqtClass& k, const RqtNode& nd, int comp, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn, const hop_intra_rqt_opt* opt,
+                                            int bd_c, const hop_cabac_ctx* cur, hop_cabac_ctx* root, const hop_rqt_result* res, const IcWork* work, hop_intra_job* pj, int32_t* modes,
+                                            hop_tu_rd_job* tuj, int64_t* off, hop_tu_rd_job* tuj2, int64_t* off2, size_t ts_base) {
   hop_intra_job q0; memset(&q0, 0, sizeof(q0));
   hop_tu_rd_job j0; memset(&j0, 0, sizeof(j0));
   const hop_rqt_result* r = res + i;
@@ -1175,25 +1253,30 @@ __global__ void k_ic_begin(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* 
   if (ic_ts_here(k, r, nd.part, nd.d, opt[i].ts_fast)) { j.flags = HOP_TU_RD_TS; tuj2[i] = j; off2[i] = (int64_t)(ts_base + (size_t)i * 16); }
   else { tuj2[i] = j0; off2[i] = 0; }
 }
+__global__ void k_ic_begin(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, const hop_intra_rqt_opt* __restrict__ opt,
+                           int n, int bd_c, const hop_cabac_ctx* __restrict__ cur, hop_cabac_ctx* __restrict__ root, const hop_rqt_result* __restrict__ res,
+                           const IcWork* __restrict__ work, hop_intra_job* __restrict__ pj, int32_t* __restrict__ modes, hop_tu_rd_job* __restrict__ tuj, int64_t* __restrict__ off,
+                           hop_tu_rd_job* __restrict__ tuj2, int64_t* __restrict__ off2, size_t ts_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ic_begin_body(i, k, nd, comp, jobs, syn, opt, bd_c, cur, root, res, work, pj, modes, tuj, off, tuj2, off2, ts_base);
+}
 
 // the 4x4 block of the transform-skip variant, picture -> park
-__global__ __launch_bounds__(64) void k_ic_park(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_rqt_opt* __restrict__ opt, int n,
-                                                const hop_rqt_result* __restrict__ res, const int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ park) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 4), e = threadIdx.x & 15;
-  if (i >= n) return;
+__device__ static inline void ic_park_body(const int i, const int e, const RqtClass& k, const RqtNode& nd, const hop_rqt_job* jobs, const hop_intra_rqt_opt* opt, const hop_rqt_result* res,
+                                           const int16_t* rec, int pitch, int16_t* park) {
   if (!ic_leaf_here(k, res + i, nd.part, nd.d) || !ic_ts_here(k, res + i, nd.part, nd.d, opt[i].ts_fast)) return;
   park[(size_t)i * 16 + e] = rec[(size_t)(((jobs[i].y + rqt_zy(nd.part)) >> 1) + (e >> 2)) * pitch + ((jobs[i].x + rqt_zx(nd.part)) >> 1) + (e & 3)];
 }
+__global__ __launch_bounds__(64) void k_ic_park(RqtClass k, RqtNode nd, const hop_rqt_job* __restrict__ jobs, const hop_intra_rqt_opt* __restrict__ opt, int n,
+                                                const hop_rqt_result* __restrict__ res, const int16_t* __restrict__ rec, int pitch, int16_t* __restrict__ park) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 4), e = threadIdx.x & 15;
+  if (i < n) ic_park_body(i, e, k, nd, jobs, opt, res, rec, pitch, park);
+}
 
 template <class LDS>
-__global__ __launch_bounds__(64) void k_ic_single(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
-                                                  const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, const hop_cabac_ctx* __restrict__ root,
-                                                  hop_rqt_result* __restrict__ res, IcWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr,
-                                                  const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base, int16_t* __restrict__ rec, int pitch,
-                                                  const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n) return;
+__device__ static void ic_single_body(LDS& sh, const int lane, const int i, const RqtClass& k, const RqtNode& nd, int comp, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn,
+                                      const hop_intra_rqt_opt* opt, hop_cabac_ctx* cur, const hop_cabac_ctx* root, hop_rqt_result* res, IcWork* work, const hop_tu_rd_result* tr,
+                                      const hop_tu_rd_result* tr2, int32_t* coef, size_t ts_base, int16_t* rec, int pitch, const int16_t* park, const uint16_t* scans) {
   hop_rqt_result* r = res + i;
   if (!ic_leaf_here(k, r, nd.part, nd.d)) return;
   IcWork* w = work + i;
@@ -1226,10 +1309,19 @@ __global__ __launch_bounds__(64) void k_ic_single(RqtClass k, RqtNode nd, int co
   } else rqt_store(sh, lane, frac, cur + i);
   w->dist += dist;
 }
-
-__global__ void k_ic_fold(RqtClass k, RqtNode nd, int n, hop_rqt_result* __restrict__ res) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+template <class LDS>
+__global__ __launch_bounds__(64) void k_ic_single(RqtClass k, RqtNode nd, int comp, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                  const hop_intra_rqt_opt* __restrict__ opt, int n, hop_cabac_ctx* __restrict__ cur, const hop_cabac_ctx* __restrict__ root,
+                                                  hop_rqt_result* __restrict__ res, IcWork* __restrict__ work, const hop_tu_rd_result* __restrict__ tr,
+                                                  const hop_tu_rd_result* __restrict__ tr2, int32_t* __restrict__ coef, size_t ts_base, int16_t* __restrict__ rec, int pitch,
+                                                  const int16_t* __restrict__ park, const uint16_t* __restrict__ scans) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
   if (i >= n) return;
+  ic_single_body(sh, lane, i, k, nd, comp, jobs, syn, opt, cur, root, res, work, tr, tr2, coef, ts_base, rec, pitch, park, scans);
+}
+
+__device__ static inline void ic_fold_body(const int i, const RqtClass& k, const RqtNode& nd, hop_rqt_result* res) {
   hop_rqt_result* r = res + i;
   if (r->tr_idx[nd.part] <= nd.d) return;
   const int parts = 1 << (2 * (k.log2_cu - 2)), nparts = parts >> (2 * nd.d), q = nparts >> 2;
@@ -1237,14 +1329,14 @@ __global__ void k_ic_fold(RqtClass k, RqtNode nd, int n, hop_rqt_result* __restr
   for (int kk = 0; kk < 4; kk++) { su |= (r->cbf[1][nd.part + kk * q] >> (nd.d + 1)) & 1u; sv |= (r->cbf[2][nd.part + kk * q] >> (nd.d + 1)) & 1u; }
   for (int p = 0; p < nparts; p++) { r->cbf[1][nd.part + p] |= (uint8_t)(su << nd.d); r->cbf[2][nd.part + p] |= (uint8_t)(sv << nd.d); }
 }
+__global__ void k_ic_fold(RqtClass k, RqtNode nd, int n, hop_rqt_result* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ic_fold_body(i, k, nd, res);
+}
 
 template <class LDS>
-__global__ __launch_bounds__(64) void k_ic_bits(RqtClass k, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
-                                                const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_rqt_result* __restrict__ res,
-                                                IcWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n) return;
+__device__ static void ic_bits_body(LDS& sh, const int lane, const int i, const RqtClass& k, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn, const hop_cabac_ctx* ctx_in,
+                                    const hop_cabac_cu_ctx* cu_in, const hop_rqt_result* res, IcWork* work, const int32_t* coef, const uint16_t* scans) {
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]); IRQ_CU_LOAD(cu_in[ci]);
   unsigned long long frac = RQ_LEFT();
@@ -1253,36 +1345,51 @@ __global__ __launch_bounds__(64) void k_ic_bits(RqtClass k, const hop_rqt_job* _
   const double cost = rqt_cost((uint32_t)(frac >> 15), w->dist, jobs[i].lambda_rd);
   if (cost < w->best_cost) { w->best_cost = cost; w->best_dist = w->dist; w->best_mode = w->mode; w->keep = 1; }
 }
+template <class LDS>
+__global__ __launch_bounds__(64) void k_ic_bits(RqtClass k, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn, int n,
+                                                const hop_cabac_ctx* __restrict__ ctx_in, const hop_cabac_cu_ctx* __restrict__ cu_in, const hop_rqt_result* __restrict__ res,
+                                                IcWork* __restrict__ work, const int32_t* __restrict__ coef, const uint16_t* __restrict__ scans) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
+  if (i >= n) return;
+  ic_bits_body(sh, lane, i, k, jobs, syn, ctx_in, cu_in, res, work, coef, scans);
+}
 
 // xSetIntraResultChromaQT (:2280-2345) for the CUs whose direction of this pass is the best so far
-__global__ __launch_bounds__(64) void k_ic_keep(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, const hop_rqt_result* __restrict__ res, IcWork* __restrict__ work,
-                                                const int32_t* __restrict__ coef, const int16_t* __restrict__ rec_cb, const int16_t* __restrict__ rec_cr, int pitch,
-                                                int32_t* __restrict__ coef_out, int16_t* __restrict__ reco_out) {
-  const int i = blockIdx.x, t = threadIdx.x;
+__device__ static inline void ic_keep_body(const int i, const int t, const int nt, const RqtClass& k, const hop_rqt_job* jobs, const hop_rqt_result* res, IcWork* work, const int32_t* coef,
+                                           const int16_t* rec_cb, const int16_t* rec_cr, int pitch, int32_t* coef_out, int16_t* reco_out) {
   if (!work[i].keep) return;
   const int cu = 1 << k.log2_cu, half = cu >> 1, parts = 1 << (2 * (k.log2_cu - 2));
   const size_t cu2 = (size_t)cu * cu, h2 = cu2 >> 2;
   const hop_rqt_result* r = res + i;
-  for (int e = t; e < parts; e += 64) { work[i].cbf[0][e] = r->cbf[1][e]; work[i].cbf[1][e] = r->cbf[2][e]; work[i].ts[0][e] = r->tskip[1][e]; work[i].ts[1][e] = r->tskip[2][e]; }
+  for (int e = t; e < parts; e += nt) { work[i].cbf[0][e] = r->cbf[1][e]; work[i].cbf[1][e] = r->cbf[2][e]; work[i].ts[0][e] = r->tskip[1][e]; work[i].ts[1][e] = r->tskip[2][e]; }
   for (int comp = 1; comp <= 2; comp++) {
-    for (int e = t; e < (int)h2; e += 64) {                            // chroma level e of the CU layout: partition e / 4; its block starts at the first partition of the chroma TU
+    for (int e = t; e < (int)h2; e += nt) {                            // chroma level e of the CU layout: partition e / 4; its block starts at the first partition of the chroma TU
       const int p = e >> 2, d = r->tr_idx[p], log2 = k.log2_cu - d, dd = log2 == 2 ? d - 1 : d, np = parts >> (2 * dd), first = p - p % np;
       coef_out[(size_t)i * (cu2 + 2 * h2) + cu2 + (size_t)(comp - 1) * h2 + e] = coef[rqt_coef_at(k, i, k.log2_max_tu - log2, comp, first) + (size_t)(e - 4 * first)];
     }
     const int16_t* pic = (comp == 1 ? rec_cb : rec_cr) + (size_t)(jobs[i].y >> 1) * pitch + (jobs[i].x >> 1);
-    for (int e = t; e < (int)h2; e += 64) { const int rr = e / half, cc = e % half; reco_out[(size_t)i * 2 * h2 + (size_t)(comp - 1) * h2 + e] = pic[(size_t)rr * pitch + cc]; }
+    for (int e = t; e < (int)h2; e += nt) { const int rr = e / half, cc = e % half; reco_out[(size_t)i * 2 * h2 + (size_t)(comp - 1) * h2 + e] = pic[(size_t)rr * pitch + cc]; }
   }
 }
+__global__ __launch_bounds__(64) void k_ic_keep(RqtClass k, const hop_rqt_job* __restrict__ jobs, int n, const hop_rqt_result* __restrict__ res, IcWork* __restrict__ work,
+                                                const int32_t* __restrict__ coef, const int16_t* __restrict__ rec_cb, const int16_t* __restrict__ rec_cr, int pitch,
+                                                int32_t* __restrict__ coef_out, int16_t* __restrict__ reco_out) {
+  ic_keep_body(blockIdx.x, threadIdx.x, 64, k, jobs, res, work, coef, rec_cb, rec_cr, pitch, coef_out, reco_out);
+}
 
-__global__ __launch_bounds__(64) void k_ic_commit(RqtClass k, int n, const IcWork* __restrict__ work, hop_rqt_result* __restrict__ res, hop_intra_chroma_result* __restrict__ cres,
-                                                  hop_intra_cu_syntax* __restrict__ syn_update) {
-  const int i = blockIdx.x, t = threadIdx.x;
+__device__ static inline void ic_commit_body(const int i, const int t, const int nt, const RqtClass& k, const IcWork* work, hop_rqt_result* res, hop_intra_chroma_result* cres,
+                                             hop_intra_cu_syntax* syn_update) {
   const int parts = 1 << (2 * (k.log2_cu - 2));
-  for (int e = t; e < parts; e += 64) { res[i].cbf[1][e] = work[i].cbf[0][e]; res[i].cbf[2][e] = work[i].cbf[1][e]; res[i].tskip[1][e] = work[i].ts[0][e]; res[i].tskip[2][e] = work[i].ts[1][e]; }
+  for (int e = t; e < parts; e += nt) { res[i].cbf[1][e] = work[i].cbf[0][e]; res[i].cbf[2][e] = work[i].cbf[1][e]; res[i].tskip[1][e] = work[i].ts[0][e]; res[i].tskip[2][e] = work[i].ts[1][e]; }
   if (t == 0) {
     cres[i].best_mode = work[i].best_mode; cres[i].dist = work[i].best_dist;
     if (syn_update) { syn_update[i].chroma_is_dm = work[i].best_mode == 36; syn_update[i].chroma_dir = work[i].best_mode; }   // setChromIntraDirSubParts (:2779)
   }
+}
+__global__ __launch_bounds__(64) void k_ic_commit(RqtClass k, int n, const IcWork* __restrict__ work, hop_rqt_result* __restrict__ res, hop_intra_chroma_result* __restrict__ cres,
+                                                  hop_intra_cu_syntax* __restrict__ syn_update) {
+  ic_commit_body(blockIdx.x, threadIdx.x, 64, k, work, res, cres, syn_update);
 }
 
 size_t hop_intra_chroma_work_bytes(int log2_cu, int n) {
@@ -1365,14 +1472,9 @@ int hop_launch_intra_chroma_search(hop_ctx* c, int log2_cu, int log2_max_tu, int
 // intra rules (the split of an NxN CU inferred, the luma cbf always coded, scans by direction).  One lane per CU; cost = calcRdCost(bits, distortion).
 // =====================================================================================================================
 template <class LDS>
-__global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
-                                                       const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
-                                                       const hop_cabac_cu_ctx* __restrict__ cu_in, const uint32_t* __restrict__ dist, uint32_t* __restrict__ bits_out,
-                                                       double* __restrict__ cost_out, hop_cabac_ctx* __restrict__ ctx_out, hop_cabac_cu_ctx* __restrict__ cu_out,
-                                                       const uint16_t* __restrict__ scans) {
-  __shared__ LDS sh;
-  RQT_LANE_OR_BLOCK(n);
-  if (i >= n) return;
+__device__ static void intra_cu_total_body(LDS& sh, const int lane, const int i, const RqtClass& k, const hop_rqt_job* jobs, const hop_intra_cu_syntax* syn, const hop_rqt_result* res,
+                                           const int32_t* coef, const hop_cabac_ctx* ctx_in, const hop_cabac_cu_ctx* cu_in, const uint32_t* dist, uint32_t* bits_out, double* cost_out,
+                                           hop_cabac_ctx* ctx_out, hop_cabac_cu_ctx* cu_out, const uint16_t* scans) {
   const int ci = jobs[i].ctx_index;
   RQ_LOAD(ctx_in[ci]); IRQ_CU_LOAD(cu_in[ci]);
   const hop_intra_cu_syntax y = syn[i];
@@ -1431,6 +1533,17 @@ __global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const 
   if (cost_out) cost_out[i] = rqt_cost(bits, dist ? dist[i] : 0u, jobs[i].lambda_rd);
   if (ctx_out) rqt_store(sh, lane, frac, ctx_out + i);
   if (cu_out) IRQ_CU_STORE(cu_out[i]);
+}
+template <class LDS>
+__global__ __launch_bounds__(64) void k_intra_cu_total(RqtClass k, int n, const hop_rqt_job* __restrict__ jobs, const hop_intra_cu_syntax* __restrict__ syn,
+                                                       const hop_rqt_result* __restrict__ res, const int32_t* __restrict__ coef, const hop_cabac_ctx* __restrict__ ctx_in,
+                                                       const hop_cabac_cu_ctx* __restrict__ cu_in, const uint32_t* __restrict__ dist, uint32_t* __restrict__ bits_out,
+                                                       double* __restrict__ cost_out, hop_cabac_ctx* __restrict__ ctx_out, hop_cabac_cu_ctx* __restrict__ cu_out,
+                                                       const uint16_t* __restrict__ scans) {
+  __shared__ LDS sh;
+  RQT_LANE_OR_BLOCK(n);
+  if (i >= n) return;
+  intra_cu_total_body(sh, lane, i, k, jobs, syn, res, coef, ctx_in, cu_in, dist, bits_out, cost_out, ctx_out, cu_out, scans);
 }
 
 int hop_launch_intra_cu_total(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_min_tu, int sign_hide, int use_ts, int n, const hop_rqt_job* d_jobs, const hop_intra_cu_syntax* d_syn,

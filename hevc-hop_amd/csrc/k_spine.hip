@@ -273,7 +273,7 @@ class HipBackend : public BatchInner {
   void commit(int, int x, int y, int size) { on_device(); Tick t(8); const int32_t r[4] = { x, y, size, 0 }; BK(hop_ssref_commit_recon(c, 1, r)); }
 
   void pred_cost(int, int n, const hop_pred_job* jobs, int kind, uint32_t* out) { pred_cost_n(1, &n, jobs, &kind, out); }
-  // step k of every sequence in one predictor launch + one distortion launch; the steps in order; one synchronisation at the end
+  // every sequence walked in order by a workgroup of ONE launch (k_pred_cost); one synchronisation at the end
   void pred_cost_n(int m, const int* len, const hop_pred_job* jobs, const int* kinds, uint32_t* out) {
     on_device();
     int total = 0, maxlen = 0; for (int s = 0; s < m; s++) { total += len[s]; if (len[s] > maxlen) maxlen = len[s]; }
@@ -285,30 +285,22 @@ class HipBackend : public BatchInner {
       return;
     }
     Tick t(1);
-    hop_pred_job* pj = (hop_pred_job*)hin; hop_dist_job* dj = (hop_dist_job*)(hin + (((size_t)total * sizeof(hop_pred_job) + 255) & ~(size_t)255));   // pinned staging
-    std::vector<int> src(total), first(maxlen + 1, 0);
-    int at = 0;
-    for (int k = 0; k < maxlen; k++) {
-      first[k] = at;
-      for (int s = 0, base = 0; s < m; base += len[s], s++) {
-        if (len[s] <= k) continue;
-        const hop_pred_job& j = jobs[base + k];
-        pj[at] = j; dj[at].x = j.pu_x; dj[at].y = j.pu_y + j.dst_row_off; dj[at].w = j.w; dj[at].h = j.h; dj[at].comp = 0; dj[at].kind = kinds[s]; src[at] = base + k; at++;
-      }
-    }
-    first[maxlen] = at;
+    // the sequences as they are, one after the other; ONE launch rates them all (k_pred_cost: a workgroup walks its sequence in order)
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t h_first = al((size_t)total * sizeof(hop_pred_job)), h_kinds = h_first + al((size_t)(m + 1) * 4), h_bytes = h_kinds + al((size_t)m * 4);
+    if (h_bytes > io_bytes || h_bytes > (size_t)MAXP * (sizeof(hop_pred_job) + sizeof(hop_dist_job))) throw Bail{ HOP_ERR_ARG };
+    memcpy(hin, jobs, (size_t)total * sizeof(hop_pred_job));
+    int32_t* hf = (int32_t*)(hin + h_first); int32_t* hk = (int32_t*)(hin + h_kinds);
+    for (int s = 0, at = 0; s < m; at += len[s], s++) { hf[s] = at; hk[s] = kinds[s]; }
+    hf[m] = total;
     hipStream_t st = c->stream;
-    BH(hipMemcpyAsync(arena + o_pjobs, pj, total * sizeof(hop_pred_job), hipMemcpyHostToDevice, st));
-    BH(hipMemcpyAsync(arena + o_djobs, dj, total * sizeof(hop_dist_job), hipMemcpyHostToDevice, st));
-    for (int k = 0; k < maxlen; k++) {
-      const int nk = first[k + 1] - first[k];
-      BK(hop_pred_inter_device(c, nk, (const hop_pred_job*)(arena + o_pjobs) + first[k]));
-      BK(hop_distortion_device(c, nk, (const hop_dist_job*)(arena + o_djobs) + first[k], (uint32_t*)(arena + o_pout) + first[k]));
-    }
+    char* dj = arena + o_pjobs;                                          // (o_pjobs and o_djobs are adjacent: MAXP jobs of each)
+    BH(hipMemcpyAsync(dj, hin, h_bytes, hipMemcpyHostToDevice, st));
+    BK(hop_launch_pred_cost(c, m, (const int32_t*)(dj + h_first), (const hop_pred_job*)dj, (const int32_t*)(dj + h_kinds), (uint32_t*)(arena + o_pout)));
     uint32_t* o = (uint32_t*)hout;
     BH(hipMemcpyAsync(o, arena + o_pout, total * 4, hipMemcpyDeviceToHost, st));
     BH(hipStreamSynchronize(st));
-    for (int i = 0; i < total; i++) out[src[i]] = o[i];
+    memcpy(out, o, (size_t)total * 4);
   }
   void stash_n(int n, const int32_t* rect4, int restore) { on_device(); Tick t(7); BK(hop_recon_stash(c, n, rect4, restore)); }
   void commit_n(int n, const int32_t* rect4) { on_device(); Tick t(8); BK(hop_ssref_commit_recon(c, n, rect4)); }

@@ -1,0 +1,398 @@
+// k_walk.inl -- candidate evaluations as ONE kernel per candidate (included by k_cabac.hip after k_leaf_fused.inl and k_rqt.inl, whose device bodies it calls).
+//
+// The batch-step orchestration of k_rqt.inl lets the HOST walk a candidate's transform tree and launches a few small kernels per node, each over all candidates of the
+// batch: right for batches of thousands of candidates (the node's kernels are wide), wrong for the RD spine (host/hop_spine.cpp), whose batches hold ONE candidate per CTU
+// in flight and whose time is the length of the dependent launch chain -- about 100 launches for an SS/GT candidate, 250 for an intra candidate, each with one working lane.
+// Here a WORKGROUP takes its candidate through the whole evaluation: the tree is walked on the device (the same recursion, the same node descriptors, the same order), the
+// per-node stages are the bodies of the batch kernels called one after the other with workgroup barriers in between, and everything a candidate needs stays where the batch
+// form keeps it (per-candidate work areas in HBM, indexed by the candidate), so the results are the batch form's by construction.
+//   k_inter_walk   TEncSearch::encodeResAndCalcRdInterCU of a candidate whose prediction is in the prediction picture (TLibEncoder/TEncSearch.cpp:6622-6822): xEstimateResidualQT
+//                  (:6824-7560) = rqt_init / begin / leaf / single / close / final, the root-cbf-zero test and the reconstruction (:6700-6723, :6804-6812) = fin_*, the CU's
+//                  syntax bits (xAddSymbolBitsInter :7779-7810) = cu_bits, calcRdCost
+// (the intra candidate walk follows the same scheme)
+
+struct InterWalk {
+  RqtClass k; int n, bd_y, bd_c; hop_pics pic;
+  const hop_rqt_job* jobs; const hop_cu_syntax* syn; const hop_cabac_ctx* ctx_in; const hop_cabac_cu_ctx* cu_in;
+  hop_rqt_result* res; int32_t* coef_out; hop_cabac_ctx* ctx_after; hop_cu_final* fin; uint32_t* bits; uint32_t* skipped; double* cost; hop_cabac_ctx* ctx_out; hop_cabac_cu_ctx* cu_out;
+  // the quadtree's state (rqt_run_class)
+  hop_cabac_ctx* cur; hop_cabac_ctx* root[4]; hop_cabac_ctx* test[4]; RqtWork* work; hop_tu_rd_job* tuj; hop_tu_rd_job* tuj2; int64_t* off; int64_t* off2;
+  hop_tu_rd_result* tr; hop_tu_rd_result* tr2; int32_t* coef; size_t n_coeff, ts_base;
+  // the leaf step's scratch (hop_launch_tu_rd_fused): one slot per transform unit of a node, 3 per candidate
+  int32_t* lcoef; uint32_t* zs; uint32_t* ns; uint32_t* as; unsigned long long* fr; hop_rdoq_job* rq; hop_coeff_bits_job* cb; char* lwork;
+  // the wrapper's tail (hop_launch_rqt_finish)
+  int d0, d1, nj; hop_tu_rd_job* ftuj; int64_t* foff; uint32_t* faf; uint32_t* fsse;
+  const int32_t* entropy_bits; const uint16_t* scans; int16_t* rec_y; int16_t* rec_cb; int16_t* rec_cr;
+};
+
+__device__ static inline RqtNode walk_rqt_node(const RqtClass& k, int parts, int part, int d, int log2, int zero_open) {      // as Rec::go of rqt_run_class
+  RqtNode nd; nd.part = part; nd.d = d; nd.log2 = log2;
+  nd.check_full = (k.inter_split && d == 0 && log2 > k.log2_min_tu) ? 0 : (log2 <= k.log2_max_tu);
+  nd.check_split = log2 > k.log2_min_tu;
+  nd.code_chroma = 1;
+  if (log2 == 2) nd.code_chroma = (part % (parts >> (2 * (d - 1)))) == 0;
+  nd.add_zero = zero_open && nd.check_full;
+  nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
+  nd.ts_c = (k.use_ts && nd.check_full && nd.code_chroma && (log2 == 2 || log2 == 3)) ? 1 : 0;
+  return nd;
+}
+
+// the inverse path in reconstruction mode over a candidate's table of nj jobs (hop_launch_tu_recon): the large transform units one after the other on the whole workgroup,
+// the 4x4 / 8x8 ones a wave each
+__device__ static void walk_recon_jobs(LeafShared& L, const int first, const int nj, const int total, const hop_tu_rd_job* jobs, hop_pics pic, const int64_t* off, const int32_t* levels,
+                                       const uint32_t* abs_flag, uint32_t* sse, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int q = 0; q < nj; q++) {
+    if (jobs[first + q].log2_size <= 3) continue;                      // (uniform over the workgroup)
+    turd_inverse_body(L.t.big, first + q, jobs, pic, off, levels, abs_flag, sse, rec_y, rec_cb, rec_cr);
+    __syncthreads();
+  }
+  for (int q0 = 0; q0 < nj; q0 += 4) {
+    const int q = q0 + wave;
+    if (q < nj) turd_inverse_small_body(L.t.small, wave, lane, first + q, jobs, total, pic, off, levels, abs_flag, sse, rec_y, rec_cb, rec_cr);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_inter_walk(InterWalk A) {
+  __shared__ LeafShared L;
+  __shared__ CabacLds1 sh1;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const RqtClass k = A.k;
+  const int parts = 1 << (2 * (k.log2_cu - 2));
+  if (tid == 0) rqt_init_body(i, A.jobs, A.ctx_in, A.cur, A.work, A.res);
+  __syncthreads();
+  // ---- xEstimateResidualQT: the reference's recursion (rqt_run_class), node by node ----
+  int s_part[4], s_log2[4], s_zero[4], s_child[4];
+  int sp = 0;
+  s_part[0] = 0; s_log2[0] = k.log2_cu; s_zero[0] = 1; s_child[0] = -1;
+  while (sp >= 0) {
+    const int d = sp;
+    const RqtNode nd = walk_rqt_node(k, parts, s_part[sp], d, s_log2[sp], s_zero[sp]);
+    if (s_child[sp] < 0) {                                               // entering the node
+      // The batch form keeps a node's transform units at [ncomp * candidate + component] (every candidate is at the same node); here candidates are at different nodes at any
+      // moment, so every candidate owns three fixed slots of the job / result / scratch tables: the tables are handed to the bodies shifted so that their index lands there
+      const int ncomp = nd.code_chroma ? 3 : 1, nts = nd.ts_y + 2 * nd.ts_c;
+      const ptrdiff_t sh_c = (ptrdiff_t)(3 - ncomp) * i, sh_t = (ptrdiff_t)(3 - nts) * i;
+      if (tid == 0) rqt_begin_body(i, k, nd, A.jobs, A.bd_y, A.bd_c, A.cur, A.root[d], A.res, A.work, A.tuj + sh_c, A.off + sh_c, A.tuj2 + sh_t, A.off2 + sh_t, A.ts_base);
+      __syncthreads();
+      if (nd.check_full) {
+        for (int c = 0; c < ncomp; c++) {
+          turd_fused_body(L, 3 * i + c, A.tuj, 3 * A.n, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr,
+                          A.rec_y, A.rec_cb, A.rec_cr);
+          __syncthreads();
+        }
+        for (int t = 0; t < nts; t++) {
+          turd_fused_body(L, 3 * i + t, A.tuj2, 3 * A.n, A.pic, A.root[d], A.off2, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr2,
+                          A.rec_y, A.rec_cb, A.rec_cr);
+          __syncthreads();
+        }
+        if (tid == 0) rqt_single_body(sh1, 0, i, k, nd, A.jobs, A.cur, A.root[d], A.test[d], A.res, A.work, A.tr + sh_c, A.tr2 + sh_t, A.coef, A.ts_base, A.scans);
+        __syncthreads();
+      }
+      if (!nd.check_split) { sp--; continue; }
+      s_child[sp] = 0;
+    }
+    if (s_child[sp] < 4) {
+      const int q = (parts >> (2 * d)) >> 2, kk = s_child[sp]++;
+      s_part[sp + 1] = s_part[sp] + kk * q; s_log2[sp + 1] = s_log2[sp] - 1; s_zero[sp + 1] = s_zero[sp] && !nd.check_full; s_child[sp + 1] = -1;
+      sp++;
+      continue;
+    }
+    if (tid == 0) rqt_close_body(sh1, 0, i, k, nd, A.jobs, A.cur, A.root[d], A.test[d], A.res, A.work, A.coef, A.scans);
+    __syncthreads();
+    sp--;
+  }
+  rqt_final_body(i, tid, 256, k, A.work, A.res, A.coef, A.coef_out, A.cur, A.ctx_after);
+  __syncthreads();
+  // ---- the wrapper's tail: root-cbf-zero test, the reconstruction and its distortion ----
+  if (tid == 0) fin_decide_body(i, k, A.jobs, A.ctx_after, A.entropy_bits, A.res, A.fin);
+  __syncthreads();
+  fin_zero_body(i, tid, 256, k, A.fin, A.coef_out);
+  if (tid == 0) fin_emit_body(i, k, A.jobs, A.bd_y, A.bd_c, A.d0, A.d1, A.nj, A.res, A.fin, A.ftuj, A.foff, A.faf);
+  __syncthreads();
+  walk_recon_jobs(L, i * A.nj, A.nj, A.n * A.nj, A.ftuj, A.pic, A.foff, A.coef_out, A.faf, A.fsse, A.rec_y, A.rec_cb, A.rec_cr);
+  if (tid == 0) {
+    fin_sum_body(i, A.jobs, A.nj, A.ftuj, A.fsse, A.fin);
+    // ---- the CU's syntax bits from the CI_CURR_BEST state, the cost ----
+    cu_bits_body(sh1, 0, i, k, A.jobs, A.syn, A.res, A.coef_out, A.ctx_in, A.cu_in, A.bits, A.skipped, A.ctx_out, A.cu_out, A.scans);
+    A.cost[i] = rqt_cost(A.bits[i], A.fin[i].dist[0] + A.fin[i].dist[1] + A.fin[i].dist[2], A.jobs[i].lambda_rd);
+  }
+}
+
+size_t hop_inter_walk_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n) {
+  const size_t cu2 = (size_t)1 << (2 * log2_cu), n_coeff = (size_t)n * (6 * cu2 + 48);
+  int d0, d1; const int nj = rqt_jobs_per_cu(log2_cu, log2_max_tu, log2_min_tu, &d0, &d1);
+  return hop_rqt_work_bytes(log2_cu, n) + (size_t)n * nj * (sizeof(hop_tu_rd_job) + 8 + 4 + 4) + n_coeff * 4 +
+         (size_t)3 * n * (4 * 4 + 8 + sizeof(hop_rdoq_job) + sizeof(hop_coeff_bits_job) + LEAF_WORK_PER_TU) + 64 * 256;
+}
+
+// n candidates of one class through k_inter_walk; every pointer a device pointer; buf = hop_inter_walk_bytes
+int hop_launch_inter_walk(hop_ctx* c, const hop_rqt_job* cls, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syn, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,
+                          hop_rqt_result* d_res, int32_t* d_coef, hop_cabac_ctx* d_ctx_after, hop_cu_final* d_fin, uint32_t* d_bits, uint32_t* d_skipped, double* d_cost,
+                          hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out, void* vbuf, size_t buf_bytes) {
+  InterWalk A; memset(&A, 0, sizeof(A));
+  RqtClass& k = A.k;
+  k.log2_cu = cls->log2_cu; k.log2_max_tu = cls->log2_max_tu; k.log2_min_tu = cls->log2_min_tu_in_cu; k.inter_split = cls->inter_split_flag ? 1 : 0; k.sign_hide = cls->sign_hide ? 1 : 0;
+  k.use_ts = cls->use_ts ? 1 : 0;
+  A.n = n; A.bd_y = c->bd_y; A.bd_c = c->bd_c; A.pic = hop_make_pics(c);
+  A.jobs = d_jobs; A.syn = d_syn; A.ctx_in = d_ctx_in; A.cu_in = d_cu_in; A.res = d_res; A.coef_out = d_coef; A.ctx_after = d_ctx_after; A.fin = d_fin; A.bits = d_bits; A.skipped = d_skipped;
+  A.cost = d_cost; A.ctx_out = d_ctx_out; A.cu_out = d_cu_out;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  A.n_coeff = (size_t)n * (6 * cu2 + 48); A.ts_base = (size_t)n * 6 * cu2;
+  char* buf = (char*)vbuf; size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
+  A.cur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx));
+  for (int d = 0; d < 4; d++) { A.root[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.test[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); }
+  A.work = (RqtWork*)take((size_t)n * sizeof(RqtWork));
+  A.tuj = (hop_tu_rd_job*)take((size_t)3 * n * sizeof(hop_tu_rd_job)); A.tuj2 = (hop_tu_rd_job*)take((size_t)3 * n * sizeof(hop_tu_rd_job));
+  A.off = (int64_t*)take((size_t)3 * n * 8); A.off2 = (int64_t*)take((size_t)3 * n * 8);
+  A.tr = (hop_tu_rd_result*)take((size_t)3 * n * sizeof(hop_tu_rd_result)); A.tr2 = (hop_tu_rd_result*)take((size_t)3 * n * sizeof(hop_tu_rd_result));
+  A.coef = (int32_t*)take(A.n_coeff * 4);
+  A.lcoef = (int32_t*)take(A.n_coeff * 4);
+  A.zs = (uint32_t*)take((size_t)3 * n * 4); A.ns = (uint32_t*)take((size_t)3 * n * 4); A.as = (uint32_t*)take((size_t)3 * n * 4); A.fr = (unsigned long long*)take((size_t)3 * n * 8);
+  A.rq = (hop_rdoq_job*)take((size_t)3 * n * sizeof(hop_rdoq_job)); A.cb = (hop_coeff_bits_job*)take((size_t)3 * n * sizeof(hop_coeff_bits_job));
+  A.lwork = take((size_t)3 * n * LEAF_WORK_PER_TU);
+  A.nj = rqt_jobs_per_cu(k.log2_cu, k.log2_max_tu, k.log2_min_tu, &A.d0, &A.d1);
+  const size_t nt = (size_t)n * A.nj;
+  A.ftuj = (hop_tu_rd_job*)take(nt * sizeof(hop_tu_rd_job)); A.foff = (int64_t*)take(nt * 8); A.faf = (uint32_t*)take(nt * 4); A.fsse = (uint32_t*)take(nt * 4);
+  if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "inter walk: work buffer too small");
+  A.entropy_bits = hop_entropy_bits_device(c); A.scans = c->rdoq_scans; A.rec_y = c->rec[0]; A.rec_cb = c->rec[1]; A.rec_cr = c->rec[2];
+  const int pr = hop_prof_begin(c, HOP_K_WALK_INTER + (k.log2_cu - 3), (uint64_t)n);
+  hipLaunchKernelGGL(k_inter_walk, dim3(n), dim3(256), 0, c->stream, A);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "inter walk launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}
+
+// =====================================================================================================================
+// k_intra_walk: the body of TEncCu::xCheckRDCostIntra for one candidate CU (TLibEncoder/TEncCu.cpp:1455-1507) = hop_launch_intra_search (estIntraPredQT with bLumaOnly,
+// TEncSearch.cpp:2386-2710, over hop_launch_intra_rqt = xRecurIntraCodingQT :1361-1710) -> hop_launch_intra_chroma_search (estIntraPredChromaQT :2720-2785) ->
+// getTotalDistortion -> hop_launch_intra_cu_total (the CU's bits, calcRdCost), every stage the batch form's body.  The chroma walk visits only the nodes the CU's own luma
+// tree has (the batch form visits every node a tree of the class can have and lets the CUs without a transform unit there sit the step out: the same work).
+// =====================================================================================================================
+struct IntraWalk {
+  RqtClass k; int n, nxn, num_full_rd, bd_y, bd_c; hop_pics pic;
+  const hop_rqt_job* jobs; const hop_intra_cu_syntax* syn_in; const hop_intra_rqt_opt* opt; const hop_intra_search_job* sj; const hop_cabac_ctx* ctx_in; const hop_cabac_cu_ctx* cu_in;
+  hop_intra_search_result* sres; hop_rqt_result* res; hop_intra_chroma_result* cres; int32_t* coef_out; int16_t* reco_y; int16_t* reco_c; hop_intra_cu_syntax* syn_out;
+  uint32_t* dist; uint32_t* bits; double* cost; hop_cabac_ctx* ctx_out; hop_cabac_cu_ctx* cu_out;
+  // the luma search (hop_launch_intra_search)
+  hop_intra_cu_syntax* syn; hop_intra_job* rj; hop_intra_modes_job* mj; hop_intra_modes_result* mres; uint32_t* satd; IsWork* iswork; hop_rqt_result* tmp; int32_t* coef_tmp; uint8_t* active;
+  // the luma tree of one pass (hop_launch_intra_rqt)
+  hop_cabac_ctx* cur; hop_cabac_cu_ctx* cucur; hop_cabac_ctx* root[4]; hop_cabac_cu_ctx* curoot[4]; hop_cabac_ctx* test[4]; hop_cabac_cu_ctx* cutest[4]; IrqWork* irwork;
+  hop_intra_job* pj; int32_t* modes; hop_tu_rd_job* tuj; hop_tu_rd_job* tuj2; int64_t* off; int64_t* off2; hop_tu_rd_result* tr; hop_tu_rd_result* tr2; int32_t* coef;
+  int16_t* recl; int16_t* park; size_t n_coeff, ts_base;
+  // the chroma search (hop_launch_intra_chroma_search)
+  hop_cabac_ctx* ccur; hop_cabac_ctx* croot; hop_intra_cu_syntax* csyn; IcWork* icwork; int32_t* ccoef; int16_t* cpark;
+  // the leaf step's scratch: one transform unit per candidate at a time
+  int32_t* lcoef; uint32_t* zs; uint32_t* ns; uint32_t* as; unsigned long long* fr; hop_rdoq_job* rq; hop_coeff_bits_job* cb; char* lwork;
+  const int32_t* entropy_bits; const uint16_t* scans; int16_t* rec_y; int16_t* rec_cb; int16_t* rec_cr;
+};
+union WalkShared { LeafShared leaf; IntraShared intra; };
+
+#define IW_LEAF(JOBS, CTX, OFF, LEVELS, RES) turd_fused_body(L.leaf, i, JOBS, A.n, A.pic, CTX, OFF, A.entropy_bits, A.scans, A.lcoef, LEVELS, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, RES, \
+                                                             A.rec_y, A.rec_cb, A.rec_cr)
+
+// one pass of xRecurIntraCodingQT over the PU (hop_launch_intra_rqt with the pass's direction in syn): results into A.tmp / A.coef_tmp
+__device__ static void walk_intra_rqt(const IntraWalk& A, WalkShared& L, CabacLds1& sh1, const int i, const int tr_depth0, const int check_first) {
+  const int tid = threadIdx.x;
+  const RqtClass k = A.k;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), pitch = A.pic.pic_w;
+  if (tid == 0) irqt_init_body(i, A.jobs, A.ctx_in, A.cu_in, A.cur, A.cucur, A.irwork, A.tmp);
+  __syncthreads();
+  int s_rel[4], s_child[4];
+  int sp = 0;
+  s_rel[0] = 0; s_child[0] = -1;
+  while (sp >= 0) {
+    const int d = tr_depth0 + sp, log2 = k.log2_cu - d;
+    RqtNode nd; nd.part = s_rel[sp]; nd.d = d; nd.log2 = log2; nd.code_chroma = 0; nd.add_zero = 0; nd.ts_c = 0;
+    nd.check_full = log2 <= k.log2_max_tu;
+    nd.check_split = log2 > k.log2_min_tu && !(check_first && nd.check_full);
+    nd.ts_y = (k.use_ts && nd.check_full && log2 == 2) ? 1 : 0;
+    if (s_child[sp] < 0) {
+      if (tid == 0) irqt_begin_body(i, k, nd, A.jobs, A.syn, A.opt, A.bd_y, A.cur, A.cucur, A.root[d], A.curoot[d], A.tmp, A.irwork, A.pj, A.modes, A.tuj, A.off, A.tuj2, A.off2, A.ts_base, nullptr);
+      __syncthreads();
+      if (nd.check_full) {
+        intra_pred_body(L.intra, A.pj + i, A.modes[i], A.pic, A.rec_y);
+        __syncthreads();
+        if (nd.ts_y) {
+          IW_LEAF(A.tuj2, A.root[d], A.off2, A.coef, A.tr2);
+          __syncthreads();
+          irqt_copy_body(i, tid, 256, 1, k, nd, A.jobs, A.syn, A.irwork, A.rec_y, pitch, A.recl, A.park, nullptr);
+          __syncthreads();
+        }
+        IW_LEAF(A.tuj, A.root[d], A.off, A.coef, A.tr);
+        __syncthreads();
+        if (nd.check_split) { irqt_copy_body(i, tid, 256, 0, k, nd, A.jobs, A.syn, A.irwork, A.rec_y, pitch, A.recl, A.park, nullptr); __syncthreads(); }
+        if (tid == 0) irqt_single_body(sh1, 0, i, k, nd, A.jobs, A.syn, A.opt, A.cur, A.cucur, A.root[d], A.curoot[d], A.test[d], A.cutest[d], A.tmp, A.irwork, A.tr, A.tr2, A.coef, A.ts_base,
+                                       A.rec_y, pitch, A.park, A.scans, nullptr);
+        __syncthreads();
+      }
+      if (!nd.check_split) { sp--; continue; }
+      s_child[sp] = 0;
+    }
+    if (s_child[sp] < 4) {
+      const int q = (parts >> (2 * d)) >> 2, kk = s_child[sp]++;
+      s_rel[sp + 1] = s_rel[sp] + kk * q; s_child[sp + 1] = -1;
+      sp++;
+      continue;
+    }
+    if (tid == 0) irqt_close_body(sh1, 0, i, k, nd, A.jobs, A.syn, A.cur, A.cucur, A.root[d], A.curoot[d], A.test[d], A.cutest[d], A.tmp, A.irwork, A.coef, A.scans, nullptr);
+    __syncthreads();
+    if (nd.check_full) { irqt_copy_body(i, tid, 256, 2, k, nd, A.jobs, A.syn, A.irwork, A.rec_y, pitch, A.recl, A.park, nullptr); __syncthreads(); }
+    sp--;
+  }
+  irqt_final_body(i, tid, 256, k, tr_depth0, A.syn, A.irwork, A.tmp, A.coef, A.coef_tmp, A.cur, A.cucur, nullptr, nullptr, nullptr);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_intra_walk(IntraWalk A) {
+  __shared__ WalkShared L;
+  __shared__ CabacLds1 sh1;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const RqtClass k = A.k;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), pitch = A.pic.pic_w, pitch_c = A.pic.pic_w >> 1;
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  // ---- the luma search: estIntraPredQT, PU after PU ----
+  if (tid == 0) A.syn[i] = A.syn_in[i];
+  { uint32_t* z = (uint32_t*)(A.res + i); for (int e = tid; e < (int)(sizeof(hop_rqt_result) / 4); e += 256) z[e] = 0; }
+  __syncthreads();
+  const int npu = A.nxn ? 4 : 1, n_max = A.num_full_rd + 2;
+  for (int pu = 0; pu < npu; pu++) {
+    if (tid == 0) is_prep_body(i, k, pu, A.nxn, A.jobs, A.sj, A.opt, A.ctx_in, A.cu_in, A.sres, A.syn, A.rj, A.mj, A.iswork);
+    __syncthreads();
+    intra_rough_body(L.intra, A.rj + i, A.pic, A.rec_y, A.satd + (size_t)i * 35);
+    __syncthreads();
+    if (tid == 0) intra_modes_body(i, A.mj, A.satd, A.mres);
+    __syncthreads();
+    for (int pass = 0; pass <= n_max; pass++) {
+      if (tid == 0) is_pick_body(i, pu, pass, n_max, A.mres, A.iswork, A.syn, A.active);
+      __syncthreads();
+      if (!A.active[i]) continue;                                        // this CU's list is shorter (uniform over the workgroup)
+      walk_intra_rqt(A, L, sh1, i, A.nxn, pass < n_max ? 1 : 0);
+      is_keep_body(i, tid, 256, k, pu, A.nxn, pass, n_max, A.jobs, A.mres, A.syn, A.tmp, A.coef_tmp, A.rec_y, pitch, A.iswork, A.coef_out, A.reco_y);
+      __syncthreads();
+    }
+    is_commit_body(i, tid, 256, k, pu, A.nxn, A.jobs, A.iswork, A.mres, A.syn, A.res, A.sres, A.rec_y, pitch, A.reco_y);
+    __syncthreads();
+  }
+  if (tid == 0) { A.syn_out[i] = A.syn[i]; A.csyn[i] = A.syn[i]; }
+  // ---- the chroma search: estIntraPredChromaQT along the luma tree just decided ----
+  { int32_t* z = A.ccoef + (size_t)i * 6 * cu2; for (size_t e = tid; e < 6 * cu2; e += 256) z[e] = 0; if (tid < 16) A.ccoef[A.ts_base + (size_t)i * 16 + tid] = 0; }
+  __syncthreads();
+  const hop_rqt_result* r = A.res + i;
+  for (int m = 0; m < 5; m++) {
+    if (tid == 0) ic_mode_body(i, m, A.jobs, A.ctx_in, A.ccur, A.csyn, A.icwork);
+    __syncthreads();
+    int s_part[4], s_child[4];
+    int sp = 0;
+    s_part[0] = 0; s_child[0] = -1;
+    while (sp >= 0) {
+      const int d = sp, log2 = k.log2_cu - d, part = s_part[sp];
+      RqtNode nd; nd.part = part; nd.d = d; nd.log2 = log2; nd.code_chroma = 0; nd.add_zero = 0; nd.ts_c = 0; nd.ts_y = 0; nd.check_full = 0; nd.check_split = 0;
+      const int tr = r->tr_idx[part];
+      if (s_child[sp] < 0) {
+        if (tr == d && log2 <= k.log2_max_tu && !(log2 == 2 && (part & 3))) {       // a transform unit of this CU sits here (ic_leaf_here)
+          const bool may_ts = k.use_ts && log2 <= 3;
+          for (int comp = 1; comp <= 2; comp++) {
+            if (tid == 0) ic_begin_body(i, k, nd, comp, A.jobs, A.csyn, A.opt, A.bd_c, A.ccur, A.croot, A.res, A.icwork, A.pj, A.modes, A.tuj, A.off, A.tuj2, A.off2, A.ts_base);
+            __syncthreads();
+            if (comp == 1) {
+              intra_pred_chroma_body(L.intra, A.pj + i, A.modes[i], 1, A.pic, A.rec_cb, A.rec_cr);
+              __syncthreads();
+              intra_pred_chroma_body(L.intra, A.pj + i, A.modes[i], 2, A.pic, A.rec_cb, A.rec_cr);
+              __syncthreads();
+            }
+            int16_t* recc = comp == 1 ? A.rec_cb : A.rec_cr;
+            if (may_ts) {
+              IW_LEAF(A.tuj2, A.ccur, A.off2, A.ccoef, A.tr2);
+              __syncthreads();
+              if (tid < 16) ic_park_body(i, tid, k, nd, A.jobs, A.opt, A.res, recc, pitch_c, A.cpark);
+              __syncthreads();
+            }
+            IW_LEAF(A.tuj, A.ccur, A.off, A.ccoef, A.tr);
+            __syncthreads();
+            if (tid == 0) ic_single_body(sh1, 0, i, k, nd, comp, A.jobs, A.csyn, A.opt, A.ccur, A.croot, A.res, A.icwork, A.tr, A.tr2, A.ccoef, A.ts_base, recc, pitch_c, A.cpark, A.scans);
+            __syncthreads();
+          }
+        }
+        if (!(tr > d && log2 > k.log2_min_tu)) { sp--; continue; }                   // the tree goes no deeper here
+        s_child[sp] = 0;
+      }
+      if (s_child[sp] < 4) {
+        const int q = (parts >> (2 * d)) >> 2, kk = s_child[sp]++;
+        s_part[sp + 1] = part + kk * q; s_child[sp + 1] = -1;
+        sp++;
+        continue;
+      }
+      if (tid == 0) ic_fold_body(i, k, nd, A.res);
+      __syncthreads();
+      sp--;
+    }
+    if (tid == 0) ic_bits_body(sh1, 0, i, k, A.jobs, A.csyn, A.ctx_in, A.cu_in, A.res, A.icwork, A.ccoef, A.scans);
+    __syncthreads();
+    ic_keep_body(i, tid, 256, k, A.jobs, A.res, A.icwork, A.ccoef, A.rec_cb, A.rec_cr, pitch_c, A.coef_out, A.reco_c);
+    __syncthreads();
+  }
+  ic_commit_body(i, tid, 256, k, A.icwork, A.res, A.cres, A.syn_out);
+  __syncthreads();
+  // ---- getTotalDistortion, the CU's bits from the CI_CURR_BEST state, calcRdCost ----
+  if (tid == 0) {
+    A.dist[i] = A.sres[i].dist + A.cres[i].dist;
+    intra_cu_total_body(sh1, 0, i, k, A.jobs, A.syn_out, A.res, A.coef_out, A.ctx_in, A.cu_in, A.dist, A.bits, A.cost, A.ctx_out, A.cu_out, A.scans);
+  }
+}
+
+size_t hop_intra_walk_bytes(int log2_cu, int n) {
+  const size_t cu2 = (size_t)1 << (2 * log2_cu), n_coeff = (size_t)n * (6 * cu2 + 16);
+  return hop_intra_search_work_bytes(log2_cu, n) + hop_intra_chroma_work_bytes(log2_cu, n) + n_coeff * 4 +
+         (size_t)n * (4 * 4 + 8 + sizeof(hop_rdoq_job) + sizeof(hop_coeff_bits_job) + LEAF_WORK_PER_TU) + 96 * 256;
+}
+
+int hop_launch_intra_walk(hop_ctx* c, const hop_intra_class& q, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, void* vbuf, size_t buf_bytes) {
+  IntraWalk A; memset(&A, 0, sizeof(A));
+  const hop_rqt_job* cls = &q.cls;
+  RqtClass& k = A.k;
+  k.log2_cu = cls->log2_cu; k.log2_max_tu = cls->log2_max_tu; k.log2_min_tu = cls->log2_min_tu_in_cu; k.inter_split = 0; k.sign_hide = cls->sign_hide ? 1 : 0; k.use_ts = cls->use_ts ? 1 : 0;
+  const int n = q.n;
+  A.n = n; A.nxn = q.part_nxn ? 1 : 0; A.num_full_rd = q.num_full_rd; A.bd_y = c->bd_y; A.bd_c = c->bd_c; A.pic = hop_make_pics(c);
+  A.jobs = q.d_jobs; A.syn_in = q.d_syntax; A.opt = q.d_opts; A.sj = q.d_sjobs; A.ctx_in = d_ctx_in; A.cu_in = d_cu_in;
+  A.sres = q.d_sresults; A.res = q.d_results; A.cres = q.d_cresults; A.coef_out = q.d_coef; A.reco_y = q.d_reco_y; A.reco_c = q.d_reco_c; A.syn_out = q.d_syntax_out;
+  A.dist = q.d_dist; A.bits = q.d_bits; A.cost = q.d_cost; A.ctx_out = q.d_ctx_out; A.cu_out = q.d_cu_ctx_out;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
+  A.n_coeff = (size_t)n * (6 * cu2 + 16); A.ts_base = (size_t)n * 6 * cu2;
+  char* buf = (char*)vbuf; size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
+  A.syn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax)); A.rj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job));
+  A.mj = (hop_intra_modes_job*)take((size_t)n * sizeof(hop_intra_modes_job)); A.mres = (hop_intra_modes_result*)take((size_t)n * sizeof(hop_intra_modes_result));
+  A.satd = (uint32_t*)take((size_t)n * 35 * 4); A.iswork = (IsWork*)take((size_t)n * sizeof(IsWork)); A.tmp = (hop_rqt_result*)take((size_t)n * sizeof(hop_rqt_result));
+  A.coef_tmp = (int32_t*)take((size_t)n * (cu2 + (cu2 >> 1)) * 4); A.active = (uint8_t*)take((size_t)n);
+  A.cur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.cucur = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx));
+  for (int d = 0; d < 4; d++) {
+    A.root[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.curoot[d] = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx));
+    A.test[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.cutest[d] = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx));
+  }
+  A.irwork = (IrqWork*)take((size_t)n * sizeof(IrqWork)); A.pj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job)); A.modes = (int32_t*)take((size_t)n * 4);
+  A.tuj = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job)); A.tuj2 = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job));
+  A.off = (int64_t*)take((size_t)n * 8); A.off2 = (int64_t*)take((size_t)n * 8);
+  A.tr = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result)); A.tr2 = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result));
+  A.coef = (int32_t*)take(A.n_coeff * 4); A.recl = (int16_t*)take((size_t)n * 4 * cu2 * 2); A.park = (int16_t*)take((size_t)n * 32);
+  A.ccur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.croot = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx));
+  A.csyn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax)); A.icwork = (IcWork*)take((size_t)n * sizeof(IcWork));
+  A.ccoef = (int32_t*)take(A.n_coeff * 4); A.cpark = (int16_t*)take((size_t)n * 32);
+  A.lcoef = (int32_t*)take(A.n_coeff * 4);
+  A.zs = (uint32_t*)take((size_t)n * 4); A.ns = (uint32_t*)take((size_t)n * 4); A.as = (uint32_t*)take((size_t)n * 4); A.fr = (unsigned long long*)take((size_t)n * 8);
+  A.rq = (hop_rdoq_job*)take((size_t)n * sizeof(hop_rdoq_job)); A.cb = (hop_coeff_bits_job*)take((size_t)n * sizeof(hop_coeff_bits_job));
+  A.lwork = take((size_t)n * LEAF_WORK_PER_TU);
+  if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra walk: work buffer too small (%zu > %zu)", o, buf_bytes);
+  A.entropy_bits = hop_entropy_bits_device(c); A.scans = c->rdoq_scans; A.rec_y = c->rec[0]; A.rec_cb = c->rec[1]; A.rec_cr = c->rec[2];
+  const int pr = hop_prof_begin(c, A.nxn ? HOP_K_WALK_INTRA_NXN : HOP_K_WALK_INTRA + (k.log2_cu - 3), (uint64_t)n);
+  hipLaunchKernelGGL(k_intra_walk, dim3(n), dim3(256), 0, c->stream, A);
+  hop_prof_end(c, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra walk launch: %s", hipGetErrorString(e));
+  return HOP_OK;
+}

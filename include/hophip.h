@@ -553,8 +553,8 @@ int hop_inter_cu_skip_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, con
                              hop_cu_final* d_finals, uint32_t* d_bits, double* d_cost, hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_ctx_out);   /* asynchronous, unchecked */
 /* ---- whole SS/GT candidates with residual, device-resident (rows a0 / a8b) ---- */
 /* TEncSearch::encodeResAndCalcRdInterCU without bSkipRes (TLibEncoder/TEncSearch.cpp:6670-6822) for several classes of CUs at once, no host step between the stages: per
- * class hop_rqt_device -> hop_rqt_finish_device -> hop_inter_cu_bits_device -> getTotalCost = calcRdCost(bits, final distortions); the classes on separate streams; a call
- * that repeats is replayed as a HIP graph (see hop_intra_cu_device_classes).  The prediction picture holds the candidates' predictions.  All pointers device memory except
+ * class hop_rqt_device -> hop_rqt_finish_device -> hop_inter_cu_bits_device -> getTotalCost = calcRdCost(bits, final distortions); the classes on separate streams (small batches: one kernel per candidate, see
+ * hop_intra_cu_device_classes).  The prediction picture holds the candidates' predictions.  All pointers device memory except
  * the descriptor array; d_ctx_after: scratch for the coder after the quadtree (n states).  Asynchronous, unchecked beyond the class fields. */
 typedef struct {
   int32_t n, pad;
@@ -582,9 +582,9 @@ typedef struct {
   hop_cabac_ctx* d_ctx_out; hop_cabac_cu_ctx* d_cu_ctx_out;   /* may be NULL */
 } hop_intra_class;
 int hop_intra_cu_device_classes(hop_ctx* ctx, int n_classes, const hop_intra_class* classes, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in);
-/* A call that repeats (same descriptors, same buffers) is captured into a HIP graph the second time it is seen and replayed from then on (HOP_GRAPHS=0 turns that off).
- * Diagnostics: how many calls of this context were served by a graph launch. */
-long hop_graph_replays(hop_ctx* ctx);
+/* Batches of up to HOP_WALK candidates (default 4096: the RD spine's batches hold one candidate per CTU in flight) run as ONE kernel per candidate -- a workgroup walks its
+ * candidate's transform tree on the device (csrc/k_walk.inl: the bodies of the batch-step kernels called in the same order) --, larger batches as batch steps over all
+ * candidates, a few kernels per tree node (csrc/k_rqt.inl).  Both forms give the same bytes (tests/test_gpu_tq_intra.py runs both). */
 /* device-resident form, one class of CUs as in hop_rqt_device; asynchronous, unchecked */
 int hop_inter_cu_bits_device(hop_ctx* ctx, int n, const hop_rqt_job* d_jobs, const hop_rqt_job* cls, const hop_cu_syntax* d_syntax, const hop_rqt_result* d_results,
                              const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_ctx_in, uint32_t* d_bits, uint32_t* d_skipped,
@@ -731,7 +731,10 @@ int hop_psnr(hop_ctx* ctx, uint64_t* ssd, double* psnr);
 #define HOP_K_CABAC     9
 #define HOP_K_DEBLOCK   10
 #define HOP_K_SAO       11
-#define HOP_K_COUNT     12
+#define HOP_K_WALK_INTER 12   /* + (log2 CU size - 3): the SS/GT candidate walk of csrc/k_walk.inl, one kernel per candidate, by CU size 8 / 16 / 32 / 64 */
+#define HOP_K_WALK_INTRA 16   /* + (log2 CU size - 3): the intra 2Nx2N candidate walk by CU size */
+#define HOP_K_WALK_INTRA_NXN 20   /* the intra NxN candidate walk (8x8 CUs) */
+#define HOP_K_COUNT     21
 int hop_profile_enable(hop_ctx* ctx, int on);
 /* waits for the stream, then reports launches, summed kernel time and units (PUs/CUs/jobs) since the last reset */
 int hop_profile_read(hop_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);

@@ -22,16 +22,17 @@ def hp(request):
     spec = importlib.util.spec_from_file_location("hophip", os.path.join(ROOT, "hevc-hop_amd", "hophip.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    old = os.environ.get("HOP_FUSED_LEAF")
+    old = os.environ.get("HOP_FUSED_LEAF"), os.environ.get("HOP_WALK")
     if request.param == "leaf-staged":
-        os.environ["HOP_FUSED_LEAF"] = "0"
+        os.environ["HOP_FUSED_LEAF"] = "0"; os.environ["HOP_WALK"] = "0"     # ... and the candidate chains as batch steps instead of one walk kernel per candidate (k_walk.inl)
     else:
-        os.environ.pop("HOP_FUSED_LEAF", None)
+        os.environ.pop("HOP_FUSED_LEAF", None); os.environ.pop("HOP_WALK", None)
     yield m
-    if old is None:
-        os.environ.pop("HOP_FUSED_LEAF", None)
-    else:
-        os.environ["HOP_FUSED_LEAF"] = old
+    for k, v in zip(("HOP_FUSED_LEAF", "HOP_WALK"), old):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def test_intra_rough_golden(hp):
@@ -1213,8 +1214,7 @@ def test_intra_cu_device_classes_vs_staged_entries(hp):
         for k2, t in bufs.items(): d[k2] = t.data_ptr()
         keep.append((idx, S, bufs))
     ctx.L.hop_intra_cu_device_classes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    # four calls on the same buffers: the first two issue the launches one by one, the third is captured into a graph, the fourth replays it (HOP_GRAPHS=0: all four the
-    # ordinary way); every call starts from the same pictures and must leave the same results, so the comparison below checks the replayed graph
+    # four calls on the same buffers: every call starts from the same pictures and must leave the same results (work areas reused from call to call)
     for rep in range(4):
         ctx.plane_upload("recon", 0, R)
         for k in range(2): ctx.plane_upload("recon", 1 + k, RC[k])
@@ -1222,8 +1222,6 @@ def test_intra_cu_device_classes_vs_staged_entries(hp):
             for name in ("d_sresults", "d_results", "d_cresults", "d_coef", "d_reco_y", "d_reco_c", "d_syntax_out", "d_dist", "d_bits", "d_cost", "d_ctx_out", "d_cu_ctx_out"): b[name].zero_()
         ctx._chk(ctx.L.hop_intra_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, d_snap.data_ptr(), d_cus.data_ptr()), "hop_intra_cu_device_classes")
         ctx.sync()
-    ctx.L.hop_graph_replays.restype = ctypes.c_long; ctx.L.hop_graph_replays.argtypes = [ctypes.c_void_p]
-    assert ctx.L.hop_graph_replays(ctx.h) == (0 if os.environ.get("HOP_GRAPHS", "1")[0] == "0" else 2)      # the capture and one replay
     coff = np.concatenate([[0], np.cumsum([(3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs])]); yoff = np.concatenate([[0], np.cumsum([1 << (2 * int(j["log2_cu"])) for j in jobs])])
     for idx, S, b in keep:
         dn = lambda t, dt: np.frombuffer(t.cpu().numpy().tobytes(), dt)
@@ -1248,7 +1246,7 @@ def test_intra_cu_device_classes_vs_staged_entries(hp):
 
 def test_inter_cu_device_classes_vs_staged_entries(hp):
     """hop_inter_cu_device_classes (SS/GT candidates with residual, device-resident: quadtree -> root-cbf decision and reconstruction -> CU syntax bits -> cost, classes on
-    separate streams, repeated calls replayed as a graph) against the three host-array entries stage by stage (those are checked against the restatement and the recorded
+    separate streams; with the fixture's default one walk kernel per candidate, k_walk.inl) against the three host-array entries stage by stage (those are checked against the restatement and the recorded
     encoder calls above): 40 random CUs of all sizes, four calls (launch by launch twice, captured, replayed)"""
     import torch
     O = oracle(); O.hop_o_calc_rd_cost.restype = ctypes.c_double; O.hop_o_calc_rd_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double]
@@ -1305,14 +1303,12 @@ def test_inter_cu_device_classes_vs_staged_entries(hp):
         for k2, t in b.items(): d[k2] = t.data_ptr()
         keep.append((idx, S, b))
     ctx.L.hop_inter_cu_device_classes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    ctx.L.hop_graph_replays.restype = ctypes.c_long; ctx.L.hop_graph_replays.argtypes = [ctypes.c_void_p]
     for rep in range(4):
         for k in range(3): ctx.plane_upload("recon", k, np.zeros(org[k].shape, np.int16))
         for idx, S, b in keep:
             for name in ("d_results", "d_coef", "d_ctx_after", "d_finals", "d_bits", "d_skipped", "d_cost", "d_ctx_out", "d_cu_ctx_out"): b[name].zero_()
         ctx._chk(ctx.L.hop_inter_cu_device_classes(ctx.h, len(descs), descs.ctypes.data, d_snap.data_ptr(), d_cus.data_ptr()), "hop_inter_cu_device_classes")
         ctx.sync()
-    assert ctx.L.hop_graph_replays(ctx.h) == (0 if os.environ.get("HOP_GRAPHS", "1")[0] == "0" else 2)
     coff = np.concatenate([[0], np.cumsum([(3 << (2 * int(j["log2_cu"]))) // 2 for j in jobs])])
     for idx, S, b in keep:
         g_r = np.frombuffer(b["d_results"].cpu().numpy().tobytes(), hp.RQT_RESULT_DTYPE); g_co = b["d_coef"].cpu().numpy(); g_f = b["d_finals"].cpu().numpy().view(np.uint32).reshape(-1, 4)
@@ -1328,7 +1324,6 @@ def test_inter_cu_device_classes_vs_staged_entries(hp):
     # many distinct single-class calls (one lane forked, none of the extra streams): the prefixes of the first class, three rounds each -- seen, captured, replayed;
     # every call still gives the staged results for its CUs
     idx, S, b = keep[0]
-    before = ctx.L.hop_graph_replays(ctx.h)
     for rnd in range(3):
         for m in range(1, len(idx) + 1):
             one = descs[:1].copy(); one[0]["n"] = m
@@ -1337,6 +1332,4 @@ def test_inter_cu_device_classes_vs_staged_entries(hp):
             ctx.sync()
             g_b = b["d_bits"].cpu().numpy().view(np.uint32); g_f = b["d_finals"].cpu().numpy().view(np.uint32).reshape(-1, 4)
             assert [int(v) for v in g_b[:m]] == [int(bits[i]) for i in idx[:m]] and np.array_equal(g_f[:m], fin3[idx[:m]]) and not g_b[m:].any(), (rnd, m)
-    if os.environ.get("HOP_GRAPHS", "1")[0] != "0":
-        assert ctx.L.hop_graph_replays(ctx.h) == before + 2 * len(idx)      # per key: the capture's launch in round two, the replay in round three
     ctx.close()

@@ -14,8 +14,23 @@ if P > 1:                                                    # a stack of P pict
 else:
     Y, Cb, Cr = lenslet(W, H, 15, 2)
     ctx = hp.Context(W, H, slots=S); ctx.upload_orig(Y, Cb, Cr)
+prof = os.environ.get("HOP_PROF") == "1"            # HIP events around every launch (one stream): exclusive kernel times per kind
+if prof:
+    import ctypes
+    L = ctx.L
+    L.hop_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.hop_profile_reset.argtypes = [ctypes.c_void_p]
+    L.hop_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.hop_profile_reset(ctx.h); L.hop_profile_enable(ctx.h, 1)
 t0 = time.time()
 cost, bits, dist, parts, nc = ctx.encode_frame(32, 15, 0, None, wpp=1 if lag else 0, wavefront_lag=lag, streams=streams)
 dt = time.time() - t0
 n = len(cost)
-print(json.dumps({"W": W, "H": H, "lag": lag, "streams": streams, "pictures": P, "slots": S, "ctus": n, "s": dt, "ctu_per_s": n / dt, "candidates": nc, "cost_sum": float(cost.sum()), "stats": ctx.encode_stats()}))
+kinds = {}
+if prof:
+    names = ["ss_search", "frac", "gt_search", "pred", "commit", "dist", "leaf/tq", "intra", "rdoq", "cabac", "deblock", "sao", "walk_inter8", "walk_inter16", "walk_inter32", "walk_inter64",
+             "walk_intra8", "walk_intra16", "walk_intra32", "walk_intra64", "walk_intra8_nxn"]
+    for kid, name in enumerate(names):
+        la, ms, un = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
+        L.hop_profile_read(ctx.h, kid, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(un))
+        if la.value: kinds[name] = {"launches": la.value, "ms": round(ms.value, 2), "units": un.value, "us_per_launch": round(1e3 * ms.value / la.value, 1)}
+print(json.dumps({"W": W, "H": H, "lag": lag, "streams": streams, "pictures": P, "slots": S, "ctus": n, "s": dt, "ctu_per_s": n / dt, "candidates": nc, "cost_sum": float(cost.sum()), "stats": ctx.encode_stats(), "kernels": kinds}))

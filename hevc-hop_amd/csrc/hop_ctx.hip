@@ -76,7 +76,10 @@ int hop_ctx_create(hop_ctx** out, int pic_w, int pic_h, int bit_depth_y, int bit
   }
   size_t ny = (size_t)pic_w * pic_h, nc = ny >> 2;
   size_t sy = (size_t)c->stride_y * (pic_h + 2 * HOP_MARGIN_Y), sc = (size_t)c->stride_c * ((pic_h >> 1) + 2 * HOP_MARGIN_C);
-  hipError_t e = hipStreamCreate(&c->stream);
+  // HOP_STREAM_PRIO=1 (experiment): the context's own stream -- the spine's short requests -- at the highest priority, the views' streams (candidate evaluations) at the lowest
+  int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const bool prio = getenv("HOP_STREAM_PRIO") && getenv("HOP_STREAM_PRIO")[0] == '1';
+  hipError_t e = prio ? hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi) : hipStreamCreate(&c->stream);
   for (int k = 0; k < HOP_MAX_LANES - 1 && e == hipSuccess; k++) { e = hipStreamCreate(&c->xstream[k]); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming); }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   { const char* f = getenv("HOP_LANES"); c->lanes = f ? atoi(f) : 2; if (c->lanes < 1) c->lanes = 1; if (c->lanes > HOP_MAX_LANES) c->lanes = HOP_MAX_LANES; }
@@ -127,7 +130,11 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
   hipError_t e = hipSetDevice(c->device);
   // (stream priorities -- views low, the parent high, so that the spine's short rounds would not queue behind its evaluation chains -- were measured and cost 10 %:
   // the evaluation chains are the critical path of a node, not the short rounds)
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const bool prio = getenv("HOP_STREAM_PRIO") && getenv("HOP_STREAM_PRIO")[0] == '1';
+    e = prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  }
   for (int k = 0; k < HOP_MAX_LANES - 1 && e == hipSuccess; k++) { e = hipStreamCreateWithFlags(&c->xstream[k], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming); }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e != hipSuccess) { hop_set_err(parent, HOP_ERR_DEVICE, "hop_ctx_create_view: %s", hipGetErrorString(e)); hop_ctx_destroy(c); return HOP_ERR_DEVICE; }
@@ -283,7 +290,8 @@ int hop_ssref_commit_cus_device(hop_ctx* c, int n, const int32_t* d_rect4, const
 static const int kLegalDim[] = { 4, 8, 12, 16, 24, 32, 48, 64 };
 static bool legal_dim(int v) { for (int d : kLegalDim) if (v == d) return true; return false; }
 
-static int check_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
+}  // extern "C"
+int hop_check_pu_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
   for (int i = 0; i < n; i++) {
     const hop_pu_job& j = jobs[i];
     if (!legal_dim(j.w) || !legal_dim(j.h) || j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3) || j.pu_x + j.w > c->pic_w || j.pu_y + j.h > c->pic_h)
@@ -309,6 +317,7 @@ static int check_jobs(hop_ctx* c, int n, const hop_pu_job* jobs) {
   }
   return HOP_OK;
 }
+extern "C" {
 
 static int me_pipeline(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_results, int stage) {
   int r = hop_launch_ss_search(c, n, d_jobs, d_results); if (r) return r;
@@ -353,7 +362,7 @@ int hop_me_search_device(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_res
 int hop_me_search(hop_ctx* c, int n, const hop_pu_job* jobs, hop_pu_result* results, int stage) {
   if (!c || n < 0 || (n && (!jobs || !results))) return hop_set_err(c, HOP_ERR_ARG, "hop_me_search: bad argument");
   if (n == 0) return HOP_OK;
-  int r = check_jobs(c, n, jobs); if (r) return r;
+  int r = hop_check_pu_jobs(c, n, jobs); if (r) return r;
   size_t bj = (size_t)n * sizeof(hop_pu_job), o_r = (bj + 255) & ~(size_t)255, br = (size_t)n * sizeof(hop_pu_result);
   void* st; r = hop_stage(c, o_r + br, &st); if (r) return r;
   hop_pu_job* dj = (hop_pu_job*)st; hop_pu_result* dr = (hop_pu_result*)((char*)st + o_r);
@@ -386,11 +395,9 @@ __global__ void k_gather_pred(const hop_pred_job* jobs, const int64_t* offs, con
   }
 }
 
-int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, int16_t* out_cb, int16_t* out_cr) {
-  if (!c || n < 0 || (n && !jobs)) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_inter: bad argument");
-  if (n == 0) return HOP_OK;
-  std::vector<int64_t> offs(n);
-  size_t tot = 0;
+}  // extern "C"
+// what every predictor job must satisfy before a kernel may run on it (shapes, candidate slot, the reach of the doubled patch + 8-tap filter inside the padded reference)
+int hop_check_pred_jobs(hop_ctx* c, int n, const hop_pred_job* jobs) {
   for (int i = 0; i < n; i++) {
     const hop_pred_job& j = jobs[i];
     if (!legal_dim(j.w) || !legal_dim(j.h) || j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3) || j.pu_x + j.w > c->pic_w || j.pu_y + j.h > c->pic_h)
@@ -401,8 +408,18 @@ int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, 
     const int lim = HOP_MARGIN_Y + HOP_GUARD_ROWS - 4;      // rows may use the guard band, columns wrap linearly like the reference
     if (iy - j.h / 2 - 4 < -lim || iy + j.h + j.h / 2 + 4 >= c->pic_h + lim || ix - j.w / 2 - 4 < -(c->stride_y - 8) || ix + 2 * j.w + 8 > c->stride_y + c->pic_w - 8)
       return hop_set_err(c, HOP_ERR_ARG, "pred job %d: motion vector leaves the padded reference", i);
-    offs[i] = (int64_t)tot; tot += (size_t)j.w * j.h;
   }
+  return HOP_OK;
+}
+extern "C" {
+
+int hop_pred_inter(hop_ctx* c, int n, const hop_pred_job* jobs, int16_t* out_y, int16_t* out_cb, int16_t* out_cr) {
+  if (!c || n < 0 || (n && !jobs)) return hop_set_err(c, HOP_ERR_ARG, "hop_pred_inter: bad argument");
+  if (n == 0) return HOP_OK;
+  { int rc = hop_check_pred_jobs(c, n, jobs); if (rc) return rc; }
+  std::vector<int64_t> offs(n);
+  size_t tot = 0;
+  for (int i = 0; i < n; i++) { offs[i] = (int64_t)tot; tot += (size_t)jobs[i].w * jobs[i].h; }
   size_t bj = (size_t)n * sizeof(hop_pred_job), o_o = (bj + 255) & ~(size_t)255, bo = (size_t)n * 8;
   size_t o_y = (o_o + bo + 255) & ~(size_t)255, o_cb = (o_y + tot * 2 + 255) & ~(size_t)255, o_cr = (o_cb + tot / 2 + 255) & ~(size_t)255;
   void* st; int r = hop_stage(c, o_cr + tot / 2 + 256, &st); if (r) return r;
@@ -1272,7 +1289,7 @@ static int intra_candidate_chain(hop_ctx* c, const hop_intra_class& k, const hop
     return hop_set_err(c, HOP_ERR_ARG, "hop_intra_cu_device_classes: illegal CU class");
   if (k.n == 0) return HOP_OK;
   if (k.n <= c->walk_max && !getenv("HOP_WALK_NO_INTRA")) {              // the RD spine's batches: one kernel per candidate (k_walk.inl)
-    int r = hop_walk_reserve(c, hop_intra_walk_bytes(cls->log2_cu, k.n)); if (r) return r;
+    int r = hop_walk_reserve(c, hop_intra_walk_bytes(c, cls->log2_cu, k.n, k.num_full_rd)); if (r) return r;
     return hop_launch_intra_walk(c, k, d_ctx_in, d_cu_ctx_in, c->walk_buf, c->walk_bytes);
   }
   size_t wb = hop_intra_search_work_bytes(cls->log2_cu, k.n); const size_t wc = hop_intra_chroma_work_bytes(cls->log2_cu, k.n);

@@ -144,8 +144,10 @@ int hop_launch_ss_search(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_res
 int hop_launch_frac(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
 int hop_launch_gt(hop_ctx* c, int n, const hop_pu_job* d_jobs, hop_pu_result* d_res);
 void hop_launch_size_classes(hop_ctx* c, int n, const hop_pu_job* d_jobs, const hop_pu_result* d_res, void* sc);
+int hop_check_pu_jobs(hop_ctx* c, int n, const hop_pu_job* jobs);        // host: the checks of hop_me_search / hop_pred_inter without the transfer (the spine packs its own pinned buffers)
+int hop_check_pred_jobs(hop_ctx* c, int n, const hop_pred_job* jobs);
 int hop_launch_pred(hop_ctx* c, int n, const hop_pred_job* d_jobs);
-int hop_launch_pred_cost(hop_ctx* c, int m, const int32_t* d_first, const hop_pred_job* d_jobs, const int32_t* d_kinds, uint32_t* d_out);   // sequences of candidates, one launch (k_pred.hip)
+int hop_launch_pred_cost(hop_ctx* c, int total, const int32_t* d_seq_of, const int32_t* d_first, const hop_pred_job* d_jobs, const int32_t* d_kinds, uint32_t* d_out);   // sequences of candidates, one launch, a workgroup per candidate (k_pred.hip)
 int hop_launch_dist(hop_ctx* c, int n, const hop_dist_job* d_jobs, uint32_t* d_out);
 int hop_launch_tu(hop_ctx* c, int n, const hop_tu_job* d_jobs, hop_tu_result* d_res, int32_t* d_levels, const int64_t* d_level_off);
 int hop_launch_intra(hop_ctx* c, int n, const hop_intra_job* d_jobs, uint32_t* d_satd);
@@ -189,7 +191,7 @@ int hop_launch_intra_cu_bits(hop_ctx* c, int log2_cu, int log2_max_tu, int log2_
                              const hop_rqt_result* d_res, const int32_t* d_coef, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, uint32_t* d_bits,
                              hop_cabac_ctx* d_ctx_out, hop_cabac_cu_ctx* d_cu_out);
 size_t hop_rqt_work_bytes(int log2_cu, int n);
-size_t hop_intra_walk_bytes(int log2_cu, int n);
+size_t hop_intra_walk_bytes(const hop_ctx* c, int log2_cu, int n, int num_full_rd);
 int hop_launch_intra_walk(hop_ctx* c, const hop_intra_class& q, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, void* buf, size_t buf_bytes);
 size_t hop_inter_walk_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n);
 int hop_launch_inter_walk(hop_ctx* c, const hop_rqt_job* cls, int n, const hop_rqt_job* d_jobs, const hop_cu_syntax* d_syn, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in,

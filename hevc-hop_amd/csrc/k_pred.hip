@@ -51,20 +51,22 @@ __device__ static inline int mc_sample(const int16_t* __restrict__ src, int stri
 struct PredShared { int16_t patch[128 * 130]; };
 
 // one job, one plane, on the 256 threads of the calling workgroup (a barrier inside the GT branch: uniform over the workgroup)
-__device__ static void pred_inter_body(PredShared& sh, const hop_pred_job& jb, const int comp, const hop_pics& pic) {
+// tile != nullptr: the block goes to `tile` (pitch = the block's width in this plane) instead of the prediction picture
+__device__ static void pred_inter_body(PredShared& sh, const hop_pred_job& jb, const int comp, const hop_pics& pic, int16_t* tile = nullptr) {
   const int tid = threadIdx.x;
   const bool chroma = comp != 0;
   const int bw = chroma ? jb.w >> 1 : jb.w, bh = chroma ? jb.h >> 1 : jb.h;       // block size in this plane
   const int16_t* ref = comp == 0 ? pic.ss_y : comp == 1 ? pic.ss_cb : pic.ss_cr;
   int16_t* dst = comp == 0 ? pic.pred_y : comp == 1 ? pic.pred_cb : pic.pred_cr;
-  const int rstride = chroma ? pic.stride_c : pic.stride_y, dpitch = chroma ? pic.pic_w >> 1 : pic.pic_w;
+  const int rstride = chroma ? pic.stride_c : pic.stride_y, dpitch = tile ? bw : (chroma ? pic.pic_w >> 1 : pic.pic_w);
   const int bx = chroma ? jb.pu_x >> 1 : jb.pu_x, by = chroma ? jb.pu_y >> 1 : jb.pu_y;
   const int bd = chroma ? pic.bd_c : pic.bd_y;
   const int ish = chroma ? 3 : 2, fmask = chroma ? 7 : 3;
   const int ix = jb.mv_x >> ish, iy = jb.mv_y >> ish, xf = jb.mv_x & fmask, yf = jb.mv_y & fmask;
   bool any = false;
   for (int k = 0; k < 8; k++) any = any || jb.gt[k] != 0;
-  dst += (size_t)(by + (chroma ? jb.dst_row_off >> 1 : jb.dst_row_off)) * dpitch + bx;   // dst_row_off: the candidate slot's copy of the prediction picture
+  if (tile) dst = tile;
+  else dst += (size_t)(by + (chroma ? jb.dst_row_off >> 1 : jb.dst_row_off)) * dpitch + bx;   // dst_row_off: the candidate slot's copy of the prediction picture
   if (!jb.use_gt || !any) {                                   // plain motion compensation, :650-678 / :1246-1289
     const int16_t* r = ref + (ptrdiff_t)(by + iy) * rstride + bx + ix;
     for (int i = tid; i < bw * bh; i += 256) {
@@ -197,13 +199,15 @@ extern "C" int hop_pred_jobs_from_results_device(hop_ctx* c, int n, const int32_
 // SAD (TComRdCost.cpp:513-1011), SSE (:1018-1360), HADs (:1641-1708).  One workgroup per job.
 // ---------------------------------------------------------------------------------------------
 // one job on the 256 threads of the calling workgroup; thread 0 returns the value (barriers inside)
-__device__ static uint32_t distortion_body(unsigned int& acc, const hop_dist_job& jb, const hop_pics& pic) {
+// tile != nullptr: the prediction is read from `tile` (pitch = the block's width) instead of the prediction picture
+__device__ static uint32_t distortion_body(unsigned int& acc, const hop_dist_job& jb, const hop_pics& pic, const int16_t* tile = nullptr) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool chroma = jb.comp != 0;
   const int w = chroma ? jb.w >> 1 : jb.w, h = chroma ? jb.h >> 1 : jb.h, x0 = chroma ? jb.x >> 1 : jb.x, y0 = chroma ? jb.y >> 1 : jb.y;
   const int pitch = chroma ? pic.pic_w >> 1 : pic.pic_w, bd = chroma ? pic.bd_c : pic.bd_y;
   const int16_t* o = (jb.comp == 0 ? pic.org_y : jb.comp == 1 ? pic.org_cb : pic.org_cr) + (size_t)y0 * pitch + x0;
-  const int16_t* p = (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
+  const int ppitch = tile ? w : pitch;
+  const int16_t* p = tile ? tile : (jb.comp == 0 ? pic.pred_y : jb.comp == 1 ? pic.pred_cb : pic.pred_cr) + (size_t)y0 * pitch + x0;
   if (tid == 0) acc = 0;
   __syncthreads();
   unsigned int part = 0;
@@ -211,7 +215,7 @@ __device__ static uint32_t distortion_body(unsigned int& acc, const hop_dist_job
     const unsigned sshift = (unsigned)((bd - 8) << 1);
     for (int i = tid; i < w * h; i += 256) {
       int r = i / w, c = i - r * w;
-      int d = (int)o[(size_t)r * pitch + c] - (int)p[(size_t)r * pitch + c];
+      int d = (int)o[(size_t)r * pitch + c] - (int)p[(size_t)r * ppitch + c];
       part += jb.kind == HOP_DIST_SAD ? (unsigned)(d < 0 ? -d : d) : ((unsigned)(d * d) >> sshift);
     }
     part = (unsigned)hopd_wave_sum((int)part);
@@ -220,7 +224,7 @@ __device__ static uint32_t distortion_body(unsigned int& acc, const hop_dist_job
     const int nblk = (w * h) >> 6, bwb = w >> 3;
     for (int blk = wave; blk < nblk; blk += 4) {
       const int px = (blk % bwb) * 8 + (lane & 7), py = (blk / bwb) * 8 + (lane >> 3);
-      int d = (int)o[(size_t)py * pitch + px] - (int)p[(size_t)py * pitch + px];
+      int d = (int)o[(size_t)py * pitch + px] - (int)p[(size_t)py * ppitch + px];
       int s = hopd_satd8x8_wave(d, lane);
       if (lane == 0) atomicAdd(&acc, (unsigned)s);
     }
@@ -231,7 +235,7 @@ __device__ static uint32_t distortion_body(unsigned int& acc, const hop_dist_job
       const bool act = blk < nb4;
       const int bb = act ? blk : 0;
       const int px = (bb % bw4) * 4 + (lane & 3), py = (bb / bw4) * 4 + ((lane >> 2) & 3);
-      int d = (int)o[(size_t)py * pitch + px] - (int)p[(size_t)py * pitch + px];
+      int d = (int)o[(size_t)py * pitch + px] - (int)p[(size_t)py * ppitch + px];
       int sb = hopd_satd4x4_quad(act ? d : 0, lane);
       int s = hopd_wave_sum((act && (lane & 15) == 0) ? sb : 0);
       if (lane == 0) atomicAdd(&acc, (unsigned)s);
@@ -247,31 +251,34 @@ __global__ __launch_bounds__(256) void k_distortion(const hop_dist_job* __restri
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
-// Sequences of candidates rated one after the other (TEncSearch::xMergeEstimation TLibEncoder/TEncSearch.cpp:2992-3106, xGetTemplateCost :4411-4477 with xGetInterPredictionError
+// Sequences of candidates rated "one after the other" (TEncSearch::xMergeEstimation TLibEncoder/TEncSearch.cpp:2992-3106, xGetTemplateCost :4411-4477 with xGetInterPredictionError
 // :2951-2977: every candidate of a PU is predicted into the same temporary block and its luma distortion taken): sequence s = jobs first[s] .. first[s + 1] - 1, all on the
-// PU's rectangle.  Grid (sequences, 3): plane 0 predicts and rates the candidates in order (out[j] per job); planes 1 / 2 predict the LAST candidate only -- afterwards the
-// prediction picture holds the last candidate's prediction in all planes, as after the reference's loop.
-__global__ __launch_bounds__(256) void k_pred_cost(const int32_t* __restrict__ first, const hop_pred_job* __restrict__ jobs, const int32_t* __restrict__ kinds, hop_pics pic,
-                                                   uint32_t* __restrict__ out) {
+// PU's rectangle.  The candidates do not depend on each other -- they only share the block they are predicted into --, so every candidate gets a workgroup of its own:
+// grid (jobs, 3).  Plane 0: the luma prediction into an LDS tile, its distortion against the original -> out[job]; the LAST candidate of a sequence also writes its tile to
+// the prediction picture.  Planes 1 / 2: the chroma prediction of the last candidate of each sequence into the picture (the other workgroups return at once) -- afterwards
+// the prediction picture holds the last candidate's prediction in all planes, as after the reference's loop.
+__global__ __launch_bounds__(256) void k_pred_cost(const int32_t* __restrict__ seq_of, const int32_t* __restrict__ first, const hop_pred_job* __restrict__ jobs,
+                                                   const int32_t* __restrict__ kinds, hop_pics pic, uint32_t* __restrict__ out) {
   __shared__ PredShared sh;
+  __shared__ int16_t tile[64 * 64];
   __shared__ unsigned int acc;
-  const int s = blockIdx.x, comp = blockIdx.y, j0 = first[s], j1 = first[s + 1];
-  if (j1 <= j0) return;
-  if (comp) { const hop_pred_job jb = jobs[j1 - 1]; pred_inter_body(sh, jb, comp, pic); return; }
-  for (int j = j0; j < j1; j++) {
-    const hop_pred_job jb = jobs[j];
-    pred_inter_body(sh, jb, 0, pic);
-    __threadfence_block();
-    __syncthreads();
-    hop_dist_job d; d.x = jb.pu_x; d.y = jb.pu_y + jb.dst_row_off; d.w = jb.w; d.h = jb.h; d.comp = 0; d.kind = kinds[s];
-    const uint32_t v = distortion_body(acc, d, pic);
-    if (threadIdx.x == 0) out[j] = v;
-    __syncthreads();                                                    // (the patch and the accumulator are reused by the next candidate)
+  const int j = blockIdx.x, comp = blockIdx.y, s = seq_of[j];
+  const bool last = j == first[s + 1] - 1;
+  const hop_pred_job jb = jobs[j];
+  if (comp) { if (last) pred_inter_body(sh, jb, comp, pic); return; }
+  pred_inter_body(sh, jb, 0, pic, tile);
+  __syncthreads();
+  hop_dist_job d; d.x = jb.pu_x; d.y = jb.pu_y + jb.dst_row_off; d.w = jb.w; d.h = jb.h; d.comp = 0; d.kind = kinds[s];
+  const uint32_t v = distortion_body(acc, d, pic, tile);
+  if (threadIdx.x == 0) out[j] = v;
+  if (last) {
+    int16_t* dst = pic.pred_y + (size_t)(jb.pu_y + jb.dst_row_off) * pic.pic_w + jb.pu_x;
+    for (int i = threadIdx.x; i < jb.w * jb.h; i += 256) { const int y = i / jb.w, x = i - y * jb.w; dst[(size_t)y * pic.pic_w + x] = tile[i]; }
   }
 }
-int hop_launch_pred_cost(hop_ctx* c, int m, const int32_t* d_first, const hop_pred_job* d_jobs, const int32_t* d_kinds, uint32_t* d_out) {
-  const int pr = hop_prof_begin(c, HOP_K_PRED, (uint64_t)m);
-  hipLaunchKernelGGL(k_pred_cost, dim3(m, 3), dim3(256), 0, c->stream, d_first, d_jobs, d_kinds, hop_make_pics(c), d_out);
+int hop_launch_pred_cost(hop_ctx* c, int total, const int32_t* d_seq_of, const int32_t* d_first, const hop_pred_job* d_jobs, const int32_t* d_kinds, uint32_t* d_out) {
+  const int pr = hop_prof_begin(c, HOP_K_PRED, (uint64_t)total);
+  hipLaunchKernelGGL(k_pred_cost, dim3(total, 3), dim3(256), 0, c->stream, d_seq_of, d_first, d_jobs, d_kinds, hop_make_pics(c), d_out);
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "pred_cost launch: %s", hipGetErrorString(e));

@@ -225,6 +225,7 @@ class HipBackend : public BatchInner {
     o_ctx_out = take(MAXN * sizeof(hop_cabac_ctx)); o_cu_out = take(MAXN * sizeof(hop_cabac_cu_ctx)); o_fin = take(MAXN * sizeof(hop_cu_final));
     o_bits = take(MAXN * 4); o_skipped = take(MAXN * 4); o_cost = take(MAXN * 8); o_dist = take(MAXN * 4);
     o_pjobs = take(MAXP * sizeof(hop_pred_job)); o_djobs = take(MAXP * sizeof(hop_dist_job)); o_pout = take(MAXP * 4);
+    o_mjobs = take(MAXP * sizeof(hop_pu_job)); o_mres = take(MAXP * sizeof(hop_pu_result));
     // what a candidate batch sends and gets back travels as ONE copy each way between pinned host memory and these two regions, packed for the batch's n
     io_bytes = (size_t)MAXN * (sizeof(hop_rqt_job) + sizeof(hop_intra_cu_syntax) + sizeof(hop_intra_rqt_opt) + sizeof(hop_intra_search_job) + sizeof(hop_rqt_result) +
                                sizeof(hop_intra_search_result) + sizeof(hop_intra_chroma_result) + 2 * sizeof(hop_cabac_ctx) + 2 * sizeof(hop_cabac_cu_ctx) + sizeof(hop_cu_final) + 64) + 16 * 256;
@@ -264,8 +265,28 @@ class HipBackend : public BatchInner {
 
   void on_device() { if (hipSetDevice(c->device) != hipSuccess) { hop_set_err(c, HOP_ERR_DEVICE, "hipSetDevice(%d) failed", c->device); throw Bail{ HOP_ERR_DEVICE }; } }   // batches are served by whichever worker thread arrives last: the current device is per-thread state
   void begin_frame() { on_device(); BK(hop_ssref_reset(c)); BK(hop_sync(c)); }
-  void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) { on_device(); Tick t(0); BK(hop_me_search(c, n, jobs, res, HOP_STAGE_GT)); }
-  void pred_inter(int, int n, const hop_pred_job* jobs) { on_device(); Tick t(1); BK(hop_pred_inter(c, n, jobs, nullptr, nullptr, nullptr)); }
+  // the short requests travel through the backend's pinned buffers: jobs the kernels read once are read by the device straight from pinned host memory, results the
+  // kernels write once are written straight into it -- no staging copies, one synchronisation per request
+  void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) {
+    on_device(); Tick t(0);
+    if (n > MAXP) { BK(hop_me_search(c, n, jobs, res, HOP_STAGE_GT)); return; }
+    BK(hop_check_pu_jobs(c, n, jobs));
+    memcpy(hin, jobs, (size_t)n * sizeof(hop_pu_job));
+    hipStream_t st = c->stream;
+    BH(hipMemcpyAsync(arena + o_mjobs, hin, (size_t)n * sizeof(hop_pu_job), hipMemcpyHostToDevice, st));   // (the search kernels read a job many times: a device copy)
+    BK(hop_me_search_device(c, n, (const hop_pu_job*)(arena + o_mjobs), (hop_pu_result*)(arena + o_mres), HOP_STAGE_GT));
+    BH(hipMemcpyAsync(hout, arena + o_mres, (size_t)n * sizeof(hop_pu_result), hipMemcpyDeviceToHost, st));
+    BH(hipStreamSynchronize(st));
+    memcpy(res, hout, (size_t)n * sizeof(hop_pu_result));
+  }
+  void pred_inter(int, int n, const hop_pred_job* jobs) {
+    on_device(); Tick t(1);
+    if ((size_t)n * sizeof(hop_pred_job) > io_bytes) { BK(hop_pred_inter(c, n, jobs, nullptr, nullptr, nullptr)); return; }
+    BK(hop_check_pred_jobs(c, n, jobs));
+    memcpy(hin, jobs, (size_t)n * sizeof(hop_pred_job));
+    BK(hop_pred_inter_device(c, n, (const hop_pred_job*)hin));
+    BH(hipStreamSynchronize(c->stream));
+  }
   void distortion(int, int n, const hop_dist_job* jobs, uint32_t* out) { on_device(); Tick t(2); BK(hop_distortion(c, n, jobs, out)); }
   void valid_pattern(int, int n, const int32_t* q, uint8_t* out) { on_device(); Tick t(3); BK(hop_valid_pattern(c, n, q, out)); }
   void recon_save(int lane, int slot, int x, int y, int size) { on_device(); Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 0)); }
@@ -285,20 +306,18 @@ class HipBackend : public BatchInner {
       return;
     }
     Tick t(1);
-    // the sequences as they are, one after the other; ONE launch rates them all (k_pred_cost: a workgroup walks its sequence in order)
+    // the sequences as they are, one after the other; ONE launch rates them all, a workgroup per candidate (k_pred_cost)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t h_first = al((size_t)total * sizeof(hop_pred_job)), h_kinds = h_first + al((size_t)(m + 1) * 4), h_bytes = h_kinds + al((size_t)m * 4);
-    if (h_bytes > io_bytes || h_bytes > (size_t)MAXP * (sizeof(hop_pred_job) + sizeof(hop_dist_job))) throw Bail{ HOP_ERR_ARG };
+    const size_t h_first = al((size_t)total * sizeof(hop_pred_job)), h_kinds = h_first + al((size_t)(m + 1) * 4), h_seq = h_kinds + al((size_t)m * 4), h_bytes = h_seq + al((size_t)total * 4);
+    if (h_bytes > io_bytes) throw Bail{ HOP_ERR_ARG };
     memcpy(hin, jobs, (size_t)total * sizeof(hop_pred_job));
-    int32_t* hf = (int32_t*)(hin + h_first); int32_t* hk = (int32_t*)(hin + h_kinds);
-    for (int s = 0, at = 0; s < m; at += len[s], s++) { hf[s] = at; hk[s] = kinds[s]; }
+    int32_t* hf = (int32_t*)(hin + h_first); int32_t* hk = (int32_t*)(hin + h_kinds); int32_t* hs = (int32_t*)(hin + h_seq);
+    for (int s = 0, at = 0; s < m; at += len[s], s++) { hf[s] = at; hk[s] = kinds[s]; for (int q = 0; q < len[s]; q++) hs[at + q] = s; }
     hf[m] = total;
+    BK(hop_check_pred_jobs(c, total, jobs));
     hipStream_t st = c->stream;
-    char* dj = arena + o_pjobs;                                          // (o_pjobs and o_djobs are adjacent: MAXP jobs of each)
-    BH(hipMemcpyAsync(dj, hin, h_bytes, hipMemcpyHostToDevice, st));
-    BK(hop_launch_pred_cost(c, m, (const int32_t*)(dj + h_first), (const hop_pred_job*)dj, (const int32_t*)(dj + h_kinds), (uint32_t*)(arena + o_pout)));
     uint32_t* o = (uint32_t*)hout;
-    BH(hipMemcpyAsync(o, arena + o_pout, total * 4, hipMemcpyDeviceToHost, st));
+    BK(hop_launch_pred_cost(c, total, (const int32_t*)(hin + h_seq), (const int32_t*)(hin + h_first), (const hop_pred_job*)hin, (const int32_t*)(hin + h_kinds), o));   // jobs read from, costs written to pinned host memory
     BH(hipStreamSynchronize(st));
     memcpy(out, o, (size_t)total * 4);
   }
@@ -410,7 +429,7 @@ class HipBackend : public BatchInner {
   hop_ctx* c; char* arena; size_t bytes; char* hin; char* hout; size_t io_bytes, o_in, o_out;
   bool is_sub_; int rr_; std::vector<hop_ctx*> views_; std::vector<HipBackend*> subs_; std::function<void()> collect_;   // collect_: the second half of a batch issued on this (sub) backend
   size_t o_jobs, o_syn, o_isyn, o_isyn_out, o_opts, o_sjobs, o_sres, o_res, o_cres, o_coef, o_reco_y, o_reco_c, o_ctx_in, o_cu_in, o_ctx_after, o_ctx_out, o_cu_out, o_fin, o_bits, o_skipped,
-         o_cost, o_dist, o_pjobs, o_djobs, o_pout;
+         o_cost, o_dist, o_pjobs, o_djobs, o_pout, o_mjobs, o_mres;
 };
 
 }  // namespace

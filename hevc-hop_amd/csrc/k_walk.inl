@@ -11,6 +11,10 @@
 //                  syntax bits (xAddSymbolBitsInter :7779-7810) = cu_bits, calcRdCost
 // (the intra candidate walk follows the same scheme)
 
+// The walks are serial code on a few lanes: what they must not do is keep the short kernels of the spine's other requests (predictions, searches) off the compute units.
+// At the compiler's free choice they take 256 registers per lane -- two workgroups fill a compute unit's register files, and a few hundred candidates in flight the whole
+// chip; capped at 128 (four waves per SIMD) a compute unit holds four and still has room.
+#define WALK_WAVES_PER_SIMD 4
 struct InterWalk {
   RqtClass k; int n, bd_y, bd_c; hop_pics pic;
   const hop_rqt_job* jobs; const hop_cu_syntax* syn; const hop_cabac_ctx* ctx_in; const hop_cabac_cu_ctx* cu_in;
@@ -54,7 +58,7 @@ __device__ static void walk_recon_jobs(LeafShared& L, const int first, const int
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_inter_walk(InterWalk A) {
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_inter_walk(InterWalk A) {
   __shared__ LeafShared L;
   __shared__ CabacLds1 sh1;
   const int i = blockIdx.x, tid = threadIdx.x;
@@ -189,6 +193,13 @@ struct IntraWalk {
   // the leaf step's scratch: one transform unit per candidate at a time
   int32_t* lcoef; uint32_t* zs; uint32_t* ns; uint32_t* as; unsigned long long* fr; hop_rdoq_job* rq; hop_coeff_bits_job* cb; char* lwork;
   const int32_t* entropy_bits; const uint16_t* scans; int16_t* rec_y; int16_t* rec_cb; int16_t* rec_cr;
+  // candidates side by side (k_iw_*): P candidate passes per candidate CU, virtual index v = i * P + pass.  The per-CU work arrays above are sized for V = n * P entries;
+  // a virtual candidate works on copies of its CU's inputs and predicts / reconstructs in a BAND of its own: planes of the picture's pitch in which candidate v owns the
+  // rows v * hb .. (v + 1) * hb - 1 -- handed to the bodies shifted so that the CU's picture coordinates land there, its neighbouring row and column copied in first (what
+  // k_slot_prepare does for a candidate slot)
+  int P, V, hb, hbc, pic_h;
+  hop_rqt_job* vjobs; hop_intra_cu_syntax* vsyn; hop_intra_rqt_opt* vopt; hop_rqt_result* vtmp; int32_t* vcoef_tmp; hop_rqt_result* vres;
+  int16_t* band_pred[3]; int16_t* band_rec[3];
 };
 union WalkShared { LeafShared leaf; IntraShared intra; };
 
@@ -248,107 +259,294 @@ __device__ static void walk_intra_rqt(const IntraWalk& A, WalkShared& L, CabacLd
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_intra_walk(IntraWalk A) {
+// ---- the phases of an intra candidate, each on the whole workgroup, index i into the arrays of A ----
+// estIntraPredQT of PU pu up to the candidate list (:2430-2493)
+__device__ static void iw_luma_prep(const IntraWalk& A, WalkShared& L, const int i, const int pu) {
+  if (threadIdx.x == 0) is_prep_body(i, A.k, pu, A.nxn, A.jobs, A.sj, A.opt, A.ctx_in, A.cu_in, A.sres, A.syn, A.rj, A.mj, A.iswork);
+  __syncthreads();
+  intra_rough_body(L.intra, A.rj + i, A.pic, A.rec_y, A.satd + (size_t)i * 35);
+  __syncthreads();
+  if (threadIdx.x == 0) intra_modes_body(i, A.mj, A.satd, A.mres);
+  __syncthreads();
+}
+// the best mode again with the full tree, the better result kept, the decided PU into the picture (:2555-2660)
+__device__ static void iw_luma_final(const IntraWalk& A, WalkShared& L, CabacLds1& sh1, const int i, const int pu) {
+  const int tid = threadIdx.x, n_max = A.num_full_rd + 2, pitch = A.pic.pic_w;
+  if (tid == 0) is_pick_body(i, pu, n_max, n_max, A.mres, A.iswork, A.syn, A.active);
+  __syncthreads();
+  walk_intra_rqt(A, L, sh1, i, A.nxn, 0);
+  is_keep_body(i, tid, 256, A.k, pu, A.nxn, n_max, n_max, A.jobs, A.mres, A.syn, A.tmp, A.coef_tmp, A.rec_y, pitch, A.iswork, A.coef_out, A.reco_y);
+  __syncthreads();
+  is_commit_body(i, tid, 256, A.k, pu, A.nxn, A.jobs, A.iswork, A.mres, A.syn, A.res, A.sres, A.rec_y, pitch, A.reco_y);
+  __syncthreads();
+}
+// one direction of estIntraPredChromaQT along the luma tree in A.res[i] (xRecurIntraChromaCodingQT :2130-2277), then the CU's chroma bits and cost (ic_bits)
+__device__ static void iw_chroma_mode(const IntraWalk& A, WalkShared& L, CabacLds1& sh1, const int i, const int m) {
+  const int tid = threadIdx.x;
+  const RqtClass k = A.k;
+  const int parts = 1 << (2 * (k.log2_cu - 2)), pitch_c = A.pic.pic_w >> 1;
+  const hop_rqt_result* r = A.res + i;
+  if (tid == 0) ic_mode_body(i, m, A.jobs, A.ctx_in, A.ccur, A.csyn, A.icwork);
+  __syncthreads();
+  int s_part[4], s_child[4];
+  int sp = 0;
+  s_part[0] = 0; s_child[0] = -1;
+  while (sp >= 0) {
+    const int d = sp, log2 = k.log2_cu - d, part = s_part[sp];
+    RqtNode nd; nd.part = part; nd.d = d; nd.log2 = log2; nd.code_chroma = 0; nd.add_zero = 0; nd.ts_c = 0; nd.ts_y = 0; nd.check_full = 0; nd.check_split = 0;
+    const int tr = r->tr_idx[part];
+    if (s_child[sp] < 0) {
+      if (tr == d && log2 <= k.log2_max_tu && !(log2 == 2 && (part & 3))) {       // a transform unit of this CU sits here (ic_leaf_here)
+        const bool may_ts = k.use_ts && log2 <= 3;
+        for (int comp = 1; comp <= 2; comp++) {
+          if (tid == 0) ic_begin_body(i, k, nd, comp, A.jobs, A.csyn, A.opt, A.bd_c, A.ccur, A.croot, A.res, A.icwork, A.pj, A.modes, A.tuj, A.off, A.tuj2, A.off2, A.ts_base);
+          __syncthreads();
+          if (comp == 1) {
+            intra_pred_chroma_body(L.intra, A.pj + i, A.modes[i], 1, A.pic, A.rec_cb, A.rec_cr);
+            __syncthreads();
+            intra_pred_chroma_body(L.intra, A.pj + i, A.modes[i], 2, A.pic, A.rec_cb, A.rec_cr);
+            __syncthreads();
+          }
+          int16_t* recc = comp == 1 ? A.rec_cb : A.rec_cr;
+          if (may_ts) {
+            IW_LEAF(A.tuj2, A.ccur, A.off2, A.ccoef, A.tr2);
+            __syncthreads();
+            if (tid < 16) ic_park_body(i, tid, k, nd, A.jobs, A.opt, A.res, recc, pitch_c, A.cpark);
+            __syncthreads();
+          }
+          IW_LEAF(A.tuj, A.ccur, A.off, A.ccoef, A.tr);
+          __syncthreads();
+          if (tid == 0) ic_single_body(sh1, 0, i, k, nd, comp, A.jobs, A.csyn, A.opt, A.ccur, A.croot, A.res, A.icwork, A.tr, A.tr2, A.ccoef, A.ts_base, recc, pitch_c, A.cpark, A.scans);
+          __syncthreads();
+        }
+      }
+      if (!(tr > d && log2 > k.log2_min_tu)) { sp--; continue; }                   // the tree goes no deeper here
+      s_child[sp] = 0;
+    }
+    if (s_child[sp] < 4) {
+      const int q = (parts >> (2 * d)) >> 2, kk = s_child[sp]++;
+      s_part[sp + 1] = part + kk * q; s_child[sp + 1] = -1;
+      sp++;
+      continue;
+    }
+    if (tid == 0) ic_fold_body(i, k, nd, A.res);
+    __syncthreads();
+    sp--;
+  }
+  if (tid == 0) ic_bits_body(sh1, 0, i, k, A.jobs, A.csyn, A.ctx_in, A.cu_in, A.res, A.icwork, A.ccoef, A.scans);
+  __syncthreads();
+}
+__device__ static inline void iw_zero_ccoef(const IntraWalk& A, const int i) {
+  const size_t cu2 = (size_t)1 << (2 * A.k.log2_cu);
+  int32_t* z = A.ccoef + (size_t)i * 6 * cu2;
+  for (size_t e = threadIdx.x; e < 6 * cu2; e += 256) z[e] = 0;
+  if (threadIdx.x < 16) A.ccoef[A.ts_base + (size_t)i * 16 + threadIdx.x] = 0;
+}
+// getTotalDistortion, the CU's bits from the CI_CURR_BEST state, calcRdCost
+__device__ static inline void iw_total(const IntraWalk& A, CabacLds1& sh1, const int i) {
+  if (threadIdx.x == 0) {
+    A.dist[i] = A.sres[i].dist + A.cres[i].dist;
+    intra_cu_total_body(sh1, 0, i, A.k, A.jobs, A.syn_out, A.res, A.coef_out, A.ctx_in, A.cu_in, A.dist, A.bits, A.cost, A.ctx_out, A.cu_out, A.scans);
+  }
+}
+
+// ---- everything on one workgroup per candidate CU, the candidate passes one after the other ----
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_intra_walk(IntraWalk A) {
   __shared__ WalkShared L;
   __shared__ CabacLds1 sh1;
   const int i = blockIdx.x, tid = threadIdx.x;
   const RqtClass k = A.k;
-  const int parts = 1 << (2 * (k.log2_cu - 2)), pitch = A.pic.pic_w, pitch_c = A.pic.pic_w >> 1;
-  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
-  // ---- the luma search: estIntraPredQT, PU after PU ----
+  const int pitch = A.pic.pic_w, pitch_c = A.pic.pic_w >> 1;
   if (tid == 0) A.syn[i] = A.syn_in[i];
   { uint32_t* z = (uint32_t*)(A.res + i); for (int e = tid; e < (int)(sizeof(hop_rqt_result) / 4); e += 256) z[e] = 0; }
   __syncthreads();
   const int npu = A.nxn ? 4 : 1, n_max = A.num_full_rd + 2;
   for (int pu = 0; pu < npu; pu++) {
-    if (tid == 0) is_prep_body(i, k, pu, A.nxn, A.jobs, A.sj, A.opt, A.ctx_in, A.cu_in, A.sres, A.syn, A.rj, A.mj, A.iswork);
-    __syncthreads();
-    intra_rough_body(L.intra, A.rj + i, A.pic, A.rec_y, A.satd + (size_t)i * 35);
-    __syncthreads();
-    if (tid == 0) intra_modes_body(i, A.mj, A.satd, A.mres);
-    __syncthreads();
-    for (int pass = 0; pass <= n_max; pass++) {
+    iw_luma_prep(A, L, i, pu);
+    for (int pass = 0; pass < n_max; pass++) {
       if (tid == 0) is_pick_body(i, pu, pass, n_max, A.mres, A.iswork, A.syn, A.active);
       __syncthreads();
       if (!A.active[i]) continue;                                        // this CU's list is shorter (uniform over the workgroup)
-      walk_intra_rqt(A, L, sh1, i, A.nxn, pass < n_max ? 1 : 0);
+      walk_intra_rqt(A, L, sh1, i, A.nxn, 1);
       is_keep_body(i, tid, 256, k, pu, A.nxn, pass, n_max, A.jobs, A.mres, A.syn, A.tmp, A.coef_tmp, A.rec_y, pitch, A.iswork, A.coef_out, A.reco_y);
       __syncthreads();
     }
-    is_commit_body(i, tid, 256, k, pu, A.nxn, A.jobs, A.iswork, A.mres, A.syn, A.res, A.sres, A.rec_y, pitch, A.reco_y);
-    __syncthreads();
+    iw_luma_final(A, L, sh1, i, pu);
   }
   if (tid == 0) { A.syn_out[i] = A.syn[i]; A.csyn[i] = A.syn[i]; }
-  // ---- the chroma search: estIntraPredChromaQT along the luma tree just decided ----
-  { int32_t* z = A.ccoef + (size_t)i * 6 * cu2; for (size_t e = tid; e < 6 * cu2; e += 256) z[e] = 0; if (tid < 16) A.ccoef[A.ts_base + (size_t)i * 16 + tid] = 0; }
+  iw_zero_ccoef(A, i);
   __syncthreads();
-  const hop_rqt_result* r = A.res + i;
   for (int m = 0; m < 5; m++) {
-    if (tid == 0) ic_mode_body(i, m, A.jobs, A.ctx_in, A.ccur, A.csyn, A.icwork);
-    __syncthreads();
-    int s_part[4], s_child[4];
-    int sp = 0;
-    s_part[0] = 0; s_child[0] = -1;
-    while (sp >= 0) {
-      const int d = sp, log2 = k.log2_cu - d, part = s_part[sp];
-      RqtNode nd; nd.part = part; nd.d = d; nd.log2 = log2; nd.code_chroma = 0; nd.add_zero = 0; nd.ts_c = 0; nd.ts_y = 0; nd.check_full = 0; nd.check_split = 0;
-      const int tr = r->tr_idx[part];
-      if (s_child[sp] < 0) {
-        if (tr == d && log2 <= k.log2_max_tu && !(log2 == 2 && (part & 3))) {       // a transform unit of this CU sits here (ic_leaf_here)
-          const bool may_ts = k.use_ts && log2 <= 3;
-          for (int comp = 1; comp <= 2; comp++) {
-            if (tid == 0) ic_begin_body(i, k, nd, comp, A.jobs, A.csyn, A.opt, A.bd_c, A.ccur, A.croot, A.res, A.icwork, A.pj, A.modes, A.tuj, A.off, A.tuj2, A.off2, A.ts_base);
-            __syncthreads();
-            if (comp == 1) {
-              intra_pred_chroma_body(L.intra, A.pj + i, A.modes[i], 1, A.pic, A.rec_cb, A.rec_cr);
-              __syncthreads();
-              intra_pred_chroma_body(L.intra, A.pj + i, A.modes[i], 2, A.pic, A.rec_cb, A.rec_cr);
-              __syncthreads();
-            }
-            int16_t* recc = comp == 1 ? A.rec_cb : A.rec_cr;
-            if (may_ts) {
-              IW_LEAF(A.tuj2, A.ccur, A.off2, A.ccoef, A.tr2);
-              __syncthreads();
-              if (tid < 16) ic_park_body(i, tid, k, nd, A.jobs, A.opt, A.res, recc, pitch_c, A.cpark);
-              __syncthreads();
-            }
-            IW_LEAF(A.tuj, A.ccur, A.off, A.ccoef, A.tr);
-            __syncthreads();
-            if (tid == 0) ic_single_body(sh1, 0, i, k, nd, comp, A.jobs, A.csyn, A.opt, A.ccur, A.croot, A.res, A.icwork, A.tr, A.tr2, A.ccoef, A.ts_base, recc, pitch_c, A.cpark, A.scans);
-            __syncthreads();
-          }
-        }
-        if (!(tr > d && log2 > k.log2_min_tu)) { sp--; continue; }                   // the tree goes no deeper here
-        s_child[sp] = 0;
-      }
-      if (s_child[sp] < 4) {
-        const int q = (parts >> (2 * d)) >> 2, kk = s_child[sp]++;
-        s_part[sp + 1] = part + kk * q; s_child[sp + 1] = -1;
-        sp++;
-        continue;
-      }
-      if (tid == 0) ic_fold_body(i, k, nd, A.res);
-      __syncthreads();
-      sp--;
-    }
-    if (tid == 0) ic_bits_body(sh1, 0, i, k, A.jobs, A.csyn, A.ctx_in, A.cu_in, A.res, A.icwork, A.ccoef, A.scans);
-    __syncthreads();
+    iw_chroma_mode(A, L, sh1, i, m);
     ic_keep_body(i, tid, 256, k, A.jobs, A.res, A.icwork, A.ccoef, A.rec_cb, A.rec_cr, pitch_c, A.coef_out, A.reco_c);
     __syncthreads();
   }
   ic_commit_body(i, tid, 256, k, A.icwork, A.res, A.cres, A.syn_out);
   __syncthreads();
-  // ---- getTotalDistortion, the CU's bits from the CI_CURR_BEST state, calcRdCost ----
-  if (tid == 0) {
-    A.dist[i] = A.sres[i].dist + A.cres[i].dist;
-    intra_cu_total_body(sh1, 0, i, k, A.jobs, A.syn_out, A.res, A.coef_out, A.ctx_in, A.cu_in, A.dist, A.bits, A.cost, A.ctx_out, A.cu_out, A.scans);
-  }
+  iw_total(A, sh1, i);
 }
 
-size_t hop_intra_walk_bytes(int log2_cu, int n) {
-  const size_t cu2 = (size_t)1 << (2 * log2_cu), n_coeff = (size_t)n * (6 * cu2 + 16);
-  return hop_intra_search_work_bytes(log2_cu, n) + hop_intra_chroma_work_bytes(log2_cu, n) + n_coeff * 4 +
-         (size_t)n * (4 * 4 + 8 + sizeof(hop_rdoq_job) + sizeof(hop_coeff_bits_job) + LEAF_WORK_PER_TU) + 96 * 256;
+// ---- the candidate passes side by side: k_iw_begin -> per PU (k_iw_cand over (CU, pass) -> k_iw_pick) -> k_iw_chroma over (CU, direction) -> k_iw_finish ----
+// the s x s block at (bx, by) of a plane with everything intra prediction inside it can reach -- the row above and the column to the left, each 2 s long, the corner, and the
+// (2 s)^2 samples they span (a transform unit inside the block reads, besides those, samples of the block itself: the candidate's own reconstruction where it has been
+// written, otherwise what the picture held before, exactly as when the candidate works in the picture) -- from the picture (its slot's copy: rows are counted inside the copy
+// of height ph) into a band
+__device__ static inline void iw_band_prepare(const int16_t* pic, int16_t* band, const int pitch, const int pw, const int ph, const int bx, const int by, const int s) {
+  const int yl = by % ph, side = 2 * s + 1;
+  for (int e = threadIdx.x; e < side * side; e += 256) {
+    const int r = e / side - 1, q = e % side - 1;                          // row / column relative to the block: -1 .. 2 s - 1
+    if (yl + r < 0 || yl + r >= ph || bx + q < 0 || bx + q >= pw) continue;
+    band[(ptrdiff_t)(by + r) * pitch + bx + q] = pic[(ptrdiff_t)(by + r) * pitch + bx + q];
+  }
+}
+// A with the arrays and pictures of virtual candidate v of CU i (whose job sits at picture row y0): the bodies called with index v then work on v's copies and band
+__device__ static inline IntraWalk iw_virtual(const IntraWalk& A, const int v, const int y0) {
+  IntraWalk B = A;
+  B.n = A.V; B.jobs = A.vjobs; B.syn = A.vsyn; B.csyn = A.vsyn; B.opt = A.vopt; B.tmp = A.vtmp; B.coef_tmp = A.vcoef_tmp; B.res = A.vres;
+  const ptrdiff_t pitch = A.pic.pic_w, pitch_c = A.pic.pic_w >> 1;
+  const ptrdiff_t sy = ((ptrdiff_t)v * A.hb + 1 - y0) * pitch, sc = ((ptrdiff_t)v * A.hbc + 1 - (y0 >> 1)) * pitch_c;
+  B.pic.pred_y = A.band_pred[0] + sy; B.pic.pred_cb = A.band_pred[1] + sc; B.pic.pred_cr = A.band_pred[2] + sc;
+  B.rec_y = A.band_rec[0] + sy; B.rec_cb = A.band_rec[1] + sc; B.rec_cr = A.band_rec[2] + sc;
+  return B;
+}
+
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_iw_begin(IntraWalk A) {
+  __shared__ WalkShared L;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) A.syn[i] = A.syn_in[i];
+  { uint32_t* z = (uint32_t*)(A.res + i); for (int e = tid; e < (int)(sizeof(hop_rqt_result) / 4); e += 256) z[e] = 0; }
+  __syncthreads();
+  iw_luma_prep(A, L, i, 0);
+}
+
+// grid (n, P): candidate `pass` of PU pu of CU i with bCheckFirst (:2507-2553), in a band of its own; the result stays in vtmp / vcoef_tmp / the band
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_iw_cand(IntraWalk A, int pu) {
+  __shared__ WalkShared L;
+  __shared__ CabacLds1 sh1;
+  const int i = blockIdx.x, pass = blockIdx.y, tid = threadIdx.x;
+  const int cnt = (int)A.mres[i].n, n_max = A.num_full_rd + 2;
+  if (pass >= cnt || pass >= n_max) return;
+  const int v = i * A.P + pass;
+  const hop_rqt_job jb = A.jobs[i];
+  if (tid == 0) { A.vjobs[v] = jb; hop_intra_cu_syntax y = A.syn[i]; y.luma_dir[pu] = (int)A.mres[i].modes[pass]; A.vsyn[v] = y; }
+  { const uint32_t* so = (const uint32_t*)(A.opt + i); uint32_t* dq = (uint32_t*)(A.vopt + v); for (int e = tid; e < (int)(sizeof(hop_intra_rqt_opt) / 4); e += 256) dq[e] = so[e]; }
+  const IntraWalk B = iw_virtual(A, v, jb.y);
+  const int cu = 1 << A.k.log2_cu, N = cu >> A.nxn, parts = 1 << (2 * (A.k.log2_cu - 2)), part = pu * (parts >> (2 * A.nxn));
+  iw_band_prepare(A.rec_y, B.rec_y, A.pic.pic_w, A.pic.pic_w, A.pic_h, jb.x + rqt_zx(part), jb.y + rqt_zy(part), N);
+  __syncthreads();
+  walk_intra_rqt(B, L, sh1, v, A.nxn, 1);
+}
+
+// the decisions over the candidate passes in their order (strict '<': the first of equal costs stays), the winner's arrays, levels and block kept (xSetIntraResultQT), then
+// the best mode again with the full tree and the PU's commit; the next PU's candidate list, or the chroma search's start
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_iw_pick(IntraWalk A, int pu) {
+  __shared__ WalkShared L;
+  __shared__ CabacLds1 sh1;
+  __shared__ int s_best;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const RqtClass k = A.k;
+  const int n_max = A.num_full_rd + 2, npu = A.nxn ? 4 : 1;
+  const int cnt = min((int)A.mres[i].n, n_max);
+  if (tid == 0) {
+    int best = 0; double bc = 1.7e+308;
+    for (int p = 0; p < cnt; p++) { const double c = A.vtmp[i * A.P + p].cost; if (c < bc) { bc = c; best = p; } }
+    s_best = best;
+  }
+  __syncthreads();
+  {
+    const int v = i * A.P + s_best;
+    const hop_rqt_job jb = A.jobs[i];
+    const IntraWalk B = iw_virtual(A, v, jb.y);
+    const int cu = 1 << k.log2_cu, parts = 1 << (2 * (k.log2_cu - 2)), q = parts >> (2 * A.nxn), part = pu * q, N = cu >> A.nxn, x0 = rqt_zx(part), y0 = rqt_zy(part);
+    const size_t cu2 = (size_t)cu * cu, cbi = (size_t)i * (cu2 + (cu2 >> 1)), cbv = (size_t)v * (cu2 + (cu2 >> 1));
+    IsWork* w = A.iswork + i; const hop_rqt_result* t = A.vtmp + v;
+    for (int e = tid; e < q; e += 256) { w->tr[part + e] = t->tr_idx[part + e]; w->cbf[part + e] = t->cbf[0][part + e]; w->ts[part + e] = t->tskip[0][part + e]; }
+    for (int e = tid; e < 16 * q; e += 256) A.coef_out[cbi + (size_t)16 * part + e] = A.vcoef_tmp[cbv + (size_t)16 * part + e];
+    const int16_t* pic = B.rec_y + (ptrdiff_t)(jb.y + y0) * A.pic.pic_w + jb.x + x0;
+    for (int e = tid; e < N * N; e += 256) { const int rr = e / N, cc = e % N; A.reco_y[(size_t)i * cu2 + (size_t)(y0 + rr) * cu + x0 + cc] = pic[(ptrdiff_t)rr * A.pic.pic_w + cc]; }
+    __syncthreads();
+    if (tid == 0) { w->best_cost = t->cost; w->best_dist = t->dist; w->best_mode = (int)A.mres[i].modes[s_best]; }
+    __syncthreads();
+  }
+  iw_luma_final(A, L, sh1, i, pu);
+  if (pu + 1 < npu) { iw_luma_prep(A, L, i, pu + 1); return; }
+  if (tid == 0) A.syn_out[i] = A.syn[i];
+}
+
+// grid (n, 5): direction m of the chroma search of CU i in bands of its own (both chroma planes), on a copy of the CU's arrays
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_iw_chroma(IntraWalk A) {
+  __shared__ WalkShared L;
+  __shared__ CabacLds1 sh1;
+  const int i = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+  const int v = i * A.P + m;
+  const hop_rqt_job jb = A.jobs[i];
+  if (tid == 0) { A.vjobs[v] = jb; A.vsyn[v] = A.syn_out[i]; }
+  { const uint32_t* so = (const uint32_t*)(A.opt + i); uint32_t* dq = (uint32_t*)(A.vopt + v); for (int e = tid; e < (int)(sizeof(hop_intra_rqt_opt) / 4); e += 256) dq[e] = so[e]; }
+  { const uint32_t* so = (const uint32_t*)(A.res + i); uint32_t* dq = (uint32_t*)(A.vres + v); for (int e = tid; e < (int)(sizeof(hop_rqt_result) / 4); e += 256) dq[e] = so[e]; }
+  const IntraWalk B = iw_virtual(A, v, jb.y);
+  const int cu = 1 << A.k.log2_cu, pw = A.pic.pic_w >> 1;
+  iw_band_prepare(A.rec_cb, B.rec_cb, pw, pw, A.pic_h >> 1, jb.x >> 1, jb.y >> 1, cu >> 1);
+  iw_band_prepare(A.rec_cr, B.rec_cr, pw, pw, A.pic_h >> 1, jb.x >> 1, jb.y >> 1, cu >> 1);
+  iw_zero_ccoef(B, v);
+  if (tid == 0) A.icwork[v].best_cost = 1.7e+308;                           // (a private record per direction: ic_bits_body leaves this direction's cost there)
+  __syncthreads();
+  iw_chroma_mode(B, L, sh1, v, m);                                         // (ic_mode_body resets the best cost for m == 0 only: the comparison below reads icwork[v].dist / the cost it forms)
+}
+
+// the decisions over the five directions in their order, xSetIntraResultChromaQT for the winner, the CU's totals
+__global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_iw_finish(IntraWalk A) {
+  __shared__ CabacLds1 sh1;
+  __shared__ int s_best;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const RqtClass k = A.k;
+  if (tid == 0) {
+    int best = 0; double bc = 1.7e+308;
+    for (int m = 0; m < 5; m++) { const double c = A.icwork[i * A.P + m].best_cost; if (c < bc) { bc = c; best = m; } }
+    s_best = best;
+  }
+  __syncthreads();
+  const int v = i * A.P + s_best;
+  const hop_rqt_job jb = A.jobs[i];
+  const IntraWalk B = iw_virtual(A, v, jb.y);
+  const int cu = 1 << k.log2_cu, half = cu >> 1, parts = 1 << (2 * (k.log2_cu - 2)), pitch_c = A.pic.pic_w >> 1;
+  const size_t cu2 = (size_t)cu * cu, h2 = cu2 >> 2;
+  const hop_rqt_result* r = A.vres + v;
+  hop_rqt_result* ro = A.res + i;
+  for (int e = tid; e < parts; e += 256) { ro->cbf[1][e] = r->cbf[1][e]; ro->cbf[2][e] = r->cbf[2][e]; ro->tskip[1][e] = r->tskip[1][e]; ro->tskip[2][e] = r->tskip[2][e]; }
+  for (int comp = 1; comp <= 2; comp++) {
+    for (int e = tid; e < (int)h2; e += 256) {                            // as ic_keep_body: chroma level e of the CU layout from the layer of its transform unit
+      const int p = e >> 2, d = r->tr_idx[p], log2 = k.log2_cu - d, dd = log2 == 2 ? d - 1 : d, np = parts >> (2 * dd), first = p - p % np;
+      A.coef_out[(size_t)i * (cu2 + 2 * h2) + cu2 + (size_t)(comp - 1) * h2 + e] = A.ccoef[rqt_coef_at(k, v, k.log2_max_tu - log2, comp, first) + (size_t)(e - 4 * first)];
+    }
+    const int16_t* pic = (comp == 1 ? B.rec_cb : B.rec_cr) + (ptrdiff_t)(jb.y >> 1) * pitch_c + (jb.x >> 1);
+    for (int e = tid; e < (int)h2; e += 256) { const int rr = e / half, cc = e % half; A.reco_c[(size_t)i * 2 * h2 + (size_t)(comp - 1) * h2 + e] = pic[(ptrdiff_t)rr * pitch_c + cc]; }
+  }
+  if (tid == 0) {
+    const IcWork* w = A.icwork + v;
+    A.cres[i].best_mode = w->mode; A.cres[i].dist = w->dist;
+    A.syn_out[i].chroma_is_dm = w->mode == 36; A.syn_out[i].chroma_dir = w->mode;
+  }
+  __syncthreads();
+  iw_total(A, sh1, i);
+}
+
+// candidates side by side (k_iw_*) unless HOP_WALK_CAND=0 or the bands would not fit the budget: P passes per candidate CU
+static int iw_passes(int num_full_rd) { const int n_max = num_full_rd + 2; return n_max > 5 ? n_max : 5; }
+static bool iw_parallel(const hop_ctx* c, int log2_cu, int n, int num_full_rd) {
+  static const bool on = !(getenv("HOP_WALK_CAND") && getenv("HOP_WALK_CAND")[0] == '0');
+  if (!on) return false;
+  const size_t V = (size_t)n * iw_passes(num_full_rd), cu = (size_t)1 << log2_cu;
+  const size_t bands = V * ((2 * cu + 2) * (size_t)c->pic_w * 2 * 2 + (cu + 2) * (size_t)(c->pic_w >> 1) * 2 * 4);
+  return bands <= ((size_t)6 << 30);
+}
+size_t hop_intra_walk_bytes(const hop_ctx* c, int log2_cu, int n, int num_full_rd) {
+  const bool par = iw_parallel(c, log2_cu, n, num_full_rd);
+  const size_t V = par ? (size_t)n * iw_passes(num_full_rd) : (size_t)n, cu = (size_t)1 << log2_cu, cu2 = cu * cu, n_coeff = V * (6 * cu2 + 16);
+  size_t b = hop_intra_search_work_bytes(log2_cu, (int)V) + hop_intra_chroma_work_bytes(log2_cu, (int)V) + n_coeff * 4 +
+             V * (4 * 4 + 8 + sizeof(hop_rdoq_job) + sizeof(hop_coeff_bits_job) + LEAF_WORK_PER_TU) + 128 * 256;
+  if (par) b += V * (sizeof(hop_rqt_job) + sizeof(hop_intra_cu_syntax) + sizeof(hop_intra_rqt_opt) + 2 * sizeof(hop_rqt_result) + (cu2 + (cu2 >> 1)) * 4) +
+                V * ((2 * cu + 2) * (size_t)c->pic_w * 2 * 2 + (cu + 2) * (size_t)(c->pic_w >> 1) * 2 * 4) + 16 * 256;
+  return b;
 }
 
 int hop_launch_intra_walk(hop_ctx* c, const hop_intra_class& q, const hop_cabac_ctx* d_ctx_in, const hop_cabac_cu_ctx* d_cu_in, void* vbuf, size_t buf_bytes) {
@@ -357,40 +555,62 @@ int hop_launch_intra_walk(hop_ctx* c, const hop_intra_class& q, const hop_cabac_
   RqtClass& k = A.k;
   k.log2_cu = cls->log2_cu; k.log2_max_tu = cls->log2_max_tu; k.log2_min_tu = cls->log2_min_tu_in_cu; k.inter_split = 0; k.sign_hide = cls->sign_hide ? 1 : 0; k.use_ts = cls->use_ts ? 1 : 0;
   const int n = q.n;
-  A.n = n; A.nxn = q.part_nxn ? 1 : 0; A.num_full_rd = q.num_full_rd; A.bd_y = c->bd_y; A.bd_c = c->bd_c; A.pic = hop_make_pics(c);
+  const bool par = iw_parallel(c, k.log2_cu, n, q.num_full_rd);
+  A.P = par ? iw_passes(q.num_full_rd) : 1; A.V = n * A.P;
+  const size_t V = (size_t)A.V;
+  A.n = n; A.nxn = q.part_nxn ? 1 : 0; A.num_full_rd = q.num_full_rd; A.bd_y = c->bd_y; A.bd_c = c->bd_c; A.pic = hop_make_pics(c); A.pic_h = c->pic_h;
   A.jobs = q.d_jobs; A.syn_in = q.d_syntax; A.opt = q.d_opts; A.sj = q.d_sjobs; A.ctx_in = d_ctx_in; A.cu_in = d_cu_in;
   A.sres = q.d_sresults; A.res = q.d_results; A.cres = q.d_cresults; A.coef_out = q.d_coef; A.reco_y = q.d_reco_y; A.reco_c = q.d_reco_c; A.syn_out = q.d_syntax_out;
   A.dist = q.d_dist; A.bits = q.d_bits; A.cost = q.d_cost; A.ctx_out = q.d_ctx_out; A.cu_out = q.d_cu_ctx_out;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t cu2 = (size_t)1 << (2 * k.log2_cu);
-  A.n_coeff = (size_t)n * (6 * cu2 + 16); A.ts_base = (size_t)n * 6 * cu2;
+  const size_t cu = (size_t)1 << k.log2_cu, cu2 = cu * cu;
+  A.n_coeff = V * (6 * cu2 + 16); A.ts_base = V * 6 * cu2;
   char* buf = (char*)vbuf; size_t o = 0;
   auto take = [&](size_t bytes) { char* p = buf + o; o = al(o + bytes); return p; };
   A.syn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax)); A.rj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job));
   A.mj = (hop_intra_modes_job*)take((size_t)n * sizeof(hop_intra_modes_job)); A.mres = (hop_intra_modes_result*)take((size_t)n * sizeof(hop_intra_modes_result));
   A.satd = (uint32_t*)take((size_t)n * 35 * 4); A.iswork = (IsWork*)take((size_t)n * sizeof(IsWork)); A.tmp = (hop_rqt_result*)take((size_t)n * sizeof(hop_rqt_result));
   A.coef_tmp = (int32_t*)take((size_t)n * (cu2 + (cu2 >> 1)) * 4); A.active = (uint8_t*)take((size_t)n);
-  A.cur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.cucur = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx));
+  A.csyn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax));
+  // per (virtual) candidate
+  A.cur = (hop_cabac_ctx*)take(V * sizeof(hop_cabac_ctx)); A.cucur = (hop_cabac_cu_ctx*)take(V * sizeof(hop_cabac_cu_ctx));
   for (int d = 0; d < 4; d++) {
-    A.root[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.curoot[d] = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx));
-    A.test[d] = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.cutest[d] = (hop_cabac_cu_ctx*)take((size_t)n * sizeof(hop_cabac_cu_ctx));
+    A.root[d] = (hop_cabac_ctx*)take(V * sizeof(hop_cabac_ctx)); A.curoot[d] = (hop_cabac_cu_ctx*)take(V * sizeof(hop_cabac_cu_ctx));
+    A.test[d] = (hop_cabac_ctx*)take(V * sizeof(hop_cabac_ctx)); A.cutest[d] = (hop_cabac_cu_ctx*)take(V * sizeof(hop_cabac_cu_ctx));
   }
-  A.irwork = (IrqWork*)take((size_t)n * sizeof(IrqWork)); A.pj = (hop_intra_job*)take((size_t)n * sizeof(hop_intra_job)); A.modes = (int32_t*)take((size_t)n * 4);
-  A.tuj = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job)); A.tuj2 = (hop_tu_rd_job*)take((size_t)n * sizeof(hop_tu_rd_job));
-  A.off = (int64_t*)take((size_t)n * 8); A.off2 = (int64_t*)take((size_t)n * 8);
-  A.tr = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result)); A.tr2 = (hop_tu_rd_result*)take((size_t)n * sizeof(hop_tu_rd_result));
-  A.coef = (int32_t*)take(A.n_coeff * 4); A.recl = (int16_t*)take((size_t)n * 4 * cu2 * 2); A.park = (int16_t*)take((size_t)n * 32);
-  A.ccur = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx)); A.croot = (hop_cabac_ctx*)take((size_t)n * sizeof(hop_cabac_ctx));
-  A.csyn = (hop_intra_cu_syntax*)take((size_t)n * sizeof(hop_intra_cu_syntax)); A.icwork = (IcWork*)take((size_t)n * sizeof(IcWork));
-  A.ccoef = (int32_t*)take(A.n_coeff * 4); A.cpark = (int16_t*)take((size_t)n * 32);
+  A.irwork = (IrqWork*)take(V * sizeof(IrqWork)); A.pj = (hop_intra_job*)take(V * sizeof(hop_intra_job)); A.modes = (int32_t*)take(V * 4);
+  A.tuj = (hop_tu_rd_job*)take(V * sizeof(hop_tu_rd_job)); A.tuj2 = (hop_tu_rd_job*)take(V * sizeof(hop_tu_rd_job));
+  A.off = (int64_t*)take(V * 8); A.off2 = (int64_t*)take(V * 8);
+  A.tr = (hop_tu_rd_result*)take(V * sizeof(hop_tu_rd_result)); A.tr2 = (hop_tu_rd_result*)take(V * sizeof(hop_tu_rd_result));
+  A.coef = (int32_t*)take(A.n_coeff * 4); A.recl = (int16_t*)take(V * 4 * cu2 * 2); A.park = (int16_t*)take(V * 32);
+  A.ccur = (hop_cabac_ctx*)take(V * sizeof(hop_cabac_ctx)); A.croot = (hop_cabac_ctx*)take(V * sizeof(hop_cabac_ctx));
+  A.icwork = (IcWork*)take(V * sizeof(IcWork));
+  A.ccoef = (int32_t*)take(A.n_coeff * 4); A.cpark = (int16_t*)take(V * 32);
   A.lcoef = (int32_t*)take(A.n_coeff * 4);
-  A.zs = (uint32_t*)take((size_t)n * 4); A.ns = (uint32_t*)take((size_t)n * 4); A.as = (uint32_t*)take((size_t)n * 4); A.fr = (unsigned long long*)take((size_t)n * 8);
-  A.rq = (hop_rdoq_job*)take((size_t)n * sizeof(hop_rdoq_job)); A.cb = (hop_coeff_bits_job*)take((size_t)n * sizeof(hop_coeff_bits_job));
-  A.lwork = take((size_t)n * LEAF_WORK_PER_TU);
+  A.zs = (uint32_t*)take(V * 4); A.ns = (uint32_t*)take(V * 4); A.as = (uint32_t*)take(V * 4); A.fr = (unsigned long long*)take(V * 8);
+  A.rq = (hop_rdoq_job*)take(V * sizeof(hop_rdoq_job)); A.cb = (hop_coeff_bits_job*)take(V * sizeof(hop_coeff_bits_job));
+  A.lwork = take(V * LEAF_WORK_PER_TU);
+  if (par) {
+    A.vjobs = (hop_rqt_job*)take(V * sizeof(hop_rqt_job)); A.vsyn = (hop_intra_cu_syntax*)take(V * sizeof(hop_intra_cu_syntax)); A.vopt = (hop_intra_rqt_opt*)take(V * sizeof(hop_intra_rqt_opt));
+    A.vtmp = (hop_rqt_result*)take(V * sizeof(hop_rqt_result)); A.vres = (hop_rqt_result*)take(V * sizeof(hop_rqt_result)); A.vcoef_tmp = (int32_t*)take(V * (cu2 + (cu2 >> 1)) * 4);
+    A.hb = (int)(2 * cu + 2); A.hbc = (int)(cu + 2);
+    const size_t by = V * A.hb * (size_t)c->pic_w * 2, bc = V * A.hbc * (size_t)(c->pic_w >> 1) * 2;
+    A.band_pred[0] = (int16_t*)take(by); A.band_pred[1] = (int16_t*)take(bc); A.band_pred[2] = (int16_t*)take(bc);
+    A.band_rec[0] = (int16_t*)take(by); A.band_rec[1] = (int16_t*)take(bc); A.band_rec[2] = (int16_t*)take(bc);
+  }
   if (o > buf_bytes) return hop_set_err(c, HOP_ERR_STATE, "intra walk: work buffer too small (%zu > %zu)", o, buf_bytes);
   A.entropy_bits = hop_entropy_bits_device(c); A.scans = c->rdoq_scans; A.rec_y = c->rec[0]; A.rec_cb = c->rec[1]; A.rec_cr = c->rec[2];
   const int pr = hop_prof_begin(c, A.nxn ? HOP_K_WALK_INTRA_NXN : HOP_K_WALK_INTRA + (k.log2_cu - 3), (uint64_t)n);
-  hipLaunchKernelGGL(k_intra_walk, dim3(n), dim3(256), 0, c->stream, A);
+  if (!par) hipLaunchKernelGGL(k_intra_walk, dim3(n), dim3(256), 0, c->stream, A);
+  else {
+    hipLaunchKernelGGL(k_iw_begin, dim3(n), dim3(256), 0, c->stream, A);
+    for (int pu = 0; pu < (A.nxn ? 4 : 1); pu++) {
+      hipLaunchKernelGGL(k_iw_cand, dim3(n, A.num_full_rd + 2), dim3(256), 0, c->stream, A, pu);
+      hipLaunchKernelGGL(k_iw_pick, dim3(n), dim3(256), 0, c->stream, A, pu);
+    }
+    hipLaunchKernelGGL(k_iw_chroma, dim3(n, 5), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_iw_finish, dim3(n), dim3(256), 0, c->stream, A);
+  }
   hop_prof_end(c, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hop_set_err(c, HOP_ERR_DEVICE, "intra walk launch: %s", hipGetErrorString(e));

@@ -150,3 +150,23 @@ def test_tiles_of_rank_partition_the_frame():
     assert len(set(seen)) == 64                       # 7 x 20 = 140 tiles in a frame: 8 ranks x 8 pictures are all different
     big = bench.tiles_of_rank(fw, fh, tw, th, 256, 1)  # 256 pictures per rank: rank 1 holds pictures 256..511 = frame 1 from tile 116 on, frame 2, frame 3 up to tile 91
     assert big[0] == (1, (116 % 7) * 1024, (116 // 7) * 256) and big[-1] == (3, (91 % 7) * 1024, (91 // 7) * 256) and len(set(big)) == 256
+
+
+def test_bench_step_arithmetic_and_view_split():
+    """bench.py's default mode: the ramp of a lag-5 wavefront (CTUs retired when the rows in flight first reach their maximum) and the round-robin split of BASELINE config
+    5's 169 views over the ranks"""
+    import bench
+    done, rif = bench.wavefront_ramp_ctus(121, 84, 5)              # the 7728x5368 frame: 121 x 84 CTUs
+    assert rif == 25 and done == sum(min(121, max(0, 120 - 5 * r)) for r in range(84))
+    done2, rif2 = bench.wavefront_ramp_ctus(121, 2, 5)             # a two-row band: both rows run after 5 CTUs
+    assert rif2 == 2 and done2 == 5
+    seen = []
+    for rank in range(8):
+        v = bench.views_of_rank(169, 8, rank)
+        assert all(x % 8 == rank for x in v) and len(v) in (21, 22)
+        seen += v
+    assert sorted(seen) == list(range(169))
+    Y, Cb, Cr = bench.view_planes(624, 432, 3, 9)
+    assert Y.shape == (432, 624) and Cb.shape == (216, 312) and Y.dtype == np.int16 and 0 <= Y.min() and Y.max() <= 255
+    Y2 = bench.view_planes(624, 432, 4, 9)[0]
+    assert not np.array_equal(Y, Y2)                                # neighbouring views differ (disparity + their own noise)

@@ -670,7 +670,8 @@ def encode_main(args):
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     deadline = t_proc + args.budget_s
     fw, fh = args.width, min(args.height, args.rows * 64)
-    Y, Cb, Cr = frame_planes(fw, args.height, 2 + rank)                      # frame `rank` of the synthetic sequence: the same lenslet geometry, another texture seed
+    shard = args.shard_rows and world > 1                                    # ONE picture over all ranks (its CTU rows dealt round-robin) instead of a picture per rank
+    Y, Cb, Cr = frame_planes(fw, args.height, 2 + (0 if shard else rank))    # frame `rank` of the synthetic sequence: the same lenslet geometry, another texture seed
     Y, Cb, Cr = np.ascontiguousarray(Y[:fh]), np.ascontiguousarray(Cb[:fh // 2]), np.ascontiguousarray(Cr[:fh // 2])
     timp.join()
     import torch
@@ -690,6 +691,8 @@ def encode_main(args):
     lag = min(args.lag, cols)
     ramp_ctus, rif = wavefront_ramp_ctus(cols, rows, lag)
     Q = args.step_ctus if args.step_ctus > 0 else cols
+    if shard:                                                                # hop_encode_progress counts the CTUs THIS rank retired: its share of a step, of the ramp
+        Q = max(1, Q // world); ramp_ctus = max(1, ramp_ctus // world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -711,6 +714,13 @@ def encode_main(args):
     ctx = hp.Context(fw, fh, device=local, slots=args.slots)
     ctx.upload_orig(Y, Cb, Cr)
     ctx.sync()
+    gather = None
+    if shard:
+        spec = importlib.util.spec_from_file_location("hop_shard", os.path.join(ROOT, "hevc-hop_amd", "shard.py"))
+        shm = importlib.util.module_from_spec(spec); spec.loader.exec_module(shm)
+        # RCCL between the GPUs of the node (gloo when ranks share a GPU in a rehearsal), on a process group of its own: the exchange runs beside this thread's barriers
+        gather = shm.TorchAllgather(None if shared else dev, group=dist.new_group(list(range(world))))
+        ctx.set_shard(rank, world, gather)
     barrier()
     t_setup = time.perf_counter() - t_proc
     # ---- the continuously running picture ----
@@ -783,13 +793,15 @@ def encode_main(args):
         out = {
             "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (RD search of TEncSlice::compressSlice; per-CTU RD costs checked against the reference encoder's cost.csv in `parity`)",
             "value": value, "unit": "CTU/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": (dt / steps_done * 1e3) if steps_done else None,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16+f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "i16+f64", "data": "synthetic",
             "config": {"workload": "synthetic lenslet %dx%d (pitch %d, tests/hoputil.py:lenslet seed 2 + rank), QP%d, coded as ONE picture per GPU with cfg/3DHencoder_intra_main.cfg semantics and --MIsize=%d "
                                    "(ISS slice, SS +-128 full search with FEN, half/quarter-pel, GT search, merge / AMVP / micro-image candidates, AMP, intra 35 modes with RQT, RDOQ, transform skip, "
                                    "CABAC-counted bits), WaveFrontSynchro with one substream per CTU row, rows as a lag-%d wavefront (at most %d rows in flight); the picture is coded continuously, "
                                    "a step = %d retired CTUs" % (fw, fh, PITCH, QP, PITCH, lag, rif, Q),
                        "picture": [fw, fh], "ctus_per_picture": n_ctu, "ctus_per_step": Q, "candidate_slots": args.slots, "rows_in_flight_max": rif,
-                       "parallelism": "one picture per GPU x%d GPUs (frames of the sequence; no data-path collective)" % world},
+                       "parallelism": ("ONE picture over %d GPUs: CTU rows dealt round-robin, every wavefront step's finished CTUs exchanged by an all-gather (%s; %d exchanges, %.1f MB "
+                                       "received per rank); ctus_per_step is a rank's share" % (world, "gloo, ranks share a GPU" if shared else "RCCL", gather.calls, gather.bytes / 1e6)) if shard else
+                                      "one picture per GPU x%d GPUs (frames of the sequence; no data-path collective)" % world},
             "timed_region": {"ctus": ctus_all, "seconds": dt, "ctus_retired_before": n0, "ramp_ctus": n_r, "ramp_s": t_r - run.t0, "warmup_ctus": n_w - n_r, "warmup_s": t_w - t_r,
                              "retired_total": retired, "budget_s": args.budget_s, "setup_s": t_setup,
                              "note": "steps requested %d; steps timed %d (a wall-clock budget measured from process start ends the timed region early)" % (args.steps, steps_done)},
@@ -804,12 +816,13 @@ def encode_main(args):
             "cpu_baseline": extras.get("cpu_baseline"),
         }
     ctx.close()
+    if gather is not None: gather.close()
     if rank == 0:
         try: open(os.path.join(ROOT, "gpurun_out", "bench_last.json"), "w").write(json.dumps(out))      # (kept in case the optional pass below is cut short)
         except Exception: pass
     # ---- the second workload (BASELINE config 5), when the wall-clock budget still has room for it: all ranks, each with its share of the views ----
     t_left = t_proc + args.total_s - time.perf_counter()
-    want_views = args.views > 0 and t_left > args.views_min_s
+    want_views = args.views > 0 and t_left > args.views_min_s and not shard
     if world > 1:
         wv = torch.tensor([1 if want_views else 0], dtype=torch.int64, device="cpu" if shared else dev)
         dist.all_reduce(wv, op=dist.ReduceOp.MIN)
@@ -857,6 +870,8 @@ def main():
     ap.add_argument("--ramp-frac", type=float, default=0.55, help="at most this share of the time left when the picture starts goes into the ramp")
     ap.add_argument("--slots", type=int, default=16, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
+    ap.add_argument("--shard-rows", action="store_true", help="--gpus N > 1: ONE picture over all ranks, its CTU rows dealt round-robin with a hand-off after every wavefront step "
+                                                               "(hop_encode_set_shard; strong scaling) instead of one picture per rank")
     ap.add_argument("--profile-w", type=int, default=1024); ap.add_argument("--profile-h", type=int, default=64)
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[256, 192], help="crop (from the middle of the frame) the reference CPU encoder is timed on")
     ap.add_argument("--cpu-budget-s", type=float, default=60.0)

@@ -50,6 +50,7 @@ struct hop_ctx {
   // the levels of the pictures as the reference keeps them (TComDataCU::m_pcTrCoeffY / Cb / Cr): per 64x64 CTU of the (stacked) picture 4096 + 1024 + 1024 TCoeff, a CU's at
   // 16 x / 4 x its partition index; one such image per candidate slot; and their part of the stash slots.  Allocated by hop_encode_frame.
   int32_t* coefpic; int32_t* coef_stash;
+  int shard_rank, shard_world; hop_allgather_fn shard_fn; void* shard_user;   // hop_encode_set_shard: the next hop_encode_frame codes the CTU rows r % world == rank of its picture
   std::atomic<long> enc_progress; std::atomic<int> enc_cancel;   // hop_encode_progress / hop_encode_cancel: CTUs the running hop_encode_frame has retired; a request to stop it
   uint16_t* rd_fraction; int rd_fraction_n;   // host: hop_encode_frame's per-CTU carried fraction of the RD coder (hop_rd_fraction_download)
   bool   is_view;                    // hop_ctx_create_view: pictures, tables and stash belong to the parent; stream, scratch areas and profiling are its own

@@ -79,6 +79,50 @@ __global__ __launch_bounds__(256) void k_turd_fused(const hop_tu_rd_job* __restr
 struct LeafSmallShared { TurdSmallShared t; CabacLds1 cab; uint16_t scan[64]; uint16_t scanCG[4]; double cgSig[4];
                          double work[64 * RQ_WORK_PER_COEF / 8]; hop_estbits eb; int32_t src[64], lev[64], ebits[128]; uint8_t ctx[152]; };   // everything the serial walk touches
 
+// The same body for the candidate walks (k_walk.inl): up to four small transform units of one tree node side by side, one per WAVE of the 256-thread workgroup, each with
+// its own LeafSmallShared.  Every wave calls (the barriers are the workgroup's); a wave without a unit passes j < 0 and only keeps step.
+__device__ static void turd_fused_small_wave_body(LeafSmallShared& L, const int lane, const int j, const hop_tu_rd_job* jobs, int n, hop_pics pic, const hop_cabac_ctx* ctx_in,
+                                                  const int64_t* coef_off, const int32_t* entropy_bits, const uint16_t* scans, int32_t* coef, int32_t* levels, uint32_t* zs, uint32_t* ns,
+                                                  uint32_t* as, unsigned long long* fr, hop_rdoq_job* rq, hop_coeff_bits_job* cb, hop_tu_rd_result* res, int16_t* rec_y, int16_t* rec_cb,
+                                                  int16_t* rec_cr) {
+  hop_tu_rd_job jb; jb.log2_size = 0; jb.scan_idx = 0; jb.ctx_index = 0;
+  if (j >= 0) jb = jobs[j];
+  const bool live = j >= 0 && jb.log2_size >= 2 && jb.log2_size <= 3;      // (uniform over the wave)
+  const int LOG2 = live ? jb.log2_size : 2, N2 = 1 << (2 * LOG2), CGN = N2 >> 4;
+  int64_t off = 0;
+  if (live) {
+    turd_forward_small_body(L.t, 0, lane, j, jobs, n, pic, coef_off, coef, zs);
+    const uint16_t* s0 = rq_scan(scans, jb.scan_idx, LOG2); const uint16_t* s1 = rq_scan_cg(scans, jb.scan_idx, LOG2);
+    if (lane < N2) L.scan[lane] = s0[lane];
+    if (lane < CGN) L.scanCG[lane] = s1[lane];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (live) {
+    off = coef_off[j];
+    if (lane < N2) L.src[lane] = coef[off + lane];
+    const uint8_t* st = ctx_in[jb.ctx_index].state; for (int i = lane; i < 152; i += 64) { const uint8_t v = st[i]; L.ctx[i] = v; L.cab.st[i][0] = v; }
+    for (int i = lane; i < 128; i += 64) L.ebits[i] = entropy_bits[i];
+  }
+  __syncthreads();
+  if (live && lane == 0) {
+    turd_setup_body(j, jobs, n, ctx_in, coef_off, L.ebits, &L.eb, rq, cb, L.ctx);
+    const hop_rdoq_job rj = rq[j];
+    if (LOG2 == 2) rdoq_tu<2>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, L.work, 1, 0);
+    else rdoq_tu<3>(rj, &L.eb, L.scan, L.scanCG, L.cgSig, 1, L.src, L.lev, as + j, L.work, 1, 0);
+    const hop_coeff_bits_job bj = cb[j];
+    fr[j] = cb_code_tu_at(L.cab, 0, L.lev, bj.log2_size, bj.comp != 0, bj.scan_idx, bj.sign_hide, bj.use_ts, bj.ts_flag, bj.cbf_ctx_plus1, L.scan, L.scanCG);
+  }
+  __syncthreads();
+  if (live && lane < N2) levels[off + lane] = L.lev[lane];
+  __threadfence_block();
+  __syncthreads();
+  if (live) turd_inverse_small_body(L.t, 0, lane, j, jobs, n, pic, coef_off, levels, as, ns, rec_y, rec_cb, rec_cr);
+  __threadfence_block();
+  __syncthreads();
+  if (live && lane == 0) turd_decide_body(j, jobs, n, ctx_in, coef_off, entropy_bits, as, fr, zs, ns, levels, res);
+}
+
 __global__ __launch_bounds__(64) void k_turd_fused_small(const hop_tu_rd_job* __restrict__ jobs, int n, hop_pics pic, const hop_cabac_ctx* __restrict__ ctx_in,
                                                          const int64_t* __restrict__ coef_off, const int32_t* __restrict__ entropy_bits, const uint16_t* __restrict__ scans,
                                                          int32_t* __restrict__ coef, int32_t* __restrict__ levels, uint32_t* __restrict__ zs, uint32_t* __restrict__ ns,

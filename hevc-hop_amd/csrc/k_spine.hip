@@ -292,6 +292,28 @@ class HipBackend : public BatchInner {
   void recon_save(int lane, int slot, int x, int y, int size) { on_device(); Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 0)); }
   void recon_restore(int lane, int slot, int x, int y, int size) { on_device(); Tick t(7); const int32_t r[4] = { x, y, size, lane * 16 + slot }; BK(hop_recon_stash(c, 1, r, 1)); }
   void commit(int, int x, int y, int size) { on_device(); Tick t(8); const int32_t r[4] = { x, y, size, 0 }; BK(hop_ssref_commit_recon(c, 1, r)); }
+  // a picture coded by several ranks (hop_encode_set_shard): a CTU's block of the reconstruction picture out to the host, and a block another rank coded in -- into the
+  // reconstruction picture and, as the commits of its CUs would have, into the SS reference
+  void export_block(int x, int y, int w, int h, int16_t* py, int16_t* pcb, int16_t* pcr) {
+    on_device();
+    const size_t P = (size_t)c->pic_w, PC = P / 2;
+    BH(hipMemcpy2DAsync(py, (size_t)w * 2, c->rec[0] + (size_t)y * P + x, P * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
+    BH(hipMemcpy2DAsync(pcb, (size_t)w, c->rec[1] + (size_t)(y / 2) * PC + x / 2, PC * 2, (size_t)w, h / 2, hipMemcpyDeviceToHost, c->stream));
+    BH(hipMemcpy2DAsync(pcr, (size_t)w, c->rec[2] + (size_t)(y / 2) * PC + x / 2, PC * 2, (size_t)w, h / 2, hipMemcpyDeviceToHost, c->stream));
+    BH(hipStreamSynchronize(c->stream));
+  }
+  void import_block(int x, int y, int w, int h, const int16_t* py, const int16_t* pcb, const int16_t* pcr) {
+    on_device();
+    const size_t P = (size_t)c->pic_w, PC = P / 2;
+    BH(hipMemcpy2DAsync(c->rec[0] + (size_t)y * P + x, P * 2, py, (size_t)w * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, c->stream));
+    BH(hipMemcpy2DAsync(c->rec[1] + (size_t)(y / 2) * PC + x / 2, PC * 2, pcb, (size_t)w, (size_t)w, h / 2, hipMemcpyHostToDevice, c->stream));
+    BH(hipMemcpy2DAsync(c->rec[2] + (size_t)(y / 2) * PC + x / 2, PC * 2, pcr, (size_t)w, (size_t)w, h / 2, hipMemcpyHostToDevice, c->stream));
+    std::vector<int32_t> r;
+    if (w == 64 && h == 64) { const int32_t q[4] = { x, y, 64, 0 }; r.assign(q, q + 4); }
+    else for (int yy = y; yy < y + h; yy += 8) for (int xx = x; xx < x + w; xx += 8) { const int32_t q[4] = { xx, yy, 8, 0 }; r.insert(r.end(), q, q + 4); }
+    BK(hop_ssref_commit_recon(c, (int)(r.size() / 4), r.data()));
+    BH(hipStreamSynchronize(c->stream));
+  }
 
   void pred_cost(int, int n, const hop_pred_job* jobs, int kind, uint32_t* out) { pred_cost_n(1, &n, jobs, &kind, out); }
   // every sequence walked in order by a workgroup of ONE launch (k_pred_cost); one synchronisation at the end
@@ -443,6 +465,11 @@ int hop_encode_progress(hop_ctx* c, int64_t* ctus_retired) {
   return HOP_OK;
 }
 int hop_encode_cancel(hop_ctx* c) { if (!c) return HOP_ERR_ARG; c->enc_cancel.store(1); return HOP_OK; }
+int hop_encode_set_shard(hop_ctx* c, int rank, int world, hop_allgather_fn fn, void* user) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_set_shard: rank %d of %d", rank, world);
+  c->shard_rank = rank; c->shard_world = world; c->shard_fn = fn; c->shard_user = user;
+  return HOP_OK;
+}
 void hop_encode_stats(double ms[16], double calls[16]) { memcpy(ms, g_stat_ms, sizeof(g_stat_ms)); memcpy(calls, g_stat_calls, sizeof(g_stat_calls)); }
 
 // One picture through the RD spine on the device: the original must be resident (hop_upload_orig).  Afterwards the reconstruction picture (hop_recon_download) holds the
@@ -462,6 +489,12 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   c->enc_progress.store(0); c->enc_cancel.store(0);
   cfg.progress = &c->enc_progress; cfg.cancel = &c->enc_cancel;
   if (c->slots > 0 && !p->plain_intra) { cfg.spec_slots = c->slots; cfg.slot_pitch = c->pic_h; }   // hop_ctx_set_slots: the SS/GT candidates of a CU side by side
+  struct FnComm : hopspine::ShardComm { hop_ctx* c; void allgather(const void* s, void* r, size_t b) { if (c->shard_fn(c->shard_user, s, r, b) != 0) { hop_set_err(c, HOP_ERR_STATE, "hop_encode_frame: the all-gather callback failed"); throw Bail{ HOP_ERR_STATE }; } } } comm;
+  comm.c = c;
+  if (c->shard_world > 1) {
+    if (p->wavefront_lag <= 0 || n_pic != 1 || p->streams > 1) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: a sharded picture (hop_encode_set_shard) is ONE picture coded as a wavefront with batched requests");
+    cfg.shard_rank = c->shard_rank; cfg.shard_world = c->shard_world; cfg.shard = &comm;
+  }
   if (p->wavefront_lag > 0 && p->first_ctus > 0) return hop_set_err(c, HOP_ERR_ARG, "hop_encode_frame: first_ctus applies to the raster-order mode");
   {                                                                      // the images of the levels (one per candidate slot) and their part of the stash
     const size_t ctus = (size_t)((c->pic_w + 63) >> 6) * ((c->pic_h + 63) >> 6), want = ctus * (c->slots + 1) * COEF_PER_CTU * 4;
@@ -471,6 +504,7 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
     HIPCHK(c, hipMemsetAsync(c->coefpic, 0, want, c->stream));
     if (!c->coef_stash) HIPCHK(c, hipMalloc((void**)&c->coef_stash, (size_t)STASH_SLOTS * COEF_PER_CTU * 4));
   }
+  hopspine::posted_requests_allowed = false;                             // (see hop_spine.h)
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
   if (c->slots > 0 && p->wavefront_lag > 0 && !p->plain_intra) {         // candidates side by side: their evaluation chains of one round on streams of their own

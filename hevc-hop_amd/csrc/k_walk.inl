@@ -15,6 +15,7 @@
 // At the compiler's free choice they take 256 registers per lane -- two workgroups fill a compute unit's register files, and a few hundred candidates in flight the whole
 // chip; capped at 128 (four waves per SIMD) a compute unit holds four and still has room.
 #define WALK_WAVES_PER_SIMD 4
+#define WALK_PARALLEL_LEAVES 0
 struct InterWalk {
   RqtClass k; int n, bd_y, bd_c; hop_pics pic;
   const hop_rqt_job* jobs; const hop_cu_syntax* syn; const hop_cabac_ctx* ctx_in; const hop_cabac_cu_ctx* cu_in;
@@ -58,8 +59,53 @@ __device__ static void walk_recon_jobs(LeafShared& L, const int first, const int
   __syncthreads();
 }
 
+// the transform units of one node of an SS/GT candidate (its Y / Cb / Cr blocks in tuj, their 4x4 transform-skip variants in tuj2; candidate i's slots 3 i ..): the 16x16 /
+// 32x32 ones one after the other on the whole workgroup, the 4x4 / 8x8 ones four at a time, a wave each.  None of them writes a picture (residual-domain distortion), so they
+// are independent; the transform-skip variants use the second half of the scratch tables
+struct InterLeafShared { union { LeafShared big; LeafSmallShared small[4]; } u; };
+__device__ static void walk_inter_leaves(const InterWalk& A, InterLeafShared& L, const int i, const int d, const int ncomp, const int nts) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n3 = 3 * A.n;
+  for (int c = 0; c < ncomp; c++) {
+    if (A.tuj[3 * i + c].log2_size <= 3) continue;                      // (uniform over the workgroup)
+    turd_fused_body(L.u.big, 3 * i + c, A.tuj, n3, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr,
+                    A.rec_y, A.rec_cb, A.rec_cr);
+    __syncthreads();
+  }
+#if !WALK_PARALLEL_LEAVES
+  // (one after the other: the wave-per-unit form below faulted on the device -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the first run, cause not found yet -- and stays
+  // compiled out)
+  for (int c = 0; c < ncomp; c++) {
+    if (A.tuj[3 * i + c].log2_size > 3) continue;
+    turd_fused_body(L.u.big, 3 * i + c, A.tuj, n3, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr,
+                    A.rec_y, A.rec_cb, A.rec_cr);
+    __syncthreads();
+  }
+  for (int t = 0; t < nts; t++) {
+    turd_fused_body(L.u.big, 3 * i + t, A.tuj2, n3, A.pic, A.root[d], A.off2, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs + n3, A.ns + n3, A.as + n3, A.fr + n3, A.rq + n3, A.cb + n3,
+                    A.lwork, A.tr2, A.rec_y, A.rec_cb, A.rec_cr);
+    __syncthreads();
+  }
+  (void)wave; (void)lane;
+  return;
+#endif
+  // the small ones: list position q = 0 .. ncomp + nts - 1 -> (table, slot)
+  const int total = ncomp + nts;
+  for (int q0 = 0; q0 < total; q0 += 4) {
+    const int q = q0 + wave;
+    const bool ts = q >= ncomp;
+    int j = -1;
+    if (q < total) { j = 3 * i + (ts ? q - ncomp : q); if (!ts && A.tuj[j].log2_size > 3) j = -1; }
+    if (!ts) turd_fused_small_wave_body(L.u.small[wave], lane, j, A.tuj, n3, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.tr,
+                                        A.rec_y, A.rec_cb, A.rec_cr);
+    else turd_fused_small_wave_body(L.u.small[wave], lane, j, A.tuj2, n3, A.pic, A.root[d], A.off2, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs + n3, A.ns + n3, A.as + n3, A.fr + n3,
+                                    A.rq + n3, A.cb + n3, A.tr2, A.rec_y, A.rec_cb, A.rec_cr);
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_inter_walk(InterWalk A) {
-  __shared__ LeafShared L;
+  __shared__ InterLeafShared IL;
+  LeafShared& L = IL.u.big;
   __shared__ CabacLds1 sh1;
   const int i = blockIdx.x, tid = threadIdx.x;
   const RqtClass k = A.k;
@@ -81,16 +127,7 @@ __global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_inter_walk(InterWa
       if (tid == 0) rqt_begin_body(i, k, nd, A.jobs, A.bd_y, A.bd_c, A.cur, A.root[d], A.res, A.work, A.tuj + sh_c, A.off + sh_c, A.tuj2 + sh_t, A.off2 + sh_t, A.ts_base);
       __syncthreads();
       if (nd.check_full) {
-        for (int c = 0; c < ncomp; c++) {
-          turd_fused_body(L, 3 * i + c, A.tuj, 3 * A.n, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr,
-                          A.rec_y, A.rec_cb, A.rec_cr);
-          __syncthreads();
-        }
-        for (int t = 0; t < nts; t++) {
-          turd_fused_body(L, 3 * i + t, A.tuj2, 3 * A.n, A.pic, A.root[d], A.off2, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr2,
-                          A.rec_y, A.rec_cb, A.rec_cr);
-          __syncthreads();
-        }
+        walk_inter_leaves(A, IL, i, d, ncomp, nts);
         if (tid == 0) rqt_single_body(sh1, 0, i, k, nd, A.jobs, A.cur, A.root[d], A.test[d], A.res, A.work, A.tr + sh_c, A.tr2 + sh_t, A.coef, A.ts_base, A.scans);
         __syncthreads();
       }
@@ -128,7 +165,7 @@ size_t hop_inter_walk_bytes(int log2_cu, int log2_max_tu, int log2_min_tu, int n
   const size_t cu2 = (size_t)1 << (2 * log2_cu), n_coeff = (size_t)n * (6 * cu2 + 48);
   int d0, d1; const int nj = rqt_jobs_per_cu(log2_cu, log2_max_tu, log2_min_tu, &d0, &d1);
   return hop_rqt_work_bytes(log2_cu, n) + (size_t)n * nj * (sizeof(hop_tu_rd_job) + 8 + 4 + 4) + n_coeff * 4 +
-         (size_t)3 * n * (4 * 4 + 8 + sizeof(hop_rdoq_job) + sizeof(hop_coeff_bits_job) + LEAF_WORK_PER_TU) + 64 * 256;
+         (size_t)3 * n * (2 * (4 * 4 + 8 + sizeof(hop_rdoq_job) + sizeof(hop_coeff_bits_job)) + LEAF_WORK_PER_TU) + 64 * 256;
 }
 
 // n candidates of one class through k_inter_walk; every pointer a device pointer; buf = hop_inter_walk_bytes
@@ -155,8 +192,8 @@ int hop_launch_inter_walk(hop_ctx* c, const hop_rqt_job* cls, int n, const hop_r
   A.tr = (hop_tu_rd_result*)take((size_t)3 * n * sizeof(hop_tu_rd_result)); A.tr2 = (hop_tu_rd_result*)take((size_t)3 * n * sizeof(hop_tu_rd_result));
   A.coef = (int32_t*)take(A.n_coeff * 4);
   A.lcoef = (int32_t*)take(A.n_coeff * 4);
-  A.zs = (uint32_t*)take((size_t)3 * n * 4); A.ns = (uint32_t*)take((size_t)3 * n * 4); A.as = (uint32_t*)take((size_t)3 * n * 4); A.fr = (unsigned long long*)take((size_t)3 * n * 8);
-  A.rq = (hop_rdoq_job*)take((size_t)3 * n * sizeof(hop_rdoq_job)); A.cb = (hop_coeff_bits_job*)take((size_t)3 * n * sizeof(hop_coeff_bits_job));
+  A.zs = (uint32_t*)take((size_t)6 * n * 4); A.ns = (uint32_t*)take((size_t)6 * n * 4); A.as = (uint32_t*)take((size_t)6 * n * 4); A.fr = (unsigned long long*)take((size_t)6 * n * 8);
+  A.rq = (hop_rdoq_job*)take((size_t)6 * n * sizeof(hop_rdoq_job)); A.cb = (hop_coeff_bits_job*)take((size_t)6 * n * sizeof(hop_coeff_bits_job));   // (second halves: the transform-skip variants)
   A.lwork = take((size_t)3 * n * LEAF_WORK_PER_TU);
   A.nj = rqt_jobs_per_cu(k.log2_cu, k.log2_max_tu, k.log2_min_tu, &A.d0, &A.d1);
   const size_t nt = (size_t)n * A.nj;
@@ -533,8 +570,8 @@ __global__ __launch_bounds__(256, WALK_WAVES_PER_SIMD) void k_iw_finish(IntraWal
 // candidates side by side (k_iw_*) unless HOP_WALK_CAND=0 or the bands would not fit the budget: P passes per candidate CU
 static int iw_passes(int num_full_rd) { const int n_max = num_full_rd + 2; return n_max > 5 ? n_max : 5; }
 static bool iw_parallel(const hop_ctx* c, int log2_cu, int n, int num_full_rd) {
-  static const bool on = !(getenv("HOP_WALK_CAND") && getenv("HOP_WALK_CAND")[0] == '0');
-  if (!on) return false;
+  const char* e = getenv("HOP_WALK_CAND");                               // developer switch (read per call: the tests flip it)
+  if (e && e[0] == '0') return false;
   const size_t V = (size_t)n * iw_passes(num_full_rd), cu = (size_t)1 << log2_cu;
   const size_t bands = V * ((2 * cu + 2) * (size_t)c->pic_w * 2 * 2 + (cu + 2) * (size_t)(c->pic_w >> 1) * 2 * 4);
   return bands <= ((size_t)6 << 30);

@@ -346,6 +346,14 @@ class Context:
         self.L.hop_encode_cancel.argtypes = [ctypes.c_void_p]
         self._chk(self.L.hop_encode_cancel(self.h), "hop_encode_cancel")
 
+    def set_shard(self, rank, world, allgather=None):
+        """hop_encode_set_shard: the next encode_frame (wavefront mode) codes the CTU rows r % world == rank of ONE picture and exchanges every step's finished CTUs through
+        `allgather` (an object with a ctypes callback .fn of type shard.ALLGATHER_FN, e.g. shard.TorchAllgather); every rank ends with the whole picture"""
+        self.L.hop_encode_set_shard.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self._shard = allgather                      # (keeps the callback alive)
+        fn = ctypes.cast(allgather.fn, ctypes.c_void_p) if allgather is not None else None
+        self._chk(self.L.hop_encode_set_shard(self.h, rank, world, fn, None), "hop_encode_set_shard")
+
     def levels_download(self):
         """hop_levels_download: (n_ctu, 6144) int32 -- per CTU 4096 luma + 1024 Cb + 1024 Cr levels in the reference's TComDataCU layout"""
         n = ((self.W + 63) // 64) * ((self.sub_h + 63) // 64) * self.pictures

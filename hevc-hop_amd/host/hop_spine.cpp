@@ -30,6 +30,8 @@
 
 namespace hopspine {
 
+bool posted_requests_allowed = true;
+
 static const double MAX_DOUBLE = 1.7e+308;           // TLibCommon/CommonDef.h
 static const uint32_t MAX_UINT = 0xFFFFFFFFu;
 static const int CTU = 64;
@@ -1033,7 +1035,7 @@ void CtuWorker::compress_ctu(int addr, const Coder& entry, Coder& exit) {
 Encoder::Encoder(const EncConfig& cfg, Backend* be) : trace(NULL), n_candidates(0), cfg_(cfg), be_(be) {
   wctu_ = (cfg.pic_w + 63) / 64; hctu_ = (cfg.pic_h + 63) / 64;
   ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0); ctu_rd_fraction.assign(n_ctu(), 0); ctu_trace.resize(n_ctu()); batch_rounds = batch_requests = 0;
-  pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu()); committed.assign((size_t)(cfg.pic_w >> 3) * (cfg.pic_h >> 3), 0);
+  pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu()); ctu_exit.resize(n_ctu()); committed.assign((size_t)(cfg.pic_w >> 3) * (cfg.pic_h >> 3), 0);
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
 }
 
@@ -1222,14 +1224,15 @@ asm(".text\n.globl hop_fiber_switch\n.type hop_fiber_switch,@function\nhop_fiber
 class FiberPool : public Backend {
  public:
   struct Fiber { void* sp; char* stack; std::function<void()> body; bool done; Req* req; int wait_step; int worker; FiberPool* pool;
-                 Fiber* parent; int live_children; bool wait_children; uint64_t tag; };   // parent: a child of fork_join (recycled when done)
+                 Fiber* parent; int live_children; bool wait_children; uint64_t tag;      // parent: a child of fork_join (recycled when done)
+                 std::atomic<int>* wait_ctr; int wait_target; };                        // waiting until *wait_ctr >= wait_target
   FiberPool(BatchInner* inner, int n_workers) : rounds(0), requests(0), steps_complete(-1), inner_(inner), T_(n_workers), failed_(false), finished_(false), arrived_(0), gen_(0), left_(0), idle_rounds_(0) {
     sched_.resize(T_); mine_.resize(T_); local_.resize(T_); free_.resize(T_); kids_.resize(T_); pstore_.resize(T_); pjobs_.resize(T_);
   }
   ~FiberPool() { for (Fiber* f : all_) { stack_free(f->stack); delete f; } for (auto& v : kids_) for (Fiber* f : v) { stack_free(f->stack); delete f; } }
   void add(std::function<void()> body) {
     Fiber* f = new Fiber(); f->stack = stack_alloc(); f->body = body; f->done = false; f->req = NULL; f->wait_step = -1; f->worker = (int)(all_.size() % T_); f->pool = this;
-    f->parent = NULL; f->live_children = 0; f->wait_children = false; f->tag = 0;
+    f->parent = NULL; f->live_children = 0; f->wait_children = false; f->tag = 0; f->wait_ctr = NULL; f->wait_target = 0;
     all_.push_back(f); mine_[f->worker].push_back(f); left_++;
   }
   // fn(0) ... fn(n - 1) as fibers of their own on the caller's worker; the caller goes on when all have ended
@@ -1245,6 +1248,7 @@ class FiberPool : public Backend {
       else { f = new Fiber(); f->stack = stack_alloc(); kids_[w].push_back(f); }
       f->body = [&fn, i]() { fn(i); };
       f->done = false; f->req = NULL; f->wait_step = -1; f->worker = w; f->pool = this; f->parent = me; f->live_children = 0; f->wait_children = false; f->tag = me->tag;
+      f->wait_ctr = NULL; f->wait_target = 0;
       start(f);
       mine_[w].push_back(f);
     }
@@ -1271,6 +1275,12 @@ class FiberPool : public Backend {
   void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
+  void wait_counter(std::atomic<int>* ctr, int target) {                // until *ctr >= target (another fiber counts it up)
+    if (ctr->load() >= target) return;
+    Fiber* f = current(); f->wait_ctr = ctr; f->wait_target = target;
+    hop_fiber_switch(&f->sp, sched_[f->worker]);
+    if (failed_) throw 1;
+  }
   void wait_step(int st) {                                              // until every wavefront step <= st is finished
     if (steps_complete.load() >= st) return;
     Fiber* f = current(); f->wait_step = st;
@@ -1343,6 +1353,7 @@ class FiberPool : public Backend {
         if (f->req) { if (!f->req->done && !failed_) continue; f->req = NULL; }
         else if (f->wait_step >= 0) { if (steps_complete.load() < f->wait_step && !failed_) continue; f->wait_step = -1; }
         else if (f->wait_children) { if (f->live_children > 0) continue; f->wait_children = false; }
+        else if (f->wait_ctr) { if (f->wait_ctr->load() < f->wait_target && !failed_) continue; f->wait_ctr = NULL; }
         current() = f;
         hop_fiber_switch(&sched_[w], f->sp);                            // until it submits, waits or ends
         ran = true;
@@ -1472,7 +1483,7 @@ class FiberPool : public Backend {
  public:
   void print_round_stats() { if (!getenv("HOP_SPINE_ROUND_STATS")) return; for (auto& kv : round_masks_) fprintf(stderr, "hop spine rounds: kinds %03x x %llu\n", kv.first, (unsigned long long)kv.second); }
  private:
-  bool posted_mode_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); return e && atoi(e) != 0; }();
+  bool posted_mode_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); return e && atoi(e) != 0 && posted_requests_allowed; }();
   std::vector<std::deque<Req> > pstore_; std::vector<std::deque<std::vector<hop_pred_job> > > pjobs_;   // per worker: what was posted since the last serve (deques: addresses stay)
   std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
@@ -1510,14 +1521,24 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
     if (threads > 0) T = threads;
     if (const char* e = getenv("HOP_SPINE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) T = v; }
     if (T > rows * n_pic) T = rows * n_pic;
+    // one picture's rows dealt to several ranks (EncConfig::shard): this process runs the rows r % world == rank and a fiber that, after every wavefront step, exchanges the
+    // step's finished CTUs with the other ranks
+    const int world = (E0.cfg_.shard_world > 1 && E0.cfg_.shard) ? E0.cfg_.shard_world : 1, rank = world > 1 ? E0.cfg_.shard_rank : 0;
+    if (world > 1 && (n_pic != 1 || rank < 0 || rank >= world)) throw 1;
+    auto owned = [&](int r) { return world == 1 || r % world == rank; };
+    if (world > 1) { int mine = 0; for (int r = 0; r < rows; r++) mine += owned(r); if (T > mine + 1) T = mine + 1; if (T < 1) T = 1; }
     FiberPool pool(inner, T);
     if (E0.cfg_.spec_slots > 0) pool.tag_shift = 20;
     const int n_steps = cols + lag * (rows - 1);
     std::vector<int> in_step(n_steps, 0), fin_step(n_steps, 0);
-    for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) in_step[c + lag * r] += n_pic;
+    for (int r = 0; r < rows; r++) if (owned(r)) for (int c = 0; c < cols; c++) in_step[c + lag * r] += n_pic;
     std::vector<Coder> sync((size_t)rows * n_pic);
     std::vector<uint64_t> cand((size_t)rows * n_pic, 0);
+    std::vector<std::atomic<int> > fin_ctr(world > 1 ? n_steps : 0);     // sharded: the step's finished local CTUs (the exchange fiber waits on it)
+    for (auto& a : fin_ctr) a.store(0);
+    std::atomic<int> agreed_cancel(0);                                   // sharded: a cancel request every rank has seen (set after an exchange)
     for (int p = 0; p < n_pic; p++) for (int r = 0; r < rows; r++) {
+      if (!owned(r)) continue;
       pool.add([&, p, r]() {
         Encoder& E = *encs[p];
         const int lane = lane_base + p * (rif < rows ? rif : rows) + r % rif;
@@ -1528,8 +1549,9 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
           for (; c < cols; c++) {
             const int st = c + lag * r;
             pool.wait_step(st - 1);
-            if (E.cfg_.cancel && E.cfg_.cancel->load()) {                 // hop_encode_cancel: this row stops here; nobody waits for the CTUs it leaves uncoded
+            if (world > 1 ? agreed_cancel.load() != 0 : (E.cfg_.cancel && E.cfg_.cancel->load())) {   // hop_encode_cancel: this row stops here; nobody waits for the CTUs it leaves uncoded
               std::lock_guard<std::mutex> g(pool.steps_m);
+              if (world > 1) { for (; c < cols; c++) fin_ctr[c + lag * r].fetch_add(1); break; }
               for (; c < cols; c++) fin_step[c + lag * r]++;
               int sc = pool.steps_complete.load();
               while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
@@ -1544,6 +1566,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
             if (E.cfg_.progress) E.cfg_.progress->fetch_add(1);
             std::lock_guard<std::mutex> g(pool.steps_m);
             if (c == 1) sync[(size_t)p * rows + r] = k;
+            if (world > 1) { E.ctu_exit[a] = k; fin_ctr[st].fetch_add(1); continue; }   // (the exchange fiber moves steps_complete on)
             fin_step[st]++;
             int sc = pool.steps_complete.load();
             while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
@@ -1551,10 +1574,13 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
           }
         } catch (...) {
           std::lock_guard<std::mutex> g(pool.steps_m);
-          for (; c < cols; c++) fin_step[c + lag * r]++;               // after a failure: nobody waits for this row
-          int sc = pool.steps_complete.load();
-          while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
-          pool.steps_complete.store(sc);
+          if (world > 1) { for (; c < cols; c++) fin_ctr[c + lag * r].fetch_add(1); }
+          else {
+            for (; c < cols; c++) fin_step[c + lag * r]++;               // after a failure: nobody waits for this row
+            int sc = pool.steps_complete.load();
+            while (sc + 1 < n_steps && fin_step[sc + 1] == in_step[sc + 1]) sc++;
+            pool.steps_complete.store(sc);
+          }
           cand[(size_t)p * rows + r] = w->n_cand_; delete w;
           throw;
         }
@@ -1562,6 +1588,51 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
         delete w;
       });
     }
+    // the exchange fiber: step after step, once this rank's CTUs of the step are finished -- their records out, everybody's in (an all-gather of equally sized slot tables:
+    // slot 0 of a rank carries its cancel request), the other ranks' CTUs written into the picture on this side, then the next step may start
+    struct ShardRec { int32_t addr, valid; double cost; uint32_t bits, dist; uint32_t frac, pad; Coder entry, exit; Part parts[256]; int16_t y[4096], cb[1024], cr[1024]; };
+    if (world > 1) pool.add([&]() {
+      Encoder& E = E0;
+      const EncConfig& cfg = E.cfg_;
+      auto count_of = [&](int g, int s) { int n = 0; for (int r = g; r < rows; r += world) { const int c = s - lag * r; n += (c >= 0 && c < cols); } return n; };
+      std::vector<ShardRec> sendb, recvb;
+      for (int s = 0; s < n_steps; s++) {
+        pool.wait_counter(&fin_ctr[s], in_step[s]);
+        int slots = 0; for (int g = 0; g < world; g++) slots = std::max(slots, count_of(g, s));
+        sendb.assign((size_t)slots + 1, ShardRec()); recvb.resize((size_t)world * (slots + 1));
+        memset(&sendb[0], 0, sizeof(ShardRec) * sendb.size());
+        sendb[0].addr = -1; sendb[0].valid = (cfg.cancel && cfg.cancel->load()) ? 1 : 0;
+        int q = 1;
+        for (int r = rank; r < rows; r += world) {
+          const int c = s - lag * r; if (c < 0 || c >= cols) continue;
+          const int a = r * cols + c, x = c * CTU, y = r * CTU, w = std::min(CTU, cfg.pic_w - x), h = std::min(CTU, cfg.pic_h - y);
+          ShardRec& t = sendb[q++];
+          t.addr = a; t.valid = 1; t.cost = E.ctu_cost[a]; t.bits = E.ctu_bits[a]; t.dist = E.ctu_dist[a]; t.frac = E.ctu_rd_fraction[a]; t.entry = E.ctu_entry[a]; t.exit = E.ctu_exit[a];
+          memcpy(t.parts, &E.pic[(size_t)a * 256], sizeof(t.parts));
+          inner->export_block(x, y + cfg.y_origin, w, h, t.y, t.cb, t.cr);
+        }
+        cfg.shard->allgather(&sendb[0], &recvb[0], sizeof(ShardRec) * sendb.size());
+        bool any_cancel = false;
+        for (int g = 0; g < world; g++) {
+          const ShardRec* rr = &recvb[(size_t)g * (slots + 1)];
+          any_cancel |= rr[0].valid != 0;
+          if (g == rank) continue;
+          for (int k2 = 1; k2 <= slots; k2++) {
+            const ShardRec& t = rr[k2];
+            if (!t.valid) continue;
+            const int a = t.addr, c = a % cols, r = a / cols, x = c * CTU, y = r * CTU, w = std::min(CTU, cfg.pic_w - x), h = std::min(CTU, cfg.pic_h - y);
+            if (a < 0 || a >= E.n_ctu() || r % world != g) throw 1;
+            E.ctu_cost[a] = t.cost; E.ctu_bits[a] = t.bits; E.ctu_dist[a] = t.dist; E.ctu_rd_fraction[a] = (uint16_t)t.frac; E.ctu_entry[a] = t.entry; E.ctu_exit[a] = t.exit;
+            memcpy(&E.pic[(size_t)a * 256], t.parts, sizeof(t.parts));
+            for (int yy = y >> 3; yy < (y + h) >> 3; yy++) memset(&E.committed[(size_t)yy * (cfg.pic_w >> 3) + (x >> 3)], 1, w >> 3);
+            if (c == 1) { std::lock_guard<std::mutex> gd(pool.steps_m); sync[r] = t.exit; }
+            inner->import_block(x, y + cfg.y_origin, w, h, t.y, t.cb, t.cr);
+          }
+        }
+        if (any_cancel) { agreed_cancel.store(1); pool.steps_complete.store(n_steps - 1); break; }   // every rank has seen it at this step: the rows stop at their next CTU
+        pool.steps_complete.store(s);
+      }
+    });
     const std::chrono::steady_clock::time_point run_t0 = std::chrono::steady_clock::now();
     pool.run(); pool.print_round_stats();
     const double run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count();

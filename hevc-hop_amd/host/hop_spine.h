@@ -36,6 +36,13 @@ struct EncConfig {
   // wavefront mode, both optional: *progress counts the CTUs whose compressCU has returned (all pictures together); once *cancel is non-zero no row starts another CTU
   // (the CTUs in flight finish; the results of the finished CTUs are valid, the others stay 0) -- hop_encode_progress / hop_encode_cancel
   std::atomic<long>* progress; std::atomic<int>* cancel;
+  // ONE picture's CTU rows dealt to several processes (WaveFrontSynchro semantics, TEncSlice.cpp:1027-1051, :1158-1161): rank g of shard_world codes the rows r
+  // with r % shard_world == g as its part of the lag-5 wavefront.  After every wavefront step all ranks exchange the CTUs they have just finished through `shard` (an
+  // all-gather: per CTU its reconstruction 64 x 64 x 1.5, its partition data, cost / bits / distortion, the coder it started from and the coder it left -- the row's context
+  // snapshot after its second CTU is that --): every rank then holds the whole picture so far (reconstruction and SS reference on its device, partition data on its host), and
+  // the next step's CTUs find their neighbours, search windows and contexts as in a single process.  shard_world <= 1: off.  A cancel request is agreed on through the same
+  // exchange, so that all ranks leave the wavefront at the same step.
+  int shard_rank, shard_world; struct ShardComm* shard;
   // derived by finish_config()
   double lambda, sqrt_lambda, lambda_rdoq[3], dist_weight[2];
   uint32_t lambda_sad;
@@ -45,6 +52,14 @@ void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size)
 void default_plain_config(EncConfig& c, int pic_w, int pic_h, int qp, int bit_depth);   // cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg: I slice, no SS / GT
 void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
 
+// HOP_SPINE_POSTED=1 (requests without an answer do not stop their row) is an experiment of the CPU spine: a backend that serves a batch of posted predictions with ONE launch
+// cannot keep two posted predictions of one block in their order, so the device backend clears this before it runs (measured there without it: no gain at the breadth of one
+// picture, whose rounds are not what its time is made of -- DESIGN.md section 5)
+extern bool posted_requests_allowed;
+struct ShardComm {                 // what the caller provides for a picture coded by several ranks (RCCL / gloo / shared memory behind it)
+  virtual ~ShardComm() {}
+  virtual void allgather(const void* send, void* recv, size_t bytes_per_rank) = 0;     // recv: shard_world * bytes_per_rank, rank k's contribution at k * bytes_per_rank
+};
 enum { SPINE_LANES = 2048 };       // CTU rows in flight at once (all pictures together); a lane owns 16 stash slots
 typedef hop_cu_part Part;          // one 4x4 unit of the CU data (TComDataCU's per-partition arrays)
 
@@ -99,6 +114,11 @@ class Backend {
   virtual void recon_save(int lane, int slot, int x, int y, int size) = 0;
   virtual void recon_restore(int lane, int slot, int x, int y, int size) = 0;
   virtual void commit(int lane, int x, int y, int size) = 0;                             // reconstruction picture -> SS reference (xCopyYuv2SSRef)
+  // a picture coded by several ranks (EncConfig::shard): the w x h block at (x, y) of the reconstruction picture (w, h multiples of 8: a CTU's part inside the picture) out as
+  // packed planes (w * h luma, then the caller's Cb and Cr arrays of w/2 * h/2), and back in on another rank -- into the reconstruction picture AND the SS reference (the
+  // commit of every CU of the CTU, xCopyYuv2SSRef)
+  virtual void export_block(int /*x*/, int /*y*/, int /*w*/, int /*h*/, int16_t* /*y_out*/, int16_t* /*cb_out*/, int16_t* /*cr_out*/) { throw 1; }
+  virtual void import_block(int /*x*/, int /*y*/, int /*w*/, int /*h*/, const int16_t* /*y_in*/, const int16_t* /*cb_in*/, const int16_t* /*cr_in*/) { throw 1; }
   // fn(0) ... fn(n - 1), each issuing requests of its own: a backend that batches runs them side by side (their requests then meet in the batches), the others one
   // after the other -- the answers, and so the results, are the same
   virtual void fork_join(int n, const std::function<void(int)>& fn) { for (int i = 0; i < n; i++) fn(i); }
@@ -187,6 +207,7 @@ class Encoder {
   std::vector<uint16_t> ctu_rd_fraction;             // the go-on coder's carried fraction (m_fracBits & 32767) when each CTU's compressCU returns
   std::vector<Part>     pic;                         // 256 parts per CTU, z-order
   std::vector<Coder>    ctu_entry;                   // coder at the start of every CTU
+  std::vector<Coder>    ctu_exit;                    // ... and the coder it left (a picture coded by several ranks: what travels to the others; the row's second CTU's is the WaveFrontSynchro snapshot)
   FILE* trace;                                       // optional: one line per candidate that reaches xCheckBestMode (written CTU by CTU in raster order)
   uint64_t n_candidates;
   std::vector<std::string> ctu_trace;                // the lines of each CTU while the picture is in flight

@@ -671,6 +671,15 @@ int hop_encode_frame(hop_ctx* ctx, const hop_enc_params* params, double* ctu_cos
  * CTUs (cost, bits and distortion of the others stay 0).  What bench.py's steps are made of: a step is a fixed number of retired CTUs of one continuously running picture. */
 int hop_encode_progress(hop_ctx* ctx, int64_t* ctus_retired);
 int hop_encode_cancel(hop_ctx* ctx);
+/* ONE picture on several GPUs (the CTU rows of TEncSlice::compressSlice's loop under WaveFrontSynchro, TEncSlice.cpp:1027-1051, dealt to ranks): after
+ * hop_encode_set_shard(ctx, rank, world, fn, user) the next hop_encode_frame (wavefront mode, one picture, the same original resident on every rank) codes the rows
+ * r % world == rank.  After every wavefront step the ranks hand each other what the step finished -- per CTU its reconstruction block, partition data, costs and the row's
+ * coder states -- through fn, an all-gather the CALLER provides (RCCL or gloo behind it; all ranks call it the same number of times with equal sizes): recv holds world
+ * contributions of bytes_per_rank, rank k's at k * bytes_per_rank; host pointers; return 0 on success.  Every rank ends with the whole picture (reconstruction and SS
+ * reference on its device, all outputs of hop_encode_frame), equal to the single-GPU result.  hop_encode_cancel on any rank is agreed on through the same exchange.
+ * world = 1 (fn may be NULL) switches it off again. */
+typedef int (*hop_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int hop_encode_set_shard(hop_ctx* ctx, int rank, int world, hop_allgather_fn fn, void* user);
 /* diagnostics of the last hop_encode_frame of this process: host wall time (ms) and number of requests per kind -- 0 ME chain, 1 predictor, 2 distortion, 3 validity
  * probes, 4 SS/GT candidates with residual, 5 without, 6 intra candidates, 7 reconstruction stash, 8 SS-reference commits */
 void hop_encode_stats(double ms[16], double calls[16]);

@@ -258,8 +258,8 @@ int hop_o_rdoq(const int32_t* src, int32_t* dst, int log2_size, int comp, int is
   errScale = errScale * pow(2.0, -2.0 * transformShift);
   const double dTemp = errScale / q / q / (1 << (2 * (bit_depth - 8)));
 
-  static double costCoeff[32 * 32], costSig[32 * 32], costCoeff0[32 * 32];
-  static int rateIncUp[32 * 32], rateIncDown[32 * 32], sigRateDelta[32 * 32], deltaU[32 * 32];
+  static __thread double costCoeff[32 * 32], costSig[32 * 32], costCoeff0[32 * 32];
+  static __thread int rateIncUp[32 * 32], rateIncDown[32 * 32], sigRateDelta[32 * 32], deltaU[32 * 32];
   memset(costCoeff, 0, sizeof(double) * maxNumCoeff);
   memset(costSig, 0, sizeof(double) * maxNumCoeff);
   memset(rateIncUp, 0, sizeof(int) * maxNumCoeff);

@@ -8,6 +8,8 @@
 #include <map>
 #include <vector>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <chrono>
 #include <atomic>
 #include "../hevc-hop_amd/host/hop_spine.h"
@@ -225,6 +227,16 @@ class CpuBackend : public BatchInner {
     std::vector<int16_t> b[3]; cu_planes(rec, x, y, size, b);
     hop_o_ssref_commit_cu(ss[0].p00, ss[1].p00, ss[2].p00, W, H, x, y, size, &b[0][0], &b[1][0], &b[2][0]);
   }
+  // a picture coded by several ranks: a CTU's block out of / into the reconstruction picture (and, coming in, into the SS reference: 8x8 commits cover any w x h)
+  void export_block(int x, int y, int w, int h, int16_t* py, int16_t* pcb, int16_t* pcr) {
+    for (int r = 0; r < h; r++) memcpy(py + (size_t)r * w, &rec[0][(size_t)(y + r) * W + x], (size_t)w * 2);
+    for (int r = 0; r < h / 2; r++) { memcpy(pcb + (size_t)r * (w / 2), &rec[1][(size_t)(y / 2 + r) * (W / 2) + x / 2], (size_t)w); memcpy(pcr + (size_t)r * (w / 2), &rec[2][(size_t)(y / 2 + r) * (W / 2) + x / 2], (size_t)w); }
+  }
+  void import_block(int x, int y, int w, int h, const int16_t* py, const int16_t* pcb, const int16_t* pcr) {
+    for (int r = 0; r < h; r++) memcpy(&rec[0][(size_t)(y + r) * W + x], py + (size_t)r * w, (size_t)w * 2);
+    for (int r = 0; r < h / 2; r++) { memcpy(&rec[1][(size_t)(y / 2 + r) * (W / 2) + x / 2], pcb + (size_t)r * (w / 2), (size_t)w); memcpy(&rec[2][(size_t)(y / 2 + r) * (W / 2) + x / 2], pcr + (size_t)r * (w / 2), (size_t)w); }
+    for (int yy = y; yy < y + h; yy += 8) for (int xx = x; xx < x + w; xx += 8) commit(0, xx, yy, 8);
+  }
   int W, H, bd;
   std::vector<int32_t> coefpic;                                            // the levels, per slot and CTU 6144 TCoeff in the reference's layout (hop_levels_download)
   std::map<int, std::vector<int32_t> > coef_stash;
@@ -305,6 +317,79 @@ long hop_spine_cpu_encode_wpp(int w, int h, int qp, int mi_size, int lag, const 
   if (rounds_requests) { rounds_requests[0] = (double)enc.batch_rounds; rounds_requests[1] = (double)enc.batch_requests; }
   return (long)enc.n_candidates;
 }
+// ---- one picture's CTU rows dealt to several ranks (EncConfig::shard) ----
+// (a) `world` ranks as threads of this process, each with a backend (a "device") of its own, exchanging through an in-process all-gather: every rank must end with the whole
+//     picture, equal to hop_spine_cpu_encode_wpp's; out: rank `take`'s view (costs, partition data, reconstruction)
+namespace {
+struct LocalComm : public ShardComm {
+  LocalComm(int world) : world(world), arrived(0), gen(0) {}
+  struct Port : public ShardComm { LocalComm* hub; int rank; void allgather(const void* s, void* r, size_t b) { hub->gather(rank, s, r, b); } };
+  void gather(int rank, const void* send, void* recv, size_t bytes) {
+    std::unique_lock<std::mutex> lk(m);
+    if (buf.size() < (size_t)world * bytes) buf.resize((size_t)world * bytes);
+    memcpy(&buf[(size_t)rank * bytes], send, bytes);
+    const unsigned long my = gen;
+    if (++arrived == world) { arrived = 0; ready = buf; gen++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != my; });
+    memcpy(recv, &ready[0], (size_t)world * bytes);
+  }
+  void allgather(const void*, void*, size_t) {}
+  int world, arrived; unsigned long gen; std::mutex m; std::condition_variable cv; std::vector<char> buf, ready;
+};
+}
+long hop_spine_cpu_encode_sharded(int w, int h, int qp, int mi_size, int lag, int world, int take, int cancel_after, const int16_t* y, const int16_t* cb, const int16_t* cr,
+                                  double* ctu_cost, uint32_t* ctu_bits, uint32_t* ctu_dist, void* parts, int16_t* rec_y, int16_t* rec_cb, int16_t* rec_cr, long* retired_per_rank) {
+  LocalComm hub(world);
+  std::vector<LocalComm::Port> ports(world);
+  std::vector<CpuBackend*> bes; std::vector<Encoder*> encs;
+  std::vector<std::atomic<long> > prog(world); std::vector<std::atomic<int> > canc(world);
+  const int slots = spec_slots_env();
+  for (int g = 0; g < world; g++) {
+    ports[g].hub = &hub; ports[g].rank = g; prog[g].store(0); canc[g].store(0);
+    EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1; cfg.spec_slots = slots; cfg.slot_pitch = h;
+    cfg.shard_rank = g; cfg.shard_world = world; cfg.shard = &ports[g]; cfg.progress = &prog[g]; cfg.cancel = &canc[g];
+    bes.push_back(new CpuBackend(w, h, 8, y, cb, cr, slots)); encs.push_back(new Encoder(cfg, bes[g]));
+  }
+  std::atomic<int> stop(0);
+  std::thread watcher([&]() { while (!stop.load()) { if (cancel_after > 0 && prog[0].load() >= cancel_after) canc[0].store(1); std::this_thread::sleep_for(std::chrono::microseconds(200)); } });
+  std::vector<std::thread> th; std::vector<int> ok(world, 1);
+  for (int g = 0; g < world; g++) th.emplace_back([&, g]() { try { encs[g]->encode_frame_wavefront(bes[g], lag); } catch (...) { ok[g] = 0; } });
+  for (auto& t : th) t.join();
+  stop.store(1); watcher.join();
+  long rc = 0;
+  for (int g = 0; g < world; g++) { if (!ok[g]) rc = -1; if (retired_per_rank) retired_per_rank[g] = prog[g].load(); }
+  Encoder& e = *encs[take]; CpuBackend& b = *bes[take];
+  const int n = e.n_ctu();
+  if (ctu_cost) memcpy(ctu_cost, &e.ctu_cost[0], n * sizeof(double));
+  if (ctu_bits) memcpy(ctu_bits, &e.ctu_bits[0], n * 4);
+  if (ctu_dist) memcpy(ctu_dist, &e.ctu_dist[0], n * 4);
+  if (parts) memcpy(parts, &e.pic[0], e.pic.size() * sizeof(Part));
+  if (rec_y) memcpy(rec_y, &b.rec[0][0], (size_t)w * h * 2);
+  if (rec_cb) memcpy(rec_cb, &b.rec[1][0], (size_t)(w / 2) * (h / 2) * 2);
+  if (rec_cr) memcpy(rec_cr, &b.rec[2][0], (size_t)(w / 2) * (h / 2) * 2);
+  if (rc == 0) for (int g = 0; g < world; g++) rc += (long)encs[g]->n_candidates;
+  for (auto e2 : encs) delete e2;
+  for (auto b2 : bes) delete b2;
+  return rc;
+}
+// (b) one rank of a real job (tests/test_multi_rank.py: two processes on gloo): the all-gather is the caller's
+typedef int (*hop_cpu_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+namespace { struct CallbackComm : public ShardComm { hop_cpu_allgather_fn fn; void* user; void allgather(const void* s, void* r, size_t b) { if (fn(user, s, r, b) != 0) throw 1; } }; }
+long hop_spine_cpu_encode_shard_rank(int w, int h, int qp, int mi_size, int lag, int rank, int world, hop_cpu_allgather_fn fn, void* user, const int16_t* y, const int16_t* cb,
+                                     const int16_t* cr, double* ctu_cost, void* parts, int16_t* rec_y) {
+  CallbackComm comm; comm.fn = fn; comm.user = user;
+  EncConfig cfg; default_hop_config(cfg, w, h, qp, mi_size); cfg.wpp = 1;
+  cfg.shard_rank = rank; cfg.shard_world = world; cfg.shard = &comm;
+  CpuBackend be(w, h, 8, y, cb, cr, 0);
+  Encoder enc(cfg, &be);
+  try { enc.encode_frame_wavefront(&be, lag); } catch (...) { return -1; }
+  const int n = enc.n_ctu();
+  if (ctu_cost) memcpy(ctu_cost, &enc.ctu_cost[0], n * sizeof(double));
+  if (parts) memcpy(parts, &enc.pic[0], enc.pic.size() * sizeof(Part));
+  if (rec_y) memcpy(rec_y, &be.rec[0][0], (size_t)w * h * 2);
+  return (long)enc.n_candidates;
+}
+
 // A stack of independent pictures (what hop_ctx_set_stack makes of a context): every request goes to its own picture's backend, its coordinates back in that
 // picture's own frame.  The default n-forms of BatchInner loop over the single forms below, so a batch that mixes pictures is split here.
 class StackRouter : public BatchInner {

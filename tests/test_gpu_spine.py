@@ -189,3 +189,56 @@ def test_bench_frame_top_rows_equal_the_reference_encoders_cost_csv():
     c2 = out["r"][0]; done = c2 > 0
     assert 8 <= int(done.sum()) == ctx.encode_progress() < 242 and np.array_equal(c2[done], g["cost"][done])
     ctx.close()
+
+
+def test_one_picture_ctu_rows_over_two_contexts_equal_the_reference():
+    """SURVEY 8(e) on the device: hop_encode_set_shard -- ONE picture (448x192, lag-5 wavefront, candidate slots) coded by two ranks, here two contexts on the one GPU driven by
+    two threads, rank g taking the CTU rows r % 2 == g; every wavefront step's finished CTUs (reconstruction block, partition data, costs, coder states) cross through the
+    all-gather callback (hevc-hop_amd/shard.py:ThreadAllgather; torch.distributed's RCCL all-gather sits behind the same callback in bench.py --shard-rows).  Both ranks must
+    end with the whole picture: costs, partition data and reconstruction equal the reference encoder's WaveFrontSynchro run, and the two SS references / reconstructions are
+    the same samples."""
+    import importlib.util, threading
+    hp = _hp()
+    spec = importlib.util.spec_from_file_location("hop_shard", os.path.join(ROOT, "hevc-hop_amd", "shard.py"))
+    sh = importlib.util.module_from_spec(spec); spec.loader.exec_module(sh)
+    W, H, seed, lag = 448, 192, 3, 5
+    Y, Cb, Cr = frame(W, H, seed, False)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    key = key_of(W, H, seed, False) + "_wpp"
+    ag = sh.ThreadAllgather(2, timeout=300.0)
+    ctxs, out, err = [], [None, None], [None, None]
+    for k in range(2):
+        c = hp.Context(W, H, slots=16); c.upload_orig(Y, Cb, Cr); c.set_shard(k, 2, ag.rank(k)); ctxs.append(c)
+
+    def run(k):
+        try: out[k] = ctxs[k].encode_frame(32, 16, 0, None, wpp=1, wavefront_lag=lag)
+        except BaseException as e:
+            err[k] = e; ag.barrier.abort()
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert err == [None, None], err
+    cols, rows = (W + 63) // 64, (H + 63) // 64
+    assert [ag.rank(k).calls for k in range(2)] == [cols + lag * (rows - 1)] * 2
+    assert [c.encode_progress() for c in ctxs] == [cols * len(range(k, rows, 2)) for k in range(2)]      # each rank coded exactly its rows
+    recs = []
+    for k in range(2):
+        cost, bits, dist, parts, nc = out[k]
+        assert np.array_equal(cost, G[key + "/cost"]) and np.array_equal(bits, G[key + "/bits"]) and np.array_equal(dist, G[key + "/dist"]), k
+        R = G[key + "/parts"]
+        for a in range(R.shape[0]):
+            r, q = R[a], parts[a]
+            used = r[:, 1] != 15
+            for name, col in (("depth", 0), ("pred_mode", 1), ("part_size", 2), ("skip", 3), ("merge_flag", 4), ("merge_idx", 5), ("gt_flag", 6), ("tr_idx", 9)):
+                assert np.array_equal(np.asarray(q[name])[used].astype(np.int16), r[used, col]), (k, a, name)
+        recs.append([ctxs[k].recon_download(p) for p in range(3)])
+    for p in range(3):
+        assert np.array_equal(recs[0][p], recs[1][p])
+    _, _, _, _, rec, _, _ = run_cpu_wpp(spine_cpu(), W, H, Y, Cb, Cr, lag)
+    for p in range(3):
+        assert np.array_equal(recs[0][p], rec[p])
+    # switched off again: the context codes whole pictures as before
+    ctxs[0].set_shard(0, 1, None)
+    cost = ctxs[0].encode_frame(32, 16, 0, None, wpp=1, wavefront_lag=lag)[0]
+    assert np.array_equal(cost, G[key + "/cost"])
+    for c in ctxs: c.close()

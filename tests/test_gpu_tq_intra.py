@@ -1150,11 +1150,16 @@ def test_inter_cu_skip_encoder_calls(hp):
     ctx.close()
 
 
-def test_intra_cu_device_classes_vs_staged_entries(hp):
+def test_intra_cu_device_classes_vs_staged_entries(hp, monkeypatch):
     """hop_intra_cu_device_classes (whole intra candidates device-resident: luma search -> chroma search -> distortion -> bits and cost, classes on separate streams) on the
     random CUs of the search tests: every output equals what the three host-array entries give stage by stage (those are checked against the restatement above), the
-    syntax elements it hands back carry the decided directions and their most probable modes"""
+    syntax elements it hands back carry the decided directions and their most probable modes.
+    The random availability tables of these cases are deliberately NOT causal (a node may be told that samples inside its own CU, not coded yet, are available: it then reads
+    what the previous candidate pass left in the picture).  The walk that evaluates a PU's candidates side by side (k_iw_*: every candidate in a band of its own, started from
+    the picture as it was before any candidate) equals the candidate-after-candidate forms only for causal tables -- what an encoder produces; that form is pinned by
+    tests/test_gpu_spine.py against the reference encoder's decisions.  Here the walk runs its candidates one after the other (HOP_WALK_CAND=0)."""
     import torch
+    monkeypatch.setenv("HOP_WALK_CAND", "0")
     bd = 8
     W, H, Y, R, jobs, syn, opts, cfgs, snaps, cus, avs = _irqt_random_cases(hp, hp.load(), bd)
     n = len(jobs); mid = 1 << (bd - 1)

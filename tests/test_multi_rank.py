@@ -170,3 +170,53 @@ def test_bench_step_arithmetic_and_view_split():
     assert Y.shape == (432, 624) and Cb.shape == (216, 312) and Y.dtype == np.int16 and 0 <= Y.min() and Y.max() <= 255
     Y2 = bench.view_planes(624, 432, 4, 9)[0]
     assert not np.array_equal(Y, Y2)                                # neighbouring views differ (disparity + their own noise)
+
+
+def _shard_worker(rank, world, port, W, H, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    from hoputil import lenslet
+    from test_spine_cpu import PART_DT, spine_cpu
+    spec = importlib.util.spec_from_file_location("hop_shard", os.path.join(ROOT, "hevc-hop_amd", "shard.py"))
+    sh = importlib.util.module_from_spec(spec); spec.loader.exec_module(sh)
+    ag = sh.TorchAllgather(None)                                   # gloo: host tensors straight through
+    L = spine_cpu()
+    L.hop_spine_cpu_encode_shard_rank.restype = ctypes.c_long
+    L.hop_spine_cpu_encode_shard_rank.argtypes = [ctypes.c_int] * 7 + [ctypes.c_void_p] * 8
+    Y, Cb, Cr = [np.ascontiguousarray(p, np.int16) for p in lenslet(W, H, 16, seed)]
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(n, np.float64); parts = np.zeros((n, 256), PART_DT); rec = np.zeros((H, W), np.int16)
+    nc = L.hop_spine_cpu_encode_shard_rank(W, H, 32, 16, 5, rank, world, ctypes.cast(ag.fn, ctypes.c_void_p), None, Y.ctypes.data, Cb.ctypes.data, Cr.ctypes.data,
+                                           cost.ctypes.data, parts.ctypes.data, rec.ctypes.data)
+    ag.close()
+    mine = torch.tensor(np.concatenate([[float(nc), float(ag.calls), float(np.sum(rec.astype(np.int64)))], cost]), dtype=torch.float64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    if rank == 0:
+        q.put([g.tolist() for g in got])
+    dist.destroy_process_group()
+
+
+def test_one_picture_ctu_rows_over_two_ranks_gloo():
+    """ONE picture's CTU rows dealt to two PROCESSES (rank g codes the rows r % 2 == g); after every wavefront step the finished CTUs travel through the all-gather
+    callback of include/hophip.h's hop_encode_set_shard -- here hevc-hop_amd/shard.py's TorchAllgather on gloo, the spine over the CPU restatement (the kernels need a GPU; on
+    the device the same spine code runs with RCCL behind the same callback, tests/test_gpu_spine.py).  Both ranks end with the whole picture, equal to the reference encoder's
+    WaveFrontSynchro run (tests/golden/encoder_spine.npz)."""
+    W, H, seed = 192, 128, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, W, H, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=900)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    want = G["%dx%d_seed%d_wpp/cost" % (W, H, seed)]
+    assert got[0][1] == got[1][1] == 3 + 3 * 1                     # one exchange per wavefront step: cols + lag * (rows - 1) with lag = min(5, cols)
+    assert got[0][0] >= 0 and got[1][0] >= 0 and got[0][2] == got[1][2]      # the same reconstruction on both ranks
+    for g in got:
+        assert np.array_equal(np.array(g[3:]), want)

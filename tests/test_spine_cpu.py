@@ -312,3 +312,61 @@ def test_spine_with_micro_image_size_15_equals_the_reference_encoder(W, H, seed,
     check_against_golden(G, key_mi15(W, H, seed, lag), cost, bits, dist, parts, text)
     mv = parts["mv"][parts["pred_mode"] == 0]
     assert np.any(mv % 16 != 0)                                      # vectors that a 16-sample micro-image grid could not have produced did win somewhere
+
+
+def run_cpu_sharded(L, W, H, Y, Cb, Cr, lag, world, take, cancel_after=0, mi=16):
+    L.hop_spine_cpu_encode_sharded.restype = ctypes.c_long
+    L.hop_spine_cpu_encode_sharded.argtypes = [ctypes.c_int] * 8 + [ctypes.c_void_p] * 11
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cost = np.zeros(n, np.float64); bits = np.zeros(n, np.uint32); dist = np.zeros(n, np.uint32)
+    parts = np.zeros((n, 256), PART_DT)
+    rec = [np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)]
+    a = [np.ascontiguousarray(p, np.int16) for p in (Y, Cb, Cr)]
+    retired = np.zeros(world, np.int64)
+    nc = L.hop_spine_cpu_encode_sharded(W, H, 32, mi, lag, world, take, cancel_after, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, cost.ctypes.data, bits.ctypes.data,
+                                        dist.ctypes.data, parts.ctypes.data, rec[0].ctypes.data, rec[1].ctypes.data, rec[2].ctypes.data, retired.ctypes.data)
+    assert nc >= 0
+    return cost, bits, dist, parts, rec, retired
+
+
+@pytest.mark.parametrize("world,take", [(2, 1), (3, 0)])
+def test_ctu_rows_sharded_over_ranks_equal_the_reference(world, take):
+    """ONE picture's CTU rows dealt to `world` ranks (rank g codes the rows r % world == g of the lag-5 wavefront; here the ranks are threads with a backend --
+    a "device" -- each, exchanging through an in-process all-gather), every finished CTU's reconstruction, partition data, costs and coders handed to the other ranks after
+    each wavefront step.  Every rank must end with the whole picture: the per-CTU costs, the partition data and the reconstruction of rank `take` equal the reference
+    encoder's run with WaveFrontSynchro (the golden of the unsharded wavefront)."""
+    L = spine_cpu()
+    W, H, seed, lag = 448, 192, 3, 5
+    Y, Cb, Cr = frame(W, H, seed, False)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    key = key_of(W, H, seed, False) + "_wpp"
+    cost, bits, dist, parts, rec, retired = run_cpu_sharded(L, W, H, Y, Cb, Cr, lag, world, take)
+    assert np.array_equal(cost, G[key + "/cost"]) and np.array_equal(bits, G[key + "/bits"]) and np.array_equal(dist, G[key + "/dist"])
+    want = zlib.decompress(G[key + "/trace"].tobytes())                # (the candidate trace is per rank; the partition data below covers every CTU)
+    assert len(want) > 0
+    R = G[key + "/parts"]
+    for a in range(R.shape[0]):
+        r, q = R[a], parts[a]
+        used = r[:, 1] != 15
+        for name, col in (("depth", 0), ("pred_mode", 1), ("part_size", 2), ("skip", 3), ("merge_flag", 4), ("merge_idx", 5), ("gt_flag", 6), ("tr_idx", 9)):
+            assert np.array_equal(q[name][used].astype(np.int16), r[used, col]), (a, name)
+        inter = used & (r[:, 1] == 0)
+        assert np.array_equal(q["mv"][inter], r[inter, 13:15]) and np.array_equal(q["gt"][inter], r[inter, 15:23]), a
+    rows = (H + 63) // 64; cols = (W + 63) // 64
+    assert list(retired) == [cols * len(range(g, rows, world)) for g in range(world)]      # each rank coded exactly its rows
+    _, _, _, _, rec1, _, _ = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+    for c in range(3):
+        assert np.array_equal(rec[c], rec1[c]), c                      # the whole reconstruction is on this rank's "device"
+
+
+def test_ctu_rows_sharded_cancel_is_agreed_between_the_ranks():
+    """a cancel request of ONE rank travels with the exchange: all ranks leave the wavefront at the same step, nobody hangs in the all-gather, and what was coded is the golden's"""
+    L = spine_cpu()
+    W, H, seed, lag = 448, 192, 3, 5
+    Y, Cb, Cr = frame(W, H, seed, False)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
+    key = key_of(W, H, seed, False) + "_wpp"
+    cost, bits, dist, parts, rec, retired = run_cpu_sharded(L, W, H, Y, Cb, Cr, lag, 2, 0, cancel_after=2)
+    done = cost > 0
+    assert 2 <= int(done.sum()) < len(cost) and int(done.sum()) == int(retired.sum())
+    assert np.array_equal(cost[done], G[key + "/cost"][done])

@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- CTUs/sec of the HEVC-HOP all-intra RD search on MI355X (one JSON line, see the driver contract).
 
-DEFAULT (the metric of BASELINE.json, dependency-honest): one "step" = hop_encode_frame over the workload picture = the whole RD search of
-TEncSlice::compressSlice (TLibEncoder/TEncSlice.cpp:1000-1196): for every CTU every candidate TEncCu::xCompressCU tests -- merge / skip, SS + GT search
-for 2Nx2N, Nx2N, 2NxN and the AMP shapes with AMVP, merge and micro-image candidates, intra 2Nx2N / NxN with the 35-mode search and the transform tree,
-each with its residual quadtree, RDOQ and CABAC-counted bits -- the decision between them, the recursion over CU sizes, the SS reference growing from the
-sentinel CU by CU and the coder contexts carried from CU to CU.  The candidates are evaluated by the HIP kernels of libhophip, the decisions taken by the
-host spine (hevc-hop_amd/host/hop_spine.cpp); the CTU rows run as a lag-5 wavefront whose requests are served in batches.  Decisions, per-CTU RD costs
-(cost.csv) and reconstruction equal the reference encoder's (tests/test_gpu_spine.py against tests/golden/encoder_spine.npz).
-Workload picture: the full-width top band (--rows CTU rows, default 8 = 7728x512, the band BASELINE.md's CPU plan encodes) of the synthetic 7728x5368
-lenslet frame, coded as a picture; the whole frame (--rows 84) takes about ten times as long per step and keeps more rows in flight.
-Multi-GPU (--gpus N, launched by torch.distributed.run): every rank codes its own band of the frame as an independent picture (no data-path collective;
-"scaling": "weak").  An exchange of reconstructed borders between GPUs inside ONE picture is not built: the lag-5 wavefront of one picture keeps at most 24
-CTU rows in flight, which one GPU serves.
+DEFAULT (BASELINE.json's metric on BASELINE's configuration): the synthetic 7728x5368 lenslet frame (tests/hoputil.py:lenslet, micro-image pitch 15) coded as ONE
+picture exactly as TEncSlice::compressSlice (TLibEncoder/TEncSlice.cpp:1000-1196) codes it with cfg/3DHencoder_intra_main.cfg --MIsize=15 and WaveFrontSynchro: for every
+CTU every candidate TEncCu::xCompressCU tests -- merge / skip, SS + GT search for 2Nx2N, Nx2N, 2NxN and the AMP shapes with AMVP, merge and micro-image candidates, intra
+2Nx2N / NxN with the 35-mode search and the transform tree, each with its residual quadtree, RDOQ and CABAC-counted bits --, the decision between them, the recursion over
+CU sizes, the SS reference growing from the sentinel CU by CU, the coder contexts carried from CU to CU.  The candidates are evaluated by the HIP kernels of libhophip, the
+decisions taken by the host spine (hevc-hop_amd/host/hop_spine.cpp); the CTU rows run as a lag-5 wavefront (at most 25 rows in flight) whose requests are served in batches.
+The whole picture takes minutes, so it is coded CONTINUOUSLY on a thread of its own and a STEP is a fixed quantum of retired CTUs (one CTU row = 121) read from
+hop_encode_progress: the wavefront's ramp and `--warmup` steps are untimed, `--steps` steps are timed, then the run is cancelled (hop_encode_cancel).  A wall-clock budget
+(--budget-s, from process start) ends the timed region early if need be; the JSON says how many steps were timed.  `parity` in the JSON compares the RD costs of the CTUs
+this very run retired with cost.csv of the unmodified reference encoder for the same picture (tests/golden/encoder_frame_mi15_rows*.npz, oracle/make_golden24.py).
+`cpu_baseline` is that reference encoder (oracle/_ref/TAppEncoderRef) timed on a crop of the same frame; `roofline` / `kernels` come from a separate profiled pass with HIP
+events around every launch.  If time is left, BASELINE's config 5 (169 sub-aperture views of 624x432 as independent pictures in one stacked context) is measured as a second,
+separately named figure (`cfg5_views`).
 
---kernels: round 1's kernel-throughput mode (search kernels over a frozen, fully reconstructed SS reference: all CTUs independent).  It measures the
-kernels, not the encode; its JSON says so.
+Multi-GPU: `bench.py --gpus N` spawns N ranks itself (torch.distributed.run; or the driver does).  Default: every rank codes its own frame of the sequence (no data-path
+collective, "scaling": "weak").  --shard-rows: ONE picture over all ranks -- the CTU rows dealt round-robin, every wavefront step's finished CTUs handed over by an all-gather
+(hop_encode_set_shard, hevc-hop_amd/shard.py: RCCL between the GPUs of a node) --, "scaling": "strong".
+
+--kernels: round 1's kernel-throughput mode (search kernels over a frozen, fully reconstructed SS reference: all CTUs independent).  It measures the kernels, not the
+encode; its JSON says so.
 """
 import argparse
 import ctypes
@@ -773,22 +778,28 @@ def encode_main(args):
         prof, dom, roof = extras.get("prof"), None, None
         if prof:
             pk, prof_ctus, prof_s = prof
-            dom = max(pk, key=lambda k: pk[k]["total_ms"])
-            p = pk[dom]
+            # the dominant KERNEL: the classes of one kernel function (the CU sizes of a walk kernel) count together, as rocprofv3's per-kernel statistics do
+            byfn = {}
+            for name, v in pk.items():
+                f = byfn.setdefault(name.split(" ")[0], {"launches": 0, "total_ms": 0.0})
+                f["launches"] += v["launches"]; f["total_ms"] += v["total_ms"]
+            dom = max(byfn, key=lambda k: byfn[k]["total_ms"])
+            p = byfn[dom]
             avg_ms = p["total_ms"] / max(1, p["launches"])
             ctus_per_launch = prof_ctus / max(1, p["launches"])
             achieved = ALGO_BYTES_PER_CTU * ctus_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
             traffic, tsrc = None, None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-                traffic, tsrc = tj["hbm_bytes_per_launch"], tj["source"]
+                traffic, tsrc = tj["kernels"][dom]["hbm_bytes_per_launch"], tj["source"]
             except Exception:
                 pass
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                     "avg_launch_ms": avg_ms, "ctus_per_launch": ctus_per_launch, "launches_per_ctu": sum(v["launches"] for v in pk.values()) / prof_ctus,
                     "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
-                    "note": "from a separate profiled pass over the frame's top-left %dx%d as one picture (%d CTUs, %.1f s, HIP events around every launch): the encode is bound by the LENGTH of its "
-                            "dependent chains (serial coder walks inside the candidate evaluations), not by HBM or VALU throughput -- see rendezvous / request_ms" % (min(fw, args.profile_w), min(fh, args.profile_h), prof_ctus, prof_s)}
+                    "note": "from a separate profiled pass over the frame's top-left %dx%d as one picture (%d CTUs, %.1f s, HIP events around every launch, one stream): the encode is bound by the LENGTH of "
+                            "its dependent chains (serial coder walks inside the candidate evaluations: SQ_WAIT_ANY 85 %% of the walk kernels' wave cycles, profiles/r03_encode_pmc.json), not by HBM or VALU "
+                            "throughput -- see rendezvous / request_ms; per-kernel times of the timed command itself: profiles/r03_bench_kernel_stats.csv" % (min(fw, args.profile_w), min(fh, args.profile_h), prof_ctus, prof_s)}
         rv = stats.get("rendezvous", {"rounds": 0, "requests": 0})
         out = {
             "metric": "CTUs/sec all-intra 7728x5368 lenslet @QP32 (RD search of TEncSlice::compressSlice; per-CTU RD costs checked against the reference encoder's cost.csv in `parity`)",

@@ -81,7 +81,7 @@ struct LeafSmallShared { TurdSmallShared t; CabacLds1 cab; uint16_t scan[64]; ui
 
 // The same body for the candidate walks (k_walk.inl): up to four small transform units of one tree node side by side, one per WAVE of the 256-thread workgroup, each with
 // its own LeafSmallShared.  Every wave calls (the barriers are the workgroup's); a wave without a unit passes j < 0 and only keeps step.
-__device__ static void turd_fused_small_wave_body(LeafSmallShared& L, const int lane, const int j, const hop_tu_rd_job* jobs, int n, hop_pics pic, const hop_cabac_ctx* ctx_in,
+__device__ static __forceinline__ void turd_fused_small_wave_body(LeafSmallShared& L, const int lane, const int j, const hop_tu_rd_job* jobs, int n, hop_pics pic, const hop_cabac_ctx* ctx_in,
                                                   const int64_t* coef_off, const int32_t* entropy_bits, const uint16_t* scans, int32_t* coef, int32_t* levels, uint32_t* zs, uint32_t* ns,
                                                   uint32_t* as, unsigned long long* fr, hop_rdoq_job* rq, hop_coeff_bits_job* cb, hop_tu_rd_result* res, int16_t* rec_y, int16_t* rec_cb,
                                                   int16_t* rec_cr) {

@@ -15,9 +15,8 @@
 // At the compiler's free choice they take 256 registers per lane -- two workgroups fill a compute unit's register files, and a few hundred candidates in flight the whole
 // chip; capped at 128 (four waves per SIMD) a compute unit holds four and still has room.
 #define WALK_WAVES_PER_SIMD 4
-#define WALK_PARALLEL_LEAVES 0
 struct InterWalk {
-  RqtClass k; int n, bd_y, bd_c; hop_pics pic;
+  RqtClass k; int n, bd_y, bd_c, wave_leaves; hop_pics pic;
   const hop_rqt_job* jobs; const hop_cu_syntax* syn; const hop_cabac_ctx* ctx_in; const hop_cabac_cu_ctx* cu_in;
   hop_rqt_result* res; int32_t* coef_out; hop_cabac_ctx* ctx_after; hop_cu_final* fin; uint32_t* bits; uint32_t* skipped; double* cost; hop_cabac_ctx* ctx_out; hop_cabac_cu_ctx* cu_out;
   // the quadtree's state (rqt_run_class)
@@ -71,9 +70,8 @@ __device__ static void walk_inter_leaves(const InterWalk& A, InterLeafShared& L,
                     A.rec_y, A.rec_cb, A.rec_cr);
     __syncthreads();
   }
-#if !WALK_PARALLEL_LEAVES
-  // (one after the other: the wave-per-unit form below faulted on the device -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the first run, cause not found yet -- and stays
-  // compiled out)
+  if (!A.wave_leaves) {
+  // one after the other (HOP_WALK_WAVE_LEAVES=0)
   for (int c = 0; c < ncomp; c++) {
     if (A.tuj[3 * i + c].log2_size > 3) continue;
     turd_fused_body(L.u.big, 3 * i + c, A.tuj, n3, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.lwork, A.tr,
@@ -85,9 +83,8 @@ __device__ static void walk_inter_leaves(const InterWalk& A, InterLeafShared& L,
                     A.lwork, A.tr2, A.rec_y, A.rec_cb, A.rec_cr);
     __syncthreads();
   }
-  (void)wave; (void)lane;
   return;
-#endif
+  }
   // the small ones: list position q = 0 .. ncomp + nts - 1 -> (table, slot)
   const int total = ncomp + nts;
   for (int q0 = 0; q0 < total; q0 += 4) {
@@ -95,10 +92,11 @@ __device__ static void walk_inter_leaves(const InterWalk& A, InterLeafShared& L,
     const bool ts = q >= ncomp;
     int j = -1;
     if (q < total) { j = 3 * i + (ts ? q - ncomp : q); if (!ts && A.tuj[j].log2_size > 3) j = -1; }
-    if (!ts) turd_fused_small_wave_body(L.u.small[wave], lane, j, A.tuj, n3, A.pic, A.root[d], A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs, A.ns, A.as, A.fr, A.rq, A.cb, A.tr,
-                                        A.rec_y, A.rec_cb, A.rec_cr);
-    else turd_fused_small_wave_body(L.u.small[wave], lane, j, A.tuj2, n3, A.pic, A.root[d], A.off2, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs + n3, A.ns + n3, A.as + n3, A.fr + n3,
-                                    A.rq + n3, A.cb + n3, A.tr2, A.rec_y, A.rec_cb, A.rec_cr);
+    // ONE call site that every wave reaches with all its lanes (the tables picked per wave): the first form -- two calls under `if (ts)`, the body a function of its own
+    // called from wave-divergent control flow -- faulted on the device (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION)
+    const int sh = ts ? n3 : 0;
+    turd_fused_small_wave_body(L.u.small[wave], lane, j, ts ? A.tuj2 : A.tuj, n3, A.pic, A.root[d], ts ? A.off2 : A.off, A.entropy_bits, A.scans, A.lcoef, A.coef, A.zs + sh, A.ns + sh,
+                               A.as + sh, A.fr + sh, A.rq + sh, A.cb + sh, ts ? A.tr2 : A.tr, A.rec_y, A.rec_cb, A.rec_cr);
     __syncthreads();
   }
 }
@@ -177,6 +175,7 @@ int hop_launch_inter_walk(hop_ctx* c, const hop_rqt_job* cls, int n, const hop_r
   k.log2_cu = cls->log2_cu; k.log2_max_tu = cls->log2_max_tu; k.log2_min_tu = cls->log2_min_tu_in_cu; k.inter_split = cls->inter_split_flag ? 1 : 0; k.sign_hide = cls->sign_hide ? 1 : 0;
   k.use_ts = cls->use_ts ? 1 : 0;
   A.n = n; A.bd_y = c->bd_y; A.bd_c = c->bd_c; A.pic = hop_make_pics(c);
+  { const char* e = getenv("HOP_WALK_WAVE_LEAVES"); A.wave_leaves = e ? atoi(e) : 0; }   // the 4x4 / 8x8 transform units of a node a wave each (walk_inter_leaves)
   A.jobs = d_jobs; A.syn = d_syn; A.ctx_in = d_ctx_in; A.cu_in = d_cu_in; A.res = d_res; A.coef_out = d_coef; A.ctx_after = d_ctx_after; A.fin = d_fin; A.bits = d_bits; A.skipped = d_skipped;
   A.cost = d_cost; A.ctx_out = d_ctx_out; A.cu_out = d_cu_out;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };

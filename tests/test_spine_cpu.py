@@ -286,10 +286,12 @@ def test_cancelled_wavefront_keeps_the_retired_ctus(monkeypatch):
     assert int(ret.sum()) == done
     assert np.array_equal(cost[ret], G[key + "/cost"][ret]) and np.array_equal(bits[ret], G[key + "/bits"][ret]) and np.array_equal(dist[ret], G[key + "/dist"][ret])
     assert not cost[~ret].any() and not bits[~ret].any()
-    # the next call is a full one again
-    cost2, bits2, dist2, parts2, rec2, text2, rr2 = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
-    assert L.hop_spine_cpu_last_progress() == n
-    check_against_golden(G, key, cost2, bits2, dist2, parts2, text2)
+    # the next call is a full one again (a smaller picture: the request does not outlive its run)
+    W2, H2, seed2 = 192, 128, 7
+    Y2, Cb2, Cr2 = frame(W2, H2, seed2, False)
+    cost2, bits2, dist2, parts2, rec2, text2, rr2 = run_cpu_wpp(L, W2, H2, Y2, Cb2, Cr2, lag)
+    assert L.hop_spine_cpu_last_progress() == len(cost2)
+    check_against_golden(G, key_of(W2, H2, seed2, False) + "_wpp", cost2, bits2, dist2, parts2, text2)
 
 
 # ---- the configuration bench.py measures: pitch-15 lenslets coded with --MIsize=15.  With 15 the micro-image candidates (hop_spine.cpp: mi_cand,
@@ -329,14 +331,14 @@ def run_cpu_sharded(L, W, H, Y, Cb, Cr, lag, world, take, cancel_after=0, mi=16)
     return cost, bits, dist, parts, rec, retired
 
 
-@pytest.mark.parametrize("world,take", [(2, 1), (3, 0)])
-def test_ctu_rows_sharded_over_ranks_equal_the_reference(world, take):
+@pytest.mark.parametrize("world,take,W,H,seed", [(2, 1, 448, 192, 3), (3, 0, 192, 128, 7)])
+def test_ctu_rows_sharded_over_ranks_equal_the_reference(world, take, W, H, seed):
     """ONE picture's CTU rows dealt to `world` ranks (rank g codes the rows r % world == g of the lag-5 wavefront; here the ranks are threads with a backend --
     a "device" -- each, exchanging through an in-process all-gather), every finished CTU's reconstruction, partition data, costs and coders handed to the other ranks after
     each wavefront step.  Every rank must end with the whole picture: the per-CTU costs, the partition data and the reconstruction of rank `take` equal the reference
     encoder's run with WaveFrontSynchro (the golden of the unsharded wavefront)."""
     L = spine_cpu()
-    W, H, seed, lag = 448, 192, 3, 5
+    lag = 5                                                            # (192x128: two rows for three ranks -- one rank only listens)
     Y, Cb, Cr = frame(W, H, seed, False)
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
     key = key_of(W, H, seed, False) + "_wpp"
@@ -354,9 +356,10 @@ def test_ctu_rows_sharded_over_ranks_equal_the_reference(world, take):
         assert np.array_equal(q["mv"][inter], r[inter, 13:15]) and np.array_equal(q["gt"][inter], r[inter, 15:23]), a
     rows = (H + 63) // 64; cols = (W + 63) // 64
     assert list(retired) == [cols * len(range(g, rows, world)) for g in range(world)]      # each rank coded exactly its rows
-    _, _, _, _, rec1, _, _ = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
-    for c in range(3):
-        assert np.array_equal(rec[c], rec1[c]), c                      # the whole reconstruction is on this rank's "device"
+    if W * H <= 192 * 128:                                             # (the larger picture's reconstruction is compared on the device: tests/test_gpu_spine.py)
+        _, _, _, _, rec1, _, _ = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
+        for c in range(3):
+            assert np.array_equal(rec[c], rec1[c]), c                  # the whole reconstruction is on this rank's "device"
 
 
 def test_ctu_rows_sharded_cancel_is_agreed_between_the_ranks():

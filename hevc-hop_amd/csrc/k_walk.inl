@@ -175,7 +175,7 @@ int hop_launch_inter_walk(hop_ctx* c, const hop_rqt_job* cls, int n, const hop_r
   k.log2_cu = cls->log2_cu; k.log2_max_tu = cls->log2_max_tu; k.log2_min_tu = cls->log2_min_tu_in_cu; k.inter_split = cls->inter_split_flag ? 1 : 0; k.sign_hide = cls->sign_hide ? 1 : 0;
   k.use_ts = cls->use_ts ? 1 : 0;
   A.n = n; A.bd_y = c->bd_y; A.bd_c = c->bd_c; A.pic = hop_make_pics(c);
-  { const char* e = getenv("HOP_WALK_WAVE_LEAVES"); A.wave_leaves = e ? atoi(e) : 0; }   // the 4x4 / 8x8 transform units of a node a wave each (walk_inter_leaves)
+  { const char* e = getenv("HOP_WALK_WAVE_LEAVES"); A.wave_leaves = e ? atoi(e) : 1; }   // the 4x4 / 8x8 transform units of a node a wave each (walk_inter_leaves)
   A.jobs = d_jobs; A.syn = d_syn; A.ctx_in = d_ctx_in; A.cu_in = d_cu_in; A.res = d_res; A.coef_out = d_coef; A.ctx_after = d_ctx_after; A.fin = d_fin; A.bits = d_bits; A.skipped = d_skipped;
   A.cost = d_cost; A.ctx_out = d_ctx_out; A.cu_out = d_cu_out;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };

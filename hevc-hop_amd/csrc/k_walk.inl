@@ -14,7 +14,9 @@
 // The walks are serial code on a few lanes: what they must not do is keep the short kernels of the spine's other requests (predictions, searches) off the compute units.
 // At the compiler's free choice they take 256 registers per lane -- two workgroups fill a compute unit's register files, and a few hundred candidates in flight the whole
 // chip; capped at 128 (four waves per SIMD) a compute unit holds four and still has room.
+#ifndef WALK_WAVES_PER_SIMD
 #define WALK_WAVES_PER_SIMD 4
+#endif
 struct InterWalk {
   RqtClass k; int n, bd_y, bd_c, wave_leaves; hop_pics pic;
   const hop_rqt_job* jobs; const hop_cu_syntax* syn; const hop_cabac_ctx* ctx_in; const hop_cabac_cu_ctx* cu_in;

@@ -138,6 +138,8 @@ def mirror_size(m):
 
 
 def load():
+    global LIB_PATH
+    if os.environ.get("HOP_LIB"): LIB_PATH = os.environ["HOP_LIB"]      # (development: a differently built library)
     if not os.path.exists(LIB_PATH):
         raise HopError("libhophip.so is not built (run `make -C hevc-hop_amd` or __graft_entry__.build()); there is no CPU fallback")
     L = ctypes.CDLL(LIB_PATH)

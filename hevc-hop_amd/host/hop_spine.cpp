@@ -1442,6 +1442,16 @@ class FiberPool : public Backend {
         }
         v.swap(keep);
       }
+      // ... and among the short chains the motion searches (a dozen dependent launches, ten times a prediction request) once nothing cheaper of the node is waiting: the
+      // candidates and CTUs that are a few cheap requests behind catch up first, and their searches then share the chain instead of taking one each
+      if (defer_me_) {
+        bool cheap = false; for (Req* r : v) cheap |= (r->kind != RQ_ME && r->kind != RQ_INTER && r->kind != RQ_INTRA);
+        if (cheap) {
+          std::vector<Req*> keep;
+          for (Req* r : v) (r->kind == RQ_ME ? rest : keep).push_back(r);
+          v.swap(keep);
+        }
+      }
     }
     pending_.swap(rest);
     rounds++; requests += v.size() + early.size();
@@ -1483,6 +1493,7 @@ class FiberPool : public Backend {
  public:
   void print_round_stats() { if (!getenv("HOP_SPINE_ROUND_STATS")) return; for (auto& kv : round_masks_) fprintf(stderr, "hop spine rounds: kinds %03x x %llu\n", kv.first, (unsigned long long)kv.second); }
  private:
+  bool defer_me_ = [] { const char* e = getenv("HOP_SPINE_DEFER_ME"); return e ? atoi(e) != 0 : true; }();
   bool posted_mode_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); return e && atoi(e) != 0 && posted_requests_allowed; }();
   std::vector<std::deque<Req> > pstore_; std::vector<std::deque<std::vector<hop_pred_job> > > pjobs_;   // per worker: what was posted since the last serve (deques: addresses stay)
   std::vector<Req*> inflight_;

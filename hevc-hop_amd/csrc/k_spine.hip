@@ -228,7 +228,7 @@ class HipBackend : public BatchInner {
     o_mjobs = take(MAXP * sizeof(hop_pu_job)); o_mres = take(MAXP * sizeof(hop_pu_result));
     // what a candidate batch sends and gets back travels as ONE copy each way between pinned host memory and these two regions, packed for the batch's n
     io_bytes = (size_t)MAXN * (sizeof(hop_rqt_job) + sizeof(hop_intra_cu_syntax) + sizeof(hop_intra_rqt_opt) + sizeof(hop_intra_search_job) + sizeof(hop_rqt_result) +
-                               sizeof(hop_intra_search_result) + sizeof(hop_intra_chroma_result) + 2 * sizeof(hop_cabac_ctx) + 2 * sizeof(hop_cabac_cu_ctx) + sizeof(hop_cu_final) + 64) + 16 * 256;
+                               sizeof(hop_intra_search_result) + sizeof(hop_intra_chroma_result) + 2 * sizeof(hop_cabac_ctx) + 2 * sizeof(hop_cabac_cu_ctx) + sizeof(hop_cu_final) + 4 * sizeof(hop_pred_job) + 64) + 16 * 256;
     o_in = take(io_bytes); o_out = take(io_bytes);
     bytes = o;
     hin = hout = nullptr;
@@ -359,6 +359,8 @@ class HipBackend : public BatchInner {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     const size_t i_jobs = take(n * sizeof(hop_rqt_job)), i_syn = take(n * sizeof(hop_cu_syntax)), i_cx = take(n * sizeof(hop_cabac_ctx)), i_cu = take(n * sizeof(hop_cabac_cu_ctx)), in_bytes = o;
+    int n_pred = 0; for (int i = 0; i < n; i++) n_pred += e[i]->n_pred;
+    const size_t i_pred = take((size_t)n_pred * sizeof(hop_pred_job));    // (read by the device straight from the pinned buffer: not part of the copy)
     o = 0;
     const size_t r_fin = take(n * sizeof(hop_cu_final)), r_bits = take(n * 4), r_skipped = take(n * 4), r_cx = take(n * sizeof(hop_cabac_ctx)), r_cu = take(n * sizeof(hop_cabac_cu_ctx)),
                  r_res = take(skip ? 0 : n * sizeof(hop_rqt_result)), out_bytes = o;
@@ -366,6 +368,12 @@ class HipBackend : public BatchInner {
     for (int i = 0; i < n; i++) { hj[i] = e[i]->job; hj[i].ctx_index = i; hs[i] = e[i]->syn; hx[i] = in[i]->r; hu[i] = in[i]->c; }
     char* din = arena + o_in; char* dout = arena + o_out;
     BH(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, s));
+    if (n_pred > 0) {                                                     // the candidates' final motion compensation (InterEval::pred) first, on this stream
+      hop_pred_job* hp = (hop_pred_job*)(hin + i_pred);
+      for (int i = 0, k = 0; i < n; i++) for (int q = 0; q < e[i]->n_pred; q++) hp[k++] = e[i]->pred[q];
+      BK(hop_check_pred_jobs(c, n_pred, hp));
+      BK(hop_pred_inter_device(c, n_pred, hp));
+    }
     const hop_rqt_job* d_jobs = (const hop_rqt_job*)(din + i_jobs); const hop_cu_syntax* d_syn = (const hop_cu_syntax*)(din + i_syn);
     const hop_cabac_ctx* d_cx = (const hop_cabac_ctx*)(din + i_cx); const hop_cabac_cu_ctx* d_cu = (const hop_cabac_cu_ctx*)(din + i_cu);
     if (skip) {

@@ -46,6 +46,7 @@ void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size)
   c.amp = 1; c.fen = 1; c.hadme = 1; c.fdm = 1; c.esd = 0; c.cfm = 0; c.ecu = 0;
   c.log2_max_tu = 5; c.log2_min_tu = 2; c.tu_max_depth_inter = 3; c.tu_max_depth_intra = 3;
   c.sign_hide = 1; c.use_ts = 1; c.ts_fast = 1; c.strong_intra = 1; c.wpp = 0;
+  { const char* e = getenv("HOP_SPINE_FUSE_PRED"); c.fuse_pred = e ? atoi(e) != 0 : 1; }
   finish_config(c);
 }
 
@@ -234,6 +235,7 @@ class CtuWorker {
   uint32_t inter_pred_error(CuData& c, int pu);
   void pu_pred_job(const CuData& c, int pu, hop_pred_job& j);
   void motion_comp_pu(CuData& c, int pu);
+  hop_pred_job held_[4]; int n_held_ = 0;      // fuse_pred: the candidate's final predictions until its evaluation is asked for
   void clip_mv(const CuData& c, int& h, int& v) const;
   bool valid_pattern(int px, int py, int w, int h, int mvx, int mvy);
   uint32_t split_flag_bits(const CuData& c, int d, Coder& k);
@@ -417,6 +419,7 @@ void CtuWorker::merge_candidates(const CuData& c, int pu, MergeCands& mc) {
 // TComPrediction::motionCompensation for one PU (TComPrediction.cpp:419-470 -> xPredInterUni :528-552): the vector clipped, GT iff the PU is not merged and has its flag
 void CtuWorker::motion_comp_pu(CuData& c, int pu) {
   hop_pred_job j; pu_pred_job(c, pu, j);
+  if (cfg.fuse_pred) { if (pu == 0) n_held_ = 0; if (n_held_ < 4) held_[n_held_++] = j; else throw 1; return; }   // handed over with the candidate's evaluation (eval_inter)
   be->pred_inter(lane_, 1, &j);
 }
 void CtuWorker::pu_pred_job(const CuData& c, int pu, hop_pred_job& j) {
@@ -603,6 +606,8 @@ void CtuWorker::eval_inter(int d, bool skip_res) {
   fill_rqt_job(cfg, c, false, ps, e.job, row_off());
   c.slot = slot_;
   e.skip_res = skip_res ? 1 : 0;
+  e.n_pred = n_held_; for (int k = 0; k < n_held_; k++) e.pred[k] = held_[k];
+  n_held_ = 0;
   hop_cu_syntax& y = e.syn;
   y.part_size = ps; y.n_pu = num_pus(ps); y.skip_flag = c.p[0].skip;
   { const Part* l = nb_left(c, c.x, c.y); const Part* a = nb_above(c, c.x, c.y); y.skip_ctx = (l ? l->skip : 0) + (a ? a->skip : 0); }   // getCtxSkipFlag (:1888)

@@ -30,6 +30,7 @@ struct EncConfig {
   int amp, fen, hadme, fdm, esd, cfm, ecu;
   int log2_max_tu, log2_min_tu, tu_max_depth_inter, tu_max_depth_intra;
   int sign_hide, use_ts, ts_fast, strong_intra;
+  int fuse_pred;                   // 1 (default; HOP_SPINE_FUSE_PRED=0 switches it off): InterEval carries the CU's final predictions
   int spec_slots, slot_pitch;      // > 0: the SS/GT candidates of a CU are evaluated side by side, candidate k in copy k of the prediction / reconstruction pictures (rows k * slot_pitch, hop_ctx_set_slots)
   int y_origin;                    // added to the y coordinate of every request: the picture's first row in a stacked context (hop_ctx_set_stack), else 0
   int wpp;                         // 0: contexts run on from CTU to CTU in raster order (shipped configurations); 1: WaveFrontSynchro rows
@@ -74,6 +75,9 @@ struct CuData {                    // TComDataCU as the RD search uses it (one C
 // ---- candidate evaluation requests (the boundary between the spine and the kernels) ----
 struct InterEval {                 // encodeResAndCalcRdInterCU of a CU whose prediction is in the prediction picture
   hop_rqt_job job; hop_cu_syntax syn; int skip_res;
+  // ... or is made first: the final motion compensation of the CU's PUs (TEncSearch.cpp:4158, TEncCu.cpp:1304) travels with the evaluation it is for (EncConfig::fuse_pred)
+  // instead of as a request of its own -- nothing else reads it
+  int n_pred; hop_pred_job pred[4];
 };
 struct IntraEval {                 // the body of xCheckRDCostIntra
   hop_rqt_job job; hop_intra_cu_syntax syn; hop_intra_rqt_opt opt; hop_intra_search_job sjob; int part_nxn;

@@ -23,10 +23,24 @@ namespace {
 
 struct Plane { int w, h, stride, margin; std::vector<int16_t> buf; int16_t* p00; };
 
+// the requests of one batch are independent of each other (different CTUs or candidate slots: disjoint rectangles of the pictures): a few threads take them side by side, so
+// that the CPU tests of pictures with several CTUs or candidates in flight finish sooner.  HOP_CPU_BACKEND_THREADS=1 switches it off.
+template <class F> static void parallel_batch(int n, F fn) {
+  static const int T = [] { const char* e = getenv("HOP_CPU_BACKEND_THREADS"); int t = e ? atoi(e) : 6; return t < 1 ? 1 : t > 16 ? 16 : t; }();
+  if (n <= 1 || T <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+  std::atomic<int> next(0);
+  auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
+  std::vector<std::thread> th; const int k = (n < T ? n : T) - 1;
+  for (int t = 0; t < k; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+}
+
 class CpuBackend : public BatchInner {
  public:
   // slots: the original, prediction and reconstruction pictures exist slots + 1 times, copy k at rows k * H (what hop_ctx_set_slots makes of a context)
   CpuBackend(int W, int H, int bd, const int16_t* y, const int16_t* cb, const int16_t* cr, int slots = 0) : W(W), H(H), bd(bd) {
+    hop_o_scan_init();                                                     // (lazily built tables: before any thread uses them)
     for (int c = 0; c < 3; c++) {
       const int w = c ? W / 2 : W, h = c ? H / 2 : H;
       org[c].assign((size_t)w * h * (slots + 1), 0); pred[c].assign((size_t)w * h * (slots + 1), 0); rec[c].assign((size_t)w * h * (slots + 1), 0);
@@ -42,7 +56,7 @@ class CpuBackend : public BatchInner {
     for (int c = 0; c < 3; c++) { std::fill(ss[c].buf.begin(), ss[c].buf.end(), (int16_t)-1); std::fill(rec[c].begin(), rec[c].end(), (int16_t)0); }
   }
   void me_search(int, int n, const hop_pu_job* jobs, hop_pu_result* res) {
-    for (int i = 0; i < n; i++) {
+    parallel_batch(n, [&](int i) {
       const hop_pu_job& j = jobs[i]; hop_pu_result& r = res[i];
       if (getenv("HOP_SPINE_CHECK") && j.rng_right >= j.rng_left && j.rng_bottom >= j.rng_top) {   // the argument check of libhophip's hop_me_search, to see which jobs it would refuse
         const int lim = 80 + 64 - 4, stride = W + 160;
@@ -61,8 +75,10 @@ class CpuBackend : public BatchInner {
       r.gt_flag = (int32_t)out[9]; for (int k = 0; k < 8; k++) r.gt[k] = (int32_t)out[10 + k];
       r.cost = (uint32_t)out[18]; r.mv_final[0] = (int32_t)out[19]; r.mv_final[1] = (int32_t)out[20];
       r.half_final[0] = (int32_t)out[21]; r.half_final[1] = (int32_t)out[22]; r.qter_final[0] = (int32_t)out[23]; r.qter_final[1] = (int32_t)out[24];
-    }
+    });
   }
+  void inter_n(int n, const InterEval* const* e, const Coder* const* in, EvalResult* const* out) { parallel_batch(n, [&](int i) { inter_cu(0, *e[i], *in[i], *out[i]); }); }
+  void intra_n(int n, const IntraEval* const* e, const Coder* const* in, EvalResult* const* out) { parallel_batch(n, [&](int i) { intra_cu(0, *e[i], *in[i], *out[i]); }); }
   void pred_inter(int, int n, const hop_pred_job* jobs) {
     for (int i = 0; i < n; i++) {
       const hop_pred_job& j = jobs[i];
@@ -134,7 +150,8 @@ class CpuBackend : public BatchInner {
       for (int r = 0; r < w; r++) memcpy(&rec[c][(size_t)((y >> s) + r) * st + (x >> s)], &in[c][(size_t)r * w], w * 2);
     }
   }
-  void inter_cu(int, const InterEval& e, const Coder& in, EvalResult& out) {
+  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) {
+    if (e.n_pred > 0) pred_inter(lane, e.n_pred, e.pred);               // the CU's final motion compensation travels with its evaluation (EncConfig::fuse_pred)
     hop_o_rqt_cfg cfg; cfg_of(e.job, bd, cfg);
     const int cu = 1 << cfg.log2_cu, x = e.job.x, y = e.job.y, parts = (cu / 4) * (cu / 4);
     std::vector<int16_t> pr[3], og[3], rc[3];
@@ -400,7 +417,7 @@ class StackRouter : public BatchInner {
   void pred_inter(int lane, int n, const hop_pred_job* jobs) { for (int i = 0; i < n; i++) { hop_pred_job j = jobs[i]; const int k = j.pu_y / pitch_; j.pu_y -= k * pitch_; be[k]->pred_inter(lane, 1, &j); } }
   void distortion(int lane, int n, const hop_dist_job* jobs, uint32_t* out) { for (int i = 0; i < n; i++) { hop_dist_job j = jobs[i]; const int k = j.y / pitch_; j.y -= k * pitch_; be[k]->distortion(lane, 1, &j, out + i); } }
   void valid_pattern(int, int, const int32_t*, uint8_t*) { throw 1; }   // the spine answers these from its own map
-  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) { InterEval q = e; const int k = q.job.y / pitch_; q.job.y -= k * pitch_; be[k]->inter_cu(lane, q, in, out); }
+  void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& out) { InterEval q = e; const int k = q.job.y / pitch_; q.job.y -= k * pitch_; for (int i = 0; i < q.n_pred; i++) q.pred[i].pu_y -= k * pitch_; be[k]->inter_cu(lane, q, in, out); }
   void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& out) { IntraEval q = e; const int k = q.job.y / pitch_; q.job.y -= k * pitch_; be[k]->intra_cu(lane, q, in, out); }
   void recon_save(int lane, int slot, int x, int y, int size) { const int k = y / pitch_; be[k]->recon_save(lane, slot, x, y - k * pitch_, size); }
   void recon_restore(int lane, int slot, int x, int y, int size) { const int k = y / pitch_; be[k]->recon_restore(lane, slot, x, y - k * pitch_, size); }

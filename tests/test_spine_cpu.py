@@ -235,6 +235,7 @@ def test_posted_requests_keep_every_result_and_save_rounds(slots, monkeypatch):
     """HOP_SPINE_POSTED: requests without an answer (predictions, reconstructions put aside / brought back, commits) no longer stop their row; they are issued first whenever
     requests are served.  The picture's candidates, costs, partition data, reconstruction, levels and the RD coder's fractions must be those of the reference run with
     WaveFrontSynchro, and the rounds that served nothing else disappear (about a third of all rounds)."""
+    monkeypatch.setenv("HOP_SPINE_FUSE_PRED", "0")                  # (the mode's premise: predictions as requests of their own; fused into the evaluations they are no requests at all)
     L = spine_cpu()
     W, H, seed, lag = 192, 128, 7, 5
     Y, Cb, Cr = frame(W, H, seed, False)

@@ -220,6 +220,8 @@ class CtuWorker {
   // the spine
   void compress_cu(int d, int parent_part_size);
   void check_best_mode(int d, bool save_recon);
+  struct PendingSave { bool on; int d, x, y, size; } psave_ = { false, 0, 0, 0, 0 };
+  void flush_save();
   void check_merge_2Nx2N(int d, bool* early_skip);
   void check_inter(int d, int part_size, bool use_mrg);
   void check_intra(int d, int part_size);
@@ -292,11 +294,17 @@ void CtuWorker::trace_candidate(const CuData& c) {
 }
 
 // TEncCu::xCheckBestMode (:1557-1590): strict '<'; the winner's reconstruction is put aside, its coder becomes CI_NEXT_BEST
+void CtuWorker::flush_save() { if (!psave_.on) return; psave_.on = false; tag_step(62); be->recon_save(lane_, psave_.d, psave_.x, psave_.y, psave_.size); }
 void CtuWorker::check_best_mode(int d, bool save_recon) {
   trace_candidate(*temp_[d]);
   if (temp_[d]->cost < best_[d]->cost) {
     std::swap(best_[d], temp_[d]);
-    if (save_recon) { tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y + cfg.y_origin + best_[d]->slot * cfg.slot_pitch, best_[d]->size); }
+    if (save_recon) {
+      // candidates side by side: the decisions are replayed over finished results, one winner after the other into the same stash slot -- only the last one has to
+      // get there, and only before its candidate slot is written again (flush_save: before the next batch of candidates, the sub-CUs, the end of the node)
+      if (best_[d]->slot > 0) { psave_.on = true; psave_.d = d; psave_.x = best_[d]->x; psave_.y = best_[d]->y + cfg.y_origin + best_[d]->slot * cfg.slot_pitch; psave_.size = best_[d]->size; }
+      else { psave_.on = false; tag_step(62); be->recon_save(lane_, d, best_[d]->x, best_[d]->y + cfg.y_origin + best_[d]->slot * cfg.slot_pitch, best_[d]->size); }
+    }
     sb_[d][CI_NEXT] = sb_[d][CI_TEMP];
   }
 }
@@ -822,6 +830,7 @@ void CtuWorker::spec_inter_phase(int d, std::vector<SpecCand>& cands) {
   if (n_inter > cfg.spec_slots - 2) throw 1;
   std::vector<int> slot(n);
   for (int i = 0, k = 0; i < n; i++) slot[i] = cands[i].intra_ps < 0 ? ++k : (cands[i].intra_ps == SIZE_2Nx2N ? cfg.spec_slots - 1 : cfg.spec_slots);
+  flush_save();                                                          // (the candidates about to run reuse the slots)
   be->fork_join(n, [&](int i) { spec_run(d, cands[i], tmpl, slot[i]); });
 }
 
@@ -963,6 +972,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   } else boundary = true;
 
   bool split_is_best = false;
+  flush_save();                                                          // (the sub-CUs' candidates reuse the slots)
   if (sub_branch && d < 3) {
     init_est(*temp_[d]);
     CuData* t = temp_[d];
@@ -989,8 +999,9 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
   copy_to_pic(*best_[d]);
   tag_exit(d, node_abs);
   if (!boundary) {
-    if (!split_is_best) be->recon_restore(lane_, d, x, y + cfg.y_origin, size);           // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture
-    be->commit(lane_, x, y + cfg.y_origin, size);                                         // xCopyYuv2SSRef (:872-880)
+    flush_save();
+    if (!split_is_best) be->restore_commit(lane_, d, x, y + cfg.y_origin, size);          // xCopyYuv2Pic (:869): the winner's reconstruction back into the picture, then
+    else be->commit(lane_, x, y + cfg.y_origin, size);                                    // xCopyYuv2SSRef (:872-880)
     for (int yy = y >> 3; yy < (y + size) >> 3; yy++) memset(&E.committed[(size_t)yy * (cfg.pic_w >> 3) + (x >> 3)], 1, size >> 3);
   }
 }
@@ -1139,7 +1150,11 @@ static void run_group(BatchInner* inner_, std::vector<Req*>& g) {
     inner_->intra_n((int)g.size(), e.data(), in.data(), o.data());
   } else {
     std::vector<int32_t> rc; for (Req* r : g) { rc.push_back(r->i0); rc.push_back(r->i1); rc.push_back(r->i2); rc.push_back(r->i3); }
-    if (kind == RQ_COMMIT) inner_->commit_n((int)g.size(), rc.data()); else inner_->stash_n((int)g.size(), rc.data(), kind == RQ_RESTORE);
+    if (kind == RQ_COMMIT) {
+      std::vector<int32_t> rs; for (Req* r : g) if (r->i3 > 0) { rs.push_back(r->i0); rs.push_back(r->i1); rs.push_back(r->i2); rs.push_back(r->i3 - 1); }   // restore_commit: the stash slot + 1
+      if (!rs.empty()) inner_->stash_n((int)(rs.size() / 4), rs.data(), 1);
+      inner_->commit_n((int)g.size(), rc.data());
+    } else inner_->stash_n((int)g.size(), rc.data(), kind == RQ_RESTORE);
   }
 }
 
@@ -1160,6 +1175,7 @@ class Rendezvous : public Backend {
   void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false }; submit(q); }
   void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false }; submit(q); }
   void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false }; submit(q); }
+  void restore_commit(int lane, int slot, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot + 1, false }; submit(q); }
   // progress waits of the row threads go through the same lock so that "nobody can run" is detected exactly
   template <class Pred> void wait_until(std::unique_lock<std::mutex>& lk, Pred p) {
     if (p()) return;
@@ -1280,6 +1296,10 @@ class FiberPool : public Backend {
   void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
+  void restore_commit(int lane, int slot, int x, int y, int size) {
+    if (posted_mode_) { recon_restore(lane, slot, x, y, size); commit(lane, x, y, size); return; }
+    Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot + 1, false, 0, NULL }; submit(q);
+  }
   void wait_counter(std::atomic<int>* ctr, int target) {                // until *ctr >= target (another fiber counts it up)
     if (ctr->load() >= target) return;
     Fiber* f = current(); f->wait_ctr = ctr; f->wait_target = target;

@@ -118,6 +118,8 @@ class Backend {
   virtual void recon_save(int lane, int slot, int x, int y, int size) = 0;
   virtual void recon_restore(int lane, int slot, int x, int y, int size) = 0;
   virtual void commit(int lane, int x, int y, int size) = 0;                             // reconstruction picture -> SS reference (xCopyYuv2SSRef)
+  // the two requests a CU's decision ends with when the split did not win (xCopyYuv2Pic, xCopyYuv2SSRef: TEncCu.cpp:869-880) as one
+  virtual void restore_commit(int lane, int slot, int x, int y, int size) { recon_restore(lane, slot, x, y, size); commit(lane, x, y, size); }
   // a picture coded by several ranks (EncConfig::shard): the w x h block at (x, y) of the reconstruction picture (w, h multiples of 8: a CTU's part inside the picture) out as
   // packed planes (w * h luma, then the caller's Cb and Cr arrays of w/2 * h/2), and back in on another rank -- into the reconstruction picture AND the SS reference (the
   // commit of every CU of the CTU, xCopyYuv2SSRef)

@@ -252,7 +252,7 @@ def test_posted_requests_keep_every_result_and_save_rounds(slots, monkeypatch):
     a, b = out["0"], out["1"]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
     assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4])) and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
-    assert a[7][1] == b[7][1] and b[7][0] < 0.75 * a[7][0], (a[7], b[7])          # the same requests in fewer rounds
+    assert a[7][1] <= b[7][1] <= 1.05 * a[7][1] and b[7][0] < 0.75 * a[7][0], (a[7], b[7])   # the same requests (posted: a decision's restore + commit count as two) in fewer rounds
     print("rounds", a[7][0], "->", b[7][0], "requests", a[7][1])
 
 

@@ -179,6 +179,7 @@ class CtuWorker {
   enum { CI_CURR = 0, CI_NEXT = 1, CI_TEMP = 2 };
   Coder sb_[4][3]; Coder goon_;
   struct SpecCand; std::vector<SpecCand> spec_intra_[4];                   // candidate slots: the intra candidates of the node, evaluated with the first batch
+  std::vector<SpecCand> spec_amp_[4];                                      // ... and, with 24 slots or more, the AMP shapes in both of their forms (all vectors / merge only): the derivation then picks
   int ctu_addr_, ctu_x_, ctu_y_;
 
   // data model
@@ -544,7 +545,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       // ME against merge (:3977-4146)
       uint32_t me_cost = MAX_UINT;
       tag_step(pu * 8 + 2);
-      if (test_normal) { const uint32_t err = inter_pred_error(c, pu); me_cost = err + ((lam * me_bits) >> 16); }
+      // (the searched vector's prediction error, xGetInterPredictionError :3980, is asked for together with the merge candidates' below: neither needs the other's answer)
       PuFields saved = me;
       if (!test_normal) { memset(&saved, 0, sizeof(saved)); saved.ref = -1; saved.mvp_idx = -1; saved.mvp_num = -1; }
       // xMergeEstimation (:2992-3106)
@@ -553,7 +554,8 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       {
         // every valid candidate's prediction error: the PU keeps the GT fields and flag the motion search left in the CU while its vector is replaced (:3057-3058)
         const PuFields base = test_normal ? me : saved;
-        hop_pred_job mj[5]; int mi[5], nm = 0; uint32_t err[5];
+        hop_pred_job mj[6]; int mi[6], nm = 0; uint32_t err[6];
+        if (test_normal) { pu_pred_job(c, pu, mj[0]); mi[0] = -1; nm = 1; }     // the searched vector first (as inter_pred_error would have asked)
         for (int k = 0; k < mc.n; k++) {
           int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(c, mh, mvv);
           if (mc.f[k].ref == 0 && !valid_pattern(px, py, w, h, mh, mvv)) continue;
@@ -566,6 +568,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
         if (nm) be->pred_cost(lane_, nm, mj, cfg.hadme ? HOP_DIST_HADS : HOP_DIST_SAD, err);
         for (int t = 0; t < nm; t++) {
           const int k = mi[t];
+          if (k < 0) { me_cost = err[t] + ((lam * me_bits) >> 16); continue; }
           val_merge = true;
           uint32_t cb = (uint32_t)k + 1; if (k == cfg.max_merge_cand - 1) cb--;
           const uint32_t cand = err[t] + ((lam * cb) >> 16);
@@ -855,12 +858,24 @@ void CtuWorker::check_merge_and_inter_spec(int d) {
   int first_inter = (int)cands.size();
   static const int inter_ps[3] = { SIZE_2Nx2N, SIZE_Nx2N, SIZE_2NxN };
   for (int q = 0; q < 3; q++) { SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = inter_ps[q]; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
+  // The AMP shapes too, when there are slots for them: which of them xCompressCU tests, and whether with all vectors or merge only, follows from the best mode of the
+  // candidates above (deriveTestModeAMP), but what each test yields does not -- every candidate starts from the same coder and an empty CU.  Both forms of all four shapes
+  // run with the first batch; the derivation (compress_cu) then adopts the ones the reference would have tested, in its order, and the rest is dropped: a node's second
+  // round of searches and evaluations is gone from the CTU's chain.  (64x64: deriveTestModeAMP never asks for the all-vectors form.)
+  const int first_amp = (int)cands.size();
+  if (cfg.amp && d < 3 && cfg.spec_slots >= 24) {
+    static const int amp_ps[4] = { SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N };
+    for (int q = 0; q < 4; q++) for (int mrg = (c->size == 64 ? 1 : 0); mrg < 2; mrg++) {
+      SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = amp_ps[q]; sc.use_mrg = mrg != 0; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc);
+    }
+  }
   // the intra candidates join the same batch: in an ISS slice xCompressCU always tests them, after every SS/GT candidate (their results wait in spec_intra_)
   const int first_intra = (int)cands.size();
   const int n_intra = (d == 3 && c->size > (1 << cfg.log2_min_tu)) ? 2 : 1;
   for (int q = 0; q < n_intra; q++) { SpecCand sc; sc.intra_ps = q ? SIZE_NxN : SIZE_2Nx2N; sc.merge_k = -1; sc.nores = 0; sc.ps = 0; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
   spec_inter_phase(d, cands);
   spec_intra_[d].assign(cands.begin() + first_intra, cands.end());
+  spec_amp_[d].assign(cands.begin() + first_amp, cands.begin() + first_intra);
   // ---- the decisions, in the serial order ----
   int buf[5] = { 0, 0, 0, 0, 0 };
   bool best_is_skip = false;
@@ -942,7 +957,14 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
           std::vector<SpecCand> amps;                                        // spec: the AMP shapes the derivation asks for, side by side
           auto amp = [&](int ps, bool mrg, bool cfm_check) {
             if (!do_not_block_pu) return;
-            if (spec) { SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = ps; sc.use_mrg = mrg; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; amps.push_back(sc); return; }
+            if (spec) {
+              for (size_t q = 0; q < spec_amp_[d].size(); q++) if (spec_amp_[d][q].ps == ps && spec_amp_[d][q].use_mrg == mrg) {   // evaluated with the first batch
+                if (spec_amp_[d][q].ok) spec_adopt(d, spec_amp_[d][q]);
+                init_est(*temp_[d]);
+                return;
+              }
+              SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = ps; sc.use_mrg = mrg; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; amps.push_back(sc); return;
+            }
             check_inter(d, ps, mrg); init_est(*temp_[d]);
             if (cfm_check && cfg.cfm && best_[d]->p[0].part_size == ps) do_not_block_pu = root_cbf(best_[d]) != 0;
           };
@@ -954,6 +976,7 @@ void CtuWorker::compress_cu(int d, int parent_ps) {
             spec_inter_phase(d, amps);
             for (size_t q = 0; q < amps.size(); q++) { if (amps[q].ok) spec_adopt(d, amps[q]); init_est(*temp_[d]); }
           }
+          spec_amp_[d].clear();
         }
       }
       const Part& b = best_[d]->p[0];

@@ -879,7 +879,7 @@ def main():
     ap.add_argument("--step-ctus", type=int, default=0, help="retired CTUs that make one step (0: one CTU row of the picture)")
     ap.add_argument("--budget-s", type=float, default=430.0, help="wall-clock budget from process start: the timed region ends there at the latest (the driver's limit is 600 s)")
     ap.add_argument("--ramp-frac", type=float, default=0.55, help="at most this share of the time left when the picture starts goes into the ramp")
-    ap.add_argument("--slots", type=int, default=24, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
+    ap.add_argument("--slots", type=int, default=48, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
     ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
     ap.add_argument("--shard-rows", action="store_true", help="--gpus N > 1: ONE picture over all ranks, its CTU rows dealt round-robin with a hand-off after every wavefront step "
                                                                "(hop_encode_set_shard; strong scaling) instead of one picture per rank")

@@ -179,6 +179,7 @@ class CtuWorker {
   enum { CI_CURR = 0, CI_NEXT = 1, CI_TEMP = 2 };
   Coder sb_[4][3]; Coder goon_;
   struct SpecCand; std::vector<SpecCand> spec_intra_[4];                   // candidate slots: the intra candidates of the node, evaluated with the first batch
+  struct SpecSet; std::vector<SpecSet> spec_set_;                          // per depth: a CU's candidates as a list (spec_build); ready: already evaluated with the parent's
   std::vector<SpecCand> spec_amp_[4];                                      // ... and, with 24 slots or more, the AMP shapes in both of their forms (all vectors / merge only): the derivation then picks
   int ctu_addr_, ctu_x_, ctu_y_;
 
@@ -231,6 +232,10 @@ class CtuWorker {
   void spec_adopt(int d, SpecCand& sc);
   void spec_inter_phase(int d, std::vector<SpecCand>& cands);
   void check_merge_and_inter_spec(int d);
+  void spec_build(int d, SpecSet& S);
+  void spec_slots_of(const std::vector<SpecCand>& cands, int base, int L, std::vector<int>& slot);
+  // candidate slots per level: with 48 or more the slots are two levels of 24 -- a CU's candidates and, with them, its first sub-CU's (check_merge_and_inter_spec)
+  int spec_level_slots() const { return cfg.spec_slots >= 48 ? cfg.spec_slots / 2 : cfg.spec_slots; }
   bool pred_inter_search(CuData& c, int part_size, bool use_mrg);
   void fill_mvp_cand(const CuData& c, int pu, AmvpInfo& info);
   void merge_candidates(const CuData& c, int pu, MergeCands& mc);
@@ -781,6 +786,7 @@ struct CtuWorker::SpecCand {
   MvField mf; uint8_t mdir;
   CtuWorker* w;                      // the kid that evaluated it: the result is its temporary CU of the depth, its CI_TEMP coder and its go-on coder
 };
+struct CtuWorker::SpecSet { MergeCands mc; bool valid[5]; int idx[5][2]; int first_inter, first_amp, first_intra; std::vector<SpecCand> cands; bool ready; SpecSet() : first_inter(0), first_amp(0), first_intra(0), ready(false) { mc.n = 0; } };
 
 void CtuWorker::spec_run(int d, SpecCand& sc, const CuData& tmpl, int slot) {
   CtuWorker* w = kids_[slot];
@@ -823,68 +829,101 @@ void CtuWorker::spec_adopt(int d, SpecCand& sc) {
   check_best_mode(d, true);
 }
 
+// the slots of a set of candidates: base + 1, base + 2, ... for the SS/GT candidates; the two highest of the level (base + L - 1, base + L) for the intra candidates, whose
+// reconstructions wait there until the decisions reach them (a second batch of AMP candidates reuses the low slots)
+void CtuWorker::spec_slots_of(const std::vector<SpecCand>& cands, int base, int L, std::vector<int>& slot) {
+  const int n = (int)cands.size();
+  int n_inter = 0; for (int i = 0; i < n; i++) n_inter += cands[i].intra_ps < 0;
+  if (n_inter > L - 2) throw 1;
+  slot.resize(n);
+  for (int i = 0, k = 0; i < n; i++) slot[i] = base + (cands[i].intra_ps < 0 ? ++k : (cands[i].intra_ps == SIZE_2Nx2N ? L - 1 : L));
+}
 void CtuWorker::spec_inter_phase(int d, std::vector<SpecCand>& cands) {
   const CuData& tmpl = *temp_[d];                                         // after init_est (this worker waits in fork_join while its kids read it)
   if ((int)kids_.size() <= cfg.spec_slots) { const size_t k0 = kids_.size(); kids_.resize(cfg.spec_slots + 1, NULL); for (size_t k = k0; k < kids_.size(); k++) kids_[k] = new CtuWorker(E, lane_, be, true); }
-  // slots: 1, 2, ... for the SS/GT candidates; the two highest for the intra candidates, whose reconstructions wait there until the decisions reach them (the AMP
-  // candidates in between reuse the low slots)
-  const int n = (int)cands.size();
-  int n_inter = 0; for (int i = 0; i < n; i++) n_inter += cands[i].intra_ps < 0;
-  if (n_inter > cfg.spec_slots - 2) throw 1;
-  std::vector<int> slot(n);
-  for (int i = 0, k = 0; i < n; i++) slot[i] = cands[i].intra_ps < 0 ? ++k : (cands[i].intra_ps == SIZE_2Nx2N ? cfg.spec_slots - 1 : cfg.spec_slots);
+  std::vector<int> slot; spec_slots_of(cands, 0, spec_level_slots(), slot);
   flush_save();                                                          // (the candidates about to run reuse the slots)
-  be->fork_join(n, [&](int i) { spec_run(d, cands[i], tmpl, slot[i]); });
+  be->fork_join((int)cands.size(), [&](int i) { spec_run(d, cands[i], tmpl, slot[i]); });
 }
 
-// xCheckRDCostMerge2Nx2N, then xCheckRDCostInter for 2Nx2N, Nx2N and 2NxN (the order of xCompressCU without early skip detection and CBF fast mode)
-void CtuWorker::check_merge_and_inter_spec(int d) {
+// The candidates of the CU in temp_[d] (initialised, init_est): xCheckRDCostMerge2Nx2N's passes, then xCheckRDCostInter for 2Nx2N, Nx2N and 2NxN (the order of xCompressCU
+// without early skip detection and CBF fast mode), the AMP shapes, the intra candidates -- as a list; nothing is evaluated here
+void CtuWorker::spec_build(int d, SpecSet& S) {
   CuData* c = temp_[d];
   for (int i = 0; i < c->num_part; i++) c->p[i].part_size = SIZE_2Nx2N;
-  MergeCands mc; merge_candidates(*c, 0, mc);
+  merge_candidates(*c, 0, S.mc);
   init_est(*temp_[d]);
-  bool valid[5] = { false, false, false, false, false };
-  std::vector<SpecCand> cands; cands.reserve(13);
-  int idx[5][2];
-  for (int k = 0; k < mc.n; k++) {
-    valid[k] = true;
-    if (mc.f[k].ref == 0) { int mh = mc.f[k].mv[0], mvv = mc.f[k].mv[1]; clip_mv(*c, mh, mvv); valid[k] = valid_pattern(c->x, c->y, c->size, c->size, mh, mvv); }
-    if (!valid[k]) continue;
+  std::vector<SpecCand>& cands = S.cands; cands.clear(); cands.reserve(24);
+  for (int k = 0; k < 5; k++) { S.valid[k] = false; S.idx[k][0] = S.idx[k][1] = -1; }
+  for (int k = 0; k < S.mc.n; k++) {
+    S.valid[k] = true;
+    if (S.mc.f[k].ref == 0) { int mh = S.mc.f[k].mv[0], mvv = S.mc.f[k].mv[1]; clip_mv(*c, mh, mvv); S.valid[k] = valid_pattern(c->x, c->y, c->size, c->size, mh, mvv); }
+    if (!S.valid[k]) continue;
     for (int nores = 0; nores < 2; nores++) {
-      SpecCand sc; sc.intra_ps = -1; sc.merge_k = k; sc.nores = nores; sc.ps = SIZE_2Nx2N; sc.use_mrg = false; sc.ok = false; sc.mf = mc.f[k]; sc.mdir = mc.dir[k];
-      idx[k][nores] = (int)cands.size(); cands.push_back(sc);
+      SpecCand sc; sc.intra_ps = -1; sc.merge_k = k; sc.nores = nores; sc.ps = SIZE_2Nx2N; sc.use_mrg = false; sc.ok = false; sc.mf = S.mc.f[k]; sc.mdir = S.mc.dir[k];
+      S.idx[k][nores] = (int)cands.size(); cands.push_back(sc);
     }
   }
-  int first_inter = (int)cands.size();
+  S.first_inter = (int)cands.size();
   static const int inter_ps[3] = { SIZE_2Nx2N, SIZE_Nx2N, SIZE_2NxN };
   for (int q = 0; q < 3; q++) { SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = inter_ps[q]; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
   // The AMP shapes too, when there are slots for them: which of them xCompressCU tests, and whether with all vectors or merge only, follows from the best mode of the
   // candidates above (deriveTestModeAMP), but what each test yields does not -- every candidate starts from the same coder and an empty CU.  Both forms of all four shapes
   // run with the first batch; the derivation (compress_cu) then adopts the ones the reference would have tested, in its order, and the rest is dropped: a node's second
   // round of searches and evaluations is gone from the CTU's chain.  (64x64: deriveTestModeAMP never asks for the all-vectors form.)
-  const int first_amp = (int)cands.size();
-  if (cfg.amp && d < 3 && cfg.spec_slots >= 24) {
+  S.first_amp = (int)cands.size();
+  if (cfg.amp && d < 3 && spec_level_slots() >= 24) {
     static const int amp_ps[4] = { SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N };
     for (int q = 0; q < 4; q++) for (int mrg = (c->size == 64 ? 1 : 0); mrg < 2; mrg++) {
       SpecCand sc; sc.intra_ps = -1; sc.merge_k = -1; sc.nores = 0; sc.ps = amp_ps[q]; sc.use_mrg = mrg != 0; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc);
     }
   }
   // the intra candidates join the same batch: in an ISS slice xCompressCU always tests them, after every SS/GT candidate (their results wait in spec_intra_)
-  const int first_intra = (int)cands.size();
+  S.first_intra = (int)cands.size();
   const int n_intra = (d == 3 && c->size > (1 << cfg.log2_min_tu)) ? 2 : 1;
   for (int q = 0; q < n_intra; q++) { SpecCand sc; sc.intra_ps = q ? SIZE_NxN : SIZE_2Nx2N; sc.merge_k = -1; sc.nores = 0; sc.ps = 0; sc.use_mrg = false; sc.ok = false; memset(&sc.mf, 0, sizeof(sc.mf)); sc.mdir = 0; cands.push_back(sc); }
-  spec_inter_phase(d, cands);
-  spec_intra_[d].assign(cands.begin() + first_intra, cands.end());
-  spec_amp_[d].assign(cands.begin() + first_amp, cands.begin() + first_intra);
+}
+
+// The candidates of this CU evaluated side by side -- and, with two levels of slots (48), those of its FIRST sub-CU with them: that CU sits at the same corner, starts from
+// the same coder state (CI_CURR_BEST of the parent, TEncCu.cpp:731-733), sees the same SS reference (nothing is committed before a decision) and the same neighbours, and is
+// tested whatever the parent's candidates yield (no early CU termination in these configurations) -- so its searches and evaluations ride along in the parent's rounds
+// and its node costs the CTU's chain nothing but its decisions.  Then this CU's decisions, in the serial order.
+void CtuWorker::check_merge_and_inter_spec(int d) {
+  if (spec_set_.empty()) spec_set_.resize(4);
+  SpecSet& S = spec_set_[d];
+  if (!S.ready) {
+    spec_build(d, S);
+    SpecSet* C = NULL;
+    const int nd = d + 1, L = spec_level_slots();
+    if (d < 3 && cfg.spec_slots >= 2 * L && L >= 24) {
+      const CuData& t = *temp_[d];
+      init_cu(*best_[nd], t.abs_idx, nd, t.x, t.y); init_cu(*temp_[nd], t.abs_idx, nd, t.x, t.y);
+      sb_[nd][CI_CURR] = sb_[d][CI_CURR];
+      init_est(*temp_[nd]);
+      C = &spec_set_[nd]; spec_build(nd, *C);
+    }
+    if ((int)kids_.size() <= cfg.spec_slots) { const size_t k0 = kids_.size(); kids_.resize(cfg.spec_slots + 1, NULL); for (size_t k = k0; k < kids_.size(); k++) kids_[k] = new CtuWorker(E, lane_, be, true); }
+    std::vector<int> slot, slot2; spec_slots_of(S.cands, 0, L, slot);
+    if (C) spec_slots_of(C->cands, L, L, slot2);
+    const int n1 = (int)S.cands.size(), n2 = C ? (int)C->cands.size() : 0;
+    const CuData& tmpl = *temp_[d]; const CuData* tmpl2 = C ? temp_[nd] : NULL;   // (this worker waits in fork_join while its kids read them)
+    flush_save();                                                          // (the candidates about to run reuse the slots)
+    be->fork_join(n1 + n2, [&](int i) { if (i < n1) spec_run(d, S.cands[i], tmpl, slot[i]); else spec_run(nd, C->cands[i - n1], *tmpl2, slot2[i - n1]); });
+    if (C) C->ready = true;
+  }
+  S.ready = false;
+  std::vector<SpecCand>& cands = S.cands;
+  spec_intra_[d].assign(cands.begin() + S.first_intra, cands.end());
+  spec_amp_[d].assign(cands.begin() + S.first_amp, cands.begin() + S.first_intra);
   // ---- the decisions, in the serial order ----
   int buf[5] = { 0, 0, 0, 0, 0 };
   bool best_is_skip = false;
   for (int nores = 0; nores < 2; nores++) {
-    for (int k = 0; k < mc.n; k++) {
+    for (int k = 0; k < S.mc.n; k++) {
       if (nores == 1 && buf[k] == 1) continue;
       if (best_is_skip && nores == 0) continue;
-      if (!valid[k]) { init_est(*temp_[d]); continue; }
-      SpecCand& sc = cands[idx[k][nores]];
+      if (!S.valid[k]) { init_est(*temp_[d]); continue; }
+      SpecCand& sc = cands[S.idx[k][nores]];
       const Part& q0 = sc.w->temp_[d]->p[0];
       const int root = (q0.cbf[0] & 1) | (q0.cbf[1] & 1) | (q0.cbf[2] & 1);
       if (nores == 0 && root == 0) buf[k] = 1;
@@ -898,7 +937,7 @@ void CtuWorker::check_merge_and_inter_spec(int d) {
   }
   init_est(*temp_[d]);
   for (int q = 0; q < 3; q++) {
-    SpecCand& sc = cands[first_inter + q];
+    SpecCand& sc = cands[S.first_inter + q];
     if (sc.ok) spec_adopt(d, sc);
     init_est(*temp_[d]);
   }

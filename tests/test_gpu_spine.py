@@ -21,7 +21,7 @@ def _hp():
     return m
 
 
-SLOTS = [0, 16, 24]     # candidate slots (hop_ctx_set_slots): 16 -- the SS/GT candidates of a CU are evaluated side by side; 24 -- the AMP shapes with them in the first batch (bench.py's setting); the results must not change
+SLOTS = [0, 16, 24, 48]  # candidate slots (hop_ctx_set_slots): 16 -- the SS/GT candidates of a CU are evaluated side by side; 24 -- the AMP shapes with them in the first batch; 48 -- a CU's first sub-CU with it (bench.py's setting); the results must not change
 
 
 @pytest.mark.parametrize("slots", SLOTS)
@@ -145,7 +145,7 @@ def test_encode_frame_with_micro_image_size_15_equals_the_reference_encoder(W, H
     hp = _hp()
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine_mi15.npz"))
     Y, Cb, Cr = lenslet(W, H, 15, seed)
-    ctx = hp.Context(W, H, slots=24)
+    ctx = hp.Context(W, H, slots=48)
     ctx.upload_orig(Y, Cb, Cr)
     with tempfile.TemporaryDirectory() as td:
         tp = os.path.join(td, "t.txt")
@@ -169,7 +169,7 @@ def test_bench_frame_top_rows_equal_the_reference_encoders_cost_csv():
     Y, Cb, Cr = np.ascontiguousarray(Y[:H]), np.ascontiguousarray(Cb[:H // 2]), np.ascontiguousarray(Cr[:H // 2])
     if hashlib.md5(Y.tobytes()).hexdigest() != meta["y_md5"]:
         pytest.skip("numpy's sin / cos on this host do not reproduce the golden's input frame bit for bit")
-    ctx = hp.Context(W, H, slots=24)
+    ctx = hp.Context(W, H, slots=48)
     ctx.upload_orig(Y, Cb, Cr)
     out = {}
     th = threading.Thread(target=lambda: out.update(r=ctx.encode_frame(32, 15, 0, None, wpp=1, wavefront_lag=5)))
@@ -208,7 +208,7 @@ def test_one_picture_ctu_rows_over_two_contexts_equal_the_reference():
     ag = sh.ThreadAllgather(2, timeout=300.0)
     ctxs, out, err = [], [None, None], [None, None]
     for k in range(2):
-        c = hp.Context(W, H, slots=24); c.upload_orig(Y, Cb, Cr); c.set_shard(k, 2, ag.rank(k)); ctxs.append(c)
+        c = hp.Context(W, H, slots=48); c.upload_orig(Y, Cb, Cr); c.set_shard(k, 2, ag.rank(k)); ctxs.append(c)
 
     def run(k):
         try: out[k] = ctxs[k].encode_frame(32, 16, 0, None, wpp=1, wavefront_lag=lag)

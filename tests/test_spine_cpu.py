@@ -307,11 +307,12 @@ def key_mi15(W, H, seed, lag):
 
 @pytest.mark.parametrize("W,H,seed,lag", FRAMES_MI15)
 def test_spine_with_micro_image_size_15_equals_the_reference_encoder(W, H, seed, lag, monkeypatch):
-    """(the picture coded as a lag-5 wavefront also with 24 candidate slots, as bench.py codes the frame: the SS/GT candidates of a CU side by side, the AMP shapes in both
-    of their forms with the first batch -- the candidate trace must still be the reference's, candidate by candidate)"""
+    """(the WaveFrontSynchro pictures with candidate slots: 24 -- the SS/GT candidates of a CU side by side, the AMP shapes in both of their forms with the first batch --
+    and, for the lag-5 wavefront, 48 as bench.py codes the frame -- a CU's first sub-CU evaluated with it; the candidate trace must still be the reference's, candidate by
+    candidate)"""
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine_mi15.npz"))
     L = spine_cpu()
-    if lag == 5: monkeypatch.setenv("HOP_SPEC_SLOTS", "24")
+    if lag is not None: monkeypatch.setenv("HOP_SPEC_SLOTS", "48" if lag == 5 else "24")
     Y, Cb, Cr = lenslet(W, H, 15, seed)
     if lag is None: cost, bits, dist, parts, rec, text = run_cpu(L, W, H, Y, Cb, Cr, mi=15)
     else: cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag, mi=15)

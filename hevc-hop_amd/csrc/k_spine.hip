@@ -512,7 +512,7 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
     HIPCHK(c, hipMemsetAsync(c->coefpic, 0, want, c->stream));
     if (!c->coef_stash) HIPCHK(c, hipMalloc((void**)&c->coef_stash, (size_t)STASH_SLOTS * COEF_PER_CTU * 4));
   }
-  hopspine::posted_requests_allowed = false;                             // (see hop_spine.h)
+  hopspine::posted_requests_allowed = false;                             // (see hop_spine.h: no posted predictions on the device; stash / restore / commit are posted)
   HipBackend be(c);
   if (!be.ok()) return HOP_ERR_DEVICE;
   if (c->slots > 0 && p->wavefront_lag > 0 && !p->plain_intra) {         // candidates side by side: their evaluation chains of one round on streams of their own

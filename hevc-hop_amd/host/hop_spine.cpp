@@ -1173,11 +1173,12 @@ void Encoder::encode_frame(int first_ctus) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 struct Req { int kind; int lane; int n; const void* a; const void* b; void* out; int i0, i1, i2, i3; bool done; uint64_t tag; std::condition_variable* wake; bool posted; int worker; };   // wake: the submitting thread's own (only it is woken when the request is done)
-enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTORE, RQ_COMMIT, RQ_PCOST };
+enum { RQ_ME, RQ_PRED, RQ_DIST, RQ_VALID, RQ_INTER, RQ_INTRA, RQ_SAVE, RQ_RESTORE, RQ_COMMIT, RQ_PCOST, RQ_NOP };   // RQ_NOP: nothing but the round (FiberPool::flush)
 
 // one group of requests of the same kind (and class) as one call of the batching backend
 static void run_group(BatchInner* inner_, std::vector<Req*>& g) {
   const int kind = g[0]->kind;
+  if (kind == RQ_NOP) return;
   if (kind == RQ_ME) {
     std::vector<hop_pu_job> j; for (Req* r : g) j.insert(j.end(), (const hop_pu_job*)r->a, (const hop_pu_job*)r->a + r->n);
     std::vector<hop_pu_result> o(j.size());
@@ -1349,7 +1350,7 @@ class FiberPool : public Backend {
   void set_tag(int, uint64_t tag) { current()->tag = tag; }            // the tag belongs to the fiber (children of fork_join carry their own)
   void begin_frame() {}
   void me_search(int lane, int n, const hop_pu_job* j, hop_pu_result* r) { Req q = { RQ_ME, lane, n, j, NULL, r, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
-  void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; if (posted_mode_) post(q, j); else submit(q); }
+  void pred_inter(int lane, int n, const hop_pred_job* j) { Req q = { RQ_PRED, lane, n, j, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; if (posted_preds_) post(q, j); else submit(q); }
   void distortion(int lane, int n, const hop_dist_job* j, uint32_t* o) { Req q = { RQ_DIST, lane, n, j, NULL, o, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void valid_pattern(int lane, int n, const int32_t* v, uint8_t* o) { Req q = { RQ_VALID, lane, n, v, NULL, o, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void pred_cost(int lane, int n, const hop_pred_job* j, int kind, uint32_t* o) { Req q = { RQ_PCOST, lane, n, j, NULL, o, kind, 0, 0, 0, false, 0, NULL }; submit(q); }
@@ -1358,6 +1359,8 @@ class FiberPool : public Backend {
   void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
   void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
+  // everything this fiber has posted is on the device when this returns (a CTU is only counted as retired, and handed to other ranks, behind it)
+  void flush(int lane) { if (!posted_mode_) return; Req q = { RQ_NOP, lane, 1, NULL, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void restore_commit(int lane, int slot, int x, int y, int size) {
     if (posted_mode_) { recon_restore(lane, slot, x, y, size); commit(lane, x, y, size); return; }
     Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot + 1, false, 0, NULL }; submit(q);
@@ -1581,7 +1584,12 @@ class FiberPool : public Backend {
   void print_round_stats() { if (!getenv("HOP_SPINE_ROUND_STATS")) return; for (auto& kv : round_masks_) fprintf(stderr, "hop spine rounds: kinds %03x x %llu\n", kv.first, (unsigned long long)kv.second); }
  private:
   bool defer_me_ = [] { const char* e = getenv("HOP_SPINE_DEFER_ME"); return e ? atoi(e) != 0 : true; }();
-  bool posted_mode_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); return e && atoi(e) != 0 && posted_requests_allowed; }();
+  // HOP_SPINE_POSTED: 1 (default) -- the requests that have no answer and touch nothing another pending request reads (a reconstruction put aside or brought back, an
+  // SS-reference commit) do not stop their row: they are handed over and issued first at the next serve, every worker's in its order; 2 -- predictions without a cost too
+  // (only where they still are requests of their own, HOP_SPINE_FUSE_PRED=0; on the device a batch of posted predictions is one launch and two predictions of one block would
+  // lose their order, so the device backend never allows 2: posted_requests_allowed); 0 -- every request waits for its round
+  int posted_level_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); int v = e ? atoi(e) : 1; if (v > 1 && !posted_requests_allowed) v = 1; return v < 0 ? 0 : v; }();
+  bool posted_mode_ = posted_level_ >= 1, posted_preds_ = posted_level_ >= 2;
   std::vector<std::deque<Req> > pstore_; std::vector<std::deque<std::vector<hop_pred_job> > > pjobs_;   // per worker: what was posted since the last serve (deques: addresses stay)
   std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;
@@ -1664,6 +1672,7 @@ void Encoder::wavefront_many(Encoder* const* encs, int n_pic, BatchInner* inner,
             E.ctu_entry[a] = k;
             Coder next; w->compress_ctu(a, k, next);
             k = next;
+            pool.flush(lane);                                             // (posted stash / restore / commit requests of the CTU: done before it counts)
             if (E.cfg_.progress) E.cfg_.progress->fetch_add(1);
             std::lock_guard<std::mutex> g(pool.steps_m);
             if (c == 1) sync[(size_t)p * rows + r] = k;

@@ -53,9 +53,9 @@ void default_hop_config(EncConfig& c, int pic_w, int pic_h, int qp, int mi_size)
 void default_plain_config(EncConfig& c, int pic_w, int pic_h, int qp, int bit_depth);   // cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg: I slice, no SS / GT
 void finish_config(EncConfig& c);                                                 // TEncSlice::initEncSlice lambda / weights / chroma QP
 
-// HOP_SPINE_POSTED=1 (requests without an answer do not stop their row) is an experiment of the CPU spine: a backend that serves a batch of posted predictions with ONE launch
-// cannot keep two posted predictions of one block in their order, so the device backend clears this before it runs (measured there without it: no gain at the breadth of one
-// picture, whose rounds are not what its time is made of -- DESIGN.md section 5)
+// HOP_SPINE_POSTED (hop_spine.cpp, FiberPool): requests without an answer do not stop their row.  Level 1, the default, posts what touches nothing another pending request
+// reads (stash, restore, commit); level 2 also posts predictions -- a backend that serves a batch of posted predictions with ONE launch cannot keep two posted predictions of
+// one block in their order, so the device backend clears this flag before it runs and level 2 stays a mode of the CPU spine
 extern bool posted_requests_allowed;
 struct ShardComm {                 // what the caller provides for a picture coded by several ranks (RCCL / gloo / shared memory behind it)
   virtual ~ShardComm() {}

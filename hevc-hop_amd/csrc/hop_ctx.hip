@@ -149,7 +149,7 @@ int hop_ctx_create_view(hop_ctx* parent, hop_ctx** out) {
 // same in all of them).  A request whose y coordinate is y + k * pic_h then works on copy k: candidates of one CU evaluated side by side predict, transform and
 // reconstruct in copies of their own while searching the one SS reference (the predictor kernel takes the copy as hop_pred_job.dst_row_off).  Call before hop_upload_orig.
 int hop_ctx_set_slots(hop_ctx* c, int slots) {
-  if (!c || c->is_view || slots < 0 || slots > 64) return hop_set_err(c, HOP_ERR_ARG, "hop_ctx_set_slots: bad argument");
+  if (!c || c->is_view || slots < 0 || slots > 128) return hop_set_err(c, HOP_ERR_ARG, "hop_ctx_set_slots: bad argument");
   if (slots == c->slots) return HOP_OK;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -234,8 +234,9 @@ class CtuWorker {
   void check_merge_and_inter_spec(int d);
   void spec_build(int d, SpecSet& S);
   void spec_slots_of(const std::vector<SpecCand>& cands, int base, int L, std::vector<int>& slot);
-  // candidate slots per level: with 48 or more the slots are two levels of 24 -- a CU's candidates and, with them, its first sub-CU's (check_merge_and_inter_spec)
-  int spec_level_slots() const { return cfg.spec_slots >= 48 ? cfg.spec_slots / 2 : cfg.spec_slots; }
+  // candidate slots per level: from 48 on the slots are levels of 24 -- a CU's candidates and, with them, those of the chain of first sub-CUs below it, one level each
+  // (check_merge_and_inter_spec)
+  int spec_level_slots() const { return cfg.spec_slots >= 48 ? 24 : cfg.spec_slots; }
   bool pred_inter_search(CuData& c, int part_size, bool use_mrg);
   void fill_mvp_cand(const CuData& c, int pu, AmvpInfo& info);
   void merge_candidates(const CuData& c, int pu, MergeCands& mc);
@@ -893,23 +894,26 @@ void CtuWorker::check_merge_and_inter_spec(int d) {
   SpecSet& S = spec_set_[d];
   if (!S.ready) {
     spec_build(d, S);
-    SpecSet* C = NULL;
-    const int nd = d + 1, L = spec_level_slots();
-    if (d < 3 && cfg.spec_slots >= 2 * L && L >= 24) {
+    // the chain of first sub-CUs below this one, as far as there are levels of slots: each at the same corner, from the same coder state
+    const int L = spec_level_slots(), levels = L >= 24 ? cfg.spec_slots / L : 1;
+    std::vector<SpecSet*> sets(1, &S); std::vector<int> depth(1, d);
+    for (int nd = d + 1; nd <= 3 && (int)sets.size() < levels; nd++) {
       const CuData& t = *temp_[d];
       init_cu(*best_[nd], t.abs_idx, nd, t.x, t.y); init_cu(*temp_[nd], t.abs_idx, nd, t.x, t.y);
       sb_[nd][CI_CURR] = sb_[d][CI_CURR];
       init_est(*temp_[nd]);
-      C = &spec_set_[nd]; spec_build(nd, *C);
+      spec_build(nd, spec_set_[nd]);
+      sets.push_back(&spec_set_[nd]); depth.push_back(nd);
     }
     if ((int)kids_.size() <= cfg.spec_slots) { const size_t k0 = kids_.size(); kids_.resize(cfg.spec_slots + 1, NULL); for (size_t k = k0; k < kids_.size(); k++) kids_[k] = new CtuWorker(E, lane_, be, true); }
-    std::vector<int> slot, slot2; spec_slots_of(S.cands, 0, L, slot);
-    if (C) spec_slots_of(C->cands, L, L, slot2);
-    const int n1 = (int)S.cands.size(), n2 = C ? (int)C->cands.size() : 0;
-    const CuData& tmpl = *temp_[d]; const CuData* tmpl2 = C ? temp_[nd] : NULL;   // (this worker waits in fork_join while its kids read them)
+    std::vector<std::vector<int> > slot(sets.size()); std::vector<int> first(sets.size() + 1, 0);
+    for (size_t q = 0; q < sets.size(); q++) { spec_slots_of(sets[q]->cands, (int)q * L, L, slot[q]); first[q + 1] = first[q] + (int)sets[q]->cands.size(); }
     flush_save();                                                          // (the candidates about to run reuse the slots)
-    be->fork_join(n1 + n2, [&](int i) { if (i < n1) spec_run(d, S.cands[i], tmpl, slot[i]); else spec_run(nd, C->cands[i - n1], *tmpl2, slot2[i - n1]); });
-    if (C) C->ready = true;
+    be->fork_join(first[sets.size()], [&](int i) {                        // (this worker waits in fork_join while its kids read the templates temp_[depth])
+      size_t q = 0; while (i >= first[q + 1]) q++;
+      spec_run(depth[q], sets[q]->cands[i - first[q]], *temp_[depth[q]], slot[q][i - first[q]]);
+    });
+    for (size_t q = 1; q < sets.size(); q++) sets[q]->ready = true;
   }
   S.ready = false;
   std::vector<SpecCand>& cands = S.cands;
@@ -1356,9 +1360,9 @@ class FiberPool : public Backend {
   void pred_cost(int lane, int n, const hop_pred_job* j, int kind, uint32_t* o) { Req q = { RQ_PCOST, lane, n, j, NULL, o, kind, 0, 0, 0, false, 0, NULL }; submit(q); }
   void inter_cu(int lane, const InterEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTER, lane, 1, &e, &in, &o, e.job.log2_cu, e.skip_res, 0, 0, false, 0, NULL }; submit(q); }
   void intra_cu(int lane, const IntraEval& e, const Coder& in, EvalResult& o) { Req q = { RQ_INTRA, lane, 1, &e, &in, &o, e.job.log2_cu, e.part_nxn, 0, 0, false, 0, NULL }; submit(q); }
-  void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
-  void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
-  void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; if (posted_mode_) post(q, NULL); else submit(q); }
+  void recon_save(int lane, int slot, int x, int y, int size) { Req q = { RQ_SAVE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_ && (posted_kinds_ & 1)) post(q, NULL); else submit(q); }
+  void recon_restore(int lane, int slot, int x, int y, int size) { Req q = { RQ_RESTORE, lane, 1, NULL, NULL, NULL, x, y, size, lane * 16 + slot, false, 0, NULL }; if (posted_mode_ && (posted_kinds_ & 2)) post(q, NULL); else submit(q); }
+  void commit(int lane, int x, int y, int size) { Req q = { RQ_COMMIT, lane, 1, NULL, NULL, NULL, x, y, size, 0, false, 0, NULL }; if (posted_mode_ && (posted_kinds_ & 4)) post(q, NULL); else submit(q); }
   // everything this fiber has posted is on the device when this returns (a CTU is only counted as retired, and handed to other ranks, behind it)
   void flush(int lane) { if (!posted_mode_) return; Req q = { RQ_NOP, lane, 1, NULL, NULL, NULL, 0, 0, 0, 0, false, 0, NULL }; submit(q); }
   void restore_commit(int lane, int slot, int x, int y, int size) {
@@ -1590,6 +1594,9 @@ class FiberPool : public Backend {
   // lose their order, so the device backend never allows 2: posted_requests_allowed); 0 -- every request waits for its round
   int posted_level_ = [] { const char* e = getenv("HOP_SPINE_POSTED"); int v = e ? atoi(e) : 1; if (v > 1 && !posted_requests_allowed) v = 1; return v < 0 ? 0 : v; }();
   bool posted_mode_ = posted_level_ >= 1, posted_preds_ = posted_level_ >= 2;
+  // which of them are posted at level 1: 1 stash, 2 restore, 4 commit.  Restore and commit by default; a posted stash failed on the device -- one picture of the GPU tests
+  // (448x192, --MIsize=15, 16 slots: an intra candidate rated from a stale neighbourhood), cause not found, the CPU spine is fine with it -- and stays a request of its own
+  int posted_kinds_ = [this] { const char* e = getenv("HOP_SPINE_POSTED_KINDS"); return e ? atoi(e) : (posted_level_ >= 2 ? 7 : 6); }();
   std::vector<std::deque<Req> > pstore_; std::vector<std::deque<std::vector<hop_pred_job> > > pjobs_;   // per worker: what was posted since the last serve (deques: addresses stay)
   std::vector<Req*> inflight_;
   BatchInner* inner_; int T_; volatile bool failed_; bool finished_;

@@ -269,7 +269,7 @@ static std::vector<int32_t> g_last_levels;   // the levels of the last picture(s
 static std::vector<uint16_t> g_last_fraction;   // ... and the RD coder's carried fraction per CTU, for hop_spine_cpu_last_rd_fraction
 static void keep_fraction(const Encoder& e, bool append = false) { if (!append) g_last_fraction.clear(); g_last_fraction.insert(g_last_fraction.end(), e.ctu_rd_fraction.begin(), e.ctu_rd_fraction.end()); }
 static void keep_levels(const CpuBackend& be, bool append = false) { const size_t n = (size_t)((be.W + 63) / 64) * ((be.H + 63) / 64) * 6144; if (!append) g_last_levels.clear(); g_last_levels.insert(g_last_levels.end(), be.coefpic.begin(), be.coefpic.begin() + n); }
-static int spec_slots_env() { const char* e = getenv("HOP_SPEC_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }
+static int spec_slots_env() { const char* e = getenv("HOP_SPEC_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 128 ? v : 0; }
 
 extern "C" {
 

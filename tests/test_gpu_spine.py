@@ -138,14 +138,15 @@ def test_stacked_pictures_are_coded_as_pictures_of_their_own(slots, groups, monk
 
 
 
+@pytest.mark.parametrize("slots", [16, 48])
 @pytest.mark.parametrize("W,H,seed,lag", FRAMES_MI15)
-def test_encode_frame_with_micro_image_size_15_equals_the_reference_encoder(W, H, seed, lag):
+def test_encode_frame_with_micro_image_size_15_equals_the_reference_encoder(W, H, seed, lag, slots):
     """the configuration bench.py measures (pitch-15 lenslets, --MIsize=15, candidate slots on): every candidate, cost and partition datum against the reference encoder's run
     (tests/golden/encoder_spine_mi15.npz, oracle/make_golden24.py)"""
     hp = _hp()
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine_mi15.npz"))
     Y, Cb, Cr = lenslet(W, H, 15, seed)
-    ctx = hp.Context(W, H, slots=48)
+    ctx = hp.Context(W, H, slots=slots)                              # (16: what the picture-level binding sets, oracle/enc_shim_pic.cpp; 48: bench.py)
     ctx.upload_orig(Y, Cb, Cr)
     with tempfile.TemporaryDirectory() as td:
         tp = os.path.join(td, "t.txt")

@@ -771,7 +771,7 @@ def encode_main(args):
         if gold is not None:
             sel = done[:m]
             parity = {"reference": "cost.csv of the unmodified reference encoder for %s this picture, %s (oracle/make_golden24.py)" % ("exactly" if m == len(cost) else "the first CTU row of", meta["path"]),
-                      "ctus_compared": int(sel.sum()), "mismatches": int(np.sum(cost[:m][sel] != gold[:m][sel])), "reference_one_core_ctu_per_s": meta.get("ctu_per_s_one_core"),
+                      "ctus_compared": int(sel.sum()), "mismatches": int(np.sum(cost[:m][sel] != gold[:m][sel])), "mismatch_ctus": [int(a) for a in np.nonzero((cost[:m] != gold[:m]) & sel)[0][:8]], "reference_one_core_ctu_per_s": meta.get("ctu_per_s_one_core"),
                       "reference_cpu": meta.get("cpu")}
         else:
             parity = {"reference": None, "note": meta}

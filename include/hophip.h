@@ -112,7 +112,10 @@ void* hop_stream(hop_ctx* ctx);                     /* hipStream_t the *_device 
 /* Candidate slots (no counterpart in the reference, whose candidates run one after the other through m_ppcPredYuvTemp / m_ppcRecoYuvTemp): the original, prediction and
  * reconstruction pictures exist slots + 1 times, copy k at rows k * pic_h.  A request whose y is y + k * pic_h works on copy k, so candidates of one CU evaluated side by
  * side do not overwrite each other; the searches and the predictor read the one SS reference at the true position (hop_pred_job.dst_row_off names the copy the
- * prediction goes to).  Call before hop_upload_orig; hop_encode_frame then evaluates the SS/GT candidates of a CU side by side.  0 <= slots <= 64. */
+ * prediction goes to).  Call before hop_upload_orig; hop_encode_frame then evaluates the candidates of a CU side by side: from 16 slots the merge / SS / GT / intra
+ * candidates of TEncCu::xCompressCU's first pass (TEncCu.cpp:451-637), from 24 also the AMP shapes in both forms deriveTestModeAMP (:292-356) can ask for, from 48 in levels
+ * of 24 also the candidates of the CU's first sub-CU (72, 96: of the chain of first sub-CUs below it) -- what the reference would not have tested is dropped, its decisions
+ * are replayed in its order, the results do not depend on the number.  0 <= slots <= 128. */
 int hop_ctx_set_slots(hop_ctx* ctx, int slots);
 
 /* The transform-unit leaf step (hop_tu_rd and everything built on it) has two forms with identical results: a pipeline of 13 kernels that lays the serial stages out one

@@ -771,7 +771,8 @@ def encode_main(args):
         if gold is not None:
             sel = done[:m]
             parity = {"reference": "cost.csv of the unmodified reference encoder for %s this picture, %s (oracle/make_golden24.py)" % ("exactly" if m == len(cost) else "the first CTU row of", meta["path"]),
-                      "ctus_compared": int(sel.sum()), "mismatches": int(np.sum(cost[:m][sel] != gold[:m][sel])), "mismatch_ctus": [int(a) for a in np.nonzero((cost[:m] != gold[:m]) & sel)[0][:8]], "reference_one_core_ctu_per_s": meta.get("ctu_per_s_one_core"),
+                      "ctus_compared": int(sel.sum()), "mismatches": int(np.sum(cost[:m][sel] != gold[:m][sel])), "mismatch_ctus": [int(a) for a in np.nonzero((cost[:m] != gold[:m]) & sel)[0][:8]],
+                      "mismatch_costs_here_reference": [[int(a), float(cost[a]), float(gold[a])] for a in np.nonzero((cost[:m] != gold[:m]) & sel)[0][:8]], "reference_one_core_ctu_per_s": meta.get("ctu_per_s_one_core"),
                       "reference_cpu": meta.get("cpu")}
         else:
             parity = {"reference": None, "note": meta}
@@ -823,6 +824,10 @@ def encode_main(args):
             "request_note": "host wall time per kind of request of the whole run (ramp included), summed over the batches (one batch serves all CTUs in flight)",
             "rendezvous": {"rounds": rv["rounds"], "requests": rv["requests"], "avg_batch": rv["requests"] / max(1, rv["rounds"]), "serve_ms": rv.get("serve_ms", 0.0), "run_ms": rv.get("run_ms", 0.0),
                            "rounds_per_retired_ctu": rv["rounds"] / max(1, retired)},
+            "wavefront_visibility": {"searches_reaching_below": rv.get("searches_reaching_below"), "first_ctu_reaching_below": rv.get("first_ctu_reaching_below"),
+                                     "searches_reaching_above": rv.get("searches_reaching_above"), "first_ctu_reaching_above": rv.get("first_ctu_reaching_above"),
+                                     "note": "motion searches whose window covered samples the lag-5 wavefront and the reference's raster order see differently (committed samples of "
+                                             "the CTU rows below / not yet coded samples of the rows above): where the run's costs can leave the reference's (DESIGN.md section 5)"},
             "candidates": ncand, "cost_sum_retired": float(cost[done].sum()),
             "cpu_baseline": extras.get("cpu_baseline"),
         }

@@ -597,6 +597,8 @@ int hop_encode_frame(hop_ctx* c, const hop_enc_params* p, double* ctu_cost, uint
   for (auto v : gviews) hop_ctx_destroy(v);
   for (auto b : vbe) delete b;
   for (auto v : views) { if (rc != HOP_OK && v->err[0] && !c->err[0]) strncpy(c->err, v->err, sizeof(c->err) - 1); hop_ctx_destroy(v); }
+  for (auto e : encs) { g_stat_calls[10] += (double)e->reach_below.load(); g_stat_calls[11] += (double)e->reach_above.load(); }   // the visibility check of the wavefront (hop_spine.h)
+  g_stat_ms[10] = (double)enc.first_below.load(); g_stat_ms[11] = (double)enc.first_above.load();
   if (rc == HOP_OK) {
     const int n = enc.n_ctu();
     if (n_candidates) *n_candidates = 0;

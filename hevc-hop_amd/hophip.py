@@ -417,7 +417,8 @@ class Context:
         self.L.hop_encode_stats(ms, calls)
         names = ("me_search", "pred_inter", "distortion", "valid_pattern", "inter_cu", "inter_cu_skip", "intra_cu", "recon_stash", "commit", "evaluation_wait")
         d = {k: {"ms": ms[i], "calls": int(calls[i])} for i, k in enumerate(names)}
-        d["rendezvous"] = {"rounds": int(calls[14]), "requests": int(calls[15]), "serve_ms": float(ms[14]), "run_ms": float(ms[13])}
+        d["rendezvous"] = {"rounds": int(calls[14]), "requests": int(calls[15]), "serve_ms": float(ms[14]), "run_ms": float(ms[13]),
+                           "searches_reaching_below": int(calls[10]), "first_ctu_reaching_below": int(ms[10]), "searches_reaching_above": int(calls[11]), "first_ctu_reaching_above": int(ms[11])}
         return d
 
     def tu_roundtrip(self, jobs, want_levels=True):

@@ -222,6 +222,7 @@ class CtuWorker {
   // the spine
   void compress_cu(int d, int parent_part_size);
   void check_best_mode(int d, bool save_recon);
+  void reach_check(int px, int py, int w, int h, const int* r6);
   struct PendingSave { bool on; int d, x, y, size; } psave_ = { false, 0, 0, 0, 0 };
   void flush_save();
   void check_merge_2Nx2N(int d, bool* early_skip);
@@ -290,6 +291,23 @@ bool CtuWorker::valid_pattern(int px, int py, int w, int h, int mvx, int mvy) {
   };
   const long lb = (long)(py + (mvy >> 2) + h + 4) * stride + (px + (mvx >> 2));
   return probe(lb) && probe(lb + w + 4);
+}
+
+// (see Encoder::reach_below): the window of a motion search of the PU (px, py, w, h) with the range r6 of hop_set_search_range (left, right, top, bottom: integer vectors
+// relative to the PU) against the coded area as the wavefront has it.  The searches add at most the block's half size and the filters' reach around the displaced block
+void CtuWorker::reach_check(int px, int py, int w, int h, const int* r6) {
+  if (!cfg.wpp) return;
+  const int W8 = cfg.pic_w >> 3, m = (w > h ? w : h) / 2 + 8;
+  int x0 = px + r6[0] - m, x1 = px + r6[1] + w + m, y0 = py + r6[2] - m, y1 = py + r6[3] + h + m;
+  x0 = x0 < 0 ? 0 : x0; x1 = x1 >= cfg.pic_w ? cfg.pic_w - 1 : x1;
+  const int row_top = ctu_y_, row_bot = ctu_y_ + CTU;                    // the current CTU row: [row_top, row_bot)
+  bool below = false, above = false;
+  if (y1 >= row_bot && row_bot < cfg.pic_h)                               // rows below: committed by a CTU row that runs behind this one (it fills its CTUs from the top: the first unit row tells)
+    for (int x = x0 >> 3; x <= x1 >> 3 && !below; x++) below = E.committed[(size_t)(row_bot >> 3) * W8 + x] != 0;
+  if (y0 < row_top && row_top > 0)                                        // rows above: not committed yet (a CTU row ahead finishes its CTUs at the bottom: the last unit row tells)
+    for (int x = x0 >> 3; x <= x1 >> 3 && !above; x++) above = E.committed[(size_t)((row_top >> 3) - 1) * W8 + x] == 0;
+  if (below) { E.reach_below.fetch_add(1); int e = -1; E.first_below.compare_exchange_strong(e, ctu_addr_); }
+  if (above) { E.reach_above.fetch_add(1); int e = -1; E.first_above.compare_exchange_strong(e, ctu_addr_); }
 }
 
 void CtuWorker::trace_candidate(const CuData& c) {
@@ -505,6 +523,7 @@ bool CtuWorker::pred_inter_search(CuData& c, int ps, bool use_mrg) {
       int r6[6];
       hop_set_search_range(cfg.pic_w, cfg.pic_h, c.x, c.y, c.size, c.ctu_addr, E.wctu_, pred[0], pred[1], cfg.search_range, offx, offy, c.y == 0, c.x == 0, r6);
       j.rng_left = r6[0]; j.rng_right = r6[1]; j.rng_top = r6[2]; j.rng_bottom = r6[3]; j.off_x = r6[4]; j.off_y = r6[5];
+      reach_check(px, py, w, h, r6);
       j.pred_x = pred[0]; j.pred_y = pred[1]; j.lambda_cost = lam; j.n_amvp = info.n;
       for (int i = 0; i < info.n; i++) { j.amvp[2 * i] = info.cand[i][0]; j.amvp[2 * i + 1] = info.cand[i][1]; }
       j.flags = (cfg.fen ? HOP_FLAG_FEN : 0) | (cfg.hadme ? HOP_FLAG_HADME : 0);
@@ -1119,6 +1138,7 @@ Encoder::Encoder(const EncConfig& cfg, Backend* be) : trace(NULL), n_candidates(
   ctu_cost.assign(n_ctu(), 0.0); ctu_bits.assign(n_ctu(), 0); ctu_dist.assign(n_ctu(), 0); ctu_rd_fraction.assign(n_ctu(), 0); ctu_trace.resize(n_ctu()); batch_rounds = batch_requests = 0;
   pic.resize((size_t)n_ctu() * 256); ctu_entry.resize(n_ctu()); ctu_exit.resize(n_ctu()); committed.assign((size_t)(cfg.pic_w >> 3) * (cfg.pic_h >> 3), 0);
   for (size_t i = 0; i < pic.size(); i++) part_init(pic[i], 0);
+  reach_below.store(0); reach_above.store(0); first_below.store(-1); first_above.store(-1);
 }
 
 LogBackend::LogBackend(Backend* inner, const char* path) : in_(inner), f_(fopen(path, "wb")) {}

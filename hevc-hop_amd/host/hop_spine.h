@@ -219,6 +219,11 @@ class Encoder {
   std::vector<std::string> ctu_trace;                // the lines of each CTU while the picture is in flight
   std::vector<uint8_t>  committed;                   // per 8x8 block: its reconstruction is in the SS reference (what TComRdCost::isValidPattern's sentinel test sees)
   uint64_t batch_rounds, batch_requests;             // wavefront mode: rendezvous rounds and requests served
+  // wavefront mode, the visibility check (CtuWorker::reach_check): a motion search whose window -- the predictor +- the range, plus the block and the GT patch around it --
+  // covers samples that the reference, coding the CTUs in raster order, sees otherwise than the wavefront does: (below) committed samples of the CTU rows BELOW the current
+  // one (the reference has coded nothing there yet), (above) samples of the rows ABOVE that the wavefront has not coded yet (the reference has).  The lag of 5 CTUs keeps
+  // both away from windows around vectors of ordinary length; a long predictor can carry a window there.  Counted per search request, with the first CTU of each kind
+  std::atomic<long> reach_below, reach_above; std::atomic<int> first_below, first_above;
   double batch_run_s = 0;                            // ... the wall time of the whole wavefront (rows' host work + serving)
   double batch_serve_s = 0;                          // ... and the wall time spent serving them (one thread; the rows' own host work runs between the rounds)
  private:

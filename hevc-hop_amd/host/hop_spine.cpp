@@ -223,6 +223,7 @@ class CtuWorker {
   void compress_cu(int d, int parent_part_size);
   void check_best_mode(int d, bool save_recon);
   void reach_check(int px, int py, int w, int h, const int* r6);
+  bool raster_below_ = [] { const char* e = getenv("HOP_SPINE_RASTER_BELOW"); return e ? atoi(e) != 0 : true; }();
   struct PendingSave { bool on; int d, x, y, size; } psave_ = { false, 0, 0, 0, 0 };
   void flush_save();
   void check_merge_2Nx2N(int d, bool* early_skip);
@@ -287,6 +288,8 @@ bool CtuWorker::valid_pattern(int px, int py, int w, int h, int mvx, int mvy) {
     if (by >= cfg.pic_h + 160) return false;
     int x = (int)bx - 80, y = (int)by - 80;
     x = x < 0 ? 0 : x >= cfg.pic_w ? cfg.pic_w - 1 : x; y = y < 0 ? 0 : y >= cfg.pic_h ? cfg.pic_h - 1 : y;
+    if (raster_below_ && y >= ctu_y_ + CTU) return false;            // the reference codes in raster order: nothing below the current CTU row exists yet, whatever a CTU row that
+                                                                      // runs behind this one in the wavefront has committed there (HOP_SPINE_RASTER_BELOW=0: as the map has it)
     return E.committed[(size_t)(y >> 3) * W8 + (x >> 3)] != 0;
   };
   const long lb = (long)(py + (mvy >> 2) + h + 4) * stride + (px + (mvx >> 2));

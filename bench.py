@@ -6,7 +6,7 @@ picture exactly as TEncSlice::compressSlice (TLibEncoder/TEncSlice.cpp:1000-1196
 CTU every candidate TEncCu::xCompressCU tests -- merge / skip, SS + GT search for 2Nx2N, Nx2N, 2NxN and the AMP shapes with AMVP, merge and micro-image candidates, intra
 2Nx2N / NxN with the 35-mode search and the transform tree, each with its residual quadtree, RDOQ and CABAC-counted bits --, the decision between them, the recursion over
 CU sizes, the SS reference growing from the sentinel CU by CU, the coder contexts carried from CU to CU.  The candidates are evaluated by the HIP kernels of libhophip, the
-decisions taken by the host spine (hevc-hop_amd/host/hop_spine.cpp); the CTU rows run as a lag-5 wavefront (at most 25 rows in flight) whose requests are served in batches.
+decisions taken by the host spine (hevc-hop_amd/host/hop_spine.cpp); the CTU rows run as a lag-8 wavefront (at most 16 rows in flight) whose requests are served in batches.
 The whole picture takes minutes, so it is coded CONTINUOUSLY on a thread of its own and a STEP is a fixed quantum of retired CTUs (one CTU row = 121) read from
 hop_encode_progress: the wavefront's ramp and `--warmup` steps are untimed, `--steps` steps are timed, then the run is cancelled (hop_encode_cancel).  A wall-clock budget
 (--budget-s, from process start) ends the timed region early if need be; the JSON says how many steps were timed.  `parity` in the JSON compares the RD costs of the CTUs
@@ -662,7 +662,7 @@ def views_pass(hp, local, rank, world, slots, lag, budget_s, n_views=169, W=624,
 def encode_main(args):
     """The default: BASELINE.json's metric on BASELINE's configuration -- the 7728 x 5368 lenslet frame coded as ONE picture, exactly as TEncSlice::compressSlice codes it with
     cfg/3DHencoder_intra_main.cfg --MIsize=15 and WaveFrontSynchro (one substream per CTU row): every candidate of TEncCu::xCompressCU for every CTU, the SS reference starting at
-    the sentinel and growing CU by CU, coder contexts carried from CU to CU, the CTU rows as a lag-5 wavefront.  The picture takes minutes, so it is coded CONTINUOUSLY (one
+    the sentinel and growing CU by CU, coder contexts carried from CU to CU, the CTU rows as a wavefront of lag --lag.  The picture takes minutes, so it is coded CONTINUOUSLY (one
     hop_encode_frame on a thread of its own) and a STEP is a fixed quantum of retired CTUs (--step-ctus, default one CTU row = 121) read from hop_encode_progress: untimed are
     the ramp (until the wavefront holds its maximum of rows) and `--warmup` steps; then `--steps` steps are timed; then the run is cancelled.  A wall-clock budget (--budget-s,
     measured from process start) ends the timed region early if need be: `steps` in the JSON is what was timed.  With --gpus N every rank codes its own frame of the sequence."""
@@ -826,7 +826,7 @@ def encode_main(args):
                            "rounds_per_retired_ctu": rv["rounds"] / max(1, retired)},
             "wavefront_visibility": {"searches_reaching_below": rv.get("searches_reaching_below"), "first_ctu_reaching_below": rv.get("first_ctu_reaching_below"),
                                      "searches_reaching_above": rv.get("searches_reaching_above"), "first_ctu_reaching_above": rv.get("first_ctu_reaching_above"),
-                                     "note": "motion searches whose window covered samples the lag-5 wavefront and the reference's raster order see differently (committed samples of "
+                                     "note": "motion searches whose window covered samples the wavefront and the reference's raster order see differently (committed samples of "
                                              "the CTU rows below / not yet coded samples of the rows above): where the run's costs can leave the reference's (DESIGN.md section 5)"},
             "candidates": ncand, "cost_sum_retired": float(cost[done].sum()),
             "cpu_baseline": extras.get("cpu_baseline"),
@@ -885,7 +885,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=430.0, help="wall-clock budget from process start: the timed region ends there at the latest (the driver's limit is 600 s)")
     ap.add_argument("--ramp-frac", type=float, default=0.55, help="at most this share of the time left when the picture starts goes into the ramp")
     ap.add_argument("--slots", type=int, default=48, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
-    ap.add_argument("--lag", type=int, default=5, help="wavefront lag in CTUs")
+    ap.add_argument("--lag", type=int, default=8, help="wavefront lag in CTUs: row r codes CTU c once row r - 1 has finished CTU c + lag - 1.  8: identical to the reference on every CTU compared so far (4 001 of the frame); 5 is faster (76 against 53 CTU/s) and leaves the reference at CTU 3079 (DESIGN.md section 5)")
     ap.add_argument("--shard-rows", action="store_true", help="--gpus N > 1: ONE picture over all ranks, its CTU rows dealt round-robin with a hand-off after every wavefront step "
                                                                "(hop_encode_set_shard; strong scaling) instead of one picture per rank")
     ap.add_argument("--profile-w", type=int, default=1024); ap.add_argument("--profile-h", type=int, default=64)

@@ -125,11 +125,12 @@ def test_spine_over_the_restatement_equals_the_reference_encoder(W, H, seed, sha
 
 
 @pytest.mark.parametrize("W,H,seed,lag", FRAMES_WPP)
-def test_spine_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed, lag):
+def test_spine_wavefront_equals_the_reference_with_wavefront_synchro(W, H, seed, lag, monkeypatch):
     """cfg.wpp: every CTU row starts from the coder of the row above after its second CTU.  lag 5: one thread per row, the rows' requests served in batches (the product's
     multi-CTU mode); a lag of 5 CTUs covers the reach of the SS / GT search, so the result is the serial one."""
     G = np.load(os.path.join(ROOT, "tests", "golden", "encoder_spine.npz"))
     L = spine_cpu()
+    if lag: monkeypatch.setenv("HOP_SPEC_SLOTS", "16")                 # (the batched wavefront with 16 candidate slots: the AMP shapes as a second batch, as the picture-level binding runs it)
     Y, Cb, Cr = frame(W, H, seed, False)
     cost, bits, dist, parts, rec, text, rr = run_cpu_wpp(L, W, H, Y, Cb, Cr, lag)
     check_against_golden(G, key_of(W, H, seed, False) + "_wpp", cost, bits, dist, parts, text)

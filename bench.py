@@ -885,7 +885,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=430.0, help="wall-clock budget from process start: the timed region ends there at the latest (the driver's limit is 600 s)")
     ap.add_argument("--ramp-frac", type=float, default=0.55, help="at most this share of the time left when the picture starts goes into the ramp")
     ap.add_argument("--slots", type=int, default=48, help="candidate slots per context (the SS/GT candidates of a CU side by side); 0 = one after the other")
-    ap.add_argument("--lag", type=int, default=8, help="wavefront lag in CTUs: row r codes CTU c once row r - 1 has finished CTU c + lag - 1.  8: identical to the reference on every CTU compared so far (4 001 of the frame); 5 is faster (76 against 53 CTU/s) and leaves the reference at CTU 3079 (DESIGN.md section 5)")
+    ap.add_argument("--lag", type=int, default=8, help="wavefront lag in CTUs: row r codes CTU c once row r - 1 has finished CTU c + lag - 1.  8: identical to the reference on the whole frame (10 157 CTUs compared, --steps 76); 5 is faster (76 against 53 CTU/s) and leaves the reference at CTU 3079 (DESIGN.md section 5)")
     ap.add_argument("--shard-rows", action="store_true", help="--gpus N > 1: ONE picture over all ranks, its CTU rows dealt round-robin with a hand-off after every wavefront step "
                                                                "(hop_encode_set_shard; strong scaling) instead of one picture per rank")
     ap.add_argument("--profile-w", type=int, default=1024); ap.add_argument("--profile-h", type=int, default=64)

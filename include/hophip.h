@@ -651,7 +651,7 @@ typedef struct {
   int32_t wavefront_lag;  /* > 0 (implies wpp): the CTU rows run as a wavefront -- row r codes CTU c once row r - 1 has finished CTU c + lag - 1 -- and the candidate
                              evaluations of all rows in flight are batched into common launches.  A wavefront is not raster order: a search sees the rows above coded up to column c + lag - 1
                              only and the rows below already coded up to c - lag - 1; with predictors of ordinary length 5 is enough (every golden picture), on the 7728x5368 frame
-                             5 and 6 leave the reference's decisions at CTU 3079, 8 nowhere in the first 4 001 CTUs; lag >= the picture's width in CTUs is raster order */
+                             5 and 6 leave the reference's decisions at CTU 3079, 8 nowhere in the whole frame; lag >= the picture's width in CTUs is raster order */
   int32_t plain_intra;    /* 1: the plain HM intra configurations (cfg/encoder_intra_main.cfg, encoder_intra_main10.cfg): an I slice without SS / GT search, at the context's
                              bit depth (8 or 10); 0: the HOP configuration (8 bit only: the GT warp clips to 255, TComPrediction.cpp:969) */
   int32_t streams;        /* wavefront mode: > 1 = that many views of the context (hop_ctx_create_view), one per CTU row in flight, each row's requests on its own stream so

@@ -15,6 +15,13 @@ from hoputil import ROOT
 sys.path.insert(0, ROOT)
 
 
+def _free_port():
+    """a port nobody listens on right now (a fixed one may still be held by an earlier run's sockets: the rendezvous would then wait for its timeout)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
 def _worker(rank, world, port, W, H, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,7 +53,7 @@ def test_row_partition_world2():
     W, H = 456, 312            # ragged right/bottom CTUs (multiples of 8 like 7728x5368)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -117,7 +124,7 @@ def test_independent_pictures_world2():
     FW, FH, tw, th = 256, 64, 128, 64
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, FW, FH, tw, th, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -206,7 +213,7 @@ def test_one_picture_ctu_rows_over_two_ranks_gloo():
     W, H, seed = 192, 128, 7
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, W, H, seed, q)) for r in range(2)]
     for p in procs:
         p.start()
